@@ -1,0 +1,1093 @@
+/*
+ * orb_oracle.c -- CPU restatement (ORACLE) of ORBextractor::operator() and the ORBmatcher
+ * Hamming routines of hwb0314/VI-ORB-SLAM-ICRA2018.  See orb_oracle.h for the status header
+ * ("parity unpinned" at the OpenCV boundary) and the rule that only tests / smoke / the
+ * cpu_baseline leg of bench.py may use this file.
+ *
+ * Build: gcc -O3 -march=native -ffp-contract=off (CMakeLists.txt:10-11 of the reference uses
+ * -O3 -march=native; contraction is disabled so that x*b + y*a is evaluated as two roundings,
+ * the canonical choice of SURVEY.md Appendix A7).
+ *
+ * All "ref:" citations are relative to /root/reference.  "cv2.4:" marks behaviour of the
+ * external OpenCV 2.4.x library restated from its published algorithm (file named for
+ * orientation only; the source is not available in this environment).
+ */
+#include "orb_oracle.h"
+#include "orb_pattern_data.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PATCH_SIZE 31        /* ref: src/ORBextractor.cc:74 */
+#define HALF_PATCH_SIZE 15   /* ref: src/ORBextractor.cc:75 */
+#define EDGE_THRESHOLD 19    /* ref: src/ORBextractor.cc:76 */
+
+/* ------------------------------------------------------------------------------------------
+ * OpenCV scalar helpers
+ * ---------------------------------------------------------------------------------------- */
+
+/* cv2.4: cvRound(double) = _mm_cvtsd_si32 => round half to even in the default MXCSR mode. */
+int orbo_cvround(double v) { return (int)lrint(v); }
+
+static int cv_floor(double v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+
+static int cv_ceil(double v)
+{
+    int i = (int)v;
+    return i + (i < v);
+}
+
+static uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* cv2.4: saturate_cast<short>(float) = saturate(cvRound(v)). */
+static short sat_s16_from_float(float v)
+{
+    int i = orbo_cvround((double)v);
+    return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i));
+}
+
+/* cv2.4 (core/mathfuncs.cpp): fastAtan2, degrees in [0,360), float32 arithmetic, 7th-order odd
+ * polynomial.  Called at ref: src/ORBextractor.cc:105. */
+float orbo_fast_atan2(float y, float x)
+{
+    static const float rad2deg = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * rad2deg;
+    const float p3 = -0.3258083974640975f * rad2deg;
+    const float p5 = 0.1555786518463281f * rad2deg;
+    const float p7 = -0.04432655554792128f * rad2deg;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E0: constructor arithmetic.  ref: src/ORBextractor.cc:412-472
+ * ---------------------------------------------------------------------------------------- */
+int orbo_params_init(orbo_params *p, int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                     int minThFAST)
+{
+    if (!p || nlevels < 1 || nlevels > ORBO_MAX_LEVELS || nfeatures < 1) return -1;
+    memset(p, 0, sizeof(*p));
+    p->nfeatures = nfeatures;
+    p->nlevels = nlevels;
+    p->iniThFAST = iniThFAST;
+    p->minThFAST = minThFAST;
+    p->scaleFactor = (double)scaleFactor; /* member is double: include/ORBextractor.h:116 */
+
+    /* :417-425  float * double -> double -> float */
+    p->mvScaleFactor[0] = 1.0f;
+    p->mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        p->mvScaleFactor[i] = (float)((double)p->mvScaleFactor[i - 1] * p->scaleFactor);
+        p->mvLevelSigma2[i] = p->mvScaleFactor[i] * p->mvScaleFactor[i];
+    }
+    /* :427-433 */
+    for (int i = 0; i < nlevels; i++) {
+        p->mvInvScaleFactor[i] = 1.0f / p->mvScaleFactor[i];
+        p->mvInvLevelSigma2[i] = 1.0f / p->mvLevelSigma2[i];
+    }
+    /* :437-448 */
+    float factor = (float)(1.0 / p->scaleFactor); /* 1.0f / double */
+    float nDesired =
+        (float)nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        p->mnFeaturesPerLevel[level] = orbo_cvround((double)nDesired);
+        sum += p->mnFeaturesPerLevel[level];
+        nDesired *= factor;
+    }
+    p->mnFeaturesPerLevel[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+
+    /* :456-471  end of each row of the radius-15 disc */
+    int vmax = cv_floor((double)(HALF_PATCH_SIZE * sqrtf(2.f) / 2 + 1));
+    int vmin = cv_ceil((double)(HALF_PATCH_SIZE * sqrtf(2.f) / 2));
+    const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+    for (int v = 0; v <= vmax; ++v) p->umax[v] = orbo_cvround(sqrt(hp2 - v * v));
+    for (int v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+        while (p->umax[v0] == p->umax[v0 + 1]) ++v0;
+        p->umax[v] = v0;
+        ++v0;
+    }
+    return 0;
+}
+
+/* ref: src/ORBextractor.cc:1132-1133 -- size from the ORIGINAL image, float multiply. */
+void orbo_level_size(const orbo_params *p, int cols, int rows, int level, int *w, int *h)
+{
+    float scale = p->mvInvScaleFactor[level];
+    *w = orbo_cvround((double)((float)cols * scale));
+    *h = orbo_cvround((double)((float)rows * scale));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E2: cv::resize(..., INTER_LINEAR) for 8UC1.  cv2.4: imgproc/imgwarp.cpp
+ *   scale = 1/(dsize/ssize) (double); f = (float)((d+0.5)*scale-0.5); s = floor(f); f -= s;
+ *   x: s<0 -> (0, f=0); s>=sw-1 -> (sw-1, f=0); weights = saturate_cast<short>(w*2048);
+ *   horizontal: S[s]*a0 + S[s+1]*a1 (int); vertical rows clamped to [0,sh-1];
+ *   out = (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+ * ---------------------------------------------------------------------------------------- */
+void orbo_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw,
+                           int dh, int dstride)
+{
+    double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    int *xofs = (int *)malloc(sizeof(int) * (size_t)dw);
+    short *ialpha = (short *)malloc(sizeof(short) * 2 * (size_t)dw);
+    int *row0 = (int *)malloc(sizeof(int) * (size_t)dw);
+    int *row1 = (int *)malloc(sizeof(int) * (size_t)dw);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor((double)fx);
+        fx -= sx;
+        if (sx < 0) {
+            fx = 0;
+            sx = 0;
+        }
+        if (sx + 1 >= sw) {
+            if (dx < xmax) xmax = dx;
+            if (sx >= sw - 1) {
+                fx = 0;
+                sx = sw - 1;
+            }
+        }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_s16_from_float((1.f - fx) * 2048);
+        ialpha[2 * dx + 1] = sat_s16_from_float(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor((double)fy);
+        fy -= sy;
+        short b0 = sat_s16_from_float((1.f - fy) * 2048);
+        short b1 = sat_s16_from_float(fy * 2048);
+        int sy0 = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
+        int sy1 = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+        const uint8_t *S0 = src + (size_t)sy0 * sstride;
+        const uint8_t *S1 = src + (size_t)sy1 * sstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx];
+            if (dx < xmax) {
+                row0[dx] = S0[sx] * ialpha[2 * dx] + S0[sx + 1] * ialpha[2 * dx + 1];
+                row1[dx] = S1[sx] * ialpha[2 * dx] + S1[sx + 1] * ialpha[2 * dx + 1];
+            } else {
+                row0[dx] = S0[sx] * 2048;
+                row1[dx] = S1[sx] * 2048;
+            }
+        }
+        uint8_t *D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++)
+            D[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs);
+    free(ialpha);
+    free(row0);
+    free(row1);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E6: cv::GaussianBlur(img, img, Size(7,7), 2, 2, BORDER_REFLECT_101) for 8UC1.
+ * ref call site: src/ORBextractor.cc:1103-1104.  cv2.4: imgproc/smooth.cpp + filter.cpp:
+ *   float kernel g[i] = exp(-(i-3)^2/8)/sum; fixed point k = cvRound(g*256) = {18,34,49,55,...}
+ *   (sum 257, not renormalised); row pass int32; column pass brings the sum back by 2^16.
+ *   On x86-64 (SSE2 always present) the column pass of the 32s->8u symmetric filter runs in
+ *   float for x < width - width%4:  s = r0*f0; s += (r[+k]+r[-k])*f[k], f = k/65536, then
+ *   cvtps2dq (round half to EVEN) and saturating packs; the last width%4 pixels use the integer
+ *   cast (sum + 32768) >> 16 (round half UP).  Both are restated literally.
+ * ---------------------------------------------------------------------------------------- */
+static int reflect101(int p, int len)
+{
+    while (p < 0 || p >= len) {
+        if (p < 0)
+            p = -p;
+        else
+            p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+static void gaussian_kernel7_fixed(int k[7])
+{
+    /* cv2.4 getGaussianKernel(7, 2, CV_32F) then convertTo(CV_32S, 256). */
+    double t[7], sum = 0;
+    float cf[7];
+    const double scale2X = -0.5 / (2.0 * 2.0);
+    for (int i = 0; i < 7; i++) {
+        double x = i - 3.0;
+        t[i] = exp(scale2X * x * x);
+        cf[i] = (float)t[i];
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 7; i++) {
+        cf[i] = (float)(cf[i] * sum);
+        k[i] = orbo_cvround((double)(cf[i] * 256.f));
+    }
+}
+
+void orbo_gaussian_blur7_u8(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+{
+    int k[7];
+    gaussian_kernel7_fixed(k);
+    float f[4];
+    for (int i = 0; i < 4; i++) f[i] = (float)((double)k[3 + i] * (1. / 65536));
+    int *rows = (int *)malloc(sizeof(int) * (size_t)w * (size_t)h);
+    int *pad = (int *)malloc(sizeof(int) * (size_t)(w + 6));
+    for (int y = 0; y < h; y++) {
+        const uint8_t *S = src + (size_t)y * sstride;
+        int *R = rows + (size_t)y * w;
+        for (int x = -3; x < w + 3; x++) pad[x + 3] = S[reflect101(x, w)];
+        for (int x = 0; x < w; x++)
+            R[x] = k[0] * (pad[x] + pad[x + 6]) + k[1] * (pad[x + 1] + pad[x + 5]) +
+                   k[2] * (pad[x + 2] + pad[x + 4]) + k[3] * pad[x + 3];
+    }
+    free(pad);
+    const int wvec = w - (w % 4);
+    for (int y = 0; y < h; y++) {
+        const int *R[7];
+        for (int j = -3; j <= 3; j++) R[j + 3] = rows + (size_t)reflect101(y + j, h) * w;
+        uint8_t *D = dst + (size_t)y * dstride;
+        for (int x = 0; x < wvec; x++) {
+            float s = (float)R[3][x] * f[0];
+            s = s + (float)(R[4][x] + R[2][x]) * f[1];
+            s = s + (float)(R[5][x] + R[1][x]) * f[2];
+            s = s + (float)(R[6][x] + R[0][x]) * f[3];
+            int v = (int)lrintf(s);
+            v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+            D[x] = sat_u8(v);
+        }
+        for (int x = wvec; x < w; x++) {
+            int s = k[3] * R[3][x];
+            for (int j = 1; j <= 3; j++) s += k[3 + j] * (R[3 + j][x] + R[3 - j][x]);
+            D[x] = sat_u8((s + 32768) >> 16);
+        }
+    }
+    free(rows);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E3f: cv::FAST(img, keypoints, threshold, nonmaxSuppression=true), TYPE_9_16.
+ * cv2.4: features2d/fast.cpp + fast_score.cpp.
+ *   ring = 16-pixel Bresenham circle of radius 3; p is a corner iff >= 9 contiguous ring pixels
+ *   are all < p - t or all > p + t.  Score = max(t, max over the 16 9-arcs of the arc-min of
+ *   (p - q), same of (q - p)) - 1, stored as uchar.  NMS: strictly greater than the 8
+ *   neighbours' scores, where non-corners and positions outside rows/cols [3, n-3) count 0.
+ *   Output KeyPoint(x, y, 7, -1, score) in raster order.
+ * ---------------------------------------------------------------------------------------- */
+static const int RING_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+static const int RING_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+static int fast_is_corner(const uint8_t *p, int stride, int th)
+{
+    int v = p[0];
+    int q[25];
+    for (int k = 0; k < 25; k++) q[k] = p[RING_DY[k & 15] * stride + RING_DX[k & 15]];
+    int lo = v - th, hi = v + th, run = 0;
+    for (int k = 0; k < 25; k++) {
+        if (q[k] < lo) {
+            if (++run > 8) return 1;
+        } else
+            run = 0;
+    }
+    run = 0;
+    for (int k = 0; k < 25; k++) {
+        if (q[k] > hi) {
+            if (++run > 8) return 1;
+        } else
+            run = 0;
+    }
+    return 0;
+}
+
+int orbo_fast_corner_score(const uint8_t *p, int stride, int th)
+{
+    int v = p[0];
+    int d[25];
+    for (int k = 0; k < 25; k++) d[k] = v - p[RING_DY[k & 15] * stride + RING_DX[k & 15]];
+    int a0 = th;
+    for (int s = 0; s < 16; s++) { /* arc s..s+8: all darker than centre by more than a0? */
+        int m = d[s];
+        for (int j = 1; j < 9; j++) m = d[s + j] < m ? d[s + j] : m;
+        if (m > a0) a0 = m;
+    }
+    int b0 = -a0;
+    for (int s = 0; s < 16; s++) {
+        int m = d[s];
+        for (int j = 1; j < 9; j++) m = d[s + j] > m ? d[s + j] : m;
+        if (m < b0) b0 = m;
+    }
+    return -b0 - 1;
+}
+
+int orbo_fast9_16(const uint8_t *img, int stride, int w, int h, int th, orbo_cand *out, int cap)
+{
+    if (w < 7 || h < 7) return 0;
+    th = th < 0 ? 0 : (th > 255 ? 255 : th);
+    /* class table: bit0 = darker than centre by more than th, bit1 = brighter (cv2.4 keeps the
+     * same 512-entry table so that most pixels are rejected after two lookups). */
+    uint8_t tab[512];
+    for (int i = -255; i <= 255; i++) tab[i + 255] = (uint8_t)(i < -th ? 1 : (i > th ? 2 : 0));
+    int off[16];
+    for (int k = 0; k < 16; k++) off[k] = RING_DY[k] * stride + RING_DX[k];
+    uint8_t *score = (uint8_t *)calloc((size_t)w * (size_t)h, 1);
+    for (int y = 3; y < h - 3; y++) {
+        const uint8_t *row = img + (size_t)y * stride;
+        uint8_t *srow = score + (size_t)y * w;
+        for (int x = 3; x < w - 3; x++) {
+            const uint8_t *p = row + x;
+            const uint8_t *t = tab + 255 - p[0];
+            /* a 9-arc contains at least one pixel of every opposite pair */
+            int d = t[p[off[0]]] | t[p[off[8]]];
+            if (!d) continue;
+            d &= t[p[off[4]]] | t[p[off[12]]];
+            if (!d) continue;
+            d &= t[p[off[2]]] | t[p[off[10]]];
+            d &= t[p[off[6]]] | t[p[off[14]]];
+            if (!d) continue;
+            d &= t[p[off[1]]] | t[p[off[9]]];
+            d &= t[p[off[3]]] | t[p[off[11]]];
+            d &= t[p[off[5]]] | t[p[off[13]]];
+            d &= t[p[off[7]]] | t[p[off[15]]];
+            if (!d) continue;
+            if (fast_is_corner(p, stride, th)) {
+                int sc = orbo_fast_corner_score(p, stride, th);
+                srow[x] = (uint8_t)sc; /* stored as uchar in cv2.4 */
+            }
+        }
+    }
+    /* NMS.  A corner always has score >= th; with th >= 1 "score != 0" identifies corners, and
+     * for th == 0 a zero-score corner can never be a strict maximum anyway. */
+    int n = 0;
+    for (int y = 3; y < h - 3; y++) {
+        const uint8_t *s0 = score + (size_t)y * w;
+        for (int x = 3; x < w - 3; x++) {
+            const uint8_t *s = s0 + x;
+            int sc = s[0];
+            if (sc == 0) continue;
+            if (sc > s[-1] && sc > s[1] && sc > s[-w - 1] && sc > s[-w] && sc > s[-w + 1] &&
+                sc > s[w - 1] && sc > s[w] && sc > s[w + 1]) {
+                if (n >= cap) {
+                    free(score);
+                    return -3;
+                }
+                out[n].x = x;
+                out[n].y = y;
+                out[n].score = sc;
+                n++;
+            }
+        }
+    }
+    free(score);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E3: per-level cell loop.  ref: src/ORBextractor.cc:767-831
+ * ---------------------------------------------------------------------------------------- */
+int orbo_level_candidates(const uint8_t *img, int w, int h, int stride, int iniTh, int minTh,
+                          orbo_cand *out, int cap)
+{
+    const float W = 30;
+    const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+    const int maxBorderX = w - EDGE_THRESHOLD + 3, maxBorderY = h - EDGE_THRESHOLD + 3;
+    const float width = (float)(maxBorderX - minBorderX);
+    const float height = (float)(maxBorderY - minBorderY);
+    const int nCols = (int)(width / W), nRows = (int)(height / W);
+    if (nCols < 1 || nRows < 1) return -2; /* reference divides by zero here */
+    const int wCell = (int)ceilf(width / nCols), hCell = (int)ceilf(height / nRows);
+    int n = 0;
+    const int cellcap = (wCell + 6) * (hCell + 6);
+    orbo_cand *cell = (orbo_cand *)malloc(sizeof(orbo_cand) * (size_t)cellcap);
+    for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBorderY + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = (float)maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+            const float iniX = (float)(minBorderX + j * wCell);
+            float maxX = iniX + wCell + 6;
+            if (iniX >= maxBorderX - 6) continue;
+            if (maxX > maxBorderX) maxX = (float)maxBorderX;
+            const uint8_t *sub = img + (size_t)(int)iniY * stride + (int)iniX;
+            int sw = (int)maxX - (int)iniX, sh = (int)maxY - (int)iniY;
+            int nc = orbo_fast9_16(sub, stride, sw, sh, iniTh, cell, cellcap);
+            if (nc == 0) nc = orbo_fast9_16(sub, stride, sw, sh, minTh, cell, cellcap);
+            if (nc < 0 || n + nc > cap) {
+                free(cell);
+                return -3;
+            }
+            for (int c = 0; c < nc; c++) {
+                out[n].x = cell[c].x + j * wCell;
+                out[n].y = cell[c].y + i * hCell;
+                out[n].score = cell[c].score;
+                n++;
+            }
+        }
+    }
+    free(cell);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E4: quadtree distribution.  ref: src/ORBextractor.cc:483-539 (DivideNode), :541-765.
+ * Index-based doubly linked list instead of std::list; behaviour per Appendix A4/C of the
+ * survey: children are pushed to the list front in order n1..n4, parents erased in place;
+ * final phase expands the largest nodes first; ties on size are broken by creation sequence
+ * (canonical replacement for the reference's pointer compare).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int ulx, uly, brx, bry; /* UL and BR corners; UR=(brx,uly), BL=(ulx,bry) */
+    int first, count;       /* points live in pts[first .. first+count) of the node's arena */
+    int *pts;
+    int nomore;
+    int prev, next;
+    int seq;
+} qnode;
+
+typedef struct {
+    qnode *nodes;
+    int nnodes, capnodes;
+    int head, tail, size;
+    int seq;
+} qlist;
+
+static int ql_new(qlist *L)
+{
+    if (L->nnodes == L->capnodes) {
+        L->capnodes = L->capnodes ? L->capnodes * 2 : 256;
+        L->nodes = (qnode *)realloc(L->nodes, sizeof(qnode) * (size_t)L->capnodes);
+    }
+    int id = L->nnodes++;
+    memset(&L->nodes[id], 0, sizeof(qnode));
+    L->nodes[id].prev = L->nodes[id].next = -1;
+    L->nodes[id].seq = L->seq++;
+    return id;
+}
+
+static void ql_push_front(qlist *L, int id)
+{
+    L->nodes[id].prev = -1;
+    L->nodes[id].next = L->head;
+    if (L->head >= 0) L->nodes[L->head].prev = id;
+    L->head = id;
+    if (L->tail < 0) L->tail = id;
+    L->size++;
+}
+
+static void ql_push_back(qlist *L, int id)
+{
+    L->nodes[id].next = -1;
+    L->nodes[id].prev = L->tail;
+    if (L->tail >= 0) L->nodes[L->tail].next = id;
+    L->tail = id;
+    if (L->head < 0) L->head = id;
+    L->size++;
+}
+
+static int ql_erase(qlist *L, int id) /* returns next */
+{
+    int p = L->nodes[id].prev, n = L->nodes[id].next;
+    if (p >= 0)
+        L->nodes[p].next = n;
+    else
+        L->head = n;
+    if (n >= 0)
+        L->nodes[n].prev = p;
+    else
+        L->tail = p;
+    L->size--;
+    free(L->nodes[id].pts);
+    L->nodes[id].pts = NULL;
+    return n;
+}
+
+/* ref: :483-539.  Creates up to four children; child[k] = -1 when empty. */
+static void q_divide(qlist *L, int id, const orbo_cand *c, int child[4])
+{
+    qnode P = L->nodes[id];
+    const int halfX = (int)ceilf((float)(P.brx - P.ulx) / 2);
+    const int halfY = (int)ceilf((float)(P.bry - P.uly) / 2);
+    const int midx = P.ulx + halfX, midy = P.uly + halfY;
+    int box[4][4] = {{P.ulx, P.uly, midx, midy},
+                     {midx, P.uly, P.brx, midy},
+                     {P.ulx, midy, midx, P.bry},
+                     {midx, midy, P.brx, P.bry}};
+    int *buf[4], cnt[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; k++) buf[k] = (int *)malloc(sizeof(int) * (size_t)(P.count ? P.count : 1));
+    for (int i = 0; i < P.count; i++) {
+        int pi = P.pts[i];
+        float px = (float)c[pi].x, py = (float)c[pi].y;
+        int k;
+        if (px < (float)midx)
+            k = (py < (float)midy) ? 0 : 2;
+        else
+            k = (py < (float)midy) ? 1 : 3;
+        buf[k][cnt[k]++] = pi;
+    }
+    for (int k = 0; k < 4; k++) {
+        if (cnt[k] == 0) {
+            free(buf[k]);
+            child[k] = -1;
+            continue;
+        }
+        int nid = ql_new(L);
+        qnode *n = &L->nodes[nid];
+        n->ulx = box[k][0];
+        n->uly = box[k][1];
+        n->brx = box[k][2];
+        n->bry = box[k][3];
+        n->pts = buf[k];
+        n->count = cnt[k];
+        n->nomore = (cnt[k] == 1);
+        child[k] = nid;
+    }
+}
+
+typedef struct {
+    int size, seq, id;
+} qsz;
+
+static int qsz_cmp(const void *a, const void *b)
+{
+    const qsz *x = (const qsz *)a, *y = (const qsz *)b;
+    if (x->size != y->size) return x->size < y->size ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0); /* canonical pointer order */
+}
+
+int orbo_distribute_octtree(const orbo_cand *c, int ncand, int width, int height, int N,
+                            int *out_idx, int cap)
+{
+    if (height <= 0 || width <= 0) return -2;
+    /* :545-547 */
+    const int nIni = (int)roundf((float)width / (float)height);
+    if (nIni < 1) return -2; /* reference divides by zero */
+    const float hX = (float)width / nIni;
+    qlist L;
+    memset(&L, 0, sizeof(L));
+    L.head = L.tail = -1;
+    int *root = (int *)malloc(sizeof(int) * (size_t)nIni);
+    for (int i = 0; i < nIni; i++) { /* :554-565 */
+        int id = ql_new(&L);
+        qnode *n = &L.nodes[id];
+        n->ulx = (int)(hX * (float)i);
+        n->uly = 0;
+        n->brx = (int)(hX * (float)(i + 1));
+        n->bry = height;
+        n->pts = (int *)malloc(sizeof(int) * (size_t)(ncand ? ncand : 1));
+        ql_push_back(&L, id);
+        root[i] = id;
+    }
+    for (int i = 0; i < ncand; i++) { /* :568-572 */
+        int r = (int)((float)c[i].x / hX);
+        if (r < 0) r = 0;
+        if (r >= nIni) r = nIni - 1; /* out-of-range is UB in the reference; never hit for x<width */
+        qnode *n = &L.nodes[root[r]];
+        n->pts[n->count++] = i;
+    }
+    free(root);
+    for (int it = L.head; it >= 0;) { /* :574-587 */
+        if (L.nodes[it].count == 1) {
+            L.nodes[it].nomore = 1;
+            it = L.nodes[it].next;
+        } else if (L.nodes[it].count == 0)
+            it = ql_erase(&L, it);
+        else
+            it = L.nodes[it].next;
+    }
+
+    int finish = 0;
+    qsz *vs = NULL, *vprev = NULL;
+    int nvs = 0, capvs = 0, nprev = 0, capprev = 0;
+#define VS_PUSH(sz_, id_)                                               \
+    do {                                                                \
+        if (nvs == capvs) {                                             \
+            capvs = capvs ? capvs * 2 : 256;                            \
+            vs = (qsz *)realloc(vs, sizeof(qsz) * (size_t)capvs);       \
+        }                                                               \
+        vs[nvs].size = (sz_);                                           \
+        vs[nvs].id = (id_);                                             \
+        vs[nvs].seq = L.nodes[(id_)].seq;                               \
+        nvs++;                                                          \
+    } while (0)
+
+    while (!finish) { /* :596-741 */
+        int prevSize = L.size;
+        int nToExpand = 0;
+        nvs = 0;
+        for (int it = L.head; it >= 0;) {
+            if (L.nodes[it].nomore) {
+                it = L.nodes[it].next;
+                continue;
+            }
+            int ch[4];
+            q_divide(&L, it, c, ch);
+            for (int k = 0; k < 4; k++) {
+                if (ch[k] < 0) continue;
+                ql_push_front(&L, ch[k]);
+                if (L.nodes[ch[k]].count > 1) {
+                    nToExpand++;
+                    VS_PUSH(L.nodes[ch[k]].count, ch[k]);
+                }
+            }
+            it = ql_erase(&L, it);
+        }
+        if (L.size >= N || L.size == prevSize) {
+            finish = 1;
+        } else if (L.size + nToExpand * 3 > N) {
+            while (!finish) { /* :675-739 */
+                prevSize = L.size;
+                if (nvs > capprev) {
+                    capprev = nvs;
+                    vprev = (qsz *)realloc(vprev, sizeof(qsz) * (size_t)capprev);
+                }
+                memcpy(vprev, vs, sizeof(qsz) * (size_t)nvs);
+                nprev = nvs;
+                nvs = 0;
+                qsort(vprev, (size_t)nprev, sizeof(qsz), qsz_cmp);
+                for (int j = nprev - 1; j >= 0; j--) {
+                    int ch[4];
+                    q_divide(&L, vprev[j].id, c, ch);
+                    for (int k = 0; k < 4; k++) {
+                        if (ch[k] < 0) continue;
+                        ql_push_front(&L, ch[k]);
+                        if (L.nodes[ch[k]].count > 1) VS_PUSH(L.nodes[ch[k]].count, ch[k]);
+                    }
+                    ql_erase(&L, vprev[j].id);
+                    if (L.size >= N) break;
+                }
+                if (L.size >= N || L.size == prevSize) finish = 1;
+            }
+        }
+    }
+#undef VS_PUSH
+    /* :743-764  best response per node, first wins ties; output in list order */
+    int n = 0, rc = 0;
+    for (int it = L.head; it >= 0; it = L.nodes[it].next) {
+        qnode *q = &L.nodes[it];
+        int best = q->pts[0];
+        float maxResponse = (float)c[best].score;
+        for (int k = 1; k < q->count; k++) {
+            if ((float)c[q->pts[k]].score > maxResponse) {
+                best = q->pts[k];
+                maxResponse = (float)c[best].score;
+            }
+        }
+        if (n >= cap) {
+            rc = -3;
+            break;
+        }
+        out_idx[n++] = best;
+    }
+    for (int i = 0; i < L.nnodes; i++) free(L.nodes[i].pts);
+    free(L.nodes);
+    free(vs);
+    free(vprev);
+    return rc < 0 ? rc : n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E5: intensity-centroid orientation.  ref: src/ORBextractor.cc:79-106
+ * ---------------------------------------------------------------------------------------- */
+float orbo_ic_angle(const uint8_t *img, int stride, int x, int y, const int *umax)
+{
+    int m_01 = 0, m_10 = 0;
+    const uint8_t *center = img + (size_t)y * stride + x;
+    for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+    for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+        int v_sum = 0, d = umax[v];
+        for (int u = -d; u <= d; ++u) {
+            int val_plus = center[u + v * stride], val_minus = center[u - v * stride];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    return orbo_fast_atan2((float)m_01, (float)m_10);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E7: steered BRIEF.  ref: src/ORBextractor.cc:109-149.  cos/sin are libm's float versions,
+ * as in the reference (`(float)cos(angle)` with a float argument under `using namespace std`).
+ * ---------------------------------------------------------------------------------------- */
+void orbo_brief(const uint8_t *blurred, int stride, int x, int y, float angle_deg, uint8_t desc[32])
+{
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float angle = angle_deg * factorPI;
+    float a = cosf(angle), b = sinf(angle);
+    const uint8_t *center = blurred + (size_t)y * stride + x;
+    const signed char *pat = ORB_PATTERN_I8;
+    for (int i = 0; i < 32; ++i) {
+        int val = 0;
+        for (int k = 0; k < 8; k++, pat += 4) {
+            float x0 = (float)pat[0], y0 = (float)pat[1], x1 = (float)pat[2], y1 = (float)pat[3];
+            int r0 = orbo_cvround((double)(x0 * b + y0 * a)), c0 = orbo_cvround((double)(x0 * a - y0 * b));
+            int r1 = orbo_cvround((double)(x1 * b + y1 * a)), c1 = orbo_cvround((double)(x1 * a - y1 * b));
+            int t0 = center[r0 * stride + c0], t1 = center[r1 * stride + c1];
+            val |= (t0 < t1) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E1: operator().  ref: src/ORBextractor.cc:1045-1153
+ * ---------------------------------------------------------------------------------------- */
+struct orbo_extractor {
+    orbo_params P;
+    int img_w, img_h;
+    int lw[ORBO_MAX_LEVELS], lh[ORBO_MAX_LEVELS];
+    uint8_t *pyr[ORBO_MAX_LEVELS];
+    uint8_t *blur[ORBO_MAX_LEVELS];
+    orbo_cand *cands[ORBO_MAX_LEVELS];
+    int ncands[ORBO_MAX_LEVELS];
+    orbo_keypoint *lkps[ORBO_MAX_LEVELS];
+    int nlkps[ORBO_MAX_LEVELS];
+};
+
+orbo_extractor *orbo_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                            int minThFAST)
+{
+    orbo_extractor *e = (orbo_extractor *)calloc(1, sizeof(*e));
+    if (!e) return NULL;
+    if (orbo_params_init(&e->P, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) != 0) {
+        free(e);
+        return NULL;
+    }
+    return e;
+}
+
+static void orbo_free_frame(orbo_extractor *e)
+{
+    for (int l = 0; l < ORBO_MAX_LEVELS; l++) {
+        free(e->pyr[l]);
+        free(e->blur[l]);
+        free(e->cands[l]);
+        free(e->lkps[l]);
+        e->pyr[l] = e->blur[l] = NULL;
+        e->cands[l] = NULL;
+        e->lkps[l] = NULL;
+        e->ncands[l] = e->nlkps[l] = 0;
+    }
+}
+
+void orbo_destroy(orbo_extractor *e)
+{
+    if (!e) return;
+    orbo_free_frame(e);
+    free(e);
+}
+
+const orbo_params *orbo_get_params(const orbo_extractor *e) { return &e->P; }
+
+int orbo_extract(orbo_extractor *e, const uint8_t *img, int w, int h, int stride,
+                 orbo_keypoint *kps, uint8_t *desc, int cap)
+{
+    if (!e || !img || w <= 0 || h <= 0 || stride < w) return -1;
+    const orbo_params *P = &e->P;
+    orbo_free_frame(e);
+    e->img_w = w;
+    e->img_h = h;
+    /* E2 ComputePyramid :1128-1153.  The 19-px border is never read downstream (survey A2). */
+    for (int l = 0; l < P->nlevels; l++) {
+        orbo_level_size(P, w, h, l, &e->lw[l], &e->lh[l]);
+        if (e->lw[l] < 1 || e->lh[l] < 1) return -2;
+        e->pyr[l] = (uint8_t *)malloc((size_t)e->lw[l] * (size_t)e->lh[l]);
+        if (l == 0)
+            for (int y = 0; y < h; y++) memcpy(e->pyr[0] + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+        else
+            orbo_resize_linear_u8(e->pyr[l - 1], e->lw[l - 1], e->lh[l - 1], e->lw[l - 1], e->pyr[l],
+                                  e->lw[l], e->lh[l], e->lw[l]);
+    }
+    /* E3/E4 ComputeKeyPointsOctTree :767-855 */
+    for (int l = 0; l < P->nlevels; l++) {
+        const int lw = e->lw[l], lh = e->lh[l];
+        int ccap = (lw * lh) / 4 + 64;
+        e->cands[l] = (orbo_cand *)malloc(sizeof(orbo_cand) * (size_t)ccap);
+        int nc = orbo_level_candidates(e->pyr[l], lw, lh, lw, P->iniThFAST, P->minThFAST, e->cands[l], ccap);
+        if (nc < 0) return nc;
+        e->ncands[l] = nc;
+        const int minB = EDGE_THRESHOLD - 3;
+        const int regw = (lw - EDGE_THRESHOLD + 3) - minB, regh = (lh - EDGE_THRESHOLD + 3) - minB;
+        int *sel = (int *)malloc(sizeof(int) * (size_t)(nc + 1));
+        int ns = orbo_distribute_octtree(e->cands[l], nc, regw, regh, P->mnFeaturesPerLevel[l], sel, nc + 1);
+        if (ns < 0) {
+            free(sel);
+            return ns;
+        }
+        e->lkps[l] = (orbo_keypoint *)malloc(sizeof(orbo_keypoint) * (size_t)(ns + 1));
+        e->nlkps[l] = ns;
+        const int scaledPatchSize = (int)(PATCH_SIZE * P->mvScaleFactor[l]); /* :836 */
+        for (int i = 0; i < ns; i++) {
+            const orbo_cand *c = &e->cands[l][sel[i]];
+            orbo_keypoint *k = &e->lkps[l][i];
+            k->x = (float)c->x + (float)minB; /* :843-844 */
+            k->y = (float)c->y + (float)minB;
+            k->size = (float)scaledPatchSize;
+            k->angle = -1.f;
+            k->response = (float)c->score;
+            k->octave = l;
+            k->class_id = -1;
+        }
+        free(sel);
+    }
+    /* E5 :852-854 */
+    for (int l = 0; l < P->nlevels; l++)
+        for (int i = 0; i < e->nlkps[l]; i++) {
+            orbo_keypoint *k = &e->lkps[l][i];
+            k->angle = orbo_ic_angle(e->pyr[l], e->lw[l], orbo_cvround((double)k->x),
+                                     orbo_cvround((double)k->y), P->umax);
+        }
+    /* E6/E7/E8 :1076-1122 */
+    int n = 0;
+    for (int l = 0; l < P->nlevels; l++) n += e->nlkps[l];
+    if (n > cap) return -3;
+    int off = 0;
+    for (int l = 0; l < P->nlevels; l++) {
+        const int nl = e->nlkps[l];
+        if (nl == 0) continue;
+        const int lw = e->lw[l], lh = e->lh[l];
+        e->blur[l] = (uint8_t *)malloc((size_t)lw * (size_t)lh);
+        orbo_gaussian_blur7_u8(e->pyr[l], lw, lh, lw, e->blur[l], lw);
+        const float scale = P->mvScaleFactor[l];
+        for (int i = 0; i < nl; i++) {
+            orbo_keypoint k = e->lkps[l][i];
+            orbo_brief(e->blur[l], lw, orbo_cvround((double)k.x), orbo_cvround((double)k.y), k.angle,
+                       desc + (size_t)(off + i) * 32);
+            if (l != 0) {
+                k.x *= scale;
+                k.y *= scale;
+            }
+            kps[off + i] = k;
+        }
+        off += nl;
+    }
+    return n;
+}
+
+const uint8_t *orbo_pyramid_level(const orbo_extractor *e, int level, int *w, int *h, int *stride)
+{
+    if (!e || level < 0 || level >= e->P.nlevels) return NULL;
+    if (w) *w = e->lw[level];
+    if (h) *h = e->lh[level];
+    if (stride) *stride = e->lw[level];
+    return e->pyr[level];
+}
+
+const uint8_t *orbo_blurred_level(const orbo_extractor *e, int level, int *w, int *h, int *stride)
+{
+    if (!e || level < 0 || level >= e->P.nlevels) return NULL;
+    if (w) *w = e->lw[level];
+    if (h) *h = e->lh[level];
+    if (stride) *stride = e->lw[level];
+    return e->blur[level];
+}
+
+int orbo_level_cands(const orbo_extractor *e, int level, const orbo_cand **c)
+{
+    if (!e || level < 0 || level >= e->P.nlevels) return -1;
+    if (c) *c = e->cands[level];
+    return e->ncands[level];
+}
+
+int orbo_level_keypoints(const orbo_extractor *e, int level, const orbo_keypoint **k)
+{
+    if (!e || level < 0 || level >= e->P.nlevels) return -1;
+    if (k) *k = e->lkps[level];
+    return e->nlkps[level];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * M0: ORBmatcher::DescriptorDistance.  ref: src/ORBmatcher.cc:1675-1691 (SWAR popcount over
+ * 8 x 32-bit words of a XOR b).
+ * ---------------------------------------------------------------------------------------- */
+int orbo_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t wa, wb;
+        memcpy(&wa, a + 4 * i, 4);
+        memcpy(&wb, b + 4 * i, 4);
+        uint32_t v = wa ^ wb;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0x0F0F0F0Fu) * 0x01010101u) >> 24);
+    }
+    return dist;
+}
+
+/* M3 shape: bestDist=256, bestIdx=-1, bestDist2=256; strict '<' updates
+ * (ref: src/ORBmatcher.cc:205-226 and the other search routines listed in SURVEY 8a M3). */
+void orbo_knn2(const uint8_t *q, int nq, const uint8_t *db, int ndb, int32_t *best_idx,
+               int32_t *best_d, int32_t *second_d)
+{
+    for (int i = 0; i < nq; i++) {
+        int b1 = 256, b2 = 256, bi = -1;
+        for (int j = 0; j < ndb; j++) {
+            int d = orbo_descriptor_distance(q + (size_t)i * 32, db + (size_t)j * 32);
+            if (d < b1) {
+                b2 = b1;
+                b1 = d;
+                bi = j;
+            } else if (d < b2)
+                b2 = d;
+        }
+        best_idx[i] = bi;
+        best_d[i] = b1;
+        second_d[i] = b2;
+    }
+}
+
+void orbo_knn2_lists(const uint8_t *q, int nq, const uint8_t *db, const int32_t *off,
+                     const int32_t *cand, int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    for (int i = 0; i < nq; i++) {
+        int b1 = 256, b2 = 256, bi = -1;
+        for (int t = off[i]; t < off[i + 1]; t++) {
+            int j = cand[t];
+            int d = orbo_descriptor_distance(q + (size_t)i * 32, db + (size_t)j * 32);
+            if (d < b1) {
+                b2 = b1;
+                b1 = d;
+                bi = j;
+            } else if (d < b2)
+                b2 = d;
+        }
+        best_idx[i] = bi;
+        best_d[i] = b1;
+        second_d[i] = b2;
+    }
+}
+
+/* ref: src/ORBmatcher.cc:1629-1670 */
+void orbo_three_maxima(const int *hs, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    int i1 = -1, i2 = -1, i3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = hs[i];
+        if (s > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = s;
+            i3 = i2;
+            i2 = i1;
+            i1 = i;
+        } else if (s > max2) {
+            max3 = max2;
+            max2 = s;
+            i3 = i2;
+            i2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            i3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        i2 = -1;
+        i3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        i3 = -1;
+    }
+    *ind1 = i1;
+    *ind2 = i2;
+    *ind3 = i3;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * M1/M2: SearchByBoW.  ref: src/ORBmatcher.cc:159-288 (KeyFrame,Frame) and :522-655 (KF,KF).
+ * Greedy, order dependent: side-1 features are visited node by node in FeatureVector order and
+ * claim side-2 features; a claimed side-2 feature is skipped by later side-1 features.
+ * Canonical FeatureVector order = ascending feature index inside a node (Appendix C.2); the
+ * caller supplies idx arrays in the order it wants reproduced.
+ * ---------------------------------------------------------------------------------------- */
+#define HISTO_LENGTH 30
+
+int orbo_search_by_bow(const uint8_t *desc1, int n1, const uint8_t *valid1, const float *angle1,
+                       const int32_t *node1, const int32_t *off1, const int32_t *idx1, int ng1,
+                       const uint8_t *desc2, int n2, const uint8_t *valid2, const float *angle2,
+                       const int32_t *node2, const int32_t *off2, const int32_t *idx2, int ng2,
+                       int th, int th_mode, float nnratio, int check_ori, int32_t *match12,
+                       int32_t *match21)
+{
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    for (int i = 0; i < n2; i++) match21[i] = -1;
+    int nmatches = 0;
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        hist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 + 1));
+        hn[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    int g1 = 0, g2 = 0;
+    while (g1 < ng1 && g2 < ng2) {
+        if (node1[g1] == node2[g2]) {
+            for (int a = off1[g1]; a < off1[g1 + 1]; a++) {
+                const int i1 = idx1[a];
+                if (!valid1[i1]) continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int b = off2[g2]; b < off2[g2 + 1]; b++) {
+                    const int i2 = idx2[b];
+                    if (match21[i2] >= 0) continue;
+                    if (valid2 && !valid2[i2]) continue;
+                    const int dist = orbo_descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = i2;
+                    } else if (dist < bestDist2)
+                        bestDist2 = dist;
+                }
+                const int pass = th_mode ? (bestDist1 < th) : (bestDist1 <= th);
+                if (pass && (float)bestDist1 < nnratio * (float)bestDist2) {
+                    match12[i1] = bestIdx2;
+                    match21[bestIdx2] = i1;
+                    if (check_ori) {
+                        float rot = angle1[i1] - angle2[bestIdx2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        if (bin >= 0 && bin < HISTO_LENGTH) hist[bin][hn[bin]++] = i1;
+                    }
+                    nmatches++;
+                }
+            }
+            g1++;
+            g2++;
+        } else if (node1[g1] < node2[g2]) {
+            while (g1 < ng1 && node1[g1] < node2[g2]) g1++; /* lower_bound */
+        } else {
+            while (g2 < ng2 && node2[g2] < node1[g1]) g2++;
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        orbo_three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; j++) {
+                int a = hist[i][j];
+                if (match12[a] >= 0) match21[match12[a]] = -1;
+                match12[a] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    return nmatches;
+}

@@ -1,0 +1,301 @@
+"""ctypes binding of the CPU ORACLE (oracle/liborb_oracle.so).
+
+Test infrastructure only: import from tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py.  Never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+MAX_LEVELS = 16
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("nlevels", C.c_int), ("iniThFAST", C.c_int),
+                ("minThFAST", C.c_int), ("scaleFactor", C.c_double),
+                ("mvScaleFactor", C.c_float * MAX_LEVELS),
+                ("mvInvScaleFactor", C.c_float * MAX_LEVELS),
+                ("mvLevelSigma2", C.c_float * MAX_LEVELS),
+                ("mvInvLevelSigma2", C.c_float * MAX_LEVELS),
+                ("mnFeaturesPerLevel", C.c_int * MAX_LEVELS),
+                ("umax", C.c_int * 16)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p = C.POINTER(C.c_uint8)
+        i32p = C.POINTER(C.c_int32)
+        f32p = C.POINTER(C.c_float)
+        vp = C.c_void_p
+        L.orbo_params_init.argtypes = [C.POINTER(Params), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orbo_level_size.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, i32p, i32p]
+        L.orbo_cvround.argtypes = [C.c_double]
+        L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orbo_fast_atan2.restype = C.c_float
+        L.orbo_resize_linear_u8.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+        L.orbo_resize_linear_u8.restype = None
+        L.orbo_gaussian_blur7_u8.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_gaussian_blur7_u8.restype = None
+        L.orbo_fast9_16.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_fast_corner_score.argtypes = [vp, C.c_int, C.c_int]
+        L.orbo_level_candidates.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_distribute_octtree.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orbo_ic_angle.argtypes = [vp, C.c_int, C.c_int, C.c_int, i32p]
+        L.orbo_ic_angle.restype = C.c_float
+        L.orbo_brief.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
+        L.orbo_brief.restype = None
+        L.orbo_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orbo_create.restype = vp
+        L.orbo_destroy.argtypes = [vp]
+        L.orbo_destroy.restype = None
+        L.orbo_get_params.argtypes = [vp]
+        L.orbo_get_params.restype = C.POINTER(Params)
+        L.orbo_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
+        for name in ("orbo_pyramid_level", "orbo_blurred_level"):
+            f = getattr(L, name)
+            f.argtypes = [vp, C.c_int, i32p, i32p, i32p]
+            f.restype = vp
+        L.orbo_level_cands.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.orbo_level_keypoints.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.orbo_descriptor_distance.argtypes = [vp, vp]
+        L.orbo_knn2.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+        L.orbo_knn2.restype = None
+        L.orbo_knn2_lists.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.orbo_knn2_lists.restype = None
+        L.orbo_three_maxima.argtypes = [i32p, C.c_int, i32p, i32p, i32p]
+        L.orbo_three_maxima.restype = None
+        L.orbo_search_by_bow.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
+                                         vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
+                                         C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 2
+    return img
+
+
+def params(nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7):
+    P = Params()
+    rc = lib().orbo_params_init(C.byref(P), nfeatures, scale, nlevels, ini, mn)
+    if rc != 0:
+        raise ValueError("orbo_params_init failed")
+    return P
+
+
+def level_size(P, cols, rows, level):
+    w, h = C.c_int32(), C.c_int32()
+    lib().orbo_level_size(C.byref(P), cols, rows, level, C.byref(w), C.byref(h))
+    return w.value, h.value
+
+
+def cvround(v):
+    return lib().orbo_cvround(float(v))
+
+
+def fast_atan2(y, x):
+    return lib().orbo_fast_atan2(float(y), float(x))
+
+
+def resize_linear(src, dw, dh):
+    src = _u8(src)
+    dst = np.empty((dh, dw), np.uint8)
+    lib().orbo_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = _u8(src)
+    dst = np.empty_like(src)
+    lib().orbo_gaussian_blur7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast9_16(img, th):
+    img = _u8(img)
+    cap = img.size // 2 + 16
+    out = np.empty(cap, CAND_DTYPE)
+    n = lib().orbo_fast9_16(_p(img), img.strides[0], img.shape[1], img.shape[0], th, _p(out), cap)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def fast_corner_score(img, x, y, th):
+    img = _u8(img)
+    ptr = img.ctypes.data + y * img.strides[0] + x
+    return lib().orbo_fast_corner_score(C.c_void_p(ptr), img.strides[0], th)
+
+
+def level_candidates(img, ini=20, mn=7):
+    img = _u8(img)
+    cap = img.size // 2 + 64
+    out = np.empty(cap, CAND_DTYPE)
+    n = lib().orbo_level_candidates(_p(img), img.shape[1], img.shape[0], img.strides[0], ini, mn, _p(out), cap)
+    if n < 0:
+        raise ValueError("orbo_level_candidates rc=%d" % n)
+    return out[:n].copy()
+
+
+def distribute_octtree(cands, width, height, N):
+    cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+    out = np.empty(len(cands) + 1, np.int32)
+    n = lib().orbo_distribute_octtree(_p(cands), len(cands), width, height, N, _p(out), len(out))
+    if n < 0:
+        raise ValueError("orbo_distribute_octtree rc=%d" % n)
+    return out[:n].copy()
+
+
+def ic_angle(img, x, y, umax):
+    img = _u8(img)
+    um = (C.c_int32 * 16)(*umax)
+    return lib().orbo_ic_angle(_p(img), img.strides[0], x, y, um)
+
+
+def brief(blurred, x, y, angle_deg):
+    blurred = _u8(blurred)
+    d = np.empty(32, np.uint8)
+    lib().orbo_brief(_p(blurred), blurred.strides[0], x, y, angle_deg, _p(d))
+    return d
+
+
+class Extractor:
+    """Mirror of ORBextractor (include/ORBextractor.h:69-103) over the oracle."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7):
+        self._h = lib().orbo_create(nfeatures, scale, nlevels, ini, mn)
+        if not self._h:
+            raise ValueError("orbo_create failed")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.params = lib().orbo_get_params(self._h).contents
+
+    def close(self):
+        if self._h:
+            lib().orbo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, img):
+        img = _u8(img)
+        cap = 4 * self.nfeatures + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = lib().orbo_extract(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), cap)
+        if n < 0:
+            raise ValueError("orbo_extract rc=%d" % n)
+        return kps[:n].copy(), desc[:n].copy()
+
+    def _level_img(self, fn, level):
+        w, h, s = C.c_int32(), C.c_int32(), C.c_int32()
+        ptr = fn(self._h, level, C.byref(w), C.byref(h), C.byref(s))
+        if not ptr:
+            return None
+        buf = (C.c_uint8 * (s.value * h.value)).from_address(ptr)
+        return np.frombuffer(buf, np.uint8).reshape(h.value, s.value)[:, :w.value].copy()
+
+    def pyramid(self, level):
+        return self._level_img(lib().orbo_pyramid_level, level)
+
+    def blurred(self, level):
+        return self._level_img(lib().orbo_blurred_level, level)
+
+    def level_cands(self, level):
+        ptr = C.c_void_p()
+        n = lib().orbo_level_cands(self._h, level, C.byref(ptr))
+        if n <= 0:
+            return np.empty(0, CAND_DTYPE)
+        buf = (C.c_uint8 * (n * CAND_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, CAND_DTYPE).copy()
+
+    def level_keypoints(self, level):
+        ptr = C.c_void_p()
+        n = lib().orbo_level_keypoints(self._h, level, C.byref(ptr))
+        if n <= 0:
+            return np.empty(0, KP_DTYPE)
+        buf = (C.c_uint8 * (n * KP_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, KP_DTYPE).copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orbo_descriptor_distance(_p(a), _p(b))
+
+
+def knn2(q, db):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    db = np.ascontiguousarray(db, np.uint8).reshape(-1, 32)
+    bi = np.empty(len(q), np.int32)
+    bd = np.empty(len(q), np.int32)
+    sd = np.empty(len(q), np.int32)
+    lib().orbo_knn2(_p(q), len(q), _p(db), len(db), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def knn2_lists(q, db, off, cand):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    db = np.ascontiguousarray(db, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.int32)
+    cand = np.ascontiguousarray(cand, np.int32)
+    bi = np.empty(len(q), np.int32)
+    bd = np.empty(len(q), np.int32)
+    sd = np.empty(len(q), np.int32)
+    lib().orbo_knn2_lists(_p(q), len(q), _p(db), _p(off), _p(cand), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def three_maxima(sizes):
+    arr = (C.c_int32 * len(sizes))(*[int(s) for s in sizes])
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    lib().orbo_three_maxima(arr, len(sizes), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def search_by_bow(desc1, valid1, angle1, groups1, desc2, valid2, angle2, groups2, th=50,
+                  th_mode=0, nnratio=0.7, check_ori=True):
+    """groups = (node_ids[ng], offsets[ng+1], idx[...]) (a DBoW2::FeatureVector in CSR form)."""
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    n1, n2 = len(desc1), len(desc2)
+    valid1 = np.ascontiguousarray(valid1, np.uint8)
+    valid2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    angle1 = np.ascontiguousarray(angle1, np.float32)
+    angle2 = np.ascontiguousarray(angle2, np.float32)
+    g1 = [np.ascontiguousarray(a, np.int32) for a in groups1]
+    g2 = [np.ascontiguousarray(a, np.int32) for a in groups2]
+    m12 = np.empty(n1, np.int32)
+    m21 = np.empty(n2, np.int32)
+    n = lib().orbo_search_by_bow(_p(desc1), n1, _p(valid1), _p(angle1), _p(g1[0]), _p(g1[1]), _p(g1[2]), len(g1[0]),
+                                 _p(desc2), n2, _p(valid2), _p(angle2), _p(g2[0]), _p(g2[1]), _p(g2[2]), len(g2[0]),
+                                 th, th_mode, nnratio, 1 if check_ori else 0, _p(m12), _p(m21))
+    return n, m12, m21

@@ -1,0 +1,125 @@
+"""Seeded procedural workloads (there are no datasets on either box).
+
+Scenes are sums of random rotated rectangles / discs over band-limited noise, so that FAST finds
+far more corners than the per-level quota at iniThFAST=20 while flat regions only respond at
+minThFAST=7.  Consecutive frames of a stream are the same scene under a slowly varying
+similarity + shear warp, so descriptor matches exist between neighbouring frames.
+"""
+import numpy as np
+
+GEOMETRY = {
+    "euroc": (752, 480),   # Examples/Monocular/EuRoC.yaml (cam0 752x480)
+    "tum": (640, 480),     # Examples/RGB-D/TUM1.yaml
+    "kitti": (1241, 376),  # Examples/Stereo/KITTI00-02.yaml
+}
+
+
+def _smooth_noise(rng, h, w, cell, amp):
+    gh, gw = h // cell + 3, w // cell + 3
+    g = rng.standard_normal((gh, gw)).astype(np.float32)
+    ys = np.arange(h, dtype=np.float32) / cell
+    xs = np.arange(w, dtype=np.float32) / cell
+    y0 = ys.astype(np.int32)
+    x0 = xs.astype(np.int32)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+
+
+def make_scene(seed, width, height, margin=96, nshapes=None):
+    """A float32 canvas (height+2*margin, width+2*margin) in [0,255]."""
+    rng = np.random.default_rng(seed)
+    H, W = height + 2 * margin, width + 2 * margin
+    img = np.full((H, W), 118.0, np.float32)
+    img += _smooth_noise(rng, H, W, 64, 30.0)
+    img += _smooth_noise(rng, H, W, 9, 6.0)
+    if nshapes is None:
+        nshapes = (H * W) // 1500
+    for _ in range(nshapes):
+        cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+        # leave roughly a quarter of the canvas with low contrast only
+        if (int(cx) // 160 + int(cy) // 160) % 4 == 0:
+            amp = rng.uniform(-14, 14)
+        else:
+            amp = rng.uniform(-110, 110)
+        if rng.random() < 0.7:
+            hw, hh = rng.uniform(4, 40), rng.uniform(4, 40)
+            th = rng.uniform(0, np.pi)
+            r = int(np.hypot(hw, hh)) + 2
+            x0, x1 = max(0, int(cx) - r), min(W, int(cx) + r + 1)
+            y0, y1 = max(0, int(cy) - r), min(H, int(cy) + r + 1)
+            if x0 >= x1 or y0 >= y1:
+                continue
+            yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+            u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+            v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+            m = (np.abs(u) <= hw) & (np.abs(v) <= hh)
+        else:
+            rad = rng.uniform(3, 24)
+            r = int(rad) + 2
+            x0, x1 = max(0, int(cx) - r), min(W, int(cx) + r + 1)
+            y0, y1 = max(0, int(cy) - r), min(H, int(cy) + r + 1)
+            if x0 >= x1 or y0 >= y1:
+                continue
+            yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+            m = (xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad
+        img[y0:y1, x0:x1] += amp * m
+    img += rng.standard_normal((H, W)).astype(np.float32) * 1.5
+    return np.clip(img, 0, 255)
+
+
+def warp_frame(scene, width, height, t, margin=96):
+    """Frame t of a stream: bilinear sample of the scene under a small similarity + shear."""
+    ang = 0.004 * t + 0.02 * np.sin(0.05 * t)
+    sc = 1.0 + 0.02 * np.sin(0.031 * t)
+    sh = 0.01 * np.sin(0.017 * t)
+    tx = 12.0 * np.sin(0.043 * t) + 0.35 * (t % 40)
+    ty = 9.0 * np.cos(0.029 * t)
+    H, W = scene.shape
+    cx, cy = width / 2.0, height / 2.0
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    dx, dy = xx - cx, yy - cy
+    c, s = np.cos(ang) * sc, np.sin(ang) * sc
+    sx = c * dx - s * dy + sh * dy + cx + margin + tx
+    sy = s * dx + c * dy + cy + margin + ty
+    sx = np.clip(sx, 0, W - 2.001)
+    sy = np.clip(sy, 0, H - 2.001)
+    x0 = sx.astype(np.int32)
+    y0 = sy.astype(np.int32)
+    fx, fy = sx - x0, sy - y0
+    a = scene[y0, x0]
+    b = scene[y0, x0 + 1]
+    cc = scene[y0 + 1, x0]
+    d = scene[y0 + 1, x0 + 1]
+    out = (a * (1 - fx) + b * fx) * (1 - fy) + (cc * (1 - fx) + d * fx) * fy
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def make_frames(seed, width, height, count, start=0):
+    """`count` consecutive uint8 frames (count, height, width) of the stream `seed`."""
+    scene = make_scene(seed, width, height)
+    return np.stack([warp_frame(scene, width, height, start + t) for t in range(count)])
+
+
+def make_descriptor_db(seed, n):
+    """Random 256-bit descriptors (n, 32) uint8 -- SURVEY 8d config 5 database."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def make_queries(seed, db, nq, max_flips=40):
+    """Queries = database rows with k in [0, max_flips] random bit flips (non-trivial
+    best/second structure).  Returns (queries, source_row)."""
+    rng = np.random.default_rng(seed)
+    rows = rng.integers(0, len(db), nq)
+    q = db[rows].copy()
+    for i in range(nq):
+        k = int(rng.integers(0, max_flips + 1))
+        bits = rng.choice(256, size=k, replace=False)
+        for b in bits:
+            q[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return q, rows
