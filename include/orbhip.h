@@ -1,0 +1,190 @@
+/*
+ * orbhip.h -- C ABI of liborbhip.so: the MI355X (gfx950) ORB front end and Hamming matcher.
+ *
+ * This is the drop-in boundary for ONE hot path of hwb0314/VI-ORB-SLAM-ICRA2018:
+ * ORBextractor::operator() and ORBmatcher's descriptor matching.  The C++ classes
+ * ORB_SLAM2::ORBextractor / ORB_SLAM2::ORBmatcher in include/orbhip/ keep the reference's
+ * signatures and forward to these entry points (INTEGRATION.md shows the binding).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Unless a name ends in _device every
+ * pointer is a HOST pointer and the call is synchronous.  *_device entry points take device
+ * pointers, enqueue on the context's HIP stream and return without synchronising; call
+ * orbhip_sync() before reading results.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repository root).
+ *
+ * Errors: 0 = ok, negative = error (see ORBHIP_E_*); orbhip_last_error() gives the text.
+ * There is no CPU fallback: without a usable HIP device orbhip_create() fails.
+ * Threading: one context = one extractor instance = one HIP stream; a context is not
+ * re-entrant (same as the reference class, which mutates mvImagePyramid), different contexts
+ * may be used concurrently from different host threads (src/Frame.cc:422-425 does this for
+ * stereo).
+ */
+#ifndef ORBHIP_H
+#define ORBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBHIP_OK 0
+#define ORBHIP_E_ARG (-1)       /* bad argument */
+#define ORBHIP_E_SIZE (-2)      /* image larger than the context or too small for the cell grid */
+#define ORBHIP_E_CAPACITY (-3)  /* output capacity too small */
+#define ORBHIP_E_HIP (-4)       /* HIP runtime error */
+#define ORBHIP_E_NODEVICE (-5)  /* no HIP device / wrong architecture */
+#define ORBHIP_E_COMM (-6)      /* RCCL error */
+
+#define ORBHIP_MAX_LEVELS 16
+
+typedef struct orbhip_ctx orbhip_ctx;
+
+/* Binary layout of cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave,
+ * class_id.  Replaces std::vector<cv::KeyPoint>& of include/ORBextractor.h:77-79. */
+typedef struct orbhip_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbhip_keypoint;
+
+/* A FAST candidate before quadtree distribution (debug/parity access): coordinates relative
+ * to (16,16) of the level as in src/ORBextractor.cc:822-827, and the FAST score. */
+typedef struct orbhip_cand {
+    int32_t x, y, score;
+} orbhip_cand;
+
+/* Number of visible HIP devices (0 if none). */
+int orbhip_device_count(void);
+
+/* Replaces ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels,
+ * int iniThFAST, int minThFAST) (include/ORBextractor.h:69-70, src/ORBextractor.cc:412-472).
+ * max_w/max_h bound the image size, max_batch the frames per batched call; all device
+ * buffers are allocated here, none in the per-frame calls.  Returns NULL on failure
+ * (orbhip_last_error(NULL) has the reason). */
+orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFactor, int nlevels,
+                          int iniThFAST, int minThFAST, int max_w, int max_h, int max_batch);
+void orbhip_destroy(orbhip_ctx *ctx);
+const char *orbhip_last_error(const orbhip_ctx *ctx);
+int orbhip_sync(orbhip_ctx *ctx);
+/* The context's hipStream_t (as void*), so a caller can order its own work against it. */
+void *orbhip_stream(orbhip_ctx *ctx);
+
+/* Replaces GetLevels/GetScaleFactor(s)/GetInverseScaleFactors/GetScaleSigmaSquares/
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:81-101) and exposes
+ * mnFeaturesPerLevel/umax (:122,:124).  Any output pointer may be NULL.  Arrays need nlevels
+ * entries (umax: 16). */
+int orbhip_get_tables(const orbhip_ctx *ctx, int *nlevels, double *scaleFactor, float *mvScaleFactor,
+                      float *mvInvScaleFactor, float *mvLevelSigma2, float *mvInvLevelSigma2,
+                      int *mnFeaturesPerLevel, int *umax);
+/* Upper bound on keypoints per frame (nfeatures plus the quadtree's overshoot); use as `cap`. */
+int orbhip_max_keypoints(const orbhip_ctx *ctx);
+/* Size of pyramid level `level` for a w x h input (src/ORBextractor.cc:1132-1133). */
+int orbhip_level_size(const orbhip_ctx *ctx, int w, int h, int level, int *lw, int *lh);
+
+/* Replaces ORBextractor::operator()(InputArray image, InputArray mask, vector<KeyPoint>&,
+ * OutputArray descriptors) (include/ORBextractor.h:77-79, src/ORBextractor.cc:1045-1126).
+ * img: 8-bit single channel, `stride` bytes per row.  kps/desc: capacity `cap` keypoints
+ * (desc is cap x 32 bytes, row i = descriptor of keypoint i).  timings_ms (may be NULL)
+ * receives {pyramid, keypoints, descriptors} in ms = GetTimeOfComputePyramid /
+ * GetTimeOfComputeKeyPointsOctTree / GetTImeOfComputeDescriptor (include/ORBextractor.h:51-53). */
+int orbhip_extract(orbhip_ctx *ctx, const uint8_t *img, int w, int h, int stride,
+                   orbhip_keypoint *kps, uint8_t *desc, int cap, int *n_out, float timings_ms[3]);
+
+/* Batched mode (new; the reference processes one image per call): B independent frames of the
+ * same size per call, one launch per stage.  imgs[b] are host pointers; outputs are
+ * kps[b*cap + i], desc[(b*cap + i)*32], n_out[b]. */
+int orbhip_extract_batch(orbhip_ctx *ctx, const uint8_t *const *imgs, int B, int w, int h,
+                         int stride, orbhip_keypoint *kps, uint8_t *desc, int cap, int *n_out);
+
+/* Same with everything resident in device memory: d_imgs = B frames, frame b at
+ * d_imgs + b*frame_stride, rows `stride` bytes apart (stride % 4 == 0 and 4-byte aligned
+ * base required).  d_kps [B*cap] orbhip_keypoint, d_desc [B*cap*32] bytes, d_counts [B]
+ * int32.  Asynchronous on the context stream.  Level 0 of the pyramid aliases d_imgs until the
+ * next extract call on this context. */
+int orbhip_extract_batch_device(orbhip_ctx *ctx, const void *d_imgs, int B, int w, int h,
+                                int stride, size_t frame_stride, void *d_kps, void *d_desc, int cap,
+                                void *d_counts);
+
+/* Replaces reads of the public member std::vector<cv::Mat> mvImagePyramid
+ * (include/ORBextractor.h:103; read by src/Frame.cc:817,907,919,924).  Copies level `level`
+ * of frame `frame` of the last extract call to dst (rows dst_stride apart). */
+int orbhip_get_pyramid_level(orbhip_ctx *ctx, int frame, int level, uint8_t *dst, int dst_stride,
+                             int *w, int *h);
+
+/* ---- parity/debug access to stage outputs of the last extract call ---- */
+/* blurred level (cv::GaussianBlur at src/ORBextractor.cc:1103-1104) */
+int orbhip_debug_get_blurred_level(orbhip_ctx *ctx, int frame, int level, uint8_t *dst,
+                                   int dst_stride, int *w, int *h);
+/* FAST candidates of one level in the reference's order (cells row-major, raster inside a
+ * cell; src/ORBextractor.cc:791-831). */
+int orbhip_debug_get_candidates(orbhip_ctx *ctx, int frame, int level, orbhip_cand *out, int cap,
+                                int *n_out);
+/* keypoints of one level after DistributeOctTree + orientation, level coordinates
+ * (src/ORBextractor.cc:833-854). */
+int orbhip_debug_get_level_keypoints(orbhip_ctx *ctx, int frame, int level, orbhip_keypoint *out,
+                                     int cap, int *n_out);
+
+/* ---- matching ---- */
+/* Replaces ORBmatcher::DescriptorDistance (include/ORBmatcher.h:47, src/ORBmatcher.cc:1675-1691)
+ * applied to a whole query set against a whole database with the best / second-best
+ * bookkeeping of every search routine (src/ORBmatcher.cc:205-226 etc.): for each query the
+ * lowest-index minimum (strict '<'), its distance and the second smallest distance; initial
+ * values 256 / -1 / 256.  Descriptors are rows of 32 bytes. */
+int orbhip_hamming_knn2(orbhip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *db, int ndb,
+                        int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+int orbhip_hamming_knn2_device(orbhip_ctx *ctx, const void *d_q, int nq, const void *d_db, int ndb,
+                               void *d_best_idx, void *d_best_d, void *d_second_d);
+
+/* Batched form for a sequence held on the device (new; the reference matches one frame pair per
+ * call): descriptor sets laid out as the outputs of orbhip_extract_batch_device (set b at
+ * d_desc + b*cap*32 with d_counts[b] rows).  For b >= lag the queries are set b and the database
+ * is set b-lag; outputs at [b*cap + i]; for b < lag the outputs are -1 / 256 / 256.  One launch for
+ * all B sets. */
+int orbhip_hamming_knn2_seq_device(orbhip_ctx *ctx, const void *d_desc, const void *d_counts, int cap,
+                                   int B, int lag, void *d_best_idx, void *d_best_d, void *d_second_d);
+
+/* Same bookkeeping over explicit candidate lists in CSR form (query i examines
+ * cand[off[i] .. off[i+1])), the shape of SearchByProjection / SearchForInitialization /
+ * Fuse / SearchBySim3 inner loops (src/ORBmatcher.cc:76-125, 432-461, 901-949, 1199-1224). */
+int orbhip_hamming_knn2_lists(orbhip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *db, int ndb,
+                              const int32_t *off, const int32_t *cand, int32_t *best_idx,
+                              int32_t *best_d, int32_t *second_d);
+
+/* Replaces the matching core of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)
+ * (src/ORBmatcher.cc:159-288; th_mode 0: accept best <= th) and
+ * SearchByBoW(KeyFrame*, KeyFrame*, ...) (:522-655; th_mode 1: accept best < th, valid2 given).
+ * Side 1/2 FeatureVectors in CSR form: sorted node ids, offsets [ng+1], feature indices.
+ * valid1[i] != 0 <=> feature i has a good MapPoint; valid2 may be NULL.
+ * match12[n1] / match21[n2] receive the matched index on the other side or -1, after the
+ * rotation histogram filter (ComputeThreeMaxima, :1629-1670) when check_ori != 0.
+ * *nmatches receives the return value of the reference routine. */
+int orbhip_search_by_bow(orbhip_ctx *ctx, const uint8_t *desc1, int n1, const uint8_t *valid1,
+                         const float *angle1, const int32_t *node1, const int32_t *off1,
+                         const int32_t *idx1, int ng1, const uint8_t *desc2, int n2,
+                         const uint8_t *valid2, const float *angle2, const int32_t *node2,
+                         const int32_t *off2, const int32_t *idx2, int ng2, int th, int th_mode,
+                         float nnratio, int check_ori, int32_t *match12, int32_t *match21,
+                         int *nmatches);
+
+/* Device time of the stages of the last extract call on this context, in ms:
+ * {pyramid, FAST, quadtree, blur, describe} and, at [5], of the last orbhip_hamming_knn2*_device
+ * call.  Measured with HIP events on the context's stream; synchronises the stream. */
+int orbhip_get_stage_times(orbhip_ctx *ctx, float ms[6]);
+
+/* ---- multi-GPU (one process per GPU) ---- */
+/* RCCL communicator over the ranks of one node.  uid: 128-byte ncclUniqueId produced by
+ * orbhip_comm_unique_id() on rank 0 and distributed by the caller (file, env, torch store). */
+int orbhip_comm_unique_id(uint8_t uid[128]);
+int orbhip_comm_init(orbhip_ctx *ctx, int rank, int nranks, const uint8_t uid[128]);
+/* Broadcast of the ORB vocabulary blob (binary format of
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1727-1751, loaded at src/System.cc:331-346)
+ * from `root` to every rank over xGMI.  d_buf: device pointer, nbytes on every rank. */
+int orbhip_bcast_blob_device(orbhip_ctx *ctx, void *d_buf, size_t nbytes, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBHIP_H */

@@ -1,0 +1,127 @@
+"""CPU tests of the product's host-side logic (no GPU): the C-ABI library loads and exports every
+declared symbol, the device quadtree formulation (serial emulation) equals the list-based oracle,
+the device cos/sin sequence equals libm on the whole angle domain."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NATIVE = os.path.join(ROOT, "tests", "native")
+
+
+@pytest.fixture(scope="module")
+def native():
+    subprocess.check_call(["make", "-C", NATIVE, "all"], stdout=subprocess.DEVNULL)
+    qt = C.CDLL(os.path.join(NATIVE, "libqt_emul.so"))
+    qt.qt_emul_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    tr = C.CDLL(os.path.join(NATIVE, "libtrig_host.so"))
+    tr.trig_host_sweep.restype = C.c_long
+    tr.trig_host_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+    tr.trig_host_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    return qt, tr
+
+
+def test_library_exports_every_declared_symbol():
+    from orbhip import capi
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    header = open(os.path.join(ROOT, "include", "orbhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(orbhip_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(capi.SYMBOLS)
+    assert sorted(capi.exported_symbols()) == sorted(capi.SYMBOLS)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a HIP device orbhip_create must fail with a reason (never a CPU path)."""
+    from orbhip import capi
+    L = capi.load()
+    if L.orbhip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert not L.orbhip_create(0, 1000, 1.2, 8, 20, 7, 640, 480, 1)
+    assert "no HIP device" in capi.last_error(None)
+    from orbhip.extractor import ORBextractor
+    with pytest.raises(capi.OrbHipError):
+        ORBextractor(max_w=640, max_h=480)
+
+
+def _pack(c):
+    return (c["x"].astype(np.uint32) | (c["y"].astype(np.uint32) << 12) | (c["score"].astype(np.uint32) << 24))
+
+
+def test_device_quadtree_formulation_equals_list_oracle(native, oracle):
+    qt, _ = native
+    rng = np.random.default_rng(1)
+    checked = 0
+    for trial in range(250):
+        w, h = int(rng.integers(60, 1300)), int(rng.integers(60, 500))
+        if round(w / h) < 1:
+            continue
+        n = int(rng.integers(1, 3000))
+        xs, ys = rng.integers(0, w, n), rng.integers(0, h, n)
+        if trial % 3 == 0:
+            xs = np.clip(rng.normal(w / 2, w / 12, n).astype(int), 0, w - 1)
+            ys = np.clip(rng.normal(h / 2, h / 12, n).astype(int), 0, h - 1)
+        pts = sorted(set(zip(ys.tolist(), xs.tolist())))
+        sc = rng.integers(7, 120, len(pts))
+        c = np.array([(x, y, s) for (y, x), s in zip(pts, sc)], dtype=oracle.CAND_DTYPE)
+        N = int(rng.integers(1, 900))
+        want = _pack(c)[oracle.distribute_octtree(c, w, h, N)]
+        out = np.zeros(N + 64, np.uint32)
+        packed = np.ascontiguousarray(_pack(c))
+        S = qt.qt_emul_distribute(packed.ctypes.data, len(c), w, h, N, out.ctypes.data, len(out))
+        assert S == len(want) and np.array_equal(out[:S], want), (trial, w, h, len(c), N)
+        checked += 1
+    assert checked > 150
+
+
+def test_device_quadtree_on_real_candidates(native, oracle):
+    from orbhip import synth
+    qt, _ = native
+    img = synth.make_frames(11, 752, 480, 1)[0]
+    ex = oracle.Extractor(1000)
+    ex(img)
+    for l in range(8):
+        c = ex.level_cands(l)
+        lvl = ex.pyramid(l)
+        N = ex.params.mnFeaturesPerLevel[l]
+        regw, regh = lvl.shape[1] - 32, lvl.shape[0] - 32
+        want = _pack(c)[oracle.distribute_octtree(c, regw, regh, N)]
+        out = np.zeros(N + 64, np.uint32)
+        packed = np.ascontiguousarray(_pack(c))
+        S = qt.qt_emul_distribute(packed.ctypes.data, len(c), regw, regh, N, out.ctypes.data, len(out))
+        assert S == len(want) and np.array_equal(out[:S], want)
+
+
+def test_device_trig_sequence_equals_libm_exhaustively(native):
+    """Every float in [0, 2*pi*1.01] (1.09e9 values, ~5 s): the double-precision sequence the
+    kernel evaluates gives the same bits as this machine's cosf/sinf (what the reference calls,
+    src/ORBextractor.cc:115)."""
+    _, tr = native
+    hi = struct.unpack("<I", struct.pack("<f", 6.2831855 * 1.01))[0]
+    bad = C.c_float()
+    assert tr.trig_host_sweep(0, hi, 1, C.byref(bad)) == 0, bad.value
+
+
+def test_device_trig_known_values(native):
+    _, tr = native
+    s, c = C.c_float(), C.c_float()
+    tr.trig_host_sincos(0.0, C.byref(s), C.byref(c))
+    assert (s.value, c.value) == (0.0, 1.0)
+    for deg in range(0, 361, 15):
+        rad = np.float32(deg) * np.float32(np.pi / np.float32(180))
+        tr.trig_host_sincos(rad, C.byref(s), C.byref(c))
+        assert abs(s.value - np.sin(np.float64(rad))) < 1e-7 and abs(c.value - np.cos(np.float64(rad))) < 1e-7
+
+
+def test_synth_frames_are_deterministic_and_textured():
+    from orbhip import synth
+    a = synth.make_frames(5, 320, 240, 2)
+    b = synth.make_frames(5, 320, 240, 2)
+    assert np.array_equal(a, b) and a.dtype == np.uint8 and a.shape == (2, 240, 320)
+    assert a.std() > 20 and not np.array_equal(a[0], a[1])

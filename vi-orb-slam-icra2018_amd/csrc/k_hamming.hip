@@ -1,0 +1,322 @@
+// k_hamming.hip -- M0/M1/M2/M3: 256-bit Hamming matching (ref: src/ORBmatcher.cc:1675-1691
+// DescriptorDistance; :205-226 and the other search routines' best / second-best bookkeeping;
+// :159-288 and :522-655 SearchByBoW).  Integer/bitwise path: XOR + v_bcnt_u32_b32, no MFMA.
+//
+//  k_knn2        brute force, query tile x database split; a thread owns one query (8 VGPRs),
+//                the database row is wave-uniform and arrives through scalar loads; partial
+//                (best, index, second) per split, merged in split order by k_knn2_merge so that
+//                the lowest index wins ties exactly like the reference's strict '<' loop.
+//                Roofline: 16 integer ops per 32-byte pair => VALU-bound for many queries,
+//                HBM-bound (database streamed once) for few.
+//  k_knn2_lists  the same bookkeeping over explicit candidate lists (guided search).
+//  k_bow_match   SearchByBoW: one wave per shared vocabulary node; side-1 features are visited
+//                serially (the reference's greedy claiming is order dependent), the 64 lanes scan
+//                the node's side-2 features in parallel and reduce with a tie-aware merge.
+#include "orbhip_internal.h"
+
+struct Best {
+    int b1, idx, b2;
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t q[8], const uint32_t r[8])
+{
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d += __popc(q[k] ^ r[k]);
+    return d;
+}
+
+// sequential update of ref: :216-226
+__device__ __forceinline__ void best_update(Best &B, int d, int j)
+{
+    if (d < B.b1) {
+        B.b2 = B.b1;
+        B.b1 = d;
+        B.idx = j;
+    } else if (d < B.b2) {
+        B.b2 = d;
+    }
+}
+
+// A holds candidates that come BEFORE all of B's in the reference's visiting order.
+__device__ __forceinline__ Best best_merge_ordered(const Best &A, const Best &B)
+{
+    Best R;
+    if (B.b1 < A.b1) {
+        R.b1 = B.b1;
+        R.idx = B.idx;
+        R.b2 = min(A.b1, B.b2);
+    } else {
+        R.b1 = A.b1;
+        R.idx = A.idx;
+        R.b2 = min(A.b2, B.b1);
+    }
+    return R;
+}
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int nq,
+                                              const uint8_t *__restrict__ db, int ndb, int rowsPerSplit,
+                                              int4 *__restrict__ partial)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int split = blockIdx.y;
+    uint32_t Q[8];
+    if (qi < nq) {
+        const uint4 a = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[0];
+        const uint4 b = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[1];
+        Q[0] = a.x; Q[1] = a.y; Q[2] = a.z; Q[3] = a.w;
+        Q[4] = b.x; Q[5] = b.y; Q[6] = b.z; Q[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) Q[k] = 0;
+    }
+    Best B = {256, -1, 256};
+    const int j0 = split * rowsPerSplit;
+    const int j1 = min(ndb, j0 + rowsPerSplit);
+    for (int j = j0; j < j1; j++) {
+        // wave-uniform address: the compiler emits scalar loads (s_load_dwordx8)
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(db + (size_t)j * 32);
+        uint32_t R[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) R[k] = row[k];
+        best_update(B, hamming256(Q, R), j);
+    }
+    if (qi < nq) partial[(size_t)split * nq + qi] = make_int4(B.b1, B.idx, B.b2, 0);
+}
+
+__global__ __launch_bounds__(256) void k_knn2_merge(const int4 *__restrict__ partial, int nq, int nsplit,
+                                                    int32_t *__restrict__ best_idx,
+                                                    int32_t *__restrict__ best_d,
+                                                    int32_t *__restrict__ second_d)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    Best A = {256, -1, 256};
+    for (int s = 0; s < nsplit; s++) {
+        const int4 p = partial[(size_t)s * nq + qi];
+        Best Bp = {p.x, p.y, p.z};
+        A = best_merge_ordered(A, Bp);
+    }
+    best_idx[qi] = A.idx;
+    best_d[qi] = A.b1;
+    second_d[qi] = A.b2;
+}
+
+static void knn2_shape(int nq, int ndb, int *qTiles, int *nsplit, int *rows)
+{
+    *qTiles = (nq + 255) / 256;
+    int want = 4096 / (*qTiles > 0 ? *qTiles : 1);
+    if (want < 1) want = 1;
+    int maxSplit = (ndb + 63) / 64;
+    if (maxSplit < 1) maxSplit = 1;
+    int ns = want < maxSplit ? want : maxSplit;
+    if (ns > 65535) ns = 65535;
+    *rows = (ndb + ns - 1) / ns;
+    if (*rows < 1) *rows = 1;
+    *nsplit = ndb > 0 ? (ndb + *rows - 1) / *rows : 1;
+}
+
+size_t knn2_scratch_bytes(int nq, int ndb)
+{
+    int qt, ns, rows;
+    knn2_shape(nq, ndb, &qt, &ns, &rows);
+    return (size_t)ns * (size_t)(nq > 0 ? nq : 1) * sizeof(int4);
+}
+
+void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int ndb, int32_t *best_idx,
+                 int32_t *best_d, int32_t *second_d, void *scratch, size_t scratch_bytes)
+{
+    if (nq <= 0) return;
+    int qt, ns, rows;
+    knn2_shape(nq, ndb, &qt, &ns, &rows);
+    (void)scratch_bytes;
+    int4 *partial = reinterpret_cast<int4 *>(scratch);
+    hipLaunchKernelGGL(k_knn2, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
+    hipLaunchKernelGGL(k_knn2_merge, dim3(qt, 1, 1), dim3(256, 1, 1), 0, s, partial, nq, ns, best_idx, best_d,
+                       second_d);
+}
+
+// B independent (query set, database set) problems of a frame sequence in one launch:
+// queries = descriptors of frame b, database = descriptors of frame b - lag.
+__global__ __launch_bounds__(256) void k_knn2_seq(const uint8_t *__restrict__ desc,
+                                                  const int32_t *__restrict__ counts, int cap, int lag,
+                                                  int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
+                                                  int32_t *__restrict__ second_d)
+{
+    const int b = blockIdx.y;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int nq = min(counts[b], cap);
+    if (blockIdx.x * 256 >= nq) return;  // whole block idle (uniform)
+    Best B = {256, -1, 256};
+    if (b >= lag) {
+        const int ndb = min(counts[b - lag], cap);
+        const uint8_t *q = desc + ((size_t)b * cap + (qi < nq ? qi : 0)) * 32;
+        const uint4 a0 = reinterpret_cast<const uint4 *>(q)[0], a1 = reinterpret_cast<const uint4 *>(q)[1];
+        const uint32_t Q[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const uint8_t *db = desc + (size_t)(b - lag) * cap * 32;
+        for (int j = 0; j < ndb; j++) {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(db + (size_t)j * 32);
+            uint32_t R[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) R[k] = row[k];
+            best_update(B, hamming256(Q, R), j);
+        }
+    }
+    if (qi < nq) {
+        const size_t o = (size_t)b * cap + qi;
+        best_idx[o] = B.idx;
+        best_d[o] = B.b1;
+        second_d[o] = B.b2;
+    }
+}
+
+void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, int cap, int B, int lag,
+                     int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    if (B <= 0) return;
+    hipLaunchKernelGGL(k_knn2_seq, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag,
+                       best_idx, best_d, second_d);
+}
+
+__global__ __launch_bounds__(256) void k_knn2_lists(const uint8_t *__restrict__ q, int nq,
+                                                    const uint8_t *__restrict__ db,
+                                                    const int32_t *__restrict__ off,
+                                                    const int32_t *__restrict__ cand,
+                                                    int32_t *__restrict__ best_idx,
+                                                    int32_t *__restrict__ best_d,
+                                                    int32_t *__restrict__ second_d)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t Q[8];
+    const uint4 a = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[0];
+    const uint4 b = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[1];
+    Q[0] = a.x; Q[1] = a.y; Q[2] = a.z; Q[3] = a.w;
+    Q[4] = b.x; Q[5] = b.y; Q[6] = b.z; Q[7] = b.w;
+    Best B = {256, -1, 256};
+    for (int t = off[qi]; t < off[qi + 1]; t++) {
+        const int j = cand[t];
+        const uint4 r0 = reinterpret_cast<const uint4 *>(db + (size_t)j * 32)[0];
+        const uint4 r1 = reinterpret_cast<const uint4 *>(db + (size_t)j * 32)[1];
+        const uint32_t R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        best_update(B, hamming256(Q, R), j);
+    }
+    best_idx[qi] = B.idx;
+    best_d[qi] = B.b1;
+    second_d[qi] = B.b2;
+}
+
+void launch_knn2_lists(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, const int32_t *off,
+                       const int32_t *cand, int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_knn2_lists, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, q, nq, db, off, cand,
+                       best_idx, best_d, second_d);
+}
+
+// ---- SearchByBoW ----
+#define BOW_CLAIM_BITS 4096  // claimed-flags kept in LDS per wave (side-2 features of one node)
+
+// (b1, pos, b2) merge for two disjoint candidate sets in arbitrary order; ties -> lower position.
+__device__ __forceinline__ void bow_merge(int &b1, int &pos, int &b2, int ob1, int opos, int ob2)
+{
+    const bool mine = (b1 < ob1) || (b1 == ob1 && pos < opos);
+    const int nb1 = mine ? b1 : ob1;
+    const int npos = mine ? pos : opos;
+    const int nb2 = mine ? min(b2, ob1) : min(ob2, b1);
+    b1 = nb1;
+    pos = npos;
+    b2 = nb2;
+}
+
+__global__ __launch_bounds__(256) void k_bow_match(const uint8_t *__restrict__ desc1,
+                                                   const uint8_t *__restrict__ valid1,
+                                                   const int32_t *__restrict__ off1,
+                                                   const int32_t *__restrict__ idx1,
+                                                   const uint8_t *__restrict__ desc2,
+                                                   const uint8_t *__restrict__ valid2,
+                                                   const int32_t *__restrict__ off2,
+                                                   const int32_t *__restrict__ idx2,
+                                                   const int2 *__restrict__ pairs, int npairs, int th,
+                                                   int th_mode, float nnratio, int32_t *__restrict__ match12,
+                                                   int32_t *__restrict__ match21)
+{
+    __shared__ uint32_t s_claim[4][BOW_CLAIM_BITS / 32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + wave;
+    if (pi >= npairs) return;
+    const int2 pr = pairs[pi];
+    const int a0 = off1[pr.x], a1 = off1[pr.x + 1];
+    const int b0 = off2[pr.y], b1e = off2[pr.y + 1];
+    const int n2 = b1e - b0;
+    uint32_t *claim = s_claim[wave];
+    const bool useLds = n2 <= BOW_CLAIM_BITS;
+    if (useLds)
+        for (int k = lane; k < (n2 + 31) / 32; k += 64) claim[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int a = a0; a < a1; a++) {
+        const int i1 = idx1[a];
+        if (!valid1[i1]) continue;  // wave-uniform
+        uint32_t Q[8];
+        {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(desc1 + (size_t)i1 * 32);
+#pragma unroll
+            for (int k = 0; k < 8; k++) Q[k] = row[k];
+        }
+        int bd1 = 256, bpos = 0x7FFFFFFF, bd2 = 256;
+        for (int p = lane; p < n2; p += 64) {
+            const int i2 = idx2[b0 + p];
+            bool skip;
+            if (useLds)
+                skip = (claim[p >> 5] >> (p & 31)) & 1u;
+            else
+                skip = __atomic_load_n(&match21[i2], __ATOMIC_RELAXED) >= 0;
+            if (valid2 && !valid2[i2]) skip = true;
+            if (skip) continue;
+            const uint4 r0 = reinterpret_cast<const uint4 *>(desc2 + (size_t)i2 * 32)[0];
+            const uint4 r1 = reinterpret_cast<const uint4 *>(desc2 + (size_t)i2 * 32)[1];
+            const uint32_t R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const int d = hamming256(Q, R);
+            if (d < bd1) {
+                bd2 = bd1;
+                bd1 = d;
+                bpos = p;
+            } else if (d < bd2) {
+                bd2 = d;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ob1 = __shfl_xor(bd1, o), opos = __shfl_xor(bpos, o), ob2 = __shfl_xor(bd2, o);
+            bow_merge(bd1, bpos, bd2, ob1, opos, ob2);
+        }
+        const bool pass = th_mode ? (bd1 < th) : (bd1 <= th);
+        if (pass && (float)bd1 < nnratio * (float)bd2) {  // ref: :228-230 / :598-600
+            const int i2 = idx2[b0 + bpos];
+            if (lane == 0) {
+                match12[i1] = i2;
+                if (useLds)
+                    claim[bpos >> 5] |= 1u << (bpos & 31);
+                __atomic_store_n(&match21[i2], i1, __ATOMIC_RELAXED);
+            }
+            if (!useLds) __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1, const int32_t *off1,
+                      const int32_t *idx1, const uint8_t *desc2, const uint8_t *valid2,
+                      const int32_t *off2, const int32_t *idx2, const int32_t *pairs, int npairs,
+                      int th, int th_mode, float nnratio, int32_t *match12, int32_t *match21)
+{
+    if (npairs <= 0) return;
+    hipLaunchKernelGGL(k_bow_match, dim3((npairs + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, desc1, valid1, off1,
+                       idx1, desc2, valid2, off2, idx2, reinterpret_cast<const int2 *>(pairs), npairs, th,
+                       th_mode, nnratio, match12, match21);
+}

@@ -1,0 +1,119 @@
+// k_quadtree.hip -- E4: DistributeOctTree on the device, one 256-thread workgroup per
+// (frame, level) (ref: src/ORBextractor.cc:541-765).  The algorithm lives in quadtree_core.h
+// (shared with the CPU test that checks it against the list-based oracle); this file supplies the
+// workgroup execution model (LDS atomics, wave-shuffle scans) and the gather of the per-cell
+// candidate slots written by k_fast into the compact, canonically ordered point array.
+#include "orbhip_internal.h"
+#include "quadtree_core.h"
+
+struct QtBlock {
+    int *wtot;  // [4] LDS
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int nth() const { return blockDim.x; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ int atomic_add(int *p, int v) const { return atomicAdd(p, v); }
+    __device__ __forceinline__ void atomic_min(int *p, int v) const { atomicMin(p, v); }
+    __device__ __forceinline__ void atomic_max(unsigned *p, unsigned v) const { atomicMax(p, v); }
+    // In-place exclusive scan of a[0..n) (LDS); returns the total.  Called by all threads.
+    __device__ int scan_exclusive(int *a, int n) const
+    {
+        const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+        const int K = (n + 255) >> 8;
+        const int beg = min(t * K, n), end = min(beg + K, n);
+        int sum = 0;
+        for (int i = beg; i < end; i++) sum += a[i];
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w = 0; w < 4; w++) {
+            const int v = wtot[w];
+            if (w < wave) base += v;
+            total += v;
+        }
+        int run = base + incl - sum;
+        for (int i = beg; i < end; i++) {
+            const int v = a[i];
+            a[i] = run;
+            run += v;
+        }
+        __syncthreads();
+        return total;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_quadtree(const OrbLevels G, const uint32_t *__restrict__ cand,
+                                                  const uint16_t *__restrict__ cellCnt,
+                                                  uint32_t *__restrict__ pts, uint32_t *__restrict__ pnode,
+                                                  int32_t *__restrict__ lvlCandCnt,
+                                                  uint32_t *__restrict__ lvlKp,
+                                                  int32_t *__restrict__ lvlKpCnt, int maxNodes, int qtBytes)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_wtot[4];
+    const int l = blockIdx.x, frame = blockIdx.y;
+    const OrbLevel &L = G.lv[l];
+    const int tid = threadIdx.x;
+    QtBlock x;
+    x.wtot = s_wtot;
+
+    // ---- gather: per-cell slots -> compact array in canonical order ----
+    int *cellOff = reinterpret_cast<int *>(smem + qtBytes);
+    const int ncells = L.nCols * L.nRows;
+    const uint16_t *cc = cellCnt + (size_t)frame * G.totalCells + L.cellBase;
+    for (int c = tid; c < ncells; c += 256) cellOff[c] = cc[c];
+    __syncthreads();
+    const int n = x.scan_exclusive(cellOff, ncells);
+    const uint32_t *slots = cand + (size_t)frame * G.totalCands + L.candBase;
+    uint32_t *P = pts + (size_t)frame * G.totalPts + L.ptBase;
+    uint32_t *PN = pnode + (size_t)frame * G.totalPts + L.ptBase;
+    for (int c = tid; c < ncells; c += 256) {
+        const int k = cc[c], o = cellOff[c];
+        const uint32_t *src = slots + (size_t)c * L.cellCap;
+        for (int j = 0; j < k; j++) P[o + j] = src[j];
+    }
+    if (tid == 0) lvlCandCnt[frame * ORBHIP_MAX_LEVELS + l] = n;
+    // make the compact array visible to the whole workgroup (global memory, same CU)
+    __threadfence_block();
+    __syncthreads();
+
+    QtShared sh;
+    qt_carve(sh, smem, maxNodes);
+    QtParams Q;
+    Q.N = L.N;
+    Q.nIni = L.nIni;
+    Q.hX = L.hX;
+    Q.regw = L.regw;
+    Q.regh = L.regh;
+    Q.maxNodes = L.kpCap;
+    uint32_t *out = lvlKp + (size_t)frame * G.totalKps + L.kpBase;
+    const int S = qt_distribute(x, Q, n, P, PN, sh, out);
+    if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
+}
+
+size_t quadtree_lds_bytes(const OrbLevels &G)
+{
+    int maxNodes = 0, maxCells = 0;
+    for (int l = 0; l < G.nlevels; l++) {
+        maxNodes = std::max(maxNodes, G.lv[l].kpCap);
+        maxCells = std::max(maxCells, G.lv[l].nCols * G.lv[l].nRows);
+    }
+    return ((qt_shared_bytes(maxNodes) + 15) & ~(size_t)15) + (size_t)maxCells * 4 + 16;
+}
+
+void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, const uint16_t *cellCnt,
+                     uint32_t *pts, uint32_t *pnode, int32_t *lvlCandCnt, uint32_t *lvlKp,
+                     int32_t *lvlKpCnt, int B)
+{
+    int maxNodes = 0;
+    for (int l = 0; l < G.nlevels; l++) maxNodes = std::max(maxNodes, G.lv[l].kpCap);
+    const int qtBytes = (int)((qt_shared_bytes(maxNodes) + 15) & ~(size_t)15);
+    dim3 grid(G.nlevels, B, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(k_quadtree, grid, block, quadtree_lds_bytes(G), s, G, cand, cellCnt, pts, pnode,
+                       lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes);
+}

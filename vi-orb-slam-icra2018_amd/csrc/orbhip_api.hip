@@ -1,0 +1,813 @@
+// orbhip_api.hip -- the C ABI of liborbhip.so (declared in include/orbhip.h): context and buffer
+// management, the per-batch launch sequence, host staging, parity/debug read-back, the host side of
+// SearchByBoW (merge walk over the two FeatureVectors, rotation histogram) and the RCCL
+// broadcast.  No CPU fallback anywhere: every compute step is a HIP kernel.
+#include "orbhip_internal.h"
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+static std::string g_last_error;
+static std::mutex g_err_mutex;
+
+static int fail(orbhip_ctx *c, int code, const std::string &msg)
+{
+    if (c)
+        c->err = msg;
+    else {
+        std::lock_guard<std::mutex> lk(g_err_mutex);
+        g_last_error = msg;
+    }
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail((c), ORBHIP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <class T>
+static int ensure(orbhip_ctx *c, T *&ptr, size_t &cap, size_t need)
+{
+    if (need <= cap && ptr) return ORBHIP_OK;
+    if (ptr) HIPCHK(c, hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    void *p = nullptr;
+    HIPCHK(c, hipMalloc(&p, need ? need : 16));
+    ptr = reinterpret_cast<T *>(p);
+    cap = need;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *orbhip_last_error(const orbhip_ctx *ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    return g_last_error.c_str();
+}
+
+// (Re)configure for a w x h image with level-0 row stride `stride0`, batch B: geometry, tables and
+// device buffers.  Cheap when nothing changed.
+static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
+{
+    if (w <= 0 || h <= 0 || B <= 0) return fail(c, ORBHIP_E_ARG, "bad image size or batch");
+    if (w > c->max_w || h > c->max_h || B > c->max_batch)
+        return fail(c, ORBHIP_E_SIZE, "image or batch larger than the context was created for");
+    const bool geomChanged = (w != c->cur_w || h != c->cur_h);
+    if (geomChanged) {
+        int rc = orb_build_geometry(c, w, h, stride0);
+        if (rc != ORBHIP_OK) {
+            c->cur_w = c->cur_h = 0;
+            return fail(c, rc, "image too small for the 30-px cell grid / quadtree roots of some level, "
+                               "or larger than the supported tile bounds");
+        }
+        // resize tables
+        std::vector<int32_t> all;
+        for (int l = 1; l < c->nlevels; l++) {
+            std::vector<int32_t> xt, yt;
+            orb_build_resize_tables(c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, xt, yt);
+            while (all.size() % 4) all.push_back(0);
+            c->resizeTabOff[l][0] = all.size();
+            all.insert(all.end(), xt.begin(), xt.end());
+            while (all.size() % 4) all.push_back(0);
+            c->resizeTabOff[l][1] = all.size();
+            all.insert(all.end(), yt.begin(), yt.end());
+        }
+        int rc2;
+        if ((rc2 = ensure(c, c->d_resizeTab, c->cap_resize, all.size() * 4 + 16))) return rc2;
+        if ((rc2 = ensure(c, c->d_fastTiles, c->cap_fastTiles, c->fastTiles.size() * sizeof(FastTile)))) return rc2;
+        if ((rc2 = ensure(c, c->d_blurTiles, c->cap_blurTiles, c->blurTiles.size() * sizeof(BlurTile)))) return rc2;
+        HIPCHK(c, hipMemcpyAsync(c->d_resizeTab, all.data(), all.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_fastTiles, c->fastTiles.data(), c->fastTiles.size() * sizeof(FastTile),
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_blurTiles, c->blurTiles.data(), c->blurTiles.size() * sizeof(BlurTile),
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // the host vectors above go out of scope
+    }
+    c->G.lv[0].stride = stride0;
+    const OrbLevels &G = c->G;
+    const size_t Bm = (size_t)c->max_batch;  // buffers are sized for the context's batch once
+    int rc;
+    if ((rc = ensure(c, c->d_pyr, c->cap_pyr, Bm * c->pyrFrameBytes))) return rc;
+    if ((rc = ensure(c, c->d_blur, c->cap_blur, Bm * (c->lvl0FrameBytes + c->pyrFrameBytes)))) return rc;
+    if ((rc = ensure(c, c->d_cand, c->cap_cand, Bm * (size_t)G.totalCands * 4))) return rc;
+    if ((rc = ensure(c, c->d_cellCnt, c->cap_cells, Bm * (size_t)G.totalCells * 2 + 64))) return rc;
+    if ((rc = ensure(c, c->d_pts, c->cap_pts, Bm * (size_t)G.totalPts * 4))) return rc;
+    if ((rc = ensure(c, c->d_pnode, c->cap_pnode, Bm * (size_t)G.totalPts * 4))) return rc;
+    if ((rc = ensure(c, c->d_lvlKp, c->cap_kps, Bm * (size_t)G.totalKps * 4))) return rc;
+    if ((rc = ensure(c, c->d_lvlAngle, c->cap_angle, Bm * (size_t)G.totalKps * 4))) return rc;
+    if ((rc = ensure(c, c->d_lvlCandCnt, c->cap_cnt1, Bm * ORBHIP_MAX_LEVELS * 4))) return rc;
+    if ((rc = ensure(c, c->d_lvlKpCnt, c->cap_cnt2, Bm * ORBHIP_MAX_LEVELS * 4))) return rc;
+    if ((rc = ensure(c, c->d_counts, c->cap_cnt3, Bm * 4))) return rc;
+    if ((rc = ensure(c, c->d_lvl0, c->cap_lvl0, Bm * c->lvl0FrameBytes))) return rc;
+    if ((size_t)G.outCap > c->cap_out) {
+        size_t d1 = 0, d2 = 0;
+        if (c->d_kps) HIPCHK(c, hipFree(c->d_kps));
+        if (c->d_desc) HIPCHK(c, hipFree(c->d_desc));
+        c->d_kps = nullptr;
+        c->d_desc = nullptr;
+        if ((rc = ensure(c, c->d_kps, d1, Bm * (size_t)G.outCap * sizeof(orbhip_keypoint)))) return rc;
+        if ((rc = ensure(c, c->d_desc, d2, Bm * (size_t)G.outCap * 32))) return rc;
+        c->cap_out = (size_t)G.outCap;
+    }
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFactor, int nlevels,
+                                     int iniThFAST, int minThFAST, int max_w, int max_h, int max_batch)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fail(nullptr, ORBHIP_E_NODEVICE, "no HIP device visible (liborbhip has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev || max_w <= 0 || max_h <= 0 || max_batch <= 0) {
+        fail(nullptr, ORBHIP_E_ARG, "orbhip_create: bad device index or sizes");
+        return nullptr;
+    }
+    orbhip_ctx *c = new orbhip_ctx();
+    c->device = device;
+    c->max_w = max_w;
+    c->max_h = max_h;
+    c->max_batch = max_batch;
+    if (orb_init_tables(c, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) != ORBHIP_OK) {
+        fail(nullptr, ORBHIP_E_ARG, "orbhip_create: bad ORB parameters");
+        delete c;
+        return nullptr;
+    }
+    auto bail = [&](const char *what, hipError_t e) {
+        fail(nullptr, ORBHIP_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        orbhip_destroy(c);
+        return (orbhip_ctx *)nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, ORBHIP_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", liborbhip is built for gfx950");
+        orbhip_destroy(c);
+        return nullptr;
+    }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int i = 0; i < 8; i++)
+        if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
+    // size everything for the largest image now, so per-frame calls never allocate
+    const int stride0 = (int)align_up((size_t)max_w, 64);
+    int rc = configure(c, max_w, max_h, stride0, max_batch);
+    if (rc != ORBHIP_OK) {
+        fail(nullptr, rc, "orbhip_create: " + c->err);
+        orbhip_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void orbhip_destroy(orbhip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
+                    c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
+                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int i = 0; i < 8; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int orbhip_sync(orbhip_ctx *c)
+{
+    if (!c) return ORBHIP_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+
+extern "C" void *orbhip_stream(orbhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int orbhip_get_tables(const orbhip_ctx *c, int *nlevels, double *scaleFactor, float *sf,
+                                 float *isf, float *s2, float *is2, int *perLevel, int *umax)
+{
+    if (!c) return ORBHIP_E_ARG;
+    if (nlevels) *nlevels = c->nlevels;
+    if (scaleFactor) *scaleFactor = c->scaleFactor;
+    for (int i = 0; i < c->nlevels; i++) {
+        if (sf) sf[i] = c->mvScaleFactor[i];
+        if (isf) isf[i] = c->mvInvScaleFactor[i];
+        if (s2) s2[i] = c->mvLevelSigma2[i];
+        if (is2) is2[i] = c->mvInvLevelSigma2[i];
+        if (perLevel) perLevel[i] = c->mnFeaturesPerLevel[i];
+    }
+    if (umax) memcpy(umax, c->umax, sizeof(int) * 16);
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_max_keypoints(const orbhip_ctx *c)
+{
+    if (!c) return ORBHIP_E_ARG;
+    // independent of the image size except through nIni (<= a handful); use the create-time value
+    return (int)c->cap_out;
+}
+
+extern "C" int orbhip_level_size(const orbhip_ctx *c, int w, int h, int level, int *lw, int *lh)
+{
+    if (!c || level < 0 || level >= c->nlevels || !lw || !lh) return ORBHIP_E_ARG;
+    orb_level_size(c, w, h, level, lw, lh);
+    return ORBHIP_OK;
+}
+
+// The launch sequence of one batch.  lvl0: device pointer of frame 0 / level 0.
+// Stage boundaries are marked with HIP events on the context stream (ev[0..5]).
+static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t frame0, int B,
+                        orbhip_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts, int cap)
+{
+    const OrbLevels &G = c->G;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    // E2 pyramid: level l from level l-1 (sequential dependency), all frames per launch
+    for (int l = 1; l < G.nlevels; l++) {
+        const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
+        const uint8_t *src = (l == 1) ? lvl0 : c->d_pyr + S.imgOff;
+        const int sstride = (l == 1) ? stride0 : S.stride;
+        const size_t sframe = (l == 1) ? frame0 : c->pyrFrameBytes;
+        launch_resize(s, src, S.w, S.h, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride,
+                      c->pyrFrameBytes, c->d_resizeTab + c->resizeTabOff[l][0],
+                      c->d_resizeTab + c->resizeTabOff[l][1], B);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    // E3 FAST, E4 quadtree (orientation is folded into the describe kernel)
+    launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles,
+                (int)c->fastTiles.size(), c->d_cand, c->d_cellCnt, B);
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
+                    c->d_lvlKpCnt, B);
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    // E6 blur, E5+E7+E8 describe
+    launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    launch_describe(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, d_kps,
+                    d_desc, d_counts, cap, B);
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    HIPCHK(c, hipGetLastError());
+    c->haveStageEvents = true;
+    c->last_lvl0 = lvl0;
+    c->last_stride0 = stride0;
+    c->last_frame0 = frame0;
+    c->last_B = B;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_get_stage_times(orbhip_ctx *c, float ms[6])
+{
+    if (!c || !ms) return fail(c, ORBHIP_E_ARG, "orbhip_get_stage_times: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 6; i++) ms[i] = 0.f;
+    if (c->haveStageEvents)
+        for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    if (c->haveMatchEvents) HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[6], c->ev[7]));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extract_batch_device(orbhip_ctx *c, const void *d_imgs, int B, int w, int h, int stride,
+                                           size_t frame_stride, void *d_kps, void *d_desc, int cap,
+                                           void *d_counts)
+{
+    if (!c || !d_imgs || !d_kps || !d_desc || !d_counts || cap <= 0 || stride < w)
+        return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch_device: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool aliasOk = (stride % 16 == 0) && (((uintptr_t)d_imgs) % 16 == 0) && (frame_stride % 16 == 0);
+    int rc;
+    if (aliasOk) {
+        if ((rc = configure(c, w, h, stride, B))) return rc;
+        return run_pipeline(c, (const uint8_t *)d_imgs, stride, frame_stride, B, (orbhip_keypoint *)d_kps,
+                            (uint8_t *)d_desc, (int32_t *)d_counts, cap);
+    }
+    // unaligned input: repack into the context's level-0 buffer first
+    const int s0 = (int)align_up((size_t)w, 64);
+    if ((rc = configure(c, w, h, s0, B))) return rc;
+    for (int b = 0; b < B; b++)
+        HIPCHK(c, hipMemcpy2DAsync(c->d_lvl0 + (size_t)b * c->lvl0FrameBytes, s0,
+                                   (const uint8_t *)d_imgs + (size_t)b * frame_stride, stride, w, h,
+                                   hipMemcpyDeviceToDevice, c->stream));
+    return run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)d_kps, (uint8_t *)d_desc,
+                        (int32_t *)d_counts, cap);
+}
+
+static int host_stage(orbhip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->h_stage_bytes) return ORBHIP_OK;
+    if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    void *p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    c->h_stage = (uint8_t *)p;
+    c->h_stage_bytes = bytes;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, int B, int w, int h, int stride,
+                                    orbhip_keypoint *kps, uint8_t *desc, int cap, int *n_out)
+{
+    if (!c || !imgs || !kps || !desc || !n_out || cap <= 0 || stride < w)
+        return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int s0 = (int)align_up((size_t)w, 64);
+    int rc;
+    if ((rc = configure(c, w, h, s0, B))) return rc;
+    for (int b = 0; b < B; b++) {
+        if (!imgs[b]) return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: null image");
+        HIPCHK(c, hipMemcpy2DAsync(c->d_lvl0 + (size_t)b * c->lvl0FrameBytes, s0, imgs[b], stride, w, h,
+                                   hipMemcpyHostToDevice, c->stream));
+    }
+    const int dcap = (int)c->cap_out;
+    if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, c->d_kps, c->d_desc, c->d_counts, dcap)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(n_out, c->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < B; b++) {
+        const int n = n_out[b];
+        if (n > cap || n > dcap) return fail(c, ORBHIP_E_CAPACITY, "orbhip_extract_batch: output capacity too small");
+        HIPCHK(c, hipMemcpyAsync(kps + (size_t)b * cap, c->d_kps + (size_t)b * dcap, (size_t)n * sizeof(orbhip_keypoint),
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(desc + (size_t)b * cap * 32, c->d_desc + (size_t)b * dcap * 32, (size_t)n * 32,
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_extract(orbhip_ctx *c, const uint8_t *img, int w, int h, int stride, orbhip_keypoint *kps,
+                              uint8_t *desc, int cap, int *n_out, float timings_ms[3])
+{
+    if (!c || !img || !n_out) return fail(c, ORBHIP_E_ARG, "orbhip_extract: bad argument");
+    const uint8_t *imgs[1] = {img};
+    int rc = orbhip_extract_batch(c, imgs, 1, w, h, stride, kps, desc, cap, n_out);
+    if (rc == ORBHIP_OK && timings_ms) {
+        // the reference's three timers: pyramid | FAST + quadtree (+ orientation) | blur + BRIEF
+        float ms[6];
+        if ((rc = orbhip_get_stage_times(c, ms))) return rc;
+        timings_ms[0] = ms[0];
+        timings_ms[1] = ms[1] + ms[2];
+        timings_ms[2] = ms[3] + ms[4];
+    }
+    return rc;
+}
+
+static int copy_level(orbhip_ctx *c, const uint8_t *src, int sstride, int w, int h, uint8_t *dst, int dst_stride)
+{
+    HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, src, sstride, w, h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_get_pyramid_level(orbhip_ctx *c, int frame, int level, uint8_t *dst, int dst_stride,
+                                        int *w, int *h)
+{
+    if (!c || !c->last_lvl0 || frame < 0 || frame >= c->last_B || level < 0 || level >= c->nlevels)
+        return fail(c, ORBHIP_E_ARG, "orbhip_get_pyramid_level: bad argument or no frame extracted yet");
+    const OrbLevel &L = c->G.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (!dst) return ORBHIP_OK;
+    if (dst_stride < L.w) return fail(c, ORBHIP_E_ARG, "dst_stride too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (level == 0)
+        return copy_level(c, c->last_lvl0 + (size_t)frame * c->last_frame0, c->last_stride0, L.w, L.h, dst, dst_stride);
+    return copy_level(c, c->d_pyr + (size_t)frame * c->pyrFrameBytes + L.imgOff, L.stride, L.w, L.h, dst, dst_stride);
+}
+
+extern "C" int orbhip_debug_get_blurred_level(orbhip_ctx *c, int frame, int level, uint8_t *dst, int dst_stride,
+                                              int *w, int *h)
+{
+    if (!c || !c->last_lvl0 || frame < 0 || frame >= c->last_B || level < 0 || level >= c->nlevels)
+        return fail(c, ORBHIP_E_ARG, "orbhip_debug_get_blurred_level: bad argument");
+    const OrbLevel &L = c->G.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (!dst) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bf = c->lvl0FrameBytes + c->pyrFrameBytes;
+    const uint8_t *src = c->d_blur + (size_t)frame * bf + (level == 0 ? 0 : c->G.boff1 + L.imgOff);
+    return copy_level(c, src, level == 0 ? c->G.bstride0 : L.stride, L.w, L.h, dst, dst_stride);
+}
+
+extern "C" int orbhip_debug_get_candidates(orbhip_ctx *c, int frame, int level, orbhip_cand *out, int cap,
+                                           int *n_out)
+{
+    if (!c || !c->last_lvl0 || frame < 0 || frame >= c->last_B || level < 0 || level >= c->nlevels || !n_out)
+        return fail(c, ORBHIP_E_ARG, "orbhip_debug_get_candidates: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const OrbLevels &G = c->G;
+    const OrbLevel &L = G.lv[level];
+    const int ncells = L.nCols * L.nRows;
+    std::vector<uint16_t> cnt(ncells);
+    std::vector<uint32_t> slots((size_t)L.ptCap);
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_cellCnt + (size_t)frame * G.totalCells + L.cellBase, (size_t)ncells * 2,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(slots.data(), c->d_cand + (size_t)frame * G.totalCands + L.candBase, (size_t)L.ptCap * 4,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int n = 0;
+    for (int cell = 0; cell < ncells; cell++)
+        for (int k = 0; k < cnt[cell]; k++) {
+            if (out && n < cap) {
+                const uint32_t p = slots[(size_t)cell * L.cellCap + k];
+                out[n].x = (int)(p & 0xFFF);
+                out[n].y = (int)((p >> 12) & 0xFFF);
+                out[n].score = (int)(p >> 24);
+            }
+            n++;
+        }
+    *n_out = n;
+    if (out && n > cap) return fail(c, ORBHIP_E_CAPACITY, "orbhip_debug_get_candidates: capacity");
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_debug_get_level_keypoints(orbhip_ctx *c, int frame, int level, orbhip_keypoint *out, int cap,
+                                                int *n_out)
+{
+    if (!c || !c->last_lvl0 || frame < 0 || frame >= c->last_B || level < 0 || level >= c->nlevels || !n_out)
+        return fail(c, ORBHIP_E_ARG, "orbhip_debug_get_level_keypoints: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const OrbLevels &G = c->G;
+    const OrbLevel &L = G.lv[level];
+    int32_t cnts[ORBHIP_MAX_LEVELS];
+    HIPCHK(c, hipMemcpyAsync(cnts, c->d_lvlKpCnt + (size_t)frame * ORBHIP_MAX_LEVELS, sizeof(cnts), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = cnts[level];
+    *n_out = n;
+    if (!out) return ORBHIP_OK;
+    if (n > cap) return fail(c, ORBHIP_E_CAPACITY, "orbhip_debug_get_level_keypoints: capacity");
+    std::vector<uint32_t> pk(n);
+    std::vector<float> ang(n);
+    HIPCHK(c, hipMemcpyAsync(pk.data(), c->d_lvlKp + (size_t)frame * G.totalKps + L.kpBase, (size_t)n * 4,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ang.data(), c->d_lvlAngle + (size_t)frame * G.totalKps + L.kpBase, (size_t)n * 4,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) {
+        out[i].x = (float)((int)(pk[i] & 0xFFF) + ORB_MIN_BORDER);
+        out[i].y = (float)((int)((pk[i] >> 12) & 0xFFF) + ORB_MIN_BORDER);
+        out[i].size = L.kpSize;
+        out[i].angle = ang[i];
+        out[i].response = (float)(pk[i] >> 24);
+        out[i].octave = level;
+        out[i].class_id = -1;
+    }
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// matching
+// ------------------------------------------------------------------------------------------------
+static int match_scratch(orbhip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->d_match_bytes && c->d_match) return ORBHIP_OK;
+    if (c->d_match) HIPCHK(c, hipFree(c->d_match));
+    c->d_match = nullptr;
+    c->d_match_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->d_match, bytes));
+    c->d_match_bytes = bytes;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_hamming_knn2_device(orbhip_ctx *c, const void *d_q, int nq, const void *d_db, int ndb,
+                                          void *d_best_idx, void *d_best_d, void *d_second_d)
+{
+    if (!c || nq < 0 || ndb < 0 || (nq > 0 && (!d_q || !d_best_idx || !d_best_d || !d_second_d)) || (ndb > 0 && !d_db))
+        return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2_device: bad argument");
+    if (nq == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    const size_t need = knn2_scratch_bytes(nq, ndb);
+    if ((rc = match_scratch(c, need))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    launch_knn2(c->stream, (const uint8_t *)d_q, nq, (const uint8_t *)d_db, ndb, (int32_t *)d_best_idx,
+                (int32_t *)d_best_d, (int32_t *)d_second_d, c->d_match, need);
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->haveMatchEvents = true;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_hamming_knn2_seq_device(orbhip_ctx *c, const void *d_desc, const void *d_counts, int cap,
+                                              int B, int lag, void *d_best_idx, void *d_best_d, void *d_second_d)
+{
+    if (!c || !d_desc || !d_counts || cap <= 0 || B <= 0 || lag < 0 || !d_best_idx || !d_best_d || !d_second_d)
+        return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2_seq_device: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    launch_knn2_seq(c->stream, (const uint8_t *)d_desc, (const int32_t *)d_counts, cap, B, lag,
+                    (int32_t *)d_best_idx, (int32_t *)d_best_d, (int32_t *)d_second_d);
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->haveMatchEvents = true;
+    return ORBHIP_OK;
+}
+
+// Bump allocator over one temporary device block (host-pointer matching entry points).
+struct TmpDev {
+    orbhip_ctx *c;
+    uint8_t *base = nullptr;
+    size_t used = 0, cap = 0;
+    explicit TmpDev(orbhip_ctx *ctx) : c(ctx) {}
+    ~TmpDev()
+    {
+        if (base) (void)hipFree(base);
+    }
+    int reserve(size_t bytes)
+    {
+        HIPCHK(c, hipMalloc((void **)&base, bytes + 4096));
+        cap = bytes + 4096;
+        return ORBHIP_OK;
+    }
+    void *take(size_t bytes)
+    {
+        used = align_up(used, 256);
+        void *p = base + used;
+        used += bytes;
+        return used <= cap ? p : nullptr;
+    }
+};
+
+extern "C" int orbhip_hamming_knn2(orbhip_ctx *c, const uint8_t *q, int nq, const uint8_t *db, int ndb,
+                                   int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    if (!c || nq < 0 || ndb < 0 || (nq > 0 && (!q || !best_idx || !best_d || !second_d)) || (ndb > 0 && !db))
+        return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2: bad argument");
+    if (nq == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)nq * 32 + (size_t)ndb * 32 + (size_t)nq * 12 + 2048))) return rc;
+    uint8_t *dq = (uint8_t *)T.take((size_t)nq * 32), *ddb = (uint8_t *)T.take((size_t)ndb * 32 + 32);
+    int32_t *dbi = (int32_t *)T.take((size_t)nq * 4), *dbd = (int32_t *)T.take((size_t)nq * 4),
+            *dsd = (int32_t *)T.take((size_t)nq * 4);
+    HIPCHK(c, hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (ndb) HIPCHK(c, hipMemcpyAsync(ddb, db, (size_t)ndb * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = orbhip_hamming_knn2_device(c, dq, nq, ddb, ndb, dbi, dbd, dsd))) return rc;
+    HIPCHK(c, hipMemcpyAsync(best_idx, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(best_d, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(second_d, dsd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_hamming_knn2_lists(orbhip_ctx *c, const uint8_t *q, int nq, const uint8_t *db, int ndb,
+                                         const int32_t *off, const int32_t *cand, int32_t *best_idx,
+                                         int32_t *best_d, int32_t *second_d)
+{
+    if (!c || nq < 0 || ndb < 0 || (nq > 0 && (!q || !off || !best_idx || !best_d || !second_d)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2_lists: bad argument");
+    if (nq == 0) return ORBHIP_OK;
+    const int ncand = off[nq];
+    for (int i = 0; i < nq; i++)
+        if (off[i] > off[i + 1] || off[i] < 0) return fail(c, ORBHIP_E_ARG, "offsets must be non-decreasing");
+    for (int t = 0; t < ncand; t++)
+        if (cand[t] < 0 || cand[t] >= ndb) return fail(c, ORBHIP_E_ARG, "candidate index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)nq * 32 + (size_t)ndb * 32 + (size_t)nq * 16 + (size_t)ncand * 4 + 4096))) return rc;
+    uint8_t *dq = (uint8_t *)T.take((size_t)nq * 32), *ddb = (uint8_t *)T.take((size_t)ndb * 32 + 32);
+    int32_t *doff = (int32_t *)T.take((size_t)(nq + 1) * 4), *dcand = (int32_t *)T.take((size_t)ncand * 4 + 4);
+    int32_t *dbi = (int32_t *)T.take((size_t)nq * 4), *dbd = (int32_t *)T.take((size_t)nq * 4),
+            *dsd = (int32_t *)T.take((size_t)nq * 4);
+    HIPCHK(c, hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (ndb) HIPCHK(c, hipMemcpyAsync(ddb, db, (size_t)ndb * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(doff, off, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (ncand) HIPCHK(c, hipMemcpyAsync(dcand, cand, (size_t)ncand * 4, hipMemcpyHostToDevice, c->stream));
+    launch_knn2_lists(c->stream, dq, nq, ddb, doff, dcand, dbi, dbd, dsd);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(best_idx, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(best_d, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(second_d, dsd, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+
+// ORBmatcher::ComputeThreeMaxima, ref: src/ORBmatcher.cc:1629-1670
+static void three_maxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1, const uint8_t *valid1,
+                                    const float *angle1, const int32_t *node1, const int32_t *off1,
+                                    const int32_t *idx1, int ng1, const uint8_t *desc2, int n2,
+                                    const uint8_t *valid2, const float *angle2, const int32_t *node2,
+                                    const int32_t *off2, const int32_t *idx2, int ng2, int th, int th_mode,
+                                    float nnratio, int check_ori, int32_t *match12, int32_t *match21,
+                                    int *nmatches)
+{
+    if (!c || n1 < 0 || n2 < 0 || ng1 < 0 || ng2 < 0 || !match12 || !match21 || !nmatches ||
+        (n1 > 0 && (!desc1 || !valid1)) || (n2 > 0 && !desc2) || (check_ori && (!angle1 || !angle2)) ||
+        (ng1 > 0 && (!node1 || !off1 || !idx1)) || (ng2 > 0 && (!node2 || !off2 || !idx2)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_by_bow: bad argument");
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    for (int i = 0; i < n2; i++) match21[i] = -1;
+    *nmatches = 0;
+    if (n1 == 0 || n2 == 0 || ng1 == 0 || ng2 == 0) return ORBHIP_OK;
+    // merge walk over the two FeatureVectors (ref: :180-264): pairs of equal node ids
+    std::vector<int32_t> pairs;
+    {
+        int g1 = 0, g2 = 0;
+        while (g1 < ng1 && g2 < ng2) {
+            if (node1[g1] == node2[g2]) {
+                pairs.push_back(g1);
+                pairs.push_back(g2);
+                g1++;
+                g2++;
+            } else if (node1[g1] < node2[g2])
+                g1++;
+            else
+                g2++;
+        }
+    }
+    const int npairs = (int)pairs.size() / 2;
+    if (npairs == 0) return ORBHIP_OK;
+    const int m1 = off1[ng1], m2 = off2[ng2];
+    for (int t = 0; t < m1; t++)
+        if (idx1[t] < 0 || idx1[t] >= n1) return fail(c, ORBHIP_E_ARG, "idx1 out of range");
+    for (int t = 0; t < m2; t++)
+        if (idx2[t] < 0 || idx2[t] >= n2) return fail(c, ORBHIP_E_ARG, "idx2 out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    size_t total = (size_t)n1 * 33 + (size_t)n2 * 33 + (size_t)(ng1 + ng2 + 2) * 4 + (size_t)(m1 + m2) * 4 +
+                   pairs.size() * 4 + (size_t)(n1 + n2) * 4 + 16 * 256;
+    if ((rc = T.reserve(total))) return rc;
+    uint8_t *dd1 = (uint8_t *)T.take((size_t)n1 * 32), *dd2 = (uint8_t *)T.take((size_t)n2 * 32);
+    uint8_t *dv1 = (uint8_t *)T.take((size_t)n1), *dv2 = valid2 ? (uint8_t *)T.take((size_t)n2) : nullptr;
+    int32_t *do1 = (int32_t *)T.take((size_t)(ng1 + 1) * 4), *do2 = (int32_t *)T.take((size_t)(ng2 + 1) * 4);
+    int32_t *di1 = (int32_t *)T.take((size_t)m1 * 4 + 4), *di2 = (int32_t *)T.take((size_t)m2 * 4 + 4);
+    int32_t *dp = (int32_t *)T.take(pairs.size() * 4);
+    int32_t *dm12 = (int32_t *)T.take((size_t)n1 * 4), *dm21 = (int32_t *)T.take((size_t)n2 * 4);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dv1, valid1, (size_t)n1, hipMemcpyHostToDevice, s));
+    if (valid2) HIPCHK(c, hipMemcpyAsync(dv2, valid2, (size_t)n2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(do1, off1, (size_t)(ng1 + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(do2, off2, (size_t)(ng2 + 1) * 4, hipMemcpyHostToDevice, s));
+    if (m1) HIPCHK(c, hipMemcpyAsync(di1, idx1, (size_t)m1 * 4, hipMemcpyHostToDevice, s));
+    if (m2) HIPCHK(c, hipMemcpyAsync(di2, idx2, (size_t)m2 * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(dm12, 0xFF, (size_t)n1 * 4, s));
+    HIPCHK(c, hipMemsetAsync(dm21, 0xFF, (size_t)n2 * 4, s));
+    launch_bow_match(s, dd1, dv1, do1, di1, dd2, dv2, do2, di2, dp, npairs, th, th_mode, nnratio, dm12, dm21);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(match12, dm12, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(match21, dm21, (size_t)n2 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    // rotation consistency (ref: :236-246, :267-285): histogram in the reference's visiting order
+    int nm = 0;
+    std::vector<int> hist[30];
+    const float factor = 1.0f / 30;
+    for (int p = 0; p < npairs; p++) {
+        const int g1 = pairs[2 * p];
+        for (int a = off1[g1]; a < off1[g1 + 1]; a++) {
+            const int i1 = idx1[a];
+            const int i2 = match12[i1];
+            if (i2 < 0) continue;
+            nm++;
+            if (check_ori) {
+                float rot = angle1[i1] - angle2[i2];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == 30) bin = 0;
+                if (bin >= 0 && bin < 30) hist[bin].push_back(i1);
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(hist, 30, i1, i2, i3);
+        for (int i = 0; i < 30; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int a : hist[i]) {
+                match21[match12[a]] = -1;
+                match12[a] = -1;
+                nm--;
+            }
+        }
+    }
+    *nmatches = nm;
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL (loaded lazily so that the library has no hard link-time dependency on it)
+// ------------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } rccl_uid_t;
+typedef int (*fn_getuid)(rccl_uid_t *);
+typedef int (*fn_initrank)(void **, int, rccl_uid_t, int);
+typedef int (*fn_bcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_destroy)(void *);
+typedef const char *(*fn_errstr)(int);
+static struct {
+    void *h = nullptr;
+    fn_getuid getuid = nullptr;
+    fn_initrank initrank = nullptr;
+    fn_bcast bcast = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_errstr errstr = nullptr;
+} g_rccl;
+
+static bool rccl_load()
+{
+    if (g_rccl.h) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) return false;
+    g_rccl.getuid = (fn_getuid)dlsym(g_rccl.h, "ncclGetUniqueId");
+    g_rccl.initrank = (fn_initrank)dlsym(g_rccl.h, "ncclCommInitRank");
+    g_rccl.bcast = (fn_bcast)dlsym(g_rccl.h, "ncclBroadcast");
+    g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
+    g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
+    return g_rccl.getuid && g_rccl.initrank && g_rccl.bcast;
+}
+
+extern "C" int orbhip_comm_unique_id(uint8_t uid[128])
+{
+    if (!uid) return ORBHIP_E_ARG;
+    if (!rccl_load()) return fail(nullptr, ORBHIP_E_COMM, "cannot load librccl");
+    rccl_uid_t u;
+    int rc = g_rccl.getuid(&u);
+    if (rc != 0) return fail(nullptr, ORBHIP_E_COMM, "ncclGetUniqueId failed");
+    memcpy(uid, u.internal, 128);
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_comm_init(orbhip_ctx *c, int rank, int nranks, const uint8_t uid[128])
+{
+    if (!c || !uid || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, ORBHIP_E_ARG, "orbhip_comm_init: bad argument");
+    if (!rccl_load()) return fail(c, ORBHIP_E_COMM, "cannot load librccl");
+    HIPCHK(c, hipSetDevice(c->device));
+    rccl_uid_t u;
+    memcpy(u.internal, uid, 128);
+    int rc = g_rccl.initrank(&c->comm, nranks, u, rank);
+    if (rc != 0) return fail(c, ORBHIP_E_COMM, std::string("ncclCommInitRank: ") + (g_rccl.errstr ? g_rccl.errstr(rc) : "error"));
+    c->rank = rank;
+    c->nranks = nranks;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_bcast_blob_device(orbhip_ctx *c, void *d_buf, size_t nbytes, int root)
+{
+    if (!c || !d_buf) return fail(c, ORBHIP_E_ARG, "orbhip_bcast_blob_device: bad argument");
+    if (c->nranks == 1) return ORBHIP_OK;
+    if (!c->comm) return fail(c, ORBHIP_E_COMM, "orbhip_comm_init was not called");
+    HIPCHK(c, hipSetDevice(c->device));
+    // ncclChar = 0
+    int rc = g_rccl.bcast(d_buf, d_buf, nbytes, 0, root, c->comm, c->stream);
+    if (rc != 0) return fail(c, ORBHIP_E_COMM, std::string("ncclBroadcast: ") + (g_rccl.errstr ? g_rccl.errstr(rc) : "error"));
+    return ORBHIP_OK;
+}

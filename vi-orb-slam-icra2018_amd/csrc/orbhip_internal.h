@@ -1,0 +1,178 @@
+// orbhip_internal.h -- context, per-level geometry and kernel launch prototypes of liborbhip.so.
+// Host-side structures only; the kernels live in k_*.hip.
+#ifndef ORBHIP_INTERNAL_H
+#define ORBHIP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/orbhip.h"
+
+#define ORB_PATCH_SIZE 31      // ref: src/ORBextractor.cc:74
+#define ORB_HALF_PATCH 15      // :75
+#define ORB_EDGE_THRESHOLD 19  // :76
+#define ORB_MIN_BORDER 16      // EDGE_THRESHOLD-3, :775
+#define ORB_CELL_W 30          // :771
+
+#define FAST_TILE_CELLS 8      // cells of one cell-row handled by one FAST workgroup
+#define FAST_MAX_TILE_W 320    // LDS tile width bound (pixels incl. halo, before 16-B rounding)
+#define FAST_MAX_TILE_H 72     // LDS tile height bound (hCell + 6)
+
+// Geometry of one pyramid level, shared by host and device code (passed by value in kernel args).
+struct OrbLevel {
+    int w, h;           // level size (:1132-1133)
+    int stride;         // bytes between rows of the device level image
+    int nCols, nRows;   // cell grid (:783-786)
+    int wCell, hCell;   // :787-788
+    int cellCap;        // candidate slots per cell = ceil(wCell/2)*ceil(hCell/2)
+    int cellBase;       // index of this level's first cell in the per-frame cell arrays
+    int candBase;       // index of this level's first slot in the per-frame candidate array
+    int ptBase;         // index of this level's first entry in the per-frame compact point arrays
+    int ptCap;          // capacity of the compact point arrays for this level (= ncells*cellCap)
+    int N;              // mnFeaturesPerLevel[level] (:437-448)
+    int nIni;           // quadtree roots (:545)
+    float hX;           // :547
+    int regw, regh;     // maxBorder - minBorder
+    int kpCap;          // node-list capacity = max(N + 4, 4*nIni + 4)
+    int kpBase;         // index of this level's first entry in the per-frame level-keypoint array
+    float scale;        // mvScaleFactor[level]
+    float kpSize;       // (float)(int)(PATCH_SIZE*mvScaleFactor[level]) (:836)
+    unsigned long long imgOff;   // byte offset of this level inside one frame's pyramid block
+};
+
+struct OrbLevels {
+    int nlevels;
+    int iniTh, minTh;
+    int totalCells;     // cells per frame (all levels)
+    int totalCands;     // candidate slots per frame
+    int totalPts;       // compact point capacity per frame
+    int totalKps;       // sum of kpCap
+    int outCap;         // keypoints per frame in the output arrays
+    int umax[16];       // :456-471
+    int bstride0;       // row stride of level 0 inside the blurred-pyramid block
+    unsigned long long boff1;    // offset of levels >= 1 inside one frame's blurred block
+    OrbLevel lv[ORBHIP_MAX_LEVELS];
+};
+
+// One FAST workgroup's work: `ncells` consecutive cells starting at column c0 of cell-row `row`.
+struct FastTile {
+    short level, row, c0, ncells;
+};
+
+// One blur workgroup's work: 64x16 output tile.
+struct BlurTile {
+    short level, tx, ty, pad;
+};
+
+struct orbhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // constructor tables (E0)
+    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
+    double scaleFactor = 0;
+    float mvScaleFactor[ORBHIP_MAX_LEVELS], mvInvScaleFactor[ORBHIP_MAX_LEVELS];
+    float mvLevelSigma2[ORBHIP_MAX_LEVELS], mvInvLevelSigma2[ORBHIP_MAX_LEVELS];
+    int mnFeaturesPerLevel[ORBHIP_MAX_LEVELS];
+    int umax[16];
+
+    int max_w = 0, max_h = 0, max_batch = 0;
+
+    // geometry of the image size currently configured (rebuilt when w/h change)
+    int cur_w = 0, cur_h = 0;
+    OrbLevels G;
+    std::vector<FastTile> fastTiles;
+    std::vector<BlurTile> blurTiles;
+    size_t pyrFrameBytes = 0;      // bytes of one frame's levels 1..n-1 (level 0 separate)
+    size_t lvl0FrameBytes = 0;
+
+    // device buffers (sized for max_w x max_h x max_batch at create time)
+    uint8_t *d_lvl0 = nullptr;     // own copy of level 0 (host API)          [B][h][stride0]
+    uint8_t *d_pyr = nullptr;      // levels 1.. of every frame               [B][pyrFrameBytes]
+    uint8_t *d_blur = nullptr;     // blurred levels 0..                      [B][lvl0+pyr bytes]
+    uint32_t *d_cand = nullptr;    // candidate slots                         [B][totalCands]
+    uint16_t *d_cellCnt = nullptr; // per-cell counts                         [B][totalCells]
+    uint32_t *d_pts = nullptr;     // compact candidates                      [B][totalPts]
+    uint32_t *d_pnode = nullptr;   // quadtree scratch                        [B][totalPts]
+    int32_t *d_lvlCandCnt = nullptr; // candidates per (frame, level)         [B][16]
+    uint32_t *d_lvlKp = nullptr;   // quadtree winners (packed)               [B][totalKps]
+    int32_t *d_lvlKpCnt = nullptr; // winners per (frame, level)              [B][16]
+    float *d_lvlAngle = nullptr;   // orientation per winner                  [B][totalKps]
+    orbhip_keypoint *d_kps = nullptr; // output staging (host API)            [B][outCap]
+    uint8_t *d_desc = nullptr;     //                                          [B][outCap][32]
+    int32_t *d_counts = nullptr;   //                                          [B]
+    FastTile *d_fastTiles = nullptr;
+    BlurTile *d_blurTiles = nullptr;
+    int32_t *d_resizeTab = nullptr; // per level: x table [dw] int2, y table [dh] int4
+    size_t resizeTabOff[ORBHIP_MAX_LEVELS][2];
+    size_t cap_lvl0 = 0, cap_pyr = 0, cap_blur = 0, cap_cand = 0, cap_cells = 0, cap_pts = 0,
+           cap_kps = 0, cap_out = 0, cap_resize = 0, cap_fastTiles = 0, cap_blurTiles = 0,
+           cap_pnode = 0, cap_angle = 0, cap_cnt1 = 0, cap_cnt2 = 0, cap_cnt3 = 0;
+
+    // state of the last extract call
+    const uint8_t *last_lvl0 = nullptr;  // device pointer to level 0 of frame 0
+    int last_stride0 = 0;
+    size_t last_frame0 = 0;
+    int last_B = 0;
+
+    // pinned host staging for the host API
+    uint8_t *h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+
+    // matching scratch
+    void *d_match = nullptr;
+    size_t d_match_bytes = 0;
+
+    // timing
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool haveStageEvents = false, haveMatchEvents = false;
+
+    // RCCL
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+// ---- geometry (orb_geometry.hip) ----
+int orb_init_tables(orbhip_ctx *c, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh);
+void orb_level_size(const orbhip_ctx *c, int w, int h, int level, int *lw, int *lh);
+// Builds c->G, tiles and resize tables for a w x h image.  Returns ORBHIP_OK or an error.
+int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0);
+// Host-side resize tables for level `l` (dst) from level l-1 (src).
+void orb_build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t> &xtab,
+                             std::vector<int32_t> &ytab);
+
+// ---- kernel launchers ----
+void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, size_t sframe,
+                   uint8_t *dst, int dw, int dh, int dstride, size_t dframe, const int32_t *xtab,
+                   const int32_t *ytab, int B);
+void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
+                 const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
+                 uint32_t *cand, uint16_t *cellCnt, int B);
+void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, const uint16_t *cellCnt,
+                     uint32_t *pts, uint32_t *pnode, int32_t *lvlCandCnt, uint32_t *lvlKp,
+                     int32_t *lvlKpCnt, int B);
+void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
+                 const uint8_t *pyr, size_t pyrFrame, uint8_t *blur, size_t blurFrame,
+                 const BlurTile *tiles, int ntiles, int B);
+void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
+                     const uint8_t *pyr, size_t pyrFrame, const uint8_t *blur, size_t blurFrame,
+                     const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
+                     orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B);
+size_t quadtree_lds_bytes(const OrbLevels &G);
+
+void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int ndb, int32_t *best_idx,
+                 int32_t *best_d, int32_t *second_d, void *scratch, size_t scratch_bytes);
+size_t knn2_scratch_bytes(int nq, int ndb);
+void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, int cap, int B, int lag,
+                     int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+void launch_knn2_lists(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, const int32_t *off,
+                       const int32_t *cand, int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1, const int32_t *off1,
+                      const int32_t *idx1, const uint8_t *desc2, const uint8_t *valid2,
+                      const int32_t *off2, const int32_t *idx2, const int32_t *pairs, int npairs,
+                      int th, int th_mode, float nnratio, int32_t *match12, int32_t *match21);
+
+#endif

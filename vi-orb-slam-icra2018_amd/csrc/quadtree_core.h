@@ -1,0 +1,422 @@
+// quadtree_core.h -- data-parallel formulation of ORBextractor::DistributeOctTree
+// (reference: src/ORBextractor.cc:541-765, DivideNode :483-539).
+//
+// The reference walks a std::list and copies keypoint vectors around.  Here nothing moves:
+//   * every candidate keeps its position in the canonical candidate order (cells row-major,
+//     raster inside a cell) and only carries the list position of the node that owns it;
+//   * a "pass" (one trip of the reference's while loop, :596-741) is: count the points of the
+//     four children of every node that is being split (one atomic per point), then rebuild the
+//     node list with prefix sums so that it has exactly the order std::list would have after
+//     the push_front/erase sequence, then relabel the points;
+//   * the final phase (:675-739: expand the largest nodes first, stop as soon as the list has N
+//     nodes) splits all candidates speculatively, ranks them by (size desc, list position asc)
+//     and commits the prefix of that order up to the break point.  List position ascending is
+//     the canonical replacement for the reference's heap-address tie-break (later-created node
+//     = greater; later-created children sit nearer the list front) -- DESIGN.md "quadtree".
+//   * the per-node winner (:746-762, max response, first in vKeys order wins ties) is one
+//     atomicMax on (score, -candidate index), valid because DivideNode keeps vKeys in candidate
+//     order.
+//
+// The template parameter X supplies the execution model: QtBlock (one HIP workgroup, LDS
+// atomics, wave scans) in k_quadtree.hip, or QtSerial (one host thread) for the CPU test that
+// checks this formulation against the list-based oracle.  Every loop between two x.sync()
+// calls is a data-parallel loop, so the serial run is one legal schedule of the parallel one.
+#ifndef ORBHIP_QUADTREE_CORE_H
+#define ORBHIP_QUADTREE_CORE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define QT_HD __host__ __device__ __forceinline__
+#else
+#define QT_HD inline
+#endif
+
+// Candidate packing: x[0..11] | y[12..23] | score[24..31]; x,y relative to (16,16) of the level.
+#define QT_PACK(x, y, s) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(s) << 24))
+#define QT_X(p) ((int)((p)&0xFFFu))
+#define QT_Y(p) ((int)(((p) >> 12) & 0xFFFu))
+#define QT_S(p) ((int)((p) >> 24))
+
+struct QtParams {
+    int N;        // mnFeaturesPerLevel[level]
+    int nIni;     // :545
+    float hX;     // :547
+    int regw;     // maxX - minX
+    int regh;     // maxY - minY
+    int maxNodes; // capacity of the node arrays (>= max(N + 3, 4 * nIni))
+};
+
+// Working set of one (frame, level) problem.  All arrays have maxNodes entries unless noted.
+struct QtShared {
+    // current node list, in std::list order
+    short *ulx, *uly, *brx, *bry;
+    int *cnt;
+    // next node list (double buffer)
+    short *n_ulx, *n_uly, *n_brx, *n_bry;
+    int *n_cnt;
+    int *ccnt;     // [4 * maxNodes] child point counts of the pass
+    int *npos;     // new list position of a surviving node (or -1 when it is erased)
+    int *cpos;     // [4 * maxNodes] new list position of child q of node p (or -1)
+    int *scan;     // scan workspace
+    int *rank;     // careful phase: rank of candidate node p, -1 if not a candidate
+    int *order;    // careful phase: node at rank r
+    unsigned *best; // winner key per node
+    int *scal;     // [8] block-wide scalars
+};
+
+enum { QT_S_SIZE = 0, QT_S_NEXP = 1, QT_S_TOTAL = 2, QT_S_JSTAR = 3, QT_S_NEWCH = 4 };
+
+QT_HD int qt_ceil_half(int d)
+{
+    // ceil(static_cast<float>(d)/2), :485-486
+    return (d + 1) >> 1; // d >= 0 always (node extents never go negative)
+}
+
+// Bytes of QtShared storage needed for maxNodes nodes (shorts first, all 4-byte aligned).
+QT_HD size_t qt_shared_bytes(int maxNodes)
+{
+    size_t m = (size_t)((maxNodes + 1) & ~1);
+    return m * 2 * 8      // 8 short arrays
+           + m * 4 * 2    // cnt, n_cnt
+           + m * 4 * 4    // ccnt
+           + m * 4        // npos
+           + m * 4 * 4    // cpos
+           + (m + 8) * 4  // scan
+           + m * 4 * 2    // rank, order
+           + m * 4        // best
+           + 8 * 4;       // scal
+}
+
+QT_HD void qt_carve(QtShared &sh, void *base, int maxNodes)
+{
+    size_t m = (size_t)((maxNodes + 1) & ~1);
+    char *p = (char *)base;
+    sh.ulx = (short *)p; p += m * 2;
+    sh.uly = (short *)p; p += m * 2;
+    sh.brx = (short *)p; p += m * 2;
+    sh.bry = (short *)p; p += m * 2;
+    sh.n_ulx = (short *)p; p += m * 2;
+    sh.n_uly = (short *)p; p += m * 2;
+    sh.n_brx = (short *)p; p += m * 2;
+    sh.n_bry = (short *)p; p += m * 2;
+    sh.cnt = (int *)p; p += m * 4;
+    sh.n_cnt = (int *)p; p += m * 4;
+    sh.ccnt = (int *)p; p += m * 16;
+    sh.npos = (int *)p; p += m * 4;
+    sh.cpos = (int *)p; p += m * 16;
+    sh.scan = (int *)p; p += (m + 8) * 4;
+    sh.rank = (int *)p; p += m * 4;
+    sh.order = (int *)p; p += m * 4;
+    sh.best = (unsigned *)p; p += m * 4;
+    sh.scal = (int *)p;
+}
+
+// Quadrant of a point inside node (ulx,uly,brx,bry): 0=n1(UL) 1=n2(UR) 2=n3(BL) 3=n4(BR), :511-528
+QT_HD int qt_quadrant(int px, int py, int ulx, int uly, int brx, int bry)
+{
+    const int midx = ulx + qt_ceil_half(brx - ulx);
+    const int midy = uly + qt_ceil_half(bry - uly);
+    return (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+}
+
+QT_HD void qt_child_box(int q, int ulx, int uly, int brx, int bry, short &cx0, short &cy0, short &cx1,
+                        short &cy1)
+{
+    const int midx = ulx + qt_ceil_half(brx - ulx);
+    const int midy = uly + qt_ceil_half(bry - uly);
+    cx0 = (short)((q & 1) ? midx : ulx);
+    cx1 = (short)((q & 1) ? brx : midx);
+    cy0 = (short)((q & 2) ? midy : uly);
+    cy1 = (short)((q & 2) ? bry : midy);
+}
+
+// Runs the whole distribution for one (frame, level).
+//   pts[n]   packed candidates in canonical order (read only)
+//   pnode[n] scratch: list position of the owning node (bits 0..29) and quadrant (bits 30..31)
+//   out[]    packed winners in list order (capacity maxNodes)
+// Returns the number of winners (every thread gets the same value).
+template <class X>
+QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__restrict__ pts,
+                        uint32_t *__restrict__ pnode, QtShared &sh, uint32_t *__restrict__ out)
+{
+    const int M = P.maxNodes;
+    // ---- roots (:549-587): nIni nodes side by side, points by x/hX, empty roots erased ----
+    for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.ccnt[i] = 0;
+    x.sync();
+    for (int i = x.tid(); i < n; i += x.nth()) {
+        int r = (int)((float)QT_X(pts[i]) / P.hX);
+        r = r < 0 ? 0 : (r >= P.nIni ? P.nIni - 1 : r);
+        pnode[i] = (uint32_t)r;
+        x.atomic_add(&sh.ccnt[r], 1);
+    }
+    x.sync();
+    for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.scan[i] = sh.ccnt[i] > 0 ? 1 : 0;
+    x.sync();
+    int S = x.scan_exclusive(sh.scan, P.nIni); // sh.scan[i] = new position of root i
+    for (int i = x.tid(); i < P.nIni; i += x.nth()) {
+        if (sh.ccnt[i] > 0) {
+            const int s = sh.scan[i];
+            sh.ulx[s] = (short)(int)(P.hX * (float)i);
+            sh.uly[s] = 0;
+            sh.brx[s] = (short)(int)(P.hX * (float)(i + 1));
+            sh.bry[s] = (short)P.regh;
+            sh.cnt[s] = sh.ccnt[i];
+            sh.npos[i] = s;
+        } else
+            sh.npos[i] = -1;
+    }
+    x.sync();
+    for (int i = x.tid(); i < n; i += x.nth()) pnode[i] = (uint32_t)sh.npos[pnode[i]];
+    x.sync();
+
+    bool careful = false; // inside the final phase (:675-739)
+    for (int iter = 0; iter < 64; ++iter) {
+        // ---- which nodes are split candidates: every node holding more than one point ----
+        // (after a full pass, and after a completed careful pass, all such nodes are children
+        //  created by the previous pass, i.e. exactly vSizeAndPointerToNode)
+        for (int i = x.tid(); i < 4 * S; i += x.nth()) sh.ccnt[i] = 0;
+        x.sync();
+        // ---- children point counts (speculative for every candidate) ----
+        for (int i = x.tid(); i < n; i += x.nth()) {
+            const uint32_t pn = pnode[i] & 0x3FFFFFFFu;
+            if (sh.cnt[pn] > 1) {
+                const uint32_t pk = pts[i];
+                const int q = qt_quadrant(QT_X(pk), QT_Y(pk), sh.ulx[pn], sh.uly[pn], sh.brx[pn], sh.bry[pn]);
+                pnode[i] = pn | ((uint32_t)q << 30);
+                x.atomic_add(&sh.ccnt[4 * pn + q], 1);
+            }
+        }
+        x.sync();
+
+        int jstar = -1; // careful phase: last rank that is processed
+        int C = 0;      // number of candidates
+        if (!careful) {
+            // full pass: every candidate is split, in list order
+            // scan value packs (#non-empty children << 16) | (node survives unsplit)
+            for (int p = x.tid(); p < S; p += x.nth()) {
+                int v;
+                if (sh.cnt[p] > 1) {
+                    int nz = (sh.ccnt[4 * p] > 0) + (sh.ccnt[4 * p + 1] > 0) + (sh.ccnt[4 * p + 2] > 0) +
+                             (sh.ccnt[4 * p + 3] > 0);
+                    v = nz << 16;
+                } else
+                    v = 1;
+                sh.scan[p] = v;
+            }
+            x.sync();
+            const int tot = x.scan_exclusive(sh.scan, S);
+            const int totalCh = tot >> 16;
+            for (int p = x.tid(); p < S; p += x.nth()) {
+                const int pre = sh.scan[p];
+                if (sh.cnt[p] > 1) {
+                    int nz = (sh.ccnt[4 * p] > 0) + (sh.ccnt[4 * p + 1] > 0) + (sh.ccnt[4 * p + 2] > 0) +
+                             (sh.ccnt[4 * p + 3] > 0);
+                    // children of later-split nodes sit in front: suffix sum
+                    int base = totalCh - (pre >> 16) - nz;
+                    // within the node: n4 first ... n1 last
+                    int k = 0;
+                    for (int q = 3; q >= 0; --q) {
+                        if (sh.ccnt[4 * p + q] > 0)
+                            sh.cpos[4 * p + q] = base + k++;
+                        else
+                            sh.cpos[4 * p + q] = -1;
+                    }
+                    sh.npos[p] = -1;
+                } else {
+                    sh.npos[p] = totalCh + (pre & 0xFFFF);
+                }
+            }
+            x.sync();
+        } else {
+            // careful pass: rank candidates by (cnt desc, list position asc)
+            for (int p = x.tid(); p < S; p += x.nth()) sh.scan[p] = sh.cnt[p] > 1 ? 1 : 0;
+            x.sync();
+            C = x.scan_exclusive(sh.scan, S); // compact candidate index
+            for (int p = x.tid(); p < S; p += x.nth())
+                if (sh.cnt[p] > 1) sh.order[sh.scan[p]] = p; // temporarily: candidates in list order
+            x.sync();
+            for (int c = x.tid(); c < C; c += x.nth()) {
+                const int p = sh.order[c];
+                const int mycnt = sh.cnt[p];
+                int r = 0;
+                for (int d = 0; d < C; ++d) {
+                    const int pc = sh.cnt[sh.order[d]];
+                    r += (pc > mycnt) || (pc == mycnt && d < c);
+                }
+                sh.rank[p] = r;
+            }
+            x.sync();
+            // (the rank loops above read order[] of every candidate: rewrite it only after the sync)
+            for (int p = x.tid(); p < S; p += x.nth())
+                if (sh.cnt[p] > 1) sh.order[sh.rank[p]] = p; // node at rank r
+            x.sync();
+            // inclusive running size after processing rank r: S + sum_{i<=r} (nz_i - 1)
+            for (int r = x.tid(); r < C; r += x.nth()) {
+                const int p = sh.order[r];
+                int nz = (sh.ccnt[4 * p] > 0) + (sh.ccnt[4 * p + 1] > 0) + (sh.ccnt[4 * p + 2] > 0) +
+                         (sh.ccnt[4 * p + 3] > 0);
+                sh.scan[r] = nz;
+            }
+            if (x.tid() == 0) sh.scal[QT_S_JSTAR] = C - 1;
+            x.sync();
+            x.scan_exclusive(sh.scan, C); // scan[r] = sum_{i<r} nz_i
+            // first rank whose inclusive size reaches N (:732-733)
+            for (int r = x.tid(); r < C; r += x.nth()) {
+                const int p = sh.order[r];
+                int nz = (sh.ccnt[4 * p] > 0) + (sh.ccnt[4 * p + 1] > 0) + (sh.ccnt[4 * p + 2] > 0) +
+                         (sh.ccnt[4 * p + 3] > 0);
+                const int sizeAfter = S + (sh.scan[r] + nz) - (r + 1);
+                if (sizeAfter >= P.N) x.atomic_min(&sh.scal[QT_S_JSTAR], r);
+            }
+            x.sync();
+            jstar = sh.scal[QT_S_JSTAR];
+            x.sync();
+            // total children created = inclusive sum at jstar
+            if (x.tid() == 0) {
+                int tc = 0;
+                if (C > 0) {
+                    const int p = sh.order[jstar];
+                    int nz = (sh.ccnt[4 * p] > 0) + (sh.ccnt[4 * p + 1] > 0) + (sh.ccnt[4 * p + 2] > 0) +
+                             (sh.ccnt[4 * p + 3] > 0);
+                    tc = sh.scan[jstar] + nz;
+                }
+                sh.scal[QT_S_NEWCH] = tc;
+            }
+            x.sync();
+            const int totalCh = sh.scal[QT_S_NEWCH];
+            // children positions: later-processed nodes in front
+            for (int r = x.tid(); r < C; r += x.nth()) {
+                const int p = sh.order[r];
+                if (r <= jstar) {
+                    int nz = (sh.ccnt[4 * p] > 0) + (sh.ccnt[4 * p + 1] > 0) + (sh.ccnt[4 * p + 2] > 0) +
+                             (sh.ccnt[4 * p + 3] > 0);
+                    int base = totalCh - sh.scan[r] - nz;
+                    int k = 0;
+                    for (int q = 3; q >= 0; --q) {
+                        if (sh.ccnt[4 * p + q] > 0)
+                            sh.cpos[4 * p + q] = base + k++;
+                        else
+                            sh.cpos[4 * p + q] = -1;
+                    }
+                }
+            }
+            x.sync();
+            // surviving old nodes keep their relative order behind the new children
+            for (int p = x.tid(); p < S; p += x.nth()) {
+                const bool processed = sh.cnt[p] > 1 && sh.rank[p] <= jstar;
+                sh.npos[p] = processed ? -1 : 0; // mark
+            }
+            x.sync();
+            for (int p = x.tid(); p < S; p += x.nth()) sh.scan[p] = sh.npos[p] < 0 ? 0 : 1;
+            x.sync();
+            x.scan_exclusive(sh.scan, S);
+            for (int p = x.tid(); p < S; p += x.nth())
+                if (sh.npos[p] >= 0) sh.npos[p] = totalCh + sh.scan[p];
+            x.sync();
+        }
+
+        // ---- build the next list ----
+        if (x.tid() == 0) {
+            sh.scal[QT_S_SIZE] = 0;
+            sh.scal[QT_S_NEXP] = 0;
+        }
+        x.sync();
+        for (int p = x.tid(); p < S; p += x.nth()) {
+            if (sh.npos[p] >= 0) {
+                const int s = sh.npos[p];
+                sh.n_ulx[s] = sh.ulx[p];
+                sh.n_uly[s] = sh.uly[p];
+                sh.n_brx[s] = sh.brx[p];
+                sh.n_bry[s] = sh.bry[p];
+                sh.n_cnt[s] = sh.cnt[p];
+                x.atomic_add(&sh.scal[QT_S_SIZE], 1);
+            } else {
+                int nexp = 0, created = 0;
+                for (int q = 0; q < 4; ++q) {
+                    const int s = sh.cpos[4 * p + q];
+                    if (s < 0) continue;
+                    qt_child_box(q, sh.ulx[p], sh.uly[p], sh.brx[p], sh.bry[p], sh.n_ulx[s], sh.n_uly[s],
+                                 sh.n_brx[s], sh.n_bry[s]);
+                    sh.n_cnt[s] = sh.ccnt[4 * p + q];
+                    created++;
+                    nexp += sh.ccnt[4 * p + q] > 1;
+                }
+                x.atomic_add(&sh.scal[QT_S_SIZE], created);
+                x.atomic_add(&sh.scal[QT_S_NEXP], nexp);
+            }
+        }
+        x.sync();
+        // ---- relabel the points ----
+        for (int i = x.tid(); i < n; i += x.nth()) {
+            const uint32_t v = pnode[i];
+            const uint32_t pn = v & 0x3FFFFFFFu;
+            const int np = sh.npos[pn];
+            pnode[i] = (uint32_t)(np >= 0 ? np : sh.cpos[4 * pn + (v >> 30)]);
+        }
+        const int newS = sh.scal[QT_S_SIZE];
+        const int nToExpand = sh.scal[QT_S_NEXP];
+        x.sync();
+        // swap list buffers
+        {
+            short *t;
+            int *ti;
+            t = sh.ulx; sh.ulx = sh.n_ulx; sh.n_ulx = t;
+            t = sh.uly; sh.uly = sh.n_uly; sh.n_uly = t;
+            t = sh.brx; sh.brx = sh.n_brx; sh.n_brx = t;
+            t = sh.bry; sh.bry = sh.n_bry; sh.n_bry = t;
+            ti = sh.cnt; sh.cnt = sh.n_cnt; sh.n_cnt = ti;
+        }
+        const int prevS = S;
+        S = newS;
+        // ---- loop control (:665-673, :736-737) ----
+        if (S >= P.N || S == prevS) break;
+        if (!careful && S + nToExpand * 3 > P.N) careful = true;
+        (void)M;
+    }
+
+    // ---- winners (:743-764) ----
+    for (int s = x.tid(); s < S; s += x.nth()) sh.best[s] = 0u;
+    x.sync();
+    for (int i = x.tid(); i < n; i += x.nth()) {
+        const uint32_t key = ((uint32_t)QT_S(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i);
+        x.atomic_max(&sh.best[pnode[i] & 0x3FFFFFFFu], key);
+    }
+    x.sync();
+    for (int s = x.tid(); s < S; s += x.nth()) out[s] = pts[0xFFFFFFu - (sh.best[s] & 0xFFFFFFu)];
+    x.sync();
+    return S;
+}
+
+// Serial execution model for the host-side check of the formulation.
+struct QtSerial {
+    QT_HD int tid() const { return 0; }
+    QT_HD int nth() const { return 1; }
+    QT_HD void sync() const {}
+    QT_HD int atomic_add(int *p, int v) const
+    {
+        int o = *p;
+        *p = o + v;
+        return o;
+    }
+    QT_HD void atomic_min(int *p, int v) const
+    {
+        if (v < *p) *p = v;
+    }
+    QT_HD void atomic_max(unsigned *p, unsigned v) const
+    {
+        if (v > *p) *p = v;
+    }
+    QT_HD int scan_exclusive(int *a, int n) const
+    {
+        int s = 0;
+        for (int i = 0; i < n; ++i) {
+            int v = a[i];
+            a[i] = s;
+            s += v;
+        }
+        return s;
+    }
+};
+
+#endif // ORBHIP_QUADTREE_CORE_H

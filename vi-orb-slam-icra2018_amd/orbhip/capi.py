@@ -1,0 +1,106 @@
+"""ctypes binding of liborbhip.so (the C ABI in include/orbhip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is
+no Python/CPU fallback for any compute step.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+LIB_PATH = os.path.join(CSRC, "liborbhip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+MAX_LEVELS = 16
+
+# every symbol include/orbhip.h declares
+SYMBOLS = [
+    "orbhip_device_count", "orbhip_create", "orbhip_destroy", "orbhip_last_error", "orbhip_sync",
+    "orbhip_stream", "orbhip_get_tables", "orbhip_max_keypoints", "orbhip_level_size",
+    "orbhip_extract", "orbhip_extract_batch", "orbhip_extract_batch_device",
+    "orbhip_get_pyramid_level", "orbhip_debug_get_blurred_level", "orbhip_debug_get_candidates",
+    "orbhip_debug_get_level_keypoints", "orbhip_hamming_knn2", "orbhip_hamming_knn2_device",
+    "orbhip_hamming_knn2_seq_device", "orbhip_get_stage_times",
+    "orbhip_hamming_knn2_lists", "orbhip_search_by_bow", "orbhip_comm_unique_id",
+    "orbhip_comm_init", "orbhip_bcast_blob_device",
+]
+
+
+class OrbHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load liborbhip.so and declare the prototypes.  Raises OrbHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbHipError("liborbhip.so is not built (%s); run __graft_entry__.build() or "
+                          "`make -C vi-orb-slam-icra2018_amd/csrc`" % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise OrbHipError("cannot load %s: %s" % (LIB_PATH, e))
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    ip = C.POINTER(C.c_int)
+    L.orbhip_device_count.restype = i32
+    L.orbhip_create.argtypes = [i32, i32, f32, i32, i32, i32, i32, i32, i32]
+    L.orbhip_create.restype = vp
+    L.orbhip_destroy.argtypes = [vp]
+    L.orbhip_destroy.restype = None
+    L.orbhip_last_error.argtypes = [vp]
+    L.orbhip_last_error.restype = C.c_char_p
+    L.orbhip_sync.argtypes = [vp]
+    L.orbhip_stream.argtypes = [vp]
+    L.orbhip_stream.restype = vp
+    L.orbhip_get_tables.argtypes = [vp, ip, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp]
+    L.orbhip_max_keypoints.argtypes = [vp]
+    L.orbhip_level_size.argtypes = [vp, i32, i32, i32, ip, ip]
+    L.orbhip_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, ip, vp]
+    L.orbhip_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.orbhip_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, C.c_size_t, vp, vp, i32, vp]
+    L.orbhip_get_pyramid_level.argtypes = [vp, i32, i32, vp, i32, ip, ip]
+    L.orbhip_debug_get_blurred_level.argtypes = [vp, i32, i32, vp, i32, ip, ip]
+    L.orbhip_debug_get_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
+    L.orbhip_debug_get_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]
+    L.orbhip_hamming_knn2.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    L.orbhip_hamming_knn2_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    L.orbhip_hamming_knn2_seq_device.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.orbhip_get_stage_times.argtypes = [vp, vp]
+    L.orbhip_hamming_knn2_lists.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.orbhip_search_by_bow.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32,
+                                       vp, i32, vp, vp, vp, vp, vp, i32,
+                                       i32, i32, f32, i32, vp, vp, ip]
+    L.orbhip_comm_unique_id.argtypes = [vp]
+    L.orbhip_comm_init.argtypes = [vp, i32, i32, vp]
+    L.orbhip_bcast_blob_device.argtypes = [vp, vp, C.c_size_t, i32]
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names from SYMBOLS that the built library actually exports (no GPU needed)."""
+    L = C.CDLL(LIB_PATH)
+    return [s for s in SYMBOLS if hasattr(L, s)]
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def last_error(ctx=None):
+    s = load().orbhip_last_error(ctx)
+    return s.decode() if s else ""
+
+
+def check(rc, ctx=None, what=""):
+    if rc != 0:
+        raise OrbHipError("%s failed (%d): %s" % (what, rc, last_error(ctx)))

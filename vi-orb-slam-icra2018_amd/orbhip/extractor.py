@@ -1,0 +1,235 @@
+"""Python mirror of the reference's operator interface for the hot path, over the C ABI.
+
+ORBextractor mirrors include/ORBextractor.h:69-103 (constructor arguments, operator(), the scale
+getters, the three timing getters and mvImagePyramid); ORBmatcher mirrors the in-scope part of
+include/ORBmatcher.h:41-89 (DescriptorDistance applied to sets, SearchByBoW, TH_LOW/TH_HIGH/
+HISTO_LENGTH).  The real drop-in classes are C++ (include/orbhip/); these wrappers exist so that
+the parity tests and bench.py read like the reference's own call sites.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import CAND_DTYPE, KP_DTYPE, OrbHipError, _p, check
+
+
+class ORBextractor:
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7,
+                 max_w=1280, max_h=720, max_batch=1, device=0):
+        self._L = capi.load()
+        self._h = self._L.orbhip_create(device, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
+                                        max_w, max_h, max_batch)
+        if not self._h:
+            raise OrbHipError("orbhip_create: " + capi.last_error(None))
+        self.nfeatures, self.nlevels, self.max_batch = nfeatures, nlevels, max_batch
+        self.cap = self._L.orbhip_max_keypoints(self._h)
+        self._timings = (C.c_float * 3)()
+        self._shape = None
+        n = C.c_int()
+        sf = C.c_double()
+        arr = [np.zeros(nlevels, np.float32) for _ in range(4)]
+        per = np.zeros(nlevels, np.int32)
+        um = np.zeros(16, np.int32)
+        check(self._L.orbhip_get_tables(self._h, C.byref(n), C.byref(sf), _p(arr[0]), _p(arr[1]), _p(arr[2]),
+                                        _p(arr[3]), _p(per), _p(um)), self._h, "orbhip_get_tables")
+        self.scaleFactor = sf.value
+        self.mvScaleFactor, self.mvInvScaleFactor, self.mvLevelSigma2, self.mvInvLevelSigma2 = arr
+        self.mnFeaturesPerLevel, self.umax = per, um
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- getters of include/ORBextractor.h:81-101, :51-53 --
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return float(np.float32(self.scaleFactor))
+
+    def GetScaleFactors(self):
+        return self.mvScaleFactor.copy()
+
+    def GetInverseScaleFactors(self):
+        return self.mvInvScaleFactor.copy()
+
+    def GetScaleSigmaSquares(self):
+        return self.mvLevelSigma2.copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self.mvInvLevelSigma2.copy()
+
+    def GetTimeOfComputePyramid(self):
+        return float(self._timings[0])
+
+    def GetTimeOfComputeKeyPointsOctTree(self):
+        return float(self._timings[1])
+
+    def GetTImeOfComputeDescriptor(self):   # sic, include/ORBextractor.h:53
+        return float(self._timings[2])
+
+    # -- operator() --
+    def __call__(self, image):
+        """(keypoints, descriptors) of one 8-bit image; keypoints as KP_DTYPE records."""
+        if image is None or image.size == 0:
+            return np.empty(0, KP_DTYPE), np.empty((0, 32), np.uint8)   # silent return, :1048-1049
+        img = np.ascontiguousarray(image, np.uint8)
+        assert img.ndim == 2, "CV_8UC1 expected (src/ORBextractor.cc:1052)"
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int()
+        check(self._L.orbhip_extract(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps),
+                                     _p(desc), self.cap, C.byref(n), self._timings), self._h, "orbhip_extract")
+        self._shape = img.shape
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """images: (B, H, W) uint8.  Returns lists of per-frame keypoints and descriptors."""
+        imgs = np.ascontiguousarray(images, np.uint8)
+        B, H, W = imgs.shape
+        ptrs = (C.c_void_p * B)(*[imgs[b].ctypes.data for b in range(B)])
+        kps = np.zeros((B, self.cap), KP_DTYPE)
+        desc = np.zeros((B, self.cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        check(self._L.orbhip_extract_batch(self._h, ptrs, B, W, H, imgs.strides[1], _p(kps), _p(desc), self.cap,
+                                           _p(n)), self._h, "orbhip_extract_batch")
+        self._shape = (H, W)
+        return [kps[b, :n[b]].copy() for b in range(B)], [desc[b, :n[b]].copy() for b in range(B)]
+
+    def extract_batch_device(self, d_imgs, B, W, H, stride, frame_stride, d_kps, d_desc, cap, d_counts):
+        """Everything resident on the device (raw pointers as ints); asynchronous."""
+        check(self._L.orbhip_extract_batch_device(self._h, d_imgs, B, W, H, stride, frame_stride, d_kps, d_desc,
+                                                  cap, d_counts), self._h, "orbhip_extract_batch_device")
+        self._shape = (H, W)
+
+    def sync(self):
+        check(self._L.orbhip_sync(self._h), self._h, "orbhip_sync")
+
+    def stream(self):
+        return self._L.orbhip_stream(self._h)
+
+    # -- mvImagePyramid (include/ORBextractor.h:103) and stage read-back --
+    def _level(self, fn, level, frame):
+        w, h = C.c_int(), C.c_int()
+        check(fn(self._h, frame, level, None, 0, C.byref(w), C.byref(h)), self._h, "level size")
+        out = np.empty((h.value, w.value), np.uint8)
+        check(fn(self._h, frame, level, _p(out), w.value, C.byref(w), C.byref(h)), self._h, "level copy")
+        return out
+
+    def image_pyramid(self, level, frame=0):
+        return self._level(self._L.orbhip_get_pyramid_level, level, frame)
+
+    @property
+    def mvImagePyramid(self):
+        return [self.image_pyramid(l) for l in range(self.nlevels)]
+
+    def blurred(self, level, frame=0):
+        return self._level(self._L.orbhip_debug_get_blurred_level, level, frame)
+
+    def level_candidates(self, level, frame=0):
+        n = C.c_int()
+        check(self._L.orbhip_debug_get_candidates(self._h, frame, level, None, 0, C.byref(n)), self._h, "cands")
+        out = np.zeros(max(n.value, 1), CAND_DTYPE)
+        check(self._L.orbhip_debug_get_candidates(self._h, frame, level, _p(out), len(out), C.byref(n)), self._h,
+              "cands")
+        return out[:n.value].copy()
+
+    def level_keypoints(self, level, frame=0):
+        n = C.c_int()
+        check(self._L.orbhip_debug_get_level_keypoints(self._h, frame, level, None, 0, C.byref(n)), self._h, "lkps")
+        out = np.zeros(max(n.value, 1), KP_DTYPE)
+        check(self._L.orbhip_debug_get_level_keypoints(self._h, frame, level, _p(out), len(out), C.byref(n)),
+              self._h, "lkps")
+        return out[:n.value].copy()
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int(), C.c_int()
+        check(self._L.orbhip_level_size(self._h, w, h, level, C.byref(lw), C.byref(lh)), self._h, "level_size")
+        return lw.value, lh.value
+
+    @property
+    def handle(self):
+        return self._h
+
+
+class ORBmatcher:
+    TH_LOW = 50          # src/ORBmatcher.cc:38
+    TH_HIGH = 100        # :37
+    HISTO_LENGTH = 30    # :39
+
+    def __init__(self, nnratio=0.6, checkOri=True, ctx=None):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self._own = None
+        if ctx is None:
+            # matching needs a device context; a tiny extractor context provides stream + scratch
+            self._own = ORBextractor(max_w=128, max_h=128, nfeatures=50, nlevels=1)
+            ctx = self._own
+        self._ctx = ctx
+        self._L = capi.load()
+
+    def close(self):
+        if self._own is not None:
+            self._own.close()
+            self._own = None
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """Single pair, host popcount (the static member is a scalar helper in the reference too)."""
+        a = np.ascontiguousarray(a, np.uint8).reshape(32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(32)
+        return int(np.unpackbits(a ^ b).sum())
+
+    def knn2(self, q, db):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        db = np.ascontiguousarray(db, np.uint8).reshape(-1, 32)
+        bi = np.empty(len(q), np.int32)
+        bd = np.empty(len(q), np.int32)
+        sd = np.empty(len(q), np.int32)
+        check(self._L.orbhip_hamming_knn2(self._ctx.handle, _p(q), len(q), _p(db), len(db), _p(bi), _p(bd), _p(sd)),
+              self._ctx.handle, "orbhip_hamming_knn2")
+        return bi, bd, sd
+
+    def knn2_lists(self, q, db, off, cand):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        db = np.ascontiguousarray(db, np.uint8).reshape(-1, 32)
+        off = np.ascontiguousarray(off, np.int32)
+        cand = np.ascontiguousarray(cand, np.int32)
+        bi = np.empty(len(q), np.int32)
+        bd = np.empty(len(q), np.int32)
+        sd = np.empty(len(q), np.int32)
+        check(self._L.orbhip_hamming_knn2_lists(self._ctx.handle, _p(q), len(q), _p(db), len(db), _p(off), _p(cand),
+                                                _p(bi), _p(bd), _p(sd)), self._ctx.handle, "orbhip_hamming_knn2_lists")
+        return bi, bd, sd
+
+    def SearchByBoW(self, desc1, valid1, angle1, fv1, desc2, valid2, angle2, fv2, kf_kf=False):
+        """fv = (node_ids, offsets, indices) CSR FeatureVectors.  kf_kf=False: SearchByBoW(KeyFrame*,
+        Frame&) (:159-288); True: SearchByBoW(KeyFrame*, KeyFrame*) (:522-655).
+        Returns (nmatches, match12, match21)."""
+        desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+        desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        n1, n2 = len(desc1), len(desc2)
+        valid1 = np.ascontiguousarray(valid1, np.uint8)
+        valid2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        angle1 = np.ascontiguousarray(angle1, np.float32)
+        angle2 = np.ascontiguousarray(angle2, np.float32)
+        g1 = [np.ascontiguousarray(a, np.int32) for a in fv1]
+        g2 = [np.ascontiguousarray(a, np.int32) for a in fv2]
+        m12 = np.empty(max(n1, 1), np.int32)
+        m21 = np.empty(max(n2, 1), np.int32)
+        nm = C.c_int()
+        check(self._L.orbhip_search_by_bow(self._ctx.handle, _p(desc1), n1, _p(valid1), _p(angle1), _p(g1[0]), _p(g1[1]),
+                                           _p(g1[2]), len(g1[0]), _p(desc2), n2, _p(valid2), _p(angle2), _p(g2[0]),
+                                           _p(g2[1]), _p(g2[2]), len(g2[0]), self.TH_LOW, 1 if kf_kf else 0,
+                                           self.mfNNratio, 1 if self.mbCheckOrientation else 0, _p(m12), _p(m21),
+                                           C.byref(nm)), self._ctx.handle, "orbhip_search_by_bow")
+        return nm.value, m12[:n1].copy(), m21[:n2].copy()
