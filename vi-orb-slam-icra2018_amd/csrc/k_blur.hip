@@ -6,16 +6,23 @@
 // Rounding of the column pass follows the x86-64 (SSE2) build of OpenCV 2.4 that the reference
 // links: for x < w - w%4 the 32s->8u symmetric column filter accumulates in float and converts
 // with cvtps2dq (round half to EVEN); the scalar tail uses (sum + 32768) >> 16 (half UP).  All
-// float products/sums here are exact below 256, so the float path is evaluated as an integer
+// float products/sums there are exact below 256, so the float path is evaluated as an integer
 // tie-break rule -- DESIGN.md "blur".
 //
-// One 256-thread workgroup per 64x16 output tile: raw (70x22) -> LDS, row pass -> LDS int32
-// (64x22), column pass -> one dword store per thread.  Bound: HBM (read + write one byte per
-// pixel).
+// One 256-thread workgroup per 128x32 output tile:
+//   1. raw rows y0-3 .. y0+34 (reflected at the top/bottom), columns x0-16 .. x0+143, into LDS with
+//      16-byte row-coalesced loads; at the left/right image edge the 3 reflected columns are
+//      patched into the halo;
+//   2. row pass: a thread produces 4 adjacent sums from 3 aligned LDS dwords; the sums are at most
+//      257*255 = 65535 and are kept as u16 pairs in LDS;
+//   3. column pass: a thread produces 4 adjacent outputs (one dword store).
+// Bound: HBM (reads and writes one byte per pixel; halo re-reads 38/32 x 160/128).
 #include "orbhip_internal.h"
 
-#define BT_W 64
-#define BT_H 16
+#define BT_W BLUR_TILE_W
+#define BT_H BLUR_TILE_H
+#define BT_RAWP (BT_W + 32)       // raw pitch: 16 halo bytes each side (16-byte aligned chunks)
+#define BT_ROWS (BT_H + 6)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -31,8 +38,8 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
                                               uint8_t *__restrict__ blur, unsigned long long blurFrame,
                                               const BlurTile *__restrict__ tiles, int4 kq)
 {
-    __shared__ uint8_t s_raw[BT_H + 6][BT_W + 8];
-    __shared__ int s_row[BT_H + 6][BT_W];
+    __shared__ __align__(16) uint8_t s_raw[BT_ROWS][BT_RAWP];
+    __shared__ __align__(16) uint16_t s_row[BT_ROWS][BT_W];
     const BlurTile T = tiles[blockIdx.x];
     const int frame = blockIdx.y, l = T.level;
     const OrbLevel &L = G.lv[l];
@@ -51,40 +58,92 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
     const int x0 = T.tx * BT_W, y0 = T.ty * BT_H;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        const int r = i / (BT_W + 6), c = i - r * (BT_W + 6);
+    // ---- 1. raw tile: LDS column j <-> image column x0 - 16 + j ----
+    const int wAl = (w + 15) & ~15;   // bytes of a row that may be read with 16-byte loads
+    for (int i = tid; i < BT_ROWS * (BT_RAWP / 16); i += 256) {
+        const int r = i / (BT_RAWP / 16), c = i - r * (BT_RAWP / 16);
         const int sy = reflect101(min(y0 - 3 + r, h + 2), h);
-        const int sx = reflect101(min(x0 - 3 + c, w + 2), w);
-        s_raw[r][c] = src[(size_t)sy * sstride + sx];
+        const int sx = x0 - 16 + (c << 4);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (sx >= 0 && sx < wAl) v = *reinterpret_cast<const uint4 *>(src + (size_t)sy * sstride + sx);
+        *reinterpret_cast<uint4 *>(&s_raw[r][c << 4]) = v;
     }
     __syncthreads();
+    // reflected halo columns at the image edges (x = -1,-2,-3 <- 1,2,3 ; x = w,w+1,w+2 <- w-2,w-3,w-4)
+    if (x0 == 0) {
+        for (int i = tid; i < BT_ROWS * 3; i += 256) {
+            const int r = i / 3, k = i - r * 3 + 1;
+            s_raw[r][16 - k] = s_raw[r][16 + k];
+        }
+    }
+    if (x0 + BT_W + 3 > w) {
+        for (int i = tid; i < BT_ROWS * 3; i += 256) {
+            const int r = i / 3, k = i - r * 3;
+            s_raw[r][16 + (w + k - x0)] = s_raw[r][16 + (w - 2 - k - x0)];
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. row pass: 4 sums per thread from bytes j-3 .. j+6 ----
     const int k0 = kq.x, k1 = kq.y, k2 = kq.z, k3 = kq.w;  // 18 34 49 55
-    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t *p = &s_raw[r][c];
-        s_row[r][c] = k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3];
+    for (int i = tid; i < BT_ROWS * (BT_W / 4); i += 256) {
+        const int r = i >> 5, g = i & 31;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(&s_raw[r][16 + (g << 2)]);
+        const uint32_t A = p[-1], Bw = p[0], C = p[1];
+        // bytes x-3..x+6 as b[0..9]
+        int b[10];
+        b[0] = (A >> 8) & 0xFF;
+        b[1] = (A >> 16) & 0xFF;
+        b[2] = A >> 24;
+        b[3] = Bw & 0xFF;
+        b[4] = (Bw >> 8) & 0xFF;
+        b[5] = (Bw >> 16) & 0xFF;
+        b[6] = Bw >> 24;
+        b[7] = C & 0xFF;
+        b[8] = (C >> 8) & 0xFF;
+        b[9] = (C >> 16) & 0xFF;
+        uint32_t s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            s[k] = (uint32_t)(k0 * (b[k] + b[k + 6]) + k1 * (b[k + 1] + b[k + 5]) + k2 * (b[k + 2] + b[k + 4]) +
+                              k3 * b[k + 3]);
+        uint2 o;
+        o.x = s[0] | (s[1] << 16);
+        o.y = s[2] | (s[3] << 16);
+        *reinterpret_cast<uint2 *>(&s_row[r][g << 2]) = o;
     }
     __syncthreads();
-    const int r = tid >> 4, cb = (tid & 15) << 2;
-    const int y = y0 + r;
-    if (y >= h) return;
+
+    // ---- 3. column pass ----
     const int wvec = w - (w & 3);
-    uint32_t packed = 0;
+    for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
+        const int r = i >> 5, g = i & 31;
+        const int y = y0 + r, xb = x0 + (g << 2);
+        if (y >= h || xb >= w) continue;
+        uint2 q[7];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int c = cb + k, x = x0 + c;
-        const int s = k0 * (s_row[r][c] + s_row[r + 6][c]) + k1 * (s_row[r + 1][c] + s_row[r + 5][c]) +
-                      k2 * (s_row[r + 2][c] + s_row[r + 4][c]) + k3 * s_row[r + 3][c];
-        int v = (s + 32768) >> 16;                                   // round half up
-        if (x < wvec && (s & 0xFFFF) == 0x8000 && (v & 1)) v -= 1;   // SSE2 body: ties to even
-        v = v > 255 ? 255 : v;
-        packed |= (uint32_t)v << (8 * k);
+        for (int j = 0; j < 7; j++) q[j] = *reinterpret_cast<const uint2 *>(&s_row[r + j][g << 2]);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int v7[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const uint32_t wd = (k < 2) ? q[j].x : q[j].y;
+                v7[j] = (k & 1) ? (int)(wd >> 16) : (int)(wd & 0xFFFF);
+            }
+            const int s = k0 * (v7[0] + v7[6]) + k1 * (v7[1] + v7[5]) + k2 * (v7[2] + v7[4]) + k3 * v7[3];
+            int v = (s + 32768) >> 16;                                        // round half up
+            if (xb + k < wvec && (s & 0xFFFF) == 0x8000 && (v & 1)) v -= 1;   // SSE2 body: ties to even
+            v = v > 255 ? 255 : v;
+            packed |= (uint32_t)v << (8 * k);
+        }
+        uint8_t *o = dst + (size_t)y * dstride + xb;
+        if (xb + 3 < w)
+            *reinterpret_cast<uint32_t *>(o) = packed;
+        else
+            for (int k = 0; k < 4 && xb + k < w; k++) o[k] = (uint8_t)(packed >> (8 * k));
     }
-    uint8_t *o = dst + (size_t)y * dstride + x0 + cb;
-    if (x0 + cb + 3 < w)
-        *reinterpret_cast<uint32_t *>(o) = packed;
-    else
-        for (int k = 0; k < 4 && x0 + cb + k < w; k++) o[k] = (uint8_t)(packed >> (8 * k));
 }
 
 // cv::getGaussianKernel(7, 2, CV_32F) converted to CV_32S with scale 256 (filter.cpp

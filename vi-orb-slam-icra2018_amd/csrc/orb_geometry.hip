@@ -171,8 +171,8 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
                 t.ncells = (short)std::min(tileCells, L.nCols - j);
                 c->fastTiles.push_back(t);
             }
-        for (int ty = 0; ty < (L.h + 15) / 16; ty++)
-            for (int tx = 0; tx < (L.w + 63) / 64; tx++) {
+        for (int ty = 0; ty < (L.h + BLUR_TILE_H - 1) / BLUR_TILE_H; ty++)
+            for (int tx = 0; tx < (L.w + BLUR_TILE_W - 1) / BLUR_TILE_W; tx++) {
                 BlurTile t;
                 t.level = (short)l;
                 t.tx = (short)tx;

@@ -61,7 +61,9 @@ struct FastTile {
     short level, row, c0, ncells;
 };
 
-// One blur workgroup's work: 64x16 output tile.
+// One blur workgroup's work: BLUR_TILE_W x BLUR_TILE_H output tile.
+#define BLUR_TILE_W 128
+#define BLUR_TILE_H 32
 struct BlurTile {
     short level, tx, ty, pad;
 };
