@@ -79,6 +79,12 @@ void *orbhip_stream(orbhip_ctx *ctx);
 int orbhip_get_tables(const orbhip_ctx *ctx, int *nlevels, double *scaleFactor, float *mvScaleFactor,
                       float *mvInvScaleFactor, float *mvLevelSigma2, float *mvInvLevelSigma2,
                       int *mnFeaturesPerLevel, int *umax);
+/* The same tables without a context or a device (pure host arithmetic of
+ * src/ORBextractor.cc:417-471), for constructing the C++ class before the first image arrives.
+ * Arrays need nlevels entries (umax: 16); any output pointer may be NULL. */
+int orbhip_tables(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                  float *mvScaleFactor, float *mvInvScaleFactor, float *mvLevelSigma2,
+                  float *mvInvLevelSigma2, int *mnFeaturesPerLevel, int *umax);
 /* Upper bound on keypoints per frame (nfeatures plus the quadtree's overshoot); use as `cap`. */
 int orbhip_max_keypoints(const orbhip_ctx *ctx);
 /* Size of pyramid level `level` for a w x h input (src/ORBextractor.cc:1132-1133). */

@@ -1,0 +1,67 @@
+// ORBmatcher.h -- drop-in replacement of the in-scope part of the reference's
+// include/ORBmatcher.h:41-89: same class name, namespace, constructor, constants, static
+// DescriptorDistance and both SearchByBoW overloads.  The Hamming work of SearchByBoW runs in
+// liborbhip.so (k_bow_match, one wave per shared vocabulary node).
+//
+// The nine guided-search routines of the reference (SearchByProjection x4, SearchForInitialization,
+// SearchForTriangulation, SearchBySim3, Fuse x2) are pose/projection logic around the same
+// best/second-best primitive; they stay in the reference's own ORBmatcher.cc (SURVEY.md section 8a,
+// row M3 / section 8f row 3) and can call orbhip_hamming_knn2_lists for their inner loops.
+#ifndef ORBMATCHER_H
+#define ORBMATCHER_H
+
+#include <vector>
+
+#ifdef ORBHIP_WITH_REFERENCE_HEADERS
+#include <opencv2/core/core.hpp>
+#include <opencv2/features2d/features2d.hpp>
+#include "MapPoint.h"
+#include "KeyFrame.h"
+#include "Frame.h"
+#else
+#include "cvlite.h"
+#include "slamlite.h"
+#endif
+
+struct orbhip_ctx;
+
+namespace ORB_SLAM2
+{
+
+class ORBmatcher
+{
+public:
+
+    ORBmatcher(float nnratio=0.6, bool checkOri=true);
+    ~ORBmatcher();
+
+    // Computes the Hamming distance between two ORB descriptors (ref: src/ORBmatcher.cc:1675-1691)
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
+
+    // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
+    // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)
+    // Used in Relocalisation and Loop Detection (ref: src/ORBmatcher.cc:159-288, 522-655)
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches);
+    int SearchByBoW(KeyFrame *pKF1, KeyFrame* pKF2, std::vector<MapPoint*> &vpMatches12);
+
+    // Device context used for matching.  By default one small context per thread is created on
+    // first use (matchers are stack objects in the reference and are used from three threads).
+    static void SetDevice(int device);
+
+public:
+
+    static const int TH_LOW;
+    static const int TH_HIGH;
+    static const int HISTO_LENGTH;
+
+protected:
+
+    void ComputeThreeMaxima(std::vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3);
+
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+}// namespace ORB_SLAM
+
+#endif // ORBMATCHER_H

@@ -1,0 +1,61 @@
+// slamlite.h -- the members of ORB_SLAM2::Frame / KeyFrame / MapPoint and DBoW2::FeatureVector
+// that ORBmatcher::SearchByBoW reads (ref: src/ORBmatcher.cc:159-288, 522-655), for builds
+// outside the reference tree.  Inside the reference tree define ORBHIP_WITH_REFERENCE_HEADERS and
+// the real "Frame.h" / "KeyFrame.h" / "MapPoint.h" are included instead.
+#ifndef ORBHIP_SLAMLITE_H
+#define ORBHIP_SLAMLITE_H
+
+#include <map>
+#include <set>
+#include <vector>
+
+#include "cvlite.h"
+
+namespace DBoW2
+{
+typedef unsigned int NodeId;
+// ref: Thirdparty/DBoW2/DBoW2/FeatureVector.h -- node id -> indices of the features under it
+class FeatureVector : public std::map<NodeId, std::vector<unsigned int> >
+{
+public:
+    void addFeature(NodeId id, unsigned int i_feature) { (*this)[id].push_back(i_feature); }
+};
+}  // namespace DBoW2
+
+namespace ORB_SLAM2
+{
+
+class MapPoint
+{
+public:
+    MapPoint() : mbBad(false) {}
+    bool isBad() { return mbBad; }          // ref: include/MapPoint.h
+    void SetBadFlag() { mbBad = true; }
+protected:
+    bool mbBad;
+};
+
+class Frame
+{
+public:
+    Frame() : N(0) {}
+    int N;                                   // ref: include/Frame.h
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
+    std::vector<MapPoint *> mvpMapPoints;
+};
+
+class KeyFrame
+{
+public:
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;   // ref: include/KeyFrame.h (const members there)
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
+    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    std::vector<MapPoint *> mvpMapPoints;
+};
+
+}  // namespace ORB_SLAM2
+
+#endif

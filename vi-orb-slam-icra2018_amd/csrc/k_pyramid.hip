@@ -2,11 +2,17 @@
 // 8UC1 (ref call site: src/ORBextractor.cc:1141).  The 19-px border of the reference
 // (copyMakeBorder :1143-1149) is never read by later stages and is not produced.
 //
-// One thread produces 4 horizontally adjacent output pixels and stores them as one dword; the
-// column/row tap tables are built on the host (orb_build_resize_tables).  Rows of one level are
-// 64-byte aligned so every store is aligned.  Bound: HBM/L2 streaming (reads 1.44 px and writes
-// 1 px per output pixel).
+// One 256-thread workgroup per 128x8 output tile.  The source rows/columns the tile touches
+// (about 156 x 12 pixels at scale 1.2) are staged into LDS with 16-byte row-coalesced loads; a
+// thread then produces 4 horizontally adjacent output pixels from LDS and stores them as one
+// dword.  The column/row tap tables (source index pair + 11-bit weights) are built on the host
+// (orb_build_resize_tables).  Bound: HBM (reads 1.44 px and writes 1 px per output pixel).
 #include "orbhip_internal.h"
+
+#define RZ_TW 128
+#define RZ_TH 8
+#define RZ_MAXCH 16    // 16-byte chunks per staged source row (source span <= 240 px + alignment)
+#define RZ_MAXROWS 24  // staged source rows
 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sstride,
                                                 unsigned long long sframe, uint8_t *__restrict__ dst,
@@ -14,27 +20,64 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
                                                 const int2 *__restrict__ xtab,
                                                 const int4 *__restrict__ ytab)
 {
-    const int gx = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    if (gx >= dw || dy >= dh) return;
+    __shared__ __align__(16) uint8_t s_src[RZ_MAXROWS][RZ_MAXCH * 16];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * RZ_TW, oy0 = blockIdx.y * RZ_TH;
+    const int ox1 = min(ox0 + RZ_TW, dw) - 1, oy1 = min(oy0 + RZ_TH, dh) - 1;   // inclusive
     const uint8_t *S = src + (size_t)blockIdx.z * sframe;
     uint8_t *D = dst + (size_t)blockIdx.z * dframe;
+
+    // source window of the tile (tables are monotone)
+    const int sxmin = xtab[ox0].x & 0xFFFF, sxmax = (unsigned)xtab[ox1].x >> 16;
+    const int symin = ytab[oy0].x, symax = ytab[oy1].y;
+    const int XA = sxmin & ~15;
+    const int nch = ((sxmax - XA) >> 4) + 1;
+    const int nrows = symax - symin + 1;
+    if (nch <= RZ_MAXCH && nrows <= RZ_MAXROWS) {
+        for (int i = tid; i < nrows * nch; i += 256) {
+            const int r = i / nch, c = i - r * nch;
+            const uint4 v = *reinterpret_cast<const uint4 *>(S + (size_t)(symin + r) * sstride + XA + (c << 4));
+            *reinterpret_cast<uint4 *>(&s_src[r][c << 4]) = v;
+        }
+    }
+    __syncthreads();
+    const int gx = ox0 + ((tid & 31) << 2);
+    const int dy = oy0 + (tid >> 5);
+    if (gx >= dw || dy >= dh) return;
     const int4 yt = ytab[dy];
-    const uint8_t *S0 = S + (size_t)yt.x * sstride;
-    const uint8_t *S1 = S + (size_t)yt.y * sstride;
     const int b0 = yt.z, b1 = yt.w;
     uint32_t packed = 0;
+    if (nch <= RZ_MAXCH && nrows <= RZ_MAXROWS) {
+        const uint8_t *S0 = &s_src[yt.x - symin][0] - XA;
+        const uint8_t *S1 = &s_src[yt.y - symin][0] - XA;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int dx = gx + k;
-        if (dx < dw) {
-            const int2 xt = xtab[dx];
-            const int sx0 = xt.x & 0xFFFF, sx1 = (unsigned)xt.x >> 16;
-            const int a0 = (short)(xt.y & 0xFFFF), a1 = xt.y >> 16;
-            const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
-            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * k);
+        for (int k = 0; k < 4; k++) {
+            const int dx = gx + k;
+            if (dx < dw) {
+                const int2 xt = xtab[dx];
+                const int sx0 = xt.x & 0xFFFF, sx1 = (unsigned)xt.x >> 16;
+                const int a0 = (short)(xt.y & 0xFFFF), a1 = xt.y >> 16;
+                const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
+                const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
+                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 0xFF) << (8 * k);
+            }
+        }
+    } else {
+        // generic path (scale factors far from 1.2 whose source window exceeds the LDS tile)
+        const uint8_t *S0 = S + (size_t)yt.x * sstride;
+        const uint8_t *S1 = S + (size_t)yt.y * sstride;
+        for (int k = 0; k < 4; k++) {
+            const int dx = gx + k;
+            if (dx < dw) {
+                const int2 xt = xtab[dx];
+                const int sx0 = xt.x & 0xFFFF, sx1 = (unsigned)xt.x >> 16;
+                const int a0 = (short)(xt.y & 0xFFFF), a1 = xt.y >> 16;
+                const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
+                const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
+                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 0xFF) << (8 * k);
+            }
         }
     }
     uint8_t *o = D + (size_t)dy * dstride + gx;
@@ -51,8 +94,8 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 {
     (void)sw;
     (void)sh;
-    dim3 block(64, 4, 1);
-    dim3 grid((dw + 255) / 256, (dh + 3) / 4, B);
+    dim3 block(256, 1, 1);
+    dim3 grid((dw + RZ_TW - 1) / RZ_TW, (dh + RZ_TH - 1) / RZ_TH, B);
     hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh,
                        dstride, (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
                        reinterpret_cast<const int4 *>(ytab));

@@ -221,6 +221,15 @@ extern "C" int orbhip_get_tables(const orbhip_ctx *c, int *nlevels, double *scal
     return ORBHIP_OK;
 }
 
+extern "C" int orbhip_tables(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                             float *sf, float *isf, float *s2, float *is2, int *perLevel, int *umax)
+{
+    orbhip_ctx tmp;
+    const int rc = orb_init_tables(&tmp, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+    if (rc != ORBHIP_OK) return fail(nullptr, rc, "orbhip_tables: bad ORB parameters");
+    return orbhip_get_tables(&tmp, nullptr, nullptr, sf, isf, s2, is2, perLevel, umax);
+}
+
 extern "C" int orbhip_max_keypoints(const orbhip_ctx *c)
 {
     if (!c) return ORBHIP_E_ARG;

@@ -1,0 +1,114 @@
+// ORBextractor.cc -- host side of the drop-in ORB_SLAM2::ORBextractor (include/orbhip/ORBextractor.h).
+// Mirrors the control flow of the reference's operator() (src/ORBextractor.cc:1045-1126): empty
+// image -> silent return, CV_8UC1 assertion, three stage timers, keypoints cleared and refilled,
+// descriptors created as N x 32 CV_8U -- with every computation delegated to liborbhip.so.
+#include "ORBextractor.h"
+
+#include <cassert>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "orbhip.h"
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint must be the 28-byte OpenCV layout");
+
+namespace ORB_SLAM2
+{
+
+static int g_device = 0;
+
+void ORBextractor::SetDevice(int device) { g_device = device; }
+
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels,
+         int _iniThFAST, int _minThFAST):
+    nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels),
+    iniThFAST(_iniThFAST), minThFAST(_minThFAST),
+    mTimeOfComputePyramid(0), mTimeOfComputeKeyPointsOctTree(0), mTimeOfComputeDescriptor(0),
+    mpCtx(nullptr), mCtxW(0), mCtxH(0), mbDownloadPyramid(true)
+{
+    // scale tables, per-level quotas and umax (ref: src/ORBextractor.cc:417-471) -- host arithmetic
+    // inside liborbhip, no device needed yet
+    mvScaleFactor.resize(nlevels);
+    mvInvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    umax.resize(16);
+    if (orbhip_tables(nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, mvScaleFactor.data(),
+                      mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
+                      mnFeaturesPerLevel.data(), umax.data()) != ORBHIP_OK)
+        throw std::invalid_argument("ORBextractor: bad parameters");
+    mvImagePyramid.resize(nlevels);
+}
+
+ORBextractor::~ORBextractor()
+{
+    if (mpCtx) orbhip_destroy(mpCtx);
+}
+
+const char *ORBextractor::LastError() const { return orbhip_last_error(mpCtx); }
+
+bool ORBextractor::EnsureContext(int w, int h)
+{
+    if (mpCtx && w <= mCtxW && h <= mCtxH) return true;
+    if (mpCtx) orbhip_destroy(mpCtx);
+    mCtxW = w > mCtxW ? w : mCtxW;
+    mCtxH = h > mCtxH ? h : mCtxH;
+    mpCtx = orbhip_create(g_device, nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, mCtxW, mCtxH, 1);
+    return mpCtx != nullptr;
+}
+
+void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints,
+                      cv::OutputArray _descriptors)
+{
+    (void)_mask;
+    if(_image.empty())
+        return;                                              // ref: :1048-1049
+
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1 );                        // ref: :1052
+
+    if (!EnsureContext(image.cols, image.rows))
+        throw std::runtime_error(std::string("ORBextractor: ") + orbhip_last_error(nullptr));
+
+    const int cap = orbhip_max_keypoints(mpCtx);
+    mvKpStage.resize(cap);
+    cv::Mat descStage(cap, 32, CV_8U);
+    int n = 0;
+    float t[3] = {0, 0, 0};
+    const int rc = orbhip_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step,
+                                  reinterpret_cast<orbhip_keypoint *>(mvKpStage.data()), descStage.data, cap, &n, t);
+    if (rc != ORBHIP_OK)
+        throw std::runtime_error(std::string("ORBextractor: ") + orbhip_last_error(mpCtx));
+    mTimeOfComputePyramid = t[0];
+    mTimeOfComputeKeyPointsOctTree = t[1];
+    mTimeOfComputeDescriptor = t[2];
+
+    if( n == 0 )
+        _descriptors.release();                              // ref: :1080-1081
+    else
+    {
+        _descriptors.create(n, 32, CV_8U);                   // ref: :1084
+        cv::Mat descriptors = _descriptors.getMat();
+        for (int i = 0; i < n; i++) memcpy(descriptors.ptr(i), descStage.ptr(i), 32);
+    }
+    _keypoints.clear();
+    _keypoints.reserve(n);
+    _keypoints.insert(_keypoints.end(), mvKpStage.begin(), mvKpStage.begin() + n);
+
+    if (mbDownloadPyramid)
+    {
+        for (int level = 0; level < nlevels; ++level)
+        {
+            int w = 0, h = 0;
+            orbhip_get_pyramid_level(mpCtx, 0, level, nullptr, 0, &w, &h);
+            mvImagePyramid[level].create(h, w, CV_8UC1);
+            if (orbhip_get_pyramid_level(mpCtx, 0, level, mvImagePyramid[level].data, (int)mvImagePyramid[level].step,
+                                         &w, &h) != ORBHIP_OK)
+                throw std::runtime_error(std::string("ORBextractor: ") + orbhip_last_error(mpCtx));
+        }
+    }
+}
+
+} //namespace ORB_SLAM

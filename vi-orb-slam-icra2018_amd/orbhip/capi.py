@@ -20,7 +20,7 @@ MAX_LEVELS = 16
 # every symbol include/orbhip.h declares
 SYMBOLS = [
     "orbhip_device_count", "orbhip_create", "orbhip_destroy", "orbhip_last_error", "orbhip_sync",
-    "orbhip_stream", "orbhip_get_tables", "orbhip_max_keypoints", "orbhip_level_size",
+    "orbhip_stream", "orbhip_get_tables", "orbhip_tables", "orbhip_max_keypoints", "orbhip_level_size",
     "orbhip_extract", "orbhip_extract_batch", "orbhip_extract_batch_device",
     "orbhip_get_pyramid_level", "orbhip_debug_get_blurred_level", "orbhip_debug_get_candidates",
     "orbhip_debug_get_level_keypoints", "orbhip_hamming_knn2", "orbhip_hamming_knn2_device",
@@ -62,6 +62,7 @@ def load():
     L.orbhip_stream.argtypes = [vp]
     L.orbhip_stream.restype = vp
     L.orbhip_get_tables.argtypes = [vp, ip, C.POINTER(C.c_double), vp, vp, vp, vp, vp, vp]
+    L.orbhip_tables.argtypes = [i32, f32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.orbhip_max_keypoints.argtypes = [vp]
     L.orbhip_level_size.argtypes = [vp, i32, i32, i32, ip, ip]
     L.orbhip_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, ip, vp]
