@@ -28,7 +28,14 @@ def test_cpp_dropin_classes_match_oracle(oracle, tmp_path):
     W, H, NF = 752, 480, 1000
     frames = synth.make_frames(50, W, H, 2)
     rng = np.random.default_rng(51)
+    # vocabulary-node assignment: frame features at random, key-frame features mostly in the node
+    # of their nearest frame descriptor (so that SearchByBoW has real matches to find)
+    pre = oracle.Extractor(NF)
+    (_, pd1), (_, pd2) = pre(frames[0]), pre(frames[1])
     node = rng.integers(0, 90, 8192).astype(np.int32)
+    nearest = oracle.knn2(pd1, pd2)[0]
+    follow = rng.random(len(pd1)) < 0.85
+    node[:len(pd1)][follow] = node[4096:][nearest[follow]]
     (tmp_path / "frames.raw").write_bytes(frames.tobytes())
     (tmp_path / "groups.bin").write_bytes(node.tobytes())
     out = tmp_path / "out.bin"
