@@ -1,0 +1,137 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend nccl = RCCL on the GPU
+box, gloo in the CPU tests).  The ORB front end shards by independent units -- frames of one
+stream, or whole streams -- so there is NO per-frame collective; the only exchange steps are the
+one-off broadcast of the ORB vocabulary and (brute-force relocalisation) a min-merge of per-shard
+(best, index, second) triples.  SURVEY.md section 8e.
+"""
+import struct
+
+import numpy as np
+
+# ---- ORB vocabulary blob: the reference's binary format --------------------------------------
+# Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1727-1751 (saveToBinaryFile) / :1680-1721 (load):
+#   u32 nb_nodes (= m_nodes.size(), root included), u32 size_node (= 4 + 32 + 4 + 1 = 41),
+#   i32 k, i32 L, i32 scoring, i32 weighting, then for node id 1..nb_nodes-1:
+#   i32 parent, u8 descriptor[32], f32 weight, u8 is_leaf.
+VOC_HEADER = struct.Struct("<IIiiii")
+VOC_NODE_SIZE = 41
+VOC_NODE_DTYPE = np.dtype([("parent", "<i4"), ("desc", "u1", 32), ("weight", "<f4"), ("leaf", "u1")])
+assert VOC_NODE_DTYPE.itemsize == VOC_NODE_SIZE
+
+
+def pack_vocabulary(k, L, scoring, weighting, parent, desc, weight, leaf):
+    """Arrays over node ids 1..n (root excluded) -> the binary blob of saveToBinaryFile."""
+    n = len(parent)
+    nodes = np.zeros(n, VOC_NODE_DTYPE)
+    nodes["parent"] = parent
+    nodes["desc"] = desc
+    nodes["weight"] = weight
+    nodes["leaf"] = leaf
+    return VOC_HEADER.pack(n + 1, VOC_NODE_SIZE, k, L, scoring, weighting) + nodes.tobytes()
+
+
+def unpack_vocabulary(blob):
+    """Inverse of pack_vocabulary: dict(k, L, scoring, weighting, nodes=structured array 1..n)."""
+    blob = bytes(blob)
+    nb, size_node, k, L, scoring, weighting = VOC_HEADER.unpack_from(blob, 0)
+    if size_node != VOC_NODE_SIZE:
+        raise ValueError("unexpected vocabulary node size %d" % size_node)
+    n = (len(blob) - VOC_HEADER.size) // VOC_NODE_SIZE
+    if n != nb - 1:
+        raise ValueError("vocabulary blob truncated: %d nodes in header, %d present" % (nb - 1, n))
+    nodes = np.frombuffer(blob, VOC_NODE_DTYPE, n, VOC_HEADER.size)
+    return {"k": k, "L": L, "scoring": scoring, "weighting": weighting, "nodes": nodes}
+
+
+def make_synthetic_vocabulary(seed, k=10, L=3):
+    """A complete k-ary tree of depth L with random 256-bit node descriptors (the stock ORBvoc is
+    k=10, L=6, ~1.08 M nodes, ~44 MB; the file is not in the reference mirror)."""
+    rng = np.random.default_rng(seed)
+    parent, leaf = [], []
+    level = [0]
+    nid = 1
+    for depth in range(1, L + 1):
+        nxt = []
+        for p in level:
+            for _ in range(k):
+                parent.append(p)
+                leaf.append(1 if depth == L else 0)
+                nxt.append(nid)
+                nid += 1
+        level = nxt
+    n = len(parent)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    weight = rng.random(n).astype(np.float32)
+    return pack_vocabulary(k, L, 0, 0, np.array(parent, np.int32), desc, weight, np.array(leaf, np.uint8))
+
+
+# ---- sharding -------------------------------------------------------------------------------
+def shard_frames(n_frames, rank, world):
+    """Contiguous block of frames for `rank` (single-stream mode): sizes differ by at most one,
+    every frame belongs to exactly one rank."""
+    base, extra = divmod(n_frames, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def assign_streams(lengths, world):
+    """Streams mode (BASELINE config 4: one sequence per GPU): longest-first greedy assignment
+    of whole streams to ranks.  Returns a list of stream-index lists, one per rank."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        out[r].append(i)
+        load[r] += lengths[i]
+    return out
+
+
+# ---- exchange steps -------------------------------------------------------------------------
+def broadcast_blob(blob, src=0, device=None):
+    """Broadcast a byte blob (the vocabulary) from `src` to every rank.  Two collectives: the
+    length, then the bytes.  With backend nccl this is RCCL over xGMI: the root has a direct
+    link to each peer, one ~44 MB send per link."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=src)
+    if rank == src:
+        buf = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    else:
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src=src)
+    return buf
+
+
+def merge_knn2_shards(best_idx, best_d, second_d, shard_offsets):
+    """Min-merge of per-shard brute-force results in shard order (lower database rows first), with
+    the reference's tie rule (strict '<': the lowest global index wins).  Inputs are lists of
+    arrays, one per shard, indices local to the shard."""
+    bi = np.full_like(best_idx[0], -1)
+    bd = np.full_like(best_d[0], 256)
+    sd = np.full_like(second_d[0], 256)
+    for li, ld, ls, off in zip(best_idx, best_d, second_d, shard_offsets):
+        gi = np.where(li >= 0, li + off, -1)
+        better = ld < bd
+        sd = np.where(better, np.minimum(bd, ls), np.minimum(sd, ld))
+        bi = np.where(better, gi, bi)
+        bd = np.where(better, ld, bd)
+    return bi, bd, sd
+
+
+def allgather_knn2(best_idx, best_d, second_d, shard_offset):
+    """The one exchange step of sharded brute force: all-gather Q x 3 int32 and merge."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.from_numpy(np.stack([best_idx, best_d, second_d,
+                                      np.full_like(best_idx, shard_offset)]).astype(np.int32)).to(dev)
+    outs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(outs, mine)
+    arrs = [o.cpu().numpy() for o in outs]
+    return merge_knn2_shards([a[0] for a in arrs], [a[1] for a in arrs], [a[2] for a in arrs],
+                             [int(a[3][0]) if a.shape[1] else 0 for a in arrs])
