@@ -15,7 +15,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, outq):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "vi-orb-slam-icra2018_amd"), os.path.join(root, "oracle")):
@@ -40,12 +40,12 @@ def _worker(rank, world, port, q):
         counts = {t: len(ex(frames[t])[0]) for t in range(a, b)}
         # 3. sharded brute force: database rows split across ranks, queries replicated
         db = synth.make_descriptor_db(7, 1001)
-        q, _ = synth.make_queries(8, db, 40)
+        qd, _ = synth.make_queries(8, db, 40)
         lo, hi = D.shard_frames(len(db), rank, world)
-        li, ld, ls = oracle.knn2(q, db[lo:hi])
+        li, ld, ls = oracle.knn2(qd, db[lo:hi])
         bi, bd, sd = D.allgather_knn2(li, ld, ls, lo)
-        q.put((rank, len(got), voc["k"], voc["L"], len(voc["nodes"]), (a, b), counts, bi.tolist(), bd.tolist(),
-                      sd.tolist()))
+        outq.put((rank, len(got), voc["k"], voc["L"], len(voc["nodes"]), (a, b), counts, bi.tolist(), bd.tolist(),
+                  sd.tolist()))
     finally:
         dist.destroy_process_group()
 
