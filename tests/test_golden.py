@@ -1,0 +1,79 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tools/gen_golden.py from the oracle):
+the oracle must still reproduce them on CPU; the HIP path must reproduce them on the GPU."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EXTRACT = sorted(glob.glob(os.path.join(GOLD, "extract_*.npz")))
+
+
+def _fv(node):
+    ids = sorted(set(int(v) for v in node))
+    lists = [np.nonzero(node == k)[0] for k in ids]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
+    return np.array(ids, np.int32), off, np.concatenate(lists).astype(np.int32)
+
+
+def test_golden_files_present():
+    assert len(EXTRACT) == 3 and os.path.exists(os.path.join(GOLD, "matching_q250_db600.npz"))
+
+
+@pytest.mark.parametrize("path", EXTRACT, ids=[os.path.basename(p) for p in EXTRACT])
+def test_oracle_reproduces_golden_extract(oracle, path):
+    g = np.load(path)
+    nf, nl, ini, mn = (int(v) for v in g["params"])
+    ex = oracle.Extractor(nf, 1.2, nl, ini, mn)
+    k, d = ex(g["image"])
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+    assert [len(ex.level_cands(l)) for l in range(nl)] == g["level_candidates"].tolist()
+    assert [int(ex.pyramid(l).astype(np.uint64).sum()) for l in range(nl)] == g["level_pixel_sum"].tolist()
+    assert [int(ex.blurred(l).astype(np.uint64).sum()) for l in range(nl)] == g["blurred_pixel_sum"].tolist()
+
+
+def test_oracle_reproduces_golden_matching(oracle):
+    g = np.load(os.path.join(GOLD, "matching_q250_db600.npz"))
+    bi, bd, sd = oracle.knn2(g["q"], g["db"])
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_d"]) and np.array_equal(sd, g["second_d"])
+    fv1, fv2 = _fv(g["node1"]), _fv(g["node2"])
+    n, m12, m21 = oracle.search_by_bow(g["q"], g["valid1"], g["angle1"], fv1, g["db"], None, g["angle2"], fv2, th=50,
+                                       th_mode=0, nnratio=0.7, check_ori=True)
+    assert n == int(g["bow_kf_f_n"]) and np.array_equal(m12, g["bow_kf_f_m12"]) and np.array_equal(m21, g["bow_kf_f_m21"])
+    n, m12, m21 = oracle.search_by_bow(g["q"], g["valid1"], g["angle1"], fv1, g["db"], g["valid2"], g["angle2"], fv2,
+                                       th=50, th_mode=1, nnratio=0.75, check_ori=True)
+    assert n == int(g["bow_kf_kf_n"]) and np.array_equal(m12, g["bow_kf_kf_m12"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", EXTRACT, ids=[os.path.basename(p) for p in EXTRACT])
+def test_hip_reproduces_golden_extract(path):
+    from orbhip.extractor import ORBextractor
+    g = np.load(path)
+    nf, nl, ini, mn = (int(v) for v in g["params"])
+    img = g["image"]
+    ex = ORBextractor(nf, 1.2, nl, ini, mn, max_w=img.shape[1], max_h=img.shape[0])
+    k, d = ex(img)
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+    assert [len(ex.level_candidates(l)) for l in range(nl)] == g["level_candidates"].tolist()
+    assert [int(ex.image_pyramid(l).astype(np.uint64).sum()) for l in range(nl)] == g["level_pixel_sum"].tolist()
+    assert [int(ex.blurred(l).astype(np.uint64).sum()) for l in range(nl)] == g["blurred_pixel_sum"].tolist()
+    ex.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_matching():
+    from orbhip.extractor import ORBextractor, ORBmatcher
+    g = np.load(os.path.join(GOLD, "matching_q250_db600.npz"))
+    ex = ORBextractor(300, max_w=320, max_h=240)
+    m = ORBmatcher(0.7, True, ctx=ex)
+    bi, bd, sd = m.knn2(g["q"], g["db"])
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_d"]) and np.array_equal(sd, g["second_d"])
+    fv1, fv2 = _fv(g["node1"]), _fv(g["node2"])
+    n, m12, m21 = m.SearchByBoW(g["q"], g["valid1"], g["angle1"], fv1, g["db"], None, g["angle2"], fv2, kf_kf=False)
+    assert n == int(g["bow_kf_f_n"]) and np.array_equal(m12, g["bow_kf_f_m12"]) and np.array_equal(m21, g["bow_kf_f_m21"])
+    m2 = ORBmatcher(0.75, True, ctx=ex)
+    n, m12, m21 = m2.SearchByBoW(g["q"], g["valid1"], g["angle1"], fv1, g["db"], g["valid2"], g["angle2"], fv2, kf_kf=True)
+    assert n == int(g["bow_kf_kf_n"]) and np.array_equal(m12, g["bow_kf_kf_m12"]) and np.array_equal(m21, g["bow_kf_kf_m21"])
+    ex.close()
