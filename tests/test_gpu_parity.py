@@ -260,3 +260,44 @@ def test_full_size_properties_batch(hip, oracle):
         rk, rd = ref(frames[b])
         assert _same_kps(ks[b], rk) and np.array_equal(ds[b], rd)
     ex.close()
+
+
+def test_noise_image_overflows_the_fast_lists(hip, oracle):
+    """White noise: most pixels pass the compass test and many are corners, so the FAST kernel's
+    LDS work/corner lists overflow and the exact fallback paths run."""
+    from orbhip.extractor import ORBextractor
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    img[:, 160:] = (img[:, 160:] // 4 + 90).astype(np.uint8)      # half of it low contrast
+    ex = ORBextractor(500, 1.2, 4, 20, 7, max_w=320, max_h=240)
+    ref = oracle.Extractor(500, 1.2, 4, 20, 7)
+    k, d = ex(img)
+    rk, rd = ref(img)
+    for l in range(4):
+        gc, rc = ex.level_candidates(l), ref.level_cands(l)
+        assert len(gc) == len(rc) and gc.tobytes() == rc.tobytes(), "FAST candidates level %d" % l
+    assert _same_kps(k, rk) and np.array_equal(d, rd)
+    ex.close()
+
+
+def test_forced_tiny_fast_lists_take_the_fallback_paths(hip):
+    """ORBHIP_FAST_LISTCAP=8 makes every tile overflow both lists; results must not change."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import orb_oracle_py as oracle\n"
+        "from orbhip import synth\n"
+        "from orbhip.extractor import ORBextractor\n"
+        "img = synth.make_frames(5, 640, 480, 1)[0]\n"
+        "ex = ORBextractor(1000, max_w=640, max_h=480); ref = oracle.Extractor(1000)\n"
+        "k, d = ex(img); rk, rd = ref(img)\n"
+        "assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)\n"
+        "print('fallback ok', len(k))\n"
+    ) % (os.path.join(root, "vi-orb-slam-icra2018_amd"), os.path.join(root, "oracle"))
+    env = dict(os.environ, ORBHIP_FAST_LISTCAP="8")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and "fallback ok" in out.stdout, out.stdout + out.stderr

@@ -9,29 +9,29 @@
 // CELL (other cells' pixels count as 0, exactly like the zeroed score rows/columns outside a
 // sub-image), and per cell keep the survivors >= iniThFAST if there is any, else all survivors.
 //
-// One 256-thread workgroup per (frame, run of <= 8 cells of one cell-row); five phases:
+// One 256-thread workgroup per (frame, run of <= FAST_TILE_CELLS cells of one cell-row):
 //   1. stage the run's pixels (+3 px halo) into LDS with 16-byte row-coalesced loads;
-//   2. compass pre-test on EVERY domain pixel, 4 pixels per lane from aligned LDS dwords: a 9-arc
-//      always contains ring pixel 0 or 8 and ring pixel 4 or 12, so a corner needs
-//      (q0|q8) & (q4|q12) beyond the threshold with one polarity.  ~10 VALU ops per pixel (SDWA
-//      byte compares, lane masks combined on the scalar unit).  Survivors (typically 10-20 %) are
-//      appended to an LDS work list;
+//   2. compass pre-test on EVERY domain pixel, 4 pixels per lane from aligned LDS dwords, in packed
+//      16-bit arithmetic (v_pk_max/min/sub_u16, 2 pixels per instruction): a 9-arc always contains
+//      ring pixel 0 or 8 and ring pixel 4 or 12, so a corner needs
+//      min(max(q0,q8), max(q4,q12)) > v + t   or   max(min(q0,q8), min(q4,q12)) < v - t.
+//      Survivors (typically 10-20 %) are appended to an LDS work list;
 //   3. full score on the work list, dense lanes: arc minima with min3 trees, one polarity unless
-//      both are possible;
-//   4. non-max suppression over the scored corners only (sparse), survivors marked in an LDS bitmap,
-//      per-cell "has a corner >= iniThFAST" flag;
-//   5. per cell, one wave walks the bitmap rows in raster order and writes the kept candidates into
-//      the cell's fixed slot range: cells row-major, raster inside a cell = the reference's
-//      candidate order.  No global atomics, no sorting, deterministic.
+//      both are possible; corners (score >= minThFAST) are compacted into a corner list;
+//   4. non-max suppression over the corner list only; survivors get a sortable key
+//      (cell, row, column, score) in a survivor list, plus a per-cell ">= iniThFAST" flag;
+//   5. survivors that pass their cell's threshold are ranked by counting inside their cell and
+//      written to the cell's fixed slot range: cells row-major, raster inside a cell = the
+//      reference's candidate order.  No global atomics, deterministic.
 // HBM traffic: each level pixel inside [16, w-16) x [16, h-16) is read once per tile that needs it;
-// the 6-row vertical halo (hCell ~ 30) is re-read by the tile below.  Roofline: HBM read,
-// algorithmic bytes = sum_l (w_l-32)(h_l-32) per frame.
+// the 6-row vertical halo (hCell ~ 30) is re-read by the tile below.  Roofline: nominally HBM read
+// (algorithmic bytes = sum_l (w_l-32)(h_l-32) per frame); measured bound is integer VALU + LDS
+// (DESIGN.md section 4).
 #include "orbhip_internal.h"
 
 #include <cstdlib>
 
-#define FAST_BM_WORDS 12   // bitmap words per domain row (domain width <= 384)
-#define FAST_MAX_DH 66     // domain rows per tile (hCell <= 66)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ const uint8_t *level_ptr(const OrbLevels &G, int l, int frame,
                                                     const uint8_t *lvl0, int stride0,
@@ -46,8 +46,30 @@ __device__ __forceinline__ const uint8_t *level_ptr(const OrbLevels &G, int l, i
     return pyr + (size_t)frame * pyrFrame + G.lv[l].imgOff;
 }
 
+__device__ __forceinline__ int mad24i(int a, int b, int c) { return __mul24(a, b) + c; }   // v_mad_i32_i24
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// bytes (0,1) / (2,3) of w zero-extended into the two 16-bit halves
+__device__ __forceinline__ us2 lo2(uint32_t w)
+{
+    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u));
+}
+__device__ __forceinline__ us2 hi2(uint32_t w)
+{
+    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+}
+
+// Compass test of two pixels: non-zero half <=> that pixel can be a FAST-9 corner at threshold t.
+__device__ __forceinline__ uint32_t compass2(us2 v, us2 qt, us2 qb, us2 ql, us2 qr, us2 tt)
+{
+    const us2 mb = __builtin_elementwise_min(__builtin_elementwise_max(qt, qb), __builtin_elementwise_max(ql, qr));
+    const us2 md = __builtin_elementwise_max(__builtin_elementwise_min(qt, qb), __builtin_elementwise_min(ql, qr));
+    const us2 hi = v + tt;
+    const us2 lo = __builtin_elementwise_sub_sat(v, tt);
+    const us2 f = __builtin_elementwise_sub_sat(mb, hi) | __builtin_elementwise_sub_sat(lo, md);   // each <= 255
+    return __builtin_bit_cast(uint32_t, f);
+}
 
 // max over the 16 cyclic 9-arcs of the arc minimum of e[]
 __device__ __forceinline__ int max_arc_min(const int e[16])
@@ -75,25 +97,25 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *p, int pitch, int t
     const bool pd = ((v - q0 > t) || (v - q8 > t)) && ((v - q4 > t) || (v - q12 > t));
     const bool pb = ((q0 - v > t) || (q8 - v > t)) && ((q4 - v > t) || (q12 - v > t));
     if (!pd && !pb) return 0;
-    const int sgn = (pb && !pd) ? -1 : 1;   // evaluate e = sgn * (v - q)
-    const int sv = sgn * v;
+    const int ns = (pb && !pd) ? 1 : -1;   // e = -ns * (v - q) = ns*q - ns*v
+    const int sv = -ns * v;
     int e[16];
-    e[0] = sv - sgn * q0;
-    e[1] = sv - sgn * (int)p[3 * pitch + 1];
-    e[2] = sv - sgn * (int)p[2 * pitch + 2];
-    e[3] = sv - sgn * (int)p[pitch + 3];
-    e[4] = sv - sgn * q4;
-    e[5] = sv - sgn * (int)p[-pitch + 3];
-    e[6] = sv - sgn * (int)p[-2 * pitch + 2];
-    e[7] = sv - sgn * (int)p[-3 * pitch + 1];
-    e[8] = sv - sgn * q8;
-    e[9] = sv - sgn * (int)p[-3 * pitch - 1];
-    e[10] = sv - sgn * (int)p[-2 * pitch - 2];
-    e[11] = sv - sgn * (int)p[-pitch - 3];
-    e[12] = sv - sgn * q12;
-    e[13] = sv - sgn * (int)p[pitch - 3];
-    e[14] = sv - sgn * (int)p[2 * pitch - 2];
-    e[15] = sv - sgn * (int)p[3 * pitch - 1];
+    e[0] = mad24i(ns, q0, sv);
+    e[1] = mad24i(ns, (int)p[3 * pitch + 1], sv);
+    e[2] = mad24i(ns, (int)p[2 * pitch + 2], sv);
+    e[3] = mad24i(ns, (int)p[pitch + 3], sv);
+    e[4] = mad24i(ns, q4, sv);
+    e[5] = mad24i(ns, (int)p[-pitch + 3], sv);
+    e[6] = mad24i(ns, (int)p[-2 * pitch + 2], sv);
+    e[7] = mad24i(ns, (int)p[-3 * pitch + 1], sv);
+    e[8] = mad24i(ns, q8, sv);
+    e[9] = mad24i(ns, (int)p[-3 * pitch - 1], sv);
+    e[10] = mad24i(ns, (int)p[-2 * pitch - 2], sv);
+    e[11] = mad24i(ns, (int)p[-pitch - 3], sv);
+    e[12] = mad24i(ns, q12, sv);
+    e[13] = mad24i(ns, (int)p[pitch - 3], sv);
+    e[14] = mad24i(ns, (int)p[2 * pitch - 2], sv);
+    e[15] = mad24i(ns, (int)p[3 * pitch - 1], sv);
     int a = max_arc_min(e);
     if (pd && pb) {   // both polarities possible (rare): evaluate the other one as well
         int f[16];
@@ -105,6 +127,60 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *p, int pitch, int t
     return s >= t ? s : 0;
 }
 
+// inclusive wave prefix sum
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// Append the lanes with `flag` set to an LDS list (order irrelevant); returns the slot or -1.
+__device__ __forceinline__ int wave_append(bool flag, int *counter, int lane)
+{
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return -1;
+    const int n = __popcll(m);
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader);
+    return flag ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+// Non-max suppression of the corner at (r, c) of the tile's score map against its 8 neighbours that
+// lie in the same cell; returns the survivor's sortable key (cell | row | column | score).
+__device__ __forceinline__ uint32_t nms_key(const uint8_t *s_score, int SP, int r, int c, int DH, int TW, int wCell,
+                                            unsigned cellMagic, int iniTh, int *s_cellAny, bool &surv)
+{
+    const uint8_t *sp = s_score + r * SP + c;
+    const int s = sp[0];
+    const int cj = (int)(((unsigned)c * cellMagic) >> 16);
+    const int cx0 = cj * wCell;
+    int cx1 = cx0 + wCell;
+    if (cx1 > TW) cx1 = TW;
+    const bool up = r > 0, dn = r < DH - 1, lf = c > cx0, rt = c < cx1 - 1;
+    int m = 0;
+    if (lf) m = max(m, (int)sp[-1]);
+    if (rt) m = max(m, (int)sp[1]);
+    if (up) {
+        m = max(m, (int)sp[-SP]);
+        if (lf) m = max(m, (int)sp[-SP - 1]);
+        if (rt) m = max(m, (int)sp[-SP + 1]);
+    }
+    if (dn) {
+        m = max(m, (int)sp[SP]);
+        if (lf) m = max(m, (int)sp[SP - 1]);
+        if (rt) m = max(m, (int)sp[SP + 1]);
+    }
+    surv = s > m;
+    if (surv && s >= iniTh) s_cellAny[cj] = 1;   // benign race: every writer stores 1
+    return ((uint32_t)cj << 28) | ((uint32_t)r << 21) | ((uint32_t)c << 8) | (uint32_t)s;
+}
+
 __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                               int stride0, unsigned long long frame0,
                                               const uint8_t *__restrict__ pyr,
@@ -112,12 +188,12 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
                                               const FastTile *__restrict__ tiles,
                                               uint32_t *__restrict__ cand,
                                               uint16_t *__restrict__ cellCnt, int pixBytes, int scoreBytes,
-                                              int phases)
+                                              int listBytes, int listCap, int cornerCap, int phases)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ uint32_t s_bitmap[FAST_MAX_DH][FAST_BM_WORDS];
     __shared__ int s_cellAny[FAST_TILE_CELLS];
-    __shared__ int s_listCount;
+    __shared__ int s_cellCnt[FAST_TILE_CELLS];
+    __shared__ int s_listCount, s_cornerCount, s_survCount;
 
     const FastTile T = tiles[blockIdx.x];
     const int frame = blockIdx.y;
@@ -151,6 +227,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     uint8_t *s_pix = smem;
     uint8_t *s_score = smem + pixBytes;
     uint16_t *s_list = reinterpret_cast<uint16_t *>(smem + pixBytes + scoreBytes);
+    uint16_t *s_corner = reinterpret_cast<uint16_t *>(smem + pixBytes + scoreBytes + listBytes);
+    // the survivor list reuses the work list's storage (the work list is dead after phase 3)
+    uint32_t *s_surv = reinterpret_cast<uint32_t *>(smem + pixBytes + scoreBytes);
     const int SP = (TW + 3) & ~3;
     for (int i = tid; i < RH * nchunk; i += 256) {
         const int r = i / nchunk, c = i - r * nchunk;
@@ -158,175 +237,186 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
         *reinterpret_cast<uint4 *>(s_pix + r * pitch + (c << 4)) = v;
     }
     for (int i = tid; i < (DH * SP) >> 2; i += 256) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
-    for (int i = tid; i < FAST_MAX_DH * FAST_BM_WORDS; i += 256) (&s_bitmap[0][0])[i] = 0;
-    if (tid < FAST_TILE_CELLS) s_cellAny[tid] = 0;
-    if (tid == 0) s_listCount = 0;
+    if (tid < FAST_TILE_CELLS) {
+        s_cellAny[tid] = 0;
+        s_cellCnt[tid] = 0;
+    }
+    if (tid == 0) {
+        s_listCount = 0;
+        s_cornerCount = 0;
+        s_survCount = 0;
+    }
     __syncthreads();
     if (phases < 2) return;   // timing ablation only (ORBHIP_FAST_PHASES), results are then invalid
 
-    // ---- 2. compass pre-test, 4 pixels per lane; survivors -> work list ----
+    // ---- 2. compass pre-test, 4 pixels per item; survivors -> work list ----
+    // items = (domain row, aligned dword column) pairs, dealt round-robin to the 256 threads so that
+    // consecutive lanes read consecutive LDS dwords of one row (conflict-free) whatever the tile width
     const int t = G.minTh;
+    const us2 tt = {(unsigned short)t, (unsigned short)t};
     const int j0 = X0 + 3 - XA;            // LDS column of domain column 0
     const int jd0 = j0 & ~3;               // first aligned dword column touching the domain
     const int GPR = ((j0 + TW + 3) >> 2) - (j0 >> 2);   // dword groups per row
-    for (int rbase = 0; rbase < DH; rbase += 32) {
-        for (int gi0 = 0; gi0 < GPR; gi0 += 64) {      // normally a single trip (GPR <= 64)
-            // every lane runs the body (wave-wide shuffles below); idle lanes contribute nothing
-            const int gi = gi0 + lane;
-            const bool live = gi < GPR;
-            const int jd = jd0 + ((live ? gi : 0) << 2);
-            unsigned mask = 0;
+    const int nitems = DH * GPR;
+    const unsigned gprMagic = (1u << 20) / (unsigned)GPR + 1u;   // item / GPR for item < 2^20 / GPR
+    for (int ibase = 0; ibase < nitems; ibase += 8 * 256) {
+        // acc: bit (4 * i + k) = pixel k of this thread's i-th item of the chunk
+        uint32_t acc = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int r = rbase + wave + 4 * i;
-                if (live && r < DH) {
-                    const uint8_t *row = s_pix + (r + 3) * pitch + jd;
-                    const uint32_t Cw = *reinterpret_cast<const uint32_t *>(row);
-                    const uint32_t Lw = *reinterpret_cast<const uint32_t *>(row - 4);
-                    const uint32_t Rw = *reinterpret_cast<const uint32_t *>(row + 4);
-                    const uint32_t Tw = *reinterpret_cast<const uint32_t *>(row - 3 * pitch);
-                    const uint32_t Bw = *reinterpret_cast<const uint32_t *>(row + 3 * pitch);
-                    // pixel k of the group: left = column-3, right = column+3
-                    const uint32_t lft = (Lw >> 8) | (Cw << 24);      // bytes: L1 L2 L3 C0
-                    const uint32_t rgt = (Cw >> 24) | (Rw << 8);      // bytes: C3 R0 R1 R2
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int v = (Cw >> (8 * k)) & 0xFF;
-                        const int hi = v + t, lo = v - t;
-                        const int qt = (Tw >> (8 * k)) & 0xFF, qb = (Bw >> (8 * k)) & 0xFF;
-                        const int ql = (lft >> (8 * k)) & 0xFF, qr = (rgt >> (8 * k)) & 0xFF;
-                        const bool br = ((qt > hi) | (qb > hi)) & ((ql > hi) | (qr > hi));
-                        const bool dk = ((qt < lo) | (qb < lo)) & ((ql < lo) | (qr < lo));
-                        const int c = jd + k - j0;
-                        const bool in = (c >= 0) & (c < TW);
-                        if ((br | dk) & in) mask |= 1u << (4 * i + k);
-                    }
-                }
+        for (int i = 0; i < 8; i++) {
+            const int item = ibase + i * 256 + tid;
+            if (item < nitems) {
+                const int r = (int)(((unsigned)item * gprMagic) >> 20);
+                const int jd = jd0 + ((item - r * GPR) << 2);
+                const uint8_t *row = s_pix + (r + 3) * pitch + jd;
+                const uint32_t Cw = *reinterpret_cast<const uint32_t *>(row);
+                const uint32_t Lw = *reinterpret_cast<const uint32_t *>(row - 4);
+                const uint32_t Rw = *reinterpret_cast<const uint32_t *>(row + 4);
+                const uint32_t Tw = *reinterpret_cast<const uint32_t *>(row - 3 * pitch);
+                const uint32_t Bw = *reinterpret_cast<const uint32_t *>(row + 3 * pitch);
+                const uint32_t lft = __builtin_amdgcn_alignbyte(Cw, Lw, 1);   // bytes L1 L2 L3 C0 (column - 3)
+                const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
+                const uint32_t fA = compass2(lo2(Cw), lo2(Tw), lo2(Bw), lo2(lft), lo2(rgt), tt);   // px 0,1
+                const uint32_t fB = compass2(hi2(Cw), hi2(Tw), hi2(Bw), hi2(lft), hi2(rgt), tt);   // px 2,3
+                // pixels of the group that lie inside the domain (first / last group of a row)
+                const int c0 = jd - j0;
+                uint32_t nib = 0;
+                if ((fA & 0xFFFFu) && c0 >= 0 && c0 < TW) nib |= 1u;
+                if ((fA >> 16) && c0 + 1 >= 0 && c0 + 1 < TW) nib |= 2u;
+                if ((fB & 0xFFFFu) && c0 + 2 >= 0 && c0 + 2 < TW) nib |= 4u;
+                if ((fB >> 16) && c0 + 3 >= 0 && c0 + 3 < TW) nib |= 8u;
+                acc |= nib << (4 * i);
             }
-            // append this lane's survivors to the work list (order is irrelevant)
-            const int n = __popc(mask);
-            int incl = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int u = __shfl_up(incl, o);
-                if (lane >= o) incl += u;
-            }
-            const int total = __shfl(incl, 63);
-            int base = 0;
-            if (lane == 63 && total > 0) base = atomicAdd(&s_listCount, total);
-            base = __shfl(base, 63);
-            int pos = base + incl - n;
-            while (mask) {
-                const int b = __ffs(mask) - 1;
-                mask &= mask - 1;
-                const int r = rbase + wave + 4 * (b >> 2);
-                const int j = jd + (b & 3);
-                s_list[pos++] = (uint16_t)((r << 9) | j);
-            }
+        }
+        // append this thread's survivors to the work list (order is irrelevant)
+        const int n = __popc(acc);
+        const int incl = wave_incl_scan(n, lane);
+        const int total = __shfl(incl, 63);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&s_listCount, total);
+        base = __shfl(base, 63);
+        int pos = base + incl - n;
+        while (acc) {
+            const int b = __ffs(acc) - 1;
+            acc &= acc - 1;
+            const int item = ibase + (b >> 2) * 256 + tid;
+            const int r = (int)(((unsigned)item * gprMagic) >> 20);
+            const int j = jd0 + ((item - r * GPR) << 2) + (b & 3);
+            if (pos < listCap) s_list[pos] = (uint16_t)((r << 9) | j);
+            pos++;
         }
     }
     __syncthreads();
     if (phases < 3) return;
 
-    // ---- 3. full score on the work list ----
+    // ---- 3. full score on the work list; corners -> corner list ----
+    // The lists have a fixed LDS budget.  If a tile has more compass survivors than the work list
+    // holds (noise-like images), every domain pixel is scored instead (the compass test is the
+    // early-out of fast_score_lds); if it has more corners than the corner list holds, phase 4 scans
+    // the score tile.  Both fallbacks produce the same result as the list paths.
     const int nlist = s_listCount;
-    for (int e = tid; e < nlist; e += 256) {
-        const int ent = s_list[e];
-        const int r = ent >> 9, j = ent & 511;
-        const int s = fast_score_lds(s_pix + (r + 3) * pitch + j, pitch, t);
-        if (s > 0) s_score[r * SP + (j - j0)] = (uint8_t)s;
+    if (nlist <= listCap) {
+        for (int e0 = 0; e0 < nlist; e0 += 256) {
+            const int e = e0 + tid;
+            int ent = 0, s = 0;
+            if (e < nlist) {
+                ent = s_list[e];
+                const int r = ent >> 9, j = ent & 511;
+                s = fast_score_lds(s_pix + (r + 3) * pitch + j, pitch, t);
+                if (s > 0) s_score[r * SP + (j - j0)] = (uint8_t)s;
+            }
+            const int slot = wave_append(s > 0, &s_cornerCount, lane);
+            if (slot >= 0 && slot < cornerCap) s_corner[slot] = (uint16_t)ent;
+        }
+    } else {
+        const unsigned twMagic = (1u << 20) / (unsigned)TW + 1u;
+        for (int p0 = 0; p0 < DH * TW; p0 += 256) {
+            const int px = p0 + tid;
+            int ent = 0, s = 0;
+            if (px < DH * TW) {
+                const int r = (int)(((unsigned)px * twMagic) >> 20);
+                const int c = px - r * TW;
+                s = fast_score_lds(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
+                if (s > 0) s_score[r * SP + c] = (uint8_t)s;
+                ent = (r << 9) | (j0 + c);
+            }
+            const int slot = wave_append(s > 0, &s_cornerCount, lane);
+            if (slot >= 0 && slot < cornerCap) s_corner[slot] = (uint16_t)ent;
+        }
     }
     __syncthreads();
     if (phases < 4) return;
 
-    // ---- 4. NMS over scored corners (cell-local neighbourhood), survivors -> bitmap ----
+    // ---- 4. NMS over the corners (cell-local neighbourhood); survivors -> keyed list ----
     const unsigned cellMagic = 65536u / (unsigned)L.wCell + 1u;   // c / wCell for c < 65536 / wCell
-    for (int e = tid; e < nlist; e += 256) {
-        const int ent = s_list[e];
-        const int r = ent >> 9, c = (ent & 511) - j0;
-        const uint8_t *sp = s_score + r * SP + c;
-        const int s = sp[0];
-        if (s == 0) continue;
-        const int cj = (int)(((unsigned)c * cellMagic) >> 16);
-        const int cx0 = cj * L.wCell;
-        int cx1 = cx0 + L.wCell;
-        if (cx1 > TW) cx1 = TW;
-        const bool up = r > 0, dn = r < DH - 1, lf = c > cx0, rt = c < cx1 - 1;
-        int m = 0;
-        if (lf) m = max(m, (int)sp[-1]);
-        if (rt) m = max(m, (int)sp[1]);
-        if (up) {
-            m = max(m, (int)sp[-SP]);
-            if (lf) m = max(m, (int)sp[-SP - 1]);
-            if (rt) m = max(m, (int)sp[-SP + 1]);
+    const int ncorner = s_cornerCount;
+    if (ncorner <= cornerCap) {
+        for (int e0 = 0; e0 < ncorner; e0 += 256) {
+            const int e = e0 + tid;
+            bool surv = false;
+            uint32_t key = 0;
+            if (e < ncorner) {
+                const int ent = s_corner[e];
+                const int r = ent >> 9, c = (ent & 511) - j0;
+                key = nms_key(s_score, SP, r, c, DH, TW, L.wCell, cellMagic, G.iniTh, s_cellAny, surv);
+            }
+            const int slot = wave_append(surv, &s_survCount, lane);
+            if (slot >= 0) s_surv[slot] = key;
         }
-        if (dn) {
-            m = max(m, (int)sp[SP]);
-            if (lf) m = max(m, (int)sp[SP - 1]);
-            if (rt) m = max(m, (int)sp[SP + 1]);
-        }
-        if (s > m) {
-            atomicOr(&s_bitmap[r][c >> 5], 1u << (c & 31));
-            if (s >= G.iniTh) s_cellAny[cj] = 1;   // benign race: every writer stores 1
+    } else {
+        // fallback: scan the score tile, 4 pixels per dword
+        const int SPW = SP >> 2;                                       // score dwords per row
+        const unsigned spwMagic = (1u << 20) / (unsigned)SPW + 1u;
+        const int nwords = DH * SPW;
+        for (int i0 = 0; i0 < nwords; i0 += 256) {
+            const int i = i0 + tid;
+            uint32_t w = i < nwords ? reinterpret_cast<const uint32_t *>(s_score)[i] : 0u;
+            const int r = (int)(((unsigned)(i < nwords ? i : 0) * spwMagic) >> 20);
+            const int cb = ((i < nwords ? i : 0) - r * SPW) << 2;
+            // every lane runs the loop body the same number of times (wave-wide append inside)
+            for (int k = 0; k < 4; k++) {
+                const int s = (w >> (8 * k)) & 0xFF;
+                bool surv = false;
+                uint32_t key = 0;
+                if (__ballot(s > 0) == 0) continue;   // wave-uniform
+                if (s > 0) key = nms_key(s_score, SP, r, cb + k, DH, TW, L.wCell, cellMagic, G.iniTh, s_cellAny, surv);
+                const int slot = wave_append(surv, &s_survCount, lane);
+                if (slot >= 0) s_surv[slot] = key;
+            }
         }
     }
     __syncthreads();
     if (phases < 5) return;
 
-    // ---- 5. per cell: threshold choice, raster-ordered extraction from the bitmap ----
+    // ---- 5. per-cell threshold, rank inside the cell (= raster order), write the slots ----
+    const int nsurv = s_survCount;
     const size_t candFrame = (size_t)frame * G.totalCands + L.candBase;
-    for (int cj = wave; cj < T.ncells; cj += 4) {
-        const int cx0 = cj * L.wCell;
-        int cx1 = cx0 + L.wCell;
-        if (cx1 > TW) cx1 = TW;
-        // a cell whose iniX >= maxBorderX-6 is skipped by the reference (:805); its domain is empty
-        if (cx1 <= cx0) {
-            if (lane == 0) cnt[cj] = 0;
-            continue;
-        }
-        const int thr = s_cellAny[cj] ? G.iniTh : G.minTh;
-        uint32_t *slot = cand + candFrame + (size_t)(T.row * L.nCols + T.c0 + cj) * L.cellCap;
-        int count = 0;
-        for (int rb = 0; rb < DH; rb += 64) {
-            const int r = rb + lane;
-            // this lane's row: kept columns as a 64-bit mask relative to cx0 (cell width <= 64)
-            unsigned long long keep = 0;
-            if (r < DH) {
-                const int w0 = cx0 >> 5;
-                unsigned long long bits = (unsigned long long)s_bitmap[r][w0];
-                bits |= (unsigned long long)s_bitmap[r][w0 + 1] << 32;
-                bits >>= (cx0 & 31);
-                if ((cx0 & 31) && w0 + 2 < FAST_BM_WORDS)
-                    bits |= (unsigned long long)s_bitmap[r][w0 + 2] << (64 - (cx0 & 31));
-                const int cw = cx1 - cx0;
-                if (cw < 64) bits &= (1ull << cw) - 1ull;
-                unsigned long long it = bits;
-                while (it) {
-                    const int b = __ffsll((long long)it) - 1;
-                    it &= it - 1;
-                    if (s_score[r * SP + cx0 + b] >= thr) keep |= 1ull << b;
+    for (int e0 = 0; e0 < nsurv; e0 += 256) {
+        const int e = e0 + tid;
+        if (e < nsurv) {
+            const uint32_t key = s_surv[e];
+            const int cj = key >> 28;
+            const int thr = s_cellAny[cj] ? G.iniTh : G.minTh;
+            const int s = key & 0xFF;
+            if (s >= thr) {
+                // kept survivors of the same cell with a smaller (row, column)
+                int rank = 0;
+                for (int o = 0; o < nsurv; o++) {
+                    const uint32_t ok = s_surv[o];   // same address in every lane: LDS broadcast
+                    rank += ((ok >> 28) == (uint32_t)cj) && ((int)(ok & 0xFF) >= thr) && ((ok >> 8) < (key >> 8));
                 }
-            }
-            const int n = __popcll(keep);
-            int incl = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int u = __shfl_up(incl, o);
-                if (lane >= o) incl += u;
-            }
-            int pos = count + incl - n;
-            while (keep) {
-                const int b = __ffsll((long long)keep) - 1;
-                keep &= keep - 1;
-                const int s = s_score[r * SP + cx0 + b];
-                const int px = X0 + 3 + cx0 + b - ORB_MIN_BORDER;   // relative to (16,16), :824-825
+                atomicAdd(&s_cellCnt[cj], 1);
+                const int r = (key >> 21) & 127, c = (key >> 8) & 0x1FFF;
+                const int px = X0 + 3 + c - ORB_MIN_BORDER;   // relative to (16,16), :824-825
                 const int py = iniY + 3 + r - ORB_MIN_BORDER;
-                slot[pos++] = (uint32_t)px | ((uint32_t)py << 12) | ((uint32_t)s << 24);
+                uint32_t *slot = cand + candFrame + (size_t)(T.row * L.nCols + T.c0 + cj) * L.cellCap;
+                slot[rank] = (uint32_t)px | ((uint32_t)py << 12) | ((uint32_t)s << 24);
             }
-            count += __shfl(incl, 63);
         }
-        if (lane == 0) cnt[cj] = (uint16_t)count;
     }
+    __syncthreads();
+    // cells whose iniX >= maxBorderX-6 are skipped by the reference (:805): their domain is empty -> 0
+    if (tid < T.ncells) cnt[tid] = (uint16_t)s_cellCnt[tid];
 }
 
 void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
@@ -334,10 +424,10 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
                  uint32_t *cand, uint16_t *cellCnt, int B)
 {
     // LDS: pixel tile + score tile + work list of the largest run over all levels
-    int pixBytes = 0, scoreBytes = 0, listBytes = 0;
+    int pixBytes = 0, scoreBytes = 0, listBytes = 0, survBytes = 0;
     for (int l = 0; l < G.nlevels; l++) {
         const OrbLevel &L = G.lv[l];
-        int tileCells = FAST_TILE_CELLS;
+        int tileCells = fast_tile_cells();
         while (tileCells > 1 && tileCells * L.wCell + 6 + 16 > FAST_MAX_TILE_W) tileCells--;
         const int regw = tileCells * L.wCell + 6;
         const int pitch = ((regw + 15 + 15) >> 4) << 4;
@@ -345,13 +435,26 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
         const int sp = (tileCells * L.wCell + 3) & ~3;
         pixBytes = std::max(pixBytes, pitch * rh);
         scoreBytes = std::max(scoreBytes, sp * L.hCell);
+        // work list: u16 per domain pixel; the survivor list (u32 per strict local maximum, at most
+        // a quarter of the pixels plus cell seams) reuses the same storage
         listBytes = std::max(listBytes, sp * L.hCell * 2);
+        survBytes = std::max(survBytes, tileCells * L.cellCap * 4);
     }
     pixBytes = (pixBytes + 15) & ~15;
     scoreBytes = (scoreBytes + 15) & ~15;
+    // fixed list budgets (entries): work list = half of the tile's pixels, corner list = an eighth;
+    // tiles that exceed them take the exact fallback paths.  ORBHIP_FAST_LISTCAP forces tiny lists
+    // (tests exercise the fallbacks with it).
+    static const int forced = getenv("ORBHIP_FAST_LISTCAP") ? atoi(getenv("ORBHIP_FAST_LISTCAP")) : 0;
+    int listCap = listBytes / 4, cornerCap = listBytes / 16;
+    if (forced > 0) listCap = cornerCap = forced;
+    // the survivor list (u32 per strict local maximum, at most survBytes/4 of them) shares the work list
+    listBytes = std::max(listCap * 2, survBytes);
+    listBytes = (listBytes + 15) & ~15;
+    const int cornerBytes = (cornerCap * 2 + 15) & ~15;
     static const int phases = getenv("ORBHIP_FAST_PHASES") ? atoi(getenv("ORBHIP_FAST_PHASES")) : 5;
     dim3 grid(ntiles, B, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(k_fast, grid, block, (size_t)(pixBytes + scoreBytes + listBytes), s, G, lvl0, stride0,
+    hipLaunchKernelGGL(k_fast, grid, block, (size_t)(pixBytes + scoreBytes + listBytes + cornerBytes), s, G, lvl0, stride0,
                        (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tiles, cand, cellCnt,
-                       pixBytes, scoreBytes, phases);
+                       pixBytes, scoreBytes, listBytes, listCap, cornerCap, phases);
 }

@@ -5,12 +5,23 @@
 #include "orbhip_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static inline int cv_round_d(double v) { return (int)lrint(v); }  // SSE2 cvtsd2si: half to even
 static inline int cv_floor_d(double v) { int i = (int)v; return i - (i > v); }
 static inline int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int fast_tile_cells()
+{
+    static const int n = [] {
+        const char *e = getenv("ORBHIP_FAST_TILE_CELLS");
+        int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > FAST_TILE_CELLS ? FAST_TILE_CELLS : v);
+    }();
+    return n;
+}
 
 int orb_init_tables(orbhip_ctx *c, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh)
 {
@@ -159,7 +170,7 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
         L.scale = c->mvScaleFactor[l];
         L.kpSize = (float)(int)(ORB_PATCH_SIZE * c->mvScaleFactor[l]);
         // FAST tiles: runs of cells of one cell-row
-        int tileCells = FAST_TILE_CELLS;
+        int tileCells = fast_tile_cells();
         while (tileCells > 1 && tileCells * L.wCell + 6 + 16 > FAST_MAX_TILE_W) tileCells--;
         if (L.wCell + 6 + 16 > FAST_MAX_TILE_W) return ORBHIP_E_SIZE;
         for (int i = 0; i < L.nRows; i++)

@@ -16,7 +16,8 @@
 #define ORB_MIN_BORDER 16      // EDGE_THRESHOLD-3, :775
 #define ORB_CELL_W 30          // :771
 
-#define FAST_TILE_CELLS 8      // cells of one cell-row handled by one FAST workgroup
+#define FAST_TILE_CELLS 8      // max cells of one cell-row handled by one FAST workgroup
+int fast_tile_cells();        // cells per workgroup actually used (<= FAST_TILE_CELLS; env ORBHIP_FAST_TILE_CELLS)
 #define FAST_MAX_TILE_W 320    // LDS tile width bound (pixels incl. halo, before 16-B rounding)
 #define FAST_MAX_TILE_H 72     // LDS tile height bound (hCell + 6)
 
