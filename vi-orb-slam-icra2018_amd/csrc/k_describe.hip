@@ -50,11 +50,16 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x)
     return a;
 }
 
+// Sum over the 64 lanes, result wave-uniform.  DPP inside each row of 16 lanes (quad swaps, half
+// mirror, mirror), then the four row sums through v_readlane: no LDS round trips.
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
 }
 
 __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
@@ -105,20 +110,30 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         stride = L.stride;
     }
     const uint8_t *center = img + (size_t)cy * stride + cx;
+    // The disc rows are read as aligned dwords: lane -> (row of a group of 7, dword 0..8 of the row),
+    // 5 trips cover the 31 rows; a row needs at most 31 + 3 bytes = 9 dwords.  (A byte gather costs the
+    // texture-address unit 16 cycles per wave instruction; this is 5 coalesced instructions, not 16.)
     int m10 = 0, m01 = 0;
     {
-        const int u = (lane & 31) - ORB_HALF_PATCH;
-        const int half = lane >> 5;
+        const int rsub = lane / 9, di = lane - rsub * 9;
+        const int xs = ((cx - ORB_HALF_PATCH) & ~3) + 4 * di;     // image column of byte 0 of this lane's dword
+        const int u0 = xs - cx;
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = -ORB_HALF_PATCH + 2 * it + half;
-            if (v <= ORB_HALF_PATCH && u <= ORB_HALF_PATCH) {
+        for (int it = 0; it < 5; it++) {
+            const int v = -ORB_HALF_PATCH + it * 7 + rsub;
+            if (lane < 63 && v <= ORB_HALF_PATCH) {
                 const int d = G.umax[v < 0 ? -v : v];
-                if (u >= -d && u <= d) {
-                    const int val = center[v * stride + u];
-                    m10 += u * val;
-                    m01 += v * val;
+                const uint32_t wd = *reinterpret_cast<const uint32_t *>(img + (size_t)(cy + v) * stride + xs);
+                int rs = 0, ru = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int u = u0 + k;
+                    const int val = (u >= -d && u <= d) ? (int)((wd >> (8 * k)) & 0xFF) : 0;
+                    rs += val;
+                    ru += u * val;
                 }
+                m10 += ru;
+                m01 += v * rs;
             }
         }
     }

@@ -29,13 +29,11 @@ __device__ __forceinline__ int hamming256(const uint32_t q[8], const uint32_t r[
 // sequential update of ref: :216-226
 __device__ __forceinline__ void best_update(Best &B, int d, int j)
 {
-    if (d < B.b1) {
-        B.b2 = B.b1;
-        B.b1 = d;
-        B.idx = j;
-    } else if (d < B.b2) {
-        B.b2 = d;
-    }
+    // branch-free form of: if (d < b1) { b2 = b1; b1 = d; idx = j; } else if (d < b2) b2 = d;
+    const bool lt = d < B.b1;
+    B.b2 = lt ? B.b1 : min(B.b2, d);
+    B.idx = lt ? j : B.idx;
+    B.b1 = min(B.b1, d);
 }
 
 // A holds candidates that come BEFORE all of B's in the reference's visiting order.
@@ -52,6 +50,42 @@ __device__ __forceinline__ Best best_merge_ordered(const Best &A, const Best &B)
         R.b2 = min(A.b2, B.b1);
     }
     return R;
+}
+
+// Visits database rows j0..j1-1 in order, four rows per trip so that four wave-uniform (scalar)
+// row loads are in flight while the previous rows are being compared.
+__device__ __forceinline__ void scan_rows(Best &B, const uint32_t Q[8], const uint8_t *__restrict__ db, int j0, int j1)
+{
+    int j = j0;
+    if (j + 4 <= j1) {
+        // software pipeline: the next four rows are requested before the current four are compared
+        uint32_t R[32];
+        {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(db + (size_t)j * 32);
+#pragma unroll
+            for (int k = 0; k < 32; k++) R[k] = row[k];
+        }
+        for (; j + 8 <= j1; j += 4) {
+            const uint32_t *nrow = reinterpret_cast<const uint32_t *>(db + (size_t)(j + 4) * 32);
+            uint32_t N[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) N[k] = nrow[k];
+#pragma unroll
+            for (int u = 0; u < 4; u++) best_update(B, hamming256(Q, R + 8 * u), j + u);
+#pragma unroll
+            for (int k = 0; k < 32; k++) R[k] = N[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) best_update(B, hamming256(Q, R + 8 * u), j + u);
+        j += 4;
+    }
+    for (; j < j1; j++) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(db + (size_t)j * 32);
+        uint32_t R[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) R[k] = row[k];
+        best_update(B, hamming256(Q, R), j);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int nq,
@@ -73,14 +107,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
     Best B = {256, -1, 256};
     const int j0 = split * rowsPerSplit;
     const int j1 = min(ndb, j0 + rowsPerSplit);
-    for (int j = j0; j < j1; j++) {
-        // wave-uniform address: the compiler emits scalar loads (s_load_dwordx8)
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(db + (size_t)j * 32);
-        uint32_t R[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) R[k] = row[k];
-        best_update(B, hamming256(Q, R), j);
-    }
+    scan_rows(B, Q, db, j0, j1);   // wave-uniform addresses: the compiler emits scalar loads
     if (qi < nq) partial[(size_t)split * nq + qi] = make_int4(B.b1, B.idx, B.b2, 0);
 }
 
@@ -154,13 +181,7 @@ __global__ __launch_bounds__(256) void k_knn2_seq(const uint8_t *__restrict__ de
         const uint4 a0 = reinterpret_cast<const uint4 *>(q)[0], a1 = reinterpret_cast<const uint4 *>(q)[1];
         const uint32_t Q[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         const uint8_t *db = desc + (size_t)(b - lag) * cap * 32;
-        for (int j = 0; j < ndb; j++) {
-            const uint32_t *row = reinterpret_cast<const uint32_t *>(db + (size_t)j * 32);
-            uint32_t R[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) R[k] = row[k];
-            best_update(B, hamming256(Q, R), j);
-        }
+        scan_rows(B, Q, db, 0, ndb);
     }
     if (qi < nq) {
         const size_t o = (size_t)b * cap + qi;
