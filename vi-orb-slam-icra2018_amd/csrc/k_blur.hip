@@ -13,16 +13,19 @@
 //   1. raw rows y0-3 .. y0+34 (reflected at the top/bottom), columns x0-16 .. x0+143, into LDS with
 //      16-byte row-coalesced loads; at the left/right image edge the 3 reflected columns are
 //      patched into the halo;
-//   2. row pass: a thread produces 4 adjacent sums from 3 aligned LDS dwords; the sums are at most
-//      257*255 = 65535 and are kept as u16 pairs in LDS;
-//   3. column pass: a thread produces 4 adjacent outputs (one dword store).
+//   2. row pass: v_dot4_u32_u8 on byte windows cut out with v_alignbyte (7 taps = 2 dot4); the sums
+//      are at most 257*255 = 65535 and two vertically adjacent rows share one LDS dword;
+//   3. column pass: 7 taps = 4 v_dot2_u32_u16 on those row pairs, 4 adjacent outputs per thread
+//      (one dword store).  Integer dot instructions on the vector ALU, not MFMA.
 // Bound: HBM (reads and writes one byte per pixel; halo re-reads 38/32 x 160/128).
 #include "orbhip_internal.h"
 
 #define BT_W BLUR_TILE_W
 #define BT_H BLUR_TILE_H
 #define BT_RAWP (BT_W + 32)       // raw pitch: 16 halo bytes each side (16-byte aligned chunks)
-#define BT_ROWS (BT_H + 6)
+#define BT_ROWS (BT_H + 6)       // 38: even, rows are processed in pairs
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
                                               const BlurTile *__restrict__ tiles, int4 kq)
 {
     __shared__ __align__(16) uint8_t s_raw[BT_ROWS][BT_RAWP];
-    __shared__ __align__(16) uint16_t s_row[BT_ROWS][BT_W];
+    __shared__ __align__(16) uint32_t s_pair[BT_ROWS / 2][BT_W];
     const BlurTile T = tiles[blockIdx.x];
     const int frame = blockIdx.y, l = T.level;
     const OrbLevel &L = G.lv[l];
@@ -84,55 +87,64 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
     }
     __syncthreads();
 
-    // ---- 2. row pass: 4 sums per thread from bytes j-3 .. j+6 ----
-    const int k0 = kq.x, k1 = kq.y, k2 = kq.z, k3 = kq.w;  // 18 34 49 55
-    for (int i = tid; i < BT_ROWS * (BT_W / 4); i += 256) {
-        const int r = i >> 5, g = i & 31;
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(&s_raw[r][16 + (g << 2)]);
-        const uint32_t A = p[-1], Bw = p[0], C = p[1];
-        // bytes x-3..x+6 as b[0..9]
-        int b[10];
-        b[0] = (A >> 8) & 0xFF;
-        b[1] = (A >> 16) & 0xFF;
-        b[2] = A >> 24;
-        b[3] = Bw & 0xFF;
-        b[4] = (Bw >> 8) & 0xFF;
-        b[5] = (Bw >> 16) & 0xFF;
-        b[6] = Bw >> 24;
-        b[7] = C & 0xFF;
-        b[8] = (C >> 8) & 0xFF;
-        b[9] = (C >> 16) & 0xFF;
-        uint32_t s[4];
+    // ---- 2. row pass with v_dot4_u32_u8: an item = (pair of raw rows, 4 adjacent columns) ----
+    // the two row sums of a column (each <= 257*255 = 65535) are packed into one dword:
+    // s_pair[rp][x] = H[2rp][x] | H[2rp+1][x] << 16, so that the column pass can use v_dot2_u32_u16
+    const uint32_t k0 = kq.x, k1 = kq.y, k2 = kq.z, k3 = kq.w;  // 18 34 49 55
+    const uint32_t wlo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);   // taps -3..0
+    const uint32_t whi = k2 | (k1 << 8) | (k0 << 16);                // taps +1..+3
+    for (int i = tid; i < (BT_ROWS / 2) * (BT_W / 4); i += 256) {
+        const int rp = i >> 5, g = i & 31;
+        uint32_t h[2][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            s[k] = (uint32_t)(k0 * (b[k] + b[k + 6]) + k1 * (b[k + 1] + b[k + 5]) + k2 * (b[k + 2] + b[k + 4]) +
-                              k3 * b[k + 3]);
-        uint2 o;
-        o.x = s[0] | (s[1] << 16);
-        o.y = s[2] | (s[3] << 16);
-        *reinterpret_cast<uint2 *>(&s_row[r][g << 2]) = o;
+        for (int q = 0; q < 2; q++) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(&s_raw[2 * rp + q][16 + (g << 2)]);
+            const uint32_t A = p[-1], Bw = p[0], C = p[1];   // columns x-4..x-1 | x..x+3 | x+4..x+7
+            // pixel k: taps are bytes k+1..k+7 of the 12-byte stream A|B|C
+            h[q][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Bw, A, 1), wlo,
+                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Bw, 1), whi, 0u, false), false);
+            h[q][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Bw, A, 2), wlo,
+                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Bw, 2), whi, 0u, false), false);
+            h[q][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Bw, A, 3), wlo,
+                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Bw, 3), whi, 0u, false), false);
+            h[q][3] = __builtin_amdgcn_udot4(Bw, wlo, __builtin_amdgcn_udot4(C, whi, 0u, false), false);
+        }
+        uint4 o;
+        o.x = h[0][0] | (h[1][0] << 16);
+        o.y = h[0][1] | (h[1][1] << 16);
+        o.z = h[0][2] | (h[1][2] << 16);
+        o.w = h[0][3] | (h[1][3] << 16);
+        *reinterpret_cast<uint4 *>(&s_pair[rp][g << 2]) = o;
     }
     __syncthreads();
 
-    // ---- 3. column pass ----
+    // ---- 3. column pass with v_dot2_u32_u16: rows r..r+6 are 4 row pairs ----
     const int wvec = w - (w & 3);
     for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
         const int r = i >> 5, g = i & 31;
         const int y = y0 + r, xb = x0 + (g << 2);
         if (y >= h || xb >= w) continue;
-        uint2 q[7];
-#pragma unroll
-        for (int j = 0; j < 7; j++) q[j] = *reinterpret_cast<const uint2 *>(&s_row[r + j][g << 2]);
+        // even r: pairs hold rows (r,r+1)(r+2,r+3)(r+4,r+5)(r+6,-); odd r: (-,r)(r+1,r+2)(r+3,r+4)(r+5,r+6)
+        const bool odd = r & 1;
+        const us2 w0 = odd ? us2{0, (unsigned short)k0} : us2{(unsigned short)k0, (unsigned short)k1};
+        const us2 w1 = odd ? us2{(unsigned short)k1, (unsigned short)k2} : us2{(unsigned short)k2, (unsigned short)k3};
+        const us2 w2 = odd ? us2{(unsigned short)k3, (unsigned short)k2} : us2{(unsigned short)k2, (unsigned short)k1};
+        const us2 w3 = odd ? us2{(unsigned short)k1, (unsigned short)k0} : us2{(unsigned short)k0, 0};
+        const int p0 = r >> 1;
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(&s_pair[p0][g << 2]);
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(&s_pair[p0 + 1][g << 2]);
+        const uint4 q2 = *reinterpret_cast<const uint4 *>(&s_pair[p0 + 2][g << 2]);
+        const uint4 q3 = *reinterpret_cast<const uint4 *>(&s_pair[p0 + 3][g << 2]);
+        const uint32_t c0[4] = {q0.x, q0.y, q0.z, q0.w}, c1[4] = {q1.x, q1.y, q1.z, q1.w};
+        const uint32_t c2[4] = {q2.x, q2.y, q2.z, q2.w}, c3[4] = {q3.x, q3.y, q3.z, q3.w};
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int v7[7];
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const uint32_t wd = (k < 2) ? q[j].x : q[j].y;
-                v7[j] = (k & 1) ? (int)(wd >> 16) : (int)(wd & 0xFFFF);
-            }
-            const int s = k0 * (v7[0] + v7[6]) + k1 * (v7[1] + v7[5]) + k2 * (v7[2] + v7[4]) + k3 * v7[3];
+            uint32_t sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), w0, 0u, false);
+            sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), w1, sum, false);
+            sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), w2, sum, false);
+            sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), w3, sum, false);
+            const int s = (int)sum;
             int v = (s + 32768) >> 16;                                        // round half up
             if (xb + k < wvec && (s & 0xFFFF) == 0x8000 && (v & 1)) v -= 1;   // SSE2 body: ties to even
             v = v > 255 ? 255 : v;
