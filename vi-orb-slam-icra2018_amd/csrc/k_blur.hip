@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
             sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), w1, sum, false);
             sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), w2, sum, false);
             sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), w3, sum, false);
-            const int s = (int)sum;
-            int v = (s + 32768) >> 16;                                        // round half up
-            if (xb + k < wvec && (s & 0xFFFF) == 0x8000 && (v & 1)) v -= 1;   // SSE2 body: ties to even
-            v = v > 255 ? 255 : v;
-            packed |= (uint32_t)v << (8 * k);
+            // SSE2 body (x < wvec): round half to even = (s + 0x7FFF + bit16(s)) >> 16;
+            // scalar tail: round half up = (s + 0x8000) >> 16
+            const uint32_t bias = (xb + k < wvec) ? 0x7FFFu + ((sum >> 16) & 1u) : 0x8000u;
+            const uint32_t v = min((sum + bias) >> 16, 255u);
+            packed |= v << (8 * k);
         }
         uint8_t *o = dst + (size_t)y * dstride + xb;
         if (xb + 3 < w)

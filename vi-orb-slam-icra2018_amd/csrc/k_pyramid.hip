@@ -40,44 +40,45 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
             *reinterpret_cast<uint4 *>(&s_src[r][c << 4]) = v;
         }
     }
-    __syncthreads();
+    // this thread's taps are requested before the barrier so that their latency overlaps the staging
     const int gx = ox0 + ((tid & 31) << 2);
     const int dy = oy0 + (tid >> 5);
-    if (gx >= dw || dy >= dh) return;
-    const int4 yt = ytab[dy];
+    const bool active = gx < dw && dy < dh;
+    int4 yt = make_int4(0, 0, 0, 0);
+    int2 xt[4] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
+    if (active) {
+        yt = ytab[dy];
+#pragma unroll
+        for (int k = 0; k < 4; k++) xt[k] = xtab[min(gx + k, dw - 1)];
+    }
+    __syncthreads();
+    if (!active) return;
     const int b0 = yt.z, b1 = yt.w;
     uint32_t packed = 0;
-    if (nch <= RZ_MAXCH && nrows <= RZ_MAXROWS) {
-        const uint8_t *S0 = &s_src[yt.x - symin][0] - XA;
-        const uint8_t *S1 = &s_src[yt.y - symin][0] - XA;
+    const bool staged = nch <= RZ_MAXCH && nrows <= RZ_MAXROWS;
+    if (staged) {
+        const uint8_t *L0 = &s_src[yt.x - symin][0];
+        const uint8_t *L1 = &s_src[yt.y - symin][0];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int dx = gx + k;
-            if (dx < dw) {
-                const int2 xt = xtab[dx];
-                const int sx0 = xt.x & 0xFFFF, sx1 = (unsigned)xt.x >> 16;
-                const int a0 = (short)(xt.y & 0xFFFF), a1 = xt.y >> 16;
-                const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
-                const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
-                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                packed |= (uint32_t)(v & 0xFF) << (8 * k);
-            }
+            const int sx0 = (xt[k].x & 0xFFFF) - XA, sx1 = (int)((unsigned)xt[k].x >> 16) - XA;
+            const int a0 = (short)(xt[k].y & 0xFFFF), a1 = xt[k].y >> 16;
+            const int r0 = L0[sx0] * a0 + L0[sx1] * a1;
+            const int r1 = L1[sx0] * a0 + L1[sx1] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * k);
         }
     } else {
-        // generic path (scale factors far from 1.2 whose source window exceeds the LDS tile)
+        // generic path (scale factors far from 1.2 whose source window exceeds the LDS tile): read global
         const uint8_t *S0 = S + (size_t)yt.x * sstride;
         const uint8_t *S1 = S + (size_t)yt.y * sstride;
         for (int k = 0; k < 4; k++) {
-            const int dx = gx + k;
-            if (dx < dw) {
-                const int2 xt = xtab[dx];
-                const int sx0 = xt.x & 0xFFFF, sx1 = (unsigned)xt.x >> 16;
-                const int a0 = (short)(xt.y & 0xFFFF), a1 = xt.y >> 16;
-                const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
-                const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
-                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                packed |= (uint32_t)(v & 0xFF) << (8 * k);
-            }
+            const int sx0 = xt[k].x & 0xFFFF, sx1 = (unsigned)xt[k].x >> 16;
+            const int a0 = (short)(xt[k].y & 0xFFFF), a1 = xt[k].y >> 16;
+            const int r0 = S0[sx0] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx0] * a0 + S1[sx1] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * k);
         }
     }
     uint8_t *o = D + (size_t)dy * dstride + gx;
