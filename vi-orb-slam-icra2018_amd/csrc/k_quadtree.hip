@@ -6,6 +6,8 @@
 #include "orbhip_internal.h"
 #include "quadtree_core.h"
 
+#include <cstdlib>
+
 struct QtBlock {
     int *wtot;  // [4] LDS
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
@@ -18,7 +20,8 @@ struct QtBlock {
     __device__ int scan_exclusive(int *a, int n) const
     {
         const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-        const int K = (n + 255) >> 8;
+        const int nt = blockDim.x;
+        const int K = (n + nt - 1) / nt;
         const int beg = min(t * K, n), end = min(beg + K, n);
         int sum = 0;
         for (int i = beg; i < end; i++) sum += a[i];
@@ -31,7 +34,7 @@ struct QtBlock {
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
         int base = 0, total = 0;
-        for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
             const int v = wtot[w];
             if (w < wave) base += v;
             total += v;
@@ -66,13 +69,13 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbLevels G, const uint3
     int *cellOff = reinterpret_cast<int *>(smem + qtBytes);
     const int ncells = L.nCols * L.nRows;
     const uint16_t *cc = cellCnt + (size_t)frame * G.totalCells + L.cellBase;
-    for (int c = tid; c < ncells; c += 256) cellOff[c] = cc[c];
+    for (int c = tid; c < ncells; c += blockDim.x) cellOff[c] = cc[c];
     __syncthreads();
     const int n = x.scan_exclusive(cellOff, ncells);
     const uint32_t *slots = cand + (size_t)frame * G.totalCands + L.candBase;
     uint32_t *P = pts + (size_t)frame * G.totalPts + L.ptBase;
     uint32_t *PN = pnode + (size_t)frame * G.totalPts + L.ptBase;
-    for (int c = tid; c < ncells; c += 256) {
+    for (int c = tid; c < ncells; c += blockDim.x) {
         const int k = cc[c], o = cellOff[c];
         const uint32_t *src = slots + (size_t)c * L.cellCap;
         for (int j = 0; j < k; j++) P[o + j] = src[j];
@@ -113,7 +116,8 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     int maxNodes = 0;
     for (int l = 0; l < G.nlevels; l++) maxNodes = std::max(maxNodes, G.lv[l].kpCap);
     const int qtBytes = (int)((qt_shared_bytes(maxNodes) + 15) & ~(size_t)15);
-    dim3 grid(G.nlevels, B, 1), block(256, 1, 1);
+    static const int nthreads = getenv("ORBHIP_QT_THREADS") ? atoi(getenv("ORBHIP_QT_THREADS")) : 256;
+    dim3 grid(G.nlevels, B, 1), block(nthreads, 1, 1);
     hipLaunchKernelGGL(k_quadtree, grid, block, quadtree_lds_bytes(G), s, G, cand, cellCnt, pts, pnode,
                        lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes);
 }

@@ -165,6 +165,9 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
         return nullptr;
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int i = 0; i < 3; i++)
+        if ((e = hipEventCreate(&c->evx[i])) != hipSuccess) return bail("hipEventCreate", e);
     for (int i = 0; i < 8; i++)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
     // size everything for the largest image now, so per-frame calls never allocate
@@ -191,6 +194,9 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (int i = 0; i < 8; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 3; i++)
+        if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -263,17 +269,23 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
                       c->d_resizeTab + c->resizeTabOff[l][1], B);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
-    // E3 FAST, E4 quadtree (orientation is folded into the describe kernel)
+    // E3 FAST alone on the device (it is the kernel whose roofline is reported), then the quadtree
+    // (latency-bound, a few thousand workgroups) and the blur (streaming) run CONCURRENTLY on two
+    // streams: both only depend on the pyramid / the FAST output; the describe kernel joins them.
     launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles,
                 (int)c->fastTiles.size(), c->d_cand, c->d_cellCnt, B);
     HIPCHK(c, hipEventRecord(c->ev[2], s));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
+    HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+    launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
+    HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
     launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
                     c->d_lvlKpCnt, B);
     HIPCHK(c, hipEventRecord(c->ev[3], s));
-    // E6 blur, E5+E7+E8 describe
-    launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
+    HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
     HIPCHK(c, hipEventRecord(c->ev[4], s));
+    // E5+E7+E8 describe
     launch_describe(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
                     c->lvl0FrameBytes + c->pyrFrameBytes, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, d_kps,
                     d_desc, d_counts, cap, B);
@@ -293,8 +305,14 @@ extern "C" int orbhip_get_stage_times(orbhip_ctx *c, float ms[6])
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 6; i++) ms[i] = 0.f;
-    if (c->haveStageEvents)
-        for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    if (c->haveStageEvents) {
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));    // pyramid
+        HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));    // FAST
+        HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]));    // quadtree (overlaps the blur)
+        HIPCHK(c, hipEventElapsedTime(&ms[3], c->evx[1], c->evx[2]));  // blur (second stream)
+        HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[4], c->ev[5]));    // describe
+    }
     if (c->haveMatchEvents) HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[6], c->ev[7]));
     return ORBHIP_OK;
 }

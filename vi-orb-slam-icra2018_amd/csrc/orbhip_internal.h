@@ -72,6 +72,8 @@ struct BlurTile {
 struct orbhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // blur runs here, concurrently with the quadtree kernel
+    hipEvent_t evx[3] = {nullptr, nullptr, nullptr};   // FAST done | blur start | blur end
     std::string err;
 
     // constructor tables (E0)
