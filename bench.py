@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
-    ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=1000, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
