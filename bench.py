@@ -74,9 +74,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ORBHIP_BENCH_FORCE_DIST"):   # the env var exercises the N>1 code path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from orbhip import synth
@@ -101,7 +102,7 @@ def main():
 
     # vocabulary blob broadcast over xGMI (RCCL) once at start-up: reference binary layout
     # (TemplatedVocabulary.h:1727-1751), synthetic content of the stock size (~44 MB)
-    if world > 1:
+    if dist is not None:
         nb_nodes = 1082073
         blob = torch.zeros(24 + nb_nodes * 41, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -145,6 +146,7 @@ def main():
     counts = d_cnt.cpu().numpy()
     matched = int(((d_bd.cpu().numpy()[1:] <= 50)).sum()) if B > 1 else 0
 
+    out = None
     if rank == 0:
         fps = world * B * args.steps / dt
         alg = fast_algorithmic_bytes(W, H, 8, ex.level_size) * B          # bytes per FAST launch
@@ -172,10 +174,14 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(uniq, args.cpu_frames)
             out["speedup_vs_cpu_1core"] = round(fps / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
     ex.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout (RCCL prints its own banner lines earlier)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
