@@ -180,6 +180,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST thing on stdout (RCCL prints its own banner lines earlier)
+        C.CDLL(None).fflush(None)      # libc-buffered banner text of RCCL / the HIP runtime goes out first
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
