@@ -175,6 +175,36 @@ int orbhip_search_by_bow(orbhip_ctx *ctx, const uint8_t *desc1, int n1, const ui
                          float nnratio, int check_ori, int32_t *match12, int32_t *match21,
                          int *nmatches);
 
+/* ---- ORB vocabulary ----
+ * Replaces ORBVocabulary::loadFromBinaryFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1680-1721,
+ * called from src/System.cc:336-339): parses the binary vocabulary (header u32 nb_nodes, u32 size_node=41,
+ * i32 k, L, scoring, weighting; then per node i32 parent, u8 desc[32], f32 weight, u8 is_leaf) and keeps
+ * it as device tables in the context.  _device: the blob is already in device memory (e.g. after
+ * orbhip_bcast_blob_device); it is copied back once for parsing. */
+int orbhip_vocab_load(orbhip_ctx *ctx, const void *blob, size_t nbytes);
+int orbhip_vocab_load_device(orbhip_ctx *ctx, const void *d_blob, size_t nbytes);
+int orbhip_vocab_info(const orbhip_ctx *ctx, int *k, int *L, int *scoring, int *weighting, int *nnodes,
+                      int *nwords);
+/* Replaces the per-feature ORBVocabulary::transform (TemplatedVocabulary.h:1443-1485) as used by
+ * Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:739-746, src/KeyFrame.cc:392-400): word id and
+ * weight of the leaf reached, node id at level L - levelsup (0 if that level is <= 0).  The caller builds
+ * BowVector (sum of weights per word, normalised) and FeatureVector (indices per node, weight > 0 only)
+ * from these arrays. */
+int orbhip_vocab_transform(orbhip_ctx *ctx, const uint8_t *desc, int n, int levelsup, int32_t *word_id,
+                           float *weight, int32_t *node_id);
+int orbhip_vocab_transform_device(orbhip_ctx *ctx, const void *d_desc, int n, int levelsup, void *d_word_id,
+                                  void *d_weight, void *d_node_id);
+/* Batched SearchByBoW (src/ORBmatcher.cc:159-288 / :522-655 with th_mode 0 / 1) for a sequence on the
+ * device, laid out like the outputs of orbhip_extract_batch_device; d_node / d_weight [B*cap] from
+ * orbhip_vocab_transform_device; d_valid [B*cap] bytes ("has a good MapPoint") or NULL = all valid.
+ * For b >= lag side 1 is set b-lag (the key frame) and side 2 is set b; d_match12[b*cap + i1] = matched
+ * side-2 feature or -1, d_match21[b*cap + i2] = matched side-1 feature or -1, d_nmatches[b] = the
+ * reference routine's return value.  TH_LOW = 50.  One launch for all B pairs. */
+int orbhip_search_by_bow_seq_device(orbhip_ctx *ctx, const void *d_desc, const void *d_kps, const void *d_counts,
+                                    const void *d_node, const void *d_weight, const void *d_valid, int cap,
+                                    int B, int lag, int th_mode, float nnratio, int check_ori, void *d_match12,
+                                    void *d_match21, void *d_nmatches);
+
 /* Device time of the stages of the last extract call on this context, in ms:
  * {pyramid, FAST, quadtree, blur, describe} and, at [5], of the last orbhip_hamming_knn2*_device
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */

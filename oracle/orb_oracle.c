@@ -1091,3 +1091,199 @@ int orbo_search_by_bow(const uint8_t *desc1, int n1, const uint8_t *valid1, cons
     for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Next row: ORB vocabulary tree -- load, per-feature transform, BowVector.
+ * ref: Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1680-1721 (load), :1443-1485 (transform),
+ * :1167-1258 (feature-set transform), BowVector.cpp:34-86, FORB.cpp:82-103 (distance = Hamming).
+ * ---------------------------------------------------------------------------------------- */
+struct orbo_vocab {
+    int k, L, scoring, weighting;
+    int nnodes;           /* including the root (id 0) */
+    int nwords;
+    int32_t *parent;      /* [nnodes] */
+    uint8_t *desc;        /* [nnodes][32] */
+    float *weight;        /* [nnodes] */
+    uint8_t *leaf;        /* [nnodes] */
+    int32_t *word;        /* [nnodes] word id of a leaf, -1 otherwise */
+    int32_t *child_off;   /* [nnodes + 1] */
+    int32_t *child;       /* children in file order */
+};
+
+orbo_vocab *orbo_vocab_load(const void *blob, size_t nbytes)
+{
+    const uint8_t *b = (const uint8_t *)blob;
+    if (!b || nbytes < 24) return NULL;
+    uint32_t nb_nodes, size_node;
+    int32_t hdr[4];
+    memcpy(&nb_nodes, b, 4);
+    memcpy(&size_node, b + 4, 4);
+    memcpy(hdr, b + 8, 16);
+    if (size_node != 41 || nb_nodes < 1) return NULL;
+    const size_t n = (nbytes - 24) / 41;
+    if (n != (size_t)nb_nodes - 1) return NULL;
+    orbo_vocab *v = (orbo_vocab *)calloc(1, sizeof(*v));
+    v->k = hdr[0];
+    v->L = hdr[1];
+    v->scoring = hdr[2];
+    v->weighting = hdr[3];
+    v->nnodes = (int)nb_nodes;
+    v->parent = (int32_t *)calloc(nb_nodes, 4);
+    v->desc = (uint8_t *)calloc(nb_nodes, 32);
+    v->weight = (float *)calloc(nb_nodes, 4);
+    v->leaf = (uint8_t *)calloc(nb_nodes, 1);
+    v->word = (int32_t *)malloc(4 * (size_t)nb_nodes);
+    v->child_off = (int32_t *)calloc((size_t)nb_nodes + 1, 4);
+    v->child = (int32_t *)calloc(nb_nodes, 4);
+    int *cnt = (int *)calloc(nb_nodes, sizeof(int));
+    for (uint32_t id = 1; id < nb_nodes; id++) {
+        const uint8_t *r = b + 24 + (size_t)(id - 1) * 41;
+        memcpy(&v->parent[id], r, 4);
+        memcpy(v->desc + (size_t)id * 32, r + 4, 32);
+        memcpy(&v->weight[id], r + 36, 4);
+        v->leaf[id] = r[40] ? 1 : 0;
+        if (v->parent[id] < 0 || v->parent[id] >= (int32_t)nb_nodes) {
+            free(cnt);
+            orbo_vocab_free(v);
+            return NULL;
+        }
+        cnt[v->parent[id]]++;
+    }
+    for (uint32_t i = 0; i < nb_nodes; i++) v->child_off[i + 1] = v->child_off[i] + cnt[i];
+    memset(cnt, 0, sizeof(int) * nb_nodes);
+    int nw = 0;
+    for (uint32_t id = 0; id < nb_nodes; id++) v->word[id] = -1;
+    for (uint32_t id = 1; id < nb_nodes; id++) {
+        const int p = v->parent[id];
+        v->child[v->child_off[p] + cnt[p]++] = (int32_t)id;   /* push_back in file order, :1703 */
+        if (v->leaf[id]) v->word[id] = nw++;                  /* :1707-1712 */
+    }
+    v->nwords = nw;
+    free(cnt);
+    return v;
+}
+
+void orbo_vocab_free(orbo_vocab *v)
+{
+    if (!v) return;
+    free(v->parent);
+    free(v->desc);
+    free(v->weight);
+    free(v->leaf);
+    free(v->word);
+    free(v->child_off);
+    free(v->child);
+    free(v);
+}
+
+int orbo_vocab_info(const orbo_vocab *v, int *k, int *L, int *scoring, int *weighting, int *nnodes, int *nwords)
+{
+    if (!v) return -1;
+    if (k) *k = v->k;
+    if (L) *L = v->L;
+    if (scoring) *scoring = v->scoring;
+    if (weighting) *weighting = v->weighting;
+    if (nnodes) *nnodes = v->nnodes;
+    if (nwords) *nwords = v->nwords;
+    return 0;
+}
+
+void orbo_vocab_transform(const orbo_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *word_id,
+                          float *weight, int32_t *node_id)
+{
+    const int nid_level = v->L - levelsup;
+    for (int i = 0; i < n; i++) {
+        const uint8_t *f = desc + (size_t)i * 32;
+        int nid = 0;             /* "root" when nid_level <= 0 (:1454); also when the level is never reached */
+        int final_id = 0, current_level = 0;
+        do {                     /* :1459-1480 */
+            ++current_level;
+            const int c0 = v->child_off[final_id], c1 = v->child_off[final_id + 1];
+            if (c0 == c1) break; /* malformed tree: inner node without children */
+            final_id = v->child[c0];
+            int best_d = orbo_descriptor_distance(f, v->desc + (size_t)final_id * 32);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = v->child[c];
+                const int d = orbo_descriptor_distance(f, v->desc + (size_t)id * 32);
+                if (d < best_d) {
+                    best_d = d;
+                    final_id = id;
+                }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (!v->leaf[final_id]);
+        word_id[i] = v->word[final_id];
+        weight[i] = v->weight[final_id];
+        node_id[i] = nid;
+    }
+}
+
+typedef struct {
+    int32_t w;
+    double val;
+} bow_ent;
+
+static int bow_cmp(const void *a, const void *b)
+{
+    const bow_ent *x = (const bow_ent *)a, *y = (const bow_ent *)b;
+    return x->w < y->w ? -1 : (x->w > y->w ? 1 : 0);
+}
+
+int orbo_vocab_bow(const orbo_vocab *v, const int32_t *word_id, const float *weight, int n, int32_t *out_word,
+                   double *out_value)
+{
+    /* weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring: 0 L1_NORM 1 L2_NORM 2 CHI_SQUARE 3 KL
+     * 4 BHATTACHARYYA 5 DOT_PRODUCT (BowVector.h enums) */
+    const int accumulate = (v->weighting == 0 || v->weighting == 1);
+    const int must = v->scoring != 5;
+    const int l2 = v->scoring == 1;
+    bow_ent *e = (bow_ent *)malloc(sizeof(bow_ent) * (size_t)(n + 1));
+    int m = 0;
+    /* stable accumulation in ascending feature order: sort (word, index) then sum runs in index order */
+    int *order = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    int cnt = 0;
+    for (int i = 0; i < n; i++)
+        if (weight[i] > 0 && word_id[i] >= 0) order[cnt++] = i; /* "not stopped", :1334 */
+    /* insertion into a std::map keyed by word: equivalent to sorting by word, keeping index order */
+    for (int a = 1; a < cnt; a++) {
+        int x = order[a], b = a - 1;
+        while (b >= 0 && word_id[order[b]] > word_id[x]) {
+            order[b + 1] = order[b];
+            b--;
+        }
+        order[b + 1] = x;
+    }
+    for (int a = 0; a < cnt; a++) {
+        const int i = order[a];
+        if (m > 0 && e[m - 1].w == word_id[i]) {
+            if (accumulate) e[m - 1].val += (double)weight[i]; /* addWeight; addIfNotExist keeps the first */
+        } else {
+            e[m].w = word_id[i];
+            e[m].val = (double)weight[i];
+            m++;
+        }
+    }
+    free(order);
+    if (accumulate && m > 0 && !must) { /* :1226-1232 */
+        const double nd = (double)m;
+        for (int a = 0; a < m; a++) e[a].val /= nd;
+    }
+    if (must) { /* BowVector::normalize */
+        double norm = 0.0;
+        if (!l2)
+            for (int a = 0; a < m; a++) norm += fabs(e[a].val);
+        else {
+            for (int a = 0; a < m; a++) norm += e[a].val * e[a].val;
+            norm = sqrt(norm);
+        }
+        if (norm > 0.0)
+            for (int a = 0; a < m; a++) e[a].val /= norm;
+    }
+    qsort(e, (size_t)m, sizeof(bow_ent), bow_cmp); /* already sorted; keeps the contract explicit */
+    for (int a = 0; a < m; a++) {
+        out_word[a] = e[a].w;
+        out_value[a] = e[a].val;
+    }
+    free(e);
+    return m;
+}

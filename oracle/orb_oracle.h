@@ -126,6 +126,26 @@ int orbo_search_by_bow(const uint8_t *desc1, int n1, const uint8_t *valid1, cons
 /* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1629-1670) on bin sizes. */
 void orbo_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 
+/* ---- next row: ORB vocabulary tree ----
+ * Binary format of Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1680-1751 (loadFromBinaryFile /
+ * saveToBinaryFile): u32 nb_nodes, u32 size_node(=41), i32 k, i32 L, i32 scoring, i32 weighting, then per
+ * node id 1..nb_nodes-1: i32 parent, u8 desc[32], f32 weight, u8 is_leaf.  Children keep file order;
+ * words are numbered in the order their leaves appear. */
+typedef struct orbo_vocab orbo_vocab;
+orbo_vocab *orbo_vocab_load(const void *blob, size_t nbytes);
+void orbo_vocab_free(orbo_vocab *v);
+int orbo_vocab_info(const orbo_vocab *v, int *k, int *L, int *scoring, int *weighting, int *nnodes, int *nwords);
+/* Per-feature transform, TemplatedVocabulary.h:1443-1485: descend from the root, at every level take
+ * the child with the smallest Hamming distance (first wins ties); word id and weight of the leaf;
+ * node id at level L - levelsup (0 when that level is <= 0 or is never reached). */
+void orbo_vocab_transform(const orbo_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *word_id,
+                          float *weight, int32_t *node_id);
+/* BowVector of a feature set (TemplatedVocabulary.h:1167-1258, BowVector.cpp:34-86), features visited in
+ * ascending index order (canonical): out_word/out_value sorted by word id; returns
+ * the number of entries (<= n). */
+int orbo_vocab_bow(const orbo_vocab *v, const int32_t *word_id, const float *weight, int n, int32_t *out_word,
+                   double *out_value);
+
 #ifdef __cplusplus
 }
 #endif

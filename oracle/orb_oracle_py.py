@@ -87,6 +87,14 @@ def lib():
         L.orbo_search_by_bow.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
                                          vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
                                          C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]
+        L.orbo_vocab_load.argtypes = [vp, C.c_size_t]
+        L.orbo_vocab_load.restype = vp
+        L.orbo_vocab_free.argtypes = [vp]
+        L.orbo_vocab_free.restype = None
+        L.orbo_vocab_info.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p]
+        L.orbo_vocab_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.orbo_vocab_transform.restype = None
+        L.orbo_vocab_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp]
         _lib = L
     return _lib
 
@@ -299,3 +307,56 @@ def search_by_bow(desc1, valid1, angle1, groups1, desc2, valid2, angle2, groups2
                                  _p(desc2), n2, _p(valid2), _p(angle2), _p(g2[0]), _p(g2[1]), _p(g2[2]), len(g2[0]),
                                  th, th_mode, nnratio, 1 if check_ori else 0, _p(m12), _p(m21))
     return n, m12, m21
+
+
+class Vocabulary:
+    """ORBVocabulary (include/ORBVocabulary.h) over the oracle: loadFromBinaryFile + transform."""
+
+    def __init__(self, blob):
+        blob = bytes(blob)
+        self._h = lib().orbo_vocab_load(blob, len(blob))
+        if not self._h:
+            raise ValueError("bad vocabulary blob")
+        vals = [C.c_int32() for _ in range(6)]
+        lib().orbo_vocab_info(self._h, *[C.byref(v) for v in vals])
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = [v.value for v in vals]
+
+    def close(self):
+        if self._h:
+            lib().orbo_vocab_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        w = np.empty(n, np.int32)
+        wt = np.empty(n, np.float32)
+        nid = np.empty(n, np.int32)
+        lib().orbo_vocab_transform(self._h, _p(desc), n, levelsup, _p(w), _p(wt), _p(nid))
+        return w, wt, nid
+
+    def bow(self, word, weight):
+        word = np.ascontiguousarray(word, np.int32)
+        weight = np.ascontiguousarray(weight, np.float32)
+        ow = np.empty(len(word) + 1, np.int32)
+        ov = np.empty(len(word) + 1, np.float64)
+        m = lib().orbo_vocab_bow(self._h, _p(word), _p(weight), len(word), _p(ow), _p(ov))
+        return ow[:m].copy(), ov[:m].copy()
+
+
+def feature_vector(node_id, weight=None):
+    """DBoW2::FeatureVector in CSR form from per-feature node ids (ascending index inside a node);
+    features with weight <= 0 are "stopped" and left out (TemplatedVocabulary.h:1334-1338)."""
+    node_id = np.asarray(node_id)
+    keep = np.arange(len(node_id)) if weight is None else np.nonzero(np.asarray(weight) > 0)[0]
+    ids = sorted(set(int(v) for v in node_id[keep]))
+    lists = [keep[node_id[keep] == k] for k in ids]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
+    idx = (np.concatenate(lists) if lists else np.zeros(0)).astype(np.int32)
+    return np.array(ids, np.int32), off, idx

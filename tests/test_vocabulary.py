@@ -1,0 +1,146 @@
+"""ORB vocabulary tree: the oracle against a definition-level Python model
+on CPU; the HIP transform and the batched SearchByBoW against the oracle on the GPU."""
+import numpy as np
+import pytest
+
+
+def _py_transform(voc, feat, levelsup):
+    """TemplatedVocabulary.h:1443-1485 with python ints; voc = unpack_vocabulary(blob)."""
+    nodes = voc["nodes"]
+    n = len(nodes) + 1
+    children = [[] for _ in range(n)]
+    for i, p in enumerate(nodes["parent"]):
+        children[int(p)].append(i + 1)
+    word = {}
+    for i, leaf in enumerate(nodes["leaf"]):
+        if leaf:
+            word[i + 1] = len(word)
+    nid_level = voc["L"] - levelsup
+    final_id, level, nid = 0, 0, 0
+    while True:
+        level += 1
+        best = None
+        for c in children[final_id]:
+            d = int(np.unpackbits(nodes["desc"][c - 1] ^ feat).sum())
+            if best is None or d < best:
+                best, nxt = d, c
+        final_id = nxt
+        if level == nid_level:
+            nid = final_id
+        if nodes["leaf"][final_id - 1]:
+            break
+    return word[final_id], float(nodes["weight"][final_id - 1]), nid
+
+
+def test_oracle_vocabulary_matches_python_model(oracle):
+    from orbhip import distributed as D, synth
+    blob = D.make_synthetic_vocabulary(5, k=4, L=3)
+    voc = D.unpack_vocabulary(blob)
+    V = oracle.Vocabulary(blob)
+    assert (V.k, V.L, V.nnodes, V.nwords) == (4, 3, 1 + 4 + 16 + 64, 64)
+    desc = synth.make_descriptor_db(6, 60)
+    desc[7] = voc["nodes"]["desc"][30]                      # exact hit on an inner/leaf node descriptor
+    for levelsup in (0, 1, 2, 3, 5):
+        w, wt, nid = V.transform(desc, levelsup)
+        for i in range(len(desc)):
+            assert (int(w[i]), float(wt[i]), int(nid[i])) == _py_transform(voc, desc[i], levelsup)
+    # BowVector: TF-IDF accumulation + L1 normalisation
+    w, wt, nid = V.transform(desc, 1)
+    bw, bv = V.bow(w, wt)
+    acc = {}
+    for i in range(len(desc)):
+        acc[int(w[i])] = acc.get(int(w[i]), 0.0) + float(wt[i])
+    keys = sorted(acc)
+    norm = sum(abs(acc[k]) for k in keys)
+    assert list(bw) == keys and np.allclose(bv, [acc[k] / norm for k in keys], rtol=0, atol=1e-15)
+    assert abs(bv.sum() - 1.0) < 1e-12
+    with pytest.raises(ValueError):
+        oracle.Vocabulary(blob[:-3])
+
+
+@pytest.mark.gpu
+def test_hip_vocab_transform_matches_oracle(oracle):
+    from orbhip import distributed as D, synth
+    from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    ex = ORBextractor(300, max_w=320, max_h=240)
+    for (k, L, seed) in [(10, 3, 11), (4, 5, 12), (10, 4, 13)]:
+        blob = D.make_synthetic_vocabulary(seed, k=k, L=L)
+        ref = oracle.Vocabulary(blob)
+        voc = ORBVocabulary(ex)
+        voc.loadFromBinaryBlob(blob)
+        assert (voc.k, voc.L, voc.nnodes, voc.nwords) == (ref.k, ref.L, ref.nnodes, ref.nwords)
+        desc = synth.make_descriptor_db(seed + 100, 3000)
+        for levelsup in (0, 2, L - 2, L, L + 3):
+            w, wt, nid = voc.transform_raw(desc, levelsup)
+            rw, rwt, rnid = ref.transform(desc, levelsup)
+            assert np.array_equal(w, rw) and np.array_equal(wt, rwt) and np.array_equal(nid, rnid)
+        (bw, bv), fv = voc.transform(desc[:500], 2)
+        rw, rwt, rnid = ref.transform(desc[:500], 2)
+        obw, obv = ref.bow(rw, rwt)
+        assert np.array_equal(bw, obw) and np.array_equal(bv, obv)        # doubles, same summation order
+        ofv = oracle.feature_vector(rnid, rwt)
+        assert all(np.array_equal(a, b) for a, b in zip(fv, ofv))
+    from orbhip.capi import OrbHipError
+    with pytest.raises(OrbHipError):
+        ORBVocabulary(ex).loadFromBinaryBlob(blob[:100])
+    ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th_mode", [0, 1])
+def test_hip_batched_search_by_bow_matches_oracle(oracle, th_mode):
+    """extract_batch_device -> vocab_transform_device -> search_by_bow_seq_device, all resident on the
+    device, against extractor + vocabulary + SearchByBoW of the oracle, frame pair by frame pair."""
+    import ctypes as C
+    import hiprt
+    from orbhip import distributed as D, synth
+    from orbhip.capi import check
+    from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    B, W, H = 4, 640, 480
+    frames = synth.make_frames(70, W, H, B)
+    blob = D.make_synthetic_vocabulary(71, k=10, L=3)           # level L - 1 = 2 -> up to 100 nodes
+    ex = ORBextractor(1000, max_w=W, max_h=H, max_batch=B)
+    ORBVocabulary(ex).loadFromBinaryBlob(blob)
+    cap = ex.cap
+    d_img = hiprt.DevBuf.from_numpy(frames)
+    d_kps, d_desc, d_cnt = hiprt.DevBuf(B * cap * 28), hiprt.DevBuf(B * cap * 32), hiprt.DevBuf(B * 4)
+    d_word, d_wt, d_node = hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * cap * 4)
+    d_m12, d_m21, d_nm = hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * 4)
+    rng = np.random.default_rng(72)
+    valid = (rng.random((B, cap)) < 0.85).astype(np.uint8)
+    d_valid = hiprt.DevBuf.from_numpy(valid)
+    L = ex._L
+    ex.extract_batch_device(d_img.ptr, B, W, H, W, H * W, d_kps.ptr, d_desc.ptr, cap, d_cnt.ptr)
+    check(L.orbhip_vocab_transform_device(ex.handle, d_desc.ptr, B * cap, 1, d_word.ptr, d_wt.ptr, d_node.ptr), ex.handle)
+    for check_ori in (1, 0):
+        check(L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.ptr, d_kps.ptr, d_cnt.ptr, d_node.ptr, d_wt.ptr,
+                                                d_valid.ptr, cap, B, 1, th_mode, C.c_float(0.7), check_ori, d_m12.ptr,
+                                                d_m21.ptr, d_nm.ptr), ex.handle, "search_by_bow_seq")
+        ex.sync()
+        cnt = d_cnt.to_numpy(np.int32, (B,))
+        m12 = d_m12.to_numpy(np.int32, (B, cap))
+        m21 = d_m21.to_numpy(np.int32, (B, cap))
+        nm = d_nm.to_numpy(np.int32, (B,))
+        refx = oracle.Extractor(1000)
+        refv = oracle.Vocabulary(blob)
+        feats = []
+        for b in range(B):
+            k, d = refx(frames[b])
+            w, wt, nid = refv.transform(d, 1)
+            feats.append((k, d, oracle.feature_vector(nid, wt)))
+            assert cnt[b] == len(k)
+        assert nm[0] == 0 and (m12[0] == -1).all() and (m21[0] == -1).all()
+        for b in range(1, B):
+            (k1, d1, fv1), (k2, d2, fv2) = feats[b - 1], feats[b]
+            n1, n2 = len(k1), len(k2)
+            wn, w12, w21 = oracle.search_by_bow(d1, valid[b - 1, :n1], k1["angle"], fv1, d2,
+                                                valid[b, :n2] if th_mode else None, k2["angle"], fv2, th=50,
+                                                th_mode=th_mode, nnratio=0.7, check_ori=bool(check_ori))
+            assert nm[b] == wn and wn > 100
+            assert np.array_equal(m12[b, :n1], w12) and (m12[b, n1:] == -1).all()
+            assert np.array_equal(m21[b, :n2], w21) and (m21[b, n2:] == -1).all()
+    ex.close()
+    for x in (d_img, d_kps, d_desc, d_cnt, d_word, d_wt, d_node, d_m12, d_m21, d_nm, d_valid):
+        x.free()

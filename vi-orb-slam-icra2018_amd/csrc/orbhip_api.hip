@@ -188,7 +188,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
-                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match};
+                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -764,6 +764,120 @@ extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1,
         }
     }
     *nmatches = nm;
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vocabulary
+// ------------------------------------------------------------------------------------------------
+extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
+{
+    if (!c || !blob) return fail(c, ORBHIP_E_ARG, "orbhip_vocab_load: bad argument");
+    OrbVocabHost H;
+    std::string err;
+    int rc = orb_vocab_parse((const uint8_t *)blob, nbytes, H, err);
+    if (rc != ORBHIP_OK) return fail(c, rc, "orbhip_vocab_load: " + err);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nn = (size_t)H.nnodes;
+    // one device block, 256-byte aligned sections
+    size_t off[6], total = 0;
+    const size_t sizes[6] = {nn * 32, nn, nn * 4, nn * 4, (nn + 1) * 4, nn * 4};
+    for (int i = 0; i < 6; i++) {
+        off[i] = total;
+        total += align_up(sizes[i], 256);
+    }
+    if (c->d_vocBlock) HIPCHK(c, hipFree(c->d_vocBlock));
+    c->d_vocBlock = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_vocBlock, total));
+    uint8_t *base = (uint8_t *)c->d_vocBlock;
+    const void *src[6] = {H.desc.data(), H.leaf.data(), H.weight.data(), H.word.data(), H.childOff.data(), H.child.data()};
+    for (int i = 0; i < 6; i++) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    OrbVocabDev &V = c->voc;
+    V.k = H.k; V.L = H.L; V.scoring = H.scoring; V.weighting = H.weighting; V.nnodes = H.nnodes; V.nwords = H.nwords;
+    V.desc = base + off[0];
+    V.leaf = base + off[1];
+    V.weight = (float *)(base + off[2]);
+    V.word = (int32_t *)(base + off[3]);
+    V.childOff = (int32_t *)(base + off[4]);
+    V.child = (int32_t *)(base + off[5]);
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_vocab_load_device(orbhip_ctx *c, const void *d_blob, size_t nbytes)
+{
+    if (!c || !d_blob || nbytes < 24) return fail(c, ORBHIP_E_ARG, "orbhip_vocab_load_device: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint8_t> host(nbytes);
+    HIPCHK(c, hipMemcpy(host.data(), d_blob, nbytes, hipMemcpyDeviceToHost));
+    return orbhip_vocab_load(c, host.data(), nbytes);
+}
+
+extern "C" int orbhip_vocab_info(const orbhip_ctx *c, int *k, int *L, int *scoring, int *weighting, int *nnodes,
+                                 int *nwords)
+{
+    if (!c || !c->voc.desc) return ORBHIP_E_ARG;
+    if (k) *k = c->voc.k;
+    if (L) *L = c->voc.L;
+    if (scoring) *scoring = c->voc.scoring;
+    if (weighting) *weighting = c->voc.weighting;
+    if (nnodes) *nnodes = c->voc.nnodes;
+    if (nwords) *nwords = c->voc.nwords;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_vocab_transform_device(orbhip_ctx *c, const void *d_desc, int n, int levelsup, void *d_word,
+                                             void *d_weight, void *d_node)
+{
+    if (!c || n < 0 || (n > 0 && (!d_desc || !d_word || !d_weight || !d_node)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_vocab_transform_device: bad argument");
+    if (!c->voc.desc) return fail(c, ORBHIP_E_ARG, "orbhip_vocab_transform: no vocabulary loaded");
+    if (n == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_vocab_transform(c->stream, c->voc, (const uint8_t *)d_desc, n, levelsup, (int32_t *)d_word, (float *)d_weight,
+                           (int32_t *)d_node);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_vocab_transform(orbhip_ctx *c, const uint8_t *desc, int n, int levelsup, int32_t *word_id,
+                                      float *weight, int32_t *node_id)
+{
+    if (!c || n < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_vocab_transform: bad argument");
+    if (n == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)n * 44 + 2048))) return rc;
+    uint8_t *dd = (uint8_t *)T.take((size_t)n * 32);
+    int32_t *dw = (int32_t *)T.take((size_t)n * 4), *dn = (int32_t *)T.take((size_t)n * 4);
+    float *dwt = (float *)T.take((size_t)n * 4);
+    HIPCHK(c, hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = orbhip_vocab_transform_device(c, dd, n, levelsup, dw, dwt, dn))) return rc;
+    HIPCHK(c, hipMemcpyAsync(word_id, dw, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(weight, dwt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(node_id, dn, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_search_by_bow_seq_device(orbhip_ctx *c, const void *d_desc, const void *d_kps,
+                                               const void *d_counts, const void *d_node, const void *d_weight,
+                                               const void *d_valid, int cap, int B, int lag, int th_mode, float nnratio,
+                                               int check_ori, void *d_match12, void *d_match21, void *d_nmatches)
+{
+    if (!c || !d_desc || !d_kps || !d_counts || !d_node || !d_weight || cap <= 0 || cap > 16384 || B <= 0 || lag < 0 ||
+        !d_match12 || !d_match21 || !d_nmatches)
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_by_bow_seq_device: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    launch_bow_seq(c->stream, (const uint8_t *)d_desc, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts,
+                   (const int32_t *)d_node, (const float *)d_weight, (const uint8_t *)d_valid, cap, B, lag, 50, th_mode,
+                   nnratio, check_ori, (int32_t *)d_match12, (int32_t *)d_match21, (int32_t *)d_nmatches);
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->haveMatchEvents = true;
     return ORBHIP_OK;
 }
 

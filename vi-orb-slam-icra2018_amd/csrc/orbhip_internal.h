@@ -69,6 +69,21 @@ struct BlurTile {
     short level, tx, ty, pad;
 };
 
+// ORB vocabulary: host-side parse result and the device tables (structure of arrays,
+// indexed by node id; id 0 = root).
+struct OrbVocabHost {
+    int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0;
+    std::vector<uint8_t> desc, leaf;
+    std::vector<float> weight;
+    std::vector<int32_t> word, childOff, child;
+};
+struct OrbVocabDev {
+    int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0;
+    uint8_t *desc = nullptr, *leaf = nullptr;
+    float *weight = nullptr;
+    int32_t *word = nullptr, *childOff = nullptr, *child = nullptr;
+};
+
 struct orbhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -135,6 +150,10 @@ struct orbhip_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool haveStageEvents = false, haveMatchEvents = false;
 
+    // vocabulary
+    OrbVocabDev voc;
+    void *d_vocBlock = nullptr;
+
     // RCCL
     void *comm = nullptr;
     int rank = 0, nranks = 1;
@@ -179,5 +198,13 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
                       const int32_t *idx1, const uint8_t *desc2, const uint8_t *valid2,
                       const int32_t *off2, const int32_t *idx2, const int32_t *pairs, int npairs,
                       int th, int th_mode, float nnratio, int32_t *match12, int32_t *match21);
+
+int orb_vocab_parse(const uint8_t *blob, size_t nbytes, OrbVocabHost &V, std::string &err);
+void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *desc, int n, int levelsup,
+                            int32_t *word_id, float *weight, int32_t *node_id);
+void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *kps, const int32_t *counts,
+                    const int32_t *node, const float *weight, const uint8_t *valid, int cap, int B, int lag, int th,
+                    int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21,
+                    int32_t *nmatches);
 
 #endif
