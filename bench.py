@@ -2,13 +2,17 @@
 """bench.py -- ORB extract + match throughput on MI355X (BASELINE.json metric).
 
 A step = one pass of the hot path over one batch of B synthetic frames resident in HBM:
-ORBextractor (8-level pyramid, FAST-9/16 per cell, quadtree, IC angle, 7x7 blur, rBRIEF) on all B
-frames, then best/second-best Hamming matching of every frame against its predecessor.
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); frames are sharded, there is
-no per-frame collective; the ORB vocabulary blob is broadcast once at start-up (not timed).
+  * ORBextractor on all B frames (8-level pyramid, FAST-9/16 per cell, quadtree, IC angle, 7x7 blur,
+    rBRIEF), then
+  * the reference's frame-to-frame matching (Tracking::TrackReferenceKeyFrame): vocabulary transform of
+    every descriptor (Frame::ComputeBoW, levelsup 4) and ORBmatcher::SearchByBoW of every frame against
+    its predecessor (--match bow, default), or brute-force best/second Hamming (--match brute), or both.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); frames are sharded, there is no
+per-frame collective; the ORB vocabulary blob is broadcast once at start-up over xGMI (not timed).
 
-Prints ONE JSON line on rank 0 (driver contract) with `roofline` (FAST kernel, HBM bound) and, at
-N=1, `cpu_baseline` (the CPU oracle on this box's host cores, bounded sample).
+Prints ONE JSON line on rank 0, last on stdout (driver contract), with `roofline` (FAST kernel) and,
+at N=1, `cpu_baseline` (the CPU oracle doing the same operations on this box's host cores, bounded
+sample).
 """
 import argparse
 import ctypes as C
@@ -24,6 +28,8 @@ import numpy as np  # noqa: E402
 
 W, H, NFEAT = 640, 480, 1000          # the size BASELINE.json's metric is quoted on
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VOC_K, VOC_L, LEVELSUP = 10, 6, 4     # stock ORBvoc shape; Frame::ComputeBoW uses levelsup 4 (src/Frame.cc:744)
+NNRATIO = 0.7                         # TrackReferenceKeyFrame: ORBmatcher matcher(0.7,true) (src/Tracking.cc:1881)
 
 
 def fast_algorithmic_bytes(w, h, nlevels, level_size):
@@ -35,23 +41,34 @@ def fast_algorithmic_bytes(w, h, nlevels, level_size):
     return tot
 
 
-def cpu_baseline(frames, nsample):
+def cpu_baseline(frames, nsample, match, blob):
     """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orb_oracle_py as oracle
     ex = oracle.Extractor(NFEAT, 1.2, 8, 20, 7)
+    voc = oracle.Vocabulary(blob) if match in ("bow", "both") else None
     ex(frames[0])  # warm up (page in)
     t0 = time.perf_counter()
     prev = None
     for i in range(nsample):
         k, d = ex(frames[i % len(frames)])
+        cur = {"k": k, "d": d}
+        if voc is not None:
+            w, wt, nid = voc.transform(d, LEVELSUP)
+            cur["fv"] = oracle.feature_vector(nid, wt)
         if prev is not None:
-            oracle.knn2(d, prev)
-        prev = d
+            if voc is not None:
+                oracle.search_by_bow(prev["d"], np.ones(len(prev["d"]), np.uint8), prev["k"]["angle"], prev["fv"], d,
+                                     None, k["angle"], cur["fv"], th=50, th_mode=0, nnratio=NNRATIO, check_ori=True)
+            if match in ("brute", "both"):
+                oracle.knn2(d, prev["d"])
+        prev = cur
     dt = time.perf_counter() - t0
+    what = {"bow": "vocabulary transform + SearchByBoW", "brute": "brute-force knn2",
+            "both": "vocabulary transform + SearchByBoW + brute-force knn2"}[match]
     return {"value": round(nsample / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames %dx%d, %d features, extract + knn2 vs previous frame, oracle/liborb_oracle.so "
-                      "(gcc -O3 -march=x86-64-v3), %.1f s" % (nsample, W, H, NFEAT, dt)}
+            "sample": "%d frames %dx%d, %d features, extract + %s vs previous frame, oracle/liborb_oracle.so "
+                      "(gcc -O3 -march=x86-64-v3), %.1f s" % (nsample, W, H, NFEAT, what, dt)}
 
 
 def main():
@@ -61,7 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
-    ap.add_argument("--cpu-frames", type=int, default=1000, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--match", choices=["bow", "brute", "both"], default="bow")
+    ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -80,8 +98,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from orbhip import synth
+    from orbhip import distributed as D, synth
     from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
 
     B = args.batch
     # independent streams per rank (weak scaling: per-GPU work fixed)
@@ -92,30 +111,46 @@ def main():
 
     ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B, device=local_rank)
     cap = ex.cap
-    d_kps = torch.empty((B, cap, 7), dtype=torch.int32, device="cuda")
-    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda")
-    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
-    d_bi = torch.empty((B, cap), dtype=torch.int32, device="cuda")
-    d_bd = torch.empty((B, cap), dtype=torch.int32, device="cuda")
-    d_sd = torch.empty((B, cap), dtype=torch.int32, device="cuda")
     L = ex._L
+    i32 = dict(dtype=torch.int32, device="cuda")
+    d_kps = torch.empty((B, cap, 7), **i32)
+    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, **i32)
+    d_bi, d_bd, d_sd = (torch.empty((B, cap), **i32) for _ in range(3))
+    d_word, d_node, d_m12, d_m21 = (torch.empty((B, cap), **i32) for _ in range(4))
+    d_wt = torch.empty((B, cap), dtype=torch.float32, device="cuda")
+    d_nm = torch.zeros(B, **i32)
 
-    # vocabulary blob broadcast over xGMI (RCCL) once at start-up: reference binary layout
-    # (TemplatedVocabulary.h:1727-1751), synthetic content of the stock size (~44 MB)
-    if dist is not None:
-        nb_nodes = 1082073
-        blob = torch.zeros(24 + nb_nodes * 41, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            blob.random_(0, 256)
-        dist.broadcast(blob, src=0)
-        torch.cuda.synchronize()
+    # ORB vocabulary: reference binary format (TemplatedVocabulary.h:1727-1751), synthetic tree of the
+    # stock shape (k=10, L=6, 1.11 M nodes, 45.6 MB).  Rank 0 builds it; N>1: one RCCL broadcast over xGMI.
+    use_bow = args.match in ("bow", "both")
+    blob = None
+    if use_bow or dist is not None:
+        blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L) if rank == 0 else b""
+        if dist is not None:
+            d_blob = D.broadcast_blob(blob, src=0, device="cuda")
+            torch.cuda.synchronize()
+            ORBVocabulary(ex).loadFromDeviceBlob(d_blob.data_ptr(), d_blob.numel())
+            del d_blob
+        else:
+            ORBVocabulary(ex).loadFromBinaryBlob(blob)
 
     def step():
         ex.extract_batch_device(d_img.data_ptr(), B, W, H, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(), cap,
                                 d_cnt.data_ptr())
-        rc = L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.data_ptr(), d_cnt.data_ptr(), cap, B, 1,
-                                              d_bi.data_ptr(), d_bd.data_ptr(), d_sd.data_ptr())
-        assert rc == 0
+        if use_bow:
+            rc = L.orbhip_vocab_transform_device(ex.handle, d_desc.data_ptr(), B * cap, LEVELSUP, d_word.data_ptr(),
+                                                 d_wt.data_ptr(), d_node.data_ptr())
+            assert rc == 0
+            rc = L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.data_ptr(), d_kps.data_ptr(), d_cnt.data_ptr(),
+                                                   d_node.data_ptr(), d_wt.data_ptr(), None, cap, B, 1, 0,
+                                                   C.c_float(NNRATIO), 1, d_m12.data_ptr(), d_m21.data_ptr(),
+                                                   d_nm.data_ptr())
+            assert rc == 0
+        if args.match in ("brute", "both"):
+            rc = L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.data_ptr(), d_cnt.data_ptr(), cap, B, 1,
+                                                  d_bi.data_ptr(), d_bd.data_ptr(), d_sd.data_ptr())
+            assert rc == 0
 
     def barrier():
         ex.sync()
@@ -131,7 +166,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # stage device times (HIP events on the context stream; reading them waits for the step)
+        # stage device times (HIP events on the context streams; reading them waits for the step)
         ms = (C.c_float * 6)()
         assert L.orbhip_get_stage_times(ex.handle, ms) == 0
         stage += np.array(list(ms))
@@ -144,7 +179,8 @@ def main():
     stage /= max(args.steps, 1)
 
     counts = d_cnt.cpu().numpy()
-    matched = int(((d_bd.cpu().numpy()[1:] <= 50)).sum()) if B > 1 else 0
+    nmatch = float(d_nm.cpu().numpy()[1:].mean()) if (use_bow and B > 1) else None
+    nbrute = float((d_bd.cpu().numpy()[1:] <= 50).sum() / max(B - 1, 1)) if args.match in ("brute", "both") else None
 
     out = None
     if rank == 0:
@@ -152,27 +188,32 @@ def main():
         alg = fast_algorithmic_bytes(W, H, 8, ex.level_size) * B          # bytes per FAST launch
         fast_ms = float(stage[1])
         achieved = alg / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+        match_desc = {"bow": "vocabulary transform (k=10, L=6, levelsup 4) + ORBmatcher::SearchByBoW(0.7, checkOri)",
+                      "brute": "Hamming best/second brute force",
+                      "both": "vocabulary transform + SearchByBoW + Hamming brute force"}[args.match]
         out = {
             "metric": "ORB extract+match frames/sec @640x480/1000 feat",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "640x480 frames, 1000 features, 8 levels, scale 1.2, FAST 20/7; "
-                                   "batched extract + Hamming best/second match vs previous frame",
-                       "frames_per_step_per_gpu": B, "unique_frames": int(len(uniq)),
+            "config": {"workload": "640x480 frames, 1000 features, 8 levels, scale 1.2, FAST 20/7; batched "
+                                   "ORBextractor + " + match_desc + " of every frame vs its predecessor",
+                       "frames_per_step_per_gpu": B, "unique_frames": int(len(uniq)), "match": args.match,
                        "parallelism": "frames sharded, 1 process per GPU, no per-frame collective"},
             "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(fast_ms, 4)},
+                         "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(fast_ms, 4),
+                         "note": "k_fast is integer-VALU/LDS bound, not HBM bound (DESIGN.md section 4)"},
             "stage_ms": {"pyramid": round(float(stage[0]), 4), "fast": round(float(stage[1]), 4),
                          "quadtree": round(float(stage[2]), 4), "blur": round(float(stage[3]), 4),
-                         "describe": round(float(stage[4]), 4), "match": round(float(stage[5]), 4)},
+                         "describe": round(float(stage[4]), 4), "last_match_kernel": round(float(stage[5]), 4)},
             "keypoints_per_frame": round(float(counts.mean()), 1),
-            "matches_le_TH_LOW_per_frame": round(matched / max(B - 1, 1), 1),
+            "bow_matches_per_frame": None if nmatch is None else round(nmatch, 1),
+            "brute_matches_le_TH_LOW_per_frame": None if nbrute is None else round(nbrute, 1),
         }
         if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(uniq, args.cpu_frames)
+            out["cpu_baseline"] = cpu_baseline(uniq, args.cpu_frames, args.match, blob)
             out["speedup_vs_cpu_1core"] = round(fps / out["cpu_baseline"]["value"], 1)
     ex.close()
     if dist is not None:

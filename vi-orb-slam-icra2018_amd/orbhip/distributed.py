@@ -44,25 +44,23 @@ def unpack_vocabulary(blob):
 
 
 def make_synthetic_vocabulary(seed, k=10, L=3):
-    """A complete k-ary tree of depth L with random 256-bit node descriptors (the stock ORBvoc is
-    k=10, L=6, ~1.08 M nodes, ~44 MB; the file is not in the reference mirror)."""
+    """A complete k-ary tree of depth L with random 256-bit node descriptors, nodes numbered level by
+    level (the stock ORBvoc is k=10, L=6, ~1.08 M nodes, ~44 MB; the file is not in the reference
+    mirror)."""
     rng = np.random.default_rng(seed)
-    parent, leaf = [], []
-    level = [0]
-    nid = 1
+    parents, leaves = [], []
+    start_prev, n_prev, next_id = 0, 1, 1          # previous level = the root
     for depth in range(1, L + 1):
-        nxt = []
-        for p in level:
-            for _ in range(k):
-                parent.append(p)
-                leaf.append(1 if depth == L else 0)
-                nxt.append(nid)
-                nid += 1
-        level = nxt
+        n = n_prev * k
+        parents.append(start_prev + np.arange(n, dtype=np.int64) // k)
+        leaves.append(np.full(n, 1 if depth == L else 0, np.uint8))
+        start_prev, n_prev, next_id = next_id, n, next_id + n
+    parent = np.concatenate(parents).astype(np.int32)
+    leaf = np.concatenate(leaves)
     n = len(parent)
     desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     weight = rng.random(n).astype(np.float32)
-    return pack_vocabulary(k, L, 0, 0, np.array(parent, np.int32), desc, weight, np.array(leaf, np.uint8))
+    return pack_vocabulary(k, L, 0, 0, parent, desc, weight, leaf)
 
 
 # ---- sharding -------------------------------------------------------------------------------
