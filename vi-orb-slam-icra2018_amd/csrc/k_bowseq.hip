@@ -16,7 +16,15 @@
 // Integer/bitwise path (XOR + popcount); no MFMA.
 #include "orbhip_internal.h"
 
+#include <cstdlib>
+
 #define BS_HISTO 30
+
+static int bs_threads()
+{
+    static const int n = getenv("ORBHIP_BOW_THREADS") ? atoi(getenv("ORBHIP_BOW_THREADS")) : 512;
+    return n;
+}
 
 struct BsBest {
     int b1, pos, b2;
@@ -50,7 +58,7 @@ __device__ void bs_sort(unsigned long long *keys, int NP, int tid)
 {
     for (int k = 2; k <= NP; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < NP / 2; t += 256) {
+            for (int t = tid; t < NP / 2; t += blockDim.x) {
                 // t-th compare-exchange pair of this (k, j) phase
                 const int i = ((t / j) * 2 * j) + (t % j);
                 const int p = i + j;
@@ -66,7 +74,7 @@ __device__ void bs_sort(unsigned long long *keys, int NP, int tid)
     }
 }
 
-__global__ __launch_bounds__(256) void k_bow_seq(const uint8_t *__restrict__ desc,
+__global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ desc,
                                                  const orbhip_keypoint *__restrict__ kps,
                                                  const int32_t *__restrict__ counts,
                                                  const int32_t *__restrict__ node, const float *__restrict__ weight,
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void k_bow_seq(const uint8_t *__restrict__ des
     int32_t *o12 = match12 + (size_t)b * cap;
     int32_t *o21 = match21 + (size_t)b * cap;
     if (b < lag) {
-        for (int i = tid; i < cap; i += 256) {
+        for (int i = tid; i < cap; i += blockDim.x) {
             o12[i] = -1;
             o21[i] = -1;
         }
@@ -105,12 +113,12 @@ __global__ __launch_bounds__(256) void k_bow_seq(const uint8_t *__restrict__ des
     const float *w1 = weight + (size_t)b1 * cap, *w2 = weight + (size_t)b * cap;
 
     // ---- 1. keys: (node << 32 | index); absent / stopped features sort last ----
-    for (int i = tid; i < NP; i += 256) {
+    for (int i = tid; i < NP; i += blockDim.x) {
         key1[i] = (i < n1 && w1[i] > 0.f) ? (((unsigned long long)(unsigned)nd1[i] << 32) | (unsigned)i) : ~0ull;
         key2[i] = (i < n2 && w2[i] > 0.f) ? (((unsigned long long)(unsigned)nd2[i] << 32) | (unsigned)i) : ~0ull;
         m12[i] = -1;
     }
-    for (int i = tid; i < NP / 32; i += 256) claim[i] = 0;
+    for (int i = tid; i < NP / 32; i += blockDim.x) claim[i] = 0;
     if (tid < BS_HISTO) s_hist[tid] = 0;
     if (tid == 0) {
         s_n1v = 0;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void k_bow_seq(const uint8_t *__restrict__ des
     bs_sort(key1, NP, tid);
     bs_sort(key2, NP, tid);
     // number of live entries per side
-    for (int i = tid; i < NP; i += 256) {
+    for (int i = tid; i < NP; i += blockDim.x) {
         if (key1[i] != ~0ull && (i + 1 == NP || key1[i + 1] == ~0ull)) s_n1v = i + 1;
         if (key2[i] != ~0ull && (i + 1 == NP || key2[i + 1] == ~0ull)) s_n2v = i + 1;
     }
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void k_bow_seq(const uint8_t *__restrict__ des
     const int n1v = s_n1v, n2v = s_n2v;
 
     // ---- 2. work items: nodes present on both sides ----
-    for (int p = tid; p < n1v; p += 256) {
+    for (int p = tid; p < n1v; p += blockDim.x) {
         const unsigned nodeId = (unsigned)(key1[p] >> 32);
         if (p == 0 || (unsigned)(key1[p - 1] >> 32) != nodeId) {
             const int s2 = bs_bound(key2, n2v, nodeId, false), e2 = bs_bound(key2, n2v, nodeId, true);
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void k_bow_seq(const uint8_t *__restrict__ des
     const orbhip_keypoint *k1 = kps + (size_t)b1 * cap, *k2 = kps + (size_t)b * cap;
     int mybin0 = -1;   // this thread handles features tid, tid+256, ...: remember bins in registers
     if (check_ori) {
-        for (int i1 = tid; i1 < n1; i1 += 256) {
+        for (int i1 = tid; i1 < n1; i1 += blockDim.x) {
             const int i2 = m12[i1];
             if (i2 >= 0) {
                 float rot = k1[i1].angle - k2[i2].angle;
@@ -242,10 +250,10 @@ __global__ __launch_bounds__(256) void k_bow_seq(const uint8_t *__restrict__ des
     }
     (void)mybin0;
     // ---- 5. outputs ----
-    for (int i = tid; i < cap; i += 256) o21[i] = -1;
+    for (int i = tid; i < cap; i += blockDim.x) o21[i] = -1;
     __syncthreads();
     int local = 0;
-    for (int i1 = tid; i1 < cap; i1 += 256) {
+    for (int i1 = tid; i1 < cap; i1 += blockDim.x) {
         int i2 = i1 < n1 ? m12[i1] : -1;
         if (i2 >= 0 && check_ori) {
             float rot = k1[i1].angle - k2[i2].angle;
@@ -276,6 +284,6 @@ void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *k
     const size_t lds = (size_t)NP * (8 + 8 + 4 + 8) + (size_t)NP / 8 + 64;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)k_bow_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_bow_seq, dim3(B, 1, 1), dim3(256, 1, 1), lds, s, desc, kps, counts, node, weight, valid, cap, NP,
+    hipLaunchKernelGGL(k_bow_seq, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid, cap, NP,
                        lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches);
 }
