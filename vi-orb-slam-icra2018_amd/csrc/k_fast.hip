@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     const int jd0 = j0 & ~3;               // first aligned dword column touching the domain
     const int GPR = ((j0 + TW + 3) >> 2) - (j0 >> 2);   // dword groups per row
     const int nitems = DH * GPR;
-    const unsigned gprMagic = (1u << 20) / (unsigned)GPR + 1u;   // item / GPR for item < 2^20 / GPR
+    const float invGPR = 1.0f / (float)GPR;   // item / GPR = floor((item + 0.5) * invGPR), exact for item < 2^16
     for (int ibase = 0; ibase < nitems; ibase += 8 * 256) {
         // acc: bit (4 * i + k) = pixel k of this thread's i-th item of the chunk
         uint32_t acc = 0;
@@ -266,9 +266,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
         for (int i = 0; i < 8; i++) {
             const int item = ibase + i * 256 + tid;
             if (item < nitems) {
-                const int r = (int)(((unsigned)item * gprMagic) >> 20);
-                const int jd = jd0 + ((item - r * GPR) << 2);
-                const uint8_t *row = s_pix + (r + 3) * pitch + jd;
+                const int r = (int)(((float)item + 0.5f) * invGPR);
+                const int jd = jd0 + ((item - __mul24(r, GPR)) << 2);
+                const uint8_t *row = s_pix + __mul24(r + 3, pitch) + jd;
                 const uint32_t Cw = *reinterpret_cast<const uint32_t *>(row);
                 const uint32_t Lw = *reinterpret_cast<const uint32_t *>(row - 4);
                 const uint32_t Rw = *reinterpret_cast<const uint32_t *>(row + 4);
@@ -278,13 +278,13 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
                 const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
                 const uint32_t fA = compass2(lo2(Cw), lo2(Tw), lo2(Bw), lo2(lft), lo2(rgt), tt);   // px 0,1
                 const uint32_t fB = compass2(hi2(Cw), hi2(Tw), hi2(Bw), hi2(lft), hi2(rgt), tt);   // px 2,3
+                // flags (each <= 255) of px 0..3 into bytes 0..3, 0x80 per non-zero byte, then 4 bits
+                const uint32_t g = __builtin_amdgcn_perm(fB, fA, 0x06040200u);
+                const uint32_t z = (((g & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | g) & 0x80808080u;
                 // pixels of the group that lie inside the domain (first / last group of a row)
                 const int c0 = jd - j0;
-                uint32_t nib = 0;
-                if ((fA & 0xFFFFu) && c0 >= 0 && c0 < TW) nib |= 1u;
-                if ((fA >> 16) && c0 + 1 >= 0 && c0 + 1 < TW) nib |= 2u;
-                if ((fB & 0xFFFFu) && c0 + 2 >= 0 && c0 + 2 < TW) nib |= 4u;
-                if ((fB >> 16) && c0 + 3 >= 0 && c0 + 3 < TW) nib |= 8u;
+                const uint32_t dom = (0xFu << max(0, -c0)) & (0xFu >> max(0, c0 + 4 - TW));
+                const uint32_t nib = ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & dom & 0xFu;
                 acc |= nib << (4 * i);
             }
         }
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
             const int b = __ffs(acc) - 1;
             acc &= acc - 1;
             const int item = ibase + (b >> 2) * 256 + tid;
-            const int r = (int)(((unsigned)item * gprMagic) >> 20);
-            const int j = jd0 + ((item - r * GPR) << 2) + (b & 3);
+            const int r = (int)(((float)item + 0.5f) * invGPR);
+            const int j = jd0 + ((item - __mul24(r, GPR)) << 2) + (b & 3);
             if (pos < listCap) s_list[pos] = (uint16_t)((r << 9) | j);
             pos++;
         }
@@ -316,17 +316,15 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     // the score tile.  Both fallbacks produce the same result as the list paths.
     const int nlist = s_listCount;
     if (nlist <= listCap) {
-        for (int e0 = 0; e0 < nlist; e0 += 256) {
-            const int e = e0 + tid;
-            int ent = 0, s = 0;
-            if (e < nlist) {
-                ent = s_list[e];
-                const int r = ent >> 9, j = ent & 511;
-                s = fast_score_lds(s_pix + (r + 3) * pitch + j, pitch, t);
-                if (s > 0) s_score[r * SP + (j - j0)] = (uint8_t)s;
+        for (int e = tid; e < nlist; e += 256) {
+            const int ent = s_list[e];
+            const int r = ent >> 9, j = ent & 511;
+            const int s = fast_score_lds(s_pix + __mul24(r + 3, pitch) + j, pitch, t);
+            if (s > 0) {
+                s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
+                const int slot = atomicAdd(&s_cornerCount, 1);   // hipcc aggregates this per wave
+                if (slot < cornerCap) s_corner[slot] = (uint16_t)ent;
             }
-            const int slot = wave_append(s > 0, &s_cornerCount, lane);
-            if (slot >= 0 && slot < cornerCap) s_corner[slot] = (uint16_t)ent;
         }
     } else {
         const unsigned twMagic = (1u << 20) / (unsigned)TW + 1u;
@@ -351,17 +349,12 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     const unsigned cellMagic = 65536u / (unsigned)L.wCell + 1u;   // c / wCell for c < 65536 / wCell
     const int ncorner = s_cornerCount;
     if (ncorner <= cornerCap) {
-        for (int e0 = 0; e0 < ncorner; e0 += 256) {
-            const int e = e0 + tid;
+        for (int e = tid; e < ncorner; e += 256) {
+            const int ent = s_corner[e];
+            const int r = ent >> 9, c = (ent & 511) - j0;
             bool surv = false;
-            uint32_t key = 0;
-            if (e < ncorner) {
-                const int ent = s_corner[e];
-                const int r = ent >> 9, c = (ent & 511) - j0;
-                key = nms_key(s_score, SP, r, c, DH, TW, L.wCell, cellMagic, G.iniTh, s_cellAny, surv);
-            }
-            const int slot = wave_append(surv, &s_survCount, lane);
-            if (slot >= 0) s_surv[slot] = key;
+            const uint32_t key = nms_key(s_score, SP, r, c, DH, TW, L.wCell, cellMagic, G.iniTh, s_cellAny, surv);
+            if (surv) s_surv[atomicAdd(&s_survCount, 1)] = key;
         }
     } else {
         // fallback: scan the score tile, 4 pixels per dword
