@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Measures the BASELINE.json configurations other than the headline one on ONE MI355X and prints a
+markdown table (committed under profiles/).  Parity for these geometries is covered by
+tests/test_gpu_parity.py; this script only times them.  Synthetic frames (orbhip/synth.py)."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vi-orb-slam-icra2018_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (device buffers only)
+
+from orbhip import distributed as D, synth  # noqa: E402
+from orbhip.extractor import ORBextractor  # noqa: E402
+from orbhip.vocabulary import ORBVocabulary  # noqa: E402
+
+
+def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
+    frames_u = synth.make_frames(seed, W, H, min(uniq, B))
+    frames = np.concatenate([frames_u] * ((B + len(frames_u) - 1) // len(frames_u)))[:B]
+    stride = (W + 15) // 16 * 16
+    host = np.zeros((B, H, stride), np.uint8)
+    host[:, :, :W] = frames
+    d_img = torch.from_numpy(host).cuda()
+    ex = ORBextractor(nfeat, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B)
+    cap = ex.cap
+    i32 = dict(dtype=torch.int32, device="cuda")
+    d_kps = torch.empty((B, cap, 7), **i32)
+    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, **i32)
+    d_a, d_b, d_c, d_d = (torch.empty((B, cap), **i32) for _ in range(4))
+    d_wt = torch.empty((B, cap), dtype=torch.float32, device="cuda")
+    d_nm = torch.zeros(B, **i32)
+    L = ex._L
+    if match == "bow":
+        ORBVocabulary(ex).loadFromBinaryBlob(D.make_synthetic_vocabulary(4242, 10, 6))
+
+    def step():
+        ex.extract_batch_device(d_img.data_ptr(), B, W, H, stride, H * stride, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_cnt.data_ptr())
+        if match == "bow":
+            assert L.orbhip_vocab_transform_device(ex.handle, d_desc.data_ptr(), B * cap, 4, d_a.data_ptr(), d_wt.data_ptr(),
+                                                   d_b.data_ptr()) == 0
+            assert L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.data_ptr(), d_kps.data_ptr(), d_cnt.data_ptr(),
+                                                     d_b.data_ptr(), d_wt.data_ptr(), None, cap, B, 1, 0, C.c_float(0.7), 1,
+                                                     d_c.data_ptr(), d_d.data_ptr(), d_nm.data_ptr()) == 0
+        elif match == "brute":
+            assert L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.data_ptr(), d_cnt.data_ptr(), cap, B, 1, d_a.data_ptr(),
+                                                    d_b.data_ptr(), d_c.data_ptr()) == 0
+    torch.cuda.synchronize()
+    for _ in range(2):
+        step()
+    ex.sync()
+    nsteps = max(1, (total_frames + B - 1) // B)
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    ex.sync()
+    dt = time.perf_counter() - t0
+    ms = (C.c_float * 6)()
+    L.orbhip_get_stage_times(ex.handle, ms)
+    kp = float(d_cnt.cpu().numpy().mean())
+    ex.close()
+    return nsteps * B / dt, dt, kp, list(ms)
+
+
+def run_single_frame_latency(W, H, nfeat):
+    img = synth.make_frames(5, W, H, 1)[0]
+    ex = ORBextractor(nfeat, max_w=W, max_h=H)
+    for _ in range(5):
+        ex(img)
+    t0 = time.perf_counter()
+    n = 200
+    for _ in range(n):
+        ex(img)
+    dt = (time.perf_counter() - t0) / n
+    t = (ex.GetTimeOfComputePyramid(), ex.GetTimeOfComputeKeyPointsOctTree(), ex.GetTImeOfComputeDescriptor())
+    ex.close()
+    return dt * 1e3, t
+
+
+def run_big_knn(nq, ndb):
+    db = torch.randint(0, 256, (ndb, 32), dtype=torch.uint8, device="cuda")
+    idx = torch.randint(0, ndb, (nq,), device="cuda")
+    q = db[idx].clone()
+    q[:, 0] ^= 0x55
+    ex = ORBextractor(1000, max_w=640, max_h=480)
+    bi = torch.empty(nq, dtype=torch.int32, device="cuda")
+    bd = torch.empty_like(bi)
+    sd = torch.empty_like(bi)
+    L = ex._L
+    torch.cuda.synchronize()
+    for _ in range(2):
+        assert L.orbhip_hamming_knn2_device(ex.handle, q.data_ptr(), nq, db.data_ptr(), ndb, bi.data_ptr(), bd.data_ptr(),
+                                            sd.data_ptr()) == 0
+    ex.sync()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        L.orbhip_hamming_knn2_device(ex.handle, q.data_ptr(), nq, db.data_ptr(), ndb, bi.data_ptr(), bd.data_ptr(), sd.data_ptr())
+    ex.sync()
+    dt = (time.perf_counter() - t0) / n
+    ok = bool((bi.cpu() == idx.cpu().int()).float().mean() > 0.99)
+    ex.close()
+    return dt, ok
+
+
+def main():
+    print("| config (BASELINE.json) | workload | frames/s | notes |")
+    print("|---|---|---|---|")
+    fps, dt, kp, ms = run_extract(752, 480, 1000, 512, 3682, "bow", seed=1)
+    print("| 2: EuRoC MH_01 full sequence | 3682 frames 752x480, 1000 feat, batches of 512, extract + transform + SearchByBoW | %.0f | %.1f kp/frame, %.3f s for the sequence |" % (fps, kp, dt))
+    fps, dt, kp, ms = run_extract(1241, 376, 2000, 256, 2048, "bow", seed=2)
+    print("| 3: KITTI 00 stereo | 1241x376, 2000 feat, L+R images as 2 frames per pair, extract + transform + SearchByBoW | %.0f images/s = %.0f stereo pairs/s | %.1f kp/image |" % (fps, fps / 2, kp))
+    tot = 0.0
+    frames = 0
+    for i, n in enumerate([2912, 1710, 2280, 3040]):
+        fps, dt, kp, ms = run_extract(752, 480, 1000, 512, n, "bow", seed=10 + i)
+        tot += dt
+        frames += (n + 511) // 512 * 512
+    print("| 4: V101/V102/V201/MH02 streams | 4 streams 752x480 run back to back on ONE GPU (1 stream/GPU needs 4 GPUs) | %.0f | %d frames in %.3f s |" % (frames / tot, frames, tot))
+    fps, dt, kp, ms = run_extract(640, 480, 4000, 256, 2048, "brute", seed=3)
+    print("| 5a: TUM fr1_desk at 4000 feat | 640x480, 4000 feat, extract + brute-force match vs previous frame | %.0f | %.1f kp/frame |" % (fps, kp))
+    dt, ok = run_big_knn(4000, 1000000)
+    print("| 5b: 1M-descriptor relocalisation query | 4000 queries x 1 000 000 database rows, best/second | %.1f queries-batches/s | %.2f ms per query batch, %.2f T pair-evals/s, %.1f GB/s database stream, exact=%s |" % (
+        1 / dt, dt * 1e3, 4000 * 1e6 / dt / 1e12, 32e6 / dt / 1e9, ok))
+    dt, ok = run_big_knn(8, 1000000)
+    print("| 5c: few-query regime | 8 queries x 1 000 000 rows | - | %.3f ms, %.1f GB/s database stream |" % (dt * 1e3, 32e6 / dt / 1e9))
+    lat, t = run_single_frame_latency(640, 480, 1000)
+    print("| 1: single frame (host pointers, incl. PCIe) | 640x480, 1000 feat, orbhip_extract per call | %.0f | %.3f ms per call; device stage times pyramid %.3f / keypoints %.3f / descriptors %.3f ms |" % (1e3 / lat, lat, t[0], t[1], t[2]))
+
+
+if __name__ == "__main__":
+    main()
