@@ -167,7 +167,9 @@ def test_knn2_matches_oracle(hip, oracle):
     db[777] = db[12]                                  # duplicate rows: lowest index must win
     q, _ = synth.make_queries(2, db, 700)
     q[5] = db[777]
-    for nq, ndb in [(700, 20000), (1, 20000), (700, 1), (257, 63), (3, 0)]:
+    # (1|8|9|32, 20000) take the few-query path (lanes own database rows), the others the many-query path
+    for nq, ndb in [(700, 20000), (1, 20000), (8, 20000), (9, 20000), (32, 20000), (33, 20000), (700, 1), (257, 63),
+                    (3, 0)]:
         got = m.knn2(q[:nq], db[:ndb])
         want = oracle.knn2(q[:nq], db[:ndb])
         for g, w in zip(got, want):

@@ -14,6 +14,8 @@
 //                the node's side-2 features in parallel and reduce with a tie-aware merge.
 #include "orbhip_internal.h"
 
+#include <algorithm>
+
 struct Best {
     int b1, idx, b2;
 };
@@ -143,8 +145,97 @@ static void knn2_shape(int nq, int ndb, int *qTiles, int *nsplit, int *rows)
     *nsplit = ndb > 0 ? (ndb + *rows - 1) / *rows : 1;
 }
 
+// ---- few queries against a large database: the HBM-bound regime ----
+// Lanes own database rows (one coalesced 32-byte row per lane and trip), the <= FQ queries of a pass
+// sit in LDS and are broadcast; every lane keeps (best, index, second) per query and the results are
+// merged across lanes, waves and workgroups with the lowest index winning ties.
+#define FQ 8
+#define FQ_BLOCKS 2048
+
+__device__ __forceinline__ void best_merge_unordered(Best &A, int ob1, int oidx, int ob2)
+{
+    const bool mine = (A.b1 < ob1) || (A.b1 == ob1 && (unsigned)A.idx < (unsigned)oidx);
+    const int nb2 = mine ? min(A.b2, ob1) : min(ob2, A.b1);
+    A.b1 = mine ? A.b1 : ob1;
+    A.idx = mine ? A.idx : oidx;
+    A.b2 = nb2;
+}
+
+__global__ __launch_bounds__(256) void k_knn2_fewq(const uint8_t *__restrict__ q, int nq, int q0,
+                                                   const uint8_t *__restrict__ db, int ndb,
+                                                   int4 *__restrict__ partial)
+{
+    __shared__ uint32_t s_q[FQ][8];
+    __shared__ int4 s_red[4][FQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nloc = min(FQ, nq - q0);
+    if (tid < FQ * 8) {
+        const int k = tid >> 3, w = tid & 7;
+        s_q[k][w] = k < nloc ? reinterpret_cast<const uint32_t *>(q + (size_t)(q0 + k) * 32)[w] : 0u;
+    }
+    __syncthreads();
+    Best B[FQ];
+#pragma unroll
+    for (int k = 0; k < FQ; k++) B[k] = {256, -1, 256};
+    const int stride = gridDim.x * 256;
+    for (int j = blockIdx.x * 256 + tid; j < ndb; j += stride) {
+        const uint4 r0 = reinterpret_cast<const uint4 *>(db + (size_t)j * 32)[0];
+        const uint4 r1 = reinterpret_cast<const uint4 *>(db + (size_t)j * 32)[1];
+        const uint32_t R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int k = 0; k < FQ; k++) {
+            uint32_t Q[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) Q[w] = s_q[k][w];
+            best_update(B[k], hamming256(Q, R), j);
+        }
+    }
+    // lanes -> wave -> workgroup
+#pragma unroll
+    for (int k = 0; k < FQ; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ob1 = __shfl_xor(B[k].b1, o), oidx = __shfl_xor(B[k].idx, o), ob2 = __shfl_xor(B[k].b2, o);
+            best_merge_unordered(B[k], ob1, oidx, ob2);
+        }
+        if (lane == 0) s_red[wave][k] = make_int4(B[k].b1, B[k].idx, B[k].b2, 0);
+    }
+    __syncthreads();
+    if (tid < FQ) {
+        Best A = {s_red[0][tid].x, s_red[0][tid].y, s_red[0][tid].z};
+        for (int w = 1; w < 4; w++) best_merge_unordered(A, s_red[w][tid].x, s_red[w][tid].y, s_red[w][tid].z);
+        partial[(size_t)blockIdx.x * FQ + tid] = make_int4(A.b1, A.idx, A.b2, 0);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_knn2_fewq_merge(const int4 *__restrict__ partial, int nblocks, int nq, int q0,
+                                                        int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
+                                                        int32_t *__restrict__ second_d)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (q0 + k >= nq) return;
+    Best A = {256, -1, 256};
+    for (int b = lane; b < nblocks; b += 64) {
+        const int4 p = partial[(size_t)b * FQ + k];
+        best_merge_unordered(A, p.x, p.y, p.z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ob1 = __shfl_xor(A.b1, o), oidx = __shfl_xor(A.idx, o), ob2 = __shfl_xor(A.b2, o);
+        best_merge_unordered(A, ob1, oidx, ob2);
+    }
+    if (lane == 0) {
+        best_idx[q0 + k] = A.idx;
+        best_d[q0 + k] = A.b1;
+        second_d[q0 + k] = A.b2;
+    }
+}
+
+static bool knn2_few(int nq, int ndb) { return nq <= 4 * FQ && ndb >= 16384; }
+
 size_t knn2_scratch_bytes(int nq, int ndb)
 {
+    if (knn2_few(nq, ndb)) return (size_t)FQ_BLOCKS * FQ * sizeof(int4);
     int qt, ns, rows;
     knn2_shape(nq, ndb, &qt, &ns, &rows);
     return (size_t)ns * (size_t)(nq > 0 ? nq : 1) * sizeof(int4);
@@ -154,10 +245,19 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
                  int32_t *best_d, int32_t *second_d, void *scratch, size_t scratch_bytes)
 {
     if (nq <= 0) return;
-    int qt, ns, rows;
-    knn2_shape(nq, ndb, &qt, &ns, &rows);
     (void)scratch_bytes;
     int4 *partial = reinterpret_cast<int4 *>(scratch);
+    if (knn2_few(nq, ndb)) {
+        const int nblocks = std::min(FQ_BLOCKS, (ndb + 255) / 256);
+        for (int q0 = 0; q0 < nq; q0 += FQ) {
+            hipLaunchKernelGGL(k_knn2_fewq, dim3(nblocks, 1, 1), dim3(256, 1, 1), 0, s, q, nq, q0, db, ndb, partial);
+            hipLaunchKernelGGL(k_knn2_fewq_merge, dim3(FQ, 1, 1), dim3(64, 1, 1), 0, s, partial, nblocks, nq, q0,
+                               best_idx, best_d, second_d);
+        }
+        return;
+    }
+    int qt, ns, rows;
+    knn2_shape(nq, ndb, &qt, &ns, &rows);
     hipLaunchKernelGGL(k_knn2, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
     hipLaunchKernelGGL(k_knn2_merge, dim3(qt, 1, 1), dim3(256, 1, 1), 0, s, partial, nq, ns, best_idx, best_d,
                        second_d);
