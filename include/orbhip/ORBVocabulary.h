@@ -1,0 +1,58 @@
+// ORBVocabulary.h -- drop-in for the part of the reference's include/ORBVocabulary.h
+// (typedef DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> ORBVocabulary) that the ORB hot path uses:
+// loadFromBinaryFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1680-1721, called from
+// src/System.cc:336-339) and transform(features, BowVector&, FeatureVector&, levelsup) (:1167-1258, called
+// from Frame::ComputeBoW src/Frame.cc:739-746 and KeyFrame::ComputeBoW src/KeyFrame.cc:392-400).
+// The tree descent runs in liborbhip.so (k_vocab_transform); the BowVector / FeatureVector maps are
+// assembled on the host in ascending feature order (the canonical order; the fork's own transform fills
+// them from four racing threads, TemplatedVocabulary.h:1202-1211).
+#ifndef ORBVOCABULARY_H
+#define ORBVOCABULARY_H
+
+#include <map>
+#include <string>
+#include <vector>
+
+#ifdef ORBHIP_WITH_REFERENCE_HEADERS
+#include "Thirdparty/DBoW2/DBoW2/BowVector.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#include <opencv2/core/core.hpp>
+#else
+#include "cvlite.h"
+#include "slamlite.h"
+#endif
+
+struct orbhip_ctx;
+
+namespace ORB_SLAM2
+{
+
+class ORBVocabulary
+{
+public:
+    ORBVocabulary();
+    ~ORBVocabulary();
+    ORBVocabulary(const ORBVocabulary &) = delete;
+    ORBVocabulary &operator=(const ORBVocabulary &) = delete;
+
+    // ref: TemplatedVocabulary.h:1680 -- returns false if the file cannot be read or is malformed
+    bool loadFromBinaryFile(const std::string &filename);
+    // same from memory (e.g. the blob received through orbhip_bcast_blob_device)
+    bool loadFromBinaryBlob(const void *blob, size_t nbytes);
+    bool empty() const { return mnNodes == 0; }
+    unsigned int size() const { return (unsigned int)mnWords; }   // number of words, ref :1109
+
+    // ref: TemplatedVocabulary.h:1167-1258
+    void transform(const std::vector<cv::Mat> &features, DBoW2::BowVector &v, DBoW2::FeatureVector &fv,
+                   int levelsup) const;
+
+    static void SetDevice(int device);
+
+private:
+    orbhip_ctx *mpCtx;
+    int mnNodes, mnWords, mK, mL, mScoring, mWeighting;
+};
+
+}  // namespace ORB_SLAM2
+
+#endif

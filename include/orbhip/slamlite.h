@@ -14,6 +14,12 @@
 namespace DBoW2
 {
 typedef unsigned int NodeId;
+typedef unsigned int WordId;
+typedef double WordValue;
+// ref: Thirdparty/DBoW2/DBoW2/BowVector.h -- word id -> value
+class BowVector : public std::map<WordId, WordValue>
+{
+};
 // ref: Thirdparty/DBoW2/DBoW2/FeatureVector.h -- node id -> indices of the features under it
 class FeatureVector : public std::map<NodeId, std::vector<unsigned int> >
 {

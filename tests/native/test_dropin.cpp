@@ -5,6 +5,8 @@
 //   Frame.cc:817          mpORBextractorLeft->mvImagePyramid[l]
 //   Tracking.cc:1881-1885 ORBmatcher matcher(0.7,true); matcher.SearchByBoW(pKF, F, vpMapPointMatches)
 //   LoopClosing.cc:291    ORBmatcher matcher(0.75,true); matcher.SearchByBoW(pKF1, pKF2, vpMatches12)
+//   System.cc:336-339     mpVocabulary->loadFromBinaryFile(strVocFile)
+//   Frame.cc:739-746      mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)
 // Inputs/outputs are raw binary files so that tests/test_gpu_dropin.py can compare with the oracle.
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +14,7 @@
 
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "ORBVocabulary.h"
 
 using namespace ORB_SLAM2;
 
@@ -139,6 +142,39 @@ int main(int argc, char **argv)
         cv::Mat a = kf.mDescriptors.row(0), b = F.mDescriptors.row(0);
         int d = ORBmatcher::DescriptorDistance(a, b);
         fwrite(&d, 4, 1, out);
+    }
+    if (argc > 7) {
+        ORBVocabulary *mpVocabulary = new ORBVocabulary();
+        const bool bVocLoad = mpVocabulary->loadFromBinaryFile(argv[7]);
+        int okflag = bVocLoad ? 1 : 0, nwords = (int)mpVocabulary->size();
+        fwrite(&okflag, 4, 1, out);
+        fwrite(&nwords, 4, 1, out);
+        // Converter::toDescriptorVector (src/Converter.cc:163-171): one 1x32 Mat per descriptor row
+        std::vector<cv::Mat> vCurrentDesc;
+        for (int j = 0; j < kf.mDescriptors.rows; j++) vCurrentDesc.push_back(kf.mDescriptors.row(j));
+        DBoW2::BowVector mBowVec;
+        DBoW2::FeatureVector mFeatVec;
+        mpVocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4);
+        int nb = (int)mBowVec.size();
+        fwrite(&nb, 4, 1, out);
+        for (DBoW2::BowVector::const_iterator it = mBowVec.begin(); it != mBowVec.end(); ++it) {
+            int w = (int)it->first;
+            double val = it->second;
+            fwrite(&w, 4, 1, out);
+            fwrite(&val, 8, 1, out);
+        }
+        int nfv = (int)mFeatVec.size();
+        fwrite(&nfv, 4, 1, out);
+        for (DBoW2::FeatureVector::const_iterator it = mFeatVec.begin(); it != mFeatVec.end(); ++it) {
+            int node = (int)it->first, cnt = (int)it->second.size();
+            fwrite(&node, 4, 1, out);
+            fwrite(&cnt, 4, 1, out);
+            for (int j = 0; j < cnt; j++) {
+                int idx = (int)it->second[j];
+                fwrite(&idx, 4, 1, out);
+            }
+        }
+        delete mpVocabulary;
     }
     delete mpORBextractorLeft;
     fclose(out);

@@ -39,8 +39,11 @@ def test_cpp_dropin_classes_match_oracle(oracle, tmp_path):
     (tmp_path / "frames.raw").write_bytes(frames.tobytes())
     (tmp_path / "groups.bin").write_bytes(node.tobytes())
     out = tmp_path / "out.bin"
+    from orbhip import distributed as D
+    blob = D.make_synthetic_vocabulary(52, k=10, L=5)
+    (tmp_path / "voc.bin").write_bytes(blob)
     subprocess.check_call([EXE, str(W), str(H), str(NF), str(tmp_path / "frames.raw"), str(tmp_path / "groups.bin"),
-                           str(out)])
+                           str(out), str(tmp_path / "voc.bin")])
     buf = out.read_bytes()
     pos = 0
 
@@ -97,4 +100,24 @@ def test_cpp_dropin_classes_match_oracle(oracle, tmp_path):
     assert nm == wn and cnt == n1 and np.array_equal(got, want) and nm > 50
     d, = take("<i")
     assert d == oracle.descriptor_distance(d1[0], d2[0])
+    # ORBVocabulary::loadFromBinaryFile + transform(features, BowVector, FeatureVector, 4)
+    ok, nwords = take("<ii")
+    V = oracle.Vocabulary(blob)
+    assert ok == 1 and nwords == V.nwords
+    w, wt, nid = V.transform(d1, 4)
+    bw, bv = V.bow(w, wt)
+    nb, = take("<i")
+    got_w, got_v = [], []
+    for _ in range(nb):
+        a, b = take("<id")
+        got_w.append(a)
+        got_v.append(b)
+    assert got_w == bw.tolist() and got_v == bv.tolist()          # doubles, same summation order
+    ids, off, idx = oracle.feature_vector(nid, wt)
+    nfv, = take("<i")
+    assert nfv == len(ids)
+    for g in range(nfv):
+        node_id, cnt = take("<ii")
+        members = list(take("<%di" % cnt))
+        assert node_id == ids[g] and members == idx[off[g]:off[g + 1]].tolist()
     assert pos == len(buf)
