@@ -303,3 +303,32 @@ def test_forced_tiny_fast_lists_take_the_fallback_paths(hip):
     env = dict(os.environ, ORBHIP_FAST_LISTCAP="8")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert out.returncode == 0 and "fallback ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_two_contexts_on_two_host_threads(hip, oracle):
+    """Stereo pattern of the reference (src/Frame.cc:422-425): left and right extractor instances run
+    concurrently on two std::threads.  Here: two contexts, two Python threads (ctypes drops the GIL)."""
+    import threading
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    frames = synth.make_frames(90, 1241, 376, 2)
+    exs = [ORBextractor(2000, max_w=1241, max_h=376) for _ in range(2)]
+    res = [None, None]
+
+    def work(i):
+        out = []
+        for _ in range(6):
+            out.append(exs[i](frames[i]))
+        res[i] = out
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    ref = oracle.Extractor(2000)
+    for i in range(2):
+        rk, rd = ref(frames[i])
+        for k, d in res[i]:
+            assert _same_kps(k, rk) and np.array_equal(d, rd)
+    for e in exs:
+        e.close()
