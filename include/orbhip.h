@@ -205,6 +205,21 @@ int orbhip_search_by_bow_seq_device(orbhip_ctx *ctx, const void *d_desc, const v
                                     int B, int lag, int th_mode, float nnratio, int check_ori, void *d_match12,
                                     void *d_match21, void *d_nmatches);
 
+/* ---- stereo ----
+ * Replaces Frame::ComputeStereoMatches (src/Frame.cc:810-984): for every left keypoint the best right
+ * keypoint in its row band (octave +-1, u in [uL - mbf/mb, uL], distance < 75), refined by the 11-shift SAD
+ * on the pyramid level of the keypoint and a parabola fit; outputs mvuRight / mvDepth (-1 = none) after the
+ * median-based outlier cut.  `left` and `right` are the two extractor contexts that have just extracted the
+ * left / right image(s) of the same size: their device-resident pyramids are read in place (the reference
+ * reads mpORBextractorLeft/Right->mvImagePyramid, :817,:907,:919,:924).  *nmatch = matches before the cut. */
+int orbhip_stereo_match(orbhip_ctx *left, orbhip_ctx *right, const orbhip_keypoint *kpsL, const uint8_t *descL,
+                        int nL, const orbhip_keypoint *kpsR, const uint8_t *descR, int nR, float mb, float mbf,
+                        float *mvuRight, float *mvDepth, int *nmatch);
+/* Batched, device-resident form (B stereo pairs; arrays laid out like orbhip_extract_batch_device outputs). */
+int orbhip_stereo_match_device(orbhip_ctx *left, orbhip_ctx *right, const void *d_kpsL, const void *d_descL,
+                               const void *d_cntL, const void *d_kpsR, const void *d_descR, const void *d_cntR,
+                               int cap, int B, float mb, float mbf, void *d_uRight, void *d_depth, void *d_nmatch);
+
 /* Device time of the stages of the last extract call on this context, in ms:
  * {pyramid, FAST, quadtree, blur, describe} and, at [5], of the last orbhip_hamming_knn2*_device
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */

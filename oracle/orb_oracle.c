@@ -1287,3 +1287,146 @@ int orbo_vocab_bow(const orbo_vocab *v, const int32_t *word_id, const float *wei
     free(e);
     return m;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Next row: Frame::ComputeStereoMatches.  ref: src/Frame.cc:810-984.
+ * Row-band table of the right keypoints (:819-837), per left keypoint the minimum descriptor distance
+ * over the band with octave +-1 and u in [uL - maxD, uL] (:848-893), 11-shift SAD on 11x11 patches of
+ * the pyramid level of the left keypoint (:896-936; cv::norm NORM_L1 of centre-subtracted float patches:
+ * every term is an integer, so the sum is exact), parabola sub-pixel fit (:938-946), disparity -> depth
+ * (:948-966), then the median-based outlier cut (:970-983).
+ * Out-of-range row indices (undefined behaviour in the reference) are skipped; an empty match set
+ * (the reference would index vDistIdx[0] of an empty vector) returns without the cut.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int dist, idx;
+} sm_pair;
+
+static int sm_cmp(const void *a, const void *b)
+{
+    const sm_pair *x = (const sm_pair *)a, *y = (const sm_pair *)b;
+    if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+int orbo_stereo_matches(const orbo_keypoint *kL, const uint8_t *dL, int nL, const orbo_keypoint *kR,
+                        const uint8_t *dR, int nR, const uint8_t *const *pyrL, const uint8_t *const *pyrR,
+                        const int *lw, const int *lh, const float *mvScaleFactors, const float *mvInvScaleFactors,
+                        float mb, float mbf, float *mvuRight, float *mvDepth)
+{
+    const int TH_HIGH = 100, TH_LOW = 50;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = lh[0];
+    for (int i = 0; i < nL; i++) {
+        mvuRight[i] = -1.0f;
+        mvDepth[i] = -1.0f;
+    }
+    /* row table: counts, then CSR */
+    int *cnt = (int *)calloc((size_t)nRows + 1, sizeof(int));
+    for (int iR = 0; iR < nR; iR++) {
+        const float kpY = kR[iR].y;
+        const float r = 2.0f * mvScaleFactors[kR[iR].octave];
+        const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) cnt[yi + 1]++;
+    }
+    for (int i = 0; i < nRows; i++) cnt[i + 1] += cnt[i];
+    int *rows = (int *)malloc(sizeof(int) * (size_t)(cnt[nRows] + 1));
+    int *fill = (int *)calloc((size_t)nRows, sizeof(int));
+    for (int iR = 0; iR < nR; iR++) {
+        const float kpY = kR[iR].y;
+        const float r = 2.0f * mvScaleFactors[kR[iR].octave];
+        const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) rows[cnt[yi] + fill[yi]++] = iR;
+    }
+    free(fill);
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    sm_pair *vDistIdx = (sm_pair *)malloc(sizeof(sm_pair) * (size_t)(nL + 1));
+    int nd = 0;
+    for (int iL = 0; iL < nL; iL++) {
+        const int levelL = kL[iL].octave;
+        const float vL = kL[iL].y, uL = kL[iL].x;
+        const int rowi = (int)vL;
+        if (rowi < 0 || rowi >= nRows) continue;
+        if (cnt[rowi + 1] == cnt[rowi]) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH, bestIdxR = 0;
+        for (int c = cnt[rowi]; c < cnt[rowi + 1]; c++) {
+            const int iR = rows[c];
+            if (kR[iR].octave < levelL - 1 || kR[iR].octave > levelL + 1) continue;
+            const float uR = kR[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orbo_descriptor_distance(dL + (size_t)iL * 32, dR + (size_t)iR * 32);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = iR;
+                }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = kR[bestIdxR].x;
+            const float scaleFactor = mvInvScaleFactors[levelL];
+            const float scaleduL = roundf(kL[iL].x * scaleFactor);
+            const float scaledvL = roundf(kL[iL].y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const uint8_t *imL = pyrL[levelL], *imR = pyrR[levelL];
+            const int W = lw[levelL];
+            const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR = (int)scaleduR0;
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= (float)W) continue;
+            int sadBest = 2147483647, bestincR = 0;
+            float vDists[11];
+            const int cLv = imL[(size_t)cy * W + cxL];
+            for (int incR = -L; incR <= +L; incR++) {
+                const int cRv = imR[(size_t)cy * W + cxR + incR];
+                long sum = 0;
+                for (int dy = -w; dy <= w; dy++)
+                    for (int dx = -w; dx <= w; dx++) {
+                        const int a = imL[(size_t)(cy + dy) * W + cxL + dx] - cLv;
+                        const int b = imR[(size_t)(cy + dy) * W + cxR + incR + dx] - cRv;
+                        sum += labs((long)(a - b));
+                    }
+                const float dist = (float)sum;
+                if (dist < (float)sadBest) {
+                    sadBest = (int)dist;
+                    bestincR = incR;
+                }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = mvScaleFactors[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01f;
+                    bestuR = (float)((double)uL - 0.01); /* `uL-0.01` is evaluated in double, :957 */
+                }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx[nd].dist = sadBest;
+                vDistIdx[nd].idx = iL;
+                nd++;
+            }
+        }
+    }
+    if (nd > 0) {
+        qsort(vDistIdx, (size_t)nd, sizeof(sm_pair), sm_cmp);
+        const float median = (float)vDistIdx[nd / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nd - 1; i >= 0; i--) {
+            if ((float)vDistIdx[i].dist < thDist) break;
+            mvuRight[vDistIdx[i].idx] = -1;
+            mvDepth[vDistIdx[i].idx] = -1;
+        }
+    }
+    free(vDistIdx);
+    free(rows);
+    free(cnt);
+    return nd;
+}

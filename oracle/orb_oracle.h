@@ -146,6 +146,14 @@ void orbo_vocab_transform(const orbo_vocab *v, const uint8_t *desc, int n, int l
 int orbo_vocab_bow(const orbo_vocab *v, const int32_t *word_id, const float *weight, int n, int32_t *out_word,
                    double *out_value);
 
+/* ---- next row: Frame::ComputeStereoMatches (src/Frame.cc:810-984) ----
+ * pyrL / pyrR: the extractor pyramids (continuous, stride = width), lw / lh their sizes.  Outputs
+ * mvuRight / mvDepth [nL] (-1 = no match).  Returns the number of matches before the outlier cut. */
+int orbo_stereo_matches(const orbo_keypoint *kL, const uint8_t *dL, int nL, const orbo_keypoint *kR,
+                        const uint8_t *dR, int nR, const uint8_t *const *pyrL, const uint8_t *const *pyrR,
+                        const int *lw, const int *lh, const float *mvScaleFactors, const float *mvInvScaleFactors,
+                        float mb, float mbf, float *mvuRight, float *mvDepth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -360,3 +360,30 @@ def feature_vector(node_id, weight=None):
     off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
     idx = (np.concatenate(lists) if lists else np.zeros(0)).astype(np.int32)
     return np.array(ids, np.int32), off, idx
+
+
+def stereo_matches(exL, kL, dL, exR, kR, dR, mb, mbf):
+    """Frame::ComputeStereoMatches (src/Frame.cc:810-984) on two oracle Extractors that have just
+    processed the left / right image.  Returns (mvuRight, mvDepth, n_before_cut)."""
+    L = lib()
+    L.orbo_stereo_matches.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 6 + \
+        [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    nl = exL.nlevels
+    pl = [np.ascontiguousarray(exL.pyramid(l)) for l in range(nl)]
+    pr = [np.ascontiguousarray(exR.pyramid(l)) for l in range(nl)]
+    lw = np.array([p.shape[1] for p in pl], np.int32)
+    lh = np.array([p.shape[0] for p in pl], np.int32)
+    PL = (C.c_void_p * nl)(*[p.ctypes.data for p in pl])
+    PR = (C.c_void_p * nl)(*[p.ctypes.data for p in pr])
+    P = exL.params
+    sf = np.array(list(P.mvScaleFactor)[:nl], np.float32)
+    isf = np.array(list(P.mvInvScaleFactor)[:nl], np.float32)
+    kL = np.ascontiguousarray(kL)
+    kR = np.ascontiguousarray(kR)
+    dL = np.ascontiguousarray(dL, np.uint8)
+    dR = np.ascontiguousarray(dR, np.uint8)
+    u = np.empty(max(len(kL), 1), np.float32)
+    z = np.empty(max(len(kL), 1), np.float32)
+    n = L.orbo_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), PL, PR, _p(lw), _p(lh), _p(sf), _p(isf),
+                              mb, mbf, _p(u), _p(z))
+    return u[:len(kL)].copy(), z[:len(kL)].copy(), n

@@ -1,0 +1,98 @@
+"""Frame::ComputeStereoMatches (src/Frame.cc:810-984): oracle sanity on CPU,
+HIP (two extractor contexts, pyramids read in place) against the oracle on the GPU."""
+import numpy as np
+import pytest
+
+
+def test_oracle_stereo_recovers_the_synthetic_disparity(oracle):
+    from orbhip import synth
+    L, R = synth.make_stereo_pair(3, 752, 480, disparity=21)
+    exL, exR = oracle.Extractor(1000), oracle.Extractor(1000)
+    kL, dL = exL(L)
+    kR, dR = exR(R)
+    u, z, n = oracle.stereo_matches(exL, kL, dL, exR, kR, dR, 0.11, 47.9)
+    ok = u >= 0
+    assert n > 400 and ok.sum() > 300 and ok.sum() <= n
+    disp = (kL["x"] - u)[ok]
+    assert abs(np.median(disp) - 21) < 0.2
+    assert np.allclose(z[ok], np.float32(47.9) / disp, rtol=1e-6)
+    assert (z[~ok] == -1).all() and (u[~ok] == -1).all()
+    # no right keypoints -> no matches, no crash (the reference would index an empty vector)
+    u2, z2, n2 = oracle.stereo_matches(exL, kL, dL, exR, kR[:0], dR[:0], 0.11, 47.9)
+    assert n2 == 0 and (u2 == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nf,disp,mb,mbf", [(1241, 376, 2000, 17, 0.54, 386.1),     # KITTI00-02.yaml
+                                                (752, 480, 1200, 33, 0.11, 47.9),      # EuRoC stereo
+                                                (640, 480, 1000, 3, 0.2, 20.0)])       # tiny disparity, small maxD
+def test_hip_stereo_matches_oracle(oracle, w, h, nf, disp, mb, mbf):
+    from orbhip import synth
+    from orbhip.extractor import ComputeStereoMatches, ORBextractor
+    L, R = synth.make_stereo_pair(100 + disp, w, h, disparity=disp)
+    exL = ORBextractor(nf, max_w=w, max_h=h)
+    exR = ORBextractor(nf, max_w=w, max_h=h)
+    kL, dL = exL(L)
+    kR, dR = exR(R)
+    u, z, nm = ComputeStereoMatches(exL, kL, dL, exR, kR, dR, mb, mbf)
+    oL, oR = oracle.Extractor(nf), oracle.Extractor(nf)
+    rkL, rdL = oL(L)
+    rkR, rdR = oR(R)
+    assert kL.tobytes() == rkL.tobytes() and kR.tobytes() == rkR.tobytes()
+    ru, rz, rn = oracle.stereo_matches(oL, rkL, rdL, oR, rkR, rdR, mb, mbf)
+    assert nm == rn and rn > 100
+    assert u.tobytes() == ru.tobytes() and z.tobytes() == rz.tobytes()          # floats compared as bit patterns
+    assert (ru >= 0).sum() > 50
+    # right side without keypoints
+    u, z, nm = ComputeStereoMatches(exL, kL, dL, exR, kR[:0], dR[:0], mb, mbf)
+    assert nm == 0 and len(u) == len(kL) and (u == -1).all() and (z == -1).all()
+    exL.close()
+    exR.close()
+
+
+@pytest.mark.gpu
+def test_hip_stereo_batched_device_resident(oracle):
+    import hiprt
+    from orbhip import synth
+    from orbhip.capi import check
+    from orbhip.extractor import ORBextractor
+    B, W, H, NF = 3, 752, 480, 1000
+    pairs = [synth.make_stereo_pair(200 + b, W, H, disparity=12 + 7 * b) for b in range(B)]
+    left = np.stack([p[0] for p in pairs])
+    right = np.stack([p[1] for p in pairs])
+    exL = ORBextractor(NF, max_w=W, max_h=H, max_batch=B)
+    exR = ORBextractor(NF, max_w=W, max_h=H, max_batch=B)
+    cap = exL.cap
+    stride = 768
+    bufs = {}
+    for name, ex, imgs in (("L", exL, left), ("R", exR, right)):
+        host = np.zeros((B, H, stride), np.uint8)
+        host[:, :, :W] = imgs
+        d_img = hiprt.DevBuf.from_numpy(host)
+        d_k, d_d, d_c = hiprt.DevBuf(B * cap * 28), hiprt.DevBuf(B * cap * 32), hiprt.DevBuf(B * 4)
+        ex.extract_batch_device(d_img.ptr, B, W, H, stride, H * stride, d_k.ptr, d_d.ptr, cap, d_c.ptr)
+        bufs[name] = (d_img, d_k, d_d, d_c)
+    d_u, d_z, d_n = hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * 4)
+    check(exL._L.orbhip_stereo_match_device(exL.handle, exR.handle, bufs["L"][1].ptr, bufs["L"][2].ptr, bufs["L"][3].ptr,
+                                            bufs["R"][1].ptr, bufs["R"][2].ptr, bufs["R"][3].ptr, cap, B, 0.11, 47.9, d_u.ptr,
+                                            d_z.ptr, d_n.ptr), exL.handle, "orbhip_stereo_match_device")
+    exL.sync()
+    u = d_u.to_numpy(np.float32, (B, cap))
+    z = d_z.to_numpy(np.float32, (B, cap))
+    n = d_n.to_numpy(np.int32, (B,))
+    oL, oR = oracle.Extractor(NF), oracle.Extractor(NF)
+    for b in range(B):
+        rkL, rdL = oL(left[b])
+        rkR, rdR = oR(right[b])
+        ru, rz, rn = oracle.stereo_matches(oL, rkL, rdL, oR, rkR, rdR, 0.11, 47.9)
+        m = len(rkL)
+        assert n[b] == rn and u[b, :m].tobytes() == ru.tobytes() and z[b, :m].tobytes() == rz.tobytes()
+        ok = ru >= 0
+        assert abs(np.median((rkL["x"] - ru)[ok]) - (12 + 7 * b)) < 0.3
+    exL.close()
+    exR.close()
+    for t in bufs.values():
+        for x in t:
+            x.free()
+    for x in (d_u, d_z, d_n):
+        x.free()

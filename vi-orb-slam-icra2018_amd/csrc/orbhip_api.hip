@@ -882,6 +882,69 @@ extern "C" int orbhip_search_by_bow_seq_device(orbhip_ctx *c, const void *d_desc
 }
 
 // ------------------------------------------------------------------------------------------------
+// stereo
+// ------------------------------------------------------------------------------------------------
+extern "C" int orbhip_stereo_match_device(orbhip_ctx *L, orbhip_ctx *R, const void *d_kpsL, const void *d_descL,
+                                          const void *d_cntL, const void *d_kpsR, const void *d_descR,
+                                          const void *d_cntR, int cap, int B, float mb, float mbf, void *d_uRight,
+                                          void *d_depth, void *d_nmatch)
+{
+    if (!L || !R || !d_kpsL || !d_descL || !d_cntL || !d_kpsR || !d_descR || !d_cntR || cap <= 0 || B <= 0 ||
+        !d_uRight || !d_depth || !d_nmatch || !(mb > 0.f) || !(mbf > 0.f))
+        return fail(L, ORBHIP_E_ARG, "orbhip_stereo_match_device: bad argument");
+    if (!L->last_lvl0 || !R->last_lvl0 || L->cur_w != R->cur_w || L->cur_h != R->cur_h || L->nlevels != R->nlevels ||
+        B > L->last_B || B > R->last_B || L->device != R->device)
+        return fail(L, ORBHIP_E_ARG, "orbhip_stereo_match_device: both contexts must have just extracted images of the "
+                                     "same size on the same device");
+    HIPCHK(L, hipSetDevice(L->device));
+    int rc;
+    if ((rc = match_scratch(L, (size_t)3 * B * cap * 4))) return rc;
+    // the right pyramid / keypoints are produced on the right context's stream
+    HIPCHK(L, hipEventRecord(R->evx[0], R->stream));
+    HIPCHK(L, hipStreamWaitEvent(L->stream, R->evx[0], 0));
+    launch_stereo(L, R, (const orbhip_keypoint *)d_kpsL, (const uint8_t *)d_descL, (const int32_t *)d_cntL,
+                  (const orbhip_keypoint *)d_kpsR, (const uint8_t *)d_descR, (const int32_t *)d_cntR, cap, B, mb, mbf,
+                  (float *)d_uRight, (float *)d_depth, (int32_t *)L->d_match, (int32_t *)d_nmatch);
+    HIPCHK(L, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_stereo_match(orbhip_ctx *L, orbhip_ctx *R, const orbhip_keypoint *kpsL, const uint8_t *descL, int nL,
+                                   const orbhip_keypoint *kpsR, const uint8_t *descR, int nR, float mb, float mbf,
+                                   float *mvuRight, float *mvDepth, int *nmatch)
+{
+    if (!L || !R || nL < 0 || nR < 0 || (nL > 0 && (!kpsL || !descL || !mvuRight || !mvDepth)) || (nR > 0 && (!kpsR || !descR)))
+        return fail(L, ORBHIP_E_ARG, "orbhip_stereo_match: bad argument");
+    if (nmatch) *nmatch = 0;
+    for (int i = 0; i < nL; i++) mvuRight[i] = mvDepth[i] = -1.0f;
+    if (nL == 0 || nR == 0) return ORBHIP_OK;
+    HIPCHK(L, hipSetDevice(L->device));
+    const int cap = std::max(nL, nR);
+    TmpDev T(L);
+    int rc;
+    if ((rc = T.reserve((size_t)cap * (28 + 32) * 2 + (size_t)cap * 8 + 4096))) return rc;
+    orbhip_keypoint *dkL = (orbhip_keypoint *)T.take((size_t)cap * 28), *dkR = (orbhip_keypoint *)T.take((size_t)cap * 28);
+    uint8_t *ddL = (uint8_t *)T.take((size_t)cap * 32), *ddR = (uint8_t *)T.take((size_t)cap * 32);
+    float *du = (float *)T.take((size_t)cap * 4), *dz = (float *)T.take((size_t)cap * 4);
+    int32_t *dc = (int32_t *)T.take(16);
+    const int32_t cnts[3] = {nL, nR, 0};
+    hipStream_t s = L->stream;
+    HIPCHK(L, hipMemcpyAsync(dkL, kpsL, (size_t)nL * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(L, hipMemcpyAsync(dkR, kpsR, (size_t)nR * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(L, hipMemcpyAsync(ddL, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(L, hipMemcpyAsync(ddR, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(L, hipMemcpyAsync(dc, cnts, 12, hipMemcpyHostToDevice, s));
+    if ((rc = orbhip_stereo_match_device(L, R, dkL, ddL, dc, dkR, ddR, dc + 1, cap, 1, mb, mbf, du, dz, dc + 2))) return rc;
+    int nm = 0;
+    HIPCHK(L, hipMemcpyAsync(mvuRight, du, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(L, hipMemcpyAsync(mvDepth, dz, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(L, hipMemcpyAsync(&nm, dc + 2, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(L, hipStreamSynchronize(s));
+    if (nmatch) *nmatch = nm;
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RCCL (loaded lazily so that the library has no hard link-time dependency on it)
 // ------------------------------------------------------------------------------------------------
 typedef struct { char internal[128]; } rccl_uid_t;

@@ -26,7 +26,7 @@ SYMBOLS = [
     "orbhip_debug_get_level_keypoints", "orbhip_hamming_knn2", "orbhip_hamming_knn2_device",
     "orbhip_hamming_knn2_seq_device", "orbhip_get_stage_times", "orbhip_vocab_load", "orbhip_vocab_load_device",
     "orbhip_vocab_info", "orbhip_vocab_transform", "orbhip_vocab_transform_device",
-    "orbhip_search_by_bow_seq_device",
+    "orbhip_search_by_bow_seq_device", "orbhip_stereo_match", "orbhip_stereo_match_device",
     "orbhip_hamming_knn2_lists", "orbhip_search_by_bow", "orbhip_comm_unique_id",
     "orbhip_comm_init", "orbhip_bcast_blob_device",
 ]
@@ -78,6 +78,8 @@ def load():
     L.orbhip_hamming_knn2_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     L.orbhip_hamming_knn2_seq_device.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.orbhip_get_stage_times.argtypes = [vp, vp]
+    L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, ip]
+    L.orbhip_stereo_match_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     L.orbhip_vocab_load.argtypes = [vp, vp, C.c_size_t]
     L.orbhip_vocab_load_device.argtypes = [vp, vp, C.c_size_t]
     L.orbhip_vocab_info.argtypes = [vp, ip, ip, ip, ip, ip, ip]

@@ -233,3 +233,19 @@ class ORBmatcher:
                                            self.mfNNratio, 1 if self.mbCheckOrientation else 0, _p(m12), _p(m21),
                                            C.byref(nm)), self._ctx.handle, "orbhip_search_by_bow")
         return nm.value, m12[:n1].copy(), m21[:n2].copy()
+
+
+def ComputeStereoMatches(exL, kpsL, descL, exR, kpsR, descR, mb, mbf):
+    """Frame::ComputeStereoMatches (src/Frame.cc:810-984) on the pyramids the two extractor contexts still
+    hold from their last operator() call.  Returns (mvuRight, mvDepth, n_before_median_cut)."""
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE)
+    kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    descL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    descR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    n = len(kpsL)
+    u = np.empty(max(n, 1), np.float32)
+    z = np.empty(max(n, 1), np.float32)
+    nm = C.c_int()
+    check(exL._L.orbhip_stereo_match(exL.handle, exR.handle, _p(kpsL), _p(descL), n, _p(kpsR), _p(descR), len(kpsR),
+                                     mb, mbf, _p(u), _p(z), C.byref(nm)), exL.handle, "orbhip_stereo_match")
+    return u[:n].copy(), z[:n].copy(), nm.value

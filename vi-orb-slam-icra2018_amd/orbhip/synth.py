@@ -123,3 +123,11 @@ def make_queries(seed, db, nq, max_flips=40):
         for b in bits:
             q[i, b >> 3] ^= np.uint8(1 << (b & 7))
     return q, rows
+
+
+def make_stereo_pair(seed, width, height, disparity=17, t=0):
+    """Rectified stereo pair of one scene: the right camera sees every point `disparity` pixels further
+    left (constant depth plane), so row-aligned matches exist (BASELINE config 3 geometry)."""
+    scene = make_scene(seed, width + disparity + 64, height)
+    big = warp_frame(scene, width + disparity + 32, height, t)
+    return big[:, 16:16 + width].copy(), big[:, 16 + disparity:16 + disparity + width].copy()
