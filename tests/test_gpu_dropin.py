@@ -121,3 +121,27 @@ def test_cpp_dropin_classes_match_oracle(oracle, tmp_path):
         members = list(take("<%di" % cnt))
         assert node_id == ids[g] and members == idx[off[g]:off[g + 1]].tolist()
     assert pos == len(buf)
+
+
+def test_cpp_stereo_frame_matches_oracle(oracle, tmp_path):
+    """Two drop-in extractors on two host threads + Frame::ComputeStereoMatches (src/Frame.cc:413-437)."""
+    from orbhip import synth
+    from orbhip.capi import KP_DTYPE
+    exe = os.path.join(ROOT, "tests", "native", "test_stereo_dropin")
+    assert os.path.exists(exe), "tests/native/test_stereo_dropin is not built (run __graft_entry__.build())"
+    W, H, NF, mb, mbf = 1241, 376, 2000, 0.53716, 386.1448
+    L, R = synth.make_stereo_pair(60, W, H, disparity=23)
+    (tmp_path / "pair.raw").write_bytes(L.tobytes() + R.tobytes())
+    out = tmp_path / "stereo.bin"
+    subprocess.check_call([exe, str(W), str(H), str(NF), repr(mb), repr(mbf), str(tmp_path / "pair.raw"), str(out)])
+    buf = out.read_bytes()
+    n, nr = struct.unpack_from("<ii", buf, 0)
+    kps = np.frombuffer(buf, KP_DTYPE, n, 8)
+    u = np.frombuffer(buf, np.float32, n, 8 + 28 * n)
+    z = np.frombuffer(buf, np.float32, n, 8 + 32 * n)
+    oL, oR = oracle.Extractor(NF), oracle.Extractor(NF)
+    kL, dL = oL(L)
+    kR, dR = oR(R)
+    assert n == len(kL) and nr == len(kR) and kps.tobytes() == kL.tobytes()
+    ru, rz, rn = oracle.stereo_matches(oL, kL, dL, oR, kR, dR, np.float32(mb), np.float32(mbf))
+    assert u.tobytes() == ru.tobytes() and z.tobytes() == rz.tobytes() and (ru >= 0).sum() > 300

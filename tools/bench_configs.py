@@ -66,6 +66,58 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
     return nsteps * B / dt, dt, kp, list(ms)
 
 
+def run_stereo(W, H, nfeat, B, total_pairs, mb, mbf, uniq=8):
+    """Config 3 end to end: left and right extraction on two contexts (two streams), then
+    Frame::ComputeStereoMatches on the resident pyramids."""
+    pairs = [synth.make_stereo_pair(300 + i, W, H, disparity=10 + 3 * i) for i in range(min(uniq, B))]
+    stride = (W + 15) // 16 * 16
+    host = np.zeros((2, B, H, stride), np.uint8)
+    for b in range(B):
+        host[0, b, :, :W], host[1, b, :, :W] = pairs[b % len(pairs)]
+    d_img = torch.from_numpy(host).cuda()
+    exs = [ORBextractor(nfeat, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B) for _ in range(2)]
+    cap = exs[0].cap
+    i32 = dict(dtype=torch.int32, device="cuda")
+    d_kps = torch.empty((2, B, cap, 7), **i32)
+    d_desc = torch.empty((2, B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((2, B), **i32)
+    d_u = torch.empty((B, cap), dtype=torch.float32, device="cuda")
+    d_z = torch.empty_like(d_u)
+    d_nm = torch.zeros(B, **i32)
+    L = exs[0]._L
+
+    def step():
+        for s in range(2):
+            exs[s].extract_batch_device(d_img[s].data_ptr(), B, W, H, stride, H * stride, d_kps[s].data_ptr(),
+                                        d_desc[s].data_ptr(), cap, d_cnt[s].data_ptr())
+        assert L.orbhip_stereo_match_device(exs[0].handle, exs[1].handle, d_kps[0].data_ptr(), d_desc[0].data_ptr(),
+                                            d_cnt[0].data_ptr(), d_kps[1].data_ptr(), d_desc[1].data_ptr(),
+                                            d_cnt[1].data_ptr(), cap, B, mb, mbf, d_u.data_ptr(), d_z.data_ptr(),
+                                            d_nm.data_ptr()) == 0
+    torch.cuda.synchronize()
+    for _ in range(2):
+        step()
+    exs[0].sync()
+    nsteps = max(1, (total_pairs + B - 1) // B)
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    exs[0].sync()
+    dt = time.perf_counter() - t0
+    # time of the stereo stage alone
+    t1 = time.perf_counter()
+    for _ in range(5):
+        L.orbhip_stereo_match_device(exs[0].handle, exs[1].handle, d_kps[0].data_ptr(), d_desc[0].data_ptr(),
+                                     d_cnt[0].data_ptr(), d_kps[1].data_ptr(), d_desc[1].data_ptr(), d_cnt[1].data_ptr(), cap,
+                                     B, mb, mbf, d_u.data_ptr(), d_z.data_ptr(), d_nm.data_ptr())
+    exs[0].sync()
+    st = (time.perf_counter() - t1) / 5
+    good = float((d_u >= 0).sum().item()) / B
+    for e in exs:
+        e.close()
+    return nsteps * B / dt, st * 1e3, good
+
+
 def run_single_frame_latency(W, H, nfeat):
     img = synth.make_frames(5, W, H, 1)[0]
     ex = ORBextractor(nfeat, max_w=W, max_h=H)
@@ -114,6 +166,8 @@ def main():
     print("| 2: EuRoC MH_01 full sequence | 3682 frames 752x480, 1000 feat, batches of 512, extract + transform + SearchByBoW | %.0f | %.1f kp/frame, %.3f s for the sequence |" % (fps, kp, dt))
     fps, dt, kp, ms = run_extract(1241, 376, 2000, 256, 2048, "bow", seed=2)
     print("| 3: KITTI 00 stereo | 1241x376, 2000 feat, L+R images as 2 frames per pair, extract + transform + SearchByBoW | %.0f images/s = %.0f stereo pairs/s | %.1f kp/image |" % (fps, fps / 2, kp))
+    pps, st, good = run_stereo(1241, 376, 2000, 128, 1024, 0.53716, 386.1448)
+    print("| 3b: KITTI 00 stereo frame | 1241x376 pairs, 2000 feat: extract L + extract R (two contexts) + ComputeStereoMatches on the resident pyramids | %.0f stereo pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
     tot = 0.0
     frames = 0
     for i, n in enumerate([2912, 1710, 2280, 3040]):
