@@ -96,3 +96,33 @@ def test_hip_stereo_batched_device_resident(oracle):
             x.free()
     for x in (d_u, d_z, d_n):
         x.free()
+
+
+@pytest.mark.gpu
+def test_hip_stereo_row_bin_overflow_falls_back_exactly(oracle, tmp_path):
+    """ORBHIP_STEREO_ENT_PER_KP=1 makes the row-bin lists overflow, so the scan over all right keypoints runs;
+    the result must not change (the variable is read once per process -> child process)."""
+    import os
+    import subprocess
+    import sys
+    from orbhip import synth
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from orbhip import synth\n"
+        "from orbhip.extractor import ComputeStereoMatches, ORBextractor\n"
+        "L, R = synth.make_stereo_pair(77, 640, 480, disparity=19)\n"
+        "a, b = ORBextractor(1500, max_w=640, max_h=480), ORBextractor(1500, max_w=640, max_h=480)\n"
+        "kL, dL = a(L); kR, dR = b(R)\n"
+        "u, z, n = ComputeStereoMatches(a, kL, dL, b, kR, dR, 0.2, 40.0)\n"
+        "np.savez(%r, u=u, z=z, n=n)\n" % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                       "vi-orb-slam-icra2018_amd"), str(tmp_path / "o.npz")))
+    env = dict(os.environ, ORBHIP_STEREO_ENT_PER_KP="1")
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    got = np.load(tmp_path / "o.npz")
+    L, R = synth.make_stereo_pair(77, 640, 480, disparity=19)
+    oL, oR = oracle.Extractor(1500), oracle.Extractor(1500)
+    kL, dL = oL(L)
+    kR, dR = oR(R)
+    ru, rz, rn = oracle.stereo_matches(oL, kL, dL, oR, kR, dR, 0.2, 40.0)
+    assert int(got["n"]) == rn and got["u"].tobytes() == ru.tobytes() and got["z"].tobytes() == rz.tobytes() and rn > 200

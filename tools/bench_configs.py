@@ -162,6 +162,10 @@ def run_big_knn(nq, ndb):
 def main():
     print("| config (BASELINE.json) | workload | frames/s | notes |")
     print("|---|---|---|---|")
+    if len(sys.argv) > 1 and sys.argv[1] == "stereo":          # profiling aid: the stereo row only
+        pps, st, good = run_stereo(1241, 376, 2000, 128, 1024, 0.53716, 386.1448)
+        print("| 3b | stereo | %.0f pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
+        return
     fps, dt, kp, ms = run_extract(752, 480, 1000, 512, 3682, "bow", seed=1)
     print("| 2: EuRoC MH_01 full sequence | 3682 frames 752x480, 1000 feat, batches of 512, extract + transform + SearchByBoW | %.0f | %.1f kp/frame, %.3f s for the sequence |" % (fps, kp, dt))
     fps, dt, kp, ms = run_extract(1241, 376, 2000, 256, 2048, "bow", seed=2)

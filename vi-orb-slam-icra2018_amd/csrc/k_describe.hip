@@ -109,7 +109,6 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         img = pyr + (size_t)frame * pyrFrame + L.imgOff;
         stride = L.stride;
     }
-    const uint8_t *center = img + (size_t)cy * stride + cx;
     // The disc rows are read as aligned dwords: lane -> (row of a group of 7, dword 0..8 of the row),
     // 5 trips cover the 31 rows; a row needs at most 31 + 3 bytes = 9 dwords.  (A byte gather costs the
     // texture-address unit 16 cycles per wave instruction; this is 5 coalesced instructions, not 16.)

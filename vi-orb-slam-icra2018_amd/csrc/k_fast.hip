@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     const FastTile T = tiles[blockIdx.x];
     const int frame = blockIdx.y;
     const OrbLevel &L = G.lv[T.level];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
 
     const int maxBX = L.w - ORB_MIN_BORDER, maxBY = L.h - ORB_MIN_BORDER;
     const int iniY = ORB_MIN_BORDER + T.row * L.hCell;

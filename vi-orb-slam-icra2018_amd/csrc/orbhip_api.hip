@@ -893,12 +893,12 @@ extern "C" int orbhip_stereo_match_device(orbhip_ctx *L, orbhip_ctx *R, const vo
         !d_uRight || !d_depth || !d_nmatch || !(mb > 0.f) || !(mbf > 0.f))
         return fail(L, ORBHIP_E_ARG, "orbhip_stereo_match_device: bad argument");
     if (!L->last_lvl0 || !R->last_lvl0 || L->cur_w != R->cur_w || L->cur_h != R->cur_h || L->nlevels != R->nlevels ||
-        B > L->last_B || B > R->last_B || L->device != R->device)
+        B > L->last_B || B > R->last_B || L->device != R->device || L->cur_h > 4095)
         return fail(L, ORBHIP_E_ARG, "orbhip_stereo_match_device: both contexts must have just extracted images of the "
-                                     "same size on the same device");
+                                     "same size (at most 4095 rows) on the same device");
     HIPCHK(L, hipSetDevice(L->device));
     int rc;
-    if ((rc = match_scratch(L, (size_t)3 * B * cap * 4))) return rc;
+    if ((rc = match_scratch(L, stereo_scratch_bytes(B, cap)))) return rc;
     // the right pyramid / keypoints are produced on the right context's stream
     HIPCHK(L, hipEventRecord(R->evx[0], R->stream));
     HIPCHK(L, hipStreamWaitEvent(L->stream, R->evx[0], 0));
@@ -906,6 +906,9 @@ extern "C" int orbhip_stereo_match_device(orbhip_ctx *L, orbhip_ctx *R, const vo
                   (const orbhip_keypoint *)d_kpsR, (const uint8_t *)d_descR, (const int32_t *)d_cntR, cap, B, mb, mbf,
                   (float *)d_uRight, (float *)d_depth, (int32_t *)L->d_match, (int32_t *)d_nmatch);
     HIPCHK(L, hipGetLastError());
+    // ... and the right context must not overwrite its pyramid before these kernels have read it
+    HIPCHK(L, hipEventRecord(L->evx[0], L->stream));
+    HIPCHK(L, hipStreamWaitEvent(R->stream, L->evx[0], 0));
     return ORBHIP_OK;
 }
 

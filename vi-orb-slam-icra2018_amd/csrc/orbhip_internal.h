@@ -199,6 +199,7 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
                       const int32_t *off2, const int32_t *idx2, const int32_t *pairs, int npairs,
                       int th, int th_mode, float nnratio, int32_t *match12, int32_t *match21);
 
+size_t stereo_scratch_bytes(int B, int cap);
 int launch_stereo(orbhip_ctx *L, orbhip_ctx *R, const orbhip_keypoint *kpsL, const uint8_t *descL, const int32_t *cntL,
                   const orbhip_keypoint *kpsR, const uint8_t *descR, const int32_t *cntR, int cap, int B, float mb,
                   float mbf, float *uRight, float *depth, int32_t *scratch, int32_t *nmatch);
