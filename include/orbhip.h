@@ -220,6 +220,65 @@ int orbhip_stereo_match_device(orbhip_ctx *left, orbhip_ctx *right, const void *
                                const void *d_cntL, const void *d_kpsR, const void *d_descR, const void *d_cntR,
                                int cap, int B, float mb, float mbf, void *d_uRight, void *d_depth, void *d_nmatch);
 
+/* ---- frame grid and guided search ----
+ * The 64 x 48 grid of include/Frame.h:41-42 as CSR: cell id = ix * 48 + iy (the order
+ * Frame::GetFeaturesInArea visits cells in), feature indices ascending inside a cell (the push_back
+ * order of Frame::AssignFeaturesToGrid, src/Frame.cc:574-589; cell of a feature by PosInGrid,
+ * :726-736).  min_x, min_y, inv_w, inv_h are Frame::mnMinX, mnMinY, mfGridElementWidthInv,
+ * mfGridElementHeightInv (:556-557).  d_cell_off [B][ORBHIP_GRID_CELLS + 1], d_cell_idx [B][cap]. */
+#define ORBHIP_GRID_COLS 64
+#define ORBHIP_GRID_ROWS 48
+#define ORBHIP_GRID_CELLS (ORBHIP_GRID_COLS * ORBHIP_GRID_ROWS)
+int orbhip_grid_build_device(orbhip_ctx *ctx, const void *d_kps_un, const void *d_counts, int cap, int B, float min_x,
+                             float min_y, float inv_w, float inv_h, void *d_cell_off, void *d_cell_idx);
+int orbhip_grid_build(orbhip_ctx *ctx, const orbhip_keypoint *kps_un, int n, float min_x, float min_y, float inv_w,
+                      float inv_h, int32_t *cell_off, int32_t *cell_idx);
+
+/* One projected point of a guided search: where it falls in the frame (u, v), the window half-size, the
+ * octave range GetFeaturesInArea filters on (min_level <= 0 and max_level < 0: no filter, :693-707), the
+ * projected right coordinate (compared with mvuRight when that is > 0) and the orientation of the source
+ * keypoint.  flags: ORBHIP_Q_ACTIVE = the point takes part (mbTrackInView && !isBad(), :55-59; or the
+ * LastFrame point is valid, not an outlier and projects inside the image, :1371-1398);
+ * ORBHIP_Q_OBSERVED = its MapPoint has Observations() > 0, so a feature it takes is closed to later points. */
+#define ORBHIP_Q_ACTIVE 1
+#define ORBHIP_Q_OBSERVED 2
+typedef struct {
+    float u, v, radius, proj_xr;
+    int32_t min_level, max_level;
+    float angle;
+    int32_t flags;
+} orbhip_proj_query;
+
+/* Replaces Frame::GetFeaturesInArea (src/Frame.cc:671-724) for nq windows at once (only u, v, radius,
+ * min_level, max_level of a query are read): out_off[nq + 1], out_idx[out_off[nq]] in the reference's
+ * order.  Returns ORBHIP_E_ARG if out_cap is too small (out_off is still filled). */
+int orbhip_features_in_area(orbhip_ctx *ctx, const orbhip_keypoint *kps_un, int n, float min_x, float min_y,
+                            float inv_w, float inv_h, const orbhip_proj_query *queries, int nq, int32_t *out_off,
+                            int32_t *out_idx, int out_cap);
+
+/* Replaces the search loops of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:45-129; use_ratio = 1: second best and the ratio test when best and second lie on the
+ * same octave) and SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (:1341-1498;
+ * use_ratio = 0: best only, rotation histogram when check_ori).  Queries are processed in index order, as
+ * the reference processes its points: occupied[i] != 0 marks frame features that already hold a MapPoint
+ * with observations (:88-90, :1413-1415).  match[i] = index of the query assigned to frame feature i (the
+ * last one, as in the reference) or -1; *nmatches = the reference routine's return value.  The caller
+ * projects the points (pose arithmetic stays on the host) and fills the queries.  TH_HIGH = th_high. */
+int orbhip_search_by_projection(orbhip_ctx *ctx, const orbhip_keypoint *kps_un, const uint8_t *desc, int n,
+                                const float *u_right, const uint8_t *occupied, float min_x, float min_y,
+                                float inv_w, float inv_h, const orbhip_proj_query *queries, const uint8_t *qdesc,
+                                int nq, int use_ratio, float nnratio, int check_ori, int th_high, int32_t *match,
+                                int *nmatches);
+/* Batched, device-resident form: B frames laid out like orbhip_extract_batch_device outputs, the grid from
+ * orbhip_grid_build_device, d_queries [B][cap_q], d_qdesc [B][cap_q][32], d_nq [B]; d_u_right / d_occupied
+ * [B][cap] or NULL; d_match [B][cap], d_nmatches [B]. */
+int orbhip_search_by_projection_device(orbhip_ctx *ctx, const void *d_kps_un, const void *d_desc,
+                                       const void *d_counts, int cap, int B, const void *d_u_right,
+                                       const void *d_occupied, float min_x, float min_y, float inv_w, float inv_h,
+                                       const void *d_cell_off, const void *d_cell_idx, const void *d_queries,
+                                       const void *d_qdesc, const void *d_nq, int cap_q, int use_ratio,
+                                       float nnratio, int check_ori, int th_high, void *d_match, void *d_nmatches);
+
 /* Device time of the stages of the last extract call on this context, in ms:
  * {pyramid, FAST, quadtree, blur, describe} and, at [5], of the last orbhip_hamming_knn2*_device
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */

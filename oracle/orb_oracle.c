@@ -1430,3 +1430,158 @@ int orbo_stereo_matches(const orbo_keypoint *kL, const uint8_t *dL, int nL, cons
     free(cnt);
     return nd;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Next row: the frame grid and the guided (projection) search built on it.
+ * ref: src/Frame.cc:574-589 (AssignFeaturesToGrid), :726-736 (PosInGrid), :671-724
+ * (GetFeaturesInArea), include/Frame.h:41-42 (64 x 48), src/ORBmatcher.cc:45-129
+ * (SearchByProjection(Frame&, vector<MapPoint*>&, th)), :1341-1498 (SearchByProjection(Current,
+ * Last, th, bMono)).  The projection itself (pose * point) stays with the caller; a query carries
+ * the projected position, the search radius and the octave range the caller derived from it.
+ * ---------------------------------------------------------------------------------------- */
+#define GRID_COLS 64
+#define GRID_ROWS 48
+
+/* cell id = ix * GRID_ROWS + iy: the order GetFeaturesInArea visits cells in (ix outer, iy inner) */
+void orbo_grid_build(const orbo_keypoint *kps, int n, float minX, float minY, float invW, float invH,
+                     int32_t *cell_off, int32_t *cell_idx)
+{
+    int *cell = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int c = 0; c <= GRID_COLS * GRID_ROWS; c++) cell_off[c] = 0;
+    for (int i = 0; i < n; i++) {
+        /* PosInGrid, :728-735: float arithmetic, round half away from zero */
+        const int px = (int)roundf((kps[i].x - minX) * invW);
+        const int py = (int)roundf((kps[i].y - minY) * invH);
+        cell[i] = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+        if (cell[i] >= 0) cell_off[cell[i] + 1]++;
+    }
+    for (int c = 0; c < GRID_COLS * GRID_ROWS; c++) cell_off[c + 1] += cell_off[c];
+    int *cur = (int *)malloc(sizeof(int) * GRID_COLS * GRID_ROWS);
+    for (int c = 0; c < GRID_COLS * GRID_ROWS; c++) cur[c] = cell_off[c];
+    for (int i = 0; i < n; i++)                      /* push_back in ascending i, :581-588 */
+        if (cell[i] >= 0) cell_idx[cur[cell[i]]++] = i;
+    free(cur);
+    free(cell);
+}
+
+int orbo_features_in_area(const orbo_keypoint *kps, const int32_t *cell_off, const int32_t *cell_idx, float minX,
+                          float minY, float invW, float invH, float x, float y, float r, int minLevel, int maxLevel,
+                          int32_t *out, int cap)
+{
+    int n = 0;
+    int nMinCellX = (int)floorf((x - minX - r) * invW);          /* :676-691 */
+    if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - minX + r) * invW);
+    if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - minY - r) * invH);
+    if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - minY + r) * invH);
+    if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);  /* :693 */
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * GRID_ROWS + iy;
+            for (int j = cell_off[c]; j < cell_off[c + 1]; j++) {
+                const orbo_keypoint *k = &kps[cell_idx[j]];
+                if (bCheckLevels) {
+                    if (k->octave < minLevel) continue;
+                    if (maxLevel >= 0 && k->octave > maxLevel) continue;
+                }
+                const float distx = k->x - x, disty = k->y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) {
+                    if (n < cap) out[n] = cell_idx[j];
+                    n++;
+                }
+            }
+        }
+    return n;
+}
+
+/* Both SearchByProjection variants as one loop over queries in order.
+ *   use_ratio = 1: :45-129  (second best + ratio when best and second lie on the same level)
+ *   use_ratio = 0: :1341-1498 (best only; rotation histogram when check_ori)
+ * occupied[i] != 0: the frame feature already holds a MapPoint with Observations() > 0 (:88-90, :1413-1415).
+ * A match of query q sets match[best] = q and, when the query's point has observations
+ * (ORBO_Q_OBSERVED), makes the feature occupied for the queries after it.  u_right may be NULL (mono). */
+int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *u_right,
+                              const uint8_t *occupied_in, float minX, float minY, float invW, float invH,
+                              const orbo_proj_query *q, const uint8_t *qdesc, int nq, int use_ratio, float nnratio,
+                              int check_ori, int th_high, int32_t *match)
+{
+    int32_t *cell_off = (int32_t *)malloc(sizeof(int32_t) * (GRID_COLS * GRID_ROWS + 1));
+    int32_t *cell_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    uint8_t *occ = (uint8_t *)calloc((size_t)n + 1, 1);
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        hist[i] = (int *)malloc(sizeof(int) * (size_t)(nq + 1));
+        hn[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    orbo_grid_build(kps, n, minX, minY, invW, invH, cell_off, cell_idx);
+    for (int i = 0; i < n; i++) {
+        match[i] = -1;
+        if (occupied_in) occ[i] = occupied_in[i] != 0;
+    }
+    int nmatches = 0;
+    for (int iq = 0; iq < nq; iq++) {
+        if (!(q[iq].flags & ORBO_Q_ACTIVE)) continue;
+        const int nc = orbo_features_in_area(kps, cell_off, cell_idx, minX, minY, invW, invH, q[iq].u, q[iq].v,
+                                             q[iq].radius, q[iq].min_level, q[iq].max_level, cand, n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (occ[idx]) continue;
+            if (u_right && u_right[idx] > 0) {
+                const float er = fabsf(q[iq].proj_xr - u_right[idx]);
+                if (er > q[iq].radius) continue;
+            }
+            const int dist = orbo_descriptor_distance(qdesc + (size_t)iq * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = kps[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kps[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= th_high) {
+            if (use_ratio && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            match[bestIdx] = iq;
+            if (q[iq].flags & ORBO_Q_OBSERVED) occ[bestIdx] = 1;
+            nmatches++;
+            if (!use_ratio && check_ori) {
+                float rot = q[iq].angle - kps[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) hist[bin][hn[bin]++] = bestIdx;
+            }
+        }
+    }
+    if (!use_ratio && check_ori) {
+        int i1, i2, i3;
+        orbo_three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; j++) {
+                match[hist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    free(occ);
+    free(cand);
+    free(cell_idx);
+    free(cell_off);
+    return nmatches;
+}

@@ -154,6 +154,26 @@ int orbo_stereo_matches(const orbo_keypoint *kL, const uint8_t *dL, int nL, cons
                         const int *lw, const int *lh, const float *mvScaleFactors, const float *mvInvScaleFactors,
                         float mb, float mbf, float *mvuRight, float *mvDepth);
 
+
+/* ---- frame grid + guided search ---- */
+#define ORBO_Q_ACTIVE 1    /* the query takes part (mbTrackInView && !isBad / LastFrame point valid and in bounds) */
+#define ORBO_Q_OBSERVED 2  /* its MapPoint has Observations() > 0: a matched feature is closed to later queries */
+typedef struct {
+    float u, v, radius, proj_xr;
+    int32_t min_level, max_level;
+    float angle;
+    int32_t flags;
+} orbo_proj_query;
+void orbo_grid_build(const orbo_keypoint *kps, int n, float minX, float minY, float invW, float invH,
+                     int32_t *cell_off /* 64*48+1 */, int32_t *cell_idx /* n */);
+int orbo_features_in_area(const orbo_keypoint *kps, const int32_t *cell_off, const int32_t *cell_idx, float minX,
+                          float minY, float invW, float invH, float x, float y, float r, int minLevel, int maxLevel,
+                          int32_t *out, int cap);
+int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *u_right,
+                              const uint8_t *occupied_in, float minX, float minY, float invW, float invH,
+                              const orbo_proj_query *q, const uint8_t *qdesc, int nq, int use_ratio, float nnratio,
+                              int check_ori, int th_high, int32_t *match);
+
 #ifdef __cplusplus
 }
 #endif

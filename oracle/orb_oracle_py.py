@@ -387,3 +387,62 @@ def stereo_matches(exL, kL, dL, exR, kR, dR, mb, mbf):
     n = L.orbo_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), PL, PR, _p(lw), _p(lh), _p(sf), _p(isf),
                               mb, mbf, _p(u), _p(z))
     return u[:len(kL)].copy(), z[:len(kL)].copy(), n
+
+
+# ---- frame grid + guided search ----
+Q_ACTIVE, Q_OBSERVED = 1, 2
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("proj_xr", "<f4"), ("min_level", "<i4"),
+                        ("max_level", "<i4"), ("angle", "<f4"), ("flags", "<i4")])
+GRID_COLS, GRID_ROWS = 64, 48
+
+
+def grid_params(min_x, max_x, min_y, max_y):
+    """(mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv) as float32 -- src/Frame.cc:556-557."""
+    f = np.float32
+    return f(min_x), f(min_y), f(GRID_COLS) / (f(max_x) - f(min_x)), f(GRID_ROWS) / (f(max_y) - f(min_y))
+
+
+def grid_build(kps, gp):
+    """Frame::AssignFeaturesToGrid (src/Frame.cc:574-589) as CSR: cell id = ix * 48 + iy."""
+    L = lib()
+    L.orbo_grid_build.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 2
+    kps = np.ascontiguousarray(kps)
+    off = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32)
+    idx = np.zeros(max(len(kps), 1), np.int32)
+    L.orbo_grid_build(_p(kps), len(kps), gp[0], gp[1], gp[2], gp[3], _p(off), _p(idx))
+    return off, idx[:off[-1]].copy()
+
+
+def features_in_area(kps, grid, gp, x, y, r, min_level=-1, max_level=-1):
+    """Frame::GetFeaturesInArea (src/Frame.cc:671-724)."""
+    L = lib()
+    L.orbo_features_in_area.argtypes = [C.c_void_p] * 3 + [C.c_float] * 7 + [C.c_int] * 2 + [C.c_void_p, C.c_int]
+    L.orbo_features_in_area.restype = C.c_int
+    kps = np.ascontiguousarray(kps)
+    off, idx = grid
+    out = np.zeros(max(len(kps), 1), np.int32)
+    idx = np.ascontiguousarray(idx if len(idx) else np.zeros(1, np.int32))
+    n = L.orbo_features_in_area(_p(kps), _p(off), _p(idx), gp[0], gp[1], gp[2], gp[3], x, y, r, min_level, max_level,
+                                _p(out), len(out))
+    return out[:n].copy()
+
+
+def search_by_projection(kps, desc, gp, queries, qdesc, u_right=None, occupied=None, use_ratio=True, nnratio=0.8,
+                         check_ori=True, th_high=100):
+    """Both ORBmatcher::SearchByProjection variants over prepared queries (src/ORBmatcher.cc:45-129 with
+    use_ratio, :1341-1498 without).  Returns (nmatches, match[feature] = query index or -1)."""
+    L = lib()
+    L.orbo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + \
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.orbo_search_by_projection.restype = C.c_int
+    kps = np.ascontiguousarray(kps)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    match = np.empty(max(len(kps), 1), np.int32)
+    n = L.orbo_search_by_projection(_p(kps), _p(desc), len(kps), None if ur is None else _p(ur),
+                                    None if occ is None else _p(occ), gp[0], gp[1], gp[2], gp[3], _p(queries), _p(qdesc),
+                                    len(queries), 1 if use_ratio else 0, nnratio, 1 if check_ori else 0, th_high, _p(match))
+    return n, match[:len(kps)].copy()

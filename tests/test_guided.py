@@ -1,0 +1,244 @@
+"""Frame grid + guided search: the oracle against definition-level numpy
+models on CPU; the HIP grid, window query and both SearchByProjection variants against the oracle on the GPU."""
+import numpy as np
+import pytest
+
+
+def _scene(oracle, seed=9, nf=1000, w=640, h=480):
+    from orbhip import synth
+    fr = synth.make_frames(seed, w, h, 2)
+    ex = oracle.Extractor(nf)
+    (k0, d0), (k1, d1) = ex(fr[0]), ex(fr[1])
+    return k0, d0, k1, d1
+
+
+def _undistort_like(k, seed):
+    """Sub-pixel, slightly out-of-image coordinates, as mvKeysUn has them after undistortion."""
+    rng = np.random.default_rng(seed)
+    k = k.copy()
+    k["x"] = (k["x"] * np.float32(1.013) - np.float32(5.3) + rng.normal(0, 0.3, len(k))).astype(np.float32)
+    k["y"] = (k["y"] * np.float32(1.011) - np.float32(3.1) + rng.normal(0, 0.3, len(k))).astype(np.float32)
+    return k
+
+
+def _queries_last_frame(oracle_or_capi, k0, th, forward=False, backward=False, seed=3):
+    from orbhip import guided
+    rng = np.random.default_rng(seed)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    valid = rng.random(len(k0)) < 0.9
+    observed = rng.random(len(k0)) < 0.8
+    return guided.queries_for_last_frame(k0["x"] + np.float32(1.5), k0["y"] - np.float32(0.75), k0["x"] - np.float32(20),
+                                         k0["octave"], k0["angle"], valid, observed, th, sf, forward, backward)
+
+
+def test_oracle_grid_and_area_match_numpy_model(oracle):
+    k0, d0, k1, d1 = _scene(oracle)
+    ku = _undistort_like(k1, 1)
+    gp = oracle.grid_params(22.5, 611.25, 19.75, 452.5)
+    off, idx = oracle.grid_build(ku, gp)
+    px = np.round((ku["x"] - gp[0]) * gp[2])          # np.round is half-to-even; no exact .5 occurs with this data
+    py = np.round((ku["y"] - gp[1]) * gp[3])
+    frac = np.abs(((ku["x"] - gp[0]) * gp[2]) % 1 - 0.5)
+    assert frac.min() > 1e-6
+    inside = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    cell = (px * 48 + py).astype(np.int64)
+    assert off[-1] == inside.sum() and (~inside).sum() > 0
+    for c in np.unique(cell[inside])[:300]:
+        assert idx[off[c]:off[c + 1]].tolist() == np.nonzero(inside & (cell == c))[0].tolist()
+    rng = np.random.default_rng(2)
+    for _ in range(40):
+        x, y, r = rng.uniform(-30, 680), rng.uniform(-30, 510), rng.uniform(3, 90)
+        mn, mx = [(-1, -1), (0, 3), (2, -1), (3, 4), (0, -1)][int(rng.integers(0, 5))]
+        got = oracle.features_in_area(ku, (off, idx), gp, x, y, r, mn, mx)
+        x, y, r = np.float32(x), np.float32(y), np.float32(r)
+        m = inside & (np.abs(ku["x"] - x) < r) & (np.abs(ku["y"] - y) < r)
+        if mn > 0 or mx >= 0:
+            m &= ku["octave"] >= mn
+            if mx >= 0:
+                m &= ku["octave"] <= mx
+        # the window is clipped to whole cells first: every returned feature satisfies the model, and every
+        # model feature whose cell lies in the window is returned -> compare as sets restricted to window cells
+        x0 = max(0, int(np.floor((x - gp[0] - r) * gp[2])))
+        x1 = min(63, int(np.ceil((x - gp[0] + r) * gp[2])))
+        y0 = max(0, int(np.floor((y - gp[1] - r) * gp[3])))
+        y1 = min(47, int(np.ceil((y - gp[1] + r) * gp[3])))
+        m &= (px >= x0) & (px <= x1) & (py >= y0) & (py <= y1)
+        order = sorted(np.nonzero(m)[0].tolist(), key=lambda i: (cell[i], i))
+        assert got.tolist() == order
+
+
+def test_oracle_search_by_projection_sequential_semantics(oracle):
+    """Hand-built case: two points compete for one feature; observed flag decides whether the second may take it."""
+    from orbhip.capi import KP_DTYPE
+    k = np.zeros(3, KP_DTYPE)
+    k["x"], k["y"], k["octave"] = [100, 103, 300], [100, 100, 300], [1, 1, 1]
+    d = np.zeros((3, 32), np.uint8)
+    d[1, 0] = 0x0F                                     # feature 1 is 4 bits from the zero descriptor
+    d[2] = 0xFF
+    gp = oracle.grid_params(0, 640, 0, 480)
+    q = np.zeros(2, oracle.QUERY_DTYPE)
+    q["u"], q["v"], q["radius"], q["min_level"], q["max_level"] = 101, 100, 10, 0, 2
+    qd = np.zeros((2, 32), np.uint8)
+    q["flags"] = [oracle.Q_ACTIVE | oracle.Q_OBSERVED, oracle.Q_ACTIVE]
+    n, m = oracle.search_by_projection(k, d, gp, q, qd, use_ratio=False, check_ori=False)
+    assert (n, m.tolist()) == (2, [0, 1, -1])          # first takes feature 0, second must settle for feature 1
+    q["flags"] = [oracle.Q_ACTIVE, oracle.Q_ACTIVE]
+    n, m = oracle.search_by_projection(k, d, gp, q, qd, use_ratio=False, check_ori=False)
+    assert (n, m.tolist()) == (2, [1, -1, -1])         # not observed: the second overwrites feature 0, both counted
+    # ratio test applies only when best and second share the octave
+    q["flags"] = [oracle.Q_ACTIVE, 0]
+    d[0, 0] = 0x07                                     # best 3 (feature 0), second 4 (feature 1)
+    n, m = oracle.search_by_projection(k, d, gp, q, qd, use_ratio=True, nnratio=0.7, check_ori=False)
+    assert n == 0                                      # 3 > 0.7 * 4
+    k["octave"][1] = 2
+    n, m = oracle.search_by_projection(k, d, gp, q, qd, use_ratio=True, nnratio=0.7, check_ori=False)
+    assert (n, m.tolist()) == (1, [0, -1, -1])
+    # initial occupancy
+    n, m = oracle.search_by_projection(k, d, gp, q, qd, occupied=np.array([1, 0, 0], np.uint8), use_ratio=True,
+                                       nnratio=0.7, check_ori=False)
+    assert (n, m.tolist()) == (1, [-1, 0, -1])
+
+
+@pytest.mark.gpu
+def test_hip_grid_and_area_match_oracle(oracle):
+    from orbhip import guided
+    from orbhip.extractor import ORBextractor
+    ex = ORBextractor(500, max_w=320, max_h=240)
+    k0, d0, k1, d1 = _scene(oracle, seed=12, nf=2000)
+    for ku, gp in [(_undistort_like(k1, 1), guided.grid_params(22.5, 611.25, 19.75, 452.5)),
+                   (k0, guided.grid_params(0, 640, 0, 480)), (k0[:0], guided.grid_params(0, 640, 0, 480))]:
+        off, idx = guided.AssignFeaturesToGrid(ex, ku, gp)
+        roff, ridx = oracle.grid_build(ku, gp)
+        assert np.array_equal(off, roff) and np.array_equal(idx, ridx)
+        rng = np.random.default_rng(5)
+        nq = 300
+        x, y = rng.uniform(-40, 690, nq).astype(np.float32), rng.uniform(-40, 520, nq).astype(np.float32)
+        r = rng.uniform(2, 120, nq).astype(np.float32)
+        r[:3] = 2000                                    # whole image: more features than the first slot guess
+        lv = np.array([(-1, -1), (0, 3), (2, -1), (3, 4), (0, -1)])[rng.integers(0, 5, nq)]
+        qoff, qidx = guided.GetFeaturesInArea(ex, ku, gp, x, y, r, lv[:, 0], lv[:, 1])
+        for i in range(nq):
+            ref = oracle.features_in_area(ku, (roff, ridx), gp, x[i], y[i], r[i], int(lv[i, 0]), int(lv[i, 1]))
+            assert np.array_equal(qidx[qoff[i]:qoff[i + 1]], ref)
+    ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["last_frame", "last_frame_forward", "last_frame_backward", "map_points", "map_points_th3"])
+def test_hip_search_by_projection_matches_oracle(oracle, mode):
+    from orbhip import guided
+    from orbhip.extractor import ORBextractor
+    ex = ORBextractor(500, max_w=320, max_h=240)
+    k0, d0, k1, d1 = _scene(oracle, seed=21, nf=1500)
+    ku = _undistort_like(k1, 4)
+    gp = guided.grid_params(22.5, 611.25, 19.75, 452.5)
+    rng = np.random.default_rng(8)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    u_right = np.where(rng.random(len(ku)) < 0.6, ku["x"] - np.float32(20) + rng.normal(0, 6, len(ku)), -1).astype(np.float32)
+    occupied = (rng.random(len(ku)) < 0.15).astype(np.uint8)
+    kq = _undistort_like(k0, 5)
+    if mode.startswith("last_frame"):
+        q = guided.queries_for_last_frame(kq["x"] + np.float32(1.5), kq["y"] - np.float32(0.75), kq["x"] - np.float32(20),
+                                          kq["octave"], kq["angle"], rng.random(len(kq)) < 0.9, rng.random(len(kq)) < 0.8,
+                                          15 if mode == "last_frame" else 7, sf, mode.endswith("forward"),
+                                          mode.endswith("backward"))
+        kw = dict(use_ratio=False, nnratio=0.9, check_ori=True)
+    else:
+        q = guided.queries_for_map_points(kq["x"] + np.float32(0.5), kq["y"] + np.float32(0.25), kq["x"] - np.float32(20),
+                                          rng.uniform(0.99, 1.0, len(kq)).astype(np.float32), kq["octave"],
+                                          rng.random(len(kq)) < 0.9, rng.random(len(kq)) < 0.8,
+                                          3.0 if mode.endswith("th3") else 1.0, sf)
+        kw = dict(use_ratio=True, nnratio=0.8, check_ori=True)
+    for ur, occ in [(u_right, occupied), (None, None)]:
+        n, m = guided.SearchByProjection(ex, ku, d1, gp, q, d0, u_right=ur, occupied=occ, **kw)
+        rn, rm = oracle.search_by_projection(ku, d1, gp, q, d0, u_right=ur, occupied=occ, **kw)
+        assert n == rn and np.array_equal(m, rm) and rn > 150
+    # no queries / no features
+    n, m = guided.SearchByProjection(ex, ku, d1, gp, q[:0], d0[:0], **kw)
+    assert n == 0 and (m == -1).all()
+    n, m = guided.SearchByProjection(ex, ku[:0], d1[:0], gp, q, d0, **kw)
+    assert n == 0 and len(m) == 0
+    ex.close()
+
+
+@pytest.mark.gpu
+def test_hip_search_by_projection_list_overflow_rescans_exactly(oracle, tmp_path):
+    """ORBHIP_PROJ_K=2: almost every point has more candidates than its list holds (child process: the
+    variable is read once)."""
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vi-orb-slam-icra2018_amd")
+    k0, d0, k1, d1 = _scene(oracle, seed=21, nf=1500)
+    gp = oracle.grid_params(0, 640, 0, 480)
+    q = _queries_last_frame(None, k0, 15)
+    np.savez(tmp_path / "in.npz", k1=k1, d1=d1, q=q, d0=d0)
+    code = ("import sys, numpy as np\nsys.path.insert(0, %r)\nfrom orbhip import guided\n"
+            "from orbhip.extractor import ORBextractor\nz = np.load(%r)\nex = ORBextractor(500, max_w=320, max_h=240)\n"
+            "gp = guided.grid_params(0, 640, 0, 480)\n"
+            "n, m = guided.SearchByProjection(ex, z['k1'], z['d1'], gp, z['q'], z['d0'], use_ratio=False, check_ori=True)\n"
+            "n2, m2 = guided.SearchByProjection(ex, z['k1'], z['d1'], gp, z['q'], z['d0'], use_ratio=True, nnratio=0.8)\n"
+            "np.savez(%r, n=n, m=m, n2=n2, m2=m2)\n" % (pkg, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, ORBHIP_PROJ_K="2"))
+    got = np.load(tmp_path / "out.npz")
+    rn, rm = oracle.search_by_projection(k1, d1, gp, q, d0, use_ratio=False, check_ori=True)
+    rn2, rm2 = oracle.search_by_projection(k1, d1, gp, q, d0, use_ratio=True, nnratio=0.8)
+    assert int(got["n"]) == rn and np.array_equal(got["m"], rm) and rn > 300
+    assert int(got["n2"]) == rn2 and np.array_equal(got["m2"], rm2)
+
+
+@pytest.mark.gpu
+def test_hip_search_by_projection_batched_device(oracle):
+    """extract_batch_device -> grid_build_device -> search_by_projection_device with frame b-1's keypoints as the
+    projected points of frame b (constant-velocity guess = same position), all resident on the device."""
+    import hiprt
+    from orbhip import capi, guided, synth
+    from orbhip.capi import check
+    from orbhip.extractor import ORBextractor
+    B, W, H, NF = 4, 640, 480, 1000
+    frames = synth.make_frames(31, W, H, B)
+    ex = ORBextractor(NF, max_w=W, max_h=H, max_batch=B)
+    cap = ex.cap
+    L = ex._L
+    d_img = hiprt.DevBuf.from_numpy(frames)
+    d_kps, d_desc, d_cnt = hiprt.DevBuf(B * cap * 28), hiprt.DevBuf(B * cap * 32), hiprt.DevBuf(B * 4)
+    ex.extract_batch_device(d_img.ptr, B, W, H, W, H * W, d_kps.ptr, d_desc.ptr, cap, d_cnt.ptr)
+    ex.sync()
+    kps = d_kps.to_numpy(capi.KP_DTYPE, (B, cap))
+    desc = d_desc.to_numpy(np.uint8, (B, cap, 32))
+    cnt = d_cnt.to_numpy(np.int32, (B,))
+    gp = guided.grid_params(0, W, 0, H)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    q = np.zeros((B, cap), capi.QUERY_DTYPE)
+    qd = np.zeros((B, cap, 32), np.uint8)
+    nq = np.zeros(B, np.int32)
+    for b in range(1, B):
+        k = kps[b - 1, :cnt[b - 1]]
+        q[b, :len(k)] = guided.queries_for_last_frame(k["x"], k["y"], k["x"], k["octave"], k["angle"], np.ones(len(k), bool),
+                                                      np.arange(len(k)) % 7 != 0, 15, sf)
+        qd[b, :len(k)] = desc[b - 1, :len(k)]
+        nq[b] = len(k)
+    d_q, d_qd, d_nq = hiprt.DevBuf.from_numpy(q), hiprt.DevBuf.from_numpy(qd), hiprt.DevBuf.from_numpy(nq)
+    d_off, d_idx = hiprt.DevBuf(B * (64 * 48 + 1) * 4), hiprt.DevBuf(B * cap * 4)
+    d_m, d_nm = hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * 4)
+    check(L.orbhip_grid_build_device(ex.handle, d_kps.ptr, d_cnt.ptr, cap, B, gp[0], gp[1], gp[2], gp[3], d_off.ptr, d_idx.ptr),
+          ex.handle, "grid")
+    check(L.orbhip_search_by_projection_device(ex.handle, d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap, B, None, None, gp[0], gp[1],
+                                               gp[2], gp[3], d_off.ptr, d_idx.ptr, d_q.ptr, d_qd.ptr, d_nq.ptr, cap, 0, 0.9, 1,
+                                               100, d_m.ptr, d_nm.ptr), ex.handle, "search_by_projection_device")
+    ex.sync()
+    m = d_m.to_numpy(np.int32, (B, cap))
+    nm = d_nm.to_numpy(np.int32, (B,))
+    off = d_off.to_numpy(np.int32, (B, 64 * 48 + 1))
+    assert nm[0] == 0 and (m[0] == -1).all()
+    for b in range(B):
+        k = kps[b, :cnt[b]]
+        roff, ridx = oracle.grid_build(k, gp)
+        assert np.array_equal(off[b], roff)
+        rn, rm = oracle.search_by_projection(k, desc[b, :cnt[b]], gp, q[b, :nq[b]], qd[b, :nq[b]], use_ratio=False,
+                                             nnratio=0.9, check_ori=True)
+        assert nm[b] == rn and np.array_equal(m[b, :cnt[b]], rm) and (m[b, cnt[b]:] == -1).all()
+        assert b == 0 or rn > 400
+    ex.close()
+    for x in (d_img, d_kps, d_desc, d_cnt, d_q, d_qd, d_nq, d_off, d_idx, d_m, d_nm):
+        x.free()

@@ -1,0 +1,455 @@
+// k_guided.hip -- SURVEY.md section 8f row 3: the frame grid and the guided (projection) search
+// (ref: src/Frame.cc:574-589 AssignFeaturesToGrid, :726-736 PosInGrid, :671-724 GetFeaturesInArea;
+//  src/ORBmatcher.cc:45-129 and :1341-1498 SearchByProjection).
+//   k_grid_build    per frame: CSR of the 64 x 48 grid (cell id = ix * 48 + iy, the visiting order of
+//                   GetFeaturesInArea) with LDS counters; cells are then sorted ascending, which is the
+//                   push_back order of the reference;
+//   k_area_list     GetFeaturesInArea for a batch of windows (one thread per window);
+//   k_proj_cands    one thread per projected point: walks its window, keeps the features that pass the octave,
+//                   distance and right-coordinate tests, in the reference's order, with their descriptor
+//                   distance -- everything that does not depend on which features earlier points took;
+//   k_proj_assign   one wave per frame: the points in index order; a point's candidates sit one per lane, the
+//                   features taken so far are a bitmap in LDS, best / second come from two wave minima over
+//                   (distance, list position); then the rotation histogram.  A point with more candidates
+//                   than the list holds is rescanned exactly as the reference does it.
+#include "orbhip_internal.h"
+
+#define GCOLS ORBHIP_GRID_COLS
+#define GROWS ORBHIP_GRID_ROWS
+#define GCELLS ORBHIP_GRID_CELLS
+#define PROJ_K 32   // candidate slots per point (one 64-point chunk of lists = 8 KB of LDS)
+
+struct GridParams {
+    float minX, minY, invW, invH;
+};
+
+__device__ __forceinline__ int grid_cell(const GridParams &gp, float x, float y)
+{
+    const int px = (int)roundf(__fmul_rn(__fsub_rn(x, gp.minX), gp.invW));   // :728-729
+    const int py = (int)roundf(__fmul_rn(__fsub_rn(y, gp.minY), gp.invH));
+    return (px < 0 || px >= GCOLS || py < 0 || py >= GROWS) ? -1 : px * GROWS + py;
+}
+
+__global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__restrict__ kps,
+                                                    const int32_t *__restrict__ cnt, int cap, const GridParams gp,
+                                                    int32_t *__restrict__ cellOff, int32_t *__restrict__ cellIdx)
+{
+    __shared__ int s_cnt[GCELLS];
+    __shared__ int s_part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(cnt[b], cap);
+    const orbhip_keypoint *K = kps + (size_t)b * cap;
+    int32_t *O = cellOff + (size_t)b * (GCELLS + 1), *I = cellIdx + (size_t)b * cap;
+    for (int c = tid; c < GCELLS; c += 256) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = grid_cell(gp, K[i].x, K[i].y);
+        if (c >= 0) atomicAdd(&s_cnt[c], 1);
+    }
+    __syncthreads();
+    constexpr int PER = GCELLS / 256;   // 12 cells per thread
+    int c[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        c[k] = s_cnt[tid * PER + k];
+        sum += c[k];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid >= d ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    if (tid == 255) O[GCELLS] = s_part[255];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        s_cnt[tid * PER + k] = run;   // fill cursor
+        O[tid * PER + k] = run;
+        run += c[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int cc = grid_cell(gp, K[i].x, K[i].y);
+        if (cc >= 0) I[atomicAdd(&s_cnt[cc], 1)] = i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ascending feature index inside each cell (cells hold a handful of features)
+    for (int cc = tid; cc < GCELLS; cc += 256) {
+        const int s = cc ? s_cnt[cc - 1] : 0, e = s_cnt[cc];   // cursors now sit at the cell ends
+        for (int a = s + 1; a < e; a++) {
+            const int v = I[a];
+            int p = a - 1;
+            while (p >= s && I[p] > v) {
+                I[p + 1] = I[p];
+                p--;
+            }
+            I[p + 1] = v;
+        }
+    }
+}
+
+// The window of GetFeaturesInArea in cells; false = the early returns of :676-691.
+__device__ __forceinline__ bool window_cells(const GridParams &gp, float x, float y, float r, int &x0, int &x1, int &y0,
+                                             int &y1)
+{
+    x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, gp.minX), r), gp.invW)));
+    if (x0 >= GCOLS) return false;
+    x1 = min(GCOLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, gp.minX), r), gp.invW)));
+    if (x1 < 0) return false;
+    y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, gp.minY), r), gp.invH)));
+    if (y0 >= GROWS) return false;
+    y1 = min(GROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, gp.minY), r), gp.invH)));
+    if (y1 < 0) return false;
+    return true;
+}
+
+// Calls f(feature index, octave) for the features of GetFeaturesInArea(q.u, q.v, q.radius, q.min_level,
+// q.max_level) in the reference's order.  Cells (ix, y0..y1) are contiguous in the CSR.
+template <typename F>
+__device__ __forceinline__ void walk_window(const GridParams &gp, const orbhip_proj_query &q,
+                                            const orbhip_keypoint *__restrict__ K, const int32_t *__restrict__ O,
+                                            const int32_t *__restrict__ I, F f)
+{
+    int x0, x1, y0, y1;
+    if (!window_cells(gp, q.u, q.v, q.radius, x0, x1, y0, y1)) return;
+    for (int ix = x0; ix <= x1; ix++) {
+        const int s = O[ix * GROWS + y0], e = O[ix * GROWS + y1 + 1];
+        for (int j = s; j < e; j++) {
+            const int idx = I[j];
+            const float kx = K[idx].x, ky = K[idx].y;
+            const int oct = K[idx].octave;
+            if (oct < q.min_level) continue;                       // with min_level <= 0 never true, :693-703
+            if (q.max_level >= 0 && oct > q.max_level) continue;
+            if (fabsf(__fsub_rn(kx, q.u)) < q.radius && fabsf(__fsub_rn(ky, q.v)) < q.radius) f(idx, oct);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_area_list(const orbhip_keypoint *__restrict__ K, const GridParams gp,
+                                                   const int32_t *__restrict__ O, const int32_t *__restrict__ I,
+                                                   const orbhip_proj_query *__restrict__ queries, int nq, int slots,
+                                                   int32_t *__restrict__ outCnt, int32_t *__restrict__ outIdx)
+{
+    const int iq = blockIdx.x * 256 + threadIdx.x;
+    if (iq >= nq) return;
+    const orbhip_proj_query q = queries[iq];
+    int n = 0;
+    int32_t *out = outIdx + (size_t)iq * slots;
+    walk_window(gp, q, K, O, I, [&](int idx, int) {
+        if (n < slots) out[n] = idx;
+        n++;
+    });
+    outCnt[iq] = n;
+}
+
+__device__ __forceinline__ int hamming256g(const uint4 a0, const uint4 a1, const uint4 r0, const uint4 r1)
+{
+    return __popc(a0.x ^ r0.x) + __popc(a0.y ^ r0.y) + __popc(a0.z ^ r0.z) + __popc(a0.w ^ r0.w) + __popc(a1.x ^ r1.x) +
+           __popc(a1.y ^ r1.y) + __popc(a1.z ^ r1.z) + __popc(a1.w ^ r1.w);
+}
+
+// candidate tuple: distance (9 bits) | octave << 9 (4 bits) | feature index << 13
+__global__ __launch_bounds__(256) void k_proj_cands(const orbhip_keypoint *__restrict__ kps,
+                                                    const uint8_t *__restrict__ desc, int cap,
+                                                    const float *__restrict__ uRight, const GridParams gp,
+                                                    const int32_t *__restrict__ cellOff,
+                                                    const int32_t *__restrict__ cellIdx,
+                                                    const orbhip_proj_query *__restrict__ queries,
+                                                    const uint8_t *__restrict__ qdesc, const int32_t *__restrict__ nq,
+                                                    int capQ, int capQpad, int keff, uint32_t *__restrict__ tuples,
+                                                    int32_t *__restrict__ tcount)
+{
+    const int b = blockIdx.y, iq = blockIdx.x * 256 + threadIdx.x;
+    if (iq >= capQpad) return;
+    int count = 0;
+    if (iq < min(nq[b], capQ)) {
+        const orbhip_proj_query q = queries[(size_t)b * capQ + iq];
+        if (q.flags & ORBHIP_Q_ACTIVE) {
+            const uint4 *qd = reinterpret_cast<const uint4 *>(qdesc + ((size_t)b * capQ + iq) * 32);
+            const uint4 a0 = qd[0], a1 = qd[1];
+            const orbhip_keypoint *K = kps + (size_t)b * cap;
+            const uint4 *D = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
+            const float *UR = uRight ? uRight + (size_t)b * cap : nullptr;
+            uint32_t *T = tuples + ((size_t)b * capQpad + iq) * PROJ_K;
+            walk_window(gp, q, K, cellOff + (size_t)b * (GCELLS + 1), cellIdx + (size_t)b * cap, [&](int idx, int oct) {
+                if (UR) {
+                    const float ur = UR[idx];
+                    if (ur > 0 && fabsf(__fsub_rn(q.proj_xr, ur)) > q.radius) return;   // :92-97, :1418-1424
+                }
+                if (count < keff) {
+                    const int d = hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]);
+                    T[count] = (uint32_t)d | ((uint32_t)oct << 9) | ((uint32_t)idx << 13);
+                }
+                count++;
+            });
+        }
+    }
+    tcount[(size_t)b * capQpad + iq] = count;
+}
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+__device__ __forceinline__ int wave_sum_g(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+#define WAVE_LDS_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__global__ __launch_bounds__(64) void k_proj_assign(const orbhip_keypoint *__restrict__ kps,
+                                                    const uint8_t *__restrict__ desc,
+                                                    const int32_t *__restrict__ cnt, int cap,
+                                                    const float *__restrict__ uRight,
+                                                    const uint8_t *__restrict__ occupied, const GridParams gp,
+                                                    const int32_t *__restrict__ cellOff,
+                                                    const int32_t *__restrict__ cellIdx,
+                                                    const orbhip_proj_query *__restrict__ queries,
+                                                    const uint8_t *__restrict__ qdesc, const int32_t *__restrict__ nq,
+                                                    int capQ, int capQpad, int keff, const uint32_t *__restrict__ tuples,
+                                                    const int32_t *__restrict__ tcount, int32_t *__restrict__ qfeat,
+                                                    int use_ratio, float nnratio, int check_ori, int th_high,
+                                                    int32_t *__restrict__ match, int32_t *__restrict__ nmatches)
+{
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_tup[64 * PROJ_K];
+    __shared__ int s_hist[30];
+    __shared__ int s_keep[3];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = min(cnt[b], cap), NQ = min(nq[b], capQ);
+    int32_t *s_match = reinterpret_cast<int32_t *>(s_dyn);      // [cap]
+    uint32_t *s_occ = s_dyn + cap;                              // [(cap + 31) / 32]
+    const orbhip_keypoint *K = kps + (size_t)b * cap;
+    const uint4 *D = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
+    const float *UR = uRight ? uRight + (size_t)b * cap : nullptr;
+    const int32_t *O = cellOff + (size_t)b * (GCELLS + 1), *I = cellIdx + (size_t)b * cap;
+    const orbhip_proj_query *Q = queries + (size_t)b * capQ;
+    for (int i = lane; i < cap; i += 64) s_match[i] = -1;
+    for (int w = lane; w < (cap + 31) / 32; w += 64) {
+        uint32_t bits = 0;
+        if (occupied)
+            for (int k = 0; k < 32; k++) {
+                const int i = w * 32 + k;
+                if (i < n && occupied[(size_t)b * cap + i]) bits |= 1u << k;
+            }
+        s_occ[w] = bits;
+    }
+    if (lane < 30) s_hist[lane] = 0;
+    WAVE_LDS_SYNC();
+    int nm = 0;
+    const uint4 *Tg = reinterpret_cast<const uint4 *>(tuples + (size_t)b * capQpad * PROJ_K);
+    for (int base = 0; base < NQ; base += 64) {
+        const int myq = base + lane;
+        const int myc = myq < NQ ? tcount[(size_t)b * capQpad + myq] : 0;
+        const int myflags = myq < NQ ? Q[myq].flags : 0;
+        int myfeat = -1;
+        unsigned long long todo = __ballot(myc > 0);
+        if (todo) {
+            // the chunk's candidate lists -> LDS (64 lists x 32 slots, contiguous in memory)
+            uint4 *s4 = reinterpret_cast<uint4 *>(s_tup);
+            const uint4 *src = Tg + (size_t)base * (PROJ_K / 4);
+#pragma unroll
+            for (int k = 0; k < PROJ_K / 4; k++) s4[k * 64 + lane] = src[k * 64 + lane];
+            WAVE_LDS_SYNC();
+        }
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int c = __builtin_amdgcn_readlane(myc, j);
+            const int flags = __builtin_amdgcn_readlane(myflags, j);
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            if (c <= keff) {
+                const uint32_t t = lane < c ? s_tup[j * PROJ_K + lane] : 0u;
+                const int idx = (int)(t >> 13);
+                const bool ok = lane < c && !((s_occ[idx >> 5] >> (idx & 31)) & 1u);
+                const int key = ok ? (int)(((t & 511u) << 6) | (uint32_t)lane) : 0x7FFFFFFF;
+                const int k1 = wave_min_i(key);
+                if (k1 != 0x7FFFFFFF) {
+                    const int l1 = k1 & 63;
+                    const int k2 = wave_min_i(lane == l1 ? 0x7FFFFFFF : key);
+                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)t, l1);
+                    bestDist = k1 >> 6;
+                    bestLevel = (int)((t1 >> 9) & 15u);
+                    bestIdx = (int)(t1 >> 13);
+                    if (k2 != 0x7FFFFFFF) {
+                        const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)t, k2 & 63);
+                        bestDist2 = k2 >> 6;
+                        bestLevel2 = (int)((t2 >> 9) & 15u);
+                    }
+                }
+            } else {
+                // more candidates than the list holds: the reference's scan, identically in every lane
+                const orbhip_proj_query q = Q[base + j];
+                const uint4 *qd = reinterpret_cast<const uint4 *>(qdesc + ((size_t)b * capQ + base + j) * 32);
+                const uint4 a0 = qd[0], a1 = qd[1];
+                walk_window(gp, q, K, O, I, [&](int idx, int oct) {
+                    if ((s_occ[idx >> 5] >> (idx & 31)) & 1u) return;
+                    if (UR) {
+                        const float ur = UR[idx];
+                        if (ur > 0 && fabsf(__fsub_rn(q.proj_xr, ur)) > q.radius) return;
+                    }
+                    const int d = hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]);
+                    if (d < bestDist) {
+                        bestDist2 = bestDist;
+                        bestDist = d;
+                        bestLevel2 = bestLevel;
+                        bestLevel = oct;
+                        bestIdx = idx;
+                    } else if (d < bestDist2) {
+                        bestLevel2 = oct;
+                        bestDist2 = d;
+                    }
+                });
+            }
+            if (bestIdx >= 0 && bestDist <= th_high) {
+                if (use_ratio && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) continue;
+                if (lane == 0) {
+                    s_match[bestIdx] = base + j;
+                    if (flags & ORBHIP_Q_OBSERVED) s_occ[bestIdx >> 5] |= 1u << (bestIdx & 31);
+                }
+                if (lane == j) myfeat = bestIdx;
+                nm++;
+                WAVE_LDS_SYNC();
+            }
+        }
+        if (myq < NQ) qfeat[(size_t)b * capQpad + myq] = myfeat;
+    }
+    // rotation consistency (:1467-1494): bins of the accepted matches, the three maxima, removal
+    if (!use_ratio && check_ori) {
+        __threadfence_block();
+        WAVE_LDS_SYNC();
+        for (int iq = lane; iq < NQ; iq += 64) {
+            const int f = qfeat[(size_t)b * capQpad + iq];
+            if (f < 0) continue;
+            float rot = __fsub_rn(Q[iq].angle, K[f].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            if (bin >= 0 && bin < 30) atomicAdd(&s_hist[bin], 1);
+        }
+        WAVE_LDS_SYNC();
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < 30; i++) {
+                const int s = s_hist[i];
+                if (s > max1) {
+                    max3 = max2; max2 = max1; max1 = s;
+                    i3 = i2; i2 = i1; i1 = i;
+                } else if (s > max2) {
+                    max3 = max2; max2 = s;
+                    i3 = i2; i2 = i;
+                } else if (s > max3) {
+                    max3 = s;
+                    i3 = i;
+                }
+            }
+            if ((float)max2 < 0.1f * (float)max1) {
+                i2 = -1;
+                i3 = -1;
+            } else if ((float)max3 < 0.1f * (float)max1) {
+                i3 = -1;
+            }
+            s_keep[0] = i1;
+            s_keep[1] = i2;
+            s_keep[2] = i3;
+        }
+        WAVE_LDS_SYNC();
+        int removed = 0;
+        for (int iq = lane; iq < NQ; iq += 64) {
+            const int f = qfeat[(size_t)b * capQpad + iq];
+            if (f < 0) continue;
+            float rot = __fsub_rn(Q[iq].angle, K[f].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            if (bin >= 0 && bin < 30 && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                s_match[f] = -1;
+                removed++;
+            }
+        }
+        nm -= wave_sum_g(removed);
+        WAVE_LDS_SYNC();
+    }
+    for (int i = lane; i < cap; i += 64) match[(size_t)b * cap + i] = s_match[i];
+    if (lane == 0) nmatches[b] = nm;
+}
+
+static int proj_keff()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ORBHIP_PROJ_K");   // tests force the rescan path with a small value
+        v = e ? atoi(e) : PROJ_K;
+        if (v < 1) v = 1;
+        if (v > PROJ_K) v = PROJ_K;
+    }
+    return v;
+}
+
+int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, float minX,
+                      float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx)
+{
+    const GridParams gp = {minX, minY, invW, invH};
+    hipLaunchKernelGGL(k_grid_build, dim3(B, 1, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, gp, cellOff, cellIdx);
+    return ORBHIP_OK;
+}
+
+int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, float minY, float invW, float invH,
+                     const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries, int nq, int slots,
+                     int32_t *outCnt, int32_t *outIdx)
+{
+    const GridParams gp = {minX, minY, invW, invH};
+    hipLaunchKernelGGL(k_area_list, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, kps, gp, cellOff, cellIdx, queries, nq,
+                       slots, outCnt, outIdx);
+    return ORBHIP_OK;
+}
+
+size_t proj_scratch_bytes(int B, int capQ)
+{
+    const size_t capQpad = ((size_t)capQ + 63) / 64 * 64;
+    return (size_t)B * capQpad * (PROJ_K * 4 + 4 + 4);
+}
+
+size_t proj_assign_lds(int cap) { return (size_t)cap * 4 + (size_t)((cap + 31) / 32) * 4; }
+
+int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const uint8_t *desc, const int32_t *cnt, int cap,
+                                int B, const float *uRight, const uint8_t *occupied, float minX, float minY, float invW,
+                                float invH, const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries,
+                                const uint8_t *qdesc, const int32_t *nq, int capQ, int use_ratio, float nnratio,
+                                int check_ori, int th_high, int32_t *match, int32_t *nmatches, void *scratch)
+{
+    const GridParams gp = {minX, minY, invW, invH};
+    const int capQpad = (capQ + 63) / 64 * 64;
+    uint32_t *tuples = (uint32_t *)scratch;
+    int32_t *tcount = (int32_t *)(tuples + (size_t)B * capQpad * PROJ_K);
+    int32_t *qfeat = tcount + (size_t)B * capQpad;
+    const int keff = proj_keff();
+    hipLaunchKernelGGL(k_proj_cands, dim3((capQpad + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, desc, cap, uRight, gp,
+                       cellOff, cellIdx, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
+    hipLaunchKernelGGL(k_proj_assign, dim3(B, 1, 1), dim3(64, 1, 1), proj_assign_lds(cap), s, kps, desc, cnt, cap, uRight,
+                       occupied, gp, cellOff, cellIdx, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount, qfeat,
+                       use_ratio, nnratio, check_ori, th_high, match, nmatches);
+    return ORBHIP_OK;
+}

@@ -948,6 +948,165 @@ extern "C" int orbhip_stereo_match(orbhip_ctx *L, orbhip_ctx *R, const orbhip_ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// frame grid and guided search
+// ------------------------------------------------------------------------------------------------
+static bool grid_params_ok(float inv_w, float inv_h) { return inv_w > 0.f && inv_h > 0.f; }
+
+extern "C" int orbhip_grid_build_device(orbhip_ctx *c, const void *d_kps, const void *d_counts, int cap, int B, float min_x,
+                                        float min_y, float inv_w, float inv_h, void *d_cell_off, void *d_cell_idx)
+{
+    if (!c || !d_kps || !d_counts || cap <= 0 || B <= 0 || !d_cell_off || !d_cell_idx || !grid_params_ok(inv_w, inv_h))
+        return fail(c, ORBHIP_E_ARG, "orbhip_grid_build_device: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_grid_build(c->stream, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts, cap, B, min_x, min_y, inv_w,
+                      inv_h, (int32_t *)d_cell_off, (int32_t *)d_cell_idx);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_grid_build(orbhip_ctx *c, const orbhip_keypoint *kps, int n, float min_x, float min_y, float inv_w,
+                                 float inv_h, int32_t *cell_off, int32_t *cell_idx)
+{
+    if (!c || n < 0 || (n > 0 && (!kps || !cell_idx)) || !cell_off || !grid_params_ok(inv_w, inv_h))
+        return fail(c, ORBHIP_E_ARG, "orbhip_grid_build: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int cap = std::max(n, 1);
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)cap * (28 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + 4096))) return rc;
+    orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)cap * 28);
+    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
+            *didx = (int32_t *)T.take((size_t)cap * 4);
+    hipStream_t s = c->stream;
+    if (n) HIPCHK(c, hipMemcpyAsync(dk, kps, (size_t)n * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dc, &n, 4, hipMemcpyHostToDevice, s));
+    if ((rc = orbhip_grid_build_device(c, dk, dc, cap, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
+    HIPCHK(c, hipMemcpyAsync(cell_off, doff, (ORBHIP_GRID_CELLS + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int total = cell_off[ORBHIP_GRID_CELLS];
+    if (total) HIPCHK(c, hipMemcpy(cell_idx, didx, (size_t)total * 4, hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_features_in_area(orbhip_ctx *c, const orbhip_keypoint *kps, int n, float min_x, float min_y,
+                                       float inv_w, float inv_h, const orbhip_proj_query *queries, int nq,
+                                       int32_t *out_off, int32_t *out_idx, int out_cap)
+{
+    if (!c || n < 0 || nq < 0 || (n > 0 && !kps) || (nq > 0 && !queries) || !out_off || out_cap < 0 ||
+        (out_cap > 0 && !out_idx) || !grid_params_ok(inv_w, inv_h))
+        return fail(c, ORBHIP_E_ARG, "orbhip_features_in_area: bad argument");
+    out_off[0] = 0;
+    if (nq == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int cap = std::max(n, 1);
+    hipStream_t s = c->stream;
+    int slots = 64;
+    std::vector<int32_t> cnt(nq), idx;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        TmpDev T(c);
+        int rc;
+        if ((rc = T.reserve((size_t)cap * 32 + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (32 + 4 + (size_t)slots * 4) + 8192)))
+            return rc;
+        orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)cap * 28);
+        int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
+                *didx = (int32_t *)T.take((size_t)cap * 4);
+        orbhip_proj_query *dq = (orbhip_proj_query *)T.take((size_t)nq * sizeof(orbhip_proj_query));
+        int32_t *dcnt = (int32_t *)T.take((size_t)nq * 4), *dout = (int32_t *)T.take((size_t)nq * slots * 4);
+        if (n) HIPCHK(c, hipMemcpyAsync(dk, kps, (size_t)n * 28, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(dc, &n, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice, s));
+        if ((rc = orbhip_grid_build_device(c, dk, dc, cap, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
+        launch_area_list(s, dk, min_x, min_y, inv_w, inv_h, doff, didx, dq, nq, slots, dcnt, dout);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), dcnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        int mx = 0;
+        for (int i = 0; i < nq; i++) mx = std::max(mx, cnt[i]);
+        if (mx > slots) {   // a window with more features than the first guess: once more with room for all
+            slots = mx;
+            continue;
+        }
+        idx.resize((size_t)nq * slots);
+        HIPCHK(c, hipMemcpy(idx.data(), dout, (size_t)nq * slots * 4, hipMemcpyDeviceToHost));
+        break;
+    }
+    for (int i = 0; i < nq; i++) out_off[i + 1] = out_off[i] + cnt[i];
+    if (out_off[nq] > out_cap) return fail(c, ORBHIP_E_ARG, "orbhip_features_in_area: out_cap too small");
+    for (int i = 0; i < nq; i++)
+        for (int k = 0; k < cnt[i]; k++) out_idx[out_off[i] + k] = idx[(size_t)i * slots + k];
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_search_by_projection_device(orbhip_ctx *c, const void *d_kps, const void *d_desc, const void *d_counts,
+                                                  int cap, int B, const void *d_u_right, const void *d_occupied, float min_x,
+                                                  float min_y, float inv_w, float inv_h, const void *d_cell_off,
+                                                  const void *d_cell_idx, const void *d_queries, const void *d_qdesc,
+                                                  const void *d_nq, int cap_q, int use_ratio, float nnratio, int check_ori,
+                                                  int th_high, void *d_match, void *d_nmatches)
+{
+    if (!c || !d_kps || !d_desc || !d_counts || cap <= 0 || B <= 0 || !d_cell_off || !d_cell_idx || !d_queries || !d_qdesc ||
+        !d_nq || cap_q <= 0 || !d_match || !d_nmatches || !grid_params_ok(inv_w, inv_h) || cap >= (1 << 19))
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_by_projection_device: bad argument");
+    if (proj_assign_lds(cap) > 120 * 1024)
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_by_projection_device: cap too large for the per-frame match table in LDS");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = match_scratch(c, proj_scratch_bytes(B, cap_q)))) return rc;
+    launch_search_by_projection(c->stream, (const orbhip_keypoint *)d_kps, (const uint8_t *)d_desc, (const int32_t *)d_counts,
+                                cap, B, (const float *)d_u_right, (const uint8_t *)d_occupied, min_x, min_y, inv_w, inv_h,
+                                (const int32_t *)d_cell_off, (const int32_t *)d_cell_idx, (const orbhip_proj_query *)d_queries,
+                                (const uint8_t *)d_qdesc, (const int32_t *)d_nq, cap_q, use_ratio, nnratio, check_ori, th_high,
+                                (int32_t *)d_match, (int32_t *)d_nmatches, c->d_match);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_search_by_projection(orbhip_ctx *c, const orbhip_keypoint *kps, const uint8_t *desc, int n,
+                                           const float *u_right, const uint8_t *occupied, float min_x, float min_y,
+                                           float inv_w, float inv_h, const orbhip_proj_query *queries, const uint8_t *qdesc,
+                                           int nq, int use_ratio, float nnratio, int check_ori, int th_high, int32_t *match,
+                                           int *nmatches)
+{
+    if (!c || n < 0 || nq < 0 || (n > 0 && (!kps || !desc || !match)) || (nq > 0 && (!queries || !qdesc)) ||
+        !grid_params_ok(inv_w, inv_h))
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_by_projection: bad argument");
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n; i++) match[i] = -1;
+    if (n == 0 || nq == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)n * (28 + 32 + 4 + 1 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * 64 + 16384))) return rc;
+    orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)n * 28);
+    uint8_t *dd = (uint8_t *)T.take((size_t)n * 32);
+    float *dur = u_right ? (float *)T.take((size_t)n * 4) : nullptr;
+    uint8_t *docc = occupied ? (uint8_t *)T.take((size_t)n) : nullptr;
+    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
+            *didx = (int32_t *)T.take((size_t)n * 4), *dm = (int32_t *)T.take((size_t)n * 4);
+    orbhip_proj_query *dq = (orbhip_proj_query *)T.take((size_t)nq * sizeof(orbhip_proj_query));
+    uint8_t *dqd = (uint8_t *)T.take((size_t)nq * 32);
+    const int32_t cnts[3] = {n, nq, 0};
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(dk, kps, (size_t)n * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    if (dur) HIPCHK(c, hipMemcpyAsync(dur, u_right, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (docc) HIPCHK(c, hipMemcpyAsync(docc, occupied, (size_t)n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dc, cnts, 12, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if ((rc = orbhip_grid_build_device(c, dk, dc, n, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
+    if ((rc = orbhip_search_by_projection_device(c, dk, dd, dc, n, 1, dur, docc, min_x, min_y, inv_w, inv_h, doff, didx, dq, dqd,
+                                                 dc + 1, nq, use_ratio, nnratio, check_ori, th_high, dm, dc + 2)))
+        return rc;
+    int nm = 0;
+    HIPCHK(c, hipMemcpyAsync(match, dm, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&nm, dc + 2, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RCCL (loaded lazily so that the library has no hard link-time dependency on it)
 // ------------------------------------------------------------------------------------------------
 typedef struct { char internal[128]; } rccl_uid_t;

@@ -199,6 +199,18 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
                       const int32_t *off2, const int32_t *idx2, const int32_t *pairs, int npairs,
                       int th, int th_mode, float nnratio, int32_t *match12, int32_t *match21);
 
+int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, float minX,
+                      float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx);
+int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, float minY, float invW, float invH,
+                     const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries, int nq, int slots,
+                     int32_t *outCnt, int32_t *outIdx);
+size_t proj_scratch_bytes(int B, int capQ);
+size_t proj_assign_lds(int cap);
+int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const uint8_t *desc, const int32_t *cnt, int cap,
+                                int B, const float *uRight, const uint8_t *occupied, float minX, float minY, float invW,
+                                float invH, const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries,
+                                const uint8_t *qdesc, const int32_t *nq, int capQ, int use_ratio, float nnratio,
+                                int check_ori, int th_high, int32_t *match, int32_t *nmatches, void *scratch);
 size_t stereo_scratch_bytes(int B, int cap);
 int launch_stereo(orbhip_ctx *L, orbhip_ctx *R, const orbhip_keypoint *kpsL, const uint8_t *descL, const int32_t *cntL,
                   const orbhip_keypoint *kpsR, const uint8_t *descR, const int32_t *cntR, int cap, int B, float mb,

@@ -28,8 +28,15 @@ SYMBOLS = [
     "orbhip_vocab_info", "orbhip_vocab_transform", "orbhip_vocab_transform_device",
     "orbhip_search_by_bow_seq_device", "orbhip_stereo_match", "orbhip_stereo_match_device",
     "orbhip_hamming_knn2_lists", "orbhip_search_by_bow", "orbhip_comm_unique_id",
-    "orbhip_comm_init", "orbhip_bcast_blob_device",
+    "orbhip_comm_init", "orbhip_bcast_blob_device", "orbhip_grid_build_device", "orbhip_grid_build",
+    "orbhip_features_in_area", "orbhip_search_by_projection", "orbhip_search_by_projection_device",
 ]
+
+
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("proj_xr", "<f4"), ("min_level", "<i4"),
+                        ("max_level", "<i4"), ("angle", "<f4"), ("flags", "<i4")])   # orbhip_proj_query
+Q_ACTIVE, Q_OBSERVED = 1, 2
+GRID_COLS, GRID_ROWS = 64, 48
 
 
 class OrbHipError(RuntimeError):
@@ -90,6 +97,13 @@ def load():
     L.orbhip_search_by_bow.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32,
                                        vp, i32, vp, vp, vp, vp, vp, i32,
                                        i32, i32, f32, i32, vp, vp, ip]
+    L.orbhip_grid_build_device.argtypes = [vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp]
+    L.orbhip_grid_build.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp]
+    L.orbhip_features_in_area.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, i32, vp, vp, i32]
+    L.orbhip_search_by_projection.argtypes = [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, i32, f32, i32, i32,
+                                              vp, ip]
+    L.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, vp,
+                                                     i32, i32, f32, i32, i32, vp, vp]
     L.orbhip_comm_unique_id.argtypes = [vp]
     L.orbhip_comm_init.argtypes = [vp, i32, i32, vp]
     L.orbhip_bcast_blob_device.argtypes = [vp, vp, C.c_size_t, i32]
