@@ -262,7 +262,8 @@ int orbhip_features_in_area(orbhip_ctx *ctx, const orbhip_keypoint *kps_un, int 
  * use_ratio = 0: best only, rotation histogram when check_ori).  Queries are processed in index order, as
  * the reference processes its points: occupied[i] != 0 marks frame features that already hold a MapPoint
  * with observations (:88-90, :1413-1415).  match[i] = index of the query assigned to frame feature i (the
- * last one, as in the reference) or -1; *nmatches = the reference routine's return value.  The caller
+ * last one, as in the reference), -1 if none was, -2 if one was and the rotation check removed it (the
+ * reference stores NULL there, :1489); *nmatches = the reference routine's return value.  The caller
  * projects the points (pose arithmetic stays on the host) and fills the queries.  TH_HIGH = th_high. */
 int orbhip_search_by_projection(orbhip_ctx *ctx, const orbhip_keypoint *kps_un, const uint8_t *desc, int n,
                                 const float *u_right, const uint8_t *occupied, float min_x, float min_y,

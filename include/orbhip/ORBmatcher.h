@@ -3,10 +3,14 @@
 // DescriptorDistance and both SearchByBoW overloads.  The Hamming work of SearchByBoW runs in
 // liborbhip.so (k_bow_match, one wave per shared vocabulary node).
 //
-// The nine guided-search routines of the reference (SearchByProjection x4, SearchForInitialization,
-// SearchForTriangulation, SearchBySim3, Fuse x2) are pose/projection logic around the same
-// best/second-best primitive; they stay in the reference's own ORBmatcher.cc (SURVEY.md section 8a,
-// row M3 / section 8f row 3) and can call orbhip_hamming_knn2_lists for their inner loops.
+// SearchByProjection(Frame&, vector<MapPoint*>&, th) and SearchByProjection(CurrentFrame, LastFrame, th,
+// bMono) run their window search on the device grid
+// (orbhip_search_by_projection); the pose arithmetic that projects the points stays on the host.
+//
+// The other guided-search routines of the reference (SearchByProjection with a KeyFrame / Sim3,
+// SearchForInitialization, SearchForTriangulation, SearchBySim3, Fuse x2) are pose/projection logic around
+// the same best/second-best primitive; they stay in the reference's own ORBmatcher.cc (SURVEY.md section 8a,
+// row M3) and can call orbhip_hamming_knn2_lists for their inner loops.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
@@ -44,6 +48,14 @@ public:
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches);
     int SearchByBoW(KeyFrame *pKF1, KeyFrame* pKF2, std::vector<MapPoint*> &vpMatches12);
 
+    // Search matches between Frame keypoints and projected MapPoints. Returns number of matches
+    // Used to track the local map (Tracking) (ref: src/ORBmatcher.cc:45-129)
+    int SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th=3);
+
+    // Project MapPoints tracked in last frame into the current frame and search matches.
+    // Used to track from previous frame (Tracking) (ref: src/ORBmatcher.cc:1341-1498)
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+
     // Device context used for matching.  By default one small context per thread is created on
     // first use (matchers are stack objects in the reference and are used from three threads).
     static void SetDevice(int device);
@@ -55,6 +67,8 @@ public:
     static const int HISTO_LENGTH;
 
 protected:
+
+    float RadiusByViewingCos(const float &viewCos);
 
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3);
 

@@ -1505,6 +1505,8 @@ int orbo_features_in_area(const orbo_keypoint *kps, const int32_t *cell_off, con
  *   use_ratio = 1: :45-129  (second best + ratio when best and second lie on the same level)
  *   use_ratio = 0: :1341-1498 (best only; rotation histogram when check_ori)
  * occupied[i] != 0: the frame feature already holds a MapPoint with Observations() > 0 (:88-90, :1413-1415).
+ * match[i]: index of the last query assigned to feature i, -1 = never assigned, -2 = assigned and then
+ * removed by the rotation check.
  * A match of query q sets match[best] = q and, when the query's point has observations
  * (ORBO_Q_OBSERVED), makes the feature occupied for the queries after it.  u_right may be NULL (mono). */
 int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *u_right,
@@ -1573,7 +1575,7 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
         for (int i = 0; i < HISTO_LENGTH; i++) {
             if (i == i1 || i == i2 || i == i3) continue;
             for (int j = 0; j < hn[i]; j++) {
-                match[hist[i][j]] = -1;
+                match[hist[i][j]] = -2; /* the reference stores NULL (:1489); -1 = never touched */
                 nmatches--;
             }
         }

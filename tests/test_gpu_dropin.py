@@ -145,3 +145,104 @@ def test_cpp_stereo_frame_matches_oracle(oracle, tmp_path):
     assert n == len(kL) and nr == len(kR) and kps.tobytes() == kL.tobytes()
     ru, rz, rn = oracle.stereo_matches(oL, kL, dL, oR, kR, dR, np.float32(mb), np.float32(mbf))
     assert u.tobytes() == ru.tobytes() and z.tobytes() == rz.tobytes() and (ru >= 0).sum() > 300
+
+
+def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
+    """Frame::AssignFeaturesToGrid / GetFeaturesInArea and both ORBmatcher::SearchByProjection drop-ins, driven
+    the way Tracking drives them (tests/native/test_guided_dropin.cpp), against the oracle; the pose arithmetic
+    of the wrapper is restated here in numpy (double accumulation, one rounding, as cv::gemm does for floats)."""
+    from orbhip import guided, synth
+    exe = os.path.join(ROOT, "tests", "native", "test_guided_dropin")
+    assert os.path.exists(exe), "tests/native/test_guided_dropin is not built (run __graft_entry__.build())"
+    f32 = np.float32
+    W, H, NF = 640, 480, 1200
+    frames = synth.make_frames(80, W, H, 2)
+    ex = oracle.Extractor(NF)
+    (k0, d0), (k1, d1) = ex(frames[0]), ex(frames[1])
+    n0, n1 = len(k0), len(k1)
+    rng = np.random.default_rng(81)
+    fx, fy, cx, cy = f32(517.3), f32(516.5), f32(318.6), f32(255.3)
+    bounds = (f32(0), f32(W), f32(0), f32(H))
+    mb, mbf, th_last, th_local = f32(0.08), f32(40.0), f32(15), f32(3)
+    ang = 0.004
+    Rc = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]).astype(f32)
+    tc = np.array([0.012, -0.006, 0.03], f32)
+    Tl = np.eye(4, dtype=f32)
+    Tc = np.eye(4, dtype=f32)
+    Tc[:3, :3], Tc[:3, 3] = Rc, tc
+    z = rng.uniform(2, 10, n0).astype(f32)
+    Xw = np.stack([(k0["x"] - cx) / fx * z, (k0["y"] - cy) / fy * z, z], 1).astype(f32)
+    Xw[5, 2] = f32(-1.0)                                            # behind the camera -> skipped
+    nobs = rng.integers(0, 4, n0)
+    outlier = rng.random(n0) < 0.05
+    rec = np.zeros((n0, 12), f32)
+    rec[:, 0:3], rec[:, 3], rec[:, 4] = Xw, nobs, outlier
+    rec[:, 5] = k0["x"] + rng.normal(0, 1.5, n0)                    # mTrackProjX / Y / XR
+    rec[:, 6] = k0["y"] + rng.normal(0, 1.5, n0)
+    rec[:, 7] = rec[:, 5] - 10
+    rec[:, 8] = rng.uniform(0.99, 1.0, n0)                          # mTrackViewCos
+    rec[:, 9] = k0["octave"]                                        # mnTrackScaleLevel
+    rec[:, 10] = rng.random(n0) < 0.9                               # mbTrackInView
+    rec[:, 11] = rng.random(n0) < 0.03                              # isBad
+    hdr = np.concatenate([[fx, fy, cx, cy, bounds[0], bounds[1], bounds[2], bounds[3], mb, mbf, th_last, th_local, 1],
+                          Tl.ravel(), Tc.ravel()]).astype(f32)
+    (tmp_path / "frames.raw").write_bytes(frames.tobytes())
+    (tmp_path / "params.bin").write_bytes(hdr.tobytes() + rec.tobytes())
+    out = tmp_path / "guided.bin"
+    subprocess.check_call([exe, str(W), str(H), str(NF), str(tmp_path / "frames.raw"), str(tmp_path / "params.bin"), str(out)])
+    buf = np.frombuffer(out.read_bytes(), np.int32)
+    pos = 0
+
+    def take(n=1):
+        nonlocal pos
+        v = buf[pos:pos + n]
+        pos += n
+        return v
+
+    gp = oracle.grid_params(*bounds)
+    assert take()[0] == n1
+    roff, ridx = oracle.grid_build(k1, gp)
+    for c in range(64 * 48):
+        cnt = take()[0]
+        assert cnt == roff[c + 1] - roff[c] and np.array_equal(take(cnt), ridx[roff[c]:roff[c + 1]])
+    for (x, y, r, mn, mx) in [(310.5, 200.25, 45.0, 1, 3), (20.0, 470.0, 60.0, -1, -1)]:
+        cnt = take()[0]
+        assert np.array_equal(take(cnt), oracle.features_in_area(k1, (roff, ridx), gp, x, y, r, mn, mx))
+
+    # --- SearchByProjection(CurrentFrame, LastFrame, th, bMono): the wrapper's projection, restated ---
+    def affine(R, x, t):                                           # float(double sum + double t)
+        s = np.zeros(x.shape[:-1] + (3,), np.float64)
+        for r in range(3):
+            acc = np.zeros(x.shape[:-1], np.float64)
+            for k in range(3):
+                acc = acc + np.float64(R[r, k]) * x[..., k].astype(np.float64)
+            s[..., r] = acc + np.float64(t[r])
+        return s.astype(f32)
+    xc = affine(Rc, Xw, tc)
+    with np.errstate(divide="ignore"):
+        invz = (1.0 / xc[:, 2].astype(np.float64)).astype(f32)
+    u = fx * xc[:, 0] * invz + cx
+    v = fy * xc[:, 1] * invz + cy
+    has_point = (np.arange(n0) % 9 != 4)
+    valid = has_point & ~outlier & ~(invz < 0) & ~(u < bounds[0]) & ~(u > bounds[1]) & ~(v < bounds[2]) & ~(v > bounds[3])
+    sf = (f32(1.2) ** np.arange(8)).astype(f32)
+    sf = np.array(list(ex.params.mvScaleFactor)[:8], f32)
+    qB = guided.queries_for_last_frame(u, v, u - mbf * invz, k0["octave"], k0["angle"], valid, nobs > 0, th_last, sf)
+    assert valid.sum() > 800 and not valid[5]
+    rn, rm = oracle.search_by_projection(k1, d1, gp, qB, d0, use_ratio=False, nnratio=0.9, check_ori=True)
+    n = take()[0]
+    got = take(n1)
+    exp = np.where(rm >= 0, rm, -1)
+    assert n == rn and rn > 500 and np.array_equal(got, exp)
+
+    # --- SearchByProjection(F, vpMapPoints, th) on top of it: points in reverse order ---
+    order = np.arange(n0)[::-1]
+    qA = guided.queries_for_map_points(rec[order, 5], rec[order, 6], rec[order, 7], rec[order, 8], rec[order, 9].astype(np.int32),
+                                       (rec[order, 10] != 0) & (rec[order, 11] == 0), nobs[order] > 0, th_local, sf)
+    occupied = np.array([1 if (e >= 0 and nobs[e] > 0) else 0 for e in exp], np.uint8)
+    rn2, rm2 = oracle.search_by_projection(k1, d1, gp, qA, d0[order], occupied=occupied, use_ratio=True, nnratio=0.8)
+    n2 = take()[0]
+    got2 = take(n1)
+    exp2 = np.where(rm2 >= 0, order[np.maximum(rm2, 0)], exp)
+    assert n2 == rn2 and rn2 > 50 and np.array_equal(got2, exp2)
+    assert pos == len(buf)

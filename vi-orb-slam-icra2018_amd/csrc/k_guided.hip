@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64) void k_proj_assign(const orbhip_keypoint *__res
             int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
             if (bin == 30) bin = 0;
             if (bin >= 0 && bin < 30 && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
-                s_match[f] = -1;
+                s_match[f] = -2;   // assigned, then removed: the reference stores NULL here (:1489)
                 removed++;
             }
         }

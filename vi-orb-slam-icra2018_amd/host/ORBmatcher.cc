@@ -5,6 +5,7 @@
 // in liborbhip.so (orbhip_search_by_bow).
 #include "ORBmatcher.h"
 
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -130,6 +131,170 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
     for (int i1 = 0; i1 < n1 && i1 < (int)vpMatches12.size(); i1++)
         if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];           // ref: :602
     return nmatches;
+}
+
+float ORBmatcher::RadiusByViewingCos(const float &viewCos)
+{
+    if(viewCos>0.998)                                          // ref: src/ORBmatcher.cc:131-137
+        return 2.5;
+    else
+        return 4.0;
+}
+
+namespace {
+// Runs the window search of one frame on the device and writes the result into F.mvpMapPoints the way the
+// reference's loops do: the last point assigned to a feature stays, a feature whose match the rotation check
+// removed becomes NULL, every other feature is left alone.
+int run_projection_search(Frame &F, const vector<orbhip_proj_query> &q, const vector<uint8_t> &qdesc,
+                          const vector<MapPoint *> &source, bool use_ratio, float nnratio, bool check_ori, int th_high)
+{
+    const int n = F.N, nq = (int)q.size();
+    if (n == 0 || nq == 0) return 0;
+    vector<uint8_t> occupied(n, 0);
+    for (int i = 0; i < n; i++)
+        if (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) occupied[i] = 1;   // ref: :88-90, :1413-1415
+    const vector<uint8_t> d = contiguous(F.mDescriptors);
+    vector<int32_t> match(n);
+    int nmatches = 0;
+    const int rc = orbhip_search_by_projection(
+        tls.get(), reinterpret_cast<const orbhip_keypoint *>(F.mvKeysUn.data()), d.data(), n,
+        (int)F.mvuRight.size() == n ? F.mvuRight.data() : NULL, occupied.data(), Frame::mnMinX, Frame::mnMinY,
+        Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv, q.data(), qdesc.data(), nq, use_ratio ? 1 : 0, nnratio,
+        check_ori ? 1 : 0, th_high, match.data(), &nmatches);
+    if (rc != ORBHIP_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection: ") + orbhip_last_error(tls.get()));
+    for (int i = 0; i < n; i++) {
+        if (match[i] >= 0)
+            F.mvpMapPoints[i] = source[match[i]];
+        else if (match[i] == -2)
+            F.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);
+    }
+    return nmatches;
+}
+
+// d = R * x + t for 3x3 / 3x1 float matrices.  OpenCV evaluates the MatExpr Rcw*x3Dw+tcw as one gemm whose
+// float kernel accumulates in double and rounds once (modules/core/src/matmul.cpp, GEMMSingleMul<float,double>).
+void affine3(const cv::Mat &R, const float x[3], const float t[3], float out[3], bool transpose = false, double alpha = 1.0)
+{
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)(transpose ? R.at<float>(k, r) : R.at<float>(r, k)) * (double)x[k];
+        out[r] = (float)(alpha * s + (t ? (double)t[r] : 0.0));
+    }
+}
+}  // namespace
+
+int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+{
+    const bool bFactor = th!=1.0;
+
+    const int nq = (int)vpMapPoints.size();
+    vector<orbhip_proj_query> q(nq);
+    vector<uint8_t> qdesc((size_t)nq * 32, 0);
+    for(int iMP=0; iMP<nq; iMP++)
+    {
+        MapPoint* pMP = vpMapPoints[iMP];
+        orbhip_proj_query &e = q[iMP];
+        memset(&e, 0, sizeof(e));
+        if(!pMP->mbTrackInView)                                // ref: :55-59
+            continue;
+        if(pMP->isBad())
+            continue;
+
+        const int &nPredictedLevel = pMP->mnTrackScaleLevel;
+
+        // The size of the window will depend on the viewing direction
+        float r = RadiusByViewingCos(pMP->mTrackViewCos);
+        if(bFactor)
+            r*=th;
+
+        e.u = pMP->mTrackProjX;                                // ref: :68-69
+        e.v = pMP->mTrackProjY;
+        e.radius = r*F.mvScaleFactors[nPredictedLevel];
+        e.min_level = nPredictedLevel-1;
+        e.max_level = nPredictedLevel;
+        e.proj_xr = pMP->mTrackProjXR;                         // ref: :94
+        e.flags = ORBHIP_Q_ACTIVE | (pMP->Observations()>0 ? ORBHIP_Q_OBSERVED : 0);
+        const cv::Mat MPdescriptor = pMP->GetDescriptor();
+        memcpy(&qdesc[(size_t)iMP * 32], MPdescriptor.ptr(0), 32);
+    }
+    return run_projection_search(F, q, qdesc, vpMapPoints, true, mfNNratio, false, TH_HIGH);
+}
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+{
+    // ref: :1351-1365 -- camera pose pieces
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0,3).colRange(0,3);
+    const cv::Mat Rlw = LastFrame.mTcw.rowRange(0,3).colRange(0,3);
+    float tcw[3], tlw[3], twc[3], tlc[3];
+    for (int r = 0; r < 3; r++) {
+        tcw[r] = CurrentFrame.mTcw.at<float>(r, 3);
+        tlw[r] = LastFrame.mTcw.at<float>(r, 3);
+    }
+    affine3(Rcw, tcw, NULL, twc, true, -1.0);                  // twc = -Rcw.t()*tcw
+    affine3(Rlw, twc, tlw, tlc);                               // tlc = Rlw*twc+tlw
+
+    const bool bForward = tlc[2]>CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc[2]>CurrentFrame.mb && !bMono;
+
+    const int nq = LastFrame.N;
+    vector<orbhip_proj_query> q(nq);
+    vector<uint8_t> qdesc((size_t)nq * 32, 0);
+    for(int i=0; i<nq; i++)
+    {
+        orbhip_proj_query &e = q[i];
+        memset(&e, 0, sizeof(e));
+        MapPoint* pMP = LastFrame.mvpMapPoints[i];
+        if(!pMP)
+            continue;
+        if(LastFrame.mvbOutlier[i])
+            continue;
+
+        // Project (ref: :1376-1398)
+        const cv::Mat x3Dw = pMP->GetWorldPos();
+        const float xw[3] = {x3Dw.at<float>(0, 0), x3Dw.at<float>(1, 0), x3Dw.at<float>(2, 0)};
+        float x3Dc[3];
+        affine3(Rcw, xw, tcw, x3Dc);
+
+        const float xc = x3Dc[0];
+        const float yc = x3Dc[1];
+        const float invzc = 1.0/x3Dc[2];
+
+        if(invzc<0)
+            continue;
+
+        float u = CurrentFrame.fx*xc*invzc+CurrentFrame.cx;
+        float v = CurrentFrame.fy*yc*invzc+CurrentFrame.cy;
+
+        if(u<CurrentFrame.mnMinX || u>CurrentFrame.mnMaxX)
+            continue;
+        if(v<CurrentFrame.mnMinY || v>CurrentFrame.mnMaxY)
+            continue;
+
+        int nLastOctave = LastFrame.mvKeys[i].octave;
+
+        // Search in a window. Size depends on scale (ref: :1403-1416)
+        e.u = u;
+        e.v = v;
+        e.radius = th*CurrentFrame.mvScaleFactors[nLastOctave];
+        if(bForward) {
+            e.min_level = nLastOctave;
+            e.max_level = -1;
+        } else if(bBackward) {
+            e.min_level = 0;
+            e.max_level = nLastOctave;
+        } else {
+            e.min_level = nLastOctave-1;
+            e.max_level = nLastOctave+1;
+        }
+        e.proj_xr = u - CurrentFrame.mbf*invzc;                // ref: :1435
+        e.angle = LastFrame.mvKeysUn[i].angle;                 // ref: :1461
+        e.flags = ORBHIP_Q_ACTIVE | (pMP->Observations()>0 ? ORBHIP_Q_OBSERVED : 0);
+        const cv::Mat dMP = pMP->GetDescriptor();
+        memcpy(&qdesc[(size_t)i * 32], dMP.ptr(0), 32);
+    }
+    return run_projection_search(CurrentFrame, q, qdesc, LastFrame.mvpMapPoints, false, mfNNratio, mbCheckOrientation,
+                                 TH_HIGH);
 }
 
 void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3)
