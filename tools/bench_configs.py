@@ -36,6 +36,31 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
     L = ex._L
     if match == "bow":
         ORBVocabulary(ex).loadFromBinaryBlob(D.make_synthetic_vocabulary(4242, 10, 6))
+    if match == "proj":
+        # tracking with the motion model: frame b-1's keypoints are the projected points of frame b
+        # (constant-position guess), th = 15 (mono), levels +-1 -- src/Tracking.cc TrackWithMotionModel
+        from orbhip import guided
+        gp = guided.grid_params(0, W, 0, H)
+        d_off = torch.empty((B, 64 * 48 + 1), **i32)
+        d_idx = torch.empty((B, cap), **i32)
+        d_q = torch.zeros((B, cap, 8), **i32)
+        d_qd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_nq = torch.zeros(B, **i32)
+        sf = torch.tensor([float(np.float32(1.2) ** l) for l in range(8)], dtype=torch.float32, device="cuda")
+
+        def build_queries():
+            k = d_kps.roll(1, 0)
+            octv = k[:, :, 5].clamp(0, 7).long()
+            d_q[:, :, 0] = k[:, :, 0]
+            d_q[:, :, 1] = k[:, :, 1]
+            d_q[:, :, 2] = (15.0 * sf[octv]).view(torch.int32)
+            d_q[:, :, 4] = k[:, :, 5] - 1
+            d_q[:, :, 5] = k[:, :, 5] + 1
+            d_q[:, :, 6] = k[:, :, 3]
+            d_q[:, :, 7] = 3
+            d_qd.copy_(d_desc.roll(1, 0))
+            d_nq.copy_(d_cnt.roll(1, 0))
+            d_nq[0] = 0
 
     def step():
         ex.extract_batch_device(d_img.data_ptr(), B, W, H, stride, H * stride, d_kps.data_ptr(), d_desc.data_ptr(), cap,
@@ -46,10 +71,23 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
             assert L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.data_ptr(), d_kps.data_ptr(), d_cnt.data_ptr(),
                                                      d_b.data_ptr(), d_wt.data_ptr(), None, cap, B, 1, 0, C.c_float(0.7), 1,
                                                      d_c.data_ptr(), d_d.data_ptr(), d_nm.data_ptr()) == 0
+        elif match == "proj":
+            assert L.orbhip_grid_build_device(ex.handle, d_kps.data_ptr(), d_cnt.data_ptr(), cap, B, gp[0], gp[1], gp[2], gp[3],
+                                              d_off.data_ptr(), d_idx.data_ptr()) == 0
+            assert L.orbhip_search_by_projection_device(ex.handle, d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, B,
+                                                        None, None, gp[0], gp[1], gp[2], gp[3], d_off.data_ptr(),
+                                                        d_idx.data_ptr(), d_q.data_ptr(), d_qd.data_ptr(), d_nq.data_ptr(), cap,
+                                                        0, 0.9, 1, 100, d_a.data_ptr(), d_nm.data_ptr()) == 0
         elif match == "brute":
             assert L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.data_ptr(), d_cnt.data_ptr(), cap, B, 1, d_a.data_ptr(),
                                                     d_b.data_ptr(), d_c.data_ptr()) == 0
     torch.cuda.synchronize()
+    if match == "proj":
+        ex.extract_batch_device(d_img.data_ptr(), B, W, H, stride, H * stride, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_cnt.data_ptr())
+        ex.sync()
+        build_queries()
+        torch.cuda.synchronize()
     for _ in range(2):
         step()
     ex.sync()
@@ -62,6 +100,8 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
     ms = (C.c_float * 6)()
     L.orbhip_get_stage_times(ex.handle, ms)
     kp = float(d_cnt.cpu().numpy().mean())
+    if match == "proj":
+        kp = float(d_nm.cpu().numpy()[1:].mean())      # matches per frame instead
     ex.close()
     return nsteps * B / dt, dt, kp, list(ms)
 
@@ -162,12 +202,18 @@ def run_big_knn(nq, ndb):
 def main():
     print("| config (BASELINE.json) | workload | frames/s | notes |")
     print("|---|---|---|---|")
+    if len(sys.argv) > 1 and sys.argv[1] == "proj":            # profiling aid: the guided-search row only
+        fps, dt, kp, ms = run_extract(640, 480, 1000, 512, 4096, "proj", seed=1)
+        print("| 1b | proj | %.0f frames/s | %.1f matches per frame |" % (fps, kp))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "stereo":          # profiling aid: the stereo row only
         pps, st, good = run_stereo(1241, 376, 2000, 128, 1024, 0.53716, 386.1448)
         print("| 3b | stereo | %.0f pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
         return
     fps, dt, kp, ms = run_extract(752, 480, 1000, 512, 3682, "bow", seed=1)
     print("| 2: EuRoC MH_01 full sequence | 3682 frames 752x480, 1000 feat, batches of 512, extract + transform + SearchByBoW | %.0f | %.1f kp/frame, %.3f s for the sequence |" % (fps, kp, dt))
+    fps, dt, kp, ms = run_extract(640, 480, 1000, 512, 4096, "proj", seed=1)
+    print("| 1b: tracking front end (headline geometry) | 640x480, 1000 feat, batches of 512: extract + AssignFeaturesToGrid + SearchByProjection(last frame, th 15) | %.0f | %.1f matches per frame |" % (fps, kp))
     fps, dt, kp, ms = run_extract(1241, 376, 2000, 256, 2048, "bow", seed=2)
     print("| 3: KITTI 00 stereo | 1241x376, 2000 feat, L+R images as 2 frames per pair, extract + transform + SearchByBoW | %.0f images/s = %.0f stereo pairs/s | %.1f kp/image |" % (fps, fps / 2, kp))
     pps, st, good = run_stereo(1241, 376, 2000, 128, 1024, 0.53716, 386.1448)

@@ -39,12 +39,14 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
                                               int stride0, unsigned long long frame0,
                                               const uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
                                               uint8_t *__restrict__ blur, unsigned long long blurFrame,
-                                              const BlurTile *__restrict__ tiles, int4 kq)
+                                              const BlurTile *__restrict__ tiles, int4 kq, int xcdMap, int ntiles)
 {
     __shared__ __align__(16) uint8_t s_raw[BT_ROWS][BT_RAWP];
     __shared__ __align__(16) uint32_t s_pair[BT_ROWS / 2][BT_W];
-    const BlurTile T = tiles[blockIdx.x];
-    const int frame = blockIdx.y, l = T.level;
+    const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
+    if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
+    const BlurTile T = tiles[tileId];
+    const int l = T.level;
     const OrbLevel &L = G.lv[l];
     const int w = L.w, h = L.h;
     const uint8_t *src;
@@ -184,8 +186,8 @@ void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
 {
     int k[4];
     gaussian_taps(k);
-    dim3 grid(ntiles, B, 1), block(256, 1, 1);
+    dim3 grid(orb_xcd_grid(ntiles), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_blur, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, tiles,
-                       make_int4(k[0], k[1], k[2], k[3]));
+                       make_int4(k[0], k[1], k[2], k[3]), orb_xcd_arg(), ntiles);
 }

@@ -73,11 +73,11 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
                                                   float *__restrict__ lvlAngle,
                                                   orbhip_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int32_t *__restrict__ counts,
-                                                  int cap)
+                                                  int cap, int xcdMap)
 {
-    const int frame = blockIdx.y;
+    const int blk = xcd_tile(xcdMap), frame = blockIdx.y;   // consecutive keypoints of a level share an XCD's L2
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);  // slot in the per-frame level-keypoint array
+    const int g = blk * 4 + (threadIdx.x >> 6);  // slot in the per-frame level-keypoint array
     if (g >= G.totalKps) return;
     const int32_t *cnts = lvlKpCnt + frame * ORBHIP_MAX_LEVELS;
     // level of this slot and output offset of the level
@@ -189,8 +189,8 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
 {
-    dim3 grid((G.totalKps + 3) / 4, B, 1), block(256, 1, 1);
+    dim3 grid(orb_xcd_grid((G.totalKps + 3) / 4), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_describe, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt,
-                       lvlAngle, kps, desc, counts, cap);
+                       lvlAngle, kps, desc, counts, cap, orb_xcd_arg());
 }

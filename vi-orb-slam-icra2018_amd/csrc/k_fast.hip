@@ -188,15 +188,16 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
                                               const FastTile *__restrict__ tiles,
                                               uint32_t *__restrict__ cand,
                                               uint16_t *__restrict__ cellCnt, int pixBytes, int scoreBytes,
-                                              int listBytes, int listCap, int cornerCap, int phases)
+                                              int listBytes, int listCap, int cornerCap, int phases, int xcdMap, int ntiles)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_cellAny[FAST_TILE_CELLS];
     __shared__ int s_cellCnt[FAST_TILE_CELLS];
     __shared__ int s_listCount, s_cornerCount, s_survCount;
 
-    const FastTile T = tiles[blockIdx.x];
-    const int frame = blockIdx.y;
+    const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
+    if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
+    const FastTile T = tiles[tileId];
     const OrbLevel &L = G.lv[T.level];
     const int tid = threadIdx.x, lane = tid & 63;
 
@@ -446,8 +447,8 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     listBytes = (listBytes + 15) & ~15;
     const int cornerBytes = (cornerCap * 2 + 15) & ~15;
     static const int phases = getenv("ORBHIP_FAST_PHASES") ? atoi(getenv("ORBHIP_FAST_PHASES")) : 5;
-    dim3 grid(ntiles, B, 1), block(256, 1, 1);
+    dim3 grid(orb_xcd_grid(ntiles), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_fast, grid, block, (size_t)(pixBytes + scoreBytes + listBytes + cornerBytes), s, G, lvl0, stride0,
                        (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tiles, cand, cellCnt,
-                       pixBytes, scoreBytes, listBytes, listCap, cornerCap, phases);
+                       pixBytes, scoreBytes, listBytes, listCap, cornerCap, phases, orb_xcd_arg(), ntiles);
 }

@@ -18,14 +18,19 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
                                                 unsigned long long sframe, uint8_t *__restrict__ dst,
                                                 int dw, int dh, int dstride, unsigned long long dframe,
                                                 const int2 *__restrict__ xtab,
-                                                const int4 *__restrict__ ytab)
+                                                const int4 *__restrict__ ytab, int xcdMap)
 {
     __shared__ __align__(16) uint8_t s_src[RZ_MAXROWS][RZ_MAXCH * 16];
     const int tid = threadIdx.x;
-    const int ox0 = blockIdx.x * RZ_TW, oy0 = blockIdx.y * RZ_TH;
+    // grid = (tiles padded to a multiple of 8, frames); orbhip_internal.h, xcd_tile
+    const int tilesX = (dw + RZ_TW - 1) / RZ_TW, tilesY = (dh + RZ_TH - 1) / RZ_TH;
+    const int t = xcd_tile(xcdMap), frame = blockIdx.y;
+    if (t >= tilesX * tilesY) return;
+    const int by = t / tilesX, bx = t - by * tilesX;
+    const int ox0 = bx * RZ_TW, oy0 = by * RZ_TH;
     const int ox1 = min(ox0 + RZ_TW, dw) - 1, oy1 = min(oy0 + RZ_TH, dh) - 1;   // inclusive
-    const uint8_t *S = src + (size_t)blockIdx.z * sframe;
-    uint8_t *D = dst + (size_t)blockIdx.z * dframe;
+    const uint8_t *S = src + (size_t)frame * sframe;
+    uint8_t *D = dst + (size_t)frame * dframe;
 
     // source window of the tile (tables are monotone)
     const int sxmin = xtab[ox0].x & 0xFFFF, sxmax = (unsigned)xtab[ox1].x >> 16;
@@ -96,8 +101,8 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
     (void)sw;
     (void)sh;
     dim3 block(256, 1, 1);
-    dim3 grid((dw + RZ_TW - 1) / RZ_TW, (dh + RZ_TH - 1) / RZ_TH, B);
+    dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + RZ_TH - 1) / RZ_TH)), B, 1);
     hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh,
                        dstride, (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
-                       reinterpret_cast<const int4 *>(ytab));
+                       reinterpret_cast<const int4 *>(ytab), orb_xcd_arg());
 }

@@ -199,6 +199,54 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
                       const int32_t *off2, const int32_t *idx2, const int32_t *pairs, int npairs,
                       int th, int th_mode, float nnratio, int32_t *match12, int32_t *match21);
 
+// XCD-aware work assignment for (tile, frame) grids -- an OPTION, off by default.  Workgroups are dealt
+// round-robin over the 8 XCDs by linear id (MI355X_MICROARCH.md, "Workgroup dispatch"; placement affects speed
+// only).  With ORBHIP_XCD_MAP != 0 the grid's x extent is padded to a multiple of 8, workgroup x of a frame runs
+// on XCD x % 8 and takes a tile from a contiguous eighth of the frame's tiles, so the 128-byte lines that
+// neighbouring tiles share (halo rows, row segments straddling a line) are fetched into one XCD's L2 once
+// instead of once per XCD.  Measured (profiles/r01e_xcd_map.md): fabric read traffic of k_fast / k_blur /
+// k_describe falls 2-3x to about the algorithmic bytes, but every variant is SLOWER than the plain mapping
+// (k_fast +2..+100 %): the re-reads are served by the Infinity Cache, the kernels are VALU/LDS- or
+// latency-bound, and spreading neighbouring tiles over all eight L2s balances the load better.  Hence 0.
+static inline int orb_xcd_map()
+{
+    static int v = -1;
+    if (v < 0) v = getenv("ORBHIP_XCD_MAP") ? atoi(getenv("ORBHIP_XCD_MAP")) : 0;
+    return v;
+}
+static inline int orb_xcd_chunk();
+static inline int orb_xcd_arg();
+static inline int orb_xcd_chunk()
+{
+    static int v = -1;
+    if (v < 0) v = getenv("ORBHIP_XCD_CHUNK") ? atoi(getenv("ORBHIP_XCD_CHUNK")) : 4;
+    return v;
+}
+static inline int orb_xcd_grid(int ntiles)
+{
+    const int m = orb_xcd_map();
+    if (!m) return ntiles;
+    const int unit = m == 3 ? 8 * orb_xcd_chunk() : 8;
+    return (ntiles + unit - 1) / unit * unit;
+}
+static inline int orb_xcd_arg() { return orb_xcd_map() | (orb_xcd_chunk() << 8); }
+#ifdef __HIPCC__
+// mode 1: band (x % 8 + frame) % 8 -- every XCD sees every band over 8 consecutive frames (tile cost differs
+// between pyramid levels); mode 2: band x % 8; mode 3: chunks of xcdMap >> 8 tiles dealt round-robin.
+__device__ __forceinline__ int xcd_tile(int xcdMap)
+{
+    const unsigned x = blockIdx.x, k = x & 7u, s = x >> 3, bw = gridDim.x >> 3;
+    const int mode = xcdMap & 255;
+    if (mode == 1) return (int)(((k + blockIdx.y) & 7u) * bw + s);
+    if (mode == 2) return (int)(k * bw + s);
+    if (mode == 3) {
+        const unsigned c = (unsigned)xcdMap >> 8;
+        return (int)(((s / c) * 8u + k) * c + s % c);
+    }
+    return (int)x;
+}
+#endif
+
 int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, float minX,
                       float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx);
 int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, float minY, float invW, float invH,
