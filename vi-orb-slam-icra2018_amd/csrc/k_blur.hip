@@ -186,8 +186,8 @@ void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
 {
     int k[4];
     gaussian_taps(k);
-    dim3 grid(orb_xcd_grid(ntiles), B, 1), block(256, 1, 1);
+    dim3 grid(orb_xcd_grid(ntiles, 2), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_blur, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, tiles,
-                       make_int4(k[0], k[1], k[2], k[3]), orb_xcd_arg(), ntiles);
+                       make_int4(k[0], k[1], k[2], k[3]), orb_xcd_arg(2), ntiles);
 }

@@ -208,28 +208,28 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
 // k_describe falls 2-3x to about the algorithmic bytes, but every variant is SLOWER than the plain mapping
 // (k_fast +2..+100 %): the re-reads are served by the Infinity Cache, the kernels are VALU/LDS- or
 // latency-bound, and spreading neighbouring tiles over all eight L2s balances the load better.  Hence 0.
-static inline int orb_xcd_map()
+static inline int orb_xcd_map(int dflt = 0)
 {
-    static int v = -1;
-    if (v < 0) v = getenv("ORBHIP_XCD_MAP") ? atoi(getenv("ORBHIP_XCD_MAP")) : 0;
-    return v;
+    static int v = -2;
+    if (v == -2) v = getenv("ORBHIP_XCD_MAP") ? atoi(getenv("ORBHIP_XCD_MAP")) : -1;
+    return v >= 0 ? v : dflt;   // k_blur's tiles cost the same everywhere: plain bands (2) are its default
 }
 static inline int orb_xcd_chunk();
-static inline int orb_xcd_arg();
+static inline int orb_xcd_arg(int dflt = 0);
 static inline int orb_xcd_chunk()
 {
     static int v = -1;
     if (v < 0) v = getenv("ORBHIP_XCD_CHUNK") ? atoi(getenv("ORBHIP_XCD_CHUNK")) : 4;
     return v;
 }
-static inline int orb_xcd_grid(int ntiles)
+static inline int orb_xcd_grid(int ntiles, int dflt = 0)
 {
-    const int m = orb_xcd_map();
+    const int m = orb_xcd_map(dflt);
     if (!m) return ntiles;
     const int unit = m == 3 ? 8 * orb_xcd_chunk() : 8;
     return (ntiles + unit - 1) / unit * unit;
 }
-static inline int orb_xcd_arg() { return orb_xcd_map() | (orb_xcd_chunk() << 8); }
+static inline int orb_xcd_arg(int dflt) { return orb_xcd_map(dflt) | (orb_xcd_chunk() << 8); }
 #ifdef __HIPCC__
 // mode 1: band (x % 8 + frame) % 8 -- every XCD sees every band over 8 consecutive frames (tile cost differs
 // between pyramid levels); mode 2: band x % 8; mode 3: chunks of xcdMap >> 8 tiles dealt round-robin.
