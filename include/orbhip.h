@@ -280,6 +280,30 @@ int orbhip_search_by_projection_device(orbhip_ctx *ctx, const void *d_kps_un, co
                                        const void *d_qdesc, const void *d_nq, int cap_q, int use_ratio,
                                        float nnratio, int check_ori, int th_high, void *d_match, void *d_nmatches);
 
+/* ---- undistortion and rectification ----
+ * Replaces the body of Frame::UndistortKeyPoints (src/Frame.cc:748-778): cv::undistortPoints(mat, mat, mK,
+ * mDistCoef, cv::Mat(), mK) on the keypoint coordinates; every other field of a keypoint is copied.  K, P: 3x3
+ * row-major float (P = NULL: normalised coordinates are returned, as OpenCV does without P; the reference passes
+ * mK); dist: ndist in {0, 4, 5, 8} coefficients (k1, k2, p1, p2[, k3[, k4, k5, k6]]).  The caller keeps the
+ * reference's shortcut "mDistCoef(0) == 0 -> mvKeysUn = mvKeys" (:750-754).  d_counts may be NULL (= cap points
+ * per set).  Also serves Frame::ComputeImageBounds (:780-808: the four image corners as keypoints). */
+int orbhip_undistort_keypoints(orbhip_ctx *ctx, const orbhip_keypoint *kps, int n, const float K[9], const float *dist,
+                               int ndist, const float *P, orbhip_keypoint *kps_un);
+int orbhip_undistort_keypoints_device(orbhip_ctx *ctx, const void *d_kps, const void *d_counts, int cap, int B,
+                                      const float K[9], const float *dist, int ndist, const float *P, void *d_kps_un);
+/* Replaces cv::initUndistortRectifyMap(K, D, R, P.rowRange(0,3).colRange(0,3), size, CV_32F, M1, M2)
+ * (Examples/Stereo/stereo_euroc.cc:96-98): a once-per-run table built on the host in double. */
+int orbhip_init_undistort_rectify_map(const double K[9], const double *dist, int ndist, const double R[9],
+                                      const double P[9], int w, int h, float *map_x, float *map_y);
+/* Replaces cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) (stereo_euroc.cc:136-137; 8-bit single channel,
+ * BORDER_CONSTANT 0).  The maps (w x h floats each) are uploaded once per context; every call rectifies B images
+ * with them.  The destination has the maps' size. */
+int orbhip_remap_set_maps(orbhip_ctx *ctx, const float *map_x, const float *map_y, int w, int h);
+int orbhip_remap(orbhip_ctx *ctx, const uint8_t *src, int src_w, int src_h, int src_stride, uint8_t *dst,
+                 int dst_stride);
+int orbhip_remap_device(orbhip_ctx *ctx, const void *d_src, int B, int src_w, int src_h, int src_stride,
+                        size_t src_frame_stride, void *d_dst, int dst_stride, size_t dst_frame_stride);
+
 /* Device time of the stages of the last extract call on this context, in ms:
  * {pyramid, FAST, quadtree, blur, describe} and, at [5], of the last orbhip_hamming_knn2*_device
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */

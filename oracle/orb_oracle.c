@@ -1587,3 +1587,123 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
     free(cell_off);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Next row: the steps either side of extraction.
+ *  - Frame::UndistortKeyPoints (ref: src/Frame.cc:748-778) = cv::undistortPoints(mat, mat, mK, mDistCoef,
+ *    cv::Mat(), mK): OpenCV 2.4 cvUndistortPoints (modules/imgproc/src/undistort.cpp) -- double arithmetic,
+ *    five fixed-point iterations of the inverse distortion, then x' = P * x.
+ *  - stereo rectification (ref: Examples/Stereo/stereo_euroc.cc:96-98, :136-137): cv::initUndistortRectifyMap
+ *    (same file, double, CV_32FC1 maps) once, cv::remap(..., INTER_LINEAR) per image: OpenCV 2.4 imgwarp.cpp --
+ *    maps to fixed point with 5 fractional bits (cvRound(m * 32)), bilinear weights in 1/32768, BORDER_CONSTANT 0.
+ * [OpenCV-2.4 recollection; parity unpinned like the rest of the OpenCV boundary]
+ * ---------------------------------------------------------------------------------------- */
+void orbo_undistort_points(const float *xy_in, int n, const float *K, const float *D, int nD, const float *P,
+                           float *xy_out)
+{
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nD && i < 8; i++) k[i] = (double)D[i];
+    const double fx = (double)K[0], fy = (double)K[4], cx = (double)K[2], cy = (double)K[5];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double RR[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (P)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) RR[r][c] = (double)P[r * 3 + c]; /* P * I */
+    const int iters = (D && nD > 0) ? 5 : 1;
+    for (int i = 0; i < n; i++) {
+        double x = (double)xy_in[2 * i], y = (double)xy_in[2 * i + 1];
+        const double x0 = x = (x - cx) * ifx;
+        const double y0 = y = (y - cy) * ify;
+        for (int j = 0; j < iters; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        xy_out[2 * i] = (float)(xx * ww);
+        xy_out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+void orbo_init_undistort_rectify_map(const double *K, const double *D, int nD, const double *R, const double *P,
+                                     int w, int h, float *mapx, float *mapy)
+{
+    /* iR = (P(:, 0:3) * R)^-1 : 3x3 product accumulated k = 0..2, inverse by cofactors (cv::invert, n == 3) */
+    double M[9], ir[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += P[r * 3 + k] * R[k * 3 + c];
+            M[r * 3 + c] = s;
+        }
+#define Sd(y, x) M[(y)*3 + (x)]
+    double d = Sd(0, 0) * (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) - Sd(0, 1) * (Sd(1, 0) * Sd(2, 2) - Sd(1, 2) * Sd(2, 0)) +
+               Sd(0, 2) * (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0));
+    d = 1. / d;
+    ir[0] = (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) * d;
+    ir[1] = (Sd(0, 2) * Sd(2, 1) - Sd(0, 1) * Sd(2, 2)) * d;
+    ir[2] = (Sd(0, 1) * Sd(1, 2) - Sd(0, 2) * Sd(1, 1)) * d;
+    ir[3] = (Sd(1, 2) * Sd(2, 0) - Sd(1, 0) * Sd(2, 2)) * d;
+    ir[4] = (Sd(0, 0) * Sd(2, 2) - Sd(0, 2) * Sd(2, 0)) * d;
+    ir[5] = (Sd(0, 2) * Sd(1, 0) - Sd(0, 0) * Sd(1, 2)) * d;
+    ir[6] = (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0)) * d;
+    ir[7] = (Sd(0, 1) * Sd(2, 0) - Sd(0, 0) * Sd(2, 1)) * d;
+    ir[8] = (Sd(0, 0) * Sd(1, 1) - Sd(0, 1) * Sd(1, 0)) * d;
+#undef Sd
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    const double k1 = nD > 0 ? D[0] : 0, k2 = nD > 1 ? D[1] : 0, p1 = nD > 2 ? D[2] : 0, p2 = nD > 3 ? D[3] : 0;
+    const double k3 = nD >= 5 ? D[4] : 0, k4 = nD >= 8 ? D[5] : 0, k5 = nD >= 8 ? D[6] : 0, k6 = nD >= 8 ? D[7] : 0;
+    for (int i = 0; i < h; i++) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < w; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double ww = 1. / _w, x = _x * ww, y = _y * ww;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double u = fx * (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)) + u0;
+            const double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy) + v0;
+            mapx[(size_t)i * w + j] = (float)u;
+            mapy[(size_t)i * w + j] = (float)v;
+        }
+    }
+}
+
+static short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+/* map conversion of cv::remap for CV_32FC1 maps and INTER_LINEAR: float product, round half to even */
+void orbo_remap_prepare(const float *mapx, const float *mapy, int w, int h, int16_t *xy, uint16_t *frac)
+{
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        const int sx = orbo_cvround((double)(mapx[i] * 32.0f)), sy = orbo_cvround((double)(mapy[i] * 32.0f));
+        xy[2 * i] = sat_short(sx >> 5);
+        xy[2 * i + 1] = sat_short(sy >> 5);
+        frac[i] = (uint16_t)((sy & 31) * 32 + (sx & 31));
+    }
+}
+
+/* remapBilinear, 8UC1, BORDER_CONSTANT with value 0.  Weights a*b*32 with a, b in 1/32 units: exactly the
+ * table OpenCV builds (saturate_cast<short>(v * 32768)); its only saturating entry (fx = fy = 0 -> 32767 plus a
+ * one-unit correction on the opposite tap) yields the same 8-bit result as the exact weight. */
+void orbo_remap_linear_u8(const uint8_t *src, int sw, int sh, int sstride, const int16_t *xy, const uint16_t *frac,
+                          int dw, int dh, uint8_t *dst, int dstride)
+{
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const size_t i = (size_t)y * dw + x;
+            const int sx = xy[2 * i], sy = xy[2 * i + 1];
+            const int fx = frac[i] & 31, fy = frac[i] >> 5;
+            const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32,
+                      w11 = fx * fy * 32;
+            int p00 = 0, p01 = 0, p10 = 0, p11 = 0;
+            if (sx >= 0 && sx < sw && sy >= 0 && sy < sh) p00 = src[(size_t)sy * sstride + sx];
+            if (sx + 1 >= 0 && sx + 1 < sw && sy >= 0 && sy < sh) p01 = src[(size_t)sy * sstride + sx + 1];
+            if (sx >= 0 && sx < sw && sy + 1 >= 0 && sy + 1 < sh) p10 = src[(size_t)(sy + 1) * sstride + sx];
+            if (sx + 1 >= 0 && sx + 1 < sw && sy + 1 >= 0 && sy + 1 < sh) p11 = src[(size_t)(sy + 1) * sstride + sx + 1];
+            dst[(size_t)y * dstride + x] = (uint8_t)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15);
+        }
+}

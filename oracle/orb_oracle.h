@@ -174,6 +174,19 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
                               const orbo_proj_query *q, const uint8_t *qdesc, int nq, int use_ratio, float nnratio,
                               int check_ori, int th_high, int32_t *match);
 
+/* ---- undistortion / rectification ---- */
+/* cv::undistortPoints(src, dst, K, D, Mat(), P) as Frame::UndistortKeyPoints calls it (src/Frame.cc:767);
+ * K, P: 3x3 row-major float (P may be NULL = identity), D: nD in {0,4,5,8} coefficients. */
+void orbo_undistort_points(const float *xy_in, int n, const float *K, const float *D, int nD, const float *P,
+                           float *xy_out);
+/* cv::initUndistortRectifyMap(K, D, R, P(0:3,0:3), size, CV_32F, map1, map2) (stereo_euroc.cc:96-98) */
+void orbo_init_undistort_rectify_map(const double *K, const double *D, int nD, const double *R, const double *P,
+                                     int w, int h, float *mapx, float *mapy);
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR) (stereo_euroc.cc:136-137), split as OpenCV does it */
+void orbo_remap_prepare(const float *mapx, const float *mapy, int w, int h, int16_t *xy, uint16_t *frac);
+void orbo_remap_linear_u8(const uint8_t *src, int sw, int sh, int sstride, const int16_t *xy, const uint16_t *frac,
+                          int dw, int dh, uint8_t *dst, int dstride);
+
 #ifdef __cplusplus
 }
 #endif

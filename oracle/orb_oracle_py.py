@@ -446,3 +446,56 @@ def search_by_projection(kps, desc, gp, queries, qdesc, u_right=None, occupied=N
                                     None if occ is None else _p(occ), gp[0], gp[1], gp[2], gp[3], _p(queries), _p(qdesc),
                                     len(queries), 1 if use_ratio else 0, nnratio, 1 if check_ori else 0, th_high, _p(match))
     return n, match[:len(kps)].copy()
+
+
+# ---- undistortion / rectification ----
+def undistort_points(xy, K, D, P=None):
+    """cv::undistortPoints(xy, K, D, Mat(), P) -- Frame::UndistortKeyPoints (src/Frame.cc:748-778)."""
+    L = lib()
+    L.orbo_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    D = np.ascontiguousarray(D, np.float32).ravel()
+    Pm = None if P is None else np.ascontiguousarray(P, np.float32).reshape(9)
+    out = np.empty_like(xy)
+    L.orbo_undistort_points(_p(xy), len(xy), _p(K), _p(D) if len(D) else None, len(D), None if Pm is None else _p(Pm), _p(out))
+    return out
+
+
+def init_undistort_rectify_map(K, D, R, P, w, h):
+    L = lib()
+    L.orbo_init_undistort_rectify_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_void_p]
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    D = np.ascontiguousarray(D, np.float64).ravel()
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    P = np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, -1)[:, :3]).reshape(9)
+    mx = np.empty((h, w), np.float32)
+    my = np.empty((h, w), np.float32)
+    L.orbo_init_undistort_rectify_map(_p(K), _p(D), len(D), _p(R), _p(P), w, h, _p(mx), _p(my))
+    return mx, my
+
+
+def remap_prepare(mapx, mapy):
+    L = lib()
+    L.orbo_remap_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    mapx = np.ascontiguousarray(mapx, np.float32)
+    mapy = np.ascontiguousarray(mapy, np.float32)
+    h, w = mapx.shape
+    xy = np.empty((h, w, 2), np.int16)
+    fr = np.empty((h, w), np.uint16)
+    L.orbo_remap_prepare(_p(mapx), _p(mapy), w, h, _p(xy), _p(fr))
+    return xy, fr
+
+
+def remap_linear(src, mapx, mapy):
+    """cv::remap(src, dst, mapx, mapy, INTER_LINEAR), BORDER_CONSTANT 0."""
+    L = lib()
+    L.orbo_remap_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int]
+    src = _u8(src)
+    xy, fr = remap_prepare(mapx, mapy)
+    h, w = fr.shape
+    dst = np.empty((h, w), np.uint8)
+    L.orbo_remap_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(xy), _p(fr), w, h, _p(dst), w)
+    return dst

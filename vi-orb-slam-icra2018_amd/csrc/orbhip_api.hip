@@ -188,7 +188,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
-                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock};
+                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1103,6 +1103,104 @@ extern "C" int orbhip_search_by_projection(orbhip_ctx *c, const orbhip_keypoint 
     HIPCHK(c, hipMemcpyAsync(&nm, dc + 2, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (nmatches) *nmatches = nm;
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// undistortion / rectification
+// ------------------------------------------------------------------------------------------------
+static bool dist_ok(const float *K, const float *dist, int ndist)
+{
+    return K && K[0] != 0.f && K[4] != 0.f && (ndist == 0 || ((ndist == 4 || ndist == 5 || ndist == 8) && dist));
+}
+
+extern "C" int orbhip_undistort_keypoints_device(orbhip_ctx *c, const void *d_kps, const void *d_counts, int cap, int B,
+                                                 const float K[9], const float *dist, int ndist, const float *P,
+                                                 void *d_kps_un)
+{
+    if (!c || !d_kps || !d_kps_un || cap <= 0 || B <= 0 || !dist_ok(K, dist, ndist))
+        return fail(c, ORBHIP_E_ARG, "orbhip_undistort_keypoints_device: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_undistort(c->stream, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts, cap, B, K, dist, ndist, P,
+                     (orbhip_keypoint *)d_kps_un);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_undistort_keypoints(orbhip_ctx *c, const orbhip_keypoint *kps, int n, const float K[9],
+                                          const float *dist, int ndist, const float *P, orbhip_keypoint *kps_un)
+{
+    if (!c || n < 0 || (n > 0 && (!kps || !kps_un)) || !dist_ok(K, dist, ndist))
+        return fail(c, ORBHIP_E_ARG, "orbhip_undistort_keypoints: bad argument");
+    if (n == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)n * 56 + 1024))) return rc;
+    orbhip_keypoint *di = (orbhip_keypoint *)T.take((size_t)n * 28), *dout = (orbhip_keypoint *)T.take((size_t)n * 28);
+    HIPCHK(c, hipMemcpyAsync(di, kps, (size_t)n * 28, hipMemcpyHostToDevice, c->stream));
+    if ((rc = orbhip_undistort_keypoints_device(c, di, nullptr, n, 1, K, dist, ndist, P, dout))) return rc;
+    HIPCHK(c, hipMemcpyAsync(kps_un, dout, (size_t)n * 28, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_init_undistort_rectify_map(const double K[9], const double *dist, int ndist, const double R[9],
+                                                 const double P[9], int w, int h, float *map_x, float *map_y)
+{
+    if (!K || !R || !P || w <= 0 || h <= 0 || !map_x || !map_y || ndist < 0 || (ndist > 0 && !dist)) return ORBHIP_E_ARG;
+    orb_init_undistort_rectify_map(K, dist, ndist, R, P, w, h, map_x, map_y);
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_remap_set_maps(orbhip_ctx *c, const float *map_x, const float *map_y, int w, int h)
+{
+    if (!c || !map_x || !map_y || w <= 0 || h <= 0) return fail(c, ORBHIP_E_ARG, "orbhip_remap_set_maps: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_maps) HIPCHK(c, hipFree(c->d_maps));
+    c->d_maps = nullptr;
+    c->map_w = c->map_h = 0;
+    const size_t n = (size_t)w * h;
+    HIPCHK(c, hipMalloc((void **)&c->d_maps, 2 * n * sizeof(float) + 64));
+    HIPCHK(c, hipMemcpy(c->d_maps, map_x, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_maps + n, map_y, n * sizeof(float), hipMemcpyHostToDevice));
+    c->map_w = w;
+    c->map_h = h;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_remap_device(orbhip_ctx *c, const void *d_src, int B, int src_w, int src_h, int src_stride,
+                                   size_t src_frame_stride, void *d_dst, int dst_stride, size_t dst_frame_stride)
+{
+    if (!c || !d_src || !d_dst || B <= 0 || src_w <= 0 || src_h <= 0 || src_stride < src_w || src_w > 32767 || src_h > 32767)
+        return fail(c, ORBHIP_E_ARG, "orbhip_remap_device: bad argument");
+    if (!c->d_maps) return fail(c, ORBHIP_E_ARG, "orbhip_remap_device: no maps (orbhip_remap_set_maps)");
+    if (dst_stride < c->map_w) return fail(c, ORBHIP_E_ARG, "orbhip_remap_device: dst_stride smaller than the map width");
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_remap(c->stream, (const uint8_t *)d_src, B, src_w, src_h, src_stride, src_frame_stride, c->d_maps,
+                 c->d_maps + (size_t)c->map_w * c->map_h, c->map_w, c->map_h, (uint8_t *)d_dst, dst_stride, dst_frame_stride);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_remap(orbhip_ctx *c, const uint8_t *src, int src_w, int src_h, int src_stride, uint8_t *dst,
+                            int dst_stride)
+{
+    if (!c || !src || !dst || src_w <= 0 || src_h <= 0 || src_stride < src_w)
+        return fail(c, ORBHIP_E_ARG, "orbhip_remap: bad argument");
+    if (!c->d_maps) return fail(c, ORBHIP_E_ARG, "orbhip_remap: no maps (orbhip_remap_set_maps)");
+    if (dst_stride < c->map_w) return fail(c, ORBHIP_E_ARG, "orbhip_remap: dst_stride smaller than the map width");
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    const size_t sbytes = (size_t)src_stride * src_h, dpitch = align_up((size_t)c->map_w, 64), dbytes = dpitch * c->map_h;
+    if ((rc = T.reserve(sbytes + dbytes + 1024))) return rc;
+    uint8_t *ds = (uint8_t *)T.take(sbytes), *dd = (uint8_t *)T.take(dbytes);
+    HIPCHK(c, hipMemcpyAsync(ds, src, sbytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = orbhip_remap_device(c, ds, 1, src_w, src_h, src_stride, sbytes, dd, (int)dpitch, dbytes))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, dd, dpitch, c->map_w, c->map_h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return ORBHIP_OK;
 }
 

@@ -150,6 +150,10 @@ struct orbhip_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool haveStageEvents = false, haveMatchEvents = false;
 
+    // rectification maps (orbhip_remap_set_maps): mapx then mapy, map_w * map_h floats each
+    float *d_maps = nullptr;
+    int map_w = 0, map_h = 0;
+
     // vocabulary
     OrbVocabDev voc;
     void *d_vocBlock = nullptr;
@@ -259,6 +263,12 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
                                 float invH, const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries,
                                 const uint8_t *qdesc, const int32_t *nq, int capQ, int use_ratio, float nnratio,
                                 int check_ori, int th_high, int32_t *match, int32_t *nmatches, void *scratch);
+int launch_undistort(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, const float *K,
+                     const float *D, int nD, const float *P, orbhip_keypoint *out);
+int launch_remap(hipStream_t s, const uint8_t *src, int B, int sw, int sh, int sstride, size_t sframe, const float *mapx,
+                 const float *mapy, int dw, int dh, uint8_t *dst, int dstride, size_t dframe);
+void orb_init_undistort_rectify_map(const double *K, const double *D, int nD, const double *R, const double *P, int w,
+                                    int h, float *mapx, float *mapy);
 size_t stereo_scratch_bytes(int B, int cap);
 int launch_stereo(orbhip_ctx *L, orbhip_ctx *R, const orbhip_keypoint *kpsL, const uint8_t *descL, const int32_t *cntL,
                   const orbhip_keypoint *kpsR, const uint8_t *descR, const int32_t *cntR, int cap, int B, float mb,

@@ -30,6 +30,8 @@ SYMBOLS = [
     "orbhip_hamming_knn2_lists", "orbhip_search_by_bow", "orbhip_comm_unique_id",
     "orbhip_comm_init", "orbhip_bcast_blob_device", "orbhip_grid_build_device", "orbhip_grid_build",
     "orbhip_features_in_area", "orbhip_search_by_projection", "orbhip_search_by_projection_device",
+    "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
+    "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
 ]
 
 
@@ -104,6 +106,12 @@ def load():
                                               vp, ip]
     L.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, vp,
                                                      i32, i32, f32, i32, i32, vp, vp]
+    L.orbhip_undistort_keypoints.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
+    L.orbhip_undistort_keypoints_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]
+    L.orbhip_init_undistort_rectify_map.argtypes = [vp, vp, i32, vp, vp, i32, i32, vp, vp]
+    L.orbhip_remap_set_maps.argtypes = [vp, vp, vp, i32, i32]
+    L.orbhip_remap.argtypes = [vp, vp, i32, i32, i32, vp, i32]
+    L.orbhip_remap_device.argtypes = [vp, vp, i32, i32, i32, i32, C.c_size_t, vp, i32, C.c_size_t]
     L.orbhip_comm_unique_id.argtypes = [vp]
     L.orbhip_comm_init.argtypes = [vp, i32, i32, vp]
     L.orbhip_bcast_blob_device.argtypes = [vp, vp, C.c_size_t, i32]
