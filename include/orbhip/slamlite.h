@@ -83,6 +83,10 @@ public:
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
     cv::Mat mTcw;                            // 4 x 4 CV_32F
     std::vector<float> mvScaleFactors;
+    cv::Mat mK;                              // 3 x 3 CV_32F
+    cv::Mat mDistCoef;                       // 4 x 1 (or 5 / 8) CV_32F
+    void UndistortKeyPoints();               // ref: src/Frame.cc:748-778
+    void ComputeImageBounds(const cv::Mat &imLeft);   // ref: :780-808
     void AssignFeaturesToGrid();
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1,
                                           const int maxLevel = -1) const;

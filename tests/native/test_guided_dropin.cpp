@@ -29,18 +29,31 @@ static std::vector<unsigned char> slurp(const char *path)
 struct Header {
     float fx, fy, cx, cy, minX, maxX, minY, maxY, mb, mbf, thLast, thLocal, bMono;
     float TcwLast[16], TcwCur[16];
+    float D[4];
 };
 struct MpRec {
     float X, Y, Z, nObs, outlier, projX, projY, projXR, viewCos, level, inView, bad;
 };
 
-static void buildFrame(Frame &F, ORBextractor *ex, const unsigned char *pix, int w, int h, const float *Tcw)
+static void buildFrame(Frame &F, ORBextractor *ex, const unsigned char *pix, int w, int h, const float *Tcw, const Header &H,
+                       bool first)
 {
     cv::Mat im(h, w, CV_8UC1, (void *)pix);
     F.mpORBextractorLeft = ex;
+    // ref: src/Frame.cc:518-572 -- extract, undistort, (first frame) image bounds and grid constants, grid
     (*ex)(im, cv::Mat(), F.mvKeys, F.mDescriptors);
     F.N = (int)F.mvKeys.size();
-    F.mvKeysUn = F.mvKeys;                                   // no distortion (UndistortKeyPoints, :750-754)
+    F.mK = cv::Mat::zeros(3, 3, CV_32F);
+    F.mK.at<float>(0, 0) = H.fx; F.mK.at<float>(1, 1) = H.fy; F.mK.at<float>(0, 2) = H.cx; F.mK.at<float>(1, 2) = H.cy;
+    F.mK.at<float>(2, 2) = 1.0f;
+    F.mDistCoef = cv::Mat(4, 1, CV_32F);
+    for (int i = 0; i < 4; i++) F.mDistCoef.at<float>(i, 0) = H.D[i];
+    F.UndistortKeyPoints();
+    if (first) {
+        F.ComputeImageBounds(im);
+        Frame::mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(Frame::mnMaxX - Frame::mnMinX);
+        Frame::mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(Frame::mnMaxY - Frame::mnMinY);
+    }
     F.mvuRight = std::vector<float>(F.N, -1);
     F.mvpMapPoints = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));
     F.mvbOutlier = std::vector<bool>(F.N, false);
@@ -63,20 +76,20 @@ int main(int argc, char **argv)
     FILE *out = fopen(argv[6], "wb");
 
     Frame::fx = H.fx; Frame::fy = H.fy; Frame::cx = H.cx; Frame::cy = H.cy;
-    Frame::mnMinX = H.minX; Frame::mnMaxX = H.maxX; Frame::mnMinY = H.minY; Frame::mnMaxY = H.maxY;
-    Frame::mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(Frame::mnMaxX - Frame::mnMinX);
-    Frame::mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(Frame::mnMaxY - Frame::mnMinY);
 
     ORBextractor *ex = new ORBextractor(nf, 1.2f, 8, 20, 7);
     ex->SetPyramidDownload(false);
     Frame mLastFrame, mCurrentFrame;
-    buildFrame(mLastFrame, ex, raw.data(), w, h, H.TcwLast);
-    buildFrame(mCurrentFrame, ex, raw.data() + (size_t)w * h, w, h, H.TcwCur);
+    buildFrame(mLastFrame, ex, raw.data(), w, h, H.TcwLast, H, true);
+    buildFrame(mCurrentFrame, ex, raw.data() + (size_t)w * h, w, h, H.TcwCur, H, false);
     mCurrentFrame.mb = H.mb;
     mCurrentFrame.mbf = H.mbf;
 
-    // grid of the current frame, cell by cell
+    // image bounds, undistorted keypoints and grid of the current frame, cell by cell
+    const float bounds[4] = {Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY};
+    fwrite(bounds, 4, 4, out);
     fwrite(&mCurrentFrame.N, 4, 1, out);
+    fwrite(mCurrentFrame.mvKeysUn.data(), sizeof(cv::KeyPoint), mCurrentFrame.N, out);
     for (int i = 0; i < FRAME_GRID_COLS; i++)
         for (int j = 0; j < FRAME_GRID_ROWS; j++) {
             int c = (int)mCurrentFrame.mGrid[i][j].size();

@@ -184,8 +184,9 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
     rec[:, 9] = k0["octave"]                                        # mnTrackScaleLevel
     rec[:, 10] = rng.random(n0) < 0.9                               # mbTrackInView
     rec[:, 11] = rng.random(n0) < 0.03                              # isBad
-    hdr = np.concatenate([[fx, fy, cx, cy, bounds[0], bounds[1], bounds[2], bounds[3], mb, mbf, th_last, th_local, 1],
-                          Tl.ravel(), Tc.ravel()]).astype(f32)
+    dist = np.array([-0.05, 0.012, 2e-4, -3e-4], f32)              # mDistCoef: keypoints move by up to a few pixels
+    hdr = np.concatenate([[fx, fy, cx, cy, 0, 0, 0, 0, mb, mbf, th_last, th_local, 1], Tl.ravel(), Tc.ravel(),
+                          dist]).astype(f32)
     (tmp_path / "frames.raw").write_bytes(frames.tobytes())
     (tmp_path / "params.bin").write_bytes(hdr.tobytes() + rec.tobytes())
     out = tmp_path / "guided.bin"
@@ -199,8 +200,24 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
         pos += n
         return v
 
-    gp = oracle.grid_params(*bounds)
+    # Frame::ComputeImageBounds and UndistortKeyPoints (src/Frame.cc:748-808)
+    Kmat = np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], f32)
+    corners = oracle.undistort_points(np.array([[0, 0], [W, 0], [0, H], [W, H]], f32), Kmat, dist, Kmat)
+    bounds = (min(corners[0, 0], corners[2, 0]), max(corners[1, 0], corners[3, 0]), min(corners[0, 1], corners[1, 1]),
+              max(corners[2, 1], corners[3, 1]))
+    assert take(4).view(f32).tolist() == [float(b) for b in bounds]
     assert take()[0] == n1
+    from orbhip.capi import KP_DTYPE
+    kun = take(7 * n1).view(KP_DTYPE)
+    und = oracle.undistort_points(np.stack([k1["x"], k1["y"]], 1), Kmat, dist, Kmat)
+    k1u = k1.copy()
+    k1u["x"], k1u["y"] = und[:, 0], und[:, 1]
+    assert kun.tobytes() == k1u.tobytes() and np.abs(k1u["x"] - k1["x"]).max() > 0.5
+    und0 = oracle.undistort_points(np.stack([k0["x"], k0["y"]], 1), Kmat, dist, Kmat)
+    k0u = k0.copy()
+    k0u["x"], k0u["y"] = und0[:, 0], und0[:, 1]
+    k1 = k1u                                                       # everything below runs on mvKeysUn
+    gp = oracle.grid_params(*bounds)
     roff, ridx = oracle.grid_build(k1, gp)
     for c in range(64 * 48):
         cnt = take()[0]
@@ -227,7 +244,7 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
     valid = has_point & ~outlier & ~(invz < 0) & ~(u < bounds[0]) & ~(u > bounds[1]) & ~(v < bounds[2]) & ~(v > bounds[3])
     sf = (f32(1.2) ** np.arange(8)).astype(f32)
     sf = np.array(list(ex.params.mvScaleFactor)[:8], f32)
-    qB = guided.queries_for_last_frame(u, v, u - mbf * invz, k0["octave"], k0["angle"], valid, nobs > 0, th_last, sf)
+    qB = guided.queries_for_last_frame(u, v, u - mbf * invz, k0["octave"], k0u["angle"], valid, nobs > 0, th_last, sf)
     assert valid.sum() > 800 and not valid[5]
     rn, rm = oracle.search_by_projection(k1, d1, gp, qB, d0, use_ratio=False, nnratio=0.9, check_ori=True)
     n = take()[0]

@@ -1,6 +1,8 @@
-// FrameGrid.cc -- Frame::AssignFeaturesToGrid and Frame::GetFeaturesInArea (ref: src/Frame.cc:574-589,
-// :671-724) on the device grid of liborbhip (orbhip_grid_build, orbhip_features_in_area).  mGrid keeps the
+// FrameGrid.cc -- Frame::UndistortKeyPoints / ComputeImageBounds (ref: src/Frame.cc:748-808) through
+// orbhip_undistort_keypoints, and Frame::AssignFeaturesToGrid / GetFeaturesInArea (:574-589, :671-724) on the
+// device grid of liborbhip (orbhip_grid_build, orbhip_features_in_area).  mGrid keeps the
 // reference's public layout (a vector of feature indices per cell).  No CPU path: errors throw.
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 
@@ -20,6 +22,64 @@ static orbhip_ctx *frame_ctx(const Frame *F, const char *who)
     if (!F->mpORBextractorLeft || !F->mpORBextractorLeft->Context())
         throw std::runtime_error(std::string(who) + ": the frame's extractor has no device context yet");
     return F->mpORBextractorLeft->Context();
+}
+
+static void calib(const Frame *F, float K[9], std::vector<float> &D)
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) K[r * 3 + c] = F->mK.at<float>(r, c);
+    const int n = F->mDistCoef.rows * F->mDistCoef.cols;
+    D.resize(n);
+    for (int i = 0; i < n; i++) D[i] = F->mDistCoef.rows == 1 ? F->mDistCoef.at<float>(0, i) : F->mDistCoef.at<float>(i, 0);
+}
+
+void Frame::UndistortKeyPoints()
+{
+    if(mDistCoef.at<float>(0, 0)==0.0)
+    {
+        mvKeysUn=mvKeys;
+        return;
+    }
+    mvKeysUn.resize(N);
+    if (N == 0) return;
+    orbhip_ctx *ctx = frame_ctx(this, "Frame::UndistortKeyPoints");
+    float K[9];
+    std::vector<float> D;
+    calib(this, K, D);
+    // cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) on (pt.x, pt.y); the other fields are copied
+    if (orbhip_undistort_keypoints(ctx, reinterpret_cast<const orbhip_keypoint *>(mvKeys.data()), N, K, D.data(), (int)D.size(),
+                                   K, reinterpret_cast<orbhip_keypoint *>(mvKeysUn.data())) != ORBHIP_OK)
+        throw std::runtime_error(std::string("Frame::UndistortKeyPoints: ") + orbhip_last_error(ctx));
+}
+
+void Frame::ComputeImageBounds(const cv::Mat &imLeft)
+{
+    if(mDistCoef.at<float>(0, 0)!=0.0)
+    {
+        orbhip_ctx *ctx = frame_ctx(this, "Frame::ComputeImageBounds");
+        float K[9];
+        std::vector<float> D;
+        calib(this, K, D);
+        cv::KeyPoint corner[4], un[4];
+        corner[0].pt = cv::Point2f(0.0f, 0.0f);
+        corner[1].pt = cv::Point2f((float)imLeft.cols, 0.0f);
+        corner[2].pt = cv::Point2f(0.0f, (float)imLeft.rows);
+        corner[3].pt = cv::Point2f((float)imLeft.cols, (float)imLeft.rows);
+        if (orbhip_undistort_keypoints(ctx, reinterpret_cast<const orbhip_keypoint *>(corner), 4, K, D.data(), (int)D.size(), K,
+                                       reinterpret_cast<orbhip_keypoint *>(un)) != ORBHIP_OK)
+            throw std::runtime_error(std::string("Frame::ComputeImageBounds: ") + orbhip_last_error(ctx));
+        mnMinX = std::min(un[0].pt.x, un[2].pt.x);
+        mnMaxX = std::max(un[1].pt.x, un[3].pt.x);
+        mnMinY = std::min(un[0].pt.y, un[1].pt.y);
+        mnMaxY = std::max(un[2].pt.y, un[3].pt.y);
+    }
+    else
+    {
+        mnMinX = 0.0f;
+        mnMaxX = imLeft.cols;
+        mnMinY = 0.0f;
+        mnMaxY = imLeft.rows;
+    }
 }
 
 void Frame::AssignFeaturesToGrid()
