@@ -181,7 +181,20 @@ def test_hip_remap_matches_oracle(oracle):
     wy[1, :5] = [-1.0, -0.25, 96.0, 96.75, 97.0]
     wx[2, 0], wy[2, 0] = 1e9, -1e9
     r2 = rectify.Rectifier(ex, wx, wy)
-    assert np.array_equal(r2(src), oracle.remap_linear(src, wx, wy))
+    ref2 = oracle.remap_linear(src, wx, wy)
+    assert np.array_equal(r2(src), ref2)                     # rows of 131 bytes: the direct kernel
+    padded = np.zeros((97, 144), np.uint8)
+    padded[:, :131] = src
+    padded[:, 131:] = 0xEE                                    # row padding must never leak into the result
+    assert np.array_equal(r2(padded[:, :131]), ref2)         # 16-byte aligned rows: the tiled kernel, windows of
+    #                                                          ~110 x 27 source pixels, every image edge crossed
+    # a map whose tiles need more than the LDS window: the tiled kernel falls back per tile
+    wx3 = (xx * np.float32(4.5) - 100).astype(np.float32)
+    wy3 = (yy * np.float32(3.5) - 50).astype(np.float32)
+    big = np.zeros((300, 512), np.uint8)
+    big[:, :500] = rng.integers(0, 256, (300, 500), dtype=np.uint8)
+    r3 = rectify.Rectifier(ex, wx3, wy3)
+    assert np.array_equal(r3(big[:, :500]), oracle.remap_linear(np.ascontiguousarray(big[:, :500]), wx3, wy3))
     ex.close()
     d_src.free()
     d_dst.free()

@@ -106,9 +106,16 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
     return nsteps * B / dt, dt, kp, list(ms)
 
 
-def run_stereo(W, H, nfeat, B, total_pairs, mb, mbf, uniq=8):
-    """Config 3 end to end: left and right extraction on two contexts (two streams), then
-    Frame::ComputeStereoMatches on the resident pyramids."""
+EUROC_K = [458.654, 0.0, 367.215, 0.0, 457.296, 248.375, 0.0, 0.0, 1.0]             # Examples/Stereo/EuRoC.yaml LEFT.*
+EUROC_D = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]
+EUROC_R = [0.999966347530033, -0.001422739138722922, 0.008079580483432283, 0.001365741834644127, 0.9999741760894847,
+           0.007055629199258132, -0.008089410156878961, -0.007044357138835809, 0.9999424675829176]
+EUROC_P = [435.2046959714599, 0, 367.4517211914062, 0, 0, 435.2046959714599, 252.2008514404297, 0, 0, 0, 1, 0]
+
+
+def run_stereo(W, H, nfeat, B, total_pairs, mb, mbf, uniq=8, rectify=False):
+    """Config 3 end to end: (optionally cv::remap of both raw images,) left and right extraction on two
+    contexts (two streams), then Frame::ComputeStereoMatches on the resident pyramids."""
     pairs = [synth.make_stereo_pair(300 + i, W, H, disparity=10 + 3 * i) for i in range(min(uniq, B))]
     stride = (W + 15) // 16 * 16
     host = np.zeros((2, B, H, stride), np.uint8)
@@ -118,6 +125,13 @@ def run_stereo(W, H, nfeat, B, total_pairs, mb, mbf, uniq=8):
     exs = [ORBextractor(nfeat, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B) for _ in range(2)]
     cap = exs[0].cap
     i32 = dict(dtype=torch.int32, device="cuda")
+    rects = None
+    if rectify:
+        from orbhip import rectify as RC
+        mx, my = RC.initUndistortRectifyMap(EUROC_K, EUROC_D, EUROC_R, EUROC_P, W, H)
+        rects = [RC.Rectifier(e, mx, my) for e in exs]      # same maps for both eyes: timing only
+        d_raw = d_img
+        d_img = torch.empty_like(d_raw)
     d_kps = torch.empty((2, B, cap, 7), **i32)
     d_desc = torch.empty((2, B, cap, 32), dtype=torch.uint8, device="cuda")
     d_cnt = torch.zeros((2, B), **i32)
@@ -128,6 +142,8 @@ def run_stereo(W, H, nfeat, B, total_pairs, mb, mbf, uniq=8):
 
     def step():
         for s in range(2):
+            if rects:
+                rects[s].remap_device(d_raw[s].data_ptr(), B, W, H, stride, H * stride, d_img[s].data_ptr(), stride, H * stride)
             exs[s].extract_batch_device(d_img[s].data_ptr(), B, W, H, stride, H * stride, d_kps[s].data_ptr(),
                                         d_desc[s].data_ptr(), cap, d_cnt[s].data_ptr())
         assert L.orbhip_stereo_match_device(exs[0].handle, exs[1].handle, d_kps[0].data_ptr(), d_desc[0].data_ptr(),
@@ -206,6 +222,10 @@ def main():
         fps, dt, kp, ms = run_extract(640, 480, 1000, 512, 4096, "proj", seed=1)
         print("| 1b | proj | %.0f frames/s | %.1f matches per frame |" % (fps, kp))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "rectify":         # profiling aid
+        pps, st, good = run_stereo(752, 480, 1200, 128, 1024, 0.11, 47.9, rectify=True)
+        print("| 3c | rectify+stereo | %.0f pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "stereo":          # profiling aid: the stereo row only
         pps, st, good = run_stereo(1241, 376, 2000, 128, 1024, 0.53716, 386.1448)
         print("| 3b | stereo | %.0f pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
@@ -218,6 +238,8 @@ def main():
     print("| 3: KITTI 00 stereo | 1241x376, 2000 feat, L+R images as 2 frames per pair, extract + transform + SearchByBoW | %.0f images/s = %.0f stereo pairs/s | %.1f kp/image |" % (fps, fps / 2, kp))
     pps, st, good = run_stereo(1241, 376, 2000, 128, 1024, 0.53716, 386.1448)
     print("| 3b: KITTI 00 stereo frame | 1241x376 pairs, 2000 feat: extract L + extract R (two contexts) + ComputeStereoMatches on the resident pyramids | %.0f stereo pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
+    pps, st, good = run_stereo(752, 480, 1200, 128, 1024, 0.11, 47.9, rectify=True)
+    print("| 3c: EuRoC stereo frame from raw images | 752x480 pairs, 1200 feat (Examples/Stereo/EuRoC.yaml): cv::remap L + R, extract L + R, ComputeStereoMatches | %.0f stereo pairs/s | %.0f depth points per pair |" % (pps, good))
     tot = 0.0
     frames = 0
     for i, n in enumerate([2912, 1710, 2280, 3040]):

@@ -8,9 +8,12 @@
 //                 Examples/Stereo/stereo_euroc.cc:136-137), CV_32FC1 maps, BORDER_CONSTANT 0: the map is taken to
 //                 fixed point with 5 fractional bits (cvRound(m * 32), round half to even), the four taps are
 //                 weighted with a*b*32 (a, b in 1/32) and the sum is brought back with (s + 2^14) >> 15 -- all
-//                 integers.  One thread per 4 destination pixels (dword store); the two taps of a row come
-//                 from one 16-bit load.  The float maps are shared by all frames of a batch (2 x 4 bytes per
-//                 pixel, L2-resident: 2.9 MB at 752x480).  Bound: HBM (1 byte read + 1 byte written per pixel).
+//                 integers.  One thread per 4 destination pixels (dword store) of up to 4 frames, so the float
+//                 maps (2 x 4 bytes per pixel, shared by all frames of a batch) are read once per 4 frames; when
+//                 the taps are neighbours (any rectification map) the eight taps of a source row come from one
+//                 8-byte load.  Bound: HBM (1 byte read + 1 byte written per pixel).  (A variant that staged a
+//                 tile's source window in LDS was measured 1.8x slower: two barriers and a min/max reduction
+//                 per tile cost more than the gathers they save.)
 // The maps themselves (cv::initUndistortRectifyMap, stereo_euroc.cc:96-98) are a once-per-run table built on the
 // host in double (orb_init_undistort_rectify_map), like the resize tap tables.
 #include "orbhip_internal.h"
@@ -86,29 +89,97 @@ __device__ __forceinline__ int remap_px(const uint8_t *__restrict__ S, int sw, i
     return (s * 32 + (1 << 14)) >> 15;
 }
 
+// One thread produces 4 horizontally adjacent destination pixels (one dword store) of up to RM_FRAMES frames:
+// the map entries (8 bytes per pixel -- four times the image bytes) are read and taken to fixed point once and
+// reused for every frame of the group.  For a rectification map the four source positions are neighbours too:
+// when the four x lie within 7 columns of each other on one source row pair, the eight taps of each row come
+// from ONE unaligned 8-byte load (2 loads per thread and frame instead of 8); otherwise every pixel fetches its
+// own taps (remap_px).
+#ifndef RM_FRAMES
+#define RM_FRAMES 4
+#endif
+
 __global__ __launch_bounds__(256) void k_remap(const uint8_t *__restrict__ src, int sw, int sh, int sstride,
                                                unsigned long long sframe, const float *__restrict__ mapx,
                                                const float *__restrict__ mapy, int dw, int dh,
-                                               uint8_t *__restrict__ dst, int dstride, unsigned long long dframe)
+                                               uint8_t *__restrict__ dst, int dstride, unsigned long long dframe, int B)
 {
     const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int frame = blockIdx.z;
+    const int f0 = blockIdx.z * RM_FRAMES, f1 = min(f0 + RM_FRAMES, B);
     if (x4 >= dw || y >= dh) return;
-    const uint8_t *S = src + (size_t)frame * sframe;
-    uint8_t *D = dst + (size_t)frame * dframe + (size_t)y * dstride + x4;
     const size_t m = (size_t)y * dw + x4;
-    if (x4 + 3 < dw && (dw & 3) == 0) {
-        const float4 mx = *reinterpret_cast<const float4 *>(mapx + m), my = *reinterpret_cast<const float4 *>(mapy + m);
-        const uint32_t v = (uint32_t)remap_px(S, sw, sh, sstride, mx.x, my.x) |
-                           ((uint32_t)remap_px(S, sw, sh, sstride, mx.y, my.y) << 8) |
-                           ((uint32_t)remap_px(S, sw, sh, sstride, mx.z, my.z) << 16) |
-                           ((uint32_t)remap_px(S, sw, sh, sstride, mx.w, my.w) << 24);
-        if ((dstride & 3) == 0)
-            *reinterpret_cast<uint32_t *>(D) = v;
+    const size_t doff = (size_t)y * dstride + x4;
+    if (x4 + 3 >= dw || (dw & 3) != 0) {            // ragged right edge / unaligned map rows
+        for (int f = f0; f < f1; f++)
+            for (int k = 0; k < 4 && x4 + k < dw; k++)
+                dst[(size_t)f * dframe + doff + k] =
+                    (uint8_t)remap_px(src + (size_t)f * sframe, sw, sh, sstride, mapx[m + k], mapy[m + k]);
+        return;
+    }
+    const float4 mx = *reinterpret_cast<const float4 *>(mapx + m), my = *reinterpret_cast<const float4 *>(mapy + m);
+    const float fxs[4] = {mx.x, mx.y, mx.z, mx.w}, fys[4] = {my.x, my.y, my.z, my.w};
+    int isx[4], isy[4], sx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        isx[k] = __float2int_rn(__fmul_rn(fxs[k], 32.0f));
+        isy[k] = __float2int_rn(__fmul_rn(fys[k], 32.0f));
+        sx[k] = isx[k] >> 5;
+    }
+    const int sy = isy[0] >> 5;
+    const int lo = min(min(sx[0], sx[1]), min(sx[2], sx[3])), hi = max(max(sx[0], sx[1]), max(sx[2], sx[3]));
+    const bool together = (isy[1] >> 5) == sy && (isy[2] >> 5) == sy && (isy[3] >> 5) == sy && hi - lo <= 6 && lo >= 0 &&
+                          lo + 8 <= sw && sy >= 0 && sy + 1 < sh;
+    const bool dword_store = ((dstride | (int)(dframe & 3)) & 3) == 0 && (((size_t)dst) & 3) == 0;
+    const size_t soff = together ? (size_t)sy * sstride + lo : 0;
+    if (together) {
+        // all loads of the group first (independent, in flight together), then the arithmetic
+        unsigned long long r0[RM_FRAMES], r1[RM_FRAMES];
+#pragma unroll
+        for (int j = 0; j < RM_FRAMES; j++) {
+            const int f = min(f0 + j, f1 - 1);
+            const uint8_t *S = src + (size_t)f * sframe + soff;
+            __builtin_memcpy(&r0[j], S, 8);
+            __builtin_memcpy(&r1[j], S + sstride, 8);
+        }
+        int wgt[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int fx = isx[k] & 31, fy = isy[k] & 31, ax = 32 - fx, ay = 32 - fy;
+            wgt[k][0] = ax * ay;
+            wgt[k][1] = fx * ay;
+            wgt[k][2] = ax * fy;
+            wgt[k][3] = fx * fy;
+        }
+#pragma unroll
+        for (int j = 0; j < RM_FRAMES; j++) {
+            if (f0 + j >= f1) break;
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sh8 = (sx[k] - lo) * 8;
+                const int p00 = (int)(r0[j] >> sh8) & 255, p01 = (int)(r0[j] >> (sh8 + 8)) & 255;
+                const int p10 = (int)(r1[j] >> sh8) & 255, p11 = (int)(r1[j] >> (sh8 + 8)) & 255;
+                const int acc = p00 * wgt[k][0] + p01 * wgt[k][1] + p10 * wgt[k][2] + p11 * wgt[k][3];
+                out |= (uint32_t)((acc * 32 + (1 << 14)) >> 15) << (8 * k);
+            }
+            uint8_t *D = dst + (size_t)(f0 + j) * dframe + doff;
+            if (dword_store)
+                *reinterpret_cast<uint32_t *>(D) = out;
+            else
+                for (int k = 0; k < 4; k++) D[k] = (uint8_t)(out >> (8 * k));
+        }
+        return;
+    }
+    for (int f = f0; f < f1; f++) {
+        const uint8_t *S = src + (size_t)f * sframe;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) out |= (uint32_t)remap_px(S, sw, sh, sstride, fxs[k], fys[k]) << (8 * k);
+        uint8_t *D = dst + (size_t)f * dframe + doff;
+        if (dword_store)
+            *reinterpret_cast<uint32_t *>(D) = out;
         else
-            for (int k = 0; k < 4; k++) D[k] = (uint8_t)(v >> (8 * k));
-    } else {
-        for (int k = 0; k < 4 && x4 + k < dw; k++) D[k] = (uint8_t)remap_px(S, sw, sh, sstride, mapx[m + k], mapy[m + k]);
+            for (int k = 0; k < 4; k++) D[k] = (uint8_t)(out >> (8 * k));
     }
 }
 
@@ -138,8 +209,9 @@ int launch_undistort(hipStream_t s, const orbhip_keypoint *kps, const int32_t *c
 int launch_remap(hipStream_t s, const uint8_t *src, int B, int sw, int sh, int sstride, size_t sframe, const float *mapx,
                  const float *mapy, int dw, int dh, uint8_t *dst, int dstride, size_t dframe)
 {
-    hipLaunchKernelGGL(k_remap, dim3((dw + 255) / 256, (dh + 3) / 4, B), dim3(256, 1, 1), 0, s, src, sw, sh, sstride,
-                       (unsigned long long)sframe, mapx, mapy, dw, dh, dst, dstride, (unsigned long long)dframe);
+    hipLaunchKernelGGL(k_remap, dim3((dw + 255) / 256, (dh + 3) / 4, (B + RM_FRAMES - 1) / RM_FRAMES), dim3(256, 1, 1), 0, s, src,
+                       sw, sh, sstride, (unsigned long long)sframe, mapx, mapy, dw, dh, dst, dstride,
+                       (unsigned long long)dframe, B);
     return ORBHIP_OK;
 }
 

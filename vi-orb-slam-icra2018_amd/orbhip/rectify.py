@@ -73,7 +73,9 @@ class Rectifier:
         check(self._L.orbhip_remap_set_maps(ctx.handle, _p(mx), _p(my), self.w, self.h), ctx.handle, "orbhip_remap_set_maps")
 
     def __call__(self, image):
-        img = np.ascontiguousarray(image, np.uint8)
+        img = np.asarray(image)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1 or img.strides[0] < img.shape[1]:
+            img = np.ascontiguousarray(image, np.uint8)          # row-padded views are passed as they are
         out = np.empty((self.h, self.w), np.uint8)
         check(self._L.orbhip_remap(self._ctx.handle, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(out), self.w),
               self._ctx.handle, "orbhip_remap")
