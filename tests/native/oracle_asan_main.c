@@ -38,6 +38,51 @@ int main(void)
     for (int i = 0; i < n; i++) { idx[i] = i; valid[i] = 1; ang[i] = k[i].angle; }
     int nm = orbo_search_by_bow(d, n, valid, ang, node, off, idx, 2, d, n, NULL, ang, node, off, idx, 2, 50, 0, 0.9f, 1, m12, m21);
     if (nm <= 0) return 4;
+    /* stereo on the extractor's own pyramid (left == right), grid + guided search,
+     * undistortion and rectification */
+    {
+        const uint8_t *pyr[6];
+        int lw[6], lh[6];
+        const orbo_params *P = orbo_get_params(e);
+        for (int l = 0; l < 6; l++) {
+            int st;
+            pyr[l] = orbo_pyramid_level(e, l, &lw[l], &lh[l], &st);
+            if (st != lw[l]) return 6;
+        }
+        float *ur = (float *)malloc(4 * (size_t)n), *dz = (float *)malloc(4 * (size_t)n);
+        int ns = orbo_stereo_matches(k, d, n, k, d, n, pyr, pyr, lw, lh, P->mvScaleFactor, P->mvInvScaleFactor, 0.1f, 30.f, ur, dz);
+        if (ns <= 0) return 7;
+        const float invW = 64.f / (float)W, invH = 48.f / (float)H;
+        int32_t *coff = (int32_t *)malloc(4 * (64 * 48 + 1)), *cidx = (int32_t *)malloc(4 * (size_t)n), *pm = (int32_t *)malloc(4 * (size_t)n);
+        orbo_grid_build(k, n, 0.f, 0.f, invW, invH, coff, cidx);
+        orbo_proj_query *q = (orbo_proj_query *)calloc((size_t)n, sizeof(orbo_proj_query));
+        for (int i = 0; i < n; i++) {
+            q[i].u = k[i].x + 1.5f; q[i].v = k[i].y - 1.f; q[i].radius = 400.f * (float)(i % 3 == 0) + 12.f;
+            q[i].min_level = k[i].octave - 1; q[i].max_level = k[i].octave + 1; q[i].angle = k[i].angle;
+            q[i].flags = ORBO_Q_ACTIVE | (i % 4 ? ORBO_Q_OBSERVED : 0);
+        }
+        q[0].u = -1e6f; q[1].v = 1e6f;
+        int np1 = orbo_search_by_projection(k, d, n, ur, NULL, 0.f, 0.f, invW, invH, q, d, n, 0, 0.9f, 1, 100, pm);
+        int np2 = orbo_search_by_projection(k, d, n, NULL, valid, 0.f, 0.f, invW, invH, q, d, n, 1, 0.8f, 0, 100, pm);
+        if (np1 <= 0 || np2 != 0) return 8;                 /* every feature occupied in the second run */
+        double K[9] = {300, 0, 200, 0, 300, 150, 0, 0, 1}, Dd[5] = {-0.2, 0.05, 1e-4, -1e-4, 0.0};
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Pm[9] = {280, 0, 205, 0, 280, 148, 0, 0, 1};
+        float *mx = (float *)malloc(4 * (size_t)W * H), *my = (float *)malloc(4 * (size_t)W * H);
+        orbo_init_undistort_rectify_map(K, Dd, 5, R, Pm, W, H, mx, my);
+        mx[5] = -40000.f; my[6] = 1e9f; mx[7] = (float)W - 0.5f;  /* off-image and edge taps */
+        int16_t *xy = (int16_t *)malloc(4 * (size_t)W * H);
+        uint16_t *fr = (uint16_t *)malloc(2 * (size_t)W * H);
+        unsigned char *rect = (unsigned char *)malloc((size_t)W * H);
+        orbo_remap_prepare(mx, my, W, H, xy, fr);
+        orbo_remap_linear_u8(img, W, H, W, xy, fr, W, H, rect, W);
+        float Kf[9] = {300, 0, 200, 0, 300, 150, 0, 0, 1}, Df[4] = {-0.2f, 0.05f, 1e-4f, -1e-4f};
+        float *pin = (float *)malloc(8 * (size_t)n), *pout = (float *)malloc(8 * (size_t)n);
+        for (int i = 0; i < n; i++) { pin[2 * i] = k[i].x; pin[2 * i + 1] = k[i].y; }
+        orbo_undistort_points(pin, n, Kf, Df, 4, Kf, pout);
+        orbo_undistort_points(pin, n, Kf, NULL, 0, NULL, pout);
+        free(ur); free(dz); free(coff); free(cidx); free(pm); free(q); free(mx); free(my); free(xy); free(fr); free(rect);
+        free(pin); free(pout);
+    }
     /* tiny image: must be rejected, not crash */
     if (orbo_extract(e, img, 60, 60, W, k, d, cap) >= 0) return 5;
     orbo_destroy(e);

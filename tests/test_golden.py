@@ -19,6 +19,8 @@ def _fv(node):
 
 def test_golden_files_present():
     assert len(EXTRACT) == 3 and os.path.exists(os.path.join(GOLD, "matching_q250_db600.npz"))
+    for name in ("vocab_k5_L3.npz", "stereo_376x241_f400_l6.npz", "guided_376x241.npz", "rectify_376x241.npz"):
+        assert os.path.exists(os.path.join(GOLD, name)), name
 
 
 @pytest.mark.parametrize("path", EXTRACT, ids=[os.path.basename(p) for p in EXTRACT])
@@ -77,3 +79,77 @@ def test_hip_reproduces_golden_matching():
     n, m12, m21 = m2.SearchByBoW(g["q"], g["valid1"], g["angle1"], fv1, g["db"], g["valid2"], g["angle2"], fv2, kf_kf=True)
     assert n == int(g["bow_kf_kf_n"]) and np.array_equal(m12, g["bow_kf_kf_m12"]) and np.array_equal(m21, g["bow_kf_kf_m21"])
     ex.close()
+
+
+# ---- vocabulary, stereo, guided search, undistortion / rectification ----
+def _g(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def test_oracle_reproduces_golden_next_rows(oracle):
+    g = _g("vocab_k5_L3.npz")
+    V = oracle.Vocabulary(g["blob"].tobytes())
+    w, wt, nid = V.transform(g["desc"], 1)
+    assert np.array_equal(w, g["word"]) and np.array_equal(wt, g["weight"]) and np.array_equal(nid, g["node"])
+    bw, bv = V.bow(w, wt)
+    assert np.array_equal(bw, g["bow_word"]) and np.array_equal(bv, g["bow_value"])
+    g = _g("stereo_376x241_f400_l6.npz")
+    exL, exR = oracle.Extractor(400, 1.2, 6), oracle.Extractor(400, 1.2, 6)
+    kL, dL = exL(g["left"])
+    kR, dR = exR(g["right"])
+    u, z, n = oracle.stereo_matches(exL, kL, dL, exR, kR, dR, g["mb_mbf"][0], g["mb_mbf"][1])
+    assert n == int(g["n_before_cut"]) and u.tobytes() == g["u_right"].tobytes() and z.tobytes() == g["depth"].tobytes()
+    g = _g("guided_376x241.npz")
+    gp = tuple(g["grid"])
+    off, idx = oracle.grid_build(g["kps"], gp)
+    assert np.array_equal(off, g["cell_off"]) and np.array_equal(idx, g["cell_idx"])
+    n, m = oracle.search_by_projection(g["kps"], g["desc"], gp, g["queries"], g["qdesc"], occupied=g["occupied"],
+                                       use_ratio=False, nnratio=0.9, check_ori=True)
+    assert n == int(g["n_last"]) and np.array_equal(m, g["match_last"])
+    n, m = oracle.search_by_projection(g["kps"], g["desc"], gp, g["queries_ratio"], g["qdesc"], occupied=g["occupied"],
+                                       use_ratio=True, nnratio=0.8, check_ori=False)
+    assert n == int(g["n_ratio"]) and np.array_equal(m, g["match_ratio"])
+    g = _g("rectify_376x241.npz")
+    mx, my = oracle.init_undistort_rectify_map(g["K"], g["D"], g["R"], g["P"], 376, 241)
+    assert float(mx.astype(np.float64).sum()) == float(g["map_x_sum"]) and np.array_equal(mx[120], g["map_x_row"])
+    assert float(my.astype(np.float64).sum()) == float(g["map_y_sum"]) and np.array_equal(my[:, 188], g["map_y_col"])
+    assert np.array_equal(oracle.remap_linear(g["image"], mx, my), g["rectified"])
+    assert oracle.undistort_points(g["points"], g["K"], g["D"][:4], g["K"]).tobytes() == g["undistorted"].tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_next_rows():
+    from orbhip import guided, rectify
+    from orbhip.extractor import ComputeStereoMatches, ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    ex = ORBextractor(400, 1.2, 6, max_w=376, max_h=241)
+    exR = ORBextractor(400, 1.2, 6, max_w=376, max_h=241)
+    g = _g("vocab_k5_L3.npz")
+    voc = ORBVocabulary(ex)
+    voc.loadFromBinaryBlob(g["blob"].tobytes())
+    w, wt, nid = voc.transform_raw(g["desc"], 1)
+    assert np.array_equal(w, g["word"]) and np.array_equal(wt, g["weight"]) and np.array_equal(nid, g["node"])
+    (bw, bv), _ = voc.transform(g["desc"], 1)
+    assert np.array_equal(bw, g["bow_word"]) and np.array_equal(bv, g["bow_value"])
+    g = _g("stereo_376x241_f400_l6.npz")
+    kL, dL = ex(g["left"])
+    kR, dR = exR(g["right"])
+    u, z, n = ComputeStereoMatches(ex, kL, dL, exR, kR, dR, float(g["mb_mbf"][0]), float(g["mb_mbf"][1]))
+    assert n == int(g["n_before_cut"]) and u.tobytes() == g["u_right"].tobytes() and z.tobytes() == g["depth"].tobytes()
+    g = _g("guided_376x241.npz")
+    gp = tuple(g["grid"])
+    off, idx = guided.AssignFeaturesToGrid(ex, g["kps"], gp)
+    assert np.array_equal(off, g["cell_off"]) and np.array_equal(idx, g["cell_idx"])
+    n, m = guided.SearchByProjection(ex, g["kps"], g["desc"], gp, g["queries"], g["qdesc"], occupied=g["occupied"],
+                                     use_ratio=False, nnratio=0.9, check_ori=True)
+    assert n == int(g["n_last"]) and np.array_equal(m, g["match_last"])
+    n, m = guided.SearchByProjection(ex, g["kps"], g["desc"], gp, g["queries_ratio"], g["qdesc"], occupied=g["occupied"],
+                                     use_ratio=True, nnratio=0.8, check_ori=False)
+    assert n == int(g["n_ratio"]) and np.array_equal(m, g["match_ratio"])
+    g = _g("rectify_376x241.npz")
+    mx, my = rectify.initUndistortRectifyMap(g["K"], g["D"], g["R"], g["P"], 376, 241)
+    assert float(mx.astype(np.float64).sum()) == float(g["map_x_sum"]) and np.array_equal(mx[120], g["map_x_row"])
+    assert np.array_equal(rectify.Rectifier(ex, mx, my)(g["image"]), g["rectified"])
+    assert rectify.undistort_points(ex, g["points"], g["K"], g["D"][:4], g["K"]).tobytes() == g["undistorted"].tobytes()
+    ex.close()
+    exR.close()

@@ -69,6 +69,59 @@ def main():
                         bow_kf_f_n=np.int32(r0[0]), bow_kf_f_m12=r0[1], bow_kf_f_m21=r0[2],
                         bow_kf_kf_n=np.int32(r1[0]), bow_kf_kf_m12=r1[1], bow_kf_kf_m21=r1[2])
     print("matching", r0[0], r1[0])
+    gen_next_rows()
+
+
+def gen_next_rows():
+    """vocabulary transform, stereo matching, guided search, undistortion / rectification."""
+    from orbhip import distributed as D, guided
+    # row 1: vocabulary (small tree: the blob itself is the fixture)
+    blob = D.make_synthetic_vocabulary(201, k=5, L=3)
+    desc = synth.make_descriptor_db(202, 400)
+    V = oracle.Vocabulary(blob)
+    w, wt, nid = V.transform(desc, 1)
+    bw, bv = V.bow(w, wt)
+    np.savez_compressed(os.path.join(OUT, "vocab_k5_L3.npz"), blob=np.frombuffer(blob, np.uint8), desc=desc, word=w, weight=wt,
+                        node=nid, bow_word=bw, bow_value=bv)
+    # row 2: stereo
+    L, R = synth.make_stereo_pair(203, 376, 241, disparity=14)
+    exL, exR = oracle.Extractor(400, 1.2, 6), oracle.Extractor(400, 1.2, 6)
+    kL, dL = exL(L)
+    kR, dR = exR(R)
+    u, z, n = oracle.stereo_matches(exL, kL, dL, exR, kR, dR, 0.12, 30.0)
+    np.savez_compressed(os.path.join(OUT, "stereo_376x241_f400_l6.npz"), left=L, right=R, mb_mbf=np.array([0.12, 30.0], np.float32),
+                        u_right=u, depth=z, n_before_cut=np.int32(n))
+    print("stereo", n, int((u >= 0).sum()))
+    # row 3: grid + guided search on those left keypoints, queries from the right ones
+    gp = oracle.grid_params(0, 376, 0, 241)
+    off, idx = oracle.grid_build(kL, gp)
+    sf = np.array(list(exL.params.mvScaleFactor)[:6], np.float32)
+    rng = np.random.default_rng(204)
+    q = guided.queries_for_last_frame(kR["x"] + np.float32(14), kR["y"], kR["x"], kR["octave"], kR["angle"],
+                                      rng.random(len(kR)) < 0.9, rng.random(len(kR)) < 0.7, 10, sf)
+    occ = (rng.random(len(kL)) < 0.1).astype(np.uint8)
+    nB, mB = oracle.search_by_projection(kL, dL, gp, q, dR, occupied=occ, use_ratio=False, nnratio=0.9, check_ori=True)
+    q2 = q.copy()
+    q2["min_level"], q2["max_level"] = kR["octave"] - 1, kR["octave"]
+    nA, mA = oracle.search_by_projection(kL, dL, gp, q2, dR, occupied=occ, use_ratio=True, nnratio=0.8, check_ori=False)
+    np.savez_compressed(os.path.join(OUT, "guided_376x241.npz"), kps=kL, desc=dL, grid=np.array(gp, np.float32), cell_off=off,
+                        cell_idx=idx, queries=q, queries_ratio=q2, qdesc=dR, occupied=occ, n_last=np.int32(nB), match_last=mB,
+                        n_ratio=np.int32(nA), match_ratio=mA)
+    print("guided", nB, nA)
+    # row 4: undistortion + rectification (small rig derived from Examples/Stereo/EuRoC.yaml LEFT.*, halved)
+    K = np.array([229.327, 0, 183.6075, 0, 228.648, 124.1875, 0, 0, 1.0])
+    Dc = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0])
+    Rm = np.array([0.999966347530033, -0.001422739138722922, 0.008079580483432283, 0.001365741834644127, 0.9999741760894847,
+                   0.007055629199258132, -0.008089410156878961, -0.007044357138835809, 0.9999424675829176])
+    P = np.array([217.60234798573, 0, 183.7258605957, 0, 217.60234798573, 126.10042572021, 0, 0, 1.0])
+    mx, my = oracle.init_undistort_rectify_map(K, Dc, Rm, P, 376, 241)
+    rect = oracle.remap_linear(L, mx, my)
+    un = oracle.undistort_points(np.stack([kL["x"], kL["y"]], 1), K, Dc[:4], K)
+    np.savez_compressed(os.path.join(OUT, "rectify_376x241.npz"), image=L, K=K, D=Dc, R=Rm, P=P,
+                        map_x_sum=np.float64(mx.astype(np.float64).sum()), map_y_sum=np.float64(my.astype(np.float64).sum()),
+                        map_x_row=mx[120], map_y_col=my[:, 188], rectified=rect, points=np.stack([kL["x"], kL["y"]], 1),
+                        undistorted=un)
+    print("rectify", float(rect.mean()))
 
 
 if __name__ == "__main__":

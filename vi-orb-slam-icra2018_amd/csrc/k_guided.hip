@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_proj_cands(const orbhip_keypoint *__res
                 }
                 if (count < keff) {
                     const int d = hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]);
-                    T[count] = (uint32_t)d | ((uint32_t)oct << 9) | ((uint32_t)idx << 13);
+                    T[count] = (uint32_t)d | (((uint32_t)oct & 15u) << 9) | ((uint32_t)idx << 13);
                 }
                 count++;
             });

@@ -893,9 +893,9 @@ extern "C" int orbhip_stereo_match_device(orbhip_ctx *L, orbhip_ctx *R, const vo
         !d_uRight || !d_depth || !d_nmatch || !(mb > 0.f) || !(mbf > 0.f))
         return fail(L, ORBHIP_E_ARG, "orbhip_stereo_match_device: bad argument");
     if (!L->last_lvl0 || !R->last_lvl0 || L->cur_w != R->cur_w || L->cur_h != R->cur_h || L->nlevels != R->nlevels ||
-        B > L->last_B || B > R->last_B || L->device != R->device || L->cur_h > 4095)
+        B > L->last_B || B > R->last_B || L->device != R->device || L->cur_h > 4095 || cap > 65535)
         return fail(L, ORBHIP_E_ARG, "orbhip_stereo_match_device: both contexts must have just extracted images of the "
-                                     "same size (at most 4095 rows) on the same device");
+                                     "same size (at most 4095 rows, at most 65535 keypoints per image) on the same device");
     HIPCHK(L, hipSetDevice(L->device));
     int rc;
     if ((rc = match_scratch(L, stereo_scratch_bytes(B, cap)))) return rc;
