@@ -88,8 +88,8 @@ def test_hip_vocab_transform_matches_oracle(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("th_mode", [0, 1])
-def test_hip_batched_search_by_bow_matches_oracle(oracle, th_mode):
+@pytest.mark.parametrize("th_mode,k,Lv,levelsup", [(0, 10, 3, 1), (1, 10, 3, 1), (0, 3, 3, 1), (1, 4, 4, 2), (0, 6, 3, 0), (0, 3, 4, 4)])
+def test_hip_batched_search_by_bow_matches_oracle(oracle, th_mode, k, Lv, levelsup):
     """extract_batch_device -> vocab_transform_device -> search_by_bow_seq_device, all resident on the
     device, against extractor + vocabulary + SearchByBoW of the oracle, frame pair by frame pair."""
     import ctypes as C
@@ -100,7 +100,9 @@ def test_hip_batched_search_by_bow_matches_oracle(oracle, th_mode):
     from orbhip.vocabulary import ORBVocabulary
     B, W, H = 4, 640, 480
     frames = synth.make_frames(70, W, H, B)
-    blob = D.make_synthetic_vocabulary(71, k=10, L=3)           # level L - 1 = 2 -> up to 100 nodes
+    # node sets from one node holding everything (levelsup >= L) over a few large nodes to ~200 small ones: the
+    # matcher treats large and small nodes differently (whole wave / 16-lane group), in cost order
+    blob = D.make_synthetic_vocabulary(71, k=k, L=Lv)
     ex = ORBextractor(1000, max_w=W, max_h=H, max_batch=B)
     ORBVocabulary(ex).loadFromBinaryBlob(blob)
     cap = ex.cap
@@ -113,7 +115,7 @@ def test_hip_batched_search_by_bow_matches_oracle(oracle, th_mode):
     d_valid = hiprt.DevBuf.from_numpy(valid)
     L = ex._L
     ex.extract_batch_device(d_img.ptr, B, W, H, W, H * W, d_kps.ptr, d_desc.ptr, cap, d_cnt.ptr)
-    check(L.orbhip_vocab_transform_device(ex.handle, d_desc.ptr, B * cap, 1, d_word.ptr, d_wt.ptr, d_node.ptr), ex.handle)
+    check(L.orbhip_vocab_transform_device(ex.handle, d_desc.ptr, B * cap, levelsup, d_word.ptr, d_wt.ptr, d_node.ptr), ex.handle)
     for check_ori in (1, 0):
         check(L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.ptr, d_kps.ptr, d_cnt.ptr, d_node.ptr, d_wt.ptr,
                                                 d_valid.ptr, cap, B, 1, th_mode, C.c_float(0.7), check_ori, d_m12.ptr,
@@ -128,7 +130,7 @@ def test_hip_batched_search_by_bow_matches_oracle(oracle, th_mode):
         feats = []
         for b in range(B):
             k, d = refx(frames[b])
-            w, wt, nid = refv.transform(d, 1)
+            w, wt, nid = refv.transform(d, levelsup)
             feats.append((k, d, oracle.feature_vector(nid, wt)))
             assert cnt[b] == len(k)
         assert nm[0] == 0 and (m12[0] == -1).all() and (m21[0] == -1).all()

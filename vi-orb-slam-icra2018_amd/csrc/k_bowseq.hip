@@ -1,16 +1,19 @@
 // k_bowseq.hip -- batched ORBmatcher::SearchByBoW for a frame sequence that lives on the device
 // (ref: src/ORBmatcher.cc:159-288 (KeyFrame, Frame) and :522-655 (KeyFrame, KeyFrame); called per
-// frame by Tracking::TrackReferenceKeyFrame src/Tracking.cc:1881-1885).  One 256-thread workgroup
-// per frame pair (side 1 = frame b - lag acting as the key frame, side 2 = frame b):
-//   1. both FeatureVectors are built in LDS: a bitonic sort of 64-bit keys (node id << 32 | feature
-//      index) groups the features by vocabulary node with ascending feature index inside a node --
-//      the canonical FeatureVector order; stopped features (weight <= 0,
+// frame by Tracking::TrackReferenceKeyFrame src/Tracking.cc:1881-1885).  One 1024-thread workgroup
+// per frame pair (side 1 = frame b - lag acting as the key frame, side 2 = frame b), one workgroup per CU:
+//   0. both descriptor sets (2 x 33 KB at 1000 features) and the validity bitmaps are staged in LDS: the
+//      matching below is a chain of dependent reads, and an LDS round trip is ~20x shorter than one to L2;
+//   1. both FeatureVectors are built in LDS: one bitonic sort pass over 64-bit keys (node id << 32 | feature
+//      index) of both sides groups the features by vocabulary node with ascending feature index inside a
+//      node -- the canonical FeatureVector order; stopped features (weight <= 0,
 //      TemplatedVocabulary.h:1334) sort to the end and are ignored;
 //   2. every node present on both sides is a work item (the reference's merge walk, :180-264);
-//   3. a wave takes a work item: side-1 features are visited serially (the greedy claiming of the
-//      reference is order dependent), the 64 lanes scan the node's unclaimed side-2 features and
-//      reduce (best, position, second) with the lowest position winning ties, then the acceptance test
-//      best <= / < TH and best < ratio * second (:228-230, :598-600);
+//   3. items are taken in cost order, largest first: side-1 features are visited serially (the greedy claiming
+//      of the reference is order dependent); the lanes of a wave -- or, for small nodes, of one of its four
+//      16-lane DPP rows -- scan the node's unclaimed side-2 features and reduce (best, position, second) with
+//      the lowest position winning ties, then the acceptance test best <= / < TH and best < ratio * second
+//      (:228-230, :598-600);
 //   4. rotation histogram of 30 bins, ComputeThreeMaxima (:1629-1670) and removal of the matches
 //      outside the three dominant bins (:267-285), all in the workgroup.
 // Integer/bitwise path (XOR + popcount); no MFMA.
@@ -22,7 +25,7 @@
 
 static int bs_threads()
 {
-    static const int n = getenv("ORBHIP_BOW_THREADS") ? atoi(getenv("ORBHIP_BOW_THREADS")) : 512;
+    static const int n = getenv("ORBHIP_BOW_THREADS") ? atoi(getenv("ORBHIP_BOW_THREADS")) : 1024;
     return n;
 }
 
@@ -30,13 +33,24 @@ struct BsBest {
     int b1, pos, b2;
 };
 
-__device__ __forceinline__ void bs_merge(BsBest &A, int ob1, int opos, int ob2)
+__device__ __forceinline__ int bs_wave_min(int v)
 {
-    const bool mine = (A.b1 < ob1) || (A.b1 == ob1 && A.pos < opos);
-    const int nb2 = mine ? min(A.b2, ob1) : min(ob2, A.b1);
-    A.b1 = mine ? A.b1 : ob1;
-    A.pos = mine ? A.pos : opos;
-    A.b2 = nb2;
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// minimum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ int bs_row_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
 }
 
 // first position in sorted keys[0..n) whose node (high 32 bits) is >= / > node
@@ -54,13 +68,16 @@ __device__ __forceinline__ int bs_bound(const unsigned long long *keys, int n, u
     return lo;
 }
 
-__device__ void bs_sort(unsigned long long *keys, int NP, int tid)
+// bitonic sort of both key arrays at once: one barrier per (k, j) phase for the two sides
+__device__ void bs_sort2(unsigned long long *keysA, unsigned long long *keysB, int NP, int tid)
 {
     for (int k = 2; k <= NP; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < NP / 2; t += blockDim.x) {
-                // t-th compare-exchange pair of this (k, j) phase
-                const int i = ((t / j) * 2 * j) + (t % j);
+            for (int t = tid; t < NP; t += blockDim.x) {
+                unsigned long long *keys = t < NP / 2 ? keysA : keysB;
+                const int u = t < NP / 2 ? t : t - NP / 2;
+                // u-th compare-exchange pair of this (k, j) phase; j is a power of two
+                const int i = ((u & ~(j - 1)) << 1) | (u & (j - 1));
                 const int p = i + j;
                 const bool up = ((i & k) == 0);
                 const unsigned long long a = keys[i], b = keys[p];
@@ -74,6 +91,9 @@ __device__ void bs_sort(unsigned long long *keys, int NP, int tid)
     }
 }
 
+// LDSD: both descriptor sets are staged in LDS (fits for cap up to ~1500 keypoints per frame); otherwise they
+// are read from global memory.
+template <bool LDSD>
 __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ desc,
                                                  const orbhip_keypoint *__restrict__ kps,
                                                  const int32_t *__restrict__ counts,
@@ -81,17 +101,24 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
                                                  const uint8_t *__restrict__ valid, int cap, int NP, int lag, int th,
                                                  int th_mode, float nnratio, int check_ori,
                                                  int32_t *__restrict__ match12, int32_t *__restrict__ match21,
-                                                 int32_t *__restrict__ nmatches)
+                                                 int32_t *__restrict__ nmatches, int dbgPhases)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     unsigned long long *key1 = reinterpret_cast<unsigned long long *>(smem);
     unsigned long long *key2 = key1 + NP;
     int *m12 = reinterpret_cast<int *>(key2 + NP);                  // [NP] side-1 feature -> side-2 feature or -1
     uint2 *items = reinterpret_cast<uint2 *>(m12 + NP);             // [NP] (s1 | e1 << 16, s2 | e2 << 16)
-    unsigned *claim = reinterpret_cast<unsigned *>(items + NP);     // [NP / 32] side-2 feature claimed
+    uint2 *sorted = items + NP;                                     // [NP] the items ordered by cost
+    unsigned *claim = reinterpret_cast<unsigned *>(sorted + NP);    // [NP / 32] side-2 feature claimed
+    unsigned *vbit1 = claim + NP / 32, *vbit2 = vbit1 + NP / 32;    // [NP / 32] "has a good MapPoint" per side
+    // both descriptor sets live in LDS: the greedy loop is a chain of dependent reads (key -> descriptor ->
+    // distance -> claim) per side-1 feature, and an LDS round trip is ~20x shorter than one to L2 / HBM
+    uint4 *ls1 = reinterpret_cast<uint4 *>(smem + (((size_t)NP * 36 + (size_t)NP / 32 * 12 + 15) & ~(size_t)15));   // [cap][2]
+    uint4 *ls2 = ls1 + (size_t)cap * 2;
     __shared__ int s_n1v, s_n2v, s_nitems, s_next, s_nm;
     __shared__ int s_hist[BS_HISTO];
     __shared__ int s_keep[3];
+    __shared__ int s_grpItem[64];
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,7 +145,24 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
         key2[i] = (i < n2 && w2[i] > 0.f) ? (((unsigned long long)(unsigned)nd2[i] << 32) | (unsigned)i) : ~0ull;
         m12[i] = -1;
     }
-    for (int i = tid; i < NP / 32; i += blockDim.x) claim[i] = 0;
+    for (int i = tid; i < NP / 32; i += blockDim.x) {
+        claim[i] = 0;
+        unsigned v1 = 0xFFFFFFFFu, v2 = 0xFFFFFFFFu;
+        if (valid) {
+            v1 = v2 = 0;
+            for (int k = 0; k < 32; k++) {
+                const int f = i * 32 + k;
+                if (f < n1 && valid[(size_t)b1 * cap + f]) v1 |= 1u << k;
+                if (f < n2 && valid[(size_t)b * cap + f]) v2 |= 1u << k;
+            }
+        }
+        vbit1[i] = v1;
+        vbit2[i] = v2;
+    }
+    if (LDSD) {
+        for (int i = tid; i < n1 * 2; i += blockDim.x) ls1[i] = reinterpret_cast<const uint4 *>(d1)[i];
+        for (int i = tid; i < n2 * 2; i += blockDim.x) ls2[i] = reinterpret_cast<const uint4 *>(d2)[i];
+    }
     if (tid < BS_HISTO) s_hist[tid] = 0;
     if (tid == 0) {
         s_n1v = 0;
@@ -128,12 +172,16 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
         s_nm = 0;
     }
     __syncthreads();
-    bs_sort(key1, NP, tid);
-    bs_sort(key2, NP, tid);
+    if (dbgPhases < 1) return;
+    // only indices < max(n1, n2) hold keys: sort the smallest power of two that covers them
+    int NS = 64;
+    while (NS < max(n1, n2)) NS <<= 1;
+    bs_sort2(key1, key2, NS, tid);
+    if (dbgPhases < 2) return;
     // number of live entries per side
-    for (int i = tid; i < NP; i += blockDim.x) {
-        if (key1[i] != ~0ull && (i + 1 == NP || key1[i + 1] == ~0ull)) s_n1v = i + 1;
-        if (key2[i] != ~0ull && (i + 1 == NP || key2[i + 1] == ~0ull)) s_n2v = i + 1;
+    for (int i = tid; i < NS; i += blockDim.x) {
+        if (key1[i] != ~0ull && (i + 1 == NS || key1[i + 1] == ~0ull)) s_n1v = i + 1;
+        if (key2[i] != ~0ull && (i + 1 == NS || key2[i + 1] == ~0ull)) s_n2v = i + 1;
     }
     __syncthreads();
     const int n1v = s_n1v, n2v = s_n2v;
@@ -152,60 +200,160 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
     }
     __syncthreads();
 
-    // ---- 3. greedy matching, one wave per work item ----
+    if (dbgPhases < 3) return;
+    // ---- 3. greedy matching ----
+    // The greedy claiming of the reference is order dependent, so the side-1 features of a node form a serial
+    // chain (key -> descriptor -> distances -> minima -> claim); the kernel's time is the longest chain plus
+    // how well the chains are packed.  Items are therefore ordered by cost, largest first (LPT); a wave works on
+    // whole nodes (candidates one per lane) until it draws one with at most 16 side-2 features, and from then on
+    // runs four nodes at a time, one per 16-lane DPP row (either form is correct for any node size).
     const int nitems = s_nitems;
-    for (;;) {
-        int it = 0;
-        if (lane == 0) it = atomicAdd(&s_next, 1);
-        it = __shfl(it, 0);
-        if (it >= nitems) break;
-        const uint2 item = items[it];
-        const int s1 = item.x & 0xFFFF, e1 = item.x >> 16, s2 = item.y & 0xFFFF, e2 = item.y >> 16;
-        for (int a = s1; a < e1; a++) {
-            const int i1 = __builtin_amdgcn_readfirstlane((int)(unsigned)key1[a]);
-            if (valid && !valid[(size_t)b1 * cap + i1]) continue;   // no (good) MapPoint: :193-199
-            const uint32_t *qrow = reinterpret_cast<const uint32_t *>(d1 + (size_t)i1 * 32);
-            uint32_t Q[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) Q[k] = qrow[k];
-            BsBest B = {256, 0x7FFFFFFF, 256};
-            for (int p = s2 + lane; p < e2; p += 64) {
-                const int i2 = (int)(unsigned)key2[p];
-                if ((claim[i2 >> 5] >> (i2 & 31)) & 1u) continue;   // already matched: :209-210
-                if (th_mode && valid && !valid[(size_t)b * cap + i2]) continue;   // KF-KF variant: :572-578
-                const uint4 r0 = reinterpret_cast<const uint4 *>(d2 + (size_t)i2 * 32)[0];
-                const uint4 r1 = reinterpret_cast<const uint4 *>(d2 + (size_t)i2 * 32)[1];
-                const int d = __popc(Q[0] ^ r0.x) + __popc(Q[1] ^ r0.y) + __popc(Q[2] ^ r0.z) + __popc(Q[3] ^ r0.w) +
-                              __popc(Q[4] ^ r1.x) + __popc(Q[5] ^ r1.y) + __popc(Q[6] ^ r1.z) + __popc(Q[7] ^ r1.w);
-                if (d < B.b1) {
-                    B.b2 = B.b1;
-                    B.b1 = d;
-                    B.pos = p;
-                } else if (d < B.b2) {
-                    B.b2 = d;
+    {
+        // order by cost = n1 * ceil(n2 / 16), ties by slot: rank by counting (nitems is at most a few hundred)
+        for (int i = tid; i < nitems; i += blockDim.x) {
+            const uint2 me = items[i];
+            const int c = (int)((me.x >> 16) - (me.x & 0xFFFF)) * (int)((((me.y >> 16) - (me.y & 0xFFFF)) + 15) >> 4);
+            int rank = 0;
+            for (int o = 0; o < nitems; o++) {
+                const uint2 ot = items[o];
+                const int oc = (int)((ot.x >> 16) - (ot.x & 0xFFFF)) * (int)((((ot.y >> 16) - (ot.y & 0xFFFF)) + 15) >> 4);
+                rank += (oc > c) || (oc == c && o < i);
+            }
+            sorted[rank] = me;
+        }
+        __syncthreads();
+        const int gl = lane & 15, grp = tid >> 4;      // lane inside the group, group inside the workgroup
+        int a = 0, e1 = 0, s2 = 0, e2 = 0;             // state of the current item (wave- or group-uniform)
+        bool have = false, done = false, groupMode = false;
+        // -- wave mode: nodes with more than 16 side-2 features --
+        while (!groupMode) {
+            int it = 0;
+            if (lane == 0) it = atomicAdd(&s_next, 1);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= nitems) {
+                done = true;
+                break;
+            }
+            const uint2 item = sorted[it];
+            a = item.x & 0xFFFF;
+            e1 = item.x >> 16;
+            s2 = item.y & 0xFFFF;
+            e2 = item.y >> 16;
+            if (e2 - s2 <= 16) {        // the large nodes are done (cost order): from here on four nodes per wave
+                groupMode = true;
+                have = lane < 16;
+                break;
+            }
+            for (; a < e1; a++) {
+                const int i1 = __builtin_amdgcn_readfirstlane((int)(unsigned)key1[a]);
+                if (!((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;   // no (good) MapPoint: :193-199
+                const uint4 q0 = LDSD ? ls1[2 * i1] : reinterpret_cast<const uint4 *>(d1)[2 * i1];
+                const uint4 q1 = LDSD ? ls1[2 * i1 + 1] : reinterpret_cast<const uint4 *>(d1)[2 * i1 + 1];
+                const uint32_t Q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                BsBest B = {256, 0x7FFFFFFF, 256};
+                for (int p = s2 + lane; p < e2; p += 64) {
+                    const int i2 = (int)(unsigned)key2[p];
+                    if ((claim[i2 >> 5] >> (i2 & 31)) & 1u) continue;   // already matched: :209-210
+                    if (th_mode && !((vbit2[i2 >> 5] >> (i2 & 31)) & 1u)) continue;   // KF-KF variant: :572-578
+                    const uint4 r0 = LDSD ? ls2[2 * i2] : reinterpret_cast<const uint4 *>(d2)[2 * i2];
+                    const uint4 r1 = LDSD ? ls2[2 * i2 + 1] : reinterpret_cast<const uint4 *>(d2)[2 * i2 + 1];
+                    const int d = __popc(Q[0] ^ r0.x) + __popc(Q[1] ^ r0.y) + __popc(Q[2] ^ r0.z) + __popc(Q[3] ^ r0.w) +
+                                  __popc(Q[4] ^ r1.x) + __popc(Q[5] ^ r1.y) + __popc(Q[6] ^ r1.z) + __popc(Q[7] ^ r1.w);
+                    if (d < B.b1) {
+                        B.b2 = B.b1;
+                        B.b1 = d;
+                        B.pos = p;
+                    } else if (d < B.b2) {
+                        B.b2 = d;
+                    }
+                }
+                // best = minimum of (distance, position) over the lanes; second = minimum of the best lane's own
+                // second and the other lanes' bests
+                const int key = B.b1 < 256 ? ((B.b1 << 16) | B.pos) : 0x7FFFFFFF;
+                const int k1 = bs_wave_min(key);
+                const int k2 = bs_wave_min(key == k1 ? B.b2 : B.b1);
+                const int b1 = k1 == 0x7FFFFFFF ? 256 : (k1 >> 16), b2 = k2;
+                const bool pass = th_mode ? (b1 < th) : (b1 <= th);
+                if (pass && (float)b1 < nnratio * (float)b2) {
+                    const int i2 = (int)(unsigned)key2[k1 & 0xFFFF];
+                    if (lane == 0) {
+                        m12[i1] = i2;
+                        atomicOr(&claim[i2 >> 5], 1u << (i2 & 31));
+                    }
+                    // the claim must be visible to this wave's next side-1 feature
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int ob1 = __shfl_xor(B.b1, o), opos = __shfl_xor(B.pos, o), ob2 = __shfl_xor(B.b2, o);
-                bs_merge(B, ob1, opos, ob2);
+        }
+        // -- group mode: four small nodes per wave at a time --
+        while (groupMode) {
+            if (!have && !done) {
+                if (gl == 0) s_grpItem[grp] = atomicAdd(&s_next, 1);
             }
-            const bool pass = th_mode ? (B.b1 < th) : (B.b1 <= th);
-            if (pass && (float)B.b1 < nnratio * (float)B.b2) {
-                const int i2 = (int)(unsigned)key2[B.pos];
-                if (lane == 0) {
-                    m12[i1] = i2;
-                    atomicOr(&claim[i2 >> 5], 1u << (i2 & 31));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!have && !done) {
+                const int it = s_grpItem[grp];
+                if (it < nitems) {
+                    const uint2 item = sorted[it];
+                    a = item.x & 0xFFFF;
+                    e1 = item.x >> 16;
+                    s2 = item.y & 0xFFFF;
+                    e2 = item.y >> 16;
+                    have = true;
+                } else {
+                    done = true;
                 }
-                // the claim must be visible to this wave's next side-1 feature
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            if (__all(done)) break;
+            if (have) {
+                const int i1 = (int)(unsigned)key1[a];
+                if ((vbit1[i1 >> 5] >> (i1 & 31)) & 1u) {   // has a (good) MapPoint: :193-199
+                    const uint4 q0 = LDSD ? ls1[2 * i1] : reinterpret_cast<const uint4 *>(d1)[2 * i1];
+                    const uint4 q1 = LDSD ? ls1[2 * i1 + 1] : reinterpret_cast<const uint4 *>(d1)[2 * i1 + 1];
+                    const uint32_t Q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    BsBest B = {256, 0x7FFFFFFF, 256};
+                    for (int p = s2 + gl; p < e2; p += 16) {   // usually one trip (small nodes come here)
+                        const int i2 = (int)(unsigned)key2[p];
+                        if ((claim[i2 >> 5] >> (i2 & 31)) & 1u) continue;   // already matched: :209-210
+                        if (th_mode && !((vbit2[i2 >> 5] >> (i2 & 31)) & 1u)) continue;   // KF-KF variant: :572-578
+                        const uint4 r0 = LDSD ? ls2[2 * i2] : reinterpret_cast<const uint4 *>(d2)[2 * i2];
+                        const uint4 r1 = LDSD ? ls2[2 * i2 + 1] : reinterpret_cast<const uint4 *>(d2)[2 * i2 + 1];
+                        const int d = __popc(Q[0] ^ r0.x) + __popc(Q[1] ^ r0.y) + __popc(Q[2] ^ r0.z) + __popc(Q[3] ^ r0.w) +
+                                      __popc(Q[4] ^ r1.x) + __popc(Q[5] ^ r1.y) + __popc(Q[6] ^ r1.z) + __popc(Q[7] ^ r1.w);
+                        if (d < B.b1) {
+                            B.b2 = B.b1;
+                            B.b1 = d;
+                            B.pos = p;
+                        } else if (d < B.b2) {
+                            B.b2 = d;
+                        }
+                    }
+                    const int key = B.b1 < 256 ? ((B.b1 << 16) | B.pos) : 0x7FFFFFFF;
+                    const int k1 = bs_row_min(key);
+                    const int k2 = bs_row_min(key == k1 ? B.b2 : B.b1);
+                    const int b1 = k1 == 0x7FFFFFFF ? 256 : (k1 >> 16), b2 = k2;
+                    const bool pass = th_mode ? (b1 < th) : (b1 <= th);
+                    if (pass && (float)b1 < nnratio * (float)b2) {
+                        const int i2 = (int)(unsigned)key2[k1 & 0xFFFF];
+                        if (gl == 0) {
+                            m12[i1] = i2;
+                            atomicOr(&claim[i2 >> 5], 1u << (i2 & 31));
+                        }
+                    }
+                }
+                a++;
+                if (a >= e1) have = false;
+            }
+            // the fence at the loop top makes the claims visible to the group's next side-1 feature
         }
     }
     __syncthreads();
 
+    if (dbgPhases < 4) return;
     // ---- 4. rotation consistency ----
     const orbhip_keypoint *k1 = kps + (size_t)b1 * cap, *k2 = kps + (size_t)b * cap;
     int mybin0 = -1;   // this thread handles features tid, tid+256, ...: remember bins in registers
@@ -281,9 +429,18 @@ void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *k
     if (B <= 0) return;
     int NP = 512;
     while (NP < cap) NP <<= 1;
-    const size_t lds = (size_t)NP * (8 + 8 + 4 + 8) + (size_t)NP / 8 + 64;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_bow_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_bow_seq, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid, cap, NP,
-                       lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches);
+    const size_t base = (((size_t)NP * 36 + (size_t)NP / 32 * 12 + 15) & ~(size_t)15) + 64;
+    const size_t full = base + (size_t)cap * 64;
+    static const int forceGlobal = getenv("ORBHIP_BOW_GLOBAL_DESC") ? atoi(getenv("ORBHIP_BOW_GLOBAL_DESC")) : 0;
+    const bool ldsd = full <= 150 * 1024 && !forceGlobal;
+    static const int dbg = getenv("ORBHIP_BOW_PHASES") ? atoi(getenv("ORBHIP_BOW_PHASES")) : 9;
+    const size_t lds = ldsd ? full : base;
+    const void *fn = ldsd ? (const void *)k_bow_seq<true> : (const void *)k_bow_seq<false>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ldsd)
+        hipLaunchKernelGGL(k_bow_seq<true>, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid,
+                           cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches, dbg);
+    else
+        hipLaunchKernelGGL(k_bow_seq<false>, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid,
+                           cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches, dbg);
 }

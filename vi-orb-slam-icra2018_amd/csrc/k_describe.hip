@@ -1,5 +1,5 @@
-// k_describe.hip -- E5 + E7 + E8 + output assembly: one 64-lane wave per retained keypoint
-// computes the intensity-centroid angle on the un-blurred level (ref: src/ORBextractor.cc:79-106),
+// k_describe.hip -- E5 + E7 + E8 + output assembly: per retained keypoint the intensity-centroid angle
+// on the un-blurred level (ref: src/ORBextractor.cc:79-106),
 // the steered 256-bit BRIEF descriptor on the blurred level (:109-149), scales the coordinates
 // (:1113-1119) and writes the cv::KeyPoint record and the descriptor row at the keypoint's final
 // position (levels concatenated in order 0..n-1, :1094-1122).
@@ -62,6 +62,21 @@ __device__ __forceinline__ int wave_sum(int v)
            __builtin_amdgcn_readlane(v, 48);
 }
 
+// One 256-thread workgroup per DS_KP = 64 slots of the per-frame level-keypoint array:
+//   0. thread per slot: level, position, output index (levels concatenated in order, :1094-1122);
+//   A. wave per keypoint (each wave walks 16 slots): the disc rows as aligned dwords, lane -> (row of a group
+//      of 7, dword 0..8 of the row), 5 trips cover the 31 rows; valid bytes are cut out with a mask and summed
+//      with v_sad_u8 / v_dot4 (sum of bytes, sum of k * byte), then two DPP wave sums;
+//   B. thread per keypoint: fastAtan2, cos / sin in double, the cv::KeyPoint record.  The scalar float / double
+//      sequence is evaluated once per keypoint by one lane instead of once per wave by 64 lanes;
+//   C. wave per keypoint again: the lane's four test pairs are decoded once (16 floats), then per keypoint 4 x
+//      (rotate, round, two byte gathers from the blurred level, compare, ballot).
+#define DS_KP 64
+#define DS_R 19                       // the rotated 31 x 31 pattern stays within 19 pixels of the keypoint
+#define DS_ROWS (2 * DS_R + 1)        // 39 patch rows
+#define DS_PDW 11                     // dwords per staged row: 39 bytes + up to 3 bytes of alignment
+#define DS_TRIPS ((DS_ROWS * DS_PDW + 63) / 64)   // 7
+
 __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                                   int stride0, unsigned long long frame0,
                                                   const uint8_t *__restrict__ pyr,
@@ -75,112 +90,208 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
                                                   uint8_t *__restrict__ desc, int32_t *__restrict__ counts,
                                                   int cap, int xcdMap)
 {
-    const int blk = xcd_tile(xcdMap), frame = blockIdx.y;   // consecutive keypoints of a level share an XCD's L2
-    const int lane = threadIdx.x & 63;
-    const int g = blk * 4 + (threadIdx.x >> 6);  // slot in the per-frame level-keypoint array
-    if (g >= G.totalKps) return;
+    __shared__ int s_pos[DS_KP];      // cx | cy << 12 | level << 24, -1 = empty slot
+    __shared__ int s_out[DS_KP];      // output index
+    __shared__ int s_m10[DS_KP], s_m01[DS_KP];
+    __shared__ float s_a[DS_KP], s_b[DS_KP];
+    __shared__ uint32_t s_patch[4][DS_ROWS * DS_PDW + 3];
+    const int blk = xcd_tile(xcdMap), frame = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g0 = blk * DS_KP;
+    if (g0 >= G.totalKps) return;
     const int32_t *cnts = lvlKpCnt + frame * ORBHIP_MAX_LEVELS;
-    // level of this slot and output offset of the level
-    int l = 0, off = 0, total = 0;
-    for (int k = 0; k < G.nlevels; k++) {
-        const int c = cnts[k];
-        if (g >= G.lv[k].kpBase) {
-            l = k;
-            off = total;
-        }
-        total += c;
-    }
-    if (g == 0 && lane == 0) counts[frame] = total;
-    const OrbLevel &L = G.lv[l];
-    const int i = g - L.kpBase;
-    if (i >= cnts[l]) return;
-    const uint32_t pk = lvlKp[(size_t)frame * G.totalKps + g];
-    const int cx = (int)(pk & 0xFFFu) + ORB_MIN_BORDER;         // :843-844
-    const int cy = (int)((pk >> 12) & 0xFFFu) + ORB_MIN_BORDER;
-    const int score = (int)(pk >> 24);
 
-    // ---- E5: IC_Angle on the un-blurred level ----
-    const uint8_t *img;
-    int stride;
-    if (l == 0) {
-        img = lvl0 + (size_t)frame * frame0;
-        stride = stride0;
-    } else {
-        img = pyr + (size_t)frame * pyrFrame + L.imgOff;
-        stride = L.stride;
+    // ---- 0. slot -> (level, position, output index) ----
+    int my_score = 0;
+    if (tid < DS_KP) {
+        const int g = g0 + tid;
+        int pos = -1, o = 0;
+        if (g < G.totalKps) {
+            int l = 0, off = 0, total = 0;
+            for (int k = 0; k < G.nlevels; k++) {
+                if (g >= G.lv[k].kpBase) {
+                    l = k;
+                    off = total;
+                }
+                total += cnts[k];
+            }
+            if (g == 0) counts[frame] = total;
+            const int i = g - G.lv[l].kpBase;
+            if (i < cnts[l]) {
+                const uint32_t pk = lvlKp[(size_t)frame * G.totalKps + g];
+                const int cx = (int)(pk & 0xFFFu) + ORB_MIN_BORDER;         // :843-844
+                const int cy = (int)((pk >> 12) & 0xFFFu) + ORB_MIN_BORDER;
+                my_score = (int)(pk >> 24);
+                pos = cx | (cy << 12) | (l << 24);
+                o = off + i;
+            }
+        }
+        s_pos[tid] = pos;
+        s_out[tid] = o;
     }
-    // The disc rows are read as aligned dwords: lane -> (row of a group of 7, dword 0..8 of the row),
-    // 5 trips cover the 31 rows; a row needs at most 31 + 3 bytes = 9 dwords.  (A byte gather costs the
-    // texture-address unit 16 cycles per wave instruction; this is 5 coalesced instructions, not 16.)
-    int m10 = 0, m01 = 0;
+    __syncthreads();
+
+    // ---- A. E5: IC_Angle moments on the un-blurred level ----
+    // software pipeline: the five row dwords of the wave's next keypoint are in flight while the current one is
+    // reduced
     {
         const int rsub = lane / 9, di = lane - rsub * 9;
-        const int xs = ((cx - ORB_HALF_PATCH) & ~3) + 4 * di;     // image column of byte 0 of this lane's dword
-        const int u0 = xs - cx;
+        auto load5 = [&](int kp, uint32_t wd[5]) {
+            const int pos = s_pos[kp];
+            const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+            const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + G.lv[l].imgOff;
+            const int stride = l == 0 ? stride0 : G.lv[l].stride;
+            const int xs = ((cx - ORB_HALF_PATCH) & ~3) + 4 * di;     // image column of byte 0 of this lane's dword
 #pragma unroll
-        for (int it = 0; it < 5; it++) {
-            const int v = -ORB_HALF_PATCH + it * 7 + rsub;
-            if (lane < 63 && v <= ORB_HALF_PATCH) {
-                const int d = G.umax[v < 0 ? -v : v];
-                const uint32_t wd = *reinterpret_cast<const uint32_t *>(img + (size_t)(cy + v) * stride + xs);
-                int rs = 0, ru = 0;
+            for (int it = 0; it < 5; it++) {
+                const int v = -ORB_HALF_PATCH + it * 7 + rsub;
+                wd[it] = (pos >= 0 && lane < 63 && v <= ORB_HALF_PATCH)
+                             ? *reinterpret_cast<const uint32_t *>(img + (size_t)(cy + v) * stride + xs)
+                             : 0u;
+            }
+        };
+        const int kp0 = wave * (DS_KP / 4);
+        uint32_t cur[5], nxt[5];
+        load5(kp0, cur);
+        for (int q = 0; q < DS_KP / 4; q++) {
+            const int kp = kp0 + q;
+            if (q + 1 < DS_KP / 4) load5(kp + 1, nxt);
+            const int pos = s_pos[kp];
+            if (pos >= 0) {   // wave-uniform
+                const int cx = pos & 0xFFF;
+                const int u0 = ((cx - ORB_HALF_PATCH) & ~3) + 4 * di - cx;
+                int m10 = 0, m01 = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int u = u0 + k;
-                    const int val = (u >= -d && u <= d) ? (int)((wd >> (8 * k)) & 0xFF) : 0;
-                    rs += val;
-                    ru += u * val;
+                for (int it = 0; it < 5; it++) {
+                    const int v = -ORB_HALF_PATCH + it * 7 + rsub;
+                    const int d = G.umax[min(v < 0 ? -v : v, ORB_HALF_PATCH)];
+                    // bytes k with -d <= u0 + k <= d
+                    const int lo = max(0, -d - u0), hi = min(3, d - u0);
+                    if (lo <= hi && lane < 63 && v <= ORB_HALF_PATCH) {
+                        const uint32_t mask = (0xFFFFFFFFu >> (8 * (3 - hi))) & (0xFFFFFFFFu << (8 * lo));
+                        const uint32_t wm = cur[it] & mask;
+                        const int rs = (int)__builtin_amdgcn_sad_u8(wm, 0u, 0u);                 // sum of the 4 bytes
+                        const int rk = (int)__builtin_amdgcn_udot4(wm, 0x03020100u, 0u, false);  // sum of k * byte
+                        m10 += __mul24(u0, rs) + rk;
+                        m01 += __mul24(v, rs);
+                    }
                 }
-                m10 += ru;
-                m01 += v * rs;
+                m10 = wave_sum(m10);
+                m01 = wave_sum(m01);
+                if (lane == 0) {
+                    s_m10[kp] = m10;
+                    s_m01[kp] = m01;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 5; it++) cur[it] = nxt[it];
+        }
+    }
+    __syncthreads();
+
+    // ---- B. angle, cos / sin, keypoint record: one thread per keypoint ----
+    if (tid < DS_KP) {
+        const int pos = s_pos[tid];
+        if (pos >= 0) {
+            const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+            const OrbLevel &L = G.lv[l];
+            const float angle = fast_atan2_dev((float)s_m01[tid], (float)s_m10[tid]);
+            const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+            const float rad = __fmul_rn(angle, factorPI);
+            float a, b;
+            orb_sincosf(rad, &b, &a);
+            s_a[tid] = a;
+            s_b[tid] = b;
+            lvlAngle[(size_t)frame * G.totalKps + g0 + tid] = angle;
+            const int o = s_out[tid];
+            if (o < cap) {
+                orbhip_keypoint kp;
+                kp.x = __fmul_rn((float)cx, L.scale);   // level 0: scale == 1.0f, identical to "no scaling"
+                kp.y = __fmul_rn((float)cy, L.scale);
+                kp.size = L.kpSize;
+                kp.angle = angle;
+                kp.response = (float)my_score;
+                kp.octave = l;
+                kp.class_id = -1;
+                kps[(size_t)frame * cap + o] = kp;
             }
         }
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = fast_atan2_dev((float)m01, (float)m10);
+    __syncthreads();
 
-    // ---- E7: steered BRIEF on the blurred level ----
-    const uint8_t *bimg = blur + (size_t)frame * blurFrame + (l == 0 ? 0ull : G.boff1 + L.imgOff);
-    const int bstride = l == 0 ? G.bstride0 : L.stride;
-    const uint8_t *bc = bimg + (size_t)cy * bstride + cx;
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float rad = __fmul_rn(angle, factorPI);
-    float a, b;
-    orb_sincosf(rad, &b, &a);
-    const int o = off + i;
-    unsigned long long words[4];
+    // ---- C. E7: steered BRIEF on the blurred level ----
+    // The 39 x 39 neighbourhood of the keypoint (the rotated pattern stays within 19 pixels) is staged per wave in
+    // LDS with row-coalesced dword loads (11 dwords per row, 7 trips), software-pipelined like phase A; the 512
+    // test pixels are then LDS byte reads.  A byte gather straight from memory touches up to 64 cache lines per
+    // wave instruction; the staged form touches each line once.
+    float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int t = 64 * j + lane;
-        const int pw = reinterpret_cast<const int *>(c_pattern)[t];
-        const float x0 = (float)(signed char)(pw & 0xFF), y0 = (float)(signed char)((pw >> 8) & 0xFF);
-        const float x1 = (float)(signed char)((pw >> 16) & 0xFF), y1 = (float)(signed char)((pw >> 24) & 0xFF);
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[r0 * bstride + c0], t1 = bc[r1 * bstride + c1];
-        words[j] = __ballot(t0 < t1);
+        const int pw = reinterpret_cast<const int *>(c_pattern)[64 * j + lane];
+        px0[j] = (float)(signed char)(pw & 0xFF);
+        py0[j] = (float)(signed char)((pw >> 8) & 0xFF);
+        px1[j] = (float)(signed char)((pw >> 16) & 0xFF);
+        py1[j] = (float)(signed char)((pw >> 24) & 0xFF);
     }
-    lvlAngle[(size_t)frame * G.totalKps + g] = angle;
-    if (o < cap) {
-        if (lane < 4) {
-            // bit (64j + lane) of the descriptor = test 64j+lane, LSB first inside each byte (:128-145)
-            const unsigned long long wsel = lane == 0 ? words[0] : (lane == 1 ? words[1] : (lane == 2 ? words[2] : words[3]));
-            reinterpret_cast<unsigned long long *>(desc + ((size_t)frame * cap + o) * 32)[lane] = wsel;
+    uint32_t *patch = s_patch[wave];
+    const uint8_t *patchB = reinterpret_cast<const uint8_t *>(patch);
+    auto load7 = [&](int kp, uint32_t wd[DS_TRIPS]) {
+        const int pos = s_pos[kp];
+        const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+        const uint8_t *bimg = blur + (size_t)frame * blurFrame + (l == 0 ? 0ull : G.boff1 + G.lv[l].imgOff);
+        const int bstride = l == 0 ? G.bstride0 : G.lv[l].stride;
+        const int xs = (cx - DS_R) & ~3;
+#pragma unroll
+        for (int it = 0; it < DS_TRIPS; it++) {
+            const int idx = it * 64 + lane;
+            const int row = (int)(((unsigned)idx * 5958u) >> 16);   // idx / 11 for idx < 448
+            const int dw = idx - row * DS_PDW;
+            wd[it] = (pos >= 0 && idx < DS_ROWS * DS_PDW)
+                         ? *reinterpret_cast<const uint32_t *>(bimg + (size_t)(cy - DS_R + row) * bstride + xs + 4 * dw)
+                         : 0u;
         }
-        if (lane == 0) {
-            orbhip_keypoint kp;
-            kp.x = __fmul_rn((float)cx, L.scale);   // level 0: scale == 1.0f, identical to "no scaling"
-            kp.y = __fmul_rn((float)cy, L.scale);
-            kp.size = L.kpSize;
-            kp.angle = angle;
-            kp.response = (float)score;
-            kp.octave = l;
-            kp.class_id = -1;
-            kps[(size_t)frame * cap + o] = kp;
+    };
+    const int kp0 = wave * (DS_KP / 4);
+    uint32_t cur[DS_TRIPS], nxt[DS_TRIPS];
+    load7(kp0, cur);
+    for (int q = 0; q < DS_KP / 4; q++) {
+        const int kp = kp0 + q;
+        const int pos = s_pos[kp];
+        if (pos >= 0) {
+#pragma unroll
+            for (int it = 0; it < DS_TRIPS; it++)
+                if (it * 64 + lane < DS_ROWS * DS_PDW) patch[it * 64 + lane] = cur[it];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (q + 1 < DS_KP / 4) load7(kp + 1, nxt);
+        const int o = s_out[kp];
+        if (pos >= 0 && o < cap) {   // wave-uniform
+            const int cx = pos & 0xFFF;
+            const uint8_t *bc = patchB + DS_R * (DS_PDW * 4) + DS_R + ((cx - DS_R) & 3);   // the keypoint inside the patch
+            const float a = s_a[kp], b = s_b[kp];
+            unsigned long long words[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[j], b), __fmul_rn(py0[j], a)));
+                const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[j], a), __fmul_rn(py0[j], b)));
+                const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[j], b), __fmul_rn(py1[j], a)));
+                const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[j], a), __fmul_rn(py1[j], b)));
+                const int t0 = bc[r0 * (DS_PDW * 4) + c0], t1 = bc[r1 * (DS_PDW * 4) + c1];
+                words[j] = __ballot(t0 < t1);
+            }
+            if (lane < 4) {
+                // bit (64j + lane) of the descriptor = test 64j+lane, LSB first inside each byte (:128-145)
+                const unsigned long long wsel = lane == 0 ? words[0] : (lane == 1 ? words[1] : (lane == 2 ? words[2] : words[3]));
+                reinterpret_cast<unsigned long long *>(desc + ((size_t)frame * cap + o) * 32)[lane] = wsel;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < DS_TRIPS; it++) cur[it] = nxt[it];
     }
 }
 
@@ -189,7 +300,7 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
 {
-    dim3 grid(orb_xcd_grid((G.totalKps + 3) / 4), B, 1), block(256, 1, 1);
+    dim3 grid(orb_xcd_grid((G.totalKps + DS_KP - 1) / DS_KP), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_describe, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt,
                        lvlAngle, kps, desc, counts, cap, orb_xcd_arg());
