@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
     __shared__ int s_out[DS_KP];      // output index
     __shared__ int s_m10[DS_KP], s_m01[DS_KP];
     __shared__ float s_a[DS_KP], s_b[DS_KP];
+    // level geometry of the slot, looked up once in phase 0 (indexing the by-value OrbLevels argument with a
+    // per-lane level costs a dependent memory round trip every time)
+    __shared__ unsigned s_ioff[DS_KP], s_boff[DS_KP];
+    __shared__ int s_istride[DS_KP], s_bstride[DS_KP];
     __shared__ uint32_t s_patch[4][DS_ROWS * DS_PDW + 3];
     const int blk = xcd_tile(xcdMap), frame = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,6 +132,11 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         }
         s_pos[tid] = pos;
         s_out[tid] = o;
+        const int l = pos >= 0 ? pos >> 24 : 0;
+        s_ioff[tid] = l == 0 ? 0u : (unsigned)G.lv[l].imgOff;
+        s_istride[tid] = l == 0 ? stride0 : G.lv[l].stride;
+        s_boff[tid] = l == 0 ? 0u : (unsigned)(G.boff1 + G.lv[l].imgOff);
+        s_bstride[tid] = l == 0 ? G.bstride0 : G.lv[l].stride;
     }
     __syncthreads();
 
@@ -136,20 +145,30 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
     // reduced
     {
         const int rsub = lane / 9, di = lane - rsub * 9;
+        // Loads are unconditional inside one wave-uniform region (lanes without a dword -- lane 63, rows beyond
+        // +15 -- read a valid neighbouring address and are masked in the arithmetic): a conditional load per
+        // trip would compile to five exec-masked regions with a full wait between them.
+        const int lrs = min(lane, 62) / 9, ldi = min(lane, 62) - lrs * 9;
         auto load5 = [&](int kp, uint32_t wd[5]) {
             const int pos = s_pos[kp];
-            const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
-            const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + G.lv[l].imgOff;
-            const int stride = l == 0 ? stride0 : G.lv[l].stride;
-            const int xs = ((cx - ORB_HALF_PATCH) & ~3) + 4 * di;     // image column of byte 0 of this lane's dword
+            if (pos >= 0) {
+                const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+                const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + s_ioff[kp];
+                const int stride = s_istride[kp];
+                const uint8_t *p = img + (size_t)cy * stride + ((cx - ORB_HALF_PATCH) & ~3) + 4 * ldi;
 #pragma unroll
-            for (int it = 0; it < 5; it++) {
-                const int v = -ORB_HALF_PATCH + it * 7 + rsub;
-                wd[it] = (pos >= 0 && lane < 63 && v <= ORB_HALF_PATCH)
-                             ? *reinterpret_cast<const uint32_t *>(img + (size_t)(cy + v) * stride + xs)
-                             : 0u;
+                for (int it = 0; it < 5; it++) {
+                    const int v = min(-ORB_HALF_PATCH + it * 7 + lrs, ORB_HALF_PATCH);
+                    wd[it] = *reinterpret_cast<const uint32_t *>(p + v * stride);
+                }
             }
         };
+        int dmax[5];   // half width of the disc row this lane reads in trip it (umax of |v|), fixed per lane
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int v = -ORB_HALF_PATCH + it * 7 + rsub;
+            dmax[it] = G.umax[min(v < 0 ? -v : v, ORB_HALF_PATCH)];
+        }
         const int kp0 = wave * (DS_KP / 4);
         uint32_t cur[5], nxt[5];
         load5(kp0, cur);
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
 #pragma unroll
                 for (int it = 0; it < 5; it++) {
                     const int v = -ORB_HALF_PATCH + it * 7 + rsub;
-                    const int d = G.umax[min(v < 0 ? -v : v, ORB_HALF_PATCH)];
+                    const int d = dmax[it];
                     // bytes k with -d <= u0 + k <= d
                     const int lo = max(0, -d - u0), hi = min(3, d - u0);
                     if (lo <= hi && lane < 63 && v <= ORB_HALF_PATCH) {
@@ -235,20 +254,23 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
     }
     uint32_t *patch = s_patch[wave];
     const uint8_t *patchB = reinterpret_cast<const uint8_t *>(patch);
+    int prow[DS_TRIPS], pdw[DS_TRIPS];     // this lane's (row, dword) of every trip; the tail lanes repeat the last dword
+#pragma unroll
+    for (int it = 0; it < DS_TRIPS; it++) {
+        const int idx = min(it * 64 + lane, DS_ROWS * DS_PDW - 1);
+        prow[it] = (int)(((unsigned)idx * 5958u) >> 16);   // idx / 11 for idx < 448
+        pdw[it] = idx - prow[it] * DS_PDW;
+    }
     auto load7 = [&](int kp, uint32_t wd[DS_TRIPS]) {
         const int pos = s_pos[kp];
-        const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
-        const uint8_t *bimg = blur + (size_t)frame * blurFrame + (l == 0 ? 0ull : G.boff1 + G.lv[l].imgOff);
-        const int bstride = l == 0 ? G.bstride0 : G.lv[l].stride;
-        const int xs = (cx - DS_R) & ~3;
+        if (pos >= 0) {   // one region, unconditional loads (see phase A)
+            const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF;
+            const uint8_t *bimg = blur + (size_t)frame * blurFrame + s_boff[kp];
+            const int bstride = s_bstride[kp];
+            const uint8_t *p = bimg + (size_t)(cy - DS_R) * bstride + ((cx - DS_R) & ~3);
 #pragma unroll
-        for (int it = 0; it < DS_TRIPS; it++) {
-            const int idx = it * 64 + lane;
-            const int row = (int)(((unsigned)idx * 5958u) >> 16);   // idx / 11 for idx < 448
-            const int dw = idx - row * DS_PDW;
-            wd[it] = (pos >= 0 && idx < DS_ROWS * DS_PDW)
-                         ? *reinterpret_cast<const uint32_t *>(bimg + (size_t)(cy - DS_R + row) * bstride + xs + 4 * dw)
-                         : 0u;
+            for (int it = 0; it < DS_TRIPS; it++)
+                wd[it] = *reinterpret_cast<const uint32_t *>(p + prow[it] * bstride + 4 * pdw[it]);
         }
     };
     const int kp0 = wave * (DS_KP / 4);
