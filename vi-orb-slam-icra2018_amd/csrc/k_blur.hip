@@ -65,13 +65,30 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
 
     // ---- 1. raw tile: LDS column j <-> image column x0 - 16 + j ----
     const int wAl = (w + 15) & ~15;   // bytes of a row that may be read with 16-byte loads
-    for (int i = tid; i < BT_ROWS * (BT_RAWP / 16); i += 256) {
-        const int r = i / (BT_RAWP / 16), c = i - r * (BT_RAWP / 16);
-        const int sy = reflect101(min(y0 - 3 + r, h + 2), h);
-        const int sx = x0 - 16 + (c << 4);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (sx >= 0 && sx < wAl) v = *reinterpret_cast<const uint4 *>(src + (size_t)sy * sstride + sx);
-        *reinterpret_cast<uint4 *>(&s_raw[r][c << 4]) = v;
+    // both 16-byte loads of a thread are issued before either is stored (unconditional loads from a clamped
+    // address, zeroed afterwards when the chunk lies outside the row: a conditional load would be waited for
+    // before the next one is issued)
+    {
+        constexpr int NCH = BT_RAWP / 16, NIT = (BT_ROWS * NCH + 255) / 256;
+        uint4 v[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = min(tid + k * 256, BT_ROWS * NCH - 1);
+            const int r = i / NCH, c = i - r * NCH;
+            const int sy = reflect101(min(y0 - 3 + r, h + 2), h);
+            const int sx = x0 - 16 + (c << 4);
+            ok[k] = sx >= 0 && sx < wAl;
+            v[k] = *reinterpret_cast<const uint4 *>(src + (size_t)sy * sstride + min(max(sx, 0), wAl - 16));
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = tid + k * 256;
+            if (i < BT_ROWS * NCH) {
+                const int r = i / NCH, c = i - r * NCH;
+                *reinterpret_cast<uint4 *>(&s_raw[r][c << 4]) = ok[k] ? v[k] : make_uint4(0, 0, 0, 0);
+            }
+        }
     }
     __syncthreads();
     // reflected halo columns at the image edges (x = -1,-2,-3 <- 1,2,3 ; x = w,w+1,w+2 <- w-2,w-3,w-4)
