@@ -11,10 +11,10 @@
 
 #define RZ_TW 128
 #ifndef RZ_TH
-#define RZ_TH 16   // rows of a tile: two per thread
+#define RZ_TH 32   // rows of a tile: four per thread
 #endif
 #define RZ_MAXCH 16    // 16-byte chunks per staged source row (source span <= 240 px + alignment)
-#define RZ_MAXROWS 24  // staged source rows
+#define RZ_MAXROWS 44  // staged source rows
 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sstride,
                                                 unsigned long long sframe, uint8_t *__restrict__ dst,
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     const int XA = sxmin & ~15;
     const int nch = ((sxmax - XA) >> 4) + 1;
     const int nrows = symax - symin + 1;
-    if (nch <= RZ_MAXCH && nrows <= RZ_MAXROWS) {
+    if (nch <= RZ_MAXCH && nrows <= RZ_MAXROWS && nrows * nch <= 512) {
         // at most RZ_MAXROWS * RZ_MAXCH = 384 chunks: two unconditional loads per thread, issued together
         const int n = nrows * nch;
         const int i0 = min(tid, n - 1), i1 = min(tid + 256, n - 1);
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     for (int k = 0; k < 4; k++) xt[k] = xtab[min(gx + k, dw - 1)];
     __syncthreads();
     if (!colLive) return;
-    const bool staged = nch <= RZ_MAXCH && nrows <= RZ_MAXROWS;
+    const bool staged = nch <= RZ_MAXCH && nrows <= RZ_MAXROWS && nrows * nch <= 512;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const int dy = dy0 + 8 * j;
