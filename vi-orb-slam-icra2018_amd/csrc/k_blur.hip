@@ -137,43 +137,55 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
     }
     __syncthreads();
 
-    // ---- 3. column pass with v_dot2_u32_u16: rows r..r+6 are 4 row pairs ----
+    // ---- 3. column pass with v_dot2_u32_u16: an item = (two output rows, 4 adjacent columns) ----
+    // Output rows r (even) and r + 1 read the same four row pairs (r,r+1)(r+2,r+3)(r+4,r+5)(r+6,r+7) with the
+    // constant weight pairs (k0,k1)(k2,k3)(k2,k1)(k0,0) and (0,k0)(k1,k2)(k3,k2)(k1,k0): four LDS reads serve
+    // eight outputs and no weight depends on the lane.
     const int wvec = w - (w & 3);
-    for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
-        const int r = i >> 5, g = i & 31;
-        const int y = y0 + r, xb = x0 + (g << 2);
+    const us2 wa0 = {(unsigned short)k0, (unsigned short)k1}, wa1 = {(unsigned short)k2, (unsigned short)k3};
+    const us2 wa2 = {(unsigned short)k2, (unsigned short)k1}, wa3 = {(unsigned short)k0, 0};
+    const us2 wb0 = {0, (unsigned short)k0}, wb1 = {(unsigned short)k1, (unsigned short)k2};
+    const us2 wb2 = {(unsigned short)k3, (unsigned short)k2}, wb3 = {(unsigned short)k1, (unsigned short)k0};
+    for (int i = tid; i < (BT_H / 2) * (BT_W / 4); i += 256) {
+        const int rp = i >> 5, g = i & 31;
+        const int y = y0 + 2 * rp, xb = x0 + (g << 2);
         if (y >= h || xb >= w) continue;
-        // even r: pairs hold rows (r,r+1)(r+2,r+3)(r+4,r+5)(r+6,-); odd r: (-,r)(r+1,r+2)(r+3,r+4)(r+5,r+6)
-        const bool odd = r & 1;
-        const us2 w0 = odd ? us2{0, (unsigned short)k0} : us2{(unsigned short)k0, (unsigned short)k1};
-        const us2 w1 = odd ? us2{(unsigned short)k1, (unsigned short)k2} : us2{(unsigned short)k2, (unsigned short)k3};
-        const us2 w2 = odd ? us2{(unsigned short)k3, (unsigned short)k2} : us2{(unsigned short)k2, (unsigned short)k1};
-        const us2 w3 = odd ? us2{(unsigned short)k1, (unsigned short)k0} : us2{(unsigned short)k0, 0};
-        const int p0 = r >> 1;
-        const uint4 q0 = *reinterpret_cast<const uint4 *>(&s_pair[p0][g << 2]);
-        const uint4 q1 = *reinterpret_cast<const uint4 *>(&s_pair[p0 + 1][g << 2]);
-        const uint4 q2 = *reinterpret_cast<const uint4 *>(&s_pair[p0 + 2][g << 2]);
-        const uint4 q3 = *reinterpret_cast<const uint4 *>(&s_pair[p0 + 3][g << 2]);
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(&s_pair[rp][g << 2]);
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(&s_pair[rp + 1][g << 2]);
+        const uint4 q2 = *reinterpret_cast<const uint4 *>(&s_pair[rp + 2][g << 2]);
+        const uint4 q3 = *reinterpret_cast<const uint4 *>(&s_pair[rp + 3][g << 2]);
         const uint32_t c0[4] = {q0.x, q0.y, q0.z, q0.w}, c1[4] = {q1.x, q1.y, q1.z, q1.w};
         const uint32_t c2[4] = {q2.x, q2.y, q2.z, q2.w}, c3[4] = {q3.x, q3.y, q3.z, q3.w};
-        uint32_t packed = 0;
+        uint32_t packedA = 0, packedB = 0;
+        const bool body = xb + 3 < wvec;   // every pixel of the group is in the SSE2 body (the usual case)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), w0, 0u, false);
-            sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), w1, sum, false);
-            sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), w2, sum, false);
-            sum = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), w3, sum, false);
+            uint32_t sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wa0, 0u, false);
+            sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wa1, sa, false);
+            sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wa2, sa, false);
+            sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wa3, sa, false);
+            uint32_t sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wb0, 0u, false);
+            sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wb1, sb, false);
+            sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wb2, sb, false);
+            sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wb3, sb, false);
             // SSE2 body (x < wvec): round half to even = (s + 0x7FFF + bit16(s)) >> 16;
             // scalar tail: round half up = (s + 0x8000) >> 16
-            const uint32_t bias = (xb + k < wvec) ? 0x7FFFu + ((sum >> 16) & 1u) : 0x8000u;
-            const uint32_t v = min((sum + bias) >> 16, 255u);
-            packed |= v << (8 * k);
+            const bool even = body || (xb + k < wvec);
+            const uint32_t ba = even ? 0x7FFFu + ((sa >> 16) & 1u) : 0x8000u;
+            const uint32_t bb = even ? 0x7FFFu + ((sb >> 16) & 1u) : 0x8000u;
+            packedA |= min((sa + ba) >> 16, 255u) << (8 * k);
+            packedB |= min((sb + bb) >> 16, 255u) << (8 * k);
         }
         uint8_t *o = dst + (size_t)y * dstride + xb;
-        if (xb + 3 < w)
-            *reinterpret_cast<uint32_t *>(o) = packed;
-        else
-            for (int k = 0; k < 4 && xb + k < w; k++) o[k] = (uint8_t)(packed >> (8 * k));
+        if (xb + 3 < w) {
+            *reinterpret_cast<uint32_t *>(o) = packedA;
+            if (y + 1 < h) *reinterpret_cast<uint32_t *>(o + dstride) = packedB;
+        } else {
+            for (int k = 0; k < 4 && xb + k < w; k++) {
+                o[k] = (uint8_t)(packedA >> (8 * k));
+                if (y + 1 < h) o[dstride + k] = (uint8_t)(packedB >> (8 * k));
+            }
+        }
     }
 }
 
