@@ -7,6 +7,11 @@ A step = one pass of the hot path over one batch of B synthetic frames resident 
   * the reference's frame-to-frame matching (Tracking::TrackReferenceKeyFrame): vocabulary transform of
     every descriptor (Frame::ComputeBoW, levelsup 4) and ORBmatcher::SearchByBoW of every frame against
     its predecessor (--match bow, default), or brute-force best/second Hamming (--match brute), or both.
+The timed region runs the whole batch on ONE extractor context (--contexts 1), so that every kernel owns the
+GPU while it runs and the per-stage HIP-event times / the roofline are clean.  A supplementary figure
+(`pipelined`) reports the free-running throughput when the same batch is split over several contexts (the
+reference itself runs two extractor instances side by side for stereo, src/Frame.cc:422-425): their streams let
+the latency-bound stages of one part overlap the VALU-bound stages of another.
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); frames are sharded, there is no
 per-frame collective; the ORB vocabulary blob is broadcast once at start-up over xGMI (not timed).
 
@@ -71,6 +76,67 @@ def cpu_baseline(frames, nsample, match, blob):
                       "(gcc -O3 -march=x86-64-v3), %.1f s" % (nsample, W, H, NFEAT, what, dt)}
 
 
+def committed_traffic(batch, contexts):
+    """HBM-side bytes per k_fast launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/profile_gpu.sh + tools/summarize_prof.py for the default configuration), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        if int(t.get("batch", -1)) == batch and int(t.get("contexts", 1)) == contexts:
+            return int(t["traffic_bytes_per_launch"]), t.get("source", "profiles/traffic.json")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def pipelined_throughput(args, d_img, blob, device, cap):
+    """Free-running multi-context throughput of the same step (no per-step readout): supplementary figure."""
+    import torch
+    from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    NC, B = args.pipelined, args.batch
+    Bc = B // NC
+    i32 = dict(dtype=torch.int32, device="cuda")
+    ctxs = []
+    for c in range(NC):
+        ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=Bc, device=device)
+        b = {"img": d_img[c * Bc:(c + 1) * Bc], "kps": torch.empty((Bc, cap, 7), **i32),
+             "desc": torch.empty((Bc, cap, 32), dtype=torch.uint8, device="cuda"), "cnt": torch.zeros(Bc, **i32),
+             "wt": torch.empty((Bc, cap), dtype=torch.float32, device="cuda"), "nm": torch.zeros(Bc, **i32)}
+        for name in ("word", "node", "m12", "m21"):
+            b[name] = torch.empty((Bc, cap), **i32)
+        if blob is not None:
+            ORBVocabulary(ex).loadFromBinaryBlob(blob)
+        ctxs.append((ex, b))
+    L = ctxs[0][0]._L
+
+    def step():
+        for ex, b in ctxs:
+            ex.extract_batch_device(b["img"].data_ptr(), Bc, W, H, W, H * W, b["kps"].data_ptr(), b["desc"].data_ptr(), cap,
+                                    b["cnt"].data_ptr())
+            if blob is not None:
+                L.orbhip_vocab_transform_device(ex.handle, b["desc"].data_ptr(), Bc * cap, LEVELSUP, b["word"].data_ptr(),
+                                                b["wt"].data_ptr(), b["node"].data_ptr())
+                L.orbhip_search_by_bow_seq_device(ex.handle, b["desc"].data_ptr(), b["kps"].data_ptr(), b["cnt"].data_ptr(),
+                                                  b["node"].data_ptr(), b["wt"].data_ptr(), None, cap, Bc, 1, 0,
+                                                  C.c_float(NNRATIO), 1, b["m12"].data_ptr(), b["m21"].data_ptr(),
+                                                  b["nm"].data_ptr())
+    for _ in range(args.warmup):
+        step()
+    for ex, _ in ctxs:
+        ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for ex, _ in ctxs:
+        ex.sync()
+    dt = time.perf_counter() - t0
+    for ex, _ in ctxs:
+        ex.close()
+    return {"value": round(B * args.steps / dt, 1), "unit": "frames/s", "contexts": NC, "frames_per_launch": Bc,
+            "note": "same step, batch split over independent contexts / HIP streams, no per-step stage readout"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +145,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--match", choices=["bow", "brute", "both"], default="bow")
+    ap.add_argument("--contexts", type=int, default=1, help="extractor contexts the batch is split over in the timed region")
+    ap.add_argument("--pipelined", type=int, default=2, help="also report the free-running throughput with this many "
+                    "contexts (0 = skip); supplementary, never `value`")
     ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -103,57 +172,69 @@ def main():
     from orbhip.vocabulary import ORBVocabulary
 
     B = args.batch
+    NC = max(1, min(args.contexts, B))
+    while B % NC:
+        NC -= 1
+    Bc = B // NC                                           # frames per context
     # independent streams per rank (weak scaling: per-GPU work fixed)
     uniq = synth.make_frames(1000 + rank, W, H, min(args.unique, B))
     reps = (B + len(uniq) - 1) // len(uniq)
     frames = np.concatenate([uniq] * reps)[:B]
     d_img = torch.from_numpy(np.ascontiguousarray(frames)).cuda()          # (B, H, W), stride W (multiple of 16)
 
-    ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B, device=local_rank)
-    cap = ex.cap
-    L = ex._L
-    i32 = dict(dtype=torch.int32, device="cuda")
-    d_kps = torch.empty((B, cap, 7), **i32)
-    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda")
-    d_cnt = torch.zeros(B, **i32)
-    d_bi, d_bd, d_sd = (torch.empty((B, cap), **i32) for _ in range(3))
-    d_word, d_node, d_m12, d_m21 = (torch.empty((B, cap), **i32) for _ in range(4))
-    d_wt = torch.empty((B, cap), dtype=torch.float32, device="cuda")
-    d_nm = torch.zeros(B, **i32)
-
     # ORB vocabulary: reference binary format (TemplatedVocabulary.h:1727-1751), synthetic tree of the
     # stock shape (k=10, L=6, 1.11 M nodes, 45.6 MB).  Rank 0 builds it; N>1: one RCCL broadcast over xGMI.
     use_bow = args.match in ("bow", "both")
     blob = None
+    d_blob = None
     if use_bow or dist is not None:
         blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L) if rank == 0 else b""
         if dist is not None:
             d_blob = D.broadcast_blob(blob, src=0, device="cuda")
             torch.cuda.synchronize()
-            ORBVocabulary(ex).loadFromDeviceBlob(d_blob.data_ptr(), d_blob.numel())
-            del d_blob
-        else:
-            ORBVocabulary(ex).loadFromBinaryBlob(blob)
+
+    i32 = dict(dtype=torch.int32, device="cuda")
+    ctxs = []
+    for c in range(NC):
+        ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=Bc, device=local_rank)
+        cap = ex.cap
+        bufs = {"img": d_img[c * Bc:(c + 1) * Bc], "kps": torch.empty((Bc, cap, 7), **i32),
+                "desc": torch.empty((Bc, cap, 32), dtype=torch.uint8, device="cuda"), "cnt": torch.zeros(Bc, **i32),
+                "wt": torch.empty((Bc, cap), dtype=torch.float32, device="cuda"), "nm": torch.zeros(Bc, **i32)}
+        for name in ("bi", "bd", "sd", "word", "node", "m12", "m21"):
+            bufs[name] = torch.empty((Bc, cap), **i32)
+        if use_bow:
+            if d_blob is not None:
+                ORBVocabulary(ex).loadFromDeviceBlob(d_blob.data_ptr(), d_blob.numel())
+            else:
+                ORBVocabulary(ex).loadFromBinaryBlob(blob)
+        ctxs.append((ex, bufs))
+    del d_blob
+    ex0 = ctxs[0][0]
+    cap = ex0.cap
+    L = ex0._L
 
     def step():
-        ex.extract_batch_device(d_img.data_ptr(), B, W, H, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                d_cnt.data_ptr())
-        if use_bow:
-            rc = L.orbhip_vocab_transform_device(ex.handle, d_desc.data_ptr(), B * cap, LEVELSUP, d_word.data_ptr(),
-                                                 d_wt.data_ptr(), d_node.data_ptr())
-            assert rc == 0
-            rc = L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.data_ptr(), d_kps.data_ptr(), d_cnt.data_ptr(),
-                                                   d_node.data_ptr(), d_wt.data_ptr(), None, cap, B, 1, 0,
-                                                   C.c_float(NNRATIO), 1, d_m12.data_ptr(), d_m21.data_ptr(),
-                                                   d_nm.data_ptr())
-            assert rc == 0
-        if args.match in ("brute", "both"):
-            rc = L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.data_ptr(), d_cnt.data_ptr(), cap, B, 1,
-                                                  d_bi.data_ptr(), d_bd.data_ptr(), d_sd.data_ptr())
-            assert rc == 0
+        for ex, b in ctxs:
+            ex.extract_batch_device(b["img"].data_ptr(), Bc, W, H, W, H * W, b["kps"].data_ptr(), b["desc"].data_ptr(), cap,
+                                    b["cnt"].data_ptr())
+            if use_bow:
+                rc = L.orbhip_vocab_transform_device(ex.handle, b["desc"].data_ptr(), Bc * cap, LEVELSUP, b["word"].data_ptr(),
+                                                     b["wt"].data_ptr(), b["node"].data_ptr())
+                assert rc == 0
+                rc = L.orbhip_search_by_bow_seq_device(ex.handle, b["desc"].data_ptr(), b["kps"].data_ptr(), b["cnt"].data_ptr(),
+                                                       b["node"].data_ptr(), b["wt"].data_ptr(), None, cap, Bc, 1, 0,
+                                                       C.c_float(NNRATIO), 1, b["m12"].data_ptr(), b["m21"].data_ptr(),
+                                                       b["nm"].data_ptr())
+                assert rc == 0
+            if args.match in ("brute", "both"):
+                rc = L.orbhip_hamming_knn2_seq_device(ex.handle, b["desc"].data_ptr(), b["cnt"].data_ptr(), cap, Bc, 1,
+                                                      b["bi"].data_ptr(), b["bd"].data_ptr(), b["sd"].data_ptr())
+                assert rc == 0
 
     def barrier():
-        ex.sync()
+        for ex, _ in ctxs:
+            ex.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -162,14 +243,15 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    stage = np.zeros(6, np.float64)
+    stage = np.zeros(6, np.float64)          # per step: summed over the contexts
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         # stage device times (HIP events on the context streams; reading them waits for the step)
-        ms = (C.c_float * 6)()
-        assert L.orbhip_get_stage_times(ex.handle, ms) == 0
-        stage += np.array(list(ms))
+        for ex, _ in ctxs:
+            ms = (C.c_float * 6)()
+            assert L.orbhip_get_stage_times(ex.handle, ms) == 0
+            stage += np.array(list(ms))
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -178,19 +260,21 @@ def main():
         dt = float(t.item())
     stage /= max(args.steps, 1)
 
-    counts = d_cnt.cpu().numpy()
-    nmatch = float(d_nm.cpu().numpy()[1:].mean()) if (use_bow and B > 1) else None
-    nbrute = float((d_bd.cpu().numpy()[1:] <= 50).sum() / max(B - 1, 1)) if args.match in ("brute", "both") else None
+    counts = np.concatenate([b["cnt"].cpu().numpy() for _, b in ctxs])
+    nmatch = float(np.mean([b["nm"].cpu().numpy()[1:].mean() for _, b in ctxs])) if (use_bow and Bc > 1) else None
+    nbrute = float(np.mean([(b["bd"].cpu().numpy()[1:] <= 50).sum() / max(Bc - 1, 1) for _, b in ctxs])) \
+        if args.match in ("brute", "both") else None
 
     out = None
     if rank == 0:
         fps = world * B * args.steps / dt
-        alg = fast_algorithmic_bytes(W, H, 8, ex.level_size) * B          # bytes per FAST launch
-        fast_ms = float(stage[1])
+        alg = fast_algorithmic_bytes(W, H, 8, ex0.level_size) * Bc        # bytes per FAST launch (one per context)
+        fast_ms = float(stage[1]) / NC                                    # average duration of one launch
         achieved = alg / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
         match_desc = {"bow": "vocabulary transform (k=10, L=6, levelsup 4) + ORBmatcher::SearchByBoW(0.7, checkOri)",
                       "brute": "Hamming best/second brute force",
                       "both": "vocabulary transform + SearchByBoW + Hamming brute force"}[args.match]
+        traffic, traffic_src = committed_traffic(B, NC)
         out = {
             "metric": "ORB extract+match frames/sec @640x480/1000 feat",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -199,12 +283,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": "640x480 frames, 1000 features, 8 levels, scale 1.2, FAST 20/7; batched "
                                    "ORBextractor + " + match_desc + " of every frame vs its predecessor",
-                       "frames_per_step_per_gpu": B, "unique_frames": int(len(uniq)), "match": args.match,
+                       "frames_per_step_per_gpu": B, "contexts": NC, "frames_per_launch": Bc,
+                       "unique_frames": int(len(uniq)), "match": args.match,
                        "parallelism": "frames sharded, 1 process per GPU, no per-frame collective"},
             "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(fast_ms, 4),
-                         "note": "k_fast is integer-VALU/LDS bound, not HBM bound (DESIGN.md section 4)"},
+                         "note": "k_fast is integer-VALU bound (VALU issue ~100 % busy), not HBM bound (DESIGN.md section 4)"
+                                 + ("; launch_ms is measured while the other contexts' kernels share the GPU" if NC > 1 else "")},
             "stage_ms": {"pyramid": round(float(stage[0]), 4), "fast": round(float(stage[1]), 4),
                          "quadtree": round(float(stage[2]), 4), "blur": round(float(stage[3]), 4),
                          "describe": round(float(stage[4]), 4), "last_match_kernel": round(float(stage[5]), 4)},
@@ -212,10 +299,13 @@ def main():
             "bow_matches_per_frame": None if nmatch is None else round(nmatch, 1),
             "brute_matches_le_TH_LOW_per_frame": None if nbrute is None else round(nbrute, 1),
         }
+        if world == 1 and args.pipelined > 1 and B % args.pipelined == 0:
+            out["pipelined"] = pipelined_throughput(args, d_img, blob if use_bow else None, local_rank, cap)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(uniq, args.cpu_frames, args.match, blob)
             out["speedup_vs_cpu_1core"] = round(fps / out["cpu_baseline"]["value"], 1)
-    ex.close()
+    for ex, _ in ctxs:
+        ex.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

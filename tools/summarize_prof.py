@@ -43,6 +43,13 @@ def main(d):
         wa = sum(wt) / len(wt) if wt else float("nan")
         print("| %s | %d | %.2f | %.2f | %.3f | %.1f | %.2f | %.1f |" % (
             k, len(v), sum(tail) / len(tail), min(v), sum(v) / 1e3, fa, 2 * fa * 1024 / 1e6, wa))
+        if k == "k_fast" and ft and wt:
+            # machine-readable copy for bench.py's roofline.traffic (bytes per launch, FETCH_SIZE doubled)
+            import json
+            with open(os.path.join(d, "traffic.json"), "w") as fh:
+                json.dump({"kernel": "k_fast", "fetch_size_kb_raw": fa, "write_size_kb": wa,
+                           "traffic_bytes_per_launch": int(2 * fa * 1024 + wa * 1024), "avg_launch_us": sum(tail) / len(tail),
+                           "launches": len(v)}, fh)
 
 
 if __name__ == "__main__":

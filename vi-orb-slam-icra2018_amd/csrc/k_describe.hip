@@ -71,12 +71,14 @@ __device__ __forceinline__ int wave_sum(int v)
 //      sequence is evaluated once per keypoint by one lane instead of once per wave by 64 lanes;
 //   C. wave per keypoint again: the lane's four test pairs are decoded once (16 floats), then per keypoint 4 x
 //      (rotate, round, two byte gathers from the blurred level, compare, ballot).
-#define DS_KP 64
+// DS_KP = slots per workgroup: 64 for batches (throughput), 8 for a single frame or two (more workgroups,
+// shorter serial chains per wave: latency)
 #define DS_R 19                       // the rotated 31 x 31 pattern stays within 19 pixels of the keypoint
 #define DS_ROWS (2 * DS_R + 1)        // 39 patch rows
 #define DS_PDW 11                     // dwords per staged row: 39 bytes + up to 3 bytes of alignment
 #define DS_TRIPS ((DS_ROWS * DS_PDW + 63) / 64)   // 7
 
+template <int DS_KP>
 __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                                   int stride0, unsigned long long frame0,
                                                   const uint8_t *__restrict__ pyr,
@@ -322,8 +324,14 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
 {
-    dim3 grid(orb_xcd_grid((G.totalKps + DS_KP - 1) / DS_KP), B, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(k_describe, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
+    const int kpw = B >= 8 ? 64 : 8;
+    dim3 grid(orb_xcd_grid((G.totalKps + kpw - 1) / kpw), B, 1), block(256, 1, 1);
+    if (kpw == 64)
+        hipLaunchKernelGGL(k_describe<64>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
+                           (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc,
+                           counts, cap, orb_xcd_arg());
+    else
+        hipLaunchKernelGGL(k_describe<8>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt,
                        lvlAngle, kps, desc, counts, cap, orb_xcd_arg());
 }

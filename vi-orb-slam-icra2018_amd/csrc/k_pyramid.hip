@@ -2,20 +2,19 @@
 // 8UC1 (ref call site: src/ORBextractor.cc:1141).  The 19-px border of the reference
 // (copyMakeBorder :1143-1149) is never read by later stages and is not produced.
 //
-// One 256-thread workgroup per 128x16 output tile.  The source rows/columns the tile touches
-// (about 156 x 21 pixels at scale 1.2) are staged into LDS with 16-byte row-coalesced loads; a
+// One 256-thread workgroup per 128x32 output tile.  The source rows/columns the tile touches
+// (about 156 x 40 pixels at scale 1.2) are staged into LDS with 16-byte row-coalesced loads; a
 // thread then produces 4 horizontally adjacent output pixels from LDS and stores them as one
 // dword.  The column/row tap tables (source index pair + 11-bit weights) are built on the host
 // (orb_build_resize_tables).  Bound: HBM (reads 1.44 px and writes 1 px per output pixel).
 #include "orbhip_internal.h"
 
 #define RZ_TW 128
-#ifndef RZ_TH
-#define RZ_TH 32   // rows of a tile: four per thread
-#endif
+// RZ_TH = rows of a tile (RZ_TH / 8 per thread): 32 for batches, 8 for a single frame or two (4x the workgroups)
 #define RZ_MAXCH 16    // 16-byte chunks per staged source row (source span <= 240 px + alignment)
 #define RZ_MAXROWS 44  // staged source rows
 
+template <int RZ_TH>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sstride,
                                                 unsigned long long sframe, uint8_t *__restrict__ dst,
                                                 int dw, int dh, int dstride, unsigned long long dframe,
@@ -111,8 +110,14 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
     (void)sw;
     (void)sh;
     dim3 block(256, 1, 1);
-    dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + RZ_TH - 1) / RZ_TH)), B, 1);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh,
-                       dstride, (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
-                       reinterpret_cast<const int4 *>(ytab), orb_xcd_arg());
+    const int th = B >= 8 ? 32 : 8;
+    dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + th - 1) / th)), B, 1);
+    if (th == 32)
+        hipLaunchKernelGGL(k_resize<32>, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
+                           (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
+                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg());
+    else
+        hipLaunchKernelGGL(k_resize<8>, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
+                           (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
+                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg());
 }
