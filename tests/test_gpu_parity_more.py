@@ -1,0 +1,79 @@
+"""More parity cases for the extraction path: unusual pyramid parameters (the non-staged resize path, one level,
+twelve levels), a large frame, frames without corners, and a batch that mixes them -- single-frame kernels and
+the batch variants (8 frames and more) alike.  Bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return len(a) == len(b) and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("scale,nlev,ini,mn,nf,w,h", [
+    (1.1, 12, 20, 7, 1500, 640, 480),      # many shallow levels
+    (1.5, 5, 20, 7, 800, 640, 480),        # source window of a resize tile exceeds the LDS stage: generic path
+    (2.0, 3, 25, 5, 500, 752, 480),
+    (1.2, 1, 20, 7, 300, 320, 240),        # a single level: no resize at all
+    (1.3, 3, 40, 12, 200, 400, 300),       # high thresholds: many cells fall back to minThFAST
+])
+def test_unusual_pyramid_parameters(oracle, scale, nlev, ini, mn, nf, w, h):
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    frames = synth.make_frames(300 + nlev, w, h, 2)
+    ref = oracle.Extractor(nf, scale, nlev, ini, mn)
+    ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h)
+    k, d = ex(frames[0])
+    rk, rd = ref(frames[0])
+    for l in range(nlev):
+        assert np.array_equal(ex.image_pyramid(l), ref.pyramid(l)), "pyramid level %d" % l
+    assert _same(k, rk) and np.array_equal(d, rd) and len(rk) > 50
+    ex.close()
+    # the same through the batch kernels (>= 8 frames)
+    exb = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=8)
+    ks, ds = exb.extract_batch(np.stack([frames[0], frames[1]] * 4))
+    rk1, rd1 = ref(frames[1])
+    for b in range(8):
+        assert _same(ks[b], rk if b % 2 == 0 else rk1) and np.array_equal(ds[b], rd if b % 2 == 0 else rd1), "frame %d" % b
+    exb.close()
+
+
+def test_full_hd_frame_4000_features(oracle):
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    img = synth.make_frames(77, 1920, 1080, 1)[0]
+    ex = ORBextractor(4000, max_w=1920, max_h=1080)
+    ref = oracle.Extractor(4000)
+    k, d = ex(img)
+    rk, rd = ref(img)
+    assert _same(k, rk) and np.array_equal(d, rd) and len(rk) >= 4000
+    ex.close()
+
+
+def test_frames_without_corners_and_mixed_batch(oracle):
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    W, H = 640, 480
+    rng = np.random.default_rng(5)
+    flat = np.full((H, W), 117, np.uint8)
+    ramp = np.tile(np.linspace(0, 255, W).astype(np.uint8), (H, 1))                 # gradient: no FAST corners
+    faint = (118 + 5 * ((np.add.outer(np.arange(H) // 24, np.arange(W) // 24)) % 2)).astype(np.uint8)   # contrast 5 < minTh
+    weak = (110 + 12 * ((np.add.outer(np.arange(H) // 17, np.arange(W) // 19)) % 2)).astype(np.uint8)   # only minThFAST fires
+    weak = np.clip(weak.astype(np.int32) + rng.integers(-1, 2, (H, W)), 0, 255).astype(np.uint8)
+    normal = synth.make_frames(6, W, H, 4)
+    ref = oracle.Extractor(1000)
+    ex = ORBextractor(1000, max_w=W, max_h=H)
+    for name, img in (("flat", flat), ("ramp", ramp), ("faint", faint), ("weak", weak)):
+        k, d = ex(img)
+        rk, rd = ref(img)
+        assert _same(k, rk) and d.shape == rd.shape and np.array_equal(d, rd), name
+    assert len(ref(flat)[0]) == 0 and len(ref(weak)[0]) > 0
+    ex.close()
+    batch = np.stack([normal[0], flat, normal[1], weak, ramp, normal[2], faint, normal[3], flat])
+    exb = ORBextractor(1000, max_w=W, max_h=H, max_batch=len(batch))
+    ks, ds = exb.extract_batch(batch)
+    for b, img in enumerate(batch):
+        rk, rd = ref(img)
+        assert _same(ks[b], rk) and np.array_equal(ds[b].reshape(-1, 32), rd.reshape(-1, 32)), "frame %d" % b
+    exb.close()
