@@ -6,8 +6,10 @@
 //     Frame::ComputeBoW src/Frame.cc:739-746 with levelsup = 4): descend from the root taking at every
 //     level the child with the smallest Hamming distance (FORB::distance, FORB.cpp:82-103; first child
 //     wins ties), return the leaf's word id and weight and the node id at level L - levelsup.
-// One thread per descriptor: the descriptor stays in 8 VGPRs, each candidate child is two 16-byte
-// loads; the upper tree levels are L2-resident, the 32 MB leaf level sits in the Infinity Cache.
+// One thread per descriptor: the descriptor stays in 8 VGPRs.  The tables are stored by edge (children of a
+// node consecutive), so a level is two dependent memory round trips -- the child range of the node just chosen,
+// then the descriptors of ten children at a time in flight together -- instead of two per child; the upper
+// tree levels are L2-resident, the 32 MB leaf level sits in the Infinity Cache.
 // k * L = 60 Hamming distances per feature for the stock vocabulary (k = 10, L = 6).
 #include "orbhip_internal.h"
 
@@ -64,22 +66,45 @@ int orb_vocab_parse(const uint8_t *blob, size_t nbytes, OrbVocabHost &V, std::st
         if (V.leaf[id]) V.word[id] = nwords++;              // words numbered in leaf order (:1707-1712)
     }
     V.nwords = nwords;
-    // an inner node without children would make the descent loop forever
-    for (uint32_t id = 0; id < nb_nodes; id++)
-        if (!V.leaf[id] && V.childOff[id] == V.childOff[id + 1]) {
-            err = "vocabulary inner node without children";
+    // The reference descends while the node has children (Node::isLeaf() = children.empty(),
+    // TemplatedVocabulary.h) and treats the file's is_leaf flag as "this node is a word"; a file in which the two
+    // disagree is malformed (an inner node without children would make the descent loop forever).
+    for (uint32_t id = 0; id < nb_nodes; id++) {
+        const bool noChildren = V.childOff[id] == V.childOff[id + 1];
+        if (id > 0 && (V.leaf[id] != 0) != noChildren) {
+            err = V.leaf[id] ? "vocabulary leaf node with children" : "vocabulary inner node without children";
             return ORBHIP_E_ARG;
         }
+        if (id == 0 && noChildren) {
+            err = "vocabulary root without children";
+            return ORBHIP_E_ARG;
+        }
+    }
+    const size_t ne = (size_t)nb_nodes - 1;
+    V.edesc.resize(ne * 32);
+    V.erange.resize(ne * 2);
+    V.eword.resize(ne);
+    V.eweight.resize(ne);
+    for (size_t e = 0; e < ne; e++) {
+        const int id = V.child[e];
+        memcpy(&V.edesc[e * 32], &V.desc[(size_t)id * 32], 32);
+        V.erange[2 * e] = V.childOff[id];
+        V.erange[2 * e + 1] = V.childOff[id + 1];
+        V.eword[e] = V.word[id];
+        V.eweight[e] = V.weight[id];
+    }
     return ORBHIP_OK;
 }
 
+#define VT_CHUNK 10   // children whose descriptors are in flight together (2 x 16 bytes each; the stock tree has k = 10)
+
 __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restrict__ desc, int n, int nidLevel,
-                                                         const uint8_t *__restrict__ vdesc,
-                                                         const int32_t *__restrict__ childOff,
-                                                         const int32_t *__restrict__ child,
-                                                         const uint8_t *__restrict__ leaf,
-                                                         const int32_t *__restrict__ word,
-                                                         const float *__restrict__ vweight,
+                                                         int rootFirst, int rootLast,
+                                                         const uint4 *__restrict__ edesc,
+                                                         const int2 *__restrict__ erange,
+                                                         const int32_t *__restrict__ eid,
+                                                         const int32_t *__restrict__ eword,
+                                                         const float *__restrict__ eweight,
                                                          int32_t *__restrict__ word_id, float *__restrict__ weight,
                                                          int32_t *__restrict__ node_id)
 {
@@ -87,27 +112,37 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restri
     if (i >= n) return;
     const uint4 a = reinterpret_cast<const uint4 *>(desc + (size_t)i * 32)[0];
     const uint4 b = reinterpret_cast<const uint4 *>(desc + (size_t)i * 32)[1];
-    int nid = 0, final_id = 0, level = 0;
+    int c0 = rootFirst, c1 = rootLast, level = 0, nidEdge = -1, e = 0;
     do {
         ++level;
-        const int c0 = childOff[final_id], c1 = childOff[final_id + 1];
-        int best_d = 1 << 30;
-        for (int c = c0; c < c1; c++) {
-            const int id = child[c];
-            const uint4 p = reinterpret_cast<const uint4 *>(vdesc + (size_t)id * 32)[0];
-            const uint4 q = reinterpret_cast<const uint4 *>(vdesc + (size_t)id * 32)[1];
-            const int d = __popc(a.x ^ p.x) + __popc(a.y ^ p.y) + __popc(a.z ^ p.z) + __popc(a.w ^ p.w) +
-                          __popc(b.x ^ q.x) + __popc(b.y ^ q.y) + __popc(b.z ^ q.z) + __popc(b.w ^ q.w);
-            if (d < best_d) {   // strict: the first child wins ties (:1470)
-                best_d = d;
-                final_id = id;
+        // key = distance << 20 | position among the children: the minimum is the first child with the smallest
+        // distance (strict '<' over the children in order, :1470)
+        unsigned best = 0xFFFFFFFFu;
+        for (int cb = c0; cb < c1; cb += VT_CHUNK) {
+            uint4 p[VT_CHUNK], q[VT_CHUNK];
+#pragma unroll
+            for (int j = 0; j < VT_CHUNK; j++) {          // unconditional loads from clamped edges, issued together
+                const int c = min(cb + j, c1 - 1);
+                p[j] = edesc[2 * (size_t)c];
+                q[j] = edesc[2 * (size_t)c + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < VT_CHUNK; j++) {
+                const unsigned d = __popc(a.x ^ p[j].x) + __popc(a.y ^ p[j].y) + __popc(a.z ^ p[j].z) + __popc(a.w ^ p[j].w) +
+                                   __popc(b.x ^ q[j].x) + __popc(b.y ^ q[j].y) + __popc(b.z ^ q[j].z) + __popc(b.w ^ q[j].w);
+                const unsigned key = (d << 20) | (unsigned)(cb + j - c0);
+                if (cb + j < c1) best = min(best, key);
             }
         }
-        if (level == nidLevel) nid = final_id;
-    } while (!leaf[final_id]);
-    word_id[i] = word[final_id];
-    weight[i] = vweight[final_id];
-    node_id[i] = nid;
+        e = c0 + (int)(best & 0xFFFFFu);
+        if (level == nidLevel) nidEdge = e;
+        const int2 r = erange[e];
+        c0 = r.x;
+        c1 = r.y;
+    } while (c0 < c1);
+    word_id[i] = eword[e];
+    weight[i] = eweight[e];
+    node_id[i] = nidEdge >= 0 ? eid[nidEdge] : 0;
 }
 
 void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *desc, int n, int levelsup,
@@ -115,5 +150,6 @@ void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_vocab_transform, dim3((n + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, desc, n, V.L - levelsup,
-                       V.desc, V.childOff, V.child, V.leaf, V.word, V.weight, word_id, weight, node_id);
+                       V.rootFirst, V.rootLast, reinterpret_cast<const uint4 *>(V.desc), reinterpret_cast<const int2 *>(V.erange),
+                       V.eid, V.eword, V.eweight, word_id, weight, node_id);
 }

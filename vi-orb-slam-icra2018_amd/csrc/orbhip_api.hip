@@ -778,29 +778,31 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
     int rc = orb_vocab_parse((const uint8_t *)blob, nbytes, H, err);
     if (rc != ORBHIP_OK) return fail(c, rc, "orbhip_vocab_load: " + err);
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t nn = (size_t)H.nnodes;
-    // one device block, 256-byte aligned sections
-    size_t off[6], total = 0;
-    const size_t sizes[6] = {nn * 32, nn, nn * 4, nn * 4, (nn + 1) * 4, nn * 4};
-    for (int i = 0; i < 6; i++) {
+    const size_t ne = (size_t)H.nnodes - 1;
+    // one device block, 256-byte aligned sections (tables by edge, see OrbVocabDev)
+    size_t off[5], total = 0;
+    const size_t sizes[5] = {ne * 32, ne * 8, ne * 4, ne * 4, ne * 4};
+    for (int i = 0; i < 5; i++) {
         off[i] = total;
         total += align_up(sizes[i], 256);
     }
     if (c->d_vocBlock) HIPCHK(c, hipFree(c->d_vocBlock));
     c->d_vocBlock = nullptr;
+    c->voc = OrbVocabDev();
     HIPCHK(c, hipMalloc(&c->d_vocBlock, total));
     uint8_t *base = (uint8_t *)c->d_vocBlock;
-    const void *src[6] = {H.desc.data(), H.leaf.data(), H.weight.data(), H.word.data(), H.childOff.data(), H.child.data()};
-    for (int i = 0; i < 6; i++) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
+    const void *src[5] = {H.edesc.data(), H.erange.data(), H.child.data(), H.eword.data(), H.eweight.data()};
+    for (int i = 0; i < 5; i++) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     OrbVocabDev &V = c->voc;
     V.k = H.k; V.L = H.L; V.scoring = H.scoring; V.weighting = H.weighting; V.nnodes = H.nnodes; V.nwords = H.nwords;
+    V.rootFirst = H.childOff[0];
+    V.rootLast = H.childOff[1];
     V.desc = base + off[0];
-    V.leaf = base + off[1];
-    V.weight = (float *)(base + off[2]);
-    V.word = (int32_t *)(base + off[3]);
-    V.childOff = (int32_t *)(base + off[4]);
-    V.child = (int32_t *)(base + off[5]);
+    V.erange = (int32_t *)(base + off[1]);
+    V.eid = (int32_t *)(base + off[2]);
+    V.eword = (int32_t *)(base + off[3]);
+    V.eweight = (float *)(base + off[4]);
     return ORBHIP_OK;
 }
 

@@ -69,19 +69,29 @@ struct BlurTile {
     short level, tx, ty, pad;
 };
 
-// ORB vocabulary: host-side parse result and the device tables (structure of arrays,
-// indexed by node id; id 0 = root).
+// ORB vocabulary: host-side parse result and the device tables.  The device tables are indexed
+// by EDGE (position in the children CSR: the children of a node are consecutive, in file order), so that a
+// descent step is two memory round trips: the child range of the current node, then all its children's
+// descriptors at once.  id 0 = root (no edge).
 struct OrbVocabHost {
     int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0;
-    std::vector<uint8_t> desc, leaf;
-    std::vector<float> weight;
+    std::vector<uint8_t> desc, leaf;          // by node id
+    std::vector<float> weight;                // by node id
     std::vector<int32_t> word, childOff, child;
+    // by edge e (child[e] = node id of the e-th edge)
+    std::vector<uint8_t> edesc;               // descriptor of the child
+    std::vector<int32_t> erange;              // 2 per edge: child range [first, last) of the child
+    std::vector<int32_t> eword;               // word id of the child (-1 for inner nodes)
+    std::vector<float> eweight;
 };
 struct OrbVocabDev {
     int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0;
-    uint8_t *desc = nullptr, *leaf = nullptr;
-    float *weight = nullptr;
-    int32_t *word = nullptr, *childOff = nullptr, *child = nullptr;
+    int rootFirst = 0, rootLast = 0;          // child range of the root
+    uint8_t *desc = nullptr;                  // [nnodes - 1][32] by edge
+    int32_t *erange = nullptr;                // [nnodes - 1][2]
+    int32_t *eid = nullptr;                   // [nnodes - 1] node id
+    int32_t *eword = nullptr;
+    float *eweight = nullptr;
 };
 
 struct orbhip_ctx {
