@@ -156,25 +156,36 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
         const uint4 q3 = *reinterpret_cast<const uint4 *>(&s_pair[rp + 3][g << 2]);
         const uint32_t c0[4] = {q0.x, q0.y, q0.z, q0.w}, c1[4] = {q1.x, q1.y, q1.z, q1.w};
         const uint32_t c2[4] = {q2.x, q2.y, q2.z, q2.w}, c3[4] = {q3.x, q3.y, q3.z, q3.w};
-        uint32_t packedA = 0, packedB = 0;
-        const bool body = xb + 3 < wvec;   // every pixel of the group is in the SSE2 body (the usual case)
+        uint32_t sa[4], sb[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wa0, 0u, false);
-            sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wa1, sa, false);
-            sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wa2, sa, false);
-            sa = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wa3, sa, false);
-            uint32_t sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wb0, 0u, false);
-            sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wb1, sb, false);
-            sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wb2, sb, false);
-            sb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wb3, sb, false);
-            // SSE2 body (x < wvec): round half to even = (s + 0x7FFF + bit16(s)) >> 16;
-            // scalar tail: round half up = (s + 0x8000) >> 16
-            const bool even = body || (xb + k < wvec);
-            const uint32_t ba = even ? 0x7FFFu + ((sa >> 16) & 1u) : 0x8000u;
-            const uint32_t bb = even ? 0x7FFFu + ((sb >> 16) & 1u) : 0x8000u;
-            packedA |= min((sa + ba) >> 16, 255u) << (8 * k);
-            packedB |= min((sb + bb) >> 16, 255u) << (8 * k);
+            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wa0, 0u, false);
+            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wa1, sa[k], false);
+            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wa2, sa[k], false);
+            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wa3, sa[k], false);
+            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wb0, 0u, false);
+            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wb1, sb[k], false);
+            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wb2, sb[k], false);
+            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wb3, sb[k], false);
+        }
+        // SSE2 body (x < wvec): round half to even = (s + 0x7FFF + bit16(s)) >> 16;
+        // scalar tail: round half up = (s + 0x8000) >> 16
+        uint32_t packedA = 0, packedB = 0;
+        if (xb + 3 < wvec) {   // every pixel of the group is in the body (all but the last group of a row)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                packedA |= min((sa[k] + 0x7FFFu + ((sa[k] >> 16) & 1u)) >> 16, 255u) << (8 * k);
+                packedB |= min((sb[k] + 0x7FFFu + ((sb[k] >> 16) & 1u)) >> 16, 255u) << (8 * k);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool even = xb + k < wvec;
+                const uint32_t ba = even ? 0x7FFFu + ((sa[k] >> 16) & 1u) : 0x8000u;
+                const uint32_t bb = even ? 0x7FFFu + ((sb[k] >> 16) & 1u) : 0x8000u;
+                packedA |= min((sa[k] + ba) >> 16, 255u) << (8 * k);
+                packedB |= min((sb[k] + bb) >> 16, 255u) << (8 * k);
+            }
         }
         uint8_t *o = dst + (size_t)y * dstride + xb;
         if (xb + 3 < w) {
