@@ -73,10 +73,10 @@ __device__ __forceinline__ int wave_sum(int v)
 //      (rotate, round, two byte gathers from the blurred level, compare, ballot).
 // DS_KP = slots per workgroup: 64 for batches (throughput), 8 for a single frame or two (more workgroups,
 // shorter serial chains per wave: latency)
-#define DS_R 19                       // the rotated 31 x 31 pattern stays within 19 pixels of the keypoint
-#define DS_ROWS (2 * DS_R + 1)        // 39 patch rows
-#define DS_PDW 11                     // dwords per staged row: 39 bytes + up to 3 bytes of alignment
-#define DS_TRIPS ((DS_ROWS * DS_PDW + 63) / 64)   // 7
+#define DS_R 18                       // pattern radius <= 18.385, so a rotated, rounded coordinate is at most 18
+#define DS_ROWS (2 * DS_R + 1)        // 37 patch rows
+#define DS_PDW 10                     // dwords per staged row: 37 bytes + up to 3 bytes of alignment
+#define DS_TRIPS ((DS_ROWS * DS_PDW + 63) / 64)   // 6
 
 template <int DS_KP>
 __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
     __syncthreads();
 
     // ---- C. E7: steered BRIEF on the blurred level ----
-    // The 39 x 39 neighbourhood of the keypoint (the rotated pattern stays within 19 pixels) is staged per wave in
-    // LDS with row-coalesced dword loads (11 dwords per row, 7 trips), software-pipelined like phase A; the 512
+    // The 37 x 37 neighbourhood of the keypoint (the rotated pattern stays within 18 pixels) is staged per wave in
+    // LDS with row-coalesced dword loads (10 dwords per row, 6 trips), software-pipelined like phase A; the 512
     // test pixels are then LDS byte reads.  A byte gather straight from memory touches up to 64 cache lines per
     // wave instruction; the staged form touches each line once.
     float px0[4], py0[4], px1[4], py1[4];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
 #pragma unroll
     for (int it = 0; it < DS_TRIPS; it++) {
         const int idx = min(it * 64 + lane, DS_ROWS * DS_PDW - 1);
-        prow[it] = (int)(((unsigned)idx * 5958u) >> 16);   // idx / 11 for idx < 448
+        prow[it] = (int)(((unsigned)idx * 6554u) >> 16);   // idx / 10 for idx < 384
         pdw[it] = idx - prow[it] * DS_PDW;
     }
     auto load7 = [&](int kp, uint32_t wd[DS_TRIPS]) {
