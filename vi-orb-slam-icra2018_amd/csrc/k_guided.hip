@@ -5,6 +5,8 @@
 //                   GetFeaturesInArea) with LDS counters; cells are then sorted ascending, which is the
 //                   push_back order of the reference;
 //   k_area_list     GetFeaturesInArea for a batch of windows (one thread per window);
+//   k_proj_records  the frame's features in CSR order as 16-byte records {x, y, octave | index}, so that a window walk
+//                   reads consecutive memory instead of chasing cell entry -> keypoint;
 //   k_proj_cands    one thread per projected point: walks its window, keeps the features that pass the octave,
 //                   distance and right-coordinate tests, in the reference's order, with their descriptor
 //                   distance -- everything that does not depend on which features earlier points took;
@@ -153,12 +155,44 @@ __device__ __forceinline__ int hamming256g(const uint4 a0, const uint4 a1, const
            __popc(a1.y ^ r1.y) + __popc(a1.z ^ r1.z) + __popc(a1.w ^ r1.w);
 }
 
+// The features of a frame in CSR order as compact records {x, y, octave | index << 8}: the window walk of
+// k_proj_cands then reads consecutive 16-byte records instead of following cell entry -> keypoint (two dependent
+// memory round trips per examined feature).
+__global__ __launch_bounds__(256) void k_proj_records(const orbhip_keypoint *__restrict__ kps, int cap,
+                                                      const int32_t *__restrict__ cellOff,
+                                                      const int32_t *__restrict__ cellIdx, float4 *__restrict__ rec)
+{
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cellOff[(size_t)b * (GCELLS + 1) + GCELLS]) return;
+    const int idx = cellIdx[(size_t)b * cap + j];
+    const orbhip_keypoint k = kps[(size_t)b * cap + idx];
+    rec[(size_t)b * cap + j] = make_float4(k.x, k.y, __int_as_float((k.octave & 255) | (idx << 8)), 0.f);
+}
+
+template <typename F>
+__device__ __forceinline__ void walk_window_rec(const GridParams &gp, const orbhip_proj_query &q,
+                                                const float4 *__restrict__ R, const int32_t *__restrict__ O, F f)
+{
+    int x0, x1, y0, y1;
+    if (!window_cells(gp, q.u, q.v, q.radius, x0, x1, y0, y1)) return;
+    for (int ix = x0; ix <= x1; ix++) {
+        const int s = O[ix * GROWS + y0], e = O[ix * GROWS + y1 + 1];
+        for (int j = s; j < e; j++) {
+            const float4 r = R[j];
+            const int w = __float_as_int(r.z), oct = w & 255;
+            if (oct < q.min_level) continue;
+            if (q.max_level >= 0 && oct > q.max_level) continue;
+            if (fabsf(__fsub_rn(r.x, q.u)) < q.radius && fabsf(__fsub_rn(r.y, q.v)) < q.radius) f(w >> 8, oct);
+        }
+    }
+}
+
 // candidate tuple: distance (9 bits) | octave << 9 (4 bits) | feature index << 13
 __global__ __launch_bounds__(256) void k_proj_cands(const orbhip_keypoint *__restrict__ kps,
                                                     const uint8_t *__restrict__ desc, int cap,
                                                     const float *__restrict__ uRight, const GridParams gp,
                                                     const int32_t *__restrict__ cellOff,
-                                                    const int32_t *__restrict__ cellIdx,
+                                                    const float4 *__restrict__ rec,
                                                     const orbhip_proj_query *__restrict__ queries,
                                                     const uint8_t *__restrict__ qdesc, const int32_t *__restrict__ nq,
                                                     int capQ, int capQpad, int keff, uint32_t *__restrict__ tuples,
@@ -172,11 +206,10 @@ __global__ __launch_bounds__(256) void k_proj_cands(const orbhip_keypoint *__res
         if (q.flags & ORBHIP_Q_ACTIVE) {
             const uint4 *qd = reinterpret_cast<const uint4 *>(qdesc + ((size_t)b * capQ + iq) * 32);
             const uint4 a0 = qd[0], a1 = qd[1];
-            const orbhip_keypoint *K = kps + (size_t)b * cap;
             const uint4 *D = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
             const float *UR = uRight ? uRight + (size_t)b * cap : nullptr;
             uint32_t *T = tuples + ((size_t)b * capQpad + iq) * PROJ_K;
-            walk_window(gp, q, K, cellOff + (size_t)b * (GCELLS + 1), cellIdx + (size_t)b * cap, [&](int idx, int oct) {
+            walk_window_rec(gp, q, rec + (size_t)b * cap, cellOff + (size_t)b * (GCELLS + 1), [&](int idx, int oct) {
                 if (UR) {
                     const float ur = UR[idx];
                     if (ur > 0 && fabsf(__fsub_rn(q.proj_xr, ur)) > q.radius) return;   // :92-97, :1418-1424
@@ -426,10 +459,10 @@ int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, floa
     return ORBHIP_OK;
 }
 
-size_t proj_scratch_bytes(int B, int capQ)
+size_t proj_scratch_bytes(int B, int capQ, int cap)
 {
     const size_t capQpad = ((size_t)capQ + 63) / 64 * 64;
-    return (size_t)B * capQpad * (PROJ_K * 4 + 4 + 4);
+    return (size_t)B * capQpad * (PROJ_K * 4 + 4 + 4) + (size_t)B * cap * 16 + 256;
 }
 
 size_t proj_assign_lds(int cap) { return (size_t)cap * 4 + (size_t)((cap + 31) / 32) * 4; }
@@ -442,12 +475,14 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
 {
     const GridParams gp = {minX, minY, invW, invH};
     const int capQpad = (capQ + 63) / 64 * 64;
-    uint32_t *tuples = (uint32_t *)scratch;
+    float4 *rec = (float4 *)scratch;                                   // scratch base is 256-byte aligned
+    uint32_t *tuples = (uint32_t *)(rec + (size_t)B * cap);
     int32_t *tcount = (int32_t *)(tuples + (size_t)B * capQpad * PROJ_K);
     int32_t *qfeat = tcount + (size_t)B * capQpad;
     const int keff = proj_keff();
+    hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
     hipLaunchKernelGGL(k_proj_cands, dim3((capQpad + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, desc, cap, uRight, gp,
-                       cellOff, cellIdx, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
+                       cellOff, rec, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
     hipLaunchKernelGGL(k_proj_assign, dim3(B, 1, 1), dim3(64, 1, 1), proj_assign_lds(cap), s, kps, desc, cnt, cap, uRight,
                        occupied, gp, cellOff, cellIdx, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount, qfeat,
                        use_ratio, nnratio, check_ori, th_high, match, nmatches);

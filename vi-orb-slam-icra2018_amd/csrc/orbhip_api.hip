@@ -1053,7 +1053,7 @@ extern "C" int orbhip_search_by_projection_device(orbhip_ctx *c, const void *d_k
         return fail(c, ORBHIP_E_ARG, "orbhip_search_by_projection_device: cap too large for the per-frame match table in LDS");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = match_scratch(c, proj_scratch_bytes(B, cap_q)))) return rc;
+    if ((rc = match_scratch(c, proj_scratch_bytes(B, cap_q, cap)))) return rc;
     launch_search_by_projection(c->stream, (const orbhip_keypoint *)d_kps, (const uint8_t *)d_desc, (const int32_t *)d_counts,
                                 cap, B, (const float *)d_u_right, (const uint8_t *)d_occupied, min_x, min_y, inv_w, inv_h,
                                 (const int32_t *)d_cell_off, (const int32_t *)d_cell_idx, (const orbhip_proj_query *)d_queries,

@@ -266,7 +266,7 @@ int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *
 int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, float minY, float invW, float invH,
                      const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries, int nq, int slots,
                      int32_t *outCnt, int32_t *outIdx);
-size_t proj_scratch_bytes(int B, int capQ);
+size_t proj_scratch_bytes(int B, int capQ, int cap);
 size_t proj_assign_lds(int cap);
 int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const uint8_t *desc, const int32_t *cnt, int cap,
                                 int B, const float *uRight, const uint8_t *occupied, float minX, float minY, float invW,
