@@ -116,7 +116,10 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     int maxNodes = 0;
     for (int l = 0; l < G.nlevels; l++) maxNodes = std::max(maxNodes, G.lv[l].kpCap);
     const int qtBytes = (int)((qt_shared_bytes(maxNodes) + 15) & ~(size_t)15);
-    static const int nthreads = getenv("ORBHIP_QT_THREADS") ? atoi(getenv("ORBHIP_QT_THREADS")) : 256;
+    // more threads were measured not to shorten the level-0 workgroup (its passes are barrier / LDS-latency chains);
+    // the switch accepts 64..256 (the kernel's launch bound)
+    static const int forced = getenv("ORBHIP_QT_THREADS") ? atoi(getenv("ORBHIP_QT_THREADS")) : 256;
+    const int nthreads = forced >= 64 && forced <= 256 && forced % 64 == 0 ? forced : 256;
     dim3 grid(G.nlevels, B, 1), block(nthreads, 1, 1);
     hipLaunchKernelGGL(k_quadtree, grid, block, quadtree_lds_bytes(G), s, G, cand, cellCnt, pts, pnode,
                        lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes);
