@@ -325,13 +325,13 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
 {
     const int kpw = B >= 8 ? 64 : 8;
-    dim3 grid(orb_xcd_grid((G.totalKps + kpw - 1) / kpw), B, 1), block(256, 1, 1);
+    dim3 grid(orb_xcd_grid((G.totalKps + kpw - 1) / kpw, 1), B, 1), block(256, 1, 1);
     if (kpw == 64)
         hipLaunchKernelGGL(k_describe<64>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                            (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc,
-                           counts, cap, orb_xcd_arg());
+                           counts, cap, orb_xcd_arg(1));
     else
         hipLaunchKernelGGL(k_describe<8>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt,
-                       lvlAngle, kps, desc, counts, cap, orb_xcd_arg());
+                       lvlAngle, kps, desc, counts, cap, orb_xcd_arg(1));
 }

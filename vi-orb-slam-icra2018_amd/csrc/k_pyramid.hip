@@ -111,13 +111,13 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
     (void)sh;
     dim3 block(256, 1, 1);
     const int th = B >= 8 ? 32 : 8;
-    dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + th - 1) / th)), B, 1);
+    dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + th - 1) / th), 1), B, 1);
     if (th == 32)
         hipLaunchKernelGGL(k_resize<32>, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
                            (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
-                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg());
+                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg(1));
     else
         hipLaunchKernelGGL(k_resize<8>, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
                            (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
-                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg());
+                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg(1));
 }

@@ -213,7 +213,7 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
                       const int32_t *off2, const int32_t *idx2, const int32_t *pairs, int npairs,
                       int th, int th_mode, float nnratio, int32_t *match12, int32_t *match21);
 
-// XCD-aware work assignment for (tile, frame) grids -- an OPTION, off by default.  Workgroups are dealt
+// XCD-aware work assignment for (tile, frame) grids -- a per-kernel default (see orb_xcd_map), off for k_fast.  Workgroups are dealt
 // round-robin over the 8 XCDs by linear id (MI355X_MICROARCH.md, "Workgroup dispatch"; placement affects speed
 // only).  With ORBHIP_XCD_MAP != 0 the grid's x extent is padded to a multiple of 8, workgroup x of a frame runs
 // on XCD x % 8 and takes a tile from a contiguous eighth of the frame's tiles, so the 128-byte lines that
@@ -226,7 +226,7 @@ static inline int orb_xcd_map(int dflt = 0)
 {
     static int v = -2;
     if (v == -2) v = getenv("ORBHIP_XCD_MAP") ? atoi(getenv("ORBHIP_XCD_MAP")) : -1;
-    return v >= 0 ? v : dflt;   // k_blur's tiles cost the same everywhere: plain bands (2) are its default
+    return v >= 0 ? v : dflt;   // per-kernel defaults: k_blur 2 (uniform tiles), k_describe / k_resize 1, k_fast 0
 }
 static inline int orb_xcd_chunk();
 static inline int orb_xcd_arg(int dflt = 0);
