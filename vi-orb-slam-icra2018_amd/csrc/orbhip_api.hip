@@ -372,17 +372,23 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
     const int dcap = (int)c->cap_out;
     if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, c->d_kps, c->d_desc, c->d_counts, dcap)))
         return rc;
-    HIPCHK(c, hipMemcpyAsync(n_out, c->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+    // results: counts, keypoints and descriptors go to pinned staging in three asynchronous copies behind the
+    // kernels and ONE synchronisation (waiting for the counts first would cost a second device round trip per
+    // call -- most of a single frame's overhead); the n[b] valid entries are then copied out on the host
+    const size_t kbytes = (size_t)B * dcap * sizeof(orbhip_keypoint), dbytes = (size_t)B * dcap * 32, cbytes = (size_t)B * 4;
+    const size_t koff = 0, doff = align_up(kbytes, 256), coff = doff + align_up(dbytes, 256);
+    if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_stage + coff, c->d_counts, cbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_stage + koff, c->d_kps, kbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_stage + doff, c->d_desc, dbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(n_out, c->h_stage + coff, cbytes);
     for (int b = 0; b < B; b++) {
         const int n = n_out[b];
         if (n > cap || n > dcap) return fail(c, ORBHIP_E_CAPACITY, "orbhip_extract_batch: output capacity too small");
-        HIPCHK(c, hipMemcpyAsync(kps + (size_t)b * cap, c->d_kps + (size_t)b * dcap, (size_t)n * sizeof(orbhip_keypoint),
-                                 hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(desc + (size_t)b * cap * 32, c->d_desc + (size_t)b * dcap * 32, (size_t)n * 32,
-                                 hipMemcpyDeviceToHost, c->stream));
+        memcpy(kps + (size_t)b * cap, c->h_stage + koff + (size_t)b * dcap * sizeof(orbhip_keypoint), (size_t)n * sizeof(orbhip_keypoint));
+        memcpy(desc + (size_t)b * cap * 32, c->h_stage + doff + (size_t)b * dcap * 32, (size_t)n * 32);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return ORBHIP_OK;
 }
 
