@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--match", choices=["bow", "brute", "both"], default="bow")
     ap.add_argument("--contexts", type=int, default=1, help="extractor contexts the batch is split over in the timed region")
