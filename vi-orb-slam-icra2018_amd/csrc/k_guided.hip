@@ -11,9 +11,11 @@
 //                   distance and right-coordinate tests, in the reference's order, with their descriptor
 //                   distance -- everything that does not depend on which features earlier points took;
 //   k_proj_assign   one wave per frame: the points in index order; a point's candidates sit one per lane, the
-//                   features taken so far are a bitmap in LDS, best / second come from two wave minima over
-//                   (distance, list position); then the rotation histogram.  A point with more candidates
-//                   than the list holds is rescanned exactly as the reference does it.
+//                   features taken so far are a bitmap in LDS, best / second come from two minima over
+//                   (distance, list position).  Four points are evaluated at a time, one per 16-lane row, and
+//                   accepted in order until a row considered a feature that an earlier row of the group has just
+//                   closed (that row is redone); then the rotation histogram.  A point with more candidates than
+//                   the list holds is rescanned exactly as the reference does it.
 #include "orbhip_internal.h"
 
 #define GCOLS ORBHIP_GRID_COLS
@@ -235,6 +237,16 @@ __device__ __forceinline__ int wave_min_i(int v)
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// minimum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ int row_min_i(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return v;
+}
+
 __device__ __forceinline__ int wave_sum_g(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
@@ -308,6 +320,80 @@ __global__ __launch_bounds__(64) void k_proj_assign(const orbhip_keypoint *__res
             WAVE_LDS_SYNC();
         }
         while (todo) {
+            // ---- four points at a time, one per 16-lane row, when the next points have at most 16 candidates ----
+            // Each row finds its best / second among the features that are free NOW; the rows are then accepted
+            // in point order as long as no earlier row of the group has just closed a feature that a later row
+            // also considered -- that row and the ones after it are simply taken up again in the next round.
+            {
+                const int gl = lane & 15, g = lane >> 4;
+                int jq[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0}, nb = 0;
+                unsigned long long m = todo;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (m != 0 && nb == r) {
+                        const int j = __builtin_ctzll(m);
+                        const int c = __builtin_amdgcn_readlane(myc, j);
+                        if (c <= 16 && c <= keff) {
+                            jq[r] = j;
+                            cq[r] = c;
+                            fq[r] = __builtin_amdgcn_readlane(myflags, j);
+                            nb = r + 1;
+                            m &= m - 1;
+                        }
+                    }
+                }
+                if (nb >= 2) {
+                    const int myj = g == 0 ? jq[0] : (g == 1 ? jq[1] : (g == 2 ? jq[2] : jq[3]));
+                    const int mycq = g == 0 ? cq[0] : (g == 1 ? cq[1] : (g == 2 ? cq[2] : cq[3]));
+                    const bool rowLive = g < nb;
+                    const uint32_t t = (rowLive && gl < mycq) ? s_tup[myj * PROJ_K + gl] : 0u;
+                    const int idx = (int)(t >> 13);
+                    const bool ok = rowLive && gl < mycq && !((s_occ[idx >> 5] >> (idx & 31)) & 1u);
+                    const int key = ok ? (int)(((t & 511u) << 6) | (uint32_t)gl) : 0x7FFFFFFF;
+                    const int k1 = row_min_i(key);
+                    const int l1 = k1 & 15;
+                    const int k2 = row_min_i((gl == l1 || k1 == 0x7FFFFFFF) ? 0x7FFFFFFF : key);
+                    const uint32_t t1 = (uint32_t)__shfl((int)t, (g << 4) + l1);
+                    const uint32_t t2 = (uint32_t)__shfl((int)t, (g << 4) + (k2 & 15));
+                    const int bDist = k1 == 0x7FFFFFFF ? 256 : (k1 >> 6), bLevel = (int)((t1 >> 9) & 15u), bIdx = (int)(t1 >> 13);
+                    const int bDist2 = k2 == 0x7FFFFFFF ? 256 : (k2 >> 6), bLevel2 = k2 == 0x7FFFFFFF ? -1 : (int)((t2 >> 9) & 15u);
+                    const bool match = rowLive && k1 != 0x7FFFFFFF && bDist <= th_high &&
+                                       !(use_ratio && bLevel == bLevel2 && (float)bDist > __fmul_rn(nnratio, (float)bDist2));
+                    // scalars of every row (row-uniform values read from the row's first lane)
+                    int rMatch[4], rIdx[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        rMatch[r] = __builtin_amdgcn_readlane((int)match, r * 16);
+                        rIdx[r] = __builtin_amdgcn_readlane(bIdx, r * 16);
+                    }
+                    // first row whose candidates contain a feature closed by an earlier row of this group
+                    int firstBad = nb;
+#pragma unroll
+                    for (int e = 0; e < 3; e++) {
+                        const bool closes = rMatch[e] && (fq[e] & ORBHIP_Q_OBSERVED) && e < nb;
+                        const unsigned long long hit = __ballot(closes && ok && g > e && idx == rIdx[e]);
+                        if (hit) firstBad = min(firstBad, (int)(__builtin_ctzll(hit) >> 4));
+                    }
+                    // commit rows [0, firstBad)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (r < firstBad) {
+                            if (rMatch[r]) {
+                                if (lane == r * 16) {
+                                    s_match[rIdx[r]] = base + jq[r];
+                                    if (fq[r] & ORBHIP_Q_OBSERVED) s_occ[rIdx[r] >> 5] |= 1u << (rIdx[r] & 31);
+                                }
+                                if (lane == jq[r]) myfeat = rIdx[r];
+                                nm++;
+                            }
+                            todo &= ~(1ull << jq[r]);
+                        }
+                    }
+                    WAVE_LDS_SYNC();
+                    continue;
+                }
+            }
+            // ---- one point with the whole wave (more than 16 candidates, or the only one left) ----
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
             const int c = __builtin_amdgcn_readlane(myc, j);
