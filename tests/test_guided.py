@@ -242,3 +242,36 @@ def test_hip_search_by_projection_batched_device(oracle):
     ex.close()
     for x in (d_img, d_kps, d_desc, d_cnt, d_q, d_qd, d_nq, d_off, d_idx, d_m, d_nm):
         x.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_hip_search_by_projection_conflict_stress(oracle, seed):
+    """Dense, clustered points with small candidate lists and every point closing its feature: consecutive points
+    compete for the same features all the time (the four-points-per-round path must give way to the order)."""
+    from orbhip import guided
+    from orbhip.extractor import ORBextractor
+    rng = np.random.default_rng(100 + seed)
+    k0, d0, k1, d1 = _scene(oracle, seed=40 + seed, nf=1200)
+    gp = guided.grid_params(0, 640, 0, 480)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    ex = ORBextractor(500, max_w=320, max_h=240)
+    # every query is a feature of the frame itself or of the other frame, visited in a spatially sorted order so that
+    # neighbours in the point order are neighbours in the image; several points per feature
+    src = np.concatenate([np.arange(len(k1)), rng.integers(0, len(k1), 2 * len(k1))])
+    src = src[np.lexsort((k1["x"][src], (k1["y"][src] // 12)))]
+    jitter = rng.normal(0, 2.0, (len(src), 2)).astype(np.float32)
+    th = [4, 7, 15][seed % 3]
+    q = guided.queries_for_last_frame(k1["x"][src] + jitter[:, 0], k1["y"][src] + jitter[:, 1], k1["x"][src], k1["octave"][src],
+                                      k1["angle"][src], rng.random(len(src)) < 0.97,
+                                      rng.random(len(src)) < (1.0 if seed % 2 else 0.5), th, sf)
+    qd = d1[src].copy()
+    flip = rng.integers(0, 32, len(src))
+    qd[np.arange(len(src)), flip] ^= rng.integers(0, 256, len(src)).astype(np.uint8)      # not all distances zero
+    occ = (rng.random(len(k1)) < 0.05).astype(np.uint8)
+    for use_ratio in (False, True):
+        kw = dict(use_ratio=use_ratio, nnratio=0.9 if not use_ratio else 0.8, check_ori=True)
+        n, m = guided.SearchByProjection(ex, k1, d1, gp, q, qd, occupied=occ, **kw)
+        rn, rm = oracle.search_by_projection(k1, d1, gp, q, qd, occupied=occ, **kw)
+        assert n == rn and np.array_equal(m, rm) and rn > 300
+    ex.close()
