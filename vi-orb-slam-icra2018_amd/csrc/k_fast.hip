@@ -20,9 +20,10 @@
 //      both are possible; corners (score >= minThFAST) are compacted into a corner list;
 //   4. non-max suppression over the corner list only; survivors get a sortable key
 //      (cell, row, column, score) in a survivor list, plus a per-cell ">= iniThFAST" flag;
-//   5. survivors that pass their cell's threshold are ranked by counting inside their cell and
-//      written to the cell's fixed slot range: cells row-major, raster inside a cell = the
-//      reference's candidate order.  No global atomics, deterministic.
+//   5. survivors that pass their cell's threshold set a bit in a per-(cell, row) bitmap; a survivor's rank
+//      is the number of bits before it (row prefix + popcount), and it is written to that slot of the
+//      cell's fixed range: cells row-major, raster inside a cell = the reference's candidate order.  No
+//      global atomics, deterministic.
 // HBM traffic: each level pixel inside [16, w-16) x [16, h-16) is read once per tile that needs it;
 // the 6-row vertical halo (hCell ~ 30) is re-read by the tile below.  Roofline: nominally HBM read
 // (algorithmic bytes = sum_l (w_l-32)(h_l-32) per frame); measured bound is integer VALU + LDS
@@ -383,29 +384,48 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     if (phases < 5) return;
 
     // ---- 5. per-cell threshold, rank inside the cell (= raster order), write the slots ----
+    // The kept survivors set one bit per (cell, row, column-in-cell) in a bitmap that reuses the score tile (dead
+    // after the NMS); the rank of a survivor is then the number of bits before it: a prefix over the rows of its
+    // cell plus a popcount inside its row -- no survivor is ever compared with another one.
     const int nsurv = s_survCount;
+    unsigned long long *s_bits = reinterpret_cast<unsigned long long *>(s_score);   // [ncells][DH]; wCell < 64
+    int *s_pre = reinterpret_cast<int *>(s_bits + T.ncells * DH);                   // [ncells][DH]
+    const int nrowsAll = T.ncells * DH;
+    for (int i = tid; i < nrowsAll; i += 256) s_bits[i] = 0ull;
+    __syncthreads();
+    for (int e = tid; e < nsurv; e += 256) {
+        const uint32_t key = s_surv[e];
+        const int cj = key >> 28;
+        const int thr = s_cellAny[cj] ? G.iniTh : G.minTh;
+        if ((int)(key & 0xFF) >= thr) {
+            const int r = (key >> 21) & 127, c = (key >> 8) & 0x1FFF;
+            atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * L.wCell));
+        }
+    }
+    __syncthreads();
+    const unsigned dhMagic = 65536u / (unsigned)DH + 1u;   // i / DH for i < 65536 / DH
+    for (int i = tid; i < nrowsAll; i += 256) {
+        const int cj = (int)(((unsigned)i * dhMagic) >> 16), r = i - cj * DH;
+        int pre = 0;
+        for (int rr = 0; rr < r; rr++) pre += __popcll(s_bits[cj * DH + rr]);
+        s_pre[i] = pre;
+        if (r == DH - 1) s_cellCnt[cj] = pre + __popcll(s_bits[i]);
+    }
+    __syncthreads();
     const size_t candFrame = (size_t)frame * G.totalCands + L.candBase;
-    for (int e0 = 0; e0 < nsurv; e0 += 256) {
-        const int e = e0 + tid;
-        if (e < nsurv) {
-            const uint32_t key = s_surv[e];
-            const int cj = key >> 28;
-            const int thr = s_cellAny[cj] ? G.iniTh : G.minTh;
-            const int s = key & 0xFF;
-            if (s >= thr) {
-                // kept survivors of the same cell with a smaller (row, column)
-                int rank = 0;
-                for (int o = 0; o < nsurv; o++) {
-                    const uint32_t ok = s_surv[o];   // same address in every lane: LDS broadcast
-                    rank += ((ok >> 28) == (uint32_t)cj) && ((int)(ok & 0xFF) >= thr) && ((ok >> 8) < (key >> 8));
-                }
-                atomicAdd(&s_cellCnt[cj], 1);
-                const int r = (key >> 21) & 127, c = (key >> 8) & 0x1FFF;
-                const int px = X0 + 3 + c - ORB_MIN_BORDER;   // relative to (16,16), :824-825
-                const int py = iniY + 3 + r - ORB_MIN_BORDER;
-                uint32_t *slot = cand + candFrame + (size_t)(T.row * L.nCols + T.c0 + cj) * L.cellCap;
-                slot[rank] = (uint32_t)px | ((uint32_t)py << 12) | ((uint32_t)s << 24);
-            }
+    for (int e = tid; e < nsurv; e += 256) {
+        const uint32_t key = s_surv[e];
+        const int cj = key >> 28;
+        const int thr = s_cellAny[cj] ? G.iniTh : G.minTh;
+        const int sc = key & 0xFF;
+        if (sc >= thr) {
+            const int r = (key >> 21) & 127, c = (key >> 8) & 0x1FFF;
+            const int cl = c - cj * L.wCell;
+            const int rank = s_pre[cj * DH + r] + __popcll(s_bits[cj * DH + r] & ((1ull << cl) - 1ull));
+            const int px = X0 + 3 + c - ORB_MIN_BORDER;   // relative to (16,16), :824-825
+            const int py = iniY + 3 + r - ORB_MIN_BORDER;
+            uint32_t *slot = cand + candFrame + (size_t)(T.row * L.nCols + T.c0 + cj) * L.cellCap;
+            slot[rank] = (uint32_t)px | ((uint32_t)py << 12) | ((uint32_t)sc << 24);
         }
     }
     __syncthreads();
