@@ -76,6 +76,37 @@ def cpu_baseline(frames, nsample, match, blob):
                       "(gcc -O3 -march=x86-64-v3), %.1f s" % (nsample, W, H, NFEAT, what, dt)}
 
 
+def cpu_worker(path, nsample, match):
+    """Child process of cpu_baseline_all_cores: never touches the GPU; prints its own frame count and seconds."""
+    z = np.load(path, allow_pickle=False)
+    blob = z["blob"].tobytes() if z["blob"].size else None
+    r = cpu_baseline(z["frames"], nsample, match, blob)
+    print(json.dumps({"frames": nsample, "fps": r["value"]}), flush=True)
+
+
+def cpu_baseline_all_cores(frames, nsample, match, blob):
+    """The same oracle loop on every host core at once: one child process per core (started as children, the
+    GPU process is never replaced), each on its own sample; value = sum of frames / slowest child's time."""
+    import subprocess
+    import tempfile
+    cores = min(len(os.sched_getaffinity(0)), 32)     # bounded: at most 32 processes
+    per = max(nsample // 4, 50)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "cpu_sample.npz")
+        np.savez(path, frames=frames, blob=np.frombuffer(blob or b"", np.uint8))
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, "--cpu-frames", str(per),
+                                   "--match", match], stdout=subprocess.PIPE, env=env) for _ in range(cores)]
+        outs = [p.communicate()[0] for p in procs]
+        wall = time.perf_counter() - t0
+    rates = [json.loads(o.decode().strip().splitlines()[-1])["fps"] for o in outs]
+    slowest = per / min(rates)
+    return {"value": round(cores * per / slowest, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d processes x %d frames (one oracle loop per host core, same operations), %.1f s wall incl. start-up"
+                      % (cores, per, wall)}
+
+
 def committed_traffic(batch, contexts):
     """HBM-side bytes per k_fast launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
     tools/profile_gpu.sh + tools/summarize_prof.py for the default configuration), or None."""
@@ -149,7 +180,11 @@ def main():
     ap.add_argument("--pipelined", type=int, default=2, help="also report the free-running throughput with this many "
                     "contexts (0 = skip); supplementary, never `value`")
     ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker, args.cpu_frames, args.match)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -304,6 +339,7 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(uniq, args.cpu_frames, args.match, blob)
             out["speedup_vs_cpu_1core"] = round(fps / out["cpu_baseline"]["value"], 1)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(uniq, args.cpu_frames, args.match, blob)
     for ex, _ in ctxs:
         ex.close()
     if dist is not None:
