@@ -280,6 +280,29 @@ int orbhip_search_by_projection_device(orbhip_ctx *ctx, const void *d_kps_un, co
                                        const void *d_qdesc, const void *d_nq, int cap_q, int use_ratio,
                                        float nnratio, int check_ori, int th_high, void *d_match, void *d_nmatches);
 
+/* Replaces the body of ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
+ * vector<int> &vnMatches12, int windowSize) (src/ORBmatcher.cc:405-520; the monocular initialiser, called at
+ * src/Tracking.cc MonocularInitialization with nnratio 0.9, windowSize 100).  kps1_un / kps2_un are mvKeysUn of the two
+ * frames; only octave-0 features of frame 1 search (:420-421), in index order, among the octave-0 features of frame 2
+ * inside the window around prev_matched[i1] (:424); a feature of frame 2 that is already matched at a distance <= the
+ * new one is skipped (:443-444), a better match displaces the earlier owner (:462-466); TH_LOW = 50 and
+ * bestDist < bestDist2 * nnratio (:458-460); rotation histogram and three maxima when check_ori (:471-509).
+ * matches12[i1] = feature of frame 2 or -1; prev_matched (n1 x 2 floats, in/out) is updated for the matched
+ * features (:512-515); *nmatches = the reference's return value. */
+int orbhip_search_for_initialization(orbhip_ctx *ctx, const orbhip_keypoint *kps1_un, const uint8_t *desc1, int n1,
+                                     const orbhip_keypoint *kps2_un, const uint8_t *desc2, int n2, float min_x, float min_y,
+                                     float inv_w, float inv_h, float *prev_matched, int window_size, float nnratio,
+                                     int check_ori, int32_t *matches12, int *nmatches);
+/* Batched, device-resident form: B frame pairs; frame 1 arrays [B][cap1], frame 2 arrays [B][cap2] with the grid
+ * of frame 2 from orbhip_grid_build_device; d_prev_matched [B][cap1][2] floats (in/out), d_matches12 [B][cap1],
+ * d_nmatches [B]. */
+int orbhip_search_for_initialization_device(orbhip_ctx *ctx, const void *d_kps1_un, const void *d_desc1,
+                                            const void *d_counts1, int cap1, const void *d_kps2_un, const void *d_desc2,
+                                            const void *d_counts2, int cap2, int B, float min_x, float min_y, float inv_w,
+                                            float inv_h, const void *d_cell_off2, const void *d_cell_idx2,
+                                            void *d_prev_matched, int window_size, float nnratio, int check_ori,
+                                            void *d_matches12, void *d_nmatches);
+
 /* ---- undistortion and rectification ----
  * Replaces the body of Frame::UndistortKeyPoints (src/Frame.cc:748-778): cv::undistortPoints(mat, mat, mK,
  * mDistCoef, cv::Mat(), mK) on the keypoint coordinates; every other field of a keypoint is copied.  K, P: 3x3

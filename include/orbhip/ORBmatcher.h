@@ -7,8 +7,11 @@
 // bMono) run their window search on the device grid
 // (orbhip_search_by_projection); the pose arithmetic that projects the points stays on the host.
 //
+// SearchForInitialization (the monocular initialiser's matcher, src/ORBmatcher.cc:405-520) runs as one call
+// (orbhip_search_for_initialization): windows and distances in parallel, the owner bookkeeping in the reference's order.
+//
 // The other guided-search routines of the reference (SearchByProjection with a KeyFrame / Sim3,
-// SearchForInitialization, SearchForTriangulation, SearchBySim3, Fuse x2) are pose/projection logic around
+// SearchForTriangulation, SearchBySim3, Fuse x2) are pose/projection logic around
 // the same best/second-best primitive; they stay in the reference's own ORBmatcher.cc (SURVEY.md section 8a,
 // row M3) and can call orbhip_hamming_knn2_lists for their inner loops.
 #ifndef ORBMATCHER_H
@@ -55,6 +58,9 @@ public:
     // Project MapPoints tracked in last frame into the current frame and search matches.
     // Used to track from previous frame (Tracking) (ref: src/ORBmatcher.cc:1341-1498)
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+
+    // Matching for the Map Initialization (only used in the monocular case) (ref: src/ORBmatcher.cc:405-520)
+    int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize=10);
 
     // Device context used for matching.  By default one small context per thread is created on
     // first use (matchers are stack objects in the reference and are used from three threads).

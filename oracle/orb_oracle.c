@@ -16,6 +16,7 @@
 #include "orb_pattern_data.h"
 
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1582,6 +1583,102 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
     }
     for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
     free(occ);
+    free(cand);
+    free(cell_idx);
+    free(cell_off);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchForInitialization (ref: src/ORBmatcher.cc:405-520), the monocular initialiser's matcher
+ * (src/Tracking.cc MonocularInitialization): level-0 features of frame 1 in index order, window search around
+ * prev_matched[i1] among the level-0 features of frame 2 (:424), a feature of frame 2 already matched at a
+ * distance <= dist is skipped (:443-444), best / second with strict '<' (:446-455), bestDist <= TH_LOW and
+ * bestDist < (float)bestDist2 * nnratio (:458-460), an earlier owner of the feature loses it (:462-466), rotation
+ * histogram over every accepted i1 -- displaced ones stay in it (:471-481) -- and removal of all bins but the three
+ * maxima (:487-509); finally prev_matched[i1] becomes the matched keypoint's position (:512-515).
+ * kps1/kps2 are the undistorted keypoints (mvKeysUn).  matches12[n1] = index into frame 2 or -1. */
+int orbo_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const orbo_keypoint *kps2,
+                                   const uint8_t *desc2, int n2, float minX, float minY, float invW, float invH,
+                                   float *prev_matched /* n1 x 2, in/out */, int window_size, float nnratio,
+                                   int check_ori, int th_low, int32_t *matches12)
+{
+    int32_t *cell_off = (int32_t *)malloc(sizeof(int32_t) * (GRID_COLS * GRID_ROWS + 1));
+    int32_t *cell_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+    int *matched_dist = (int *)malloc(sizeof(int) * (size_t)(n2 + 1));
+    int32_t *matches21 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        hist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 + 1));
+        hn[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    orbo_grid_build(kps2, n2, minX, minY, invW, invH, cell_off, cell_idx);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (int i = 0; i < n2; i++) {
+        matched_dist[i] = INT_MAX;
+        matches21[i] = -1;
+    }
+    int nmatches = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = kps1[i1].octave;
+        if (level1 > 0) continue;
+        const int nc = orbo_features_in_area(kps2, cell_off, cell_idx, minX, minY, invW, invH, prev_matched[2 * i1],
+                                             prev_matched[2 * i1 + 1], (float)window_size, level1, level1, cand, n2);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            const int dist = orbo_descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+            if (matched_dist[i2] <= dist) continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= th_low && (float)bestDist < (float)bestDist2 * nnratio) {
+            if (matches21[bestIdx2] >= 0) {
+                matches12[matches21[bestIdx2]] = -1;
+                nmatches--;
+            }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matched_dist[bestIdx2] = bestDist;
+            nmatches++;
+            if (check_ori) {
+                float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) hist[bin][hn[bin]++] = i1;
+            }
+        }
+    }
+    if (check_ori) {
+        int a, b, c;
+        orbo_three_maxima(hn, HISTO_LENGTH, &a, &b, &c);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == a || i == b || i == c) continue;
+            for (int j = 0; j < hn[i]; j++) {
+                const int idx1 = hist[i][j];
+                if (matches12[idx1] >= 0) {
+                    matches12[idx1] = -1;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = kps2[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = kps2[matches12[i1]].y;
+        }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    free(matches21);
+    free(matched_dist);
     free(cand);
     free(cell_idx);
     free(cell_off);

@@ -174,6 +174,12 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
                               const orbo_proj_query *q, const uint8_t *qdesc, int nq, int use_ratio, float nnratio,
                               int check_ori, int th_high, int32_t *match);
 
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520); prev_matched n1 x 2 floats, in/out */
+int orbo_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const orbo_keypoint *kps2,
+                                   const uint8_t *desc2, int n2, float minX, float minY, float invW, float invH,
+                                   float *prev_matched, int window_size, float nnratio, int check_ori, int th_low,
+                                   int32_t *matches12);
+
 /* ---- undistortion / rectification ---- */
 /* cv::undistortPoints(src, dst, K, D, Mat(), P) as Frame::UndistortKeyPoints calls it (src/Frame.cc:767);
  * K, P: 3x3 row-major float (P may be NULL = identity), D: nD in {0,4,5,8} coefficients. */

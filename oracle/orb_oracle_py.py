@@ -448,6 +448,25 @@ def search_by_projection(kps, desc, gp, queries, qdesc, u_right=None, occupied=N
     return n, match[:len(kps)].copy()
 
 
+def search_for_initialization(kps1, desc1, kps2, desc2, gp, prev_matched, window_size=100, nnratio=0.9, check_ori=True,
+                              th_low=50):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520).  Returns (nmatches, matches12, prev_matched')."""
+    L = lib()
+    L.orbo_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + \
+        [C.c_float] * 4 + [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.orbo_search_for_initialization.restype = C.c_int
+    kps1 = np.ascontiguousarray(kps1)
+    kps2 = np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1, np.uint8)
+    desc2 = np.ascontiguousarray(desc2, np.uint8)
+    prev = np.array(prev_matched, np.float32).reshape(-1, 2).copy()
+    assert len(prev) == len(kps1)
+    m12 = np.empty(max(len(kps1), 1), np.int32)
+    n = L.orbo_search_for_initialization(_p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2), gp[0], gp[1], gp[2],
+                                         gp[3], _p(prev), int(window_size), nnratio, 1 if check_ori else 0, th_low, _p(m12))
+    return n, m12[:len(kps1)].copy(), prev
+
+
 # ---- undistortion / rectification (SURVEY 8f row 4) ----
 def undistort_points(xy, K, D, P=None):
     """cv::undistortPoints(xy, K, D, Mat(), P) -- Frame::UndistortKeyPoints (src/Frame.cc:748-778)."""

@@ -150,6 +150,22 @@ int main(int argc, char **argv)
             fwrite(&v, 4, 1, out);
         }
     }
+    {
+        // Tracking::MonocularInitialization (src/Tracking.cc:1636-1671): mvbPrevMatched = the initial frame's undistorted
+        // keypoints, ORBmatcher matcher(0.9,true), window 100 -- and once more with the updated mvbPrevMatched, as the
+        // next frame of a failed initialisation would
+        Frame &mInitialFrame = mLastFrame;
+        std::vector<cv::Point2f> mvbPrevMatched(mInitialFrame.mvKeysUn.size());
+        for (size_t i = 0; i < mInitialFrame.mvKeysUn.size(); i++) mvbPrevMatched[i] = mInitialFrame.mvKeysUn[i].pt;
+        std::vector<int> mvIniMatches;
+        ORBmatcher matcher(0.9, true);
+        for (int round = 0; round < 2; round++) {
+            int nmatches = matcher.SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100);
+            fwrite(&nmatches, 4, 1, out);
+            fwrite(mvIniMatches.data(), 4, mvIniMatches.size(), out);
+            fwrite(mvbPrevMatched.data(), 8, mvbPrevMatched.size(), out);
+        }
+    }
     fclose(out);
     delete ex;
     return 0;

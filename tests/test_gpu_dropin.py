@@ -262,4 +262,12 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
     got2 = take(n1)
     exp2 = np.where(rm2 >= 0, order[np.maximum(rm2, 0)], exp)
     assert n2 == rn2 and rn2 > 50 and np.array_equal(got2, exp2)
+
+    # --- SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100), twice ---
+    prev = np.stack([k0u["x"], k0u["y"]], 1).astype(f32)
+    for _ in range(2):
+        rn3, rm3, prev = oracle.search_for_initialization(k0u, d0, k1, d1, gp, prev, 100, 0.9, True)
+        n3 = take()[0]
+        assert n3 == rn3 and rn3 > 100 and np.array_equal(take(n0), rm3)
+        assert take(2 * n0).view(f32).tobytes() == prev.tobytes()
     assert pos == len(buf)

@@ -1,0 +1,264 @@
+"""ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520): the oracle against a definition-level Python
+model on CPU; the HIP path (list, rescan and batched forms) against the oracle on the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vi-orb-slam-icra2018_amd")
+
+
+def _scene(oracle, seed=9, nf=2000, w=640, h=480):
+    from orbhip import synth
+    fr = synth.make_frames(seed, w, h, 2)
+    ex = oracle.Extractor(nf)
+    (k0, d0), (k1, d1) = ex(fr[0]), ex(fr[1])
+    return k0, d0, k1, d1
+
+
+def _prev(k):
+    return np.stack([k["x"], k["y"]], 1).astype(np.float32)
+
+
+def _three_maxima(h):
+    m1 = m2 = m3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(h):
+        if s > m1:
+            m3, m2, m1, i3, i2, i1 = m2, m1, s, i2, i1, i
+        elif s > m2:
+            m3, m2, i3, i2 = m2, s, i2, i
+        elif s > m3:
+            m3, i3 = s, i
+    if m2 < np.float32(0.1) * np.float32(m1):
+        i2 = i3 = -1
+    elif m3 < np.float32(0.1) * np.float32(m1):
+        i3 = -1
+    return i1, i2, i3
+
+
+def _model(oracle, k1, d1, k2, d2, gp, prev, window, nnratio, check_ori):
+    """The routine as the reference writes it, in Python (windows from the oracle's GetFeaturesInArea)."""
+    grid = oracle.grid_build(k2, gp)
+    bits = np.unpackbits(d2, axis=1).astype(np.int32)
+    b1 = np.unpackbits(d1, axis=1).astype(np.int32)
+    INT_MAX = 2**31 - 1
+    m12 = np.full(len(k1), -1, np.int64)
+    m21 = np.full(len(k2), -1, np.int64)
+    md = np.full(len(k2), INT_MAX, np.int64)
+    hist = [[] for _ in range(30)]
+    n = 0
+    for i1 in range(len(k1)):
+        if k1["octave"][i1] > 0:
+            continue
+        cand = oracle.features_in_area(k2, grid, gp, prev[i1, 0], prev[i1, 1], float(window), 0, 0)
+        best, best2, bi = INT_MAX, INT_MAX, -1
+        for i2 in cand:
+            dist = int(np.abs(bits[i2] - b1[i1]).sum())
+            if md[i2] <= dist:
+                continue
+            if dist < best:
+                best2, best, bi = best, dist, int(i2)
+            elif dist < best2:
+                best2 = dist
+        if best <= 50 and np.float32(best) < np.float32(best2) * np.float32(nnratio):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1
+                n -= 1
+            m12[i1], m21[bi], md[bi] = bi, i1, best
+            n += 1
+            if check_ori:
+                rot = np.float32(k1["angle"][i1]) - np.float32(k2["angle"][bi])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360.0))
+                v = float(np.float32(rot * np.float32(1.0 / 30)))
+                b = int(np.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)     # C round(): half away from zero
+                if b == 30:
+                    b = 0
+                hist[b].append(i1)
+    if check_ori:
+        keep = _three_maxima([len(x) for x in hist])
+        for b in range(30):
+            if b in keep:
+                continue
+            for i1 in hist[b]:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    n -= 1
+    out = prev.copy()
+    for i1 in np.nonzero(m12 >= 0)[0]:
+        out[i1] = (k2["x"][m12[i1]], k2["y"][m12[i1]])
+    return n, m12.astype(np.int32), out
+
+
+@pytest.mark.parametrize("check_ori,window", [(True, 100), (False, 30)])
+def test_oracle_matches_python_model(oracle, check_ori, window):
+    k0, d0, k1, d1 = _scene(oracle, seed=14, nf=1000)
+    gp = oracle.grid_params(0, 640, 0, 480)
+    n, m, p = oracle.search_for_initialization(k0, d0, k1, d1, gp, _prev(k0), window, 0.9, check_ori)
+    rn, rm, rp = _model(oracle, k0, d0, k1, d1, gp, _prev(k0), window, 0.9, check_ori)
+    assert n == rn and np.array_equal(m, rm) and np.array_equal(p, rp)
+    assert n > 60 and n == (m >= 0).sum()
+    assert (k0["octave"][m >= 0] == 0).all() and (k1["octave"][m[m >= 0]] == 0).all()
+    assert len(set(m[m >= 0].tolist())) == n                 # a feature of frame 2 has one owner
+
+
+def test_oracle_displacement_semantics(oracle):
+    """Three level-0 features of frame 1 compete for one feature of frame 2: a strictly better one displaces the owner,
+    an equal one is skipped (:443-444), and the displaced one is not re-matched."""
+    from orbhip.capi import KP_DTYPE
+    k1 = np.zeros(4, KP_DTYPE)
+    k1["x"], k1["y"] = [100, 101, 102, 300], [100, 100, 100, 300]
+    k1["octave"] = [0, 0, 0, 1]                               # the last one never searches
+    k2 = np.zeros(2, KP_DTYPE)
+    k2["x"], k2["y"] = [100, 300], [101, 300]
+    d2 = np.zeros((2, 32), np.uint8)
+    d1 = np.zeros((4, 32), np.uint8)
+    d1[0, 0] = 0x0F                                           # distance 4 to feature 0 of frame 2
+    d1[1, 0] = 0x03                                           # distance 2: displaces i1 = 0
+    d1[2, 0] = 0x05                                           # distance 2: skipped, the owner already has 2
+    gp = oracle.grid_params(0, 640, 0, 480)
+    n, m, p = oracle.search_for_initialization(k1, d1, k2, d2, gp, _prev(k1), 20, 0.9, False)
+    assert n == 1 and m.tolist() == [-1, 0, -1, -1]
+    assert p[1].tolist() == [100, 101] and p[0].tolist() == [100, 100]
+    # with only one candidate left bestDist2 stays INT_MAX and the ratio test passes; TH_LOW = 50 still applies
+    d1[1] = 0xFF
+    d1[0] = 0
+    d1[0, :7] = 0xFF                                          # distance 56 > TH_LOW
+    n, m, _ = oracle.search_for_initialization(k1[:2], d1[:2], k2, d2, gp, _prev(k1[:2]), 20, 0.9, False)
+    assert n == 0 and (m == -1).all()
+
+
+def _check_gpu(oracle, ex, k1, d1, k2, d2, gp, prev, window, nnratio, check_ori, min_matches):
+    from orbhip import guided
+    n, m, p = guided.SearchForInitialization(ex, k1, d1, k2, d2, gp, prev, window, nnratio, check_ori)
+    rn, rm, rp = oracle.search_for_initialization(k1, d1, k2, d2, gp, prev, window, nnratio, check_ori)
+    assert n == rn and np.array_equal(m, rm) and np.array_equal(p, rp) and rn >= min_matches
+    return n, m, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nf,window,check_ori", [(2000, 100, True), (2000, 100, False), (1000, 10, True), (4000, 60, True)])
+def test_hip_search_for_initialization_matches_oracle(oracle, nf, window, check_ori):
+    from orbhip import guided
+    from orbhip.extractor import ORBextractor
+    ex = ORBextractor(500, max_w=320, max_h=240)
+    k0, d0, k1, d1 = _scene(oracle, seed=40 + nf // 1000, nf=nf)
+    gp = guided.grid_params(0, 640, 0, 480)
+    n, m, p = _check_gpu(oracle, ex, k0, d0, k1, d1, gp, _prev(k0), window, 0.9, check_ori, 20 if window == 10 else 100)
+    # the initialiser calls it again on the next frame with the updated vbPrevMatched (Tracking.cc MonocularInitialization)
+    _check_gpu(oracle, ex, k0, d0, k1, d1, gp, p, window, 0.9, check_ori, 20 if window == 10 else 100)
+    # undistorted (sub-pixel, partly outside the grid) coordinates, another grid
+    rng = np.random.default_rng(3)
+    ku0, ku1 = k0.copy(), k1.copy()
+    for k in (ku0, ku1):
+        k["x"] = (k["x"] * np.float32(1.013) - np.float32(5.3) + rng.normal(0, 0.3, len(k))).astype(np.float32)
+        k["y"] = (k["y"] * np.float32(1.011) - np.float32(3.1) + rng.normal(0, 0.3, len(k))).astype(np.float32)
+    _check_gpu(oracle, ex, ku0, d0, ku1, d1, guided.grid_params(22.5, 611.25, 19.75, 452.5), _prev(ku0), window, 0.9, check_ori, 10)
+    # empty sides
+    n, m, p = guided.SearchForInitialization(ex, k0[:0], d0[:0], k1, d1, gp, _prev(k0[:0]), window)
+    assert n == 0 and len(m) == 0
+    n, m, p = guided.SearchForInitialization(ex, k0, d0, k1[:0], d1[:0], gp, _prev(k0), window)
+    assert n == 0 and (m == -1).all() and np.array_equal(p, _prev(k0))
+    ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_hip_search_for_initialization_displacement_stress(oracle, seed):
+    """Few distinct descriptors, all features on level 0 and close together: owners are displaced all the time and
+    many candidates tie (equal distances -> the vMatchedDistance rule and the first-minimum rule decide)."""
+    from orbhip import guided
+    from orbhip.capi import KP_DTYPE
+    from orbhip.extractor import ORBextractor
+    rng = np.random.default_rng(seed)
+    n1, n2 = 700, 650
+    base = rng.integers(0, 256, (12, 32), dtype=np.uint8)
+
+    def mk(n):
+        k = np.zeros(n, KP_DTYPE)
+        k["x"], k["y"] = rng.uniform(200, 330, n), rng.uniform(150, 260, n)
+        k["octave"] = (rng.random(n) < 0.1).astype(np.int32)
+        k["angle"] = rng.choice([10.0, 12.0, 100.0, 250.0, 359.5], n) + rng.uniform(0, 2, n)
+        d = base[rng.integers(0, len(base), n)].copy()
+        flips = rng.integers(0, 6, n)
+        for i in range(n):
+            for b in rng.integers(0, 256, flips[i]):
+                d[i, b >> 3] ^= 1 << (b & 7)
+        return k, d
+    (k1, d1), (k2, d2) = mk(n1), mk(n2)
+    gp = guided.grid_params(0, 640, 0, 480)
+    ex = ORBextractor(500, max_w=320, max_h=240)
+    for window, ratio, ori in [(25, 0.9, True), (60, 1.0, False), (8, 0.9, True)]:
+        _check_gpu(oracle, ex, k1, d1, k2, d2, gp, _prev(k1), window, ratio, ori, 5)
+    ex.close()
+
+
+@pytest.mark.gpu
+def test_hip_search_for_initialization_list_overflow_rescans_exactly(oracle, tmp_path):
+    """ORBHIP_INIT_K=3: most features have more candidates than the list holds (child process: read once)."""
+    k0, d0, k1, d1 = _scene(oracle, seed=41, nf=2000)
+    gp = oracle.grid_params(0, 640, 0, 480)
+    np.savez(tmp_path / "in.npz", k0=k0, d0=d0, k1=k1, d1=d1, prev=_prev(k0))
+    code = ("import sys, numpy as np\nsys.path.insert(0, %r)\nfrom orbhip import guided\n"
+            "from orbhip.extractor import ORBextractor\nz = np.load(%r)\nex = ORBextractor(500, max_w=320, max_h=240)\n"
+            "gp = guided.grid_params(0, 640, 0, 480)\n"
+            "n, m, p = guided.SearchForInitialization(ex, z['k0'], z['d0'], z['k1'], z['d1'], gp, z['prev'], 100, 0.9, True)\n"
+            "np.savez(%r, n=n, m=m, p=p)\n" % (PKG, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, ORBHIP_INIT_K="3"))
+    got = np.load(tmp_path / "out.npz")
+    rn, rm, rp = oracle.search_for_initialization(k0, d0, k1, d1, gp, _prev(k0), 100, 0.9, True)
+    assert int(got["n"]) == rn and np.array_equal(got["m"], rm) and np.array_equal(got["p"], rp) and rn > 100
+
+
+@pytest.mark.gpu
+def test_hip_search_for_initialization_batched_device(oracle):
+    """extract_batch_device -> grid_build_device -> search_for_initialization_device: frame b against frame b+1 for a
+    whole batch, everything resident on the device."""
+    import hiprt
+    from orbhip import capi, guided, synth
+    from orbhip.capi import check
+    from orbhip.extractor import ORBextractor
+    B, W, H, NF = 5, 640, 480, 2000
+    frames = synth.make_frames(33, W, H, B + 1)
+    ex = ORBextractor(NF, max_w=W, max_h=H, max_batch=B + 1)
+    cap = ex.cap
+    L = ex._L
+    d_img = hiprt.DevBuf.from_numpy(frames)
+    d_kps, d_desc, d_cnt = hiprt.DevBuf((B + 1) * cap * 28), hiprt.DevBuf((B + 1) * cap * 32), hiprt.DevBuf((B + 1) * 4)
+    ex.extract_batch_device(d_img.ptr, B + 1, W, H, W, H * W, d_kps.ptr, d_desc.ptr, cap, d_cnt.ptr)
+    ex.sync()
+    kps = d_kps.to_numpy(capi.KP_DTYPE, (B + 1, cap))
+    desc = d_desc.to_numpy(np.uint8, (B + 1, cap, 32))
+    cnt = d_cnt.to_numpy(np.int32, (B + 1,))
+    gp = guided.grid_params(0, W, 0, H)
+    prev = np.zeros((B, cap, 2), np.float32)
+    for b in range(B):
+        prev[b, :cnt[b]] = _prev(kps[b, :cnt[b]])
+    d_prev = hiprt.DevBuf.from_numpy(prev)
+    d_off, d_idx = hiprt.DevBuf(B * (64 * 48 + 1) * 4), hiprt.DevBuf(B * cap * 4)
+    d_m, d_nm = hiprt.DevBuf(B * cap * 4), hiprt.DevBuf(B * 4)
+    # frame 2 of pair b is frame b + 1: the same arrays, one frame further
+    import ctypes as C
+    k2p, d2p, c2p = (C.c_void_p(x.ptr.value + o) for x, o in ((d_kps, cap * 28), (d_desc, cap * 32), (d_cnt, 4)))
+    check(L.orbhip_grid_build_device(ex.handle, k2p, c2p, cap, B, gp[0], gp[1], gp[2], gp[3], d_off.ptr,
+                                     d_idx.ptr), ex.handle, "grid")
+    check(L.orbhip_search_for_initialization_device(ex.handle, d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap, k2p,
+                                                    d2p, c2p, cap, B, gp[0], gp[1], gp[2], gp[3],
+                                                    d_off.ptr, d_idx.ptr, d_prev.ptr, 100, 0.9, 1, d_m.ptr, d_nm.ptr),
+          ex.handle, "search_for_initialization_device")
+    ex.sync()
+    m = d_m.to_numpy(np.int32, (B, cap))
+    nm = d_nm.to_numpy(np.int32, (B,))
+    p = d_prev.to_numpy(np.float32, (B, cap, 2))
+    for b in range(B):
+        a, c = cnt[b], cnt[b + 1]
+        rn, rm, rp = oracle.search_for_initialization(kps[b, :a], desc[b, :a], kps[b + 1, :c], desc[b + 1, :c], gp,
+                                                      prev[b, :a], 100, 0.9, True)
+        assert nm[b] == rn and np.array_equal(m[b, :a], rm) and (m[b, a:] == -1).all() and rn > 100
+        assert np.array_equal(p[b, :a], rp)
+    ex.close()
+    for x in (d_img, d_kps, d_desc, d_cnt, d_prev, d_off, d_idx, d_m, d_nm):
+        x.free()

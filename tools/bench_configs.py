@@ -62,10 +62,27 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
             d_nq.copy_(d_cnt.roll(1, 0))
             d_nq[0] = 0
 
+    if match == "init":
+        # monocular initialisation (src/Tracking.cc:1636-1671): frame b is the initial frame of pair b, frame b + 1 the
+        # current one; mvbPrevMatched starts as the initial frame's keypoints and is carried from step to step
+        from orbhip import guided
+        gp = guided.grid_params(0, W, 0, H)
+        d_off = torch.empty((B, 64 * 48 + 1), **i32)
+        d_idx = torch.empty((B, cap), **i32)
+        d_prev = torch.zeros((B, cap, 2), dtype=torch.float32, device="cuda")
+
     def step():
         ex.extract_batch_device(d_img.data_ptr(), B, W, H, stride, H * stride, d_kps.data_ptr(), d_desc.data_ptr(), cap,
                                 d_cnt.data_ptr())
-        if match == "bow":
+        if match == "init":
+            assert L.orbhip_grid_build_device(ex.handle, d_kps.data_ptr() + cap * 28, d_cnt.data_ptr() + 4, cap, B - 1, gp[0], gp[1],
+                                              gp[2], gp[3], d_off.data_ptr(), d_idx.data_ptr()) == 0
+            assert L.orbhip_search_for_initialization_device(ex.handle, d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap,
+                                                             d_kps.data_ptr() + cap * 28, d_desc.data_ptr() + cap * 32,
+                                                             d_cnt.data_ptr() + 4, cap, B - 1, gp[0], gp[1], gp[2], gp[3],
+                                                             d_off.data_ptr(), d_idx.data_ptr(), d_prev.data_ptr(), 100, 0.9, 1,
+                                                             d_a.data_ptr(), d_nm.data_ptr()) == 0
+        elif match == "bow":
             assert L.orbhip_vocab_transform_device(ex.handle, d_desc.data_ptr(), B * cap, 4, d_a.data_ptr(), d_wt.data_ptr(),
                                                    d_b.data_ptr()) == 0
             assert L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.data_ptr(), d_kps.data_ptr(), d_cnt.data_ptr(),
@@ -88,6 +105,12 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
         ex.sync()
         build_queries()
         torch.cuda.synchronize()
+    if match == "init":
+        ex.extract_batch_device(d_img.data_ptr(), B, W, H, stride, H * stride, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_cnt.data_ptr())
+        ex.sync()
+        d_prev.copy_(d_kps[:, :, 0:2].view(torch.float32))
+        torch.cuda.synchronize()
     for _ in range(2):
         step()
     ex.sync()
@@ -102,6 +125,8 @@ def run_extract(W, H, nfeat, B, total_frames, match, uniq=16, seed=0):
     kp = float(d_cnt.cpu().numpy().mean())
     if match == "proj":
         kp = float(d_nm.cpu().numpy()[1:].mean())      # matches per frame instead
+    if match == "init":
+        kp = float(d_nm.cpu().numpy()[:B - 1].mean())
     ex.close()
     return nsteps * B / dt, dt, kp, list(ms)
 
@@ -222,6 +247,10 @@ def main():
         fps, dt, kp, ms = run_extract(640, 480, 1000, 512, 4096, "proj", seed=1)
         print("| 1b | proj | %.0f frames/s | %.1f matches per frame |" % (fps, kp))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "init":            # profiling aid
+        fps, dt, kp, ms = run_extract(640, 480, 2000, 256, 2048, "init", seed=1)
+        print("| 1c | init | %.0f frames/s | %.1f matches per pair |" % (fps, kp))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "rectify":         # profiling aid
         pps, st, good = run_stereo(752, 480, 1200, 128, 1024, 0.11, 47.9, rectify=True)
         print("| 3c | rectify+stereo | %.0f pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
@@ -234,6 +263,8 @@ def main():
     print("| 2: EuRoC MH_01 full sequence | 3682 frames 752x480, 1000 feat, batches of 512, extract + transform + SearchByBoW | %.0f | %.1f kp/frame, %.3f s for the sequence |" % (fps, kp, dt))
     fps, dt, kp, ms = run_extract(640, 480, 1000, 512, 4096, "proj", seed=1)
     print("| 1b: tracking front end (headline geometry) | 640x480, 1000 feat, batches of 512: extract + AssignFeaturesToGrid + SearchByProjection(last frame, th 15) | %.0f | %.1f matches per frame |" % (fps, kp))
+    fps, dt, kp, ms = run_extract(640, 480, 2000, 256, 2048, "init", seed=1)
+    print("| 1c: monocular initialisation (headline geometry) | 640x480, 2000 feat (mpIniORBextractor), batches of 256: extract + AssignFeaturesToGrid + SearchForInitialization(frame b, frame b+1, window 100) | %.0f | %.1f matches per pair |" % (fps, kp))
     fps, dt, kp, ms = run_extract(1241, 376, 2000, 256, 2048, "bow", seed=2)
     print("| 3: KITTI 00 stereo | 1241x376, 2000 feat, L+R images as 2 frames per pair, extract + transform + SearchByBoW | %.0f images/s = %.0f stereo pairs/s | %.1f kp/image |" % (fps, fps / 2, kp))
     pps, st, good = run_stereo(1241, 376, 2000, 128, 1024, 0.53716, 386.1448)

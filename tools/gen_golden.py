@@ -124,5 +124,24 @@ def gen_next_rows():
     print("rectify", float(rect.mean()))
 
 
+def gen_init_search():
+    """ORBmatcher::SearchForInitialization on a stereo pair's keypoints (right = initial frame, left = current)."""
+    L, R = synth.make_stereo_pair(203, 376, 241, disparity=14)
+    kL, dL = oracle.Extractor(400, 1.2, 6)(L)
+    kR, dR = oracle.Extractor(400, 1.2, 6)(R)
+    gp = oracle.grid_params(0, 376, 0, 241)
+    prev = np.stack([kR["x"], kR["y"]], 1).astype(np.float32)
+    n, m, p = oracle.search_for_initialization(kR, dR, kL, dL, gp, prev, 30, 0.9, True)
+    n2, m2, p2 = oracle.search_for_initialization(kR, dR, kL, dL, gp, p, 30, 0.9, True)
+    np.savez_compressed(os.path.join(OUT, "init_search_376x241.npz"), kps1=kR, desc1=dR, kps2=kL, desc2=dL,
+                        grid=np.array(gp, np.float32), prev=prev, n=np.int32(n), matches12=m, prev_out=p, n_again=np.int32(n2),
+                        matches12_again=m2, prev_out_again=p2)
+    print("init_search", n, n2)
+
+
 if __name__ == "__main__":
-    main()
+    if "init_search" in sys.argv[1:]:
+        gen_init_search()
+    else:
+        main()
+        gen_init_search()

@@ -515,6 +515,302 @@ __global__ __launch_bounds__(64) void k_proj_assign(const orbhip_keypoint *__res
     if (lane == 0) nmatches[b] = nm;
 }
 
+// ---- ORBmatcher::SearchForInitialization (ref: src/ORBmatcher.cc:405-520) ----------------------------------
+//   k_init_cands   one wave per level-0 feature of frame 1: the window of GetFeaturesInArea(prev_matched[i1], windowSize,
+//                  0, 0) over frame 2's records, 64 at a time; the features that pass keep the reference's order through
+//                  a ballot prefix count; tuple = distance | index << 9.
+//   k_init_assign  one wave per frame pair, features of frame 1 in index order: a candidate is skipped when frame 2's
+//                  feature is already matched at a distance <= this one (vMatchedDistance, LDS), best / second are two
+//                  minima over (distance, list position), an accepted match displaces the earlier owner.  Then the rotation
+//                  histogram over every accepted i1 (displaced ones included, as in the reference) and the removal.
+#define INIT_K 128   // candidate slots per feature (64 lists = 32 KB of LDS)
+
+__global__ __launch_bounds__(256) void k_init_cands(const orbhip_keypoint *__restrict__ kps1,
+                                                    const uint8_t *__restrict__ desc1, const int32_t *__restrict__ cnt1,
+                                                    int cap1, const float2 *__restrict__ prev, float radius,
+                                                    const GridParams gp, const int32_t *__restrict__ cellOff2,
+                                                    const float4 *__restrict__ rec2, const uint8_t *__restrict__ desc2,
+                                                    int cap2, int cap1pad, int keff, uint32_t *__restrict__ tuples,
+                                                    int32_t *__restrict__ tcount)
+{
+    __shared__ int s_pre[4][65];
+    __shared__ int s_beg[4][64];
+    const int b = blockIdx.y, i1 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i1 >= cap1pad) return;
+    int count = 0;
+    const int n1 = min(cnt1[b], cap1);
+    if (i1 < n1) {
+        const int level1 = kps1[(size_t)b * cap1 + i1].octave;
+        const float2 pm = prev[(size_t)b * cap1 + i1];
+        int x0, x1, y0, y1;
+        if (level1 <= 0 && window_cells(gp, pm.x, pm.y, radius, x0, x1, y0, y1)) {   // :420-421
+            const uint4 *qd = reinterpret_cast<const uint4 *>(desc1 + ((size_t)b * cap1 + i1) * 32);
+            const uint4 a0 = qd[0], a1 = qd[1];
+            const uint4 *D = reinterpret_cast<const uint4 *>(desc2 + (size_t)b * cap2 * 32);
+            const float4 *R = rec2 + (size_t)b * cap2;
+            const int32_t *O = cellOff2 + (size_t)b * (GCELLS + 1);
+            uint32_t *T = tuples + ((size_t)b * cap1pad + i1) * INIT_K;
+            // The window's cell columns are contiguous record ranges; the wave walks their concatenation 64 records at
+            // a time (lane c holds column c's range, a prefix sum over the lengths maps a flat position back to its
+            // column), which is the visiting order of GetFeaturesInArea.
+            const int wv = threadIdx.x >> 6, ncols = x1 - x0 + 1;
+            int cs = 0, ce = 0;
+            if (lane < ncols) {
+                cs = O[(x0 + lane) * GROWS + y0];
+                ce = O[(x0 + lane) * GROWS + y1 + 1];
+            }
+            int incl = ce - cs;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            s_pre[wv][lane + 1] = incl;
+            if (lane == 0) s_pre[wv][0] = 0;
+            s_beg[wv][lane] = cs;
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            WAVE_LDS_SYNC();
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                const int t = min(t0 + lane, total - 1);
+                int c = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (c + step < ncols && s_pre[wv][c + step] <= t) c += step;
+                const float4 r = R[s_beg[wv][c] + (t - s_pre[wv][c])];
+                const int w = __float_as_int(r.z), oct = w & 255;
+                const bool pass = t0 + lane < total && !(oct < level1) && !(level1 >= 0 && oct > level1) &&
+                                  fabsf(__fsub_rn(r.x, pm.x)) < radius && fabsf(__fsub_rn(r.y, pm.y)) < radius;
+                const unsigned long long m = __ballot(pass);
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                if (pass && pos < keff) {
+                    const int idx = w >> 8;
+                    T[pos] = (uint32_t)hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]) | ((uint32_t)idx << 9);
+                }
+                count += __popcll(m);
+            }
+        }
+    }
+    if (lane == 0) tcount[(size_t)b * cap1pad + i1] = count;
+}
+
+__global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__restrict__ kps1,
+                                                    const uint8_t *__restrict__ desc1, const int32_t *__restrict__ cnt1,
+                                                    int cap1, const orbhip_keypoint *__restrict__ kps2,
+                                                    const uint8_t *__restrict__ desc2, const int32_t *__restrict__ cnt2,
+                                                    int cap2, float2 *__restrict__ prev, float radius, const GridParams gp,
+                                                    const int32_t *__restrict__ cellOff2,
+                                                    const int32_t *__restrict__ cellIdx2, int cap1pad, int keff,
+                                                    const uint32_t *__restrict__ tuples, const int32_t *__restrict__ tcount,
+                                                    float nnratio, int check_ori, int th_low,
+                                                    int32_t *__restrict__ matches12, int32_t *__restrict__ nmatches)
+{
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_tup[64 * INIT_K];
+    __shared__ int s_hist[30];
+    __shared__ int s_keep[3];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n1 = min(cnt1[b], cap1);   // (features of frame 2 beyond cnt2 are not in its grid)
+    int *s_md = reinterpret_cast<int *>(s_dyn);   // vMatchedDistance [cap2]
+    int *s_m21 = s_md + cap2;                     // vnMatches21 [cap2]
+    int *s_m12 = s_m21 + cap2;                    // vnMatches12 [cap1]
+    int *s_acc = s_m12 + cap1;                    // feature of frame 2 at the time i1 was accepted, or -1 [cap1]
+    const orbhip_keypoint *K1 = kps1 + (size_t)b * cap1, *K2 = kps2 + (size_t)b * cap2;
+    const uint4 *D2 = reinterpret_cast<const uint4 *>(desc2 + (size_t)b * cap2 * 32);
+    const int32_t *O = cellOff2 + (size_t)b * (GCELLS + 1), *I = cellIdx2 + (size_t)b * cap2;
+    float2 *PM = prev + (size_t)b * cap1;
+    for (int i = lane; i < cap2; i += 64) {
+        s_md[i] = 0x7FFFFFFF;
+        s_m21[i] = -1;
+    }
+    for (int i = lane; i < cap1; i += 64) {
+        s_m12[i] = -1;
+        s_acc[i] = -1;
+    }
+    if (lane < 30) s_hist[lane] = 0;
+    WAVE_LDS_SYNC();
+    int nm = 0;
+    const uint4 *Tg = reinterpret_cast<const uint4 *>(tuples + (size_t)b * cap1pad * INIT_K);
+    for (int base = 0; base < n1; base += 64) {
+        const int myq = base + lane;
+        const int myc = myq < n1 ? tcount[(size_t)b * cap1pad + myq] : 0;
+        unsigned long long todo = __ballot(myc > 0);
+        if (todo) {
+            uint4 *s4 = reinterpret_cast<uint4 *>(s_tup);
+            const uint4 *src = Tg + (size_t)base * (INIT_K / 4);
+#pragma unroll 8
+            for (int k = 0; k < INIT_K / 4; k++) s4[k * 64 + lane] = src[k * 64 + lane];
+            WAVE_LDS_SYNC();
+        }
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int i1 = base + j;
+            const int c = __builtin_amdgcn_readlane(myc, j);
+            int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx = -1;
+            if (c <= keff) {
+                int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
+                for (int p = lane; p < c; p += 64) {
+                    const uint32_t t = s_tup[j * INIT_K + p];
+                    const int d = (int)(t & 511u), idx = (int)(t >> 9);
+                    const int key = s_md[idx] <= d ? 0x7FFFFFFF : ((d << 16) | p);   // :443-444
+                    if (key < m1) {
+                        m2 = m1;
+                        m1 = key;
+                    } else if (key < m2) {
+                        m2 = key;
+                    }
+                }
+                const int k1 = wave_min_i(m1);
+                if (k1 != 0x7FFFFFFF) {
+                    const int k2 = wave_min_i(m1 == k1 ? m2 : m1);   // list positions are unique: one lane holds k1
+                    bestDist = k1 >> 16;
+                    bestIdx = (int)(s_tup[j * INIT_K + (k1 & 0xFFFF)] >> 9);
+                    if (k2 != 0x7FFFFFFF) bestDist2 = k2 >> 16;
+                }
+            } else {
+                // more candidates than the list holds: the reference's scan, identically in every lane
+                orbhip_proj_query q;
+                const float2 pm = PM[i1];
+                q.u = pm.x;
+                q.v = pm.y;
+                q.radius = radius;
+                q.min_level = q.max_level = K1[i1].octave;
+                const uint4 *qd = reinterpret_cast<const uint4 *>(desc1 + ((size_t)b * cap1 + i1) * 32);
+                const uint4 a0 = qd[0], a1 = qd[1];
+                walk_window(gp, q, K2, O, I, [&](int idx, int) {
+                    const int d = hamming256g(a0, a1, D2[2 * idx], D2[2 * idx + 1]);
+                    if (s_md[idx] <= d) return;
+                    if (d < bestDist) {
+                        bestDist2 = bestDist;
+                        bestDist = d;
+                        bestIdx = idx;
+                    } else if (d < bestDist2) {
+                        bestDist2 = d;
+                    }
+                });
+            }
+            if (bestIdx >= 0 && bestDist <= th_low && (float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {   // :458-460
+                const int old = s_m21[bestIdx];
+                if (old >= 0) nm--;
+                if (lane == 0) {
+                    if (old >= 0) s_m12[old] = -1;
+                    s_m12[i1] = bestIdx;
+                    s_m21[bestIdx] = i1;
+                    s_md[bestIdx] = bestDist;
+                    s_acc[i1] = bestIdx;
+                }
+                nm++;
+                WAVE_LDS_SYNC();
+            }
+        }
+    }
+    WAVE_LDS_SYNC();
+    if (check_ori) {
+        for (int i1 = lane; i1 < n1; i1 += 64) {
+            const int f = s_acc[i1];
+            if (f < 0) continue;
+            float rot = __fsub_rn(K1[i1].angle, K2[f].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            if (bin >= 0 && bin < 30) atomicAdd(&s_hist[bin], 1);
+        }
+        WAVE_LDS_SYNC();
+        if (lane == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < 30; i++) {
+                const int s = s_hist[i];
+                if (s > max1) {
+                    max3 = max2; max2 = max1; max1 = s;
+                    i3 = i2; i2 = i1; i1 = i;
+                } else if (s > max2) {
+                    max3 = max2; max2 = s;
+                    i3 = i2; i2 = i;
+                } else if (s > max3) {
+                    max3 = s;
+                    i3 = i;
+                }
+            }
+            if ((float)max2 < 0.1f * (float)max1) {
+                i2 = -1;
+                i3 = -1;
+            } else if ((float)max3 < 0.1f * (float)max1) {
+                i3 = -1;
+            }
+            s_keep[0] = i1;
+            s_keep[1] = i2;
+            s_keep[2] = i3;
+        }
+        WAVE_LDS_SYNC();
+        int removed = 0;
+        for (int i1 = lane; i1 < n1; i1 += 64) {
+            const int f = s_acc[i1];
+            if (f < 0) continue;
+            float rot = __fsub_rn(K1[i1].angle, K2[f].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            if (bin >= 0 && bin < 30 && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2] && s_m12[i1] >= 0) {
+                s_m12[i1] = -1;
+                removed++;
+            }
+        }
+        nm -= wave_sum_g(removed);
+        WAVE_LDS_SYNC();
+    }
+    for (int i1 = lane; i1 < cap1; i1 += 64) {
+        const int m = i1 < n1 ? s_m12[i1] : -1;
+        matches12[(size_t)b * cap1 + i1] = m;
+        if (m >= 0) PM[i1] = make_float2(K2[m].x, K2[m].y);   // :512-515
+    }
+    if (lane == 0) nmatches[b] = nm;
+}
+
+static int init_keff()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ORBHIP_INIT_K");   // tests force the rescan path with a small value
+        v = e ? atoi(e) : INIT_K;
+        if (v < 1) v = 1;
+        if (v > INIT_K) v = INIT_K;
+    }
+    return v;
+}
+
+size_t init_scratch_bytes(int B, int cap1, int cap2)
+{
+    const size_t cap1pad = ((size_t)cap1 + 63) / 64 * 64;
+    return (size_t)B * cap2 * 16 + (size_t)B * cap1pad * (INIT_K * 4 + 4) + 256;
+}
+
+size_t init_assign_lds(int cap1, int cap2) { return ((size_t)cap1 * 2 + (size_t)cap2 * 2) * 4; }
+
+int launch_search_for_initialization(hipStream_t s, const orbhip_keypoint *kps1, const uint8_t *desc1, const int32_t *cnt1,
+                                     int cap1, const orbhip_keypoint *kps2, const uint8_t *desc2, const int32_t *cnt2, int cap2,
+                                     int B, float minX, float minY, float invW, float invH, const int32_t *cellOff2,
+                                     const int32_t *cellIdx2, float *prev, int windowSize, float nnratio, int check_ori,
+                                     int th_low, int32_t *matches12, int32_t *nmatches, void *scratch)
+{
+    const GridParams gp = {minX, minY, invW, invH};
+    const int cap1pad = (cap1 + 63) / 64 * 64;
+    float4 *rec = (float4 *)scratch;
+    uint32_t *tuples = (uint32_t *)(rec + (size_t)B * cap2);
+    int32_t *tcount = (int32_t *)(tuples + (size_t)B * cap1pad * INIT_K);
+    const int keff = init_keff();
+    const float radius = (float)windowSize;
+    hipLaunchKernelGGL(k_proj_records, dim3((cap2 + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps2, cap2, cellOff2, cellIdx2, rec);
+    hipLaunchKernelGGL(k_init_cands, dim3(cap1pad / 4, B, 1), dim3(256, 1, 1), 0, s, kps1, desc1, cnt1, cap1, (const float2 *)prev,
+                       radius, gp, cellOff2, rec, desc2, cap2, cap1pad, keff, tuples, tcount);
+    if (init_assign_lds(cap1, cap2) > 16 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_init_assign, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)init_assign_lds(cap1, cap2));
+    hipLaunchKernelGGL(k_init_assign, dim3(B, 1, 1), dim3(64, 1, 1), init_assign_lds(cap1, cap2), s, kps1, desc1, cnt1, cap1, kps2,
+                       desc2, cnt2, cap2, (float2 *)prev, radius, gp, cellOff2, cellIdx2, cap1pad, keff, tuples, tcount, nnratio,
+                       check_ori, th_low, matches12, nmatches);
+    return ORBHIP_OK;
+}
+
 static int proj_keff()
 {
     static int v = -1;
@@ -569,6 +865,9 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
     hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
     hipLaunchKernelGGL(k_proj_cands, dim3((capQpad + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, desc, cap, uRight, gp,
                        cellOff, rec, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
+    if (proj_assign_lds(cap) > 32 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_proj_assign, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)proj_assign_lds(cap));
     hipLaunchKernelGGL(k_proj_assign, dim3(B, 1, 1), dim3(64, 1, 1), proj_assign_lds(cap), s, kps, desc, cnt, cap, uRight,
                        occupied, gp, cellOff, cellIdx, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount, qfeat,
                        use_ratio, nnratio, check_ori, th_high, match, nmatches);

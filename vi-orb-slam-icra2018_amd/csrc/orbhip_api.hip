@@ -1130,6 +1130,73 @@ extern "C" int orbhip_search_by_projection(orbhip_ctx *c, const orbhip_keypoint 
     return ORBHIP_OK;
 }
 
+extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *c, const void *d_kps1, const void *d_desc1,
+                                                       const void *d_counts1, int cap1, const void *d_kps2,
+                                                       const void *d_desc2, const void *d_counts2, int cap2, int B,
+                                                       float min_x, float min_y, float inv_w, float inv_h,
+                                                       const void *d_cell_off2, const void *d_cell_idx2, void *d_prev_matched,
+                                                       int window_size, float nnratio, int check_ori, void *d_matches12,
+                                                       void *d_nmatches)
+{
+    if (!c || !d_kps1 || !d_desc1 || !d_counts1 || !d_kps2 || !d_desc2 || !d_counts2 || cap1 <= 0 || cap2 <= 0 || B <= 0 ||
+        !d_cell_off2 || !d_cell_idx2 || !d_prev_matched || !d_matches12 || !d_nmatches || window_size < 0 ||
+        !grid_params_ok(inv_w, inv_h) || cap2 >= (1 << 23) || cap1 >= (1 << 23))
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_for_initialization_device: bad argument");
+    if (init_assign_lds(cap1, cap2) > 112 * 1024)
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_for_initialization_device: cap too large for the per-pair match tables in LDS");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = match_scratch(c, init_scratch_bytes(B, cap1, cap2)))) return rc;
+    launch_search_for_initialization(c->stream, (const orbhip_keypoint *)d_kps1, (const uint8_t *)d_desc1,
+                                     (const int32_t *)d_counts1, cap1, (const orbhip_keypoint *)d_kps2, (const uint8_t *)d_desc2,
+                                     (const int32_t *)d_counts2, cap2, B, min_x, min_y, inv_w, inv_h, (const int32_t *)d_cell_off2,
+                                     (const int32_t *)d_cell_idx2, (float *)d_prev_matched, window_size, nnratio, check_ori,
+                                     /*TH_LOW*/ 50, (int32_t *)d_matches12, (int32_t *)d_nmatches, c->d_match);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_search_for_initialization(orbhip_ctx *c, const orbhip_keypoint *kps1, const uint8_t *desc1, int n1,
+                                                const orbhip_keypoint *kps2, const uint8_t *desc2, int n2, float min_x,
+                                                float min_y, float inv_w, float inv_h, float *prev_matched, int window_size,
+                                                float nnratio, int check_ori, int32_t *matches12, int *nmatches)
+{
+    if (!c || n1 < 0 || n2 < 0 || (n1 > 0 && (!kps1 || !desc1 || !matches12 || !prev_matched)) || (n2 > 0 && (!kps2 || !desc2)) ||
+        window_size < 0 || !grid_params_ok(inv_w, inv_h))
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_for_initialization: bad argument");
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)n1 * (28 + 32 + 8 + 4) + (size_t)n2 * (28 + 32 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + 16384))) return rc;
+    orbhip_keypoint *dk1 = (orbhip_keypoint *)T.take((size_t)n1 * 28), *dk2 = (orbhip_keypoint *)T.take((size_t)n2 * 28);
+    uint8_t *dd1 = (uint8_t *)T.take((size_t)n1 * 32), *dd2 = (uint8_t *)T.take((size_t)n2 * 32);
+    float *dpm = (float *)T.take((size_t)n1 * 8);
+    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
+            *didx = (int32_t *)T.take((size_t)n2 * 4), *dm = (int32_t *)T.take((size_t)n1 * 4);
+    const int32_t cnts[3] = {n1, n2, 0};
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(dk1, kps1, (size_t)n1 * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dk2, kps2, (size_t)n2 * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dpm, prev_matched, (size_t)n1 * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dc, cnts, 12, hipMemcpyHostToDevice, s));
+    if ((rc = orbhip_grid_build_device(c, dk2, dc + 1, n2, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
+    if ((rc = orbhip_search_for_initialization_device(c, dk1, dd1, dc, n1, dk2, dd2, dc + 1, n2, 1, min_x, min_y, inv_w, inv_h, doff,
+                                                      didx, dpm, window_size, nnratio, check_ori, dm, dc + 2)))
+        return rc;
+    int nm = 0;
+    HIPCHK(c, hipMemcpyAsync(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(prev_matched, dpm, (size_t)n1 * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&nm, dc + 2, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // undistortion / rectification
 // ------------------------------------------------------------------------------------------------

@@ -279,6 +279,13 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
                                 float invH, const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries,
                                 const uint8_t *qdesc, const int32_t *nq, int capQ, int use_ratio, float nnratio,
                                 int check_ori, int th_high, int32_t *match, int32_t *nmatches, void *scratch);
+size_t init_scratch_bytes(int B, int cap1, int cap2);
+size_t init_assign_lds(int cap1, int cap2);
+int launch_search_for_initialization(hipStream_t s, const orbhip_keypoint *kps1, const uint8_t *desc1, const int32_t *cnt1,
+                                     int cap1, const orbhip_keypoint *kps2, const uint8_t *desc2, const int32_t *cnt2, int cap2,
+                                     int B, float minX, float minY, float invW, float invH, const int32_t *cellOff2,
+                                     const int32_t *cellIdx2, float *prev, int windowSize, float nnratio, int check_ori,
+                                     int th_low, int32_t *matches12, int32_t *nmatches, void *scratch);
 int launch_undistort(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, const float *K,
                      const float *D, int nD, const float *P, orbhip_keypoint *out);
 int launch_remap(hipStream_t s, const uint8_t *src, int B, int sw, int sh, int sstride, size_t sframe, const float *mapx,

@@ -297,6 +297,26 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
                                  TH_HIGH);
 }
 
+int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)
+{
+    // ref: src/ORBmatcher.cc:405-520.  cv::KeyPoint is the 28-byte record of orbhip_keypoint, cv::Point2f two floats.
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = vector<int>(n1,-1);
+    if(n1==0 || n2==0)
+        return 0;
+    if((int)vbPrevMatched.size()<n1)
+        throw std::runtime_error("ORBmatcher::SearchForInitialization: vbPrevMatched is shorter than F1.mvKeysUn");
+    int nmatches=0;
+    const int rc = orbhip_search_for_initialization(tls.get(), (const orbhip_keypoint *)F1.mvKeysUn.data(), F1.mDescriptors.ptr(0), n1,
+                                                    (const orbhip_keypoint *)F2.mvKeysUn.data(), F2.mDescriptors.ptr(0), n2,
+                                                    Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv,
+                                                    Frame::mfGridElementHeightInv, (float *)vbPrevMatched.data(), windowSize,
+                                                    mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches);
+    if(rc != ORBHIP_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization: ") + orbhip_last_error(tls.get()));
+    return nmatches;
+}
+
 void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3)
 {
     // ref: src/ORBmatcher.cc:1629-1670

@@ -1,6 +1,7 @@
 """Python mirror of the frame grid and the guided search:
 Frame::AssignFeaturesToGrid / GetFeaturesInArea (src/Frame.cc:574-589, :671-724) and the two
-ORBmatcher::SearchByProjection variants that run on it (src/ORBmatcher.cc:45-129, :1341-1498).
+ORBmatcher::SearchByProjection variants that run on it (src/ORBmatcher.cc:45-129, :1341-1498), and
+ORBmatcher::SearchForInitialization (:405-520).
 All arithmetic of the search runs in liborbhip; the helpers here only fill orbhip_proj_query records the way
 the reference derives the window of a point (float32 throughout, as in the C++ code)."""
 import ctypes as C
@@ -93,3 +94,23 @@ def SearchByProjection(ctx, kps_un, desc, gp, queries, qdesc, u_right=None, occu
                                                   nnratio, 1 if check_ori else 0, th_high, _p(match), C.byref(nm)),
           ctx.handle, "orbhip_search_by_projection")
     return nm.value, match[:len(kps_un)].copy()
+
+
+def SearchForInitialization(ctx, kps1_un, desc1, kps2_un, desc2, gp, prev_matched, window_size=100, nnratio=0.9,
+                            check_ori=True):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520).  Returns (nmatches, vnMatches12,
+    vbPrevMatched after the update of :512-515)."""
+    kps1_un = np.ascontiguousarray(kps1_un, KP_DTYPE)
+    kps2_un = np.ascontiguousarray(kps2_un, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    prev = np.array(prev_matched, f32).reshape(-1, 2).copy()
+    if len(prev) != len(kps1_un):
+        raise ValueError("vbPrevMatched must hold one point per keypoint of frame 1")
+    m12 = np.empty(max(len(kps1_un), 1), np.int32)
+    nm = C.c_int()
+    check(capi.load().orbhip_search_for_initialization(ctx.handle, _p(kps1_un), _p(desc1), len(kps1_un), _p(kps2_un), _p(desc2),
+                                                       len(kps2_un), gp[0], gp[1], gp[2], gp[3], _p(prev), int(window_size),
+                                                       nnratio, 1 if check_ori else 0, _p(m12), C.byref(nm)),
+          ctx.handle, "orbhip_search_for_initialization")
+    return nm.value, m12[:len(kps1_un)].copy(), prev
