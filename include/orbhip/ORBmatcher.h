@@ -3,20 +3,22 @@
 // DescriptorDistance and both SearchByBoW overloads.  The Hamming work of SearchByBoW runs in
 // liborbhip.so (k_bow_match, one wave per shared vocabulary node).
 //
-// SearchByProjection(Frame&, vector<MapPoint*>&, th) and SearchByProjection(CurrentFrame, LastFrame, th,
-// bMono) run their window search on the device grid
+// SearchByProjection(Frame&, vector<MapPoint*>&, th), SearchByProjection(CurrentFrame, LastFrame, th,
+// bMono) and the relocalisation variant SearchByProjection(CurrentFrame, KeyFrame*,
+// sAlreadyFound, th, ORBdist) run their window search on the device grid
 // (orbhip_search_by_projection); the pose arithmetic that projects the points stays on the host.
 //
 // SearchForInitialization (the monocular initialiser's matcher, src/ORBmatcher.cc:405-520) runs as one call
 // (orbhip_search_for_initialization): windows and distances in parallel, the owner bookkeeping in the reference's order.
 //
-// The other guided-search routines of the reference (SearchByProjection with a KeyFrame / Sim3,
+// The other guided-search routines of the reference (SearchByProjection with a Sim3,
 // SearchForTriangulation, SearchBySim3, Fuse x2) are pose/projection logic around
 // the same best/second-best primitive; they stay in the reference's own ORBmatcher.cc (SURVEY.md section 8a,
 // row M3) and can call orbhip_hamming_knn2_lists for their inner loops.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <set>
 #include <vector>
 
 #ifdef ORBHIP_WITH_REFERENCE_HEADERS
@@ -58,6 +60,10 @@ public:
     // Project MapPoints tracked in last frame into the current frame and search matches.
     // Used to track from previous frame (Tracking) (ref: src/ORBmatcher.cc:1341-1498)
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+
+    // Project MapPoints seen in KeyFrame into the Frame and search matches.
+    // Used in relocalisation (Tracking) (ref: src/ORBmatcher.cc:1500-1627)
+    int SearchByProjection(Frame &CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist);
 
     // Matching for the Map Initialization (only used in the monocular case) (ref: src/ORBmatcher.cc:405-520)
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize=10);

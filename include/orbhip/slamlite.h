@@ -6,6 +6,7 @@
 #ifndef ORBHIP_SLAMLITE_H
 #define ORBHIP_SLAMLITE_H
 
+#include <cmath>
 #include <map>
 #include <set>
 #include <vector>
@@ -32,16 +33,21 @@ public:
 namespace ORB_SLAM2
 {
 
+class Frame;
+
 class MapPoint
 {
 public:
     MapPoint() : mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
-                 mTrackViewCos(0), nObs(0), mbBad(false) {}
+                 mTrackViewCos(0), nObs(0), mfMinDistance(0), mfMaxDistance(0), mbBad(false) {}
     bool isBad() { return mbBad; }          // ref: include/MapPoint.h
     void SetBadFlag() { mbBad = true; }
     int Observations() { return nObs; }
     cv::Mat GetDescriptor() { return mDescriptor.clone(); }
     cv::Mat GetWorldPos() { return mWorldPos.clone(); }
+    float GetMinDistanceInvariance() { return 0.8f*mfMinDistance; }   // ref: src/MapPoint.cc:388-398
+    float GetMaxDistanceInvariance() { return 1.2f*mfMaxDistance; }
+    int PredictScale(const float &currentDist, Frame *pF);           // ref: src/MapPoint.cc:417-432 (body below Frame)
 
     // Variables used by the tracking (ref: include/MapPoint.h:102-107), read by SearchByProjection
     float mTrackProjX;
@@ -55,6 +61,7 @@ public:
     int nObs;
     cv::Mat mDescriptor;                     // 1 x 32 CV_8U
     cv::Mat mWorldPos;                       // 3 x 1 CV_32F
+    float mfMinDistance, mfMaxDistance;      // scale invariance distances
 protected:
     bool mbBad;
 };
@@ -67,7 +74,8 @@ class ORBextractor;
 class Frame
 {
 public:
-    Frame() : N(0), mpORBextractorLeft(0), mpORBextractorRight(0), mbf(0), mb(0) {}
+    Frame() : N(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0), mpORBextractorLeft(0), mpORBextractorRight(0),
+              mbf(0), mb(0) {}
     int N;                                   // ref: include/Frame.h
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     cv::Mat mDescriptors;
@@ -83,6 +91,8 @@ public:
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
     cv::Mat mTcw;                            // 4 x 4 CV_32F
     std::vector<float> mvScaleFactors;
+    int mnScaleLevels;                       // ref: src/Frame.cc:61-63 (mfLogScaleFactor = log(mfScaleFactor), float)
+    float mfScaleFactor, mfLogScaleFactor;
     cv::Mat mK;                              // 3 x 3 CV_32F
     cv::Mat mDistCoef;                       // 4 x 1 (or 5 / 8) CV_32F
     void UndistortKeyPoints();               // ref: src/Frame.cc:748-778
@@ -100,6 +110,17 @@ public:
     float mbf, mb;
     void ComputeStereoMatches();
 };
+
+inline int MapPoint::PredictScale(const float &currentDist, Frame *pF)
+{
+    const float ratio = mfMaxDistance/currentDist;
+    int nScale = std::ceil(std::log(ratio)/pF->mfLogScaleFactor);
+    if(nScale<0)
+        nScale = 0;
+    else if(nScale>=pF->mnScaleLevels)
+        nScale = pF->mnScaleLevels-1;
+    return nScale;
+}
 
 class KeyFrame
 {

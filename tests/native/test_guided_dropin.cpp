@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <set>
 #include <vector>
 
 #include "ORBextractor.h"
@@ -32,7 +34,7 @@ struct Header {
     float D[4];
 };
 struct MpRec {
-    float X, Y, Z, nObs, outlier, projX, projY, projXR, viewCos, level, inView, bad;
+    float X, Y, Z, nObs, outlier, projX, projY, projXR, viewCos, level, inView, bad, minDist, maxDist;
 };
 
 static void buildFrame(Frame &F, ORBextractor *ex, const unsigned char *pix, int w, int h, const float *Tcw, const Header &H,
@@ -123,6 +125,8 @@ int main(int argc, char **argv)
         p.mTrackViewCos = rec[i].viewCos;
         p.mnTrackScaleLevel = (int)rec[i].level;
         p.mbTrackInView = rec[i].inView != 0;
+        p.mfMinDistance = rec[i].minDist;
+        p.mfMaxDistance = rec[i].maxDist;
         if (rec[i].bad != 0) p.SetBadFlag();
         if (i % 9 != 4) mLastFrame.mvpMapPoints[i] = &p;     // some last-frame features carry no point
         mLastFrame.mvbOutlier[i] = rec[i].outlier != 0;
@@ -144,6 +148,29 @@ int main(int argc, char **argv)
         for (int i = nmp - 1; i >= 0; i--) vpMapPoints.push_back(&points[i]);
         ORBmatcher matcher(0.8);
         int nmatches = matcher.SearchByProjection(mCurrentFrame, vpMapPoints, H.thLocal);
+        fwrite(&nmatches, 4, 1, out);
+        for (int i = 0; i < mCurrentFrame.N; i++) {
+            int v = mCurrentFrame.mvpMapPoints[i] ? (int)(mCurrentFrame.mvpMapPoints[i] - &points[0]) : -1;
+            fwrite(&v, 4, 1, out);
+        }
+    }
+    {
+        // Tracking::Relocalization (src/Tracking.cc: matcher2.SearchByProjection(mCurrentFrame, vpCandidateKFs[i], sFound,
+        // 10, 100)): the last frame plays the candidate keyframe; every third feature of the current frame is opened
+        // again, the points still held are the ones "already found"
+        KeyFrame kf;
+        kf.mvKeysUn = mLastFrame.mvKeysUn;
+        kf.mvpMapPoints = mLastFrame.mvpMapPoints;
+        std::set<MapPoint *> sFound;
+        for (int i = 0; i < mCurrentFrame.N; i++) {
+            if (i % 3 == 0) mCurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);
+            if (mCurrentFrame.mvpMapPoints[i]) sFound.insert(mCurrentFrame.mvpMapPoints[i]);
+        }
+        mCurrentFrame.mnScaleLevels = ex->GetLevels();
+        mCurrentFrame.mfScaleFactor = ex->GetScaleFactor();
+        mCurrentFrame.mfLogScaleFactor = log(mCurrentFrame.mfScaleFactor);
+        ORBmatcher matcher2(0.9, true);
+        int nmatches = matcher2.SearchByProjection(mCurrentFrame, &kf, sFound, 10, 100);
         fwrite(&nmatches, 4, 1, out);
         for (int i = 0; i < mCurrentFrame.N; i++) {
             int v = mCurrentFrame.mvpMapPoints[i] ? (int)(mCurrentFrame.mvpMapPoints[i] - &points[0]) : -1;

@@ -175,7 +175,7 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
     Xw[5, 2] = f32(-1.0)                                            # behind the camera -> skipped
     nobs = rng.integers(0, 4, n0)
     outlier = rng.random(n0) < 0.05
-    rec = np.zeros((n0, 12), f32)
+    rec = np.zeros((n0, 14), f32)
     rec[:, 0:3], rec[:, 3], rec[:, 4] = Xw, nobs, outlier
     rec[:, 5] = k0["x"] + rng.normal(0, 1.5, n0)                    # mTrackProjX / Y / XR
     rec[:, 6] = k0["y"] + rng.normal(0, 1.5, n0)
@@ -184,6 +184,16 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
     rec[:, 9] = k0["octave"]                                        # mnTrackScaleLevel
     rec[:, 10] = rng.random(n0) < 0.9                               # mbTrackInView
     rec[:, 11] = rng.random(n0) < 0.03                              # isBad
+    # scale-invariance distances (MapPoint::UpdateNormalAndDepth): maxDistance = dist * 1.2^octave; here relative to the
+    # CURRENT camera centre, with a factor that keeps PredictScale away from its rounding boundaries
+    Ow = np.array([f32(-np.sum(Rc[:, r].astype(np.float64) * tc.astype(np.float64))) for r in range(3)], f32)
+    PO = (Xw - Ow).astype(f32)
+    dist3D = np.sqrt((PO.astype(np.float64) ** 2).sum(1)).astype(f32)
+    sfac = np.array(list(ex.params.mvScaleFactor)[:8], f32)
+    rec[:, 13] = dist3D * sfac[k0["octave"]] * rng.uniform(0.85, 0.98, n0).astype(f32)
+    rec[:, 12] = rec[:, 13] / sfac[7]
+    far = rng.random(n0) < 0.05
+    rec[far, 13] *= f32(0.05)                                       # dist3D > 1.2 * maxDistance -> skipped
     dist = np.array([-0.05, 0.012, 2e-4, -3e-4], f32)              # mDistCoef: keypoints move by up to a few pixels
     hdr = np.concatenate([[fx, fy, cx, cy, 0, 0, 0, 0, mb, mbf, th_last, th_local, 1], Tl.ravel(), Tc.ravel(),
                           dist]).astype(f32)
@@ -262,6 +272,38 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
     got2 = take(n1)
     exp2 = np.where(rm2 >= 0, order[np.maximum(rm2, 0)], exp)
     assert n2 == rn2 and rn2 > 50 and np.array_equal(got2, exp2)
+
+    # --- SearchByProjection(CurrentFrame, pKF, sAlreadyFound, 10, 100): relocalisation on top of that state ---
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.logf.restype, libm.logf.argtypes = ctypes.c_float, [ctypes.c_float]
+    state = exp2.copy()
+    state[np.arange(n1) % 3 == 0] = -1
+    found = set(state[state >= 0].tolist())
+    logs = f32(libm.logf(f32(sfac[1])))
+    assert sfac[1] == f32(1.2)
+    qC = np.zeros(n0, guided.QUERY_DTYPE)
+    nactive = 0
+    for i in range(n0):
+        if not has_point[i] or rec[i, 11] != 0 or i in found:
+            continue
+        if u[i] < bounds[0] or u[i] > bounds[1] or v[i] < bounds[2] or v[i] > bounds[3]:
+            continue
+        if dist3D[i] < f32(0.8) * rec[i, 12] or dist3D[i] > f32(1.2) * rec[i, 13]:
+            continue
+        ratio = f32(rec[i, 13] / dist3D[i])
+        lv = f32(libm.logf(ratio)) / logs
+        assert abs(lv - np.round(lv)) > 0.02                       # PredictScale is not at a rounding boundary
+        lvl = min(max(int(np.ceil(lv)), 0), 7)
+        qC[i] = (u[i], v[i], f32(10) * sfac[lvl], 0, lvl - 1, lvl + 1, k0u["angle"][i], 3)
+        nactive += 1
+    assert nactive > 300 and far.sum() > 10
+    rn4, rm4 = oracle.search_by_projection(k1, d1, gp, qC, d0, occupied=(state >= 0).astype(np.uint8), use_ratio=False,
+                                           nnratio=0.9, check_ori=True, th_high=100)
+    n4 = take()[0]
+    got4 = take(n1)
+    exp4 = np.where(rm4 >= 0, rm4, np.where(rm4 == -2, -1, state))
+    assert n4 == rn4 and rn4 > 100 and np.array_equal(got4, exp4)
 
     # --- SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100), twice ---
     prev = np.stack([k0u["x"], k0u["y"]], 1).astype(f32)

@@ -146,19 +146,21 @@ namespace {
 // reference's loops do: the last point assigned to a feature stays, a feature whose match the rotation check
 // removed becomes NULL, every other feature is left alone.
 int run_projection_search(Frame &F, const vector<orbhip_proj_query> &q, const vector<uint8_t> &qdesc,
-                          const vector<MapPoint *> &source, bool use_ratio, float nnratio, bool check_ori, int th_high)
+                          const vector<MapPoint *> &source, bool use_ratio, float nnratio, bool check_ori, int th_high,
+                          bool anyPointCloses = false, bool useRight = true)
 {
     const int n = F.N, nq = (int)q.size();
     if (n == 0 || nq == 0) return 0;
     vector<uint8_t> occupied(n, 0);
     for (int i = 0; i < n; i++)
-        if (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) occupied[i] = 1;   // ref: :88-90, :1413-1415
+        if (F.mvpMapPoints[i] && (anyPointCloses || F.mvpMapPoints[i]->Observations() > 0))
+            occupied[i] = 1;   // ref: :88-90, :1413-1415 (observed points only); :1565-1566 (any point)
     const vector<uint8_t> d = contiguous(F.mDescriptors);
     vector<int32_t> match(n);
     int nmatches = 0;
     const int rc = orbhip_search_by_projection(
         tls.get(), reinterpret_cast<const orbhip_keypoint *>(F.mvKeysUn.data()), d.data(), n,
-        (int)F.mvuRight.size() == n ? F.mvuRight.data() : NULL, occupied.data(), Frame::mnMinX, Frame::mnMinY,
+        (useRight && (int)F.mvuRight.size() == n) ? F.mvuRight.data() : NULL, occupied.data(), Frame::mnMinX, Frame::mnMinY,
         Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv, q.data(), qdesc.data(), nq, use_ratio ? 1 : 0, nnratio,
         check_ori ? 1 : 0, th_high, match.data(), &nmatches);
     if (rc != ORBHIP_OK)
@@ -295,6 +297,78 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     }
     return run_projection_search(CurrentFrame, q, qdesc, LastFrame.mvpMapPoints, false, mfNNratio, mbCheckOrientation,
                                  TH_HIGH);
+}
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th , const int ORBdist)
+{
+    // ref: src/ORBmatcher.cc:1500-1627 (relocalisation).  Best only, no right-coordinate test, every assigned
+    // feature is closed to the points after it (:1565-1566), threshold ORBdist, rotation histogram.
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0,3).colRange(0,3);
+    float tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) tcw[r] = CurrentFrame.mTcw.at<float>(r, 3);
+    affine3(Rcw, tcw, NULL, Ow, true, -1.0);                   // Ow = -Rcw.t()*tcw
+
+    const vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+    const int nq = (int)vpMPs.size();
+    vector<orbhip_proj_query> q(nq);
+    vector<uint8_t> qdesc((size_t)nq * 32, 0);
+    for(int i=0; i<nq; i++)
+    {
+        orbhip_proj_query &e = q[i];
+        memset(&e, 0, sizeof(e));
+        MapPoint* pMP = vpMPs[i];
+        if(!pMP)
+            continue;
+        if(pMP->isBad() || sAlreadyFound.count(pMP))
+            continue;
+
+        //Project (ref: :1524-1539)
+        const cv::Mat x3Dw = pMP->GetWorldPos();
+        const float xw[3] = {x3Dw.at<float>(0, 0), x3Dw.at<float>(1, 0), x3Dw.at<float>(2, 0)};
+        float x3Dc[3];
+        affine3(Rcw, xw, tcw, x3Dc);
+
+        const float xc = x3Dc[0];
+        const float yc = x3Dc[1];
+        const float invzc = 1.0/x3Dc[2];
+
+        const float u = CurrentFrame.fx*xc*invzc+CurrentFrame.cx;
+        const float v = CurrentFrame.fy*yc*invzc+CurrentFrame.cy;
+
+        if(u<CurrentFrame.mnMinX || u>CurrentFrame.mnMaxX)
+            continue;
+        if(v<CurrentFrame.mnMinY || v>CurrentFrame.mnMaxY)
+            continue;
+
+        // Compute predicted scale level (ref: :1541-1553); cv::norm of a float vector sums the squares in double
+        double sq = 0;
+        for (int k = 0; k < 3; k++) {
+            const float po = xw[k]-Ow[k];
+            sq += (double)po*(double)po;
+        }
+        float dist3D = std::sqrt(sq);
+
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+
+        // Depth must be inside the scale pyramid of the image
+        if(dist3D<minDistance || dist3D>maxDistance)
+            continue;
+
+        int nPredictedLevel = pMP->PredictScale(dist3D,&CurrentFrame);
+
+        // Search in a window (ref: :1555-1558)
+        e.u = u;
+        e.v = v;
+        e.radius = th*CurrentFrame.mvScaleFactors[nPredictedLevel];
+        e.min_level = nPredictedLevel-1;
+        e.max_level = nPredictedLevel+1;
+        e.angle = pKF->mvKeysUn[i].angle;                      // ref: :1587
+        e.flags = ORBHIP_Q_ACTIVE | ORBHIP_Q_OBSERVED;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        memcpy(&qdesc[(size_t)i * 32], dMP.ptr(0), 32);
+    }
+    return run_projection_search(CurrentFrame, q, qdesc, vpMPs, false, mfNNratio, mbCheckOrientation, ORBdist, true, false);
 }
 
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)
