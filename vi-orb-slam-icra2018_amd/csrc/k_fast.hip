@@ -139,6 +139,18 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
+// inclusive wave prefix sum on the DPP network (row shifts, then the row totals of the lower rows)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+
 // Append the lanes with `flag` set to an LDS list (order irrelevant); returns the slot or -1.
 __device__ __forceinline__ int wave_append(bool flag, int *counter, int lane)
 {
@@ -292,11 +304,11 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
         }
         // append this thread's survivors to the work list (order is irrelevant)
         const int n = __popc(acc);
-        const int incl = wave_incl_scan(n, lane);
-        const int total = __shfl(incl, 63);
+        const int incl = wave_incl_scan_dpp(n);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         int base = 0;
         if (lane == 63 && total > 0) base = atomicAdd(&s_listCount, total);
-        base = __shfl(base, 63);
+        base = __builtin_amdgcn_readlane(base, 63);
         int pos = base + incl - n;
         while (acc) {
             const int b = __ffs(acc) - 1;
@@ -403,13 +415,23 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
         }
     }
     __syncthreads();
-    const unsigned dhMagic = 65536u / (unsigned)DH + 1u;   // i / DH for i < 65536 / DH
-    for (int i = tid; i < nrowsAll; i += 256) {
-        const int cj = (int)(((unsigned)i * dhMagic) >> 16), r = i - cj * DH;
-        int pre = 0;
-        for (int rr = 0; rr < r; rr++) pre += __popcll(s_bits[cj * DH + rr]);
-        s_pre[i] = pre;
-        if (r == DH - 1) s_cellCnt[cj] = pre + __popcll(s_bits[i]);
+    if (DH <= 64) {
+        // one wave per cell, one lane per row: the row prefix is a wave scan of the row popcounts
+        for (int cj = tid >> 6; cj < T.ncells; cj += 4) {
+            const int n = lane < DH ? __popcll(s_bits[cj * DH + lane]) : 0;
+            const int incl = wave_incl_scan_dpp(n);
+            if (lane < DH) s_pre[cj * DH + lane] = incl - n;
+            if (lane == 63) s_cellCnt[cj] = incl;
+        }
+    } else {
+        const unsigned dhMagic = 65536u / (unsigned)DH + 1u;   // i / DH for i < 65536 / DH
+        for (int i = tid; i < nrowsAll; i += 256) {
+            const int cj = (int)(((unsigned)i * dhMagic) >> 16), r = i - cj * DH;
+            int pre = 0;
+            for (int rr = 0; rr < r; rr++) pre += __popcll(s_bits[cj * DH + rr]);
+            s_pre[i] = pre;
+            if (r == DH - 1) s_cellCnt[cj] = pre + __popcll(s_bits[i]);
+        }
     }
     __syncthreads();
     const size_t candFrame = (size_t)frame * G.totalCands + L.candBase;
