@@ -72,6 +72,81 @@ __device__ __forceinline__ uint32_t compass2(us2 v, us2 qt, us2 qb, us2 ql, us2 
     return __builtin_bit_cast(uint32_t, f);
 }
 
+// ---- score of one polarity on packed halves (gfx950: v_pk_minimum3_f16 / v_pk_maximum3_f16) ----
+// The 16 ring pixels sit as 8 registers P[k] = (q_k, q_{k+8}) whose halves are the pixel values with bit 14 set:
+// as binary16 bit patterns these are the normal numbers 2.0 .. 2.498, ordered like the integers, so the packed
+// three-input float minimum / maximum order them exactly.  op_sel feeds a register with its halves exchanged,
+// which is how "index + 8" is read.
+#define PKOP3(name, op, sel)                                                                            \
+    __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b, uint32_t c)                      \
+    {                                                                                                   \
+        uint32_t r;                                                                                     \
+        asm("v_pk_" op "_f16 %0, %1, %2, %3" sel : "=v"(r) : "v"(a), "v"(b), "v"(c));                   \
+        return r;                                                                                       \
+    }
+PKOP3(pkmin3, "minimum3", "")
+PKOP3(pkmin3_x3, "minimum3", " op_sel:[0,0,1] op_sel_hi:[1,1,0]")      // third operand with exchanged halves
+PKOP3(pkmin3_x23, "minimum3", " op_sel:[0,1,1] op_sel_hi:[1,0,0]")    // second and third
+PKOP3(pkmax3, "maximum3", "")
+PKOP3(pkmax3_x2, "maximum3", " op_sel:[0,1,0] op_sel_hi:[1,0,1]")
+
+// max over the 16 cyclic 9-arcs of the arc minimum of the ring P (pairs (k, k + 8)) after P ^= C, minus v, minus 1
+__device__ __forceinline__ int arcs_score(const uint32_t P[8], uint32_t C, int v)
+{
+    uint32_t Q[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) Q[k] = P[k] ^ C;
+    // minima of 3 consecutive ring pixels: M[k] = (m3[k], m3[k + 8])
+    uint32_t M[8];
+#pragma unroll
+    for (int k = 0; k < 6; k++) M[k] = pkmin3(Q[k], Q[k + 1], Q[k + 2]);
+    M[6] = pkmin3_x3(Q[6], Q[7], Q[0]);
+    M[7] = pkmin3_x23(Q[7], Q[0], Q[1]);
+    // minima of the 9-arcs: X[k] = (arc starting at k, arc starting at k + 8)
+    uint32_t X[8];
+    X[0] = pkmin3(M[0], M[3], M[6]);
+    X[1] = pkmin3(M[1], M[4], M[7]);
+    X[2] = pkmin3_x3(M[2], M[5], M[0]);
+    X[3] = pkmin3_x3(M[3], M[6], M[1]);
+    X[4] = pkmin3_x3(M[4], M[7], M[2]);
+    X[5] = pkmin3_x23(M[5], M[0], M[3]);
+    X[6] = pkmin3_x23(M[6], M[1], M[4]);
+    X[7] = pkmin3_x23(M[7], M[2], M[5]);
+    const uint32_t R0 = pkmax3(X[0], X[1], X[2]), R1 = pkmax3(X[3], X[4], X[5]), R2 = pkmax3(X[6], X[7], X[7]);
+    const uint32_t R = pkmax3(R0, R1, R2);
+    const uint32_t Rm = pkmax3_x2(R, R, R);                      // both halves = max(low, high)
+    return (int)(Rm & 0xFFu) - v - 1;
+}
+
+// FAST score of the pixel at p, 0 if it is not a corner at threshold t (t >= 1).  bright (q - v > t): max_arcs min_arc (q - v) - 1 = (max_arcs min_arc q) - v - 1; dark: the same
+// on the complemented bytes, v - q = (255 - q) - (255 - v).
+__device__ __forceinline__ int fast_score_pol(const uint8_t *p, int pitch, int t)
+{
+    const uint8_t *rm3 = p - 3 * pitch - 3, *rm2 = p - 2 * pitch - 3, *rm1 = p - pitch - 3, *r0 = p - 3;
+    const uint8_t *rp1 = p + pitch - 3, *rp2 = p + 2 * pitch - 3, *rp3 = p + 3 * pitch - 3;
+    // ring pixel k (OpenCV order, see fast_score_lds) paired with pixel k + 8
+    const int v0 = p[0];
+    const int q0 = rp3[3], q8 = rm3[3], q4 = r0[6], q12 = r0[0];
+    // polarity that can hold a 9-arc (it contains ring pixel 0 or 8 and ring pixel 4 or 12)
+    const bool pb = min(max(q0, q8), max(q4, q12)) > v0 + t;    // bright: q - v > t
+    const bool pd = max(min(q0, q8), min(q4, q12)) < v0 - t;    // dark:   v - q > t
+    if (!pb && !pd) return 0;
+    const bool dark = !pb;
+    const uint32_t C = dark ? 0x40FF40FFu : 0x40004000u;
+    uint32_t P[8];
+    P[0] = ((uint32_t)q0 | ((uint32_t)q8 << 16));               // (0, +3)  | (0, -3)
+    P[1] = ((uint32_t)rp3[4] | ((uint32_t)rm3[2] << 16));       // (+1, +3) | (-1, -3)
+    P[2] = ((uint32_t)rp2[5] | ((uint32_t)rm2[1] << 16));       // (+2, +2) | (-2, -2)
+    P[3] = ((uint32_t)rp1[6] | ((uint32_t)rm1[0] << 16));       // (+3, +1) | (-3, -1)
+    P[4] = ((uint32_t)q4 | ((uint32_t)q12 << 16));              // (+3, 0)  | (-3, 0)
+    P[5] = ((uint32_t)rm1[6] | ((uint32_t)rp1[0] << 16));       // (+3, -1) | (-3, +1)
+    P[6] = ((uint32_t)rm2[5] | ((uint32_t)rp2[1] << 16));       // (+2, -2) | (-2, +2)
+    P[7] = ((uint32_t)rm3[4] | ((uint32_t)rp3[2] << 16));       // (+1, -3) | (-1, +3)
+    int sc = arcs_score(P, C, v0 ^ (dark ? 0xFF : 0));
+    if (pb && pd) sc = max(sc, arcs_score(P, 0x40FF40FFu, v0 ^ 0xFF));   // both possible (rare): the dark one as well
+    return sc >= t ? sc : 0;
+}
+
 // max over the 16 cyclic 9-arcs of the arc minimum of e[]
 __device__ __forceinline__ int max_arc_min(const int e[16])
 {
@@ -333,7 +408,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
         for (int e = tid; e < nlist; e += 256) {
             const int ent = s_list[e];
             const int r = ent >> 9, j = ent & 511;
-            const int s = fast_score_lds(s_pix + __mul24(r + 3, pitch) + j, pitch, t);
+            const int s = fast_score_pol(s_pix + __mul24(r + 3, pitch) + j, pitch, t);
             if (s > 0) {
                 s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
                 const int slot = atomicAdd(&s_cornerCount, 1);   // hipcc aggregates this per wave
