@@ -320,12 +320,12 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     // the survivor list reuses the work list's storage (the work list is dead after phase 3)
     uint32_t *s_surv = reinterpret_cast<uint32_t *>(smem + pixBytes + scoreBytes);
     const int SP = (TW + 3) & ~3;
+    uint16_t *s_ent = reinterpret_cast<uint16_t *>(s_score);   // phase 2 only: u16 per item (2 * items <= DH * SP)
     for (int i = tid; i < RH * nchunk; i += 256) {
         const int r = i / nchunk, c = i - r * nchunk;
         const uint4 v = *reinterpret_cast<const uint4 *>(img + (size_t)(iniY + r) * stride + XA + (c << 4));
         *reinterpret_cast<uint4 *>(s_pix + r * pitch + (c << 4)) = v;
     }
-    for (int i = tid; i < (DH * SP) >> 2; i += 256) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
     if (tid < FAST_TILE_CELLS) {
         s_cellAny[tid] = 0;
         s_cellCnt[tid] = 0;
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
             if (item < nitems) {
                 const int r = (int)(((float)item + 0.5f) * invGPR);
                 const int jd = jd0 + ((item - __mul24(r, GPR)) << 2);
+                s_ent[item] = (uint16_t)((r << 9) | jd);   // list entry of the item's pixel 0
                 const uint8_t *row = s_pix + __mul24(r + 3, pitch) + jd;
                 const uint32_t Cw = *reinterpret_cast<const uint32_t *>(row);
                 const uint32_t Lw = *reinterpret_cast<const uint32_t *>(row - 4);
@@ -388,13 +389,14 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
         while (acc) {
             const int b = __ffs(acc) - 1;
             acc &= acc - 1;
-            const int item = ibase + (b >> 2) * 256 + tid;
-            const int r = (int)(((float)item + 0.5f) * invGPR);
-            const int j = jd0 + ((item - __mul24(r, GPR)) << 2) + (b & 3);
-            if (pos < listCap) s_list[pos] = (uint16_t)((r << 9) | j);
+            const int ent = s_ent[ibase + (b >> 2) * 256 + tid] + (b & 3);   // written by this thread above
+            if (pos < listCap) s_list[pos] = (uint16_t)ent;
             pos++;
         }
     }
+    __syncthreads();
+    // the score tile (its storage held the items' entries until here) starts at zero
+    for (int i = tid; i < (DH * SP) >> 2; i += 256) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
     __syncthreads();
     if (phases < 3) return;
 
