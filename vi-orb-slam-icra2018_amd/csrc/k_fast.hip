@@ -61,14 +61,15 @@ __device__ __forceinline__ us2 hi2(uint32_t w)
     return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
 }
 
-// Compass test of two pixels: non-zero half <=> that pixel can be a FAST-9 corner at threshold t.
+// Compass test of two pixels: bit 15 of a half is set <=> that pixel can be a FAST-9 corner at threshold t (the
+// differences are below 2^15 in magnitude, so the wrapped 16-bit difference carries the sign).
 __device__ __forceinline__ uint32_t compass2(us2 v, us2 qt, us2 qb, us2 ql, us2 qr, us2 tt)
 {
     const us2 mb = __builtin_elementwise_min(__builtin_elementwise_max(qt, qb), __builtin_elementwise_max(ql, qr));
     const us2 md = __builtin_elementwise_max(__builtin_elementwise_min(qt, qb), __builtin_elementwise_min(ql, qr));
     const us2 hi = v + tt;
     const us2 lo = __builtin_elementwise_sub_sat(v, tt);
-    const us2 f = __builtin_elementwise_sub_sat(mb, hi) | __builtin_elementwise_sub_sat(lo, md);   // each <= 255
+    const us2 f = (us2)(hi - mb) | (us2)(md - lo);   // mb > v + t  or  md < v - t  (lo = max(v - t, 0); md < 0 never holds)
     return __builtin_bit_cast(uint32_t, f);
 }
 
@@ -348,15 +349,25 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     const int GPR = ((j0 + TW + 3) >> 2) - (j0 >> 2);   // dword groups per row
     const int nitems = DH * GPR;
     const float invGPR = 1.0f / (float)GPR;   // item / GPR = floor((item + 0.5) * invGPR), exact for item < 2^16
+    // domain masks of a row's first and last dword group (pixel k at bit 8k + 7)
+    uint32_t domFirst = 0, domLast = 0;
+    {
+        const int cLast = jd0 + ((GPR - 1) << 2) - j0;
+        for (int k = 0; k < 4; k++) {
+            if (jd0 - j0 + k >= 0 && jd0 - j0 + k < TW) domFirst |= 0x80u << (8 * k);
+            if (cLast + k >= 0 && cLast + k < TW) domLast |= 0x80u << (8 * k);
+        }
+    }
     for (int ibase = 0; ibase < nitems; ibase += 8 * 256) {
-        // acc: bit (4 * i + k) = pixel k of this thread's i-th item of the chunk
+        // acc: bit (8 * k + 7 - i) = pixel k of this thread's i-th item of the chunk
         uint32_t acc = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int item = ibase + i * 256 + tid;
             if (item < nitems) {
                 const int r = (int)(((float)item + 0.5f) * invGPR);
-                const int jd = jd0 + ((item - __mul24(r, GPR)) << 2);
+                const int g = item - __mul24(r, GPR);
+                const int jd = jd0 + (g << 2);
                 s_ent[item] = (uint16_t)((r << 9) | jd);   // list entry of the item's pixel 0
                 const uint8_t *row = s_pix + __mul24(r + 3, pitch) + jd;
                 const uint32_t Cw = *reinterpret_cast<const uint32_t *>(row);
@@ -368,14 +379,11 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
                 const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
                 const uint32_t fA = compass2(lo2(Cw), lo2(Tw), lo2(Bw), lo2(lft), lo2(rgt), tt);   // px 0,1
                 const uint32_t fB = compass2(hi2(Cw), hi2(Tw), hi2(Bw), hi2(lft), hi2(rgt), tt);   // px 2,3
-                // flags (each <= 255) of px 0..3 into bytes 0..3, 0x80 per non-zero byte, then 4 bits
-                const uint32_t g = __builtin_amdgcn_perm(fB, fA, 0x06040200u);
-                const uint32_t z = (((g & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | g) & 0x80808080u;
-                // pixels of the group that lie inside the domain (first / last group of a row)
-                const int c0 = jd - j0;
-                const uint32_t dom = (0xFu << max(0, -c0)) & (0xFu >> max(0, c0 + 4 - TW));
-                const uint32_t nib = ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & dom & 0xFu;
-                acc |= nib << (4 * i);
+                // the sign bytes of px 0..3 into bytes 0..3; pixels outside the domain (first / last group of a row) are
+                // masked; item slot i keeps bit 7 - i of each byte
+                const uint32_t z = __builtin_amdgcn_perm(fB, fA, 0x07050301u);
+                const uint32_t dom = (g == 0 ? domFirst : 0x80808080u) & (g == GPR - 1 ? domLast : 0x80808080u);
+                acc |= (z & dom) >> i;
             }
         }
         // append this thread's survivors to the work list (order is irrelevant)
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
         while (acc) {
             const int b = __ffs(acc) - 1;
             acc &= acc - 1;
-            const int ent = s_ent[ibase + (b >> 2) * 256 + tid] + (b & 3);   // written by this thread above
+            const int ent = s_ent[ibase + (7 - (b & 7)) * 256 + tid] + (b >> 3);   // written by this thread above
             if (pos < listCap) s_list[pos] = (uint16_t)ent;
             pos++;
         }
