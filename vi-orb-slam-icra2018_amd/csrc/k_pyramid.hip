@@ -3,13 +3,21 @@
 // (copyMakeBorder :1143-1149) is never read by later stages and is not produced.
 //
 // One 256-thread workgroup per 128x32 output tile.  The source rows/columns the tile touches
-// (about 156 x 40 pixels at scale 1.2) are staged into LDS with 16-byte row-coalesced loads; a
-// thread then produces 4 horizontally adjacent output pixels from LDS and stores them as one
-// dword.  The column/row tap tables (source index pair + 11-bit weights) are built on the host
-// (orb_build_resize_tables).  Bound: HBM (reads 1.44 px and writes 1 px per output pixel).
+// (about 156 x 40 pixels at scale 1.2) are staged into LDS with 16-byte row-coalesced loads; the window
+// is derived from the scale factors so that the staging loads do not wait for a table read (measured: the
+// kernel is bound by that dependent-load latency and by HBM, not by arithmetic).  A thread then produces 4
+// horizontally adjacent output pixels from LDS and stores them as one dword: the taps of the four pixels
+// are byte selectors into one realigned 8-byte window (v_perm), the horizontal sums are v_dot2, the
+// vertical products mul_hi -- the tables (orb_build_resize_tables, orb_build_resize_groups) are built on the
+// host.  Bound: HBM (reads 1.44 px and writes 1 px per output pixel; with halo ~1.8 px).
+// Measured and dropped: building two levels per launch (level l+1 kept in LDS, written once): -3 % before the
+// window hint, slower than one level per launch after it.
 #include "orbhip_internal.h"
 
+#include <algorithm>
+
 #define RZ_TW 128
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // RZ_TH = rows of a tile (RZ_TH / 8 per thread): 32 for batches, 8 for a single frame or two (4x the workgroups)
 #define RZ_MAXCH 16    // 16-byte chunks per staged source row (source span <= 240 px + alignment)
 #define RZ_MAXROWS 44  // staged source rows
@@ -19,9 +27,10 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
                                                 unsigned long long sframe, uint8_t *__restrict__ dst,
                                                 int dw, int dh, int dstride, unsigned long long dframe,
                                                 const int2 *__restrict__ xtab,
-                                                const int4 *__restrict__ ytab, int xcdMap)
+                                                const int4 *__restrict__ ytab, const int4 *__restrict__ gtab, int sw, int sh,
+                                                float winx, float winy, int xcdMap)
 {
-    __shared__ __align__(16) uint8_t s_src[RZ_MAXROWS][RZ_MAXCH * 16];
+    __shared__ __align__(16) uint8_t s_src[RZ_MAXROWS + 1][RZ_MAXCH * 16];   // + 1: the 12-byte window reads of the last row
     const int tid = threadIdx.x;
     // grid = (tiles padded to a multiple of 8, frames); orbhip_internal.h, xcd_tile
     const int tilesX = (dw + RZ_TW - 1) / RZ_TW, tilesY = (dh + RZ_TH - 1) / RZ_TH;
@@ -33,9 +42,22 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     const uint8_t *S = src + (size_t)frame * sframe;
     uint8_t *D = dst + (size_t)frame * dframe;
 
-    // source window of the tile (tables are monotone)
-    const int sxmin = xtab[ox0].x & 0xFFFF, sxmax = (unsigned)xtab[ox1].x >> 16;
-    const int symin = ytab[oy0].x, symax = ytab[oy1].y;
+    // source window of the tile.  With a window hint (scale factors, winx / winy > 0) the bounds are computed, with a
+    // margin of one pixel each side, instead of being read from the tables: the staging loads below then depend on
+    // nothing that has to come from memory first (taps lie in [floor(o * scale), floor((o + 1) * scale)] for scale >= 1;
+    // the host checks the hint against the tables before it passes one).
+    int sxmin, sxmax, symin, symax;
+    if (winx > 0.f) {
+        sxmin = max((int)((float)ox0 * winx) - 1, 0);
+        sxmax = min((int)((float)(ox1 + 1) * winx) + 1, sw - 1);
+        symin = max((int)((float)oy0 * winy) - 1, 0);
+        symax = min((int)((float)(oy1 + 1) * winy) + 1, sh - 1);
+    } else {
+        sxmin = xtab[ox0].x & 0xFFFF;
+        sxmax = (unsigned)xtab[ox1].x >> 16;
+        symin = ytab[oy0].x;
+        symax = ytab[oy1].y;
+    }
     const int XA = sxmin & ~15;
     const int nch = ((sxmax - XA) >> 4) + 1;
     const int nrows = symax - symin + 1;
@@ -58,11 +80,58 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     int2 xt[4] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
 #pragma unroll
     for (int j = 0; j < NR; j++) yt[j] = ytab[min(dy0 + 8 * j, dh - 1)];
+    const bool staged = nch <= RZ_MAXCH && nrows <= RZ_MAXROWS && nrows * nch <= 512;
+    const bool grouped = staged && gtab != nullptr;
+    int4 g0 = make_int4(0, 0, 0, 0), gsel = g0, gw = g0;
+    if (grouped) {
+        const int4 *gp = gtab + 3 * (min(gx, dw - 1) >> 2);
+        g0 = gp[0];
+        gsel = gp[1];
+        gw = gp[2];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) xt[k] = xtab[min(gx + k, dw - 1)];
+        for (int k = 0; k < 4; k++) xt[k] = xtab[min(gx + k, dw - 1)];
+    }
     __syncthreads();
     if (!colLive) return;
-    const bool staged = nch <= RZ_MAXCH && nrows <= RZ_MAXROWS && nrows * nch <= 512;
+    if (grouped) {
+        // Fast path: the 8 source bytes from the group's base column on (three aligned LDS dwords, realigned) hold all
+        // eight taps of a row; a pixel's tap pair comes out with one v_perm, the horizontal sum is one v_dot2 with
+        // the weight pair, and (b * (r >> 4)) >> 16 is the high half of (b << 16) * (r >> 4).  Same integers as the
+        // generic path below.
+        const int bcol = g0.x - XA, wb = bcol & ~3, sh = bcol & 3;
+        const uint32_t sel[4] = {(uint32_t)gsel.x, (uint32_t)gsel.y, (uint32_t)gsel.z, (uint32_t)gsel.w};
+        const uint32_t wt[4] = {(uint32_t)gw.x, (uint32_t)gw.y, (uint32_t)gw.z, (uint32_t)gw.w};
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int dy = dy0 + 8 * j;
+            if (dy >= dh) break;
+            const uint32_t b0s = (uint32_t)yt[j].z << 16, b1s = (uint32_t)yt[j].w << 16;
+            const uint32_t *q0 = reinterpret_cast<const uint32_t *>(&s_src[yt[j].x - symin][wb]);
+            const uint32_t *q1 = reinterpret_cast<const uint32_t *>(&s_src[yt[j].y - symin][wb]);
+            const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], c0 = q1[0], c1 = q1[1], c2 = q1[2];
+            const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, sh), hi0 = __builtin_amdgcn_alignbyte(a2, a1, sh);
+            const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, sh), hi1 = __builtin_amdgcn_alignbyte(c2, c1, sh);
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const us2 p0 = __builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, sel[k]));
+                const us2 p1 = __builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, sel[k]));
+                const us2 w2 = __builtin_bit_cast(us2, wt[k]);
+                const uint32_t r0 = __builtin_amdgcn_udot2(p0, w2, 0u, false);
+                const uint32_t r1 = __builtin_amdgcn_udot2(p1, w2, 0u, false);
+                v[k] = (__umulhi(b0s, r0 >> 4) + __umulhi(b1s, r1 >> 4) + 2u) >> 2;   // <= 255
+            }
+            const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            uint8_t *o = D + (size_t)dy * dstride + gx;
+            if (gx + 3 < dw) {
+                *reinterpret_cast<uint32_t *>(o) = packed;
+            } else {
+                for (int k = 0; k < 4 && gx + k < dw; k++) o[k] = (uint8_t)(packed >> (8 * k));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const int dy = dy0 + 8 * j;
@@ -103,207 +172,49 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     }
 }
 
-// ---- two levels per launch ------------------------------------------------------------------------------
-// Level l+1 and level l+2 from level l in one pass: a workgroup owns a 128 x 16 tile of level l+2, computes
-// the patch of level l+1 that tile reads (about 158 x 22 pixels) from a staged window of level l, keeps it in
-// LDS, writes the part of it that it OWNS to memory, and resizes the tile from LDS.  Level l+1 is therefore
-// written once and never read back, and the pyramid takes 4 launches instead of 7.  Ownership: the columns of
-// level l+1 are cut at the first source column of every tile's first pixel (the tables are monotone), rows
-// likewise; the first / last tile of a row or column takes the margins.  The arithmetic of each level is the
-// one of k_resize (same tables), so the levels are bit-identical to the single-level kernels.
-#define R2_TW 128
-#define R2_TH 16
-#define R2_MW 176   // bytes of a patch row of level l+1 (multiple of 16)
-#define R2_MH 24    // patch rows
-#define R2_SCH 14   // 16-byte chunks of a staged row of level l
-#define R2_SH 32    // staged rows of level l
-
-struct Resize2Args {
-    const uint8_t *src;
-    uint8_t *mid, *dst;
-    int sstride, mw, mh, mstride, dw, dh, dstride;
-    unsigned long long sframe, mframe, dframe;
-    const int2 *xt1, *xt2;
-    const int4 *yt1, *yt2;
-};
-
-__global__ __launch_bounds__(256) void k_resize2(const Resize2Args A, int xcdMap)
+// Can every tile of the level stage the window that the kernel derives from the scale factors, and does that window
+// contain the taps of the tile?  (Checked on the host against the tables; otherwise the kernel reads the bounds.)
+static bool resize_window_hint_ok(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, int th, float winx,
+                                  float winy)
 {
-    __shared__ __align__(16) uint8_t s_src[R2_SH][R2_SCH * 16];
-    __shared__ __align__(16) uint8_t s_mid[R2_MH][R2_MW];
-    __shared__ int2 s_xt[R2_MW];
-    __shared__ int4 s_yt[R2_MH];
-    const int tid = threadIdx.x;
-    const int tilesX = (A.dw + R2_TW - 1) / R2_TW, tilesY = (A.dh + R2_TH - 1) / R2_TH;
-    const int t = xcd_tile(xcdMap), frame = blockIdx.y;
-    if (t >= tilesX * tilesY) return;
-    const int by = t / tilesX, bx = t - by * tilesX;
-    const int ox0 = bx * R2_TW, oy0 = by * R2_TH;
-    const int ox1 = min(ox0 + R2_TW, A.dw) - 1, oy1 = min(oy0 + R2_TH, A.dh) - 1;   // inclusive
-    const uint8_t *S = A.src + (size_t)frame * A.sframe;
-    uint8_t *M = A.mid + (size_t)frame * A.mframe;
-    uint8_t *D = A.dst + (size_t)frame * A.dframe;
-
-    // patch of level l+1: what the tile reads, united with what it owns
-    const int mx0 = A.xt2[ox0].x & 0xFFFF, mx1 = (unsigned)A.xt2[ox1].x >> 16;
-    const int my0 = A.yt2[oy0].x, my1 = A.yt2[oy1].y;
-    const int ownX0 = bx == 0 ? 0 : mx0, ownX1 = bx == tilesX - 1 ? A.mw : (A.xt2[ox1 + 1].x & 0xFFFF);   // [ , )
-    const int ownY0 = by == 0 ? 0 : my0, ownY1 = by == tilesY - 1 ? A.mh : A.yt2[oy1 + 1].x;
-    const int rx0 = min(ownX0, mx0) & ~3, rx1 = max(ownX1 - 1, mx1);
-    const int ry0 = min(ownY0, my0), ry1 = max(ownY1 - 1, my1);
-    const int RW4 = (rx1 - rx0 + 4) >> 2, RH = ry1 - ry0 + 1;     // groups of 4 columns, rows
-    // taps of the patch (level l -> l+1) into LDS
-    for (int i = tid; i < RW4 * 4; i += 256) s_xt[i] = A.xt1[min(rx0 + i, A.mw - 1)];
-    if (tid < RH) s_yt[tid] = A.yt1[ry0 + tid];
-    // window of level l
-    const int sxmin = A.xt1[rx0].x & 0xFFFF, sxmax = (unsigned)A.xt1[rx1].x >> 16;
-    const int symin = A.yt1[ry0].x, symax = A.yt1[ry1].y;
-    const int XA = sxmin & ~15;
-    const int nch = ((sxmax - XA) >> 4) + 1, nrows = symax - symin + 1;
-    {
-        const int n = nrows * nch;     // <= R2_SH * R2_SCH = 448 (checked on the host): two loads per thread
-        const int i0 = min(tid, n - 1), i1 = min(tid + 256, n - 1);
-        const int r0 = i0 / nch, c0 = i0 - r0 * nch, r1 = i1 / nch, c1 = i1 - r1 * nch;
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(S + (size_t)(symin + r0) * A.sstride + XA + (c0 << 4));
-        const uint4 v1 = *reinterpret_cast<const uint4 *>(S + (size_t)(symin + r1) * A.sstride + XA + (c1 << 4));
-        if (tid < n) *reinterpret_cast<uint4 *>(&s_src[r0][c0 << 4]) = v0;
-        if (tid + 256 < n) *reinterpret_cast<uint4 *>(&s_src[r1][c1 << 4]) = v1;
-    }
-    // the tile's own taps (level l+1 -> l+2), requested before the barrier
-    const int gx = ox0 + ((tid & 31) << 2);
-    const int dy0 = oy0 + (tid >> 5);
-    int4 yt2[2];
-    int2 xt2[4];
-#pragma unroll
-    for (int j = 0; j < 2; j++) yt2[j] = A.yt2[min(dy0 + 8 * j, A.dh - 1)];
-#pragma unroll
-    for (int k = 0; k < 4; k++) xt2[k] = A.xt2[min(gx + k, A.dw - 1)];
-    __syncthreads();
-
-    // ---- level l+1 patch: 4 pixels per item ----
-    const unsigned rwMagic = 65536u / (unsigned)RW4 + 1u;   // i / RW4 for i < 65536 / RW4
-    for (int i = tid; i < RH * RW4; i += 256) {
-        const int row = (int)(((unsigned)i * rwMagic) >> 16), g = i - row * RW4;
-        const int4 yt = s_yt[row];
-        const uint8_t *L0 = &s_src[yt.x - symin][0], *L1 = &s_src[yt.y - symin][0];
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int2 xt = s_xt[4 * g + k];
-            const int sx0 = (xt.x & 0xFFFF) - XA, sx1 = (int)((unsigned)xt.x >> 16) - XA;
-            const int a0 = (short)(xt.y & 0xFFFF), a1 = xt.y >> 16;
-            const int r0 = L0[sx0] * a0 + L0[sx1] * a1;
-            const int r1 = L1[sx0] * a0 + L1[sx1] * a1;
-            const int v = (((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * k);
-        }
-        *reinterpret_cast<uint32_t *>(&s_mid[row][4 * g]) = packed;
-        const int y = ry0 + row, x = rx0 + 4 * g;
-        if (y >= ownY0 && y < ownY1) {
-            uint8_t *o = M + (size_t)y * A.mstride + x;
-            if (x >= ownX0 && x + 3 < ownX1)
-                *reinterpret_cast<uint32_t *>(o) = packed;
-            else
-                for (int k = 0; k < 4; k++)
-                    if (x + k >= ownX0 && x + k < ownX1) o[k] = (uint8_t)(packed >> (8 * k));
-        }
-    }
-    __syncthreads();
-
-    // ---- level l+2 tile from the patch ----
-    if (gx >= A.dw) return;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int dy = dy0 + 8 * j;
-        if (dy >= A.dh) break;
-        const uint8_t *L0 = &s_mid[yt2[j].x - ry0][0], *L1 = &s_mid[yt2[j].y - ry0][0];
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int sx0 = (xt2[k].x & 0xFFFF) - rx0, sx1 = (int)((unsigned)xt2[k].x >> 16) - rx0;
-            const int a0 = (short)(xt2[k].y & 0xFFFF), a1 = xt2[k].y >> 16;
-            const int r0 = L0[sx0] * a0 + L0[sx1] * a1;
-            const int r1 = L1[sx0] * a0 + L1[sx1] * a1;
-            const int v = (((yt2[j].z * (r0 >> 4)) >> 16) + ((yt2[j].w * (r1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * k);
-        }
-        uint8_t *o = D + (size_t)dy * A.dstride + gx;
-        if (gx + 3 < A.dw)
-            *reinterpret_cast<uint32_t *>(o) = packed;
-        else
-            for (int k = 0; k < 4 && gx + k < A.dw; k++) o[k] = (uint8_t)(packed >> (8 * k));
-    }
-}
-
-// Host check: do all tiles of this level pair fit the LDS windows of k_resize2?  (Tables as built by
-// orb_build_resize_tables: xt = {sx0 | sx1 << 16, weights}, yt = {sy0, sy1, b0, b1}.)
-bool resize2_fits(const int32_t *xt1, const int32_t *yt1, int mw, int mh, const int32_t *xt2, const int32_t *yt2, int dw,
-                  int dh)
-{
-    const int tilesX = (dw + R2_TW - 1) / R2_TW, tilesY = (dh + R2_TH - 1) / R2_TH;
-    for (int bx = 0; bx < tilesX; bx++) {
-        const int ox0 = bx * R2_TW, ox1 = std::min(ox0 + R2_TW, dw) - 1;
-        const int mx0 = xt2[2 * ox0] & 0xFFFF, mx1 = (unsigned)xt2[2 * ox1] >> 16;
-        const int ownX0 = bx == 0 ? 0 : mx0, ownX1 = bx == tilesX - 1 ? mw : (xt2[2 * (ox1 + 1)] & 0xFFFF);
-        const int rx0 = std::min(ownX0, mx0) & ~3, rx1 = std::max(ownX1 - 1, mx1);
-        if (rx1 >= mw || ((rx1 - rx0 + 4) >> 2) * 4 > R2_MW) return false;
-        const int sxmin = xt1[2 * rx0] & 0xFFFF, sxmax = (unsigned)xt1[2 * rx1] >> 16;
-        const int nch = ((sxmax - (sxmin & ~15)) >> 4) + 1;
-        if (nch > R2_SCH) return false;
-        for (int by = 0; by < tilesY; by++) {
-            const int oy0 = by * R2_TH, oy1 = std::min(oy0 + R2_TH, dh) - 1;
-            const int my0 = yt2[4 * oy0], my1 = yt2[4 * oy1 + 1];
-            const int ownY0 = by == 0 ? 0 : my0, ownY1 = by == tilesY - 1 ? mh : yt2[4 * (oy1 + 1)];
-            const int ry0 = std::min(ownY0, my0), ry1 = std::max(ownY1 - 1, my1);
-            if (ry1 >= mh || ry1 - ry0 + 1 > R2_MH) return false;
-            const int nrows = yt1[4 * ry1 + 1] - yt1[4 * ry0] + 1;
-            if (nrows > R2_SH || nrows * nch > 512) return false;
+    for (int ox0 = 0; ox0 < dw; ox0 += RZ_TW) {
+        const int ox1 = std::min(ox0 + RZ_TW, dw) - 1;
+        const int lo = std::max((int)((float)ox0 * winx) - 1, 0), hi = std::min((int)((float)(ox1 + 1) * winx) + 1, sw - 1);
+        if (lo > (xt[2 * ox0] & 0xFFFF) || hi < (int)((uint32_t)xt[2 * ox1] >> 16)) return false;
+        const int nch = ((hi - (lo & ~15)) >> 4) + 1;
+        if (nch > RZ_MAXCH) return false;
+        for (int oy0 = 0; oy0 < dh; oy0 += th) {
+            const int oy1 = std::min(oy0 + th, dh) - 1;
+            const int rlo = std::max((int)((float)oy0 * winy) - 1, 0), rhi = std::min((int)((float)(oy1 + 1) * winy) + 1, sh - 1);
+            if (rlo > yt[4 * oy0] || rhi < yt[4 * oy1 + 1]) return false;
+            const int nrows = rhi - rlo + 1;
+            if (nrows > RZ_MAXROWS || nrows * nch > 512) return false;
         }
     }
     return true;
 }
 
-void launch_resize2(hipStream_t s, const uint8_t *src, int sstride, size_t sframe, uint8_t *mid, int mw, int mh, int mstride,
-                    uint8_t *dst, int dw, int dh, int dstride, size_t pyrFrame, const int32_t *xt1, const int32_t *yt1,
-                    const int32_t *xt2, const int32_t *yt2, int B)
+bool resize_hint_fits(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, int th)
 {
-    Resize2Args A;
-    A.src = src;
-    A.mid = mid;
-    A.dst = dst;
-    A.sstride = sstride;
-    A.mw = mw;
-    A.mh = mh;
-    A.mstride = mstride;
-    A.dw = dw;
-    A.dh = dh;
-    A.dstride = dstride;
-    A.sframe = sframe;
-    A.mframe = pyrFrame;
-    A.dframe = pyrFrame;
-    A.xt1 = reinterpret_cast<const int2 *>(xt1);
-    A.xt2 = reinterpret_cast<const int2 *>(xt2);
-    A.yt1 = reinterpret_cast<const int4 *>(yt1);
-    A.yt2 = reinterpret_cast<const int4 *>(yt2);
-    dim3 grid(orb_xcd_grid(((dw + R2_TW - 1) / R2_TW) * ((dh + R2_TH - 1) / R2_TH), 1), B, 1);
-    hipLaunchKernelGGL(k_resize2, grid, dim3(256, 1, 1), 0, s, A, orb_xcd_arg(1));
+    return resize_window_hint_ok(xt, yt, sw, sh, dw, dh, th, (float)sw / (float)dw, (float)sh / (float)dh);
 }
 
 void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, size_t sframe,
                    uint8_t *dst, int dw, int dh, int dstride, size_t dframe, const int32_t *xtab,
-                   const int32_t *ytab, int B)
+                   const int32_t *ytab, const int32_t *gtab, bool hint, int B)
 {
-    (void)sw;
-    (void)sh;
     dim3 block(256, 1, 1);
     const int th = B >= 8 ? 32 : 8;
+    const float winx = hint ? (float)sw / (float)dw : 0.f, winy = hint ? (float)sh / (float)dh : 0.f;
     dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + th - 1) / th), 1), B, 1);
     if (th == 32)
         hipLaunchKernelGGL(k_resize<32>, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
                            (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
-                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg(1));
+                           reinterpret_cast<const int4 *>(ytab), reinterpret_cast<const int4 *>(gtab), sw, sh, winx, winy,
+                           orb_xcd_arg(1));
     else
         hipLaunchKernelGGL(k_resize<8>, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
                            (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
-                           reinterpret_cast<const int4 *>(ytab), orb_xcd_arg(1));
+                           reinterpret_cast<const int4 *>(ytab), reinterpret_cast<const int4 *>(gtab), sw, sh, winx, winy,
+                           orb_xcd_arg(1));
 }

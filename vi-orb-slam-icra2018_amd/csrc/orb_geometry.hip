@@ -117,6 +117,33 @@ void orb_build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t
     }
 }
 
+// Column taps of four adjacent destination pixels as byte selectors into the 8 source bytes that start at the
+// first pixel's left tap: 12 ints per group = {base column, 0, 0, 0}, v_perm selectors of the four pixels
+// (bytes [left tap, 0, right tap, 0]), weight pairs a0 | a1 << 16.  Returns false when a group does not fit
+// (a tap more than 7 columns from the base: scale factors above 2, or a negative weight).
+bool orb_build_resize_groups(const std::vector<int32_t> &xtab, const std::vector<int32_t> &ytab, int dw,
+                             std::vector<int32_t> &gtab)
+{
+    const int ng = (dw + 3) / 4;
+    gtab.assign((size_t)ng * 12, 0);
+    for (size_t dy = 0; dy < ytab.size() / 4; dy++)
+        if (ytab[4 * dy + 2] < 0 || ytab[4 * dy + 2] > 2048 || ytab[4 * dy + 3] < 0 || ytab[4 * dy + 3] > 2048) return false;
+    for (int g = 0; g < ng; g++) {
+        const int base = xtab[2 * (4 * g)] & 0xFFFF;
+        gtab[(size_t)g * 12] = base;
+        for (int k = 0; k < 4; k++) {
+            const int dx = std::min(4 * g + k, dw - 1);
+            const int sx0 = xtab[2 * dx] & 0xFFFF, sx1 = (int)((uint32_t)xtab[2 * dx] >> 16);
+            const int a0 = (int16_t)(xtab[2 * dx + 1] & 0xFFFF), a1 = xtab[2 * dx + 1] >> 16;
+            const int o0 = sx0 - base, o1 = sx1 - base;
+            if (o0 < 0 || o0 > 7 || o1 < 0 || o1 > 7 || a0 < 0 || a1 < 0 || a0 > 2048 || a1 > 2048) return false;
+            gtab[(size_t)g * 12 + 4 + k] = o0 | (0x0c << 8) | (o1 << 16) | (0x0c << 24);
+            gtab[(size_t)g * 12 + 8 + k] = a0 | (a1 << 16);
+        }
+    }
+    return true;
+}
+
 int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
 {
     OrbLevels &G = c->G;

@@ -87,14 +87,14 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
             while (all.size() % 4) all.push_back(0);
             c->resizeTabOff[l][1] = all.size();
             all.insert(all.end(), yt.begin(), yt.end());
+            std::vector<int32_t> gt;
+            c->resizeGroups[l] = orb_build_resize_groups(xt, yt, c->G.lv[l].w, gt);
+            c->resizeHint[l][0] = resize_hint_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, 32);
+            c->resizeHint[l][1] = resize_hint_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, 8);
+            while (all.size() % 4) all.push_back(0);
+            c->resizeTabOff[l][2] = all.size();
+            if (c->resizeGroups[l]) all.insert(all.end(), gt.begin(), gt.end());
         }
-        // which level pairs (l, l+1), l = 1, 3, 5, ..., fit the two-level kernel
-        static const int noFuse = getenv("ORBHIP_RESIZE_FUSE") ? !atoi(getenv("ORBHIP_RESIZE_FUSE")) : 0;
-        for (int l = 0; l < ORBHIP_MAX_LEVELS; l++) c->fusePair[l] = false;
-        for (int l = 1; l + 1 < c->nlevels; l += 2)
-            c->fusePair[l] = !noFuse && resize2_fits(all.data() + c->resizeTabOff[l][0], all.data() + c->resizeTabOff[l][1],
-                                                     c->G.lv[l].w, c->G.lv[l].h, all.data() + c->resizeTabOff[l + 1][0],
-                                                     all.data() + c->resizeTabOff[l + 1][1], c->G.lv[l + 1].w, c->G.lv[l + 1].h);
         int rc2;
         if ((rc2 = ensure(c, c->d_resizeTab, c->cap_resize, all.size() * 4 + 16))) return rc2;
         if ((rc2 = ensure(c, c->d_fastTiles, c->cap_fastTiles, c->fastTiles.size() * sizeof(FastTile)))) return rc2;
@@ -271,18 +271,10 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
         const uint8_t *src = (l == 1) ? lvl0 : c->d_pyr + S.imgOff;
         const int sstride = (l == 1) ? stride0 : S.stride;
         const size_t sframe = (l == 1) ? frame0 : c->pyrFrameBytes;
-        if (c->fusePair[l] && B >= 8) {   // levels l and l+1 in one launch (batches; a frame or two keeps the short launches)
-            const OrbLevel &D2 = G.lv[l + 1];
-            launch_resize2(s, src, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride, c->d_pyr + D2.imgOff, D2.w, D2.h,
-                           D2.stride, c->pyrFrameBytes, c->d_resizeTab + c->resizeTabOff[l][0],
-                           c->d_resizeTab + c->resizeTabOff[l][1], c->d_resizeTab + c->resizeTabOff[l + 1][0],
-                           c->d_resizeTab + c->resizeTabOff[l + 1][1], B);
-            l++;
-            continue;
-        }
         launch_resize(s, src, S.w, S.h, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride,
                       c->pyrFrameBytes, c->d_resizeTab + c->resizeTabOff[l][0],
-                      c->d_resizeTab + c->resizeTabOff[l][1], B);
+                      c->d_resizeTab + c->resizeTabOff[l][1],
+                      c->resizeGroups[l] ? c->d_resizeTab + c->resizeTabOff[l][2] : nullptr, c->resizeHint[l][B >= 8 ? 0 : 1], B);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     // E3 FAST alone on the device (it is the kernel whose roofline is reported), then the quadtree

@@ -137,8 +137,9 @@ struct orbhip_ctx {
     FastTile *d_fastTiles = nullptr;
     BlurTile *d_blurTiles = nullptr;
     int32_t *d_resizeTab = nullptr; // per level: x table [dw] int2, y table [dh] int4
-    size_t resizeTabOff[ORBHIP_MAX_LEVELS][2];
-    bool fusePair[ORBHIP_MAX_LEVELS] = {};   // fusePair[l]: levels l and l+1 are built by one k_resize2 launch
+    size_t resizeTabOff[ORBHIP_MAX_LEVELS][3];   // column taps, row taps, 4-pixel groups (k_pyramid.hip)
+    bool resizeGroups[ORBHIP_MAX_LEVELS] = {};
+    bool resizeHint[ORBHIP_MAX_LEVELS][2] = {};  // the computed source window is valid for 32-row / 8-row tiles    // the level has a group table (fast path of k_resize)
     size_t cap_lvl0 = 0, cap_pyr = 0, cap_blur = 0, cap_cand = 0, cap_cells = 0, cap_pts = 0,
            cap_kps = 0, cap_out = 0, cap_resize = 0, cap_fastTiles = 0, cap_blurTiles = 0,
            cap_pnode = 0, cap_angle = 0, cap_cnt1 = 0, cap_cnt2 = 0, cap_cnt3 = 0;
@@ -180,18 +181,16 @@ void orb_level_size(const orbhip_ctx *c, int w, int h, int level, int *lw, int *
 // Builds c->G, tiles and resize tables for a w x h image.  Returns ORBHIP_OK or an error.
 int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0);
 // Host-side resize tables for level `l` (dst) from level l-1 (src).
-bool resize2_fits(const int32_t *xt1, const int32_t *yt1, int mw, int mh, const int32_t *xt2, const int32_t *yt2, int dw,
-                  int dh);
-void launch_resize2(hipStream_t s, const uint8_t *src, int sstride, size_t sframe, uint8_t *mid, int mw, int mh, int mstride,
-                    uint8_t *dst, int dw, int dh, int dstride, size_t pyrFrame, const int32_t *xt1, const int32_t *yt1,
-                    const int32_t *xt2, const int32_t *yt2, int B);
+bool orb_build_resize_groups(const std::vector<int32_t> &xtab, const std::vector<int32_t> &ytab, int dw,
+                             std::vector<int32_t> &gtab);
 void orb_build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t> &xtab,
                              std::vector<int32_t> &ytab);
 
 // ---- kernel launchers ----
 void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, size_t sframe,
                    uint8_t *dst, int dw, int dh, int dstride, size_t dframe, const int32_t *xtab,
-                   const int32_t *ytab, int B);
+                   const int32_t *ytab, const int32_t *gtab, bool hint, int B);
+bool resize_hint_fits(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, int th);
 void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
                  uint32_t *cand, uint16_t *cellCnt, int B);
