@@ -49,7 +49,10 @@ def main(d):
             with open(os.path.join(d, "traffic.json"), "w") as fh:
                 json.dump({"kernel": "k_fast", "fetch_size_kb_raw": fa, "write_size_kb": wa,
                            "traffic_bytes_per_launch": int(2 * fa * 1024 + wa * 1024), "avg_launch_us": sum(tail) / len(tail),
-                           "launches": len(v)}, fh)
+                           "launches": len(v), "batch": 1024, "contexts": 1,
+                           "source": "profiles/%s/summary.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate "
+                                     "passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+                                     % os.path.basename(os.path.normpath(d)).replace("prof_", "")}, fh, indent=1)
 
 
 if __name__ == "__main__":
