@@ -17,7 +17,7 @@ int fast_tile_cells()
 {
     static const int n = [] {
         const char *e = getenv("ORBHIP_FAST_TILE_CELLS");
-        int v = e ? atoi(e) : 4;
+        int v = e ? atoi(e) : 5;
         return v < 1 ? 1 : (v > FAST_TILE_CELLS ? FAST_TILE_CELLS : v);
     }();
     return n;
@@ -200,13 +200,16 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
         int tileCells = fast_tile_cells();
         while (tileCells > 1 && tileCells * L.wCell + 6 + 16 > FAST_MAX_TILE_W) tileCells--;
         if (L.wCell + 6 + 16 > FAST_MAX_TILE_W) return ORBHIP_E_SIZE;
+        // the cells of a cell-row are dealt to ceil(nCols / tileCells) runs of nearly equal length
+        const int nruns = (L.nCols + tileCells - 1) / tileCells, runBase = L.nCols / nruns, runExtra = L.nCols % nruns;
         for (int i = 0; i < L.nRows; i++)
-            for (int j = 0; j < L.nCols; j += tileCells) {
+            for (int r = 0, j = 0; r < nruns; r++) {
                 FastTile t;
                 t.level = (short)l;
                 t.row = (short)i;
                 t.c0 = (short)j;
-                t.ncells = (short)std::min(tileCells, L.nCols - j);
+                t.ncells = (short)(runBase + (r < runExtra ? 1 : 0));
+                j += t.ncells;
                 c->fastTiles.push_back(t);
             }
         for (int ty = 0; ty < (L.h + BLUR_TILE_H - 1) / BLUR_TILE_H; ty++)
