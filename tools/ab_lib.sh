@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of two prebuilt libraries inside ONE gpurun call (run-to-run differences between boxes exceed small gains):
+#   tools/ab_lib.sh old.so new.so [rounds]
+OLD=$1; NEW=$2; N=${3:-3}
+LIB=vi-orb-slam-icra2018_amd/csrc/liborbhip.so
+cp $LIB /tmp/liborbhip_keep.so
+for i in $(seq $N); do
+  for v in OLD NEW; do
+    cp ${!v} $LIB
+    python bench.py --cpu-frames 0 --pipelined 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['stage_ms'])"
+  done
+done
+cp /tmp/liborbhip_keep.so $LIB
