@@ -303,6 +303,22 @@ int orbhip_search_for_initialization_device(orbhip_ctx *ctx, const void *d_kps1_
                                             void *d_prev_matched, int window_size, float nnratio, int check_ori,
                                             void *d_matches12, void *d_nmatches);
 
+/* Replaces the matching core of ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
+ * vector<pair<size_t,size_t>> &vMatchedPairs, bool bOnlyStereo) (src/ORBmatcher.cc:657-827, with
+ * CheckDistEpipolarLine :140-157; called by LocalMapping::CreateNewMapPoints).  Both key frames as mvKeysUn,
+ * descriptors, skip[i] != 0 <=> GetMapPoint(i) != NULL, mvuRight (NULL = monocular) and their FeatureVectors in CSR
+ * form; F12 3x3 row-major float; (ex, ey) the epipole in the second image (:664-671, computed by the caller);
+ * scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2.  TH_LOW = 50.  matches12[i1] = feature of
+ * key frame 2 or -1 after the rotation histogram; *nmatches = the reference's return value.  (This fork does not mark
+ * matched features of key frame 2, so one of them can be matched by several features of key frame 1.) */
+int orbhip_search_for_triangulation(orbhip_ctx *ctx, const orbhip_keypoint *kps1_un, const uint8_t *desc1, int n1,
+                                    const uint8_t *skip1, const float *u_right1, const int32_t *node1, const int32_t *off1,
+                                    const int32_t *idx1, int ng1, const orbhip_keypoint *kps2_un, const uint8_t *desc2, int n2,
+                                    const uint8_t *skip2, const float *u_right2, const int32_t *node2, const int32_t *off2,
+                                    const int32_t *idx2, int ng2, const float F12[9], float ex, float ey,
+                                    const float *scale_factors2, const float *level_sigma2_2, int nlevels2, int only_stereo,
+                                    int check_ori, int32_t *matches12, int *nmatches);
+
 /* ---- undistortion and rectification ----
  * Replaces the body of Frame::UndistortKeyPoints (src/Frame.cc:748-778): cv::undistortPoints(mat, mat, mK,
  * mDistCoef, cv::Mat(), mK) on the keypoint coordinates; every other field of a keypoint is copied.  K, P: 3x3

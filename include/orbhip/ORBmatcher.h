@@ -11,14 +11,18 @@
 // SearchForInitialization (the monocular initialiser's matcher, src/ORBmatcher.cc:405-520) runs as one call
 // (orbhip_search_for_initialization): windows and distances in parallel, the owner bookkeeping in the reference's order.
 //
+// SearchForTriangulation (LocalMapping::CreateNewMapPoints, src/ORBmatcher.cc:657-827): node-grouped matching with the
+// epipolar tests, one call (orbhip_search_for_triangulation); the epipole is computed here on the host.
+//
 // The other guided-search routines of the reference (SearchByProjection with a Sim3,
-// SearchForTriangulation, SearchBySim3, Fuse x2) are pose/projection logic around
+// SearchBySim3, Fuse x2) are pose/projection logic around
 // the same best/second-best primitive; they stay in the reference's own ORBmatcher.cc (SURVEY.md section 8a,
 // row M3) and can call orbhip_hamming_knn2_lists for their inner loops.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
 #include <set>
+#include <utility>
 #include <vector>
 
 #ifdef ORBHIP_WITH_REFERENCE_HEADERS
@@ -67,6 +71,10 @@ public:
 
     // Matching for the Map Initialization (only used in the monocular case) (ref: src/ORBmatcher.cc:405-520)
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize=10);
+
+    // Matching to triangulate new MapPoints. Check Epipolar Constraint. (ref: src/ORBmatcher.cc:657-827)
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame* pKF2, cv::Mat F12,
+                               std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo);
 
     // Device context used for matching.  By default one small context per thread is created on
     // first use (matchers are stack objects in the reference and are used from three threads).

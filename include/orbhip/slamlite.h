@@ -125,11 +125,29 @@ inline int MapPoint::PredictScale(const float &currentDist, Frame *pF)
 class KeyFrame
 {
 public:
+    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0) {}
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;   // ref: include/KeyFrame.h (const members there)
     cv::Mat mDescriptors;
     DBoW2::FeatureVector mFeatVec;
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
     std::vector<MapPoint *> mvpMapPoints;
+
+    // read by ORBmatcher::SearchForTriangulation (ref: src/ORBmatcher.cc:657-827)
+    int N;
+    float fx, fy, cx, cy;
+    std::vector<float> mvuRight;                  // negative value for monocular points
+    std::vector<float> mvScaleFactors, mvLevelSigma2;
+    MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
+    cv::Mat GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }     // ref: src/KeyFrame.cc
+    cv::Mat GetTranslation()
+    {
+        cv::Mat t(3, 1, CV_32F);
+        for (int r = 0; r < 3; r++) t.at<float>(r, 0) = Tcw.at<float>(r, 3);
+        return t;
+    }
+    cv::Mat GetCameraCenter() { return Ow.clone(); }
+    cv::Mat Tcw;                                  // 4 x 4 CV_32F (protected in the reference; the test programs fill it)
+    cv::Mat Ow;                                   // 3 x 1 CV_32F
 };
 
 }  // namespace ORB_SLAM2

@@ -1685,6 +1685,99 @@ int orbo_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *des
     return nmatches;
 }
 
+/* ORBmatcher::SearchForTriangulation (ref: src/ORBmatcher.cc:657-827; the matcher of LocalMapping::CreateNewMapPoints)
+ * with CheckDistEpipolarLine (:140-157).  Features of key frame 1 that hold no MapPoint search, inside their vocabulary
+ * node, the features of key frame 2 that hold none: Hamming distance <= TH_LOW and <= the best so far (:719-720, a later
+ * candidate at the same distance replaces the earlier one), not closer than 10 px * scale to the epipole when neither
+ * feature is stereo (:724-730), distance to the epipolar line x1' F12 below 3.84 sigma2 (:732-736).  This fork never
+ * sets vbMatched2, so a feature of key frame 2 may be the match of several features of key frame 1.  Rotation histogram
+ * as in the other routines (:745-755, :775-794).  skip1/skip2[i] != 0: the feature holds a MapPoint; u_right1/2 may be
+ * NULL (monocular: nothing is stereo).  matches12[n1] = index into key frame 2 or -1; returns nmatches. */
+int orbo_search_for_triangulation(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const uint8_t *skip1,
+                                  const float *u_right1, const int32_t *node1, const int32_t *off1, const int32_t *idx1,
+                                  int ng1, const orbo_keypoint *kps2, const uint8_t *desc2, int n2, const uint8_t *skip2,
+                                  const float *u_right2, const int32_t *node2, const int32_t *off2, const int32_t *idx2,
+                                  int ng2, const float *F12, float ex, float ey, const float *scale_factors2,
+                                  const float *level_sigma2_2, int only_stereo, int check_ori, int th_low,
+                                  int32_t *matches12)
+{
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        hist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 + 1));
+        hn[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    int nmatches = 0;
+    int g1 = 0, g2 = 0;
+    while (g1 < ng1 && g2 < ng2) {
+        if (node1[g1] == node2[g2]) {
+            for (int a = off1[g1]; a < off1[g1 + 1]; a++) {
+                const int i1 = idx1[a];
+                if (skip1[i1]) continue;
+                const int bStereo1 = u_right1 && u_right1[i1] >= 0;
+                if (only_stereo && !bStereo1) continue;
+                const orbo_keypoint *kp1 = &kps1[i1];
+                int bestDist = th_low, bestIdx2 = -1;
+                for (int b = off2[g2]; b < off2[g2 + 1]; b++) {
+                    const int i2 = idx2[b];
+                    if (skip2[i2]) continue; /* vbMatched2 stays false in this fork */
+                    const int bStereo2 = u_right2 && u_right2[i2] >= 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = orbo_descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                    if (dist > th_low || dist > bestDist) continue;
+                    const orbo_keypoint *kp2 = &kps2[i2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2->x, distey = ey - kp2->y;
+                        if (distex * distex + distey * distey < 100 * scale_factors2[kp2->octave]) continue;
+                    }
+                    /* CheckDistEpipolarLine */
+                    const float la = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+                    const float lb = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+                    const float lc = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+                    const float num = la * kp2->x + lb * kp2->y + lc;
+                    const float den = la * la + lb * lb;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if (dsqr < 3.84 * level_sigma2_2[kp2->octave]) {
+                        bestIdx2 = i2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[i1] = bestIdx2;
+                    nmatches++;
+                    if (check_ori) {
+                        float rot = kp1->angle - kps2[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        if (bin >= 0 && bin < HISTO_LENGTH) hist[bin][hn[bin]++] = i1;
+                    }
+                }
+            }
+            g1++;
+            g2++;
+        } else if (node1[g1] < node2[g2])
+            g1++; /* lower_bound on a sorted map = advance */
+        else
+            g2++;
+    }
+    if (check_ori) {
+        int a, b, c;
+        orbo_three_maxima(hn, HISTO_LENGTH, &a, &b, &c);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == a || i == b || i == c) continue;
+            for (int j = 0; j < hn[i]; j++) {
+                matches12[hist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Next row: the steps either side of extraction.
  *  - Frame::UndistortKeyPoints (ref: src/Frame.cc:748-778) = cv::undistortPoints(mat, mat, mK, mDistCoef,

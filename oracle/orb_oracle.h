@@ -180,6 +180,15 @@ int orbo_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *des
                                    float *prev_matched, int window_size, float nnratio, int check_ori, int th_low,
                                    int32_t *matches12);
 
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-827) with CheckDistEpipolarLine (:140-157); F12 row-major */
+int orbo_search_for_triangulation(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const uint8_t *skip1,
+                                  const float *u_right1, const int32_t *node1, const int32_t *off1, const int32_t *idx1,
+                                  int ng1, const orbo_keypoint *kps2, const uint8_t *desc2, int n2, const uint8_t *skip2,
+                                  const float *u_right2, const int32_t *node2, const int32_t *off2, const int32_t *idx2,
+                                  int ng2, const float *F12, float ex, float ey, const float *scale_factors2,
+                                  const float *level_sigma2_2, int only_stereo, int check_ori, int th_low,
+                                  int32_t *matches12);
+
 /* ---- undistortion / rectification ---- */
 /* cv::undistortPoints(src, dst, K, D, Mat(), P) as Frame::UndistortKeyPoints calls it (src/Frame.cc:767);
  * K, P: 3x3 row-major float (P may be NULL = identity), D: nD in {0,4,5,8} coefficients. */

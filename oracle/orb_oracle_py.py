@@ -467,6 +467,35 @@ def search_for_initialization(kps1, desc1, kps2, desc2, gp, prev_matched, window
     return n, m12[:len(kps1)].copy(), prev
 
 
+def search_for_triangulation(kps1, desc1, skip1, groups1, kps2, desc2, skip2, groups2, F12, ex, ey, scale_factors2,
+                             level_sigma2_2, u_right1=None, u_right2=None, only_stereo=False, check_ori=True, th_low=50):
+    """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-827).  groups = FeatureVector in CSR form (node ids,
+    offsets, feature indices).  Returns (nmatches, matches12)."""
+    L = lib()
+    vp = C.c_void_p
+    L.orbo_search_for_triangulation.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int] * 2 + \
+        [vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.orbo_search_for_triangulation.restype = C.c_int
+    kps1, kps2 = np.ascontiguousarray(kps1), np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    skip1, skip2 = np.ascontiguousarray(skip1, np.uint8), np.ascontiguousarray(skip2, np.uint8)
+    g1 = [np.ascontiguousarray(a, np.int32) for a in groups1]
+    g2 = [np.ascontiguousarray(a, np.int32) for a in groups2]
+    ur1 = None if u_right1 is None else np.ascontiguousarray(u_right1, np.float32)
+    ur2 = None if u_right2 is None else np.ascontiguousarray(u_right2, np.float32)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sf = np.ascontiguousarray(scale_factors2, np.float32)
+    s2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+    m12 = np.empty(max(len(kps1), 1), np.int32)
+    n = L.orbo_search_for_triangulation(_p(kps1), _p(desc1), len(kps1), _p(skip1), None if ur1 is None else _p(ur1),
+                                        _p(g1[0]), _p(g1[1]), _p(g1[2]), len(g1[0]), _p(kps2), _p(desc2), len(kps2), _p(skip2),
+                                        None if ur2 is None else _p(ur2), _p(g2[0]), _p(g2[1]), _p(g2[2]), len(g2[0]), _p(F),
+                                        float(ex), float(ey), _p(sf), _p(s2), 1 if only_stereo else 0, 1 if check_ori else 0,
+                                        th_low, _p(m12))
+    return n, m12[:len(kps1)].copy()
+
+
 # ---- undistortion / rectification (SURVEY 8f row 4) ----
 def undistort_points(xy, K, D, P=None):
     """cv::undistortPoints(xy, K, D, Mat(), P) -- Frame::UndistortKeyPoints (src/Frame.cc:748-778)."""

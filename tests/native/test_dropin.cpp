@@ -8,6 +8,7 @@
 //   System.cc:336-339     mpVocabulary->loadFromBinaryFile(strVocFile)
 //   Frame.cc:739-746      mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)
 // Inputs/outputs are raw binary files so that tests/test_gpu_dropin.py can compare with the oracle.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -142,6 +143,43 @@ int main(int argc, char **argv)
         cv::Mat a = kf.mDescriptors.row(0), b = F.mDescriptors.row(0);
         int d = ORBmatcher::DescriptorDistance(a, b);
         fwrite(&d, 4, 1, out);
+    }
+    {
+        // LocalMapping::CreateNewMapPoints: ORBmatcher matcher(0.6,false); matcher.SearchForTriangulation(mpCurrentKeyFrame,
+        // pKF2, F12, vMatchedIndices, false) -- here with the orientation check on as well; monocular key frames
+        kf.N = (int)kf.mvKeysUn.size();
+        kf2.N = (int)kf2.mvKeysUn.size();
+        const float K[4] = {458.654f, 457.296f, 367.215f, 248.375f};
+        for (int which = 0; which < 2; which++) {
+            KeyFrame &k = which ? kf2 : kf;
+            k.fx = K[0]; k.fy = K[1]; k.cx = K[2]; k.cy = K[3];
+            k.mvuRight = std::vector<float>(k.N, -1.0f);
+            k.mvScaleFactors = sfs;
+            k.mvLevelSigma2 = s2;
+            k.Tcw = cv::Mat::zeros(4, 4, CV_32F);
+            for (int d = 0; d < 4; d++) k.Tcw.at<float>(d, d) = 1.0f;
+            k.Ow = cv::Mat::zeros(3, 1, CV_32F);
+        }
+        // key frame 2: a little rotation about y and a baseline along x (Tcw given, Ow = -R' t)
+        const float ang = 0.01f, tx = -0.2f, ty = 0.01f, tz = 0.05f;
+        kf2.Tcw.at<float>(0, 0) = cosf(ang); kf2.Tcw.at<float>(0, 2) = sinf(ang);
+        kf2.Tcw.at<float>(2, 0) = -sinf(ang); kf2.Tcw.at<float>(2, 2) = cosf(ang);
+        kf2.Tcw.at<float>(0, 3) = tx; kf2.Tcw.at<float>(1, 3) = ty; kf2.Tcw.at<float>(2, 3) = tz;
+        cv::Mat F12(3, 3, CV_32F);
+        const float Fv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, -1.f, 0.f, 1.f, 0.f};   // epipolar lines = image rows
+        for (int i = 0; i < 9; i++) F12.at<float>(i / 3, i % 3) = Fv[i];
+        for (int ori = 0; ori < 2; ori++) {
+            ORBmatcher matcher(0.6, ori != 0);
+            std::vector<std::pair<size_t, size_t> > vMatchedIndices;
+            int nmatches = matcher.SearchForTriangulation(&kf, &kf2, F12, vMatchedIndices, false);
+            int n = (int)vMatchedIndices.size();
+            fwrite(&nmatches, 4, 1, out);
+            fwrite(&n, 4, 1, out);
+            for (int i = 0; i < n; i++) {
+                int v[2] = {(int)vMatchedIndices[i].first, (int)vMatchedIndices[i].second};
+                fwrite(v, 4, 2, out);
+            }
+        }
     }
     if (argc > 7) {
         ORBVocabulary *mpVocabulary = new ORBVocabulary();

@@ -20,7 +20,7 @@ def _fv(node):
 def test_golden_files_present():
     assert len(EXTRACT) == 3 and os.path.exists(os.path.join(GOLD, "matching_q250_db600.npz"))
     for name in ("vocab_k5_L3.npz", "stereo_376x241_f400_l6.npz", "guided_376x241.npz", "rectify_376x241.npz",
-                 "init_search_376x241.npz"):
+                 "init_search_376x241.npz", "triangulation_376x241.npz"):
         assert os.path.exists(os.path.join(GOLD, name)), name
 
 
@@ -115,6 +115,11 @@ def test_oracle_reproduces_golden_next_rows(oracle):
     assert n == int(g["n"]) and np.array_equal(m, g["matches12"]) and np.array_equal(p, g["prev_out"])
     n, m, p = oracle.search_for_initialization(g["kps1"], g["desc1"], g["kps2"], g["desc2"], tuple(g["grid"]), p, 30, 0.9, True)
     assert n == int(g["n_again"]) and np.array_equal(m, g["matches12_again"]) and np.array_equal(p, g["prev_out_again"])
+    g = _g("triangulation_376x241.npz")
+    n, m = oracle.search_for_triangulation(g["kps1"], g["desc1"], g["skip1"], (g["node1"], g["off1"], g["idx1"]), g["kps2"],
+                                           g["desc2"], g["skip2"], (g["node2"], g["off2"], g["idx2"]), g["F12"],
+                                           g["epipole"][0], g["epipole"][1], g["scale_factors"], g["level_sigma2"])
+    assert n == int(g["n"]) and np.array_equal(m, g["matches12"])
     g = _g("rectify_376x241.npz")
     mx, my = oracle.init_undistort_rectify_map(g["K"], g["D"], g["R"], g["P"], 376, 241)
     assert float(mx.astype(np.float64).sum()) == float(g["map_x_sum"]) and np.array_equal(mx[120], g["map_x_row"])
@@ -157,6 +162,11 @@ def test_hip_reproduces_golden_next_rows():
     assert n == int(g["n"]) and np.array_equal(m, g["matches12"]) and np.array_equal(p, g["prev_out"])
     n, m, p = guided.SearchForInitialization(ex, g["kps1"], g["desc1"], g["kps2"], g["desc2"], tuple(g["grid"]), p, 30, 0.9)
     assert n == int(g["n_again"]) and np.array_equal(m, g["matches12_again"]) and np.array_equal(p, g["prev_out_again"])
+    g = _g("triangulation_376x241.npz")
+    n, m = guided.SearchForTriangulation(ex, g["kps1"], g["desc1"], g["skip1"], (g["node1"], g["off1"], g["idx1"]), g["kps2"],
+                                         g["desc2"], g["skip2"], (g["node2"], g["off2"], g["idx2"]), g["F12"],
+                                         g["epipole"][0], g["epipole"][1], g["scale_factors"], g["level_sigma2"])
+    assert n == int(g["n"]) and np.array_equal(m, g["matches12"])
     g = _g("rectify_376x241.npz")
     mx, my = rectify.initUndistortRectifyMap(g["K"], g["D"], g["R"], g["P"], 376, 241)
     assert float(mx.astype(np.float64).sum()) == float(g["map_x_sum"]) and np.array_equal(mx[120], g["map_x_row"])

@@ -100,6 +100,33 @@ def test_cpp_dropin_classes_match_oracle(oracle, tmp_path):
     assert nm == wn and cnt == n1 and np.array_equal(got, want) and nm > 50
     d, = take("<i")
     assert d == oracle.descriptor_distance(d1[0], d2[0])
+    # SearchForTriangulation(&kf, &kf2, F12, vMatchedIndices, false): the wrapper's epipole restated (gemm: double
+    # accumulation, one rounding), then the oracle
+    f32 = np.float32
+    ang = f32(0.01)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.cosf.restype = libm.sinf.restype = ctypes.c_float
+    libm.cosf.argtypes = libm.sinf.argtypes = [ctypes.c_float]
+    ca, sa = f32(libm.cosf(ang)), f32(libm.sinf(ang))
+    R2 = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]], f32)
+    t2 = np.array([-0.2, 0.01, 0.05], f32)
+    C2 = np.array([f32(sum(np.float64(R2[r, k]) * 0.0 for k in range(3)) + np.float64(t2[r])) for r in range(3)], f32)
+    invz = f32(f32(1.0) / C2[2])
+    exx = f32(f32(f32(f32(458.654) * C2[0]) * invz) + f32(367.215))
+    eyy = f32(f32(f32(f32(457.296) * C2[1]) * invz) + f32(248.375))
+    Frows = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], f32)
+    skip1 = np.array([0 if i % 7 == 3 else 1 for i in range(n1)], np.uint8)     # GetMapPoint(i) != NULL (bad ones too)
+    skip2 = np.array([0 if i % 5 == 1 else 1 for i in range(n2)], np.uint8)
+    sfv = np.array(list(P.mvScaleFactor)[:8], f32)
+    s2v = np.array(list(P.mvLevelSigma2)[:8], f32)
+    for ori in (False, True):
+        nm, cnt = take("<ii")
+        pairs = np.array(take("<%di" % (2 * cnt)), np.int32).reshape(-1, 2)
+        wn, wm = oracle.search_for_triangulation(k1, d1, skip1, fv1, k2, d2, skip2, fv2, Frows, exx, eyy, sfv, s2v,
+                                                 u_right1=np.full(n1, -1, f32), u_right2=np.full(n2, -1, f32), check_ori=ori)
+        want = np.stack([np.nonzero(wm >= 0)[0], wm[wm >= 0]], 1)
+        assert nm == wn and cnt == wn and np.array_equal(pairs, want) and wn > 3
     # ORBVocabulary::loadFromBinaryFile + transform(features, BowVector, FeatureVector, 4)
     ok, nwords = take("<ii")
     V = oracle.Vocabulary(blob)

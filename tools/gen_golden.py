@@ -139,9 +139,37 @@ def gen_init_search():
     print("init_search", n, n2)
 
 
+def gen_triangulation():
+    """ORBmatcher::SearchForTriangulation on a stereo pair's keypoints with a small synthetic vocabulary."""
+    from orbhip import distributed as D
+    L, R = synth.make_stereo_pair(203, 376, 241, disparity=14)
+    ex = oracle.Extractor(400, 1.2, 6)
+    kL, dL = ex(L)
+    kR, dR = ex(R)
+    blob = D.make_synthetic_vocabulary(205, k=5, L=3)
+    V = oracle.Vocabulary(blob)
+    g = []
+    for d in (dL, dR):
+        _, wt, nid = V.transform(d, 1)
+        g.append(oracle.feature_vector(nid, wt))
+    rng = np.random.default_rng(206)
+    skip1, skip2 = (rng.random(len(kL)) < 0.3).astype(np.uint8), (rng.random(len(kR)) < 0.3).astype(np.uint8)
+    F = np.array([[1e-6, 2e-5, -0.004], [-2e-5, 1e-6, -1.0], [0.003, 1.0, 0.05]], np.float32)
+    sf = np.array(list(ex.params.mvScaleFactor)[:6], np.float32)
+    s2 = np.array(list(ex.params.mvLevelSigma2)[:6], np.float32)
+    n, m = oracle.search_for_triangulation(kL, dL, skip1, g[0], kR, dR, skip2, g[1], F, 150.0, 100.0, sf, s2, check_ori=True)
+    np.savez_compressed(os.path.join(OUT, "triangulation_376x241.npz"), kps1=kL, desc1=dL, skip1=skip1, node1=g[0][0], off1=g[0][1],
+                        idx1=g[0][2], kps2=kR, desc2=dR, skip2=skip2, node2=g[1][0], off2=g[1][1], idx2=g[1][2], F12=F,
+                        epipole=np.array([150.0, 100.0], np.float32), scale_factors=sf, level_sigma2=s2, n=np.int32(n), matches12=m)
+    print("triangulation", n)
+
+
 if __name__ == "__main__":
-    if "init_search" in sys.argv[1:]:
+    if "triangulation" in sys.argv[1:]:
+        gen_triangulation()
+    elif "init_search" in sys.argv[1:]:
         gen_init_search()
     else:
         main()
         gen_init_search()
+        gen_triangulation()

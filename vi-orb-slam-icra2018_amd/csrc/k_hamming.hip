@@ -441,3 +441,95 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
                        idx1, desc2, valid2, off2, idx2, reinterpret_cast<const int2 *>(pairs), npairs, th,
                        th_mode, nnratio, match12, match21);
 }
+
+// ---- ORBmatcher::SearchForTriangulation (ref: src/ORBmatcher.cc:657-827, CheckDistEpipolarLine :140-157) ----
+// One wave per shared vocabulary node; the node's side-1 features one after the other, the side-2 features one per
+// lane.  A candidate counts when its distance is <= TH_LOW, it is not too close to the epipole (mono pairs) and it lies
+// within 3.84 sigma2 of the epipolar line; among those the reference keeps the smallest distance and, at equal
+// distance, the LAST one in the node's list (":719 dist>bestDist continue").  This fork never marks a side-2 feature as
+// taken, so the side-1 features are independent of each other.  Float expressions in the reference's order, no
+// contraction; the final comparison is in double as in the reference (3.84 is a double literal).
+struct TriParams {
+    float F[9];
+    float ex, ey;
+    int only_stereo, th_low;
+};
+
+__global__ __launch_bounds__(256) void k_tri_match(const orbhip_keypoint *__restrict__ kps1,
+                                                   const uint8_t *__restrict__ desc1, const uint8_t *__restrict__ skip1,
+                                                   const float *__restrict__ ur1, const int32_t *__restrict__ off1,
+                                                   const int32_t *__restrict__ idx1,
+                                                   const orbhip_keypoint *__restrict__ kps2,
+                                                   const uint8_t *__restrict__ desc2, const uint8_t *__restrict__ skip2,
+                                                   const float *__restrict__ ur2, const int32_t *__restrict__ off2,
+                                                   const int32_t *__restrict__ idx2, const int2 *__restrict__ pairs,
+                                                   int npairs, const TriParams P, const float *__restrict__ scale2,
+                                                   const float *__restrict__ sigma2, int32_t *__restrict__ match12)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + wave;
+    if (pi >= npairs) return;
+    const int2 pr = pairs[pi];
+    const int a0 = off1[pr.x], a1 = off1[pr.x + 1];
+    const int b0 = off2[pr.y], n2 = off2[pr.y + 1] - b0;
+    for (int a = a0; a < a1; a++) {
+        const int i1 = idx1[a];
+        if (skip1[i1]) continue;   // wave-uniform
+        const bool stereo1 = ur1 && ur1[i1] >= 0.f;
+        if (P.only_stereo && !stereo1) continue;
+        const float x1 = kps1[i1].x, y1 = kps1[i1].y;
+        // epipolar line in the second image: l = x1' F12 = [la lb lc]
+        const float la = __fadd_rn(__fadd_rn(__fmul_rn(x1, P.F[0]), __fmul_rn(y1, P.F[3])), P.F[6]);
+        const float lb = __fadd_rn(__fadd_rn(__fmul_rn(x1, P.F[1]), __fmul_rn(y1, P.F[4])), P.F[7]);
+        const float lc = __fadd_rn(__fadd_rn(__fmul_rn(x1, P.F[2]), __fmul_rn(y1, P.F[5])), P.F[8]);
+        const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+        uint32_t Q[8];
+        {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(desc1 + (size_t)i1 * 32);
+#pragma unroll
+            for (int k = 0; k < 8; k++) Q[k] = row[k];
+        }
+        int key = 0x7FFFFFFF;   // distance << 16 | (0xFFFF - list position): smallest distance, then the last position
+        for (int p = lane; p < n2; p += 64) {
+            const int i2 = idx2[b0 + p];
+            if (skip2[i2]) continue;
+            const bool stereo2 = ur2 && ur2[i2] >= 0.f;
+            if (P.only_stereo && !stereo2) continue;
+            const uint4 r0 = reinterpret_cast<const uint4 *>(desc2 + (size_t)i2 * 32)[0];
+            const uint4 r1 = reinterpret_cast<const uint4 *>(desc2 + (size_t)i2 * 32)[1];
+            const uint32_t R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const int d = hamming256(Q, R);
+            if (d > P.th_low) continue;
+            const orbhip_keypoint k2 = kps2[i2];
+            if (!stereo1 && !stereo2) {
+                const float dx = __fsub_rn(P.ex, k2.x), dy = __fsub_rn(P.ey, k2.y);
+                if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, scale2[k2.octave])) continue;
+            }
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2.x), __fmul_rn(lb, k2.y)), lc);
+            if (den == 0.f) continue;
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < __dmul_rn(3.84, (double)sigma2[k2.octave]))) continue;
+            key = min(key, (d << 16) | (0xFFFF - min(p, 0xFFFF)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));
+        if (lane == 0 && key != 0x7FFFFFFF) match12[i1] = idx2[b0 + (0xFFFF - (key & 0xFFFF))];
+    }
+}
+
+void launch_tri_match(hipStream_t s, const orbhip_keypoint *kps1, const uint8_t *desc1, const uint8_t *skip1, const float *ur1,
+                      const int32_t *off1, const int32_t *idx1, const orbhip_keypoint *kps2, const uint8_t *desc2,
+                      const uint8_t *skip2, const float *ur2, const int32_t *off2, const int32_t *idx2, const int32_t *pairs,
+                      int npairs, const float F12[9], float ex, float ey, int only_stereo, int th_low, const float *scale2,
+                      const float *sigma2, int32_t *match12)
+{
+    if (npairs <= 0) return;
+    TriParams P;
+    for (int i = 0; i < 9; i++) P.F[i] = F12[i];
+    P.ex = ex;
+    P.ey = ey;
+    P.only_stereo = only_stereo;
+    P.th_low = th_low;
+    hipLaunchKernelGGL(k_tri_match, dim3((npairs + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, kps1, desc1, skip1, ur1, off1, idx1, kps2,
+                       desc2, skip2, ur2, off2, idx2, reinterpret_cast<const int2 *>(pairs), npairs, P, scale2, sigma2, match12);
+}

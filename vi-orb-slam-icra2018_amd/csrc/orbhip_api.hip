@@ -1189,6 +1189,110 @@ extern "C" int orbhip_search_for_initialization(orbhip_ctx *c, const orbhip_keyp
     return ORBHIP_OK;
 }
 
+extern "C" int orbhip_search_for_triangulation(orbhip_ctx *c, const orbhip_keypoint *kps1, const uint8_t *desc1, int n1,
+                                               const uint8_t *skip1, const float *u_right1, const int32_t *node1,
+                                               const int32_t *off1, const int32_t *idx1, int ng1,
+                                               const orbhip_keypoint *kps2, const uint8_t *desc2, int n2,
+                                               const uint8_t *skip2, const float *u_right2, const int32_t *node2,
+                                               const int32_t *off2, const int32_t *idx2, int ng2, const float F12[9],
+                                               float ex, float ey, const float *scale_factors2,
+                                               const float *level_sigma2_2, int nlevels2, int only_stereo, int check_ori,
+                                               int32_t *matches12, int *nmatches)
+{
+    if (!c || n1 < 0 || n2 < 0 || ng1 < 0 || ng2 < 0 || !matches12 || !nmatches || !F12 || !scale_factors2 ||
+        !level_sigma2_2 || nlevels2 < 1 || nlevels2 > 64 || n2 > 65535 || (n1 > 0 && (!kps1 || !desc1 || !skip1)) ||
+        (n2 > 0 && (!kps2 || !desc2 || !skip2)) || (ng1 > 0 && (!node1 || !off1 || !idx1)) ||
+        (ng2 > 0 && (!node2 || !off2 || !idx2)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_search_for_triangulation: bad argument");
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    *nmatches = 0;
+    if (n1 == 0 || n2 == 0 || ng1 == 0 || ng2 == 0) return ORBHIP_OK;
+    std::vector<int32_t> pairs;   // merge walk over the two FeatureVectors (ref: :690-765)
+    for (int g1 = 0, g2 = 0; g1 < ng1 && g2 < ng2;) {
+        if (node1[g1] == node2[g2]) {
+            pairs.push_back(g1++);
+            pairs.push_back(g2++);
+        } else if (node1[g1] < node2[g2])
+            g1++;
+        else
+            g2++;
+    }
+    const int npairs = (int)pairs.size() / 2;
+    if (npairs == 0) return ORBHIP_OK;
+    const int m1 = off1[ng1], m2 = off2[ng2];
+    for (int t = 0; t < m1; t++)
+        if (idx1[t] < 0 || idx1[t] >= n1) return fail(c, ORBHIP_E_ARG, "idx1 out of range");
+    for (int t = 0; t < m2; t++)
+        if (idx2[t] < 0 || idx2[t] >= n2) return fail(c, ORBHIP_E_ARG, "idx2 out of range");
+    for (int i = 0; i < n2; i++)
+        if (kps2[i].octave < 0 || kps2[i].octave >= nlevels2) return fail(c, ORBHIP_E_ARG, "octave of key frame 2 out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    const size_t total = (size_t)(n1 + n2) * (28 + 32 + 1 + 4) + (size_t)(ng1 + ng2 + 2) * 4 + (size_t)(m1 + m2 + 2) * 4 +
+                         pairs.size() * 4 + (size_t)n1 * 4 + 512 + 20 * 256;
+    if ((rc = T.reserve(total))) return rc;
+    orbhip_keypoint *dk1 = (orbhip_keypoint *)T.take((size_t)n1 * 28), *dk2 = (orbhip_keypoint *)T.take((size_t)n2 * 28);
+    uint8_t *dd1 = (uint8_t *)T.take((size_t)n1 * 32), *dd2 = (uint8_t *)T.take((size_t)n2 * 32);
+    uint8_t *ds1 = (uint8_t *)T.take((size_t)n1), *ds2 = (uint8_t *)T.take((size_t)n2);
+    float *du1 = u_right1 ? (float *)T.take((size_t)n1 * 4) : nullptr, *du2 = u_right2 ? (float *)T.take((size_t)n2 * 4) : nullptr;
+    int32_t *do1 = (int32_t *)T.take((size_t)(ng1 + 1) * 4), *do2 = (int32_t *)T.take((size_t)(ng2 + 1) * 4);
+    int32_t *di1 = (int32_t *)T.take((size_t)m1 * 4 + 4), *di2 = (int32_t *)T.take((size_t)m2 * 4 + 4);
+    int32_t *dp = (int32_t *)T.take(pairs.size() * 4), *dm = (int32_t *)T.take((size_t)n1 * 4);
+    float *dsf = (float *)T.take(256), *dsg = (float *)T.take(256);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(dk1, kps1, (size_t)n1 * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dk2, kps2, (size_t)n2 * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(ds1, skip1, (size_t)n1, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(ds2, skip2, (size_t)n2, hipMemcpyHostToDevice, s));
+    if (du1) HIPCHK(c, hipMemcpyAsync(du1, u_right1, (size_t)n1 * 4, hipMemcpyHostToDevice, s));
+    if (du2) HIPCHK(c, hipMemcpyAsync(du2, u_right2, (size_t)n2 * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(do1, off1, (size_t)(ng1 + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(do2, off2, (size_t)(ng2 + 1) * 4, hipMemcpyHostToDevice, s));
+    if (m1) HIPCHK(c, hipMemcpyAsync(di1, idx1, (size_t)m1 * 4, hipMemcpyHostToDevice, s));
+    if (m2) HIPCHK(c, hipMemcpyAsync(di2, idx2, (size_t)m2 * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dsf, scale_factors2, (size_t)nlevels2 * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dsg, level_sigma2_2, (size_t)nlevels2 * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(dm, 0xFF, (size_t)n1 * 4, s));
+    launch_tri_match(s, dk1, dd1, ds1, du1, do1, di1, dk2, dd2, ds2, du2, do2, di2, dp, npairs, F12, ex, ey, only_stereo ? 1 : 0,
+                     /*TH_LOW*/ 50, dsf, dsg, dm);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    // rotation consistency (ref: :745-755, :775-794)
+    int nm = 0;
+    std::vector<int> hist[30];
+    const float factor = 1.0f / 30;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int i2 = matches12[i1];
+        if (i2 < 0) continue;
+        nm++;
+        if (check_ori) {
+            float rot = kps1[i1].angle - kps2[i2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == 30) bin = 0;
+            if (bin >= 0 && bin < 30) hist[bin].push_back(i1);
+        }
+    }
+    if (check_ori) {
+        int a, b, d;
+        three_maxima(hist, 30, a, b, d);
+        for (int i = 0; i < 30; i++) {
+            if (i == a || i == b || i == d) continue;
+            for (int i1 : hist[i]) {
+                matches12[i1] = -1;
+                nm--;
+            }
+        }
+    }
+    *nmatches = nm;
+    return ORBHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // undistortion / rectification
 // ------------------------------------------------------------------------------------------------

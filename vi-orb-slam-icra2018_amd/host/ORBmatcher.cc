@@ -371,6 +371,57 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
     return run_projection_search(CurrentFrame, q, qdesc, vpMPs, false, mfNNratio, mbCheckOrientation, ORBdist, true, false);
 }
 
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
+                                       vector<pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo)
+{
+    // ref: src/ORBmatcher.cc:657-827.  Epipole in the second image (:664-671) on the host; the node-grouped search with
+    // the epipolar tests and the rotation histogram in one call.
+    cv::Mat Cw = pKF1->GetCameraCenter();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    const float cw[3] = {Cw.at<float>(0, 0), Cw.at<float>(1, 0), Cw.at<float>(2, 0)};
+    const float t2[3] = {t2w.at<float>(0, 0), t2w.at<float>(1, 0), t2w.at<float>(2, 0)};
+    float C2[3];
+    affine3(R2w, cw, t2, C2);                                  // C2 = R2w*Cw+t2w
+    const float invz = 1.0f/C2[2];
+    const float ex =pKF2->fx*C2[0]*invz+pKF2->cx;
+    const float ey =pKF2->fy*C2[1]*invz+pKF2->cy;
+
+    const int n1 = pKF1->N, n2 = pKF2->N;
+    vMatchedPairs.clear();
+    if(n1==0 || n2==0)
+        return 0;
+    vector<uint8_t> skip1(n1), skip2(n2);
+    for(int i=0; i<n1; i++) skip1[i] = pKF1->GetMapPoint(i) ? 1 : 0;     // ref: :702-705
+    for(int i=0; i<n2; i++) skip2[i] = pKF2->GetMapPoint(i) ? 1 : 0;     // ref: :727-731
+    const Csr f1 = flatten(pKF1->mFeatVec), f2 = flatten(pKF2->mFeatVec);
+    float F[9];
+    for(int r=0; r<3; r++)
+        for(int c=0; c<3; c++)
+            F[3*r+c] = F12.at<float>(r,c);
+    const vector<uint8_t> d1 = contiguous(pKF1->mDescriptors), d2 = contiguous(pKF2->mDescriptors);
+    vector<int> vMatches12(n1,-1);
+    int nmatches=0;
+    const int rc = orbhip_search_for_triangulation(
+        tls.get(), reinterpret_cast<const orbhip_keypoint *>(pKF1->mvKeysUn.data()), d1.data(), n1, skip1.data(),
+        (int)pKF1->mvuRight.size()==n1 ? pKF1->mvuRight.data() : NULL, f1.node.data(), f1.off.data(), f1.idx.data(), (int)f1.node.size(),
+        reinterpret_cast<const orbhip_keypoint *>(pKF2->mvKeysUn.data()), d2.data(), n2, skip2.data(),
+        (int)pKF2->mvuRight.size()==n2 ? pKF2->mvuRight.data() : NULL, f2.node.data(), f2.off.data(), f2.idx.data(), (int)f2.node.size(),
+        F, ex, ey, pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(), (int)pKF2->mvScaleFactors.size(),
+        bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, vMatches12.data(), &nmatches);
+    if(rc != ORBHIP_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation: ") + orbhip_last_error(tls.get()));
+
+    vMatchedPairs.reserve(nmatches);
+    for(size_t i=0, iend=vMatches12.size(); i<iend; i++)
+    {
+        if(vMatches12[i]<0)
+            continue;
+        vMatchedPairs.push_back(make_pair(i,vMatches12[i]));
+    }
+    return nmatches;
+}
+
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)
 {
     // ref: src/ORBmatcher.cc:405-520.  cv::KeyPoint is the 28-byte record of orbhip_keypoint, cv::Point2f two floats.

@@ -114,3 +114,30 @@ def SearchForInitialization(ctx, kps1_un, desc1, kps2_un, desc2, gp, prev_matche
                                                        nnratio, 1 if check_ori else 0, _p(m12), C.byref(nm)),
           ctx.handle, "orbhip_search_for_initialization")
     return nm.value, m12[:len(kps1_un)].copy(), prev
+
+
+def SearchForTriangulation(ctx, kps1_un, desc1, skip1, groups1, kps2_un, desc2, skip2, groups2, F12, ex, ey, scale_factors2,
+                           level_sigma2_2, u_right1=None, u_right2=None, only_stereo=False, check_ori=True):
+    """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-827).  groups = FeatureVector as (node ids, offsets,
+    feature indices).  Returns (nmatches, vMatches12); vMatchedPairs = [(i, m) for i, m in enumerate(vMatches12) if m >= 0]."""
+    kps1_un = np.ascontiguousarray(kps1_un, KP_DTYPE)
+    kps2_un = np.ascontiguousarray(kps2_un, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    skip1, skip2 = np.ascontiguousarray(skip1, np.uint8), np.ascontiguousarray(skip2, np.uint8)
+    g1 = [np.ascontiguousarray(a, np.int32) for a in groups1]
+    g2 = [np.ascontiguousarray(a, np.int32) for a in groups2]
+    ur1 = None if u_right1 is None else np.ascontiguousarray(u_right1, f32)
+    ur2 = None if u_right2 is None else np.ascontiguousarray(u_right2, f32)
+    F = np.ascontiguousarray(F12, f32).reshape(9)
+    sf = np.ascontiguousarray(scale_factors2, f32)
+    s2 = np.ascontiguousarray(level_sigma2_2, f32)
+    m12 = np.empty(max(len(kps1_un), 1), np.int32)
+    nm = C.c_int()
+    check(capi.load().orbhip_search_for_triangulation(ctx.handle, _p(kps1_un), _p(desc1), len(kps1_un), _p(skip1), _p(ur1),
+                                                      _p(g1[0]), _p(g1[1]), _p(g1[2]), len(g1[0]), _p(kps2_un), _p(desc2),
+                                                      len(kps2_un), _p(skip2), _p(ur2), _p(g2[0]), _p(g2[1]), _p(g2[2]),
+                                                      len(g2[0]), _p(F), float(ex), float(ey), _p(sf), _p(s2), len(sf),
+                                                      1 if only_stereo else 0, 1 if check_ori else 0, _p(m12), C.byref(nm)),
+          ctx.handle, "orbhip_search_for_triangulation")
+    return nm.value, m12[:len(kps1_un)].copy()
