@@ -214,6 +214,29 @@ def run_single_frame_latency(W, H, nfeat):
     return dt * 1e3, t
 
 
+def run_host_batch(W, H, nfeat, B):
+    """orbhip_extract_batch: B frames through HOST pointers (H2D of the images, D2H of keypoints and descriptors)."""
+    import ctypes as C
+    from orbhip.capi import KP_DTYPE, _p
+    imgs = np.ascontiguousarray(synth.make_frames(6, W, H, 8)[np.arange(B) % 8])
+    ex = ORBextractor(nfeat, max_w=W, max_h=H, max_batch=B)
+    ptrs = (C.c_void_p * B)(*[imgs[b].ctypes.data for b in range(B)])
+    kps = np.zeros((B, ex.cap), KP_DTYPE)
+    desc = np.zeros((B, ex.cap, 32), np.uint8)
+    n = np.zeros(B, np.int32)
+
+    def call():
+        assert ex._L.orbhip_extract_batch(ex.handle, ptrs, B, W, H, W, _p(kps), _p(desc), ex.cap, _p(n)) == 0
+    call()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        call()
+    dt = (time.perf_counter() - t0) / reps
+    ex.close()
+    return B / dt, dt * 1e3, float(n.mean())
+
+
 def run_big_knn(nq, ndb):
     db = torch.randint(0, 256, (ndb, 32), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, ndb, (nq,), device="cuda")
@@ -246,6 +269,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "proj":            # profiling aid: the guided-search row only
         fps, dt, kp, ms = run_extract(640, 480, 1000, 512, 4096, "proj", seed=1)
         print("| 1b | proj | %.0f frames/s | %.1f matches per frame |" % (fps, kp))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "host":
+        fps, ms, kp = run_host_batch(640, 480, 1000, 256)
+        print("| 1d | host batch | %.0f frames/s | %.2f ms per call, %.1f kp |" % (fps, ms, kp))
         return
     if len(sys.argv) > 1 and sys.argv[1] == "init":            # profiling aid
         fps, dt, kp, ms = run_extract(640, 480, 2000, 256, 2048, "init", seed=1)
@@ -285,6 +312,8 @@ def main():
         1 / dt, dt * 1e3, 4000 * 1e6 / dt / 1e12, 32e6 / dt / 1e9, ok))
     dt, ok = run_big_knn(8, 1000000)
     print("| 5c: few-query regime | 8 queries x 1 000 000 rows | - | %.3f ms, %.1f GB/s database stream |" % (dt * 1e3, 32e6 / dt / 1e9))
+    fps, ms, kp = run_host_batch(640, 480, 1000, 256)
+    print("| 1d: batch through host pointers (incl. PCIe) | 256 frames 640x480, 1000 feat, orbhip_extract_batch from pageable host memory: H2D images, extraction, D2H keypoints + descriptors | %.0f | %.2f ms per 256-frame call, %.1f kp/frame |" % (fps, ms, kp))
     lat, t = run_single_frame_latency(640, 480, 1000)
     print("| 1: single frame (host pointers, incl. PCIe) | 640x480, 1000 feat, orbhip_extract per call | %.0f | %.3f ms per call; device stage times pyramid %.3f / keypoints %.3f / descriptors %.3f ms |" % (1e3 / lat, lat, t[0], t[1], t[2]))
 
