@@ -125,7 +125,8 @@ inline int MapPoint::PredictScale(const float &currentDist, Frame *pF)
 class KeyFrame
 {
 public:
-    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0) {}
+    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0), mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
+                 mfGridElementWidthInv(0), mfGridElementHeightInv(0), mnMinX(0), mnMinY(0), mnMaxX(0), mnMaxY(0) {}
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;   // ref: include/KeyFrame.h (const members there)
     cv::Mat mDescriptors;
     DBoW2::FeatureVector mFeatVec;
@@ -148,6 +149,16 @@ public:
     cv::Mat GetCameraCenter() { return Ow.clone(); }
     cv::Mat Tcw;                                  // 4 x 4 CV_32F (protected in the reference; the test programs fill it)
     cv::Mat Ow;                                   // 3 x 1 CV_32F
+
+    // grid twin of the frame (ref: include/KeyFrame.h:226-229, 306; the constructor copies F.mGrid, src/KeyFrame.cc:55-89)
+    // and KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:1138-1177: no level filter); body in host/ORBmatcher.cc
+    int mnGridCols, mnGridRows;
+    float mfGridElementWidthInv, mfGridElementHeightInv;
+    float mnMinX, mnMinY, mnMaxX, mnMaxY;
+    std::vector<std::vector<std::vector<size_t> > > mGrid;
+    void CopyGridFrom(const Frame &F);            // the grid part of KeyFrame::KeyFrame(Frame &F, ...)
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r) const;
+    bool IsInImage(const float &x, const float &y) const { return (x>=mnMinX && x<mnMaxX && y>=mnMinY && y<mnMaxY); }
 };
 
 }  // namespace ORB_SLAM2

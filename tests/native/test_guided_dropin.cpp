@@ -108,6 +108,25 @@ int main(int argc, char **argv)
         for (int k = 0; k < c; k++) { int e = (int)v[k]; fwrite(&e, 4, 1, out); }
     }
 
+    {
+        // KeyFrame::KeyFrame(Frame&,...) copies the grid; KeyFrame::GetFeaturesInArea (no level filter) -- used by Fuse / Sim3
+        KeyFrame kfg;
+        kfg.mvKeysUn = mCurrentFrame.mvKeysUn;
+        kfg.CopyGridFrom(mCurrentFrame);
+        int same = 1;
+        for (int i = 0; i < FRAME_GRID_COLS; i++)
+            for (int j = 0; j < FRAME_GRID_ROWS; j++) same &= (kfg.mGrid[i][j] == mCurrentFrame.mGrid[i][j]) ? 1 : 0;
+        int inimg[2] = {kfg.IsInImage(10.f, 10.f) ? 1 : 0, kfg.IsInImage(-5000.f, 10.f) ? 1 : 0};
+        fwrite(&same, 4, 1, out);
+        fwrite(inimg, 4, 2, out);
+        for (int t = 0; t < 2; t++) {
+            std::vector<size_t> v = kfg.GetFeaturesInArea(wx[t], wy[t], wr[t]);
+            int c = (int)v.size();
+            fwrite(&c, 4, 1, out);
+            for (int k = 0; k < c; k++) { int e = (int)v[k]; fwrite(&e, 4, 1, out); }
+        }
+    }
+
     // map points seen in the last frame
     const int nmp = nrec < mLastFrame.N ? nrec : mLastFrame.N;
     std::vector<MapPoint> points(nmp);

@@ -263,6 +263,12 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
         cnt = take()[0]
         assert np.array_equal(take(cnt), oracle.features_in_area(k1, (roff, ridx), gp, x, y, r, mn, mx))
 
+    # KeyFrame grid twin: copied grid, IsInImage, GetFeaturesInArea without a level filter
+    assert take()[0] == 1 and take(2).tolist() == [1, 0]
+    for (x, y, r) in [(310.5, 200.25, 45.0), (20.0, 470.0, 60.0)]:
+        cnt = take()[0]
+        assert np.array_equal(take(cnt), oracle.features_in_area(k1, (roff, ridx), gp, x, y, r, -1, -1))
+
     # --- SearchByProjection(CurrentFrame, LastFrame, th, bMono): the wrapper's projection, restated ---
     def affine(R, x, t):                                           # float(double sum + double t)
         s = np.zeros(x.shape[:-1] + (3,), np.float64)

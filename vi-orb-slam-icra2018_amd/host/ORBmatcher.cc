@@ -442,6 +442,40 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f
     return nmatches;
 }
 
+// ---- KeyFrame grid twin (ref: src/KeyFrame.cc:55-89, :1138-1177) ----
+void KeyFrame::CopyGridFrom(const Frame &F)
+{
+    mnGridCols = FRAME_GRID_COLS;
+    mnGridRows = FRAME_GRID_ROWS;
+    mfGridElementWidthInv = Frame::mfGridElementWidthInv;
+    mfGridElementHeightInv = Frame::mfGridElementHeightInv;
+    mnMinX = Frame::mnMinX; mnMinY = Frame::mnMinY; mnMaxX = Frame::mnMaxX; mnMaxY = Frame::mnMaxY;
+    mGrid.resize(mnGridCols);
+    for(int i=0; i<mnGridCols;i++)
+    {
+        mGrid[i].resize(mnGridRows);
+        for(int j=0; j<mnGridRows; j++)
+            mGrid[i][j] = F.mGrid[i][j];
+    }
+}
+
+vector<size_t> KeyFrame::GetFeaturesInArea(const float &x, const float &y, const float &r) const
+{
+    // the window query of liborbhip on mvKeysUn (the grid it builds from them is the one mGrid holds)
+    vector<size_t> vIndices;
+    const int n = (int)mvKeysUn.size();
+    if(n==0)
+        return vIndices;
+    orbhip_proj_query q = {x, y, r, 0.f, -1, -1, 0.f, ORBHIP_Q_ACTIVE};
+    vector<int32_t> idx(n);
+    int32_t off[2] = {0, 0};
+    if(orbhip_features_in_area(tls.get(), reinterpret_cast<const orbhip_keypoint *>(mvKeysUn.data()), n, mnMinX, mnMinY,
+                               mfGridElementWidthInv, mfGridElementHeightInv, &q, 1, off, idx.data(), n) != ORBHIP_OK)
+        throw std::runtime_error(std::string("KeyFrame::GetFeaturesInArea: ") + orbhip_last_error(tls.get()));
+    vIndices.assign(idx.begin(), idx.begin() + off[1]);
+    return vIndices;
+}
+
 void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3)
 {
     // ref: src/ORBmatcher.cc:1629-1670
