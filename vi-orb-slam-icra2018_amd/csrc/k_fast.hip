@@ -15,9 +15,11 @@
 //      16-bit arithmetic (v_pk_max/min/sub_u16, 2 pixels per instruction): a 9-arc always contains
 //      ring pixel 0 or 8 and ring pixel 4 or 12, so a corner needs
 //      min(max(q0,q8), max(q4,q12)) > v + t   or   max(min(q0,q8), min(q4,q12)) < v - t.
-//      Survivors (typically 10-20 %) are appended to an LDS work list;
-//   3. full score on the work list, dense lanes: arc minima with min3 trees, one polarity unless
-//      both are possible; corners (score >= minThFAST) are compacted into a corner list;
+//      (the two conditions are sign bits of wrapped 16-bit differences).  Survivors (18 % of the pixels at
+//      level 0, 60 % at level 7) are appended to an LDS work list;
+//   3. full score on the work list, dense lanes, on packed halves: the ring as 8 registers (q_k, q_k+8) and the
+//      gfx950 three-input packed minimum / maximum (fast_score_pol below), one polarity unless both are
+//      possible; corners (score >= minThFAST) are compacted into a corner list;
 //   4. non-max suppression over the corner list only; survivors get a sortable key
 //      (cell, row, column, score) in a survivor list, plus a per-cell ">= iniThFAST" flag;
 //   5. survivors that pass their cell's threshold set a bit in a per-(cell, row) bitmap; a survivor's rank
@@ -46,10 +48,6 @@ __device__ __forceinline__ const uint8_t *level_ptr(const OrbLevels &G, int l, i
     stride = G.lv[l].stride;
     return pyr + (size_t)frame * pyrFrame + G.lv[l].imgOff;
 }
-
-__device__ __forceinline__ int mad24i(int a, int b, int c) { return __mul24(a, b) + c; }   // v_mad_i32_i24
-__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
-__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
 // bytes (0,1) / (2,3) of w zero-extended into the two 16-bit halves
 __device__ __forceinline__ us2 lo2(uint32_t w)
@@ -125,7 +123,7 @@ __device__ __forceinline__ int fast_score_pol(const uint8_t *p, int pitch, int t
 {
     const uint8_t *rm3 = p - 3 * pitch - 3, *rm2 = p - 2 * pitch - 3, *rm1 = p - pitch - 3, *r0 = p - 3;
     const uint8_t *rp1 = p + pitch - 3, *rp2 = p + 2 * pitch - 3, *rp3 = p + 3 * pitch - 3;
-    // ring pixel k (OpenCV order, see fast_score_lds) paired with pixel k + 8
+    // ring pixel k (OpenCV's order: k = 0 at (0, +3), then clockwise in image coordinates) paired with pixel k + 8
     const int v0 = p[0];
     const int q0 = rp3[3], q8 = rm3[3], q4 = r0[6], q12 = r0[0];
     // polarity that can hold a 9-arc (it contains ring pixel 0 or 8 and ring pixel 4 or 12)
@@ -146,62 +144,6 @@ __device__ __forceinline__ int fast_score_pol(const uint8_t *p, int pitch, int t
     int sc = arcs_score(P, C, v0 ^ (dark ? 0xFF : 0));
     if (pb && pd) sc = max(sc, arcs_score(P, 0x40FF40FFu, v0 ^ 0xFF));   // both possible (rare): the dark one as well
     return sc >= t ? sc : 0;
-}
-
-// max over the 16 cyclic 9-arcs of the arc minimum of e[]
-__device__ __forceinline__ int max_arc_min(const int e[16])
-{
-    int m3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) m3[k] = min3i(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
-    int a = -256;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        const int x = min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-        const int y = min3i(m3[k + 1], m3[(k + 4) & 15], m3[(k + 7) & 15]);
-        a = max3i(a, x, y);
-    }
-    return a;
-}
-
-// FAST score of the pixel at p (LDS), 0 if it is not a corner at threshold t (t >= 1).
-// score = max over the 16 cyclic 9-arcs of min_{q in arc} (v - q), same for (q - v), minus 1.
-__device__ __forceinline__ int fast_score_lds(const uint8_t *p, int pitch, int t)
-{
-    const int v = p[0];
-    const int q0 = p[3 * pitch], q8 = p[-3 * pitch], q4 = p[3], q12 = p[-3];
-    // polarity that can hold a 9-arc: dark (v - q > t) / bright (q - v > t)
-    const bool pd = ((v - q0 > t) || (v - q8 > t)) && ((v - q4 > t) || (v - q12 > t));
-    const bool pb = ((q0 - v > t) || (q8 - v > t)) && ((q4 - v > t) || (q12 - v > t));
-    if (!pd && !pb) return 0;
-    const int ns = (pb && !pd) ? 1 : -1;   // e = -ns * (v - q) = ns*q - ns*v
-    const int sv = -ns * v;
-    int e[16];
-    e[0] = mad24i(ns, q0, sv);
-    e[1] = mad24i(ns, (int)p[3 * pitch + 1], sv);
-    e[2] = mad24i(ns, (int)p[2 * pitch + 2], sv);
-    e[3] = mad24i(ns, (int)p[pitch + 3], sv);
-    e[4] = mad24i(ns, q4, sv);
-    e[5] = mad24i(ns, (int)p[-pitch + 3], sv);
-    e[6] = mad24i(ns, (int)p[-2 * pitch + 2], sv);
-    e[7] = mad24i(ns, (int)p[-3 * pitch + 1], sv);
-    e[8] = mad24i(ns, q8, sv);
-    e[9] = mad24i(ns, (int)p[-3 * pitch - 1], sv);
-    e[10] = mad24i(ns, (int)p[-2 * pitch - 2], sv);
-    e[11] = mad24i(ns, (int)p[-pitch - 3], sv);
-    e[12] = mad24i(ns, q12, sv);
-    e[13] = mad24i(ns, (int)p[pitch - 3], sv);
-    e[14] = mad24i(ns, (int)p[2 * pitch - 2], sv);
-    e[15] = mad24i(ns, (int)p[3 * pitch - 1], sv);
-    int a = max_arc_min(e);
-    if (pd && pb) {   // both polarities possible (rare): evaluate the other one as well
-        int f[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) f[k] = -e[k];
-        a = max(a, max_arc_min(f));
-    }
-    const int s = a - 1;
-    return s >= t ? s : 0;
 }
 
 // inclusive wave prefix sum
@@ -411,7 +353,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     // ---- 3. full score on the work list; corners -> corner list ----
     // The lists have a fixed LDS budget.  If a tile has more compass survivors than the work list
     // holds (noise-like images), every domain pixel is scored instead (the compass test is the
-    // early-out of fast_score_lds); if it has more corners than the corner list holds, phase 4 scans
+    // early-out of fast_score_pol); if it has more corners than the corner list holds, phase 4 scans
     // the score tile.  Both fallbacks produce the same result as the list paths.
     const int nlist = s_listCount;
     if (nlist <= listCap) {
@@ -433,7 +375,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
             if (px < DH * TW) {
                 const int r = (int)(((unsigned)px * twMagic) >> 20);
                 const int c = px - r * TW;
-                s = fast_score_lds(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
+                s = fast_score_pol(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
                 if (s > 0) s_score[r * SP + c] = (uint8_t)s;
                 ent = (r << 9) | (j0 + c);
             }
