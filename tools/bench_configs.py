@@ -270,6 +270,10 @@ def main():
         fps, dt, kp, ms = run_extract(640, 480, 1000, 512, 4096, "proj", seed=1)
         print("| 1b | proj | %.0f frames/s | %.1f matches per frame |" % (fps, kp))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "single":
+        lat, t = run_single_frame_latency(640, 480, 1000)
+        print("| 1 | single frame | %.0f | %.3f ms per call; pyramid %.3f / keypoints %.3f / descriptors %.3f ms |" % (1e3 / lat, lat, t[0], t[1], t[2]))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "host":
         fps, ms, kp = run_host_batch(640, 480, 1000, 256)
         print("| 1d | host batch | %.0f frames/s | %.2f ms per call, %.1f kp |" % (fps, ms, kp))

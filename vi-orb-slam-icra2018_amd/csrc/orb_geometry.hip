@@ -153,6 +153,8 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
     G.minTh = c->minTh;
     memcpy(G.umax, c->umax, sizeof(G.umax));
     c->fastTiles.clear();
+    c->nFastTilesBatch = 0;
+    std::vector<FastTile> single;   // one cell per workgroup: the list used for a frame or two (more, shorter workgroups)
     c->blurTiles.clear();
     size_t pyrOff = 0;
     int cellBase = 0, candBase = 0, kpBase = 0;
@@ -212,6 +214,15 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
                 j += t.ncells;
                 c->fastTiles.push_back(t);
             }
+        for (int i = 0; i < L.nRows; i++)
+            for (int j = 0; j < L.nCols; j++) {
+                FastTile t;
+                t.level = (short)l;
+                t.row = (short)i;
+                t.c0 = (short)j;
+                t.ncells = 1;
+                single.push_back(t);
+            }
         for (int ty = 0; ty < (L.h + BLUR_TILE_H - 1) / BLUR_TILE_H; ty++)
             for (int tx = 0; tx < (L.w + BLUR_TILE_W - 1) / BLUR_TILE_W; tx++) {
                 BlurTile t;
@@ -222,6 +233,8 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
                 c->blurTiles.push_back(t);
             }
     }
+    c->nFastTilesBatch = (int)c->fastTiles.size();
+    c->fastTiles.insert(c->fastTiles.end(), single.begin(), single.end());   // [batch list | single-frame list]
     G.totalCells = cellBase;
     G.totalCands = candBase;
     G.totalPts = candBase;

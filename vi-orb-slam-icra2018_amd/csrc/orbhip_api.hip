@@ -280,8 +280,14 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
     // E3 FAST alone on the device (it is the kernel whose roofline is reported), then the quadtree
     // (latency-bound, a few thousand workgroups) and the blur (streaming) run CONCURRENTLY on two
     // streams: both only depend on the pyramid / the FAST output; the describe kernel joins them.
-    launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles,
-                (int)c->fastTiles.size(), c->d_cand, c->d_cellCnt, B);
+    // batches: runs of up to 5 cells per workgroup; a frame or two: one cell per workgroup (four times the workgroups,
+    // each a shorter chain -- the single-frame FAST time is one workgroup's latency)
+    if (B >= 8)
+        launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles, c->nFastTilesBatch, c->d_cand,
+                    c->d_cellCnt, B);
+    else
+        launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
+                    (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
     HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));

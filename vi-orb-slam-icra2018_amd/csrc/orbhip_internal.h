@@ -114,7 +114,8 @@ struct orbhip_ctx {
     // geometry of the image size currently configured (rebuilt when w/h change)
     int cur_w = 0, cur_h = 0;
     OrbLevels G;
-    std::vector<FastTile> fastTiles;
+    std::vector<FastTile> fastTiles;              // runs of up to 5 cells (batches), then runs of 1 cell (a frame or two)
+    int nFastTilesBatch = 0;
     std::vector<BlurTile> blurTiles;
     size_t pyrFrameBytes = 0;      // bytes of one frame's levels 1..n-1 (level 0 separate)
     size_t lvl0FrameBytes = 0;
