@@ -120,7 +120,6 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
     if ((rc = ensure(c, c->d_lvlAngle, c->cap_angle, Bm * (size_t)G.totalKps * 4))) return rc;
     if ((rc = ensure(c, c->d_lvlCandCnt, c->cap_cnt1, Bm * ORBHIP_MAX_LEVELS * 4))) return rc;
     if ((rc = ensure(c, c->d_lvlKpCnt, c->cap_cnt2, Bm * ORBHIP_MAX_LEVELS * 4))) return rc;
-    if ((rc = ensure(c, c->d_counts, c->cap_cnt3, Bm * 4))) return rc;
     if ((rc = ensure(c, c->d_lvl0, c->cap_lvl0, Bm * c->lvl0FrameBytes))) return rc;
     if ((size_t)G.outCap > c->cap_out) {
         size_t d1 = 0, d2 = 0;
@@ -128,8 +127,10 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
         if (c->d_desc) HIPCHK(c, hipFree(c->d_desc));
         c->d_kps = nullptr;
         c->d_desc = nullptr;
-        if ((rc = ensure(c, c->d_kps, d1, Bm * (size_t)G.outCap * sizeof(orbhip_keypoint)))) return rc;
-        if ((rc = ensure(c, c->d_desc, d2, Bm * (size_t)G.outCap * 32))) return rc;
+        // one block for keypoints | descriptors | counts of a call (carved per call for its B, orbhip_extract_batch):
+        // the results of the host-pointer API come back in ONE device-to-host copy
+        if ((rc = ensure(c, c->d_kps, d1, Bm * (size_t)G.outCap * (sizeof(orbhip_keypoint) + 32) + Bm * 4 + 1024))) return rc;
+        (void)d2;
         c->cap_out = (size_t)G.outCap;
     }
     return ORBHIP_OK;
@@ -289,15 +290,26 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
-    HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
-    launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
-    HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
-    launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
-                    c->d_lvlKpCnt, B);
-    HIPCHK(c, hipEventRecord(c->ev[3], s));
-    HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
+    if (B >= 8) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
+        HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+        launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
+        HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
+        launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
+                        c->d_lvlKpCnt, B);
+        HIPCHK(c, hipEventRecord(c->ev[3], s));
+        HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
+    } else {
+        // a frame or two: the blur takes a few microseconds, a cross-stream hand-over costs more than it hides
+        launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
+                        c->d_lvlKpCnt, B);
+        HIPCHK(c, hipEventRecord(c->ev[3], s));
+        HIPCHK(c, hipEventRecord(c->evx[1], s));
+        launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
+        HIPCHK(c, hipEventRecord(c->evx[2], s));
+    }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     // E5+E7+E8 describe
     launch_describe(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
@@ -384,17 +396,17 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
                                    hipMemcpyHostToDevice, c->stream));
     }
     const int dcap = (int)c->cap_out;
-    if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, c->d_kps, c->d_desc, c->d_counts, dcap)))
-        return rc;
-    // results: counts, keypoints and descriptors go to pinned staging in three asynchronous copies behind the
-    // kernels and ONE synchronisation (waiting for the counts first would cost a second device round trip per
-    // call -- most of a single frame's overhead); the n[b] valid entries are then copied out on the host
+    // results: keypoints | descriptors | counts of the B frames are one device block that goes to pinned staging in ONE
+    // asynchronous copy behind the kernels and ONE synchronisation (every extra copy or wait is a device round trip --
+    // most of a single frame's overhead); the n[b] valid entries are then copied out on the host
     const size_t kbytes = (size_t)B * dcap * sizeof(orbhip_keypoint), dbytes = (size_t)B * dcap * 32, cbytes = (size_t)B * 4;
     const size_t koff = 0, doff = align_up(kbytes, 256), coff = doff + align_up(dbytes, 256);
+    uint8_t *blk = reinterpret_cast<uint8_t *>(c->d_kps);
+    if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
+                           (int32_t *)(blk + coff), dcap)))
+        return rc;
     if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_stage + coff, c->d_counts, cbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_stage + koff, c->d_kps, kbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_stage + doff, c->d_desc, dbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     memcpy(n_out, c->h_stage + coff, cbytes);
     for (int b = 0; b < B; b++) {
