@@ -65,6 +65,23 @@ int main(void)
         int np1 = orbo_search_by_projection(k, d, n, ur, NULL, 0.f, 0.f, invW, invH, q, d, n, 0, 0.9f, 1, 100, pm);
         int np2 = orbo_search_by_projection(k, d, n, NULL, valid, 0.f, 0.f, invW, invH, q, d, n, 1, 0.8f, 0, 100, pm);
         if (np1 <= 0 || np2 != 0) return 8;                 /* every feature occupied in the second run */
+        {
+            /* SearchForInitialization (huge and tiny windows, points outside the grid) and SearchForTriangulation */
+            float *prev = (float *)malloc(8 * (size_t)n);
+            for (int i = 0; i < n; i++) { prev[2 * i] = k[i].x + 2.f; prev[2 * i + 1] = k[i].y - 1.f; }
+            prev[0] = -1e6f; prev[3] = 1e6f;
+            int ni1 = orbo_search_for_initialization(k, d, n, k, d, n, 0.f, 0.f, invW, invH, prev, 100, 0.9f, 1, 50, pm);
+            int ni2 = orbo_search_for_initialization(k, d, n, k, d, n, 0.f, 0.f, invW, invH, prev, 0, 0.9f, 0, 50, pm);
+            if (ni1 <= 0 || ni2 != 0) return 9;
+            const float F12[9] = {0.f, 0.f, 0.f, 0.f, 0.f, -1.f, 0.f, 1.f, 0.f};
+            uint8_t *skip = (uint8_t *)calloc((size_t)n, 1);
+            for (int i = 0; i < n; i += 5) skip[i] = 1;
+            int nt = orbo_search_for_triangulation(k, d, n, skip, NULL, node, off, idx, 2, k, d, n, skip, ur, node, off, idx, 2, F12,
+                                                   -50.f, 40.f, P->mvScaleFactor, P->mvLevelSigma2, 0, 1, 50, pm);
+            if (nt <= 0) return 10;
+            free(skip);
+            free(prev);
+        }
         double K[9] = {300, 0, 200, 0, 300, 150, 0, 0, 1}, Dd[5] = {-0.2, 0.05, 1e-4, -1e-4, 0.0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Pm[9] = {280, 0, 205, 0, 280, 148, 0, 0, 1};
         float *mx = (float *)malloc(4 * (size_t)W * H), *my = (float *)malloc(4 * (size_t)W * H);
