@@ -244,6 +244,73 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
                 have = lane < 16;
                 break;
             }
+            if (e2 - s2 <= 128) {
+                // At most two candidates per lane: their indices, descriptors and "still free" flags stay in registers
+                // for the whole node (a side-2 feature belongs to one node, so only this wave ever claims it), and the
+                // next side-1 descriptor is fetched while the current one is reduced.  The serial step is then distances
+                // + two wave minima with no memory round trip in it -- the largest node's chain is the critical path of
+                // the workgroup.
+                int pc[2], i2c[2];
+                bool avail[2];
+                uint4 r0[2], r1[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    pc[c] = s2 + lane + 64 * c;
+                    const bool hasC = pc[c] < e2;
+                    i2c[c] = hasC ? (int)(unsigned)key2[pc[c]] : 0;
+                    avail[c] = hasC && !((claim[i2c[c] >> 5] >> (i2c[c] & 31)) & 1u) &&
+                               !(th_mode && !((vbit2[i2c[c] >> 5] >> (i2c[c] & 31)) & 1u));   // :209-210, :572-578
+                    r0[c] = LDSD ? ls2[2 * i2c[c]] : reinterpret_cast<const uint4 *>(d2)[2 * i2c[c]];
+                    r1[c] = LDSD ? ls2[2 * i2c[c] + 1] : reinterpret_cast<const uint4 *>(d2)[2 * i2c[c] + 1];
+                }
+                int ni1 = a < e1 ? __builtin_amdgcn_readfirstlane((int)(unsigned)key1[a]) : 0;
+                uint4 nq0 = LDSD ? ls1[2 * ni1] : reinterpret_cast<const uint4 *>(d1)[2 * ni1];
+                uint4 nq1 = LDSD ? ls1[2 * ni1 + 1] : reinterpret_cast<const uint4 *>(d1)[2 * ni1 + 1];
+                bool nvalid = a < e1 && ((vbit1[ni1 >> 5] >> (ni1 & 31)) & 1u);
+                for (; a < e1; a++) {
+                    const int i1 = ni1;
+                    const uint4 q0 = nq0, q1 = nq1;
+                    const bool valid1 = nvalid;
+                    if (a + 1 < e1) {
+                        ni1 = __builtin_amdgcn_readfirstlane((int)(unsigned)key1[a + 1]);
+                        nq0 = LDSD ? ls1[2 * ni1] : reinterpret_cast<const uint4 *>(d1)[2 * ni1];
+                        nq1 = LDSD ? ls1[2 * ni1 + 1] : reinterpret_cast<const uint4 *>(d1)[2 * ni1 + 1];
+                        nvalid = (vbit1[ni1 >> 5] >> (ni1 & 31)) & 1u;
+                    }
+                    if (!valid1) continue;   // no (good) MapPoint: :193-199
+                    BsBest B = {256, 0x7FFFFFFF, 256};
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const int d = __popc(q0.x ^ r0[c].x) + __popc(q0.y ^ r0[c].y) + __popc(q0.z ^ r0[c].z) + __popc(q0.w ^ r0[c].w) +
+                                      __popc(q1.x ^ r1[c].x) + __popc(q1.y ^ r1[c].y) + __popc(q1.z ^ r1[c].z) + __popc(q1.w ^ r1[c].w);
+                        if (avail[c]) {
+                            if (d < B.b1) {
+                                B.b2 = B.b1;
+                                B.b1 = d;
+                                B.pos = pc[c];
+                            } else if (d < B.b2) {
+                                B.b2 = d;
+                            }
+                        }
+                    }
+                    const int key = B.b1 < 256 ? ((B.b1 << 16) | B.pos) : 0x7FFFFFFF;
+                    const int k1 = bs_wave_min(key);
+                    const int k2 = bs_wave_min(key == k1 ? B.b2 : B.b1);
+                    const int b1 = k1 == 0x7FFFFFFF ? 256 : (k1 >> 16), b2 = k2;
+                    const bool pass = th_mode ? (b1 < th) : (b1 <= th);
+                    if (pass && (float)b1 < nnratio * (float)b2) {
+                        const int pw = k1 & 0xFFFF;                          // winning position
+                        const int i2 = (int)(unsigned)key2[pw];
+                        if (lane == 0) {
+                            m12[i1] = i2;
+                            atomicOr(&claim[i2 >> 5], 1u << (i2 & 31));
+                        }
+                        if (pc[0] == pw) avail[0] = false;
+                        if (pc[1] == pw) avail[1] = false;
+                    }
+                }
+                continue;
+            }
             for (; a < e1; a++) {
                 const int i1 = __builtin_amdgcn_readfirstlane((int)(unsigned)key1[a]);
                 if (!((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;   // no (good) MapPoint: :193-199
