@@ -68,27 +68,40 @@ __device__ __forceinline__ int bs_bound(const unsigned long long *keys, int n, u
     return lo;
 }
 
-// bitonic sort of both key arrays at once: one barrier per (k, j) phase for the two sides
+// bitonic sort of both key arrays at once.  A compare-exchange phase with distance j <= 32 stays inside aligned
+// blocks of 64 keys, and the 32 pairs of such a block belong to 32 consecutive threads of ONE wave: those phases
+// (45 of the 55 for 1024 keys) only need the wave to agree, not the workgroup.
 __device__ void bs_sort2(unsigned long long *keysA, unsigned long long *keysB, int NP, int tid)
 {
+    auto exchange = [&](int t, int k, int j) {
+        unsigned long long *keys = t < NP / 2 ? keysA : keysB;
+        const int u = t < NP / 2 ? t : t - NP / 2;
+        // u-th compare-exchange pair of this (k, j) phase; j is a power of two
+        const int i = ((u & ~(j - 1)) << 1) | (u & (j - 1));
+        const int p = i + j;
+        const bool up = ((i & k) == 0);
+        const unsigned long long a = keys[i], b = keys[p];
+        if ((a > b) == up) {
+            keys[i] = b;
+            keys[p] = a;
+        }
+    };
     for (int k = 2; k <= NP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < NP; t += blockDim.x) {
-                unsigned long long *keys = t < NP / 2 ? keysA : keysB;
-                const int u = t < NP / 2 ? t : t - NP / 2;
-                // u-th compare-exchange pair of this (k, j) phase; j is a power of two
-                const int i = ((u & ~(j - 1)) << 1) | (u & (j - 1));
-                const int p = i + j;
-                const bool up = ((i & k) == 0);
-                const unsigned long long a = keys[i], b = keys[p];
-                if ((a > b) == up) {
-                    keys[i] = b;
-                    keys[p] = a;
-                }
-            }
+        int j = k >> 1;
+        for (; j >= 64; j >>= 1) {
+            for (int t = tid; t < NP; t += blockDim.x) exchange(t, k, j);
             __syncthreads();
         }
+        for (int t = tid; t < NP; t += blockDim.x)
+            for (int jj = j; jj > 0; jj >>= 1) {
+                exchange(t, k, jj);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        if (k >= 64) __syncthreads();   // the next phase (distance k >= 64) crosses waves
     }
+    __syncthreads();
 }
 
 // LDSD: both descriptor sets are staged in LDS (fits for cap up to ~1500 keypoints per frame); otherwise they
