@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbLevels G, const uint3
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_wtot[4];
-    const int l = blockIdx.x, frame = blockIdx.y;
+    // level = blockIdx.y: workgroups are dispatched x-fastest, so every frame's level 0 (the longest chain) starts first
+    // and the short upper levels fill the tail
+    const int l = blockIdx.y, frame = blockIdx.x;
     const OrbLevel &L = G.lv[l];
     const int tid = threadIdx.x;
     QtBlock x;
@@ -120,7 +122,7 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     // the switch accepts 64..256 (the kernel's launch bound)
     static const int forced = getenv("ORBHIP_QT_THREADS") ? atoi(getenv("ORBHIP_QT_THREADS")) : 256;
     const int nthreads = forced >= 64 && forced <= 256 && forced % 64 == 0 ? forced : 256;
-    dim3 grid(G.nlevels, B, 1), block(nthreads, 1, 1);
+    dim3 grid(B, G.nlevels, 1), block(nthreads, 1, 1);
     hipLaunchKernelGGL(k_quadtree, grid, block, quadtree_lds_bytes(G), s, G, cand, cellCnt, pts, pnode,
                        lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes);
 }
