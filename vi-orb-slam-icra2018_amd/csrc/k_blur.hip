@@ -172,10 +172,12 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
         // scalar tail: round half up = (s + 0x8000) >> 16
         uint32_t packedA = 0, packedB = 0;
         if (xb + 3 < wvec) {   // every pixel of the group is in the body (all but the last group of a row)
+            // exactly what the SSE2 body does: the sum as a float (exact below 2^24) times 2^-16, converted with round
+            // half to even and packed with unsigned saturation -- v_cvt_pk_u8_f32 does the last two in one instruction
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                packedA |= min((sa[k] + 0x7FFFu + ((sa[k] >> 16) & 1u)) >> 16, 255u) << (8 * k);
-                packedB |= min((sb[k] + 0x7FFFu + ((sb[k] >> 16) & 1u)) >> 16, 255u) << (8 * k);
+                packedA = __builtin_amdgcn_cvt_pk_u8_f32((float)sa[k] * (1.0f / 65536.0f), k, packedA);
+                packedB = __builtin_amdgcn_cvt_pk_u8_f32((float)sb[k] * (1.0f / 65536.0f), k, packedB);
             }
         } else {
 #pragma unroll
