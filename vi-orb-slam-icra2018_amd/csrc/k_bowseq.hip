@@ -19,6 +19,8 @@
 // Integer/bitwise path (XOR + popcount); no MFMA.
 #include "orbhip_internal.h"
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #define BS_HISTO 30
@@ -258,16 +260,18 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
                 break;
             }
             if (e2 - s2 <= 128) {
+                auto chain = [&](auto ncTag) {
+                constexpr int NC = decltype(ncTag)::value;   // candidates per lane: 1 for nodes up to 64 side-2 features
                 // At most two candidates per lane: their indices, descriptors and "still free" flags stay in registers
                 // for the whole node (a side-2 feature belongs to one node, so only this wave ever claims it), and the
                 // next side-1 descriptor is fetched while the current one is reduced.  The serial step is then distances
                 // + two wave minima with no memory round trip in it -- the largest node's chain is the critical path of
                 // the workgroup.
-                int pc[2], i2c[2];
-                bool avail[2];
-                uint4 r0[2], r1[2];
+                int pc[NC], i2c[NC];
+                bool avail[NC];
+                uint4 r0[NC], r1[NC];
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
+                for (int c = 0; c < NC; c++) {
                     pc[c] = s2 + lane + 64 * c;
                     const bool hasC = pc[c] < e2;
                     i2c[c] = hasC ? (int)(unsigned)key2[pc[c]] : 0;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
                     if (!valid1) continue;   // no (good) MapPoint: :193-199
                     BsBest B = {256, 0x7FFFFFFF, 256};
 #pragma unroll
-                    for (int c = 0; c < 2; c++) {
+                    for (int c = 0; c < NC; c++) {
                         const int d = __popc(q0.x ^ r0[c].x) + __popc(q0.y ^ r0[c].y) + __popc(q0.z ^ r0[c].z) + __popc(q0.w ^ r0[c].w) +
                                       __popc(q1.x ^ r1[c].x) + __popc(q1.y ^ r1[c].y) + __popc(q1.z ^ r1[c].z) + __popc(q1.w ^ r1[c].w);
                         if (avail[c]) {
@@ -318,10 +322,16 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
                             m12[i1] = i2;
                             atomicOr(&claim[i2 >> 5], 1u << (i2 & 31));
                         }
-                        if (pc[0] == pw) avail[0] = false;
-                        if (pc[1] == pw) avail[1] = false;
+#pragma unroll
+                        for (int c = 0; c < NC; c++)
+                            if (pc[c] == pw) avail[c] = false;
                     }
                 }
+                };
+                if (e2 - s2 <= 64)
+                    chain(std::integral_constant<int, 1>{});
+                else
+                    chain(std::integral_constant<int, 2>{});
                 continue;
             }
             for (; a < e1; a++) {
