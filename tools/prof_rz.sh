@@ -1,5 +1,4 @@
 cd /tmp && export TMPDIR=/tmp
-export ORBHIP_RESIZE_FUSE=0
 rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/rz -o rz -- python3 /root/repo/bench.py --steps 3 --warmup 1 --cpu-frames 0 --pipelined 0 > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob
