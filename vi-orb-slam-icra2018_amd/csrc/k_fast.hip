@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     uint32_t *s_surv = reinterpret_cast<uint32_t *>(smem + pixBytes + scoreBytes);
     const int SP = (TW + 3) & ~3;
     uint16_t *s_ent = reinterpret_cast<uint16_t *>(s_score);   // phase 2 only: u16 per item (2 * items <= DH * SP)
+    const float invNchunk = 1.0f / (float)nchunk;   // i / nchunk = floor((i + 0.5) * invNchunk), exact for i < 2^16
     for (int i = tid; i < RH * nchunk; i += 256) {
-        const int r = i / nchunk, c = i - r * nchunk;
+        const int r = (int)(((float)i + 0.5f) * invNchunk), c = i - r * nchunk;
         const uint4 v = *reinterpret_cast<const uint4 *>(img + (size_t)(iniY + r) * stride + XA + (c << 4));
         *reinterpret_cast<uint4 *>(s_pix + r * pitch + (c << 4)) = v;
     }

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
         // at most RZ_MAXROWS * RZ_MAXCH = 384 chunks: two unconditional loads per thread, issued together
         const int n = nrows * nch;
         const int i0 = min(tid, n - 1), i1 = min(tid + 256, n - 1);
-        const int r0 = i0 / nch, c0 = i0 - r0 * nch, r1 = i1 / nch, c1 = i1 - r1 * nch;
+        const float invNch = 1.0f / (float)nch;   // i / nch = floor((i + 0.5) * invNch), exact for i < 2^16
+        const int r0 = (int)(((float)i0 + 0.5f) * invNch), c0 = i0 - r0 * nch;
+        const int r1 = (int)(((float)i1 + 0.5f) * invNch), c1 = i1 - r1 * nch;
         const uint4 v0 = *reinterpret_cast<const uint4 *>(S + (size_t)(symin + r0) * sstride + XA + (c0 << 4));
         const uint4 v1 = *reinterpret_cast<const uint4 *>(S + (size_t)(symin + r1) * sstride + XA + (c1 << 4));
         if (tid < n) *reinterpret_cast<uint4 *>(&s_src[r0][c0 << 4]) = v0;
