@@ -157,3 +157,33 @@ def test_hip_search_for_triangulation_matches_oracle(oracle, mono, only_stereo, 
     n, m = guided.SearchForTriangulation(ex, k1[:0], d1[:0], skip1[:0], e, k2, d2, skip2, g2, F_ROWS, 0, 0, sf, s2)
     assert n == 0 and len(m) == 0
     ex.close()
+
+
+@pytest.mark.gpu
+def test_hip_matcher_entry_points_reject_bad_arguments(oracle):
+    """Negative C return codes surface as OrbHipError (never a crash, never a silent wrong answer)."""
+    from orbhip import guided
+    from orbhip.capi import KP_DTYPE, OrbHipError
+    from orbhip.extractor import ORBextractor
+    ex = ORBextractor(500, max_w=320, max_h=240)
+    k = np.zeros(4, KP_DTYPE)
+    k["x"], k["y"] = [10, 20, 30, 40], [10, 20, 30, 40]
+    d = np.zeros((4, 32), np.uint8)
+    z = np.zeros(4, np.uint8)
+    sf, s2 = np.ones(8, np.float32), np.ones(8, np.float32)
+    g_ok = (np.array([1], np.int32), np.array([0, 4], np.int32), np.arange(4, dtype=np.int32))
+    g_bad = (np.array([1], np.int32), np.array([0, 4], np.int32), np.array([0, 1, 2, 9], np.int32))   # index 9 of 4
+    with pytest.raises(OrbHipError):
+        guided.SearchForTriangulation(ex, k, d, z, g_bad, k, d, z, g_ok, F_ROWS, 0, 0, sf, s2)
+    kb = k.copy()
+    kb["octave"][2] = 11                                                                                # no such level
+    with pytest.raises(OrbHipError):
+        guided.SearchForTriangulation(ex, k, d, z, g_ok, kb, d, z, g_ok, F_ROWS, 0, 0, sf, s2)
+    with pytest.raises(OrbHipError):                                                                    # degenerate grid
+        guided.SearchForInitialization(ex, k, d, k, d, (np.float32(0), np.float32(0), np.float32(0), np.float32(0.1)),
+                                       np.zeros((4, 2), np.float32), 10)
+    with pytest.raises(ValueError):                                                                     # vbPrevMatched too short
+        guided.SearchForInitialization(ex, k, d, k, d, guided.grid_params(0, 640, 0, 480), np.zeros((3, 2), np.float32), 10)
+    n, m = guided.SearchForTriangulation(ex, k, d, z, g_ok, k, d, z, g_ok, F_ROWS, 500, 500, sf, s2, check_ori=False)
+    assert n == 4 and m.tolist() == [0, 1, 2, 3]          # the valid call still works on the same context (each feature finds itself)
+    ex.close()
