@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU box: HIP path vs the CPU oracle over many random geometries / parameters / seeds.
+Not part of the test suite (minutes); run with `gpurun -- python tools/soak_parity.py [seconds]`.  Prints a summary, exits
+non-zero on the first mismatch."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vi-orb-slam-icra2018_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+
+import orb_oracle_py as oracle  # noqa: E402
+from orbhip import distributed as D, guided, synth  # noqa: E402
+from orbhip.extractor import ORBextractor  # noqa: E402
+from orbhip.vocabulary import ORBVocabulary  # noqa: E402
+
+
+def soak_bow_seq(budget, rng):
+    """Random vocabulary shapes / feature counts / thresholds for the batched SearchByBoW kernel (k_bow_seq)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hiprt
+    from orbhip.capi import check
+    t0 = time.time()
+    n = 0
+    nmatch = 0
+    while time.time() - t0 < budget:
+        k, Lv = int(rng.integers(2, 11)), int(rng.integers(2, 5))
+        levelsup = int(rng.integers(0, Lv + 1))
+        NF = int(rng.choice([200, 600, 1000, 1500, 2500]))
+        W, H = int(rng.integers(300, 900)), int(rng.integers(240, 600))
+        th_mode = int(rng.integers(0, 2))
+        ratio = float(rng.choice([0.6, 0.7, 0.75, 0.9]))
+        seed = int(rng.integers(0, 1 << 30))
+        B = 3
+        frames = synth.make_frames(seed, W, H, B)
+        blob = D.make_synthetic_vocabulary(seed % 1000, k=k, L=Lv)
+        try:
+            refx = oracle.Extractor(NF)
+            feats_k = [refx(f) for f in frames]
+        except Exception:
+            continue
+        ex = ORBextractor(NF, max_w=W, max_h=H, max_batch=B)
+        ORBVocabulary(ex).loadFromBinaryBlob(blob)
+        cap = ex.cap
+        L = ex._L
+        d_img = hiprt.DevBuf.from_numpy(frames)
+        bufs = [hiprt.DevBuf(B * cap * 28), hiprt.DevBuf(B * cap * 32), hiprt.DevBuf(B * 4)] + [hiprt.DevBuf(B * cap * 4) for _ in range(5)] + \
+            [hiprt.DevBuf(B * 4)]
+        d_kps, d_desc, d_cnt, d_word, d_wt, d_node, d_m12, d_m21, d_nm = bufs
+        valid = (rng.random((B, cap)) < 0.85).astype(np.uint8)
+        d_valid = hiprt.DevBuf.from_numpy(valid)
+        ex.extract_batch_device(d_img.ptr, B, W, H, W, H * W, d_kps.ptr, d_desc.ptr, cap, d_cnt.ptr)
+        check(L.orbhip_vocab_transform_device(ex.handle, d_desc.ptr, B * cap, levelsup, d_word.ptr, d_wt.ptr, d_node.ptr), ex.handle)
+        check_ori = int(rng.integers(0, 2))
+        check(L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.ptr, d_kps.ptr, d_cnt.ptr, d_node.ptr, d_wt.ptr, d_valid.ptr, cap, B,
+                                                1, th_mode, C.c_float(ratio), check_ori, d_m12.ptr, d_m21.ptr, d_nm.ptr), ex.handle)
+        ex.sync()
+        m12 = d_m12.to_numpy(np.int32, (B, cap))
+        m21 = d_m21.to_numpy(np.int32, (B, cap))
+        nm = d_nm.to_numpy(np.int32, (B,))
+        refv = oracle.Vocabulary(blob)
+        fv = []
+        for b in range(B):
+            _, wt, nid = refv.transform(feats_k[b][1], levelsup)
+            fv.append(oracle.feature_vector(nid, wt))
+        for b in range(1, B):
+            (k1, d1), (k2, d2) = feats_k[b - 1], feats_k[b]
+            n1, n2 = len(k1), len(k2)
+            wn, w12, w21 = oracle.search_by_bow(d1, valid[b - 1, :n1], k1["angle"], fv[b - 1], d2, valid[b, :n2] if th_mode else None,
+                                                k2["angle"], fv[b], th=50, th_mode=th_mode, nnratio=ratio, check_ori=bool(check_ori))
+            if nm[b] != wn or not np.array_equal(m12[b, :n1], w12) or not np.array_equal(m21[b, :n2], w21):
+                print("MISMATCH bow_seq", k, Lv, levelsup, NF, W, H, th_mode, ratio, seed, b)
+                sys.exit(1)
+            nmatch += wn
+        ex.close()
+        for x in [d_img, d_valid] + bufs:
+            x.free()
+        n += 1
+    print("soak bow_seq ok: %d random configurations in %.0f s, %d matches" % (n, time.time() - t0, nmatch))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    if len(sys.argv) > 3 and sys.argv[3] == "bow":
+        soak_bow_seq(budget, np.random.default_rng(int(sys.argv[2])))
+        return
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    t0 = time.time()
+    blob = D.make_synthetic_vocabulary(99, k=6, L=4)
+    V = oracle.Vocabulary(blob)
+    n = 0
+    stats = {"frames": 0, "kps": 0, "bow": 0, "proj": 0, "init": 0, "tri": 0}
+    while time.time() - t0 < budget:
+        w = int(rng.integers(200, 900))
+        h = int(rng.integers(160, 700))
+        nf = int(rng.choice([150, 400, 1000, 2000, 3500]))
+        nlev = int(rng.integers(2, 9))
+        scale = float(rng.choice([1.2, 1.15, 1.3, 1.5]))
+        ini, mn = (20, 7) if rng.random() < 0.7 else (int(rng.integers(12, 40)), int(rng.integers(3, 12)))
+        seed = int(rng.integers(0, 1 << 30))
+        try:
+            ref = oracle.Extractor(nf, scale, nlev, ini, mn)
+            frames = synth.make_frames(seed, w, h, 2)
+            r = [ref(f) for f in frames]
+        except Exception:
+            continue                                  # geometry the reference cannot handle (too small for some level)
+        ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=2)
+        try:
+            ks, ds = ex.extract_batch(frames)
+        except Exception as e:
+            if "too small" in str(e):
+                ex.close()
+                continue
+            raise
+        for b in range(2):
+            if ks[b].tobytes() != r[b][0].tobytes() or not np.array_equal(ds[b], r[b][1]):
+                print("MISMATCH extract", w, h, nf, nlev, scale, ini, mn, seed, b)
+                sys.exit(1)
+        (k0, d0), (k1, d1) = r
+        stats["frames"] += 2
+        stats["kps"] += len(k0) + len(k1)
+        if len(k0) > 20 and len(k1) > 20:
+            # vocabulary + SearchByBoW (host API)
+            voc = ORBVocabulary(ex)
+            voc.loadFromBinaryBlob(blob)
+            g = []
+            for d in (d0, d1):
+                wd, wt, nid = V.transform(d, 2)
+                g.append(oracle.feature_vector(nid, wt))
+                hw, hwt, hnid = voc.transform_raw(d, 2)
+                if not (np.array_equal(hw, wd) and np.array_equal(hwt, wt) and np.array_equal(hnid, nid)):
+                    print("MISMATCH vocab", seed)
+                    sys.exit(1)
+            # guided search / initialisation / triangulation
+            gp = guided.grid_params(0, w, 0, h)
+            sf = np.array(list(ref.params.mvScaleFactor)[:nlev], np.float32)
+            s2 = np.array(list(ref.params.mvLevelSigma2)[:nlev], np.float32)
+            q = guided.queries_for_last_frame(k0["x"] + np.float32(rng.normal(0, 2)), k0["y"] + np.float32(rng.normal(0, 2)), k0["x"],
+                                              k0["octave"], k0["angle"], rng.random(len(k0)) < 0.9, rng.random(len(k0)) < 0.7,
+                                              float(rng.choice([7, 15, 30])), sf)
+            a = guided.SearchByProjection(ex, k1, d1, gp, q, d0, use_ratio=False, nnratio=0.9, check_ori=True)
+            b_ = oracle.search_by_projection(k1, d1, gp, q, d0, use_ratio=False, nnratio=0.9, check_ori=True)
+            if a[0] != b_[0] or not np.array_equal(a[1], b_[1]):
+                print("MISMATCH proj", w, h, nf, seed)
+                sys.exit(1)
+            stats["proj"] += a[0]
+            prev = np.stack([k0["x"], k0["y"]], 1).astype(np.float32)
+            win = int(rng.choice([10, 40, 100]))
+            a = guided.SearchForInitialization(ex, k0, d0, k1, d1, gp, prev, win, 0.9, True)
+            b_ = oracle.search_for_initialization(k0, d0, k1, d1, gp, prev, win, 0.9, True)
+            if a[0] != b_[0] or not np.array_equal(a[1], b_[1]) or not np.array_equal(a[2], b_[2]):
+                print("MISMATCH init", w, h, nf, seed, win)
+                sys.exit(1)
+            stats["init"] += a[0]
+            F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-5, (3, 3)).astype(np.float32)
+            sk0, sk1 = (rng.random(len(k0)) < 0.3).astype(np.uint8), (rng.random(len(k1)) < 0.3).astype(np.uint8)
+            a = guided.SearchForTriangulation(ex, k0, d0, sk0, g[0], k1, d1, sk1, g[1], F, w / 2, h / 2, sf, s2)
+            b_ = oracle.search_for_triangulation(k0, d0, sk0, g[0], k1, d1, sk1, g[1], F, w / 2, h / 2, sf, s2)
+            if a[0] != b_[0] or not np.array_equal(a[1], b_[1]):
+                print("MISMATCH tri", w, h, nf, seed)
+                sys.exit(1)
+            stats["tri"] += a[0]
+        ex.close()
+        n += 1
+    print("soak ok: %d random configurations in %.0f s, %s" % (n, time.time() - t0, stats))
+
+
+if __name__ == "__main__":
+    main()
