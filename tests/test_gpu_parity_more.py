@@ -77,3 +77,22 @@ def test_frames_without_corners_and_mixed_batch(oracle):
         rk, rd = ref(img)
         assert _same(ks[b], rk) and np.array_equal(ds[b].reshape(-1, 32), rd.reshape(-1, 32)), "frame %d" % b
     exb.close()
+
+
+@pytest.mark.gpu
+def test_tall_cells_with_dense_corners_in_a_batch(oracle):
+    """Found by tools/soak_parity.py: 880 x 345 at scale 1.3 has a level with two cell-rows of 45 pixels; with 5-cell FAST runs a
+    workgroup then scores 45 x 155 = 6975 pixels, and when the corners are dense enough for the score-every-pixel fallback the
+    row / column split of a flat pixel index must still be exact at the end of that range (a 20-bit integer reciprocal was not:
+    a corner landed one column outside the run and its rank went out of bounds)."""
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    w, h, nf, nlev, scale, ini, mn, seed = 880, 345, 150, 7, 1.3, 38, 7, 772947031
+    frames = synth.make_frames(seed, w, h, 2)
+    ref = oracle.Extractor(nf, scale, nlev, ini, mn)
+    want = [ref(f) for f in frames]
+    ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=8)
+    ks, ds = ex.extract_batch(np.concatenate([frames] * 4))
+    for b in range(8):
+        assert _same(ks[b], want[b % 2][0]) and np.array_equal(ds[b], want[b % 2][1])
+    ex.close()

@@ -107,9 +107,19 @@ def main():
             r = [ref(f) for f in frames]
         except Exception:
             continue                                  # geometry the reference cannot handle (too small for some level)
-        ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=2)
+        # every other configuration goes through the batch kernels (B >= 8: 5-cell FAST runs, 32-row resize tiles, 64-slot
+        # describe workgroups); the others through the forms used for a frame or two
+        reps = 4 if n % 2 else 1
+        if os.environ.get("SOAK_TRACE"):
+            with open(os.environ["SOAK_TRACE"], "a") as fh:     # last line = the configuration that was running
+                fh.write("%d %d %d %d %g %d %d %d reps=%d\n" % (w, h, nf, nlev, scale, ini, mn, seed, reps))
+        ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=2 * reps)
         try:
-            ks, ds = ex.extract_batch(frames)
+            ks, ds = ex.extract_batch(np.concatenate([frames] * reps))
+            for b in range(2, 2 * reps):
+                if ks[b].tobytes() != ks[b % 2].tobytes() or not np.array_equal(ds[b], ds[b % 2]):
+                    print("MISMATCH batch copy", w, h, nf, nlev, scale, ini, mn, seed, b)
+                    sys.exit(1)
         except Exception as e:
             if "too small" in str(e):
                 ex.close()

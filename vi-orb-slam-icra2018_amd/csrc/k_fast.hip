@@ -369,12 +369,13 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
             }
         }
     } else {
-        const unsigned twMagic = (1u << 20) / (unsigned)TW + 1u;
+        const float invTW = 1.0f / (float)TW;   // px / TW = floor((px + 0.5) * invTW): exact for every px < DH * TW (a 20-bit
+                                                 // integer reciprocal is NOT: it fails from px ~ 2^20 / TW on, e.g. TW 155, DH 45)
         for (int p0 = 0; p0 < DH * TW; p0 += 256) {
             const int px = p0 + tid;
             int ent = 0, s = 0;
             if (px < DH * TW) {
-                const int r = (int)(((unsigned)px * twMagic) >> 20);
+                const int r = (int)(((float)px + 0.5f) * invTW);
                 const int c = px - r * TW;
                 s = fast_score_pol(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
                 if (s > 0) s_score[r * SP + c] = (uint8_t)s;
