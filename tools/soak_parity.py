@@ -82,8 +82,85 @@ def soak_bow_seq(budget, rng):
     print("soak bow_seq ok: %d random configurations in %.0f s, %d matches" % (n, time.time() - t0, nmatch))
 
 
+def soak_stereo(budget, rng):
+    """Random stereo rigs: ComputeStereoMatches on the resident pyramids, keypoint undistortion, rectification."""
+    from orbhip import rectify
+    from orbhip.extractor import ComputeStereoMatches
+    t0 = time.time()
+    n = 0
+    stats = {"depth_points": 0, "remapped_px": 0, "undistorted": 0}
+    while time.time() - t0 < budget:
+        W, H = int(rng.integers(300, 1300)), int(rng.integers(200, 520))
+        NF = int(rng.choice([300, 800, 1500, 2000]))
+        nlev = int(rng.integers(3, 9))
+        seed = int(rng.integers(0, 1 << 30))
+        disp = int(rng.integers(3, 60))
+        mbf = float(rng.uniform(20, 400))
+        mb = float(rng.uniform(0.05, 0.6))
+        try:
+            L_, R_ = synth.make_stereo_pair(seed, W, H, disparity=disp)
+            rL, rR = oracle.Extractor(NF, 1.2, nlev), oracle.Extractor(NF, 1.2, nlev)
+            kL, dL = rL(L_)
+            kR, dR = rR(R_)
+        except Exception:
+            continue
+        exL = ORBextractor(NF, 1.2, nlev, max_w=W, max_h=H)
+        exR = ORBextractor(NF, 1.2, nlev, max_w=W, max_h=H)
+        try:
+            gkL, gdL = exL(L_)
+            gkR, gdR = exR(R_)
+        except Exception as e:
+            exL.close()
+            exR.close()
+            if "too small" in str(e):
+                continue
+            raise
+        if gkL.tobytes() != kL.tobytes() or gkR.tobytes() != kR.tobytes():
+            print("MISMATCH extract (stereo)", W, H, NF, nlev, seed)
+            sys.exit(1)
+        u, z, nb = ComputeStereoMatches(exL, gkL, gdL, exR, gkR, gdR, mb, mbf)
+        ru, rz, rn = oracle.stereo_matches(rL, kL, dL, rR, kR, dR, mb, mbf)
+        if nb != rn or u.tobytes() != ru.tobytes() or z.tobytes() != rz.tobytes():
+            print("MISMATCH stereo", W, H, NF, nlev, seed, disp, mb, mbf)
+            sys.exit(1)
+        stats["depth_points"] += int((u >= 0).sum())
+        # undistortion of the keypoints and rectification of the left image with a random mild rig
+        fx, fy = float(rng.uniform(0.6, 1.2) * W), float(rng.uniform(0.6, 1.2) * W)
+        K = np.array([fx, 0, W / 2 + rng.uniform(-20, 20), 0, fy, H / 2 + rng.uniform(-20, 20), 0, 0, 1.0])
+        Dc = np.array([rng.uniform(-0.35, 0.1), rng.uniform(-0.1, 0.15), rng.uniform(-2e-3, 2e-3), rng.uniform(-2e-3, 2e-3), 0.0])
+        a = rng.uniform(-0.02, 0.02, 3)
+        Rm = np.array([[1, -a[2], a[1]], [a[2], 1, -a[0]], [-a[1], a[0], 1.0]])
+        Rm, _ = np.linalg.qr(Rm)
+        P = np.array([fx * 0.95, 0, K[2] + 1.5, 0, fx * 0.95, K[5] - 0.75, 0, 0, 1.0])
+        pts = np.stack([kL["x"], kL["y"]], 1).astype(np.float32)
+        nd = int(rng.choice([4, 5]))
+        gu = rectify.undistort_points(exL, pts, K.astype(np.float32), Dc[:nd].astype(np.float32), K.astype(np.float32))
+        ruu = oracle.undistort_points(pts, K.astype(np.float32), Dc[:nd].astype(np.float32), K.astype(np.float32))
+        if gu.tobytes() != ruu.tobytes():
+            print("MISMATCH undistort", W, H, seed)
+            sys.exit(1)
+        stats["undistorted"] += len(pts)
+        mx, my = rectify.initUndistortRectifyMap(K, Dc, Rm.ravel(), P, W, H)
+        omx, omy = oracle.init_undistort_rectify_map(K, Dc, Rm.ravel(), P, W, H)
+        if not (np.array_equal(mx, omx) and np.array_equal(my, omy)):
+            print("MISMATCH rectify map", W, H, seed)
+            sys.exit(1)
+        rect = rectify.Rectifier(exL, mx, my)(L_)
+        if not np.array_equal(rect, oracle.remap_linear(L_, omx, omy)):
+            print("MISMATCH remap", W, H, seed)
+            sys.exit(1)
+        stats["remapped_px"] += W * H
+        exL.close()
+        exR.close()
+        n += 1
+    print("soak stereo/rectify ok: %d random configurations in %.0f s, %s" % (n, time.time() - t0, stats))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    if len(sys.argv) > 3 and sys.argv[3] == "stereo":
+        soak_stereo(budget, np.random.default_rng(int(sys.argv[2])))
+        return
     if len(sys.argv) > 3 and sys.argv[3] == "bow":
         soak_bow_seq(budget, np.random.default_rng(int(sys.argv[2])))
         return
