@@ -63,7 +63,10 @@ int orbhip_device_count(void);
  * int iniThFAST, int minThFAST) (include/ORBextractor.h:69-70, src/ORBextractor.cc:412-472).
  * max_w/max_h bound the image size, max_batch the frames per batched call; all device
  * buffers are allocated here, none in the per-frame calls.  Returns NULL on failure
- * (orbhip_last_error(NULL) has the reason). */
+ * (orbhip_last_error(NULL) has the reason).  Limits (ORBHIP_E_SIZE): every pyramid level must hold at least one
+ * 30-pixel cell and one quadtree root (the reference divides by zero there); levels up to 4128 x 4128; a level's
+ * feature quota up to about 2000 (the quadtree tables of a level live in LDS: e.g. 4000 features over 8 levels is
+ * fine, 3500 over 2 levels is not). */
 orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFactor, int nlevels,
                           int iniThFAST, int minThFAST, int max_w, int max_h, int max_batch);
 void orbhip_destroy(orbhip_ctx *ctx);

@@ -175,12 +175,26 @@ def main():
         h = int(rng.integers(160, 700))
         nf = int(rng.choice([150, 400, 1000, 2000, 3500]))
         nlev = int(rng.integers(2, 9))
-        scale = float(rng.choice([1.2, 1.15, 1.3, 1.5]))
+        scale = float(rng.choice([1.2, 1.2, 1.15, 1.3, 1.5, 1.08, 1.75, 2.0]))
         ini, mn = (20, 7) if rng.random() < 0.7 else (int(rng.integers(12, 40)), int(rng.integers(3, 12)))
         seed = int(rng.integers(0, 1 << 30))
+        if rng.random() < 0.06:                       # now and then a large frame
+            w, h = int(rng.integers(900, 1930)), int(rng.integers(500, 1090))
+        kind = rng.choice(["scene", "scene", "scene", "noise", "blocks", "lowcontrast", "scene2x"])
         try:
             ref = oracle.Extractor(nf, scale, nlev, ini, mn)
             frames = synth.make_frames(seed, w, h, 2)
+            if kind == "noise":                       # corners everywhere: the FAST list / corner-list fallbacks
+                frames = np.random.default_rng(seed).integers(0, 256, frames.shape, dtype=np.uint8)
+            elif kind == "blocks":                    # hard edges + a little noise: ties in scores and distances
+                g = np.random.default_rng(seed)
+                s_ = int(g.integers(5, 40))
+                base = ((np.add.outer(np.arange(h) // s_, np.arange(w) // s_) % 2) * int(g.integers(20, 200)) + 20).astype(np.int32)
+                frames = np.stack([np.clip(base + g.integers(-2, 3, base.shape), 0, 255).astype(np.uint8) for _ in range(2)])
+            elif kind == "lowcontrast":               # most cells need the second threshold, many are empty
+                frames = (frames.astype(np.int32) // 8 + 100).astype(np.uint8)
+            elif kind == "scene2x":                   # saturating contrast
+                frames = np.clip((frames.astype(np.int32) - 128) * 3 + 128, 0, 255).astype(np.uint8)
             r = [ref(f) for f in frames]
         except Exception:
             continue                                  # geometry the reference cannot handle (too small for some level)
@@ -189,17 +203,19 @@ def main():
         reps = 4 if n % 2 else 1
         if os.environ.get("SOAK_TRACE"):
             with open(os.environ["SOAK_TRACE"], "a") as fh:     # last line = the configuration that was running
-                fh.write("%d %d %d %d %g %d %d %d reps=%d\n" % (w, h, nf, nlev, scale, ini, mn, seed, reps))
-        ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=2 * reps)
+                fh.write("%d %d %d %d %g %d %d %d reps=%d kind=%s\n" % (w, h, nf, nlev, scale, ini, mn, seed, reps, kind))
+        ex = None
         try:
+            ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=2 * reps)
             ks, ds = ex.extract_batch(np.concatenate([frames] * reps))
             for b in range(2, 2 * reps):
                 if ks[b].tobytes() != ks[b % 2].tobytes() or not np.array_equal(ds[b], ds[b % 2]):
                     print("MISMATCH batch copy", w, h, nf, nlev, scale, ini, mn, seed, b)
                     sys.exit(1)
         except Exception as e:
-            if "too small" in str(e):
-                ex.close()
+            if "too small" in str(e) or "too large for this number of levels" in str(e):   # documented limits
+                if ex is not None:
+                    ex.close()
                 continue
             raise
         for b in range(2):

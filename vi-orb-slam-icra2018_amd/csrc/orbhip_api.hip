@@ -76,6 +76,13 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
             return fail(c, rc, "image too small for the 30-px cell grid / quadtree roots of some level, "
                                "or larger than the supported tile bounds");
         }
+        // the quadtree keeps the node lists of a (frame, level) in LDS: a level's feature quota must fit (about 2000 features
+        // on ONE level; 4000 features over 8 levels need 868 on level 0)
+        if (quadtree_lds_bytes(c->G) > 156 * 1024) {
+            c->cur_w = c->cur_h = 0;
+            return fail(c, ORBHIP_E_SIZE, "nfeatures is too large for this number of levels: the per-level quadtree tables exceed "
+                                          "the 160 KB of LDS (at most ~2000 features on one level)");
+        }
         // resize tables
         std::vector<int32_t> all;
         for (int l = 1; l < c->nlevels; l++) {
