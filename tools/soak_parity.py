@@ -156,8 +156,90 @@ def soak_stereo(budget, rng):
     print("soak stereo/rectify ok: %d random configurations in %.0f s, %s" % (n, time.time() - t0, stats))
 
 
+def soak_match(budget, rng):
+    """Random descriptor sets for the matcher primitives: knn2 (all-pairs, incl. the few-query form and ties), knn2_lists,
+    SearchByBoW through the host API with random node groups, the grid and window queries."""
+    from orbhip.capi import KP_DTYPE
+    from orbhip.extractor import ORBmatcher
+    t0 = time.time()
+    n = 0
+    M = ORBmatcher(0.7, True)
+    ex = M._ctx
+    while time.time() - t0 < budget:
+        nq = int(rng.choice([1, 3, 17, 32, 33, 100, 700, 2000]))
+        ndb = int(rng.choice([1, 2, 50, 333, 1000, 5000, 40000]))
+        # low-entropy descriptors: many exact ties in distance, decided by the first-minimum rule
+        base = rng.integers(0, 256, (int(rng.integers(1, 40)), 32), dtype=np.uint8)
+
+        def mk(m):
+            d = base[rng.integers(0, len(base), m)].copy()
+            flips = rng.integers(0, 4, m)
+            for i in np.nonzero(flips)[0]:
+                for b in rng.integers(0, 256, flips[i]):
+                    d[i, b >> 3] ^= 1 << (b & 7)
+            return d
+        q, db = mk(nq), mk(ndb)
+        a, b_ = M.knn2(q, db), oracle.knn2(q, db)
+        if not all(np.array_equal(x, y) for x, y in zip(a, b_)):
+            print("MISMATCH knn2", nq, ndb)
+            sys.exit(1)
+        lens = rng.integers(0, min(ndb, 60) + 1, nq)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        cand = rng.integers(0, ndb, int(off[-1])).astype(np.int32)
+        a, b_ = M.knn2_lists(q, db, off, cand), oracle.knn2_lists(q, db, off, cand)
+        if not all(np.array_equal(x, y) for x, y in zip(a, b_)):
+            print("MISMATCH knn2_lists", nq, ndb)
+            sys.exit(1)
+        # SearchByBoW, host API: random node ids (sparse, large), some nodes on one side only, invalid flags
+        n1, n2 = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+        d1, d2 = mk(n1), mk(n2)
+        nn = int(rng.integers(1, 120))
+        ids = np.sort(rng.choice(1 << 20, nn, replace=False))
+        fv = []
+        for m in (n1, n2):
+            node = ids[rng.integers(0, nn, m)]
+            wt = (rng.random(m) < 0.95).astype(np.float32)           # stopped words are left out of the FeatureVector
+            fv.append(oracle.feature_vector(node, wt))
+        v1, v2 = (rng.random(n1) < 0.8).astype(np.uint8), (rng.random(n2) < 0.8).astype(np.uint8)
+        a1, a2 = rng.uniform(0, 360, n1).astype(np.float32), rng.uniform(0, 360, n2).astype(np.float32)
+        for kf in (False, True):
+            ga = M.SearchByBoW(d1, v1, a1, fv[0], d2, v2 if kf else None, a2, fv[1], kf_kf=kf)
+            gb = oracle.search_by_bow(d1, v1, a1, fv[0], d2, v2 if kf else None, a2, fv[1], th=50, th_mode=1 if kf else 0, nnratio=0.7,
+                                      check_ori=True)
+            if ga[0] != gb[0] or not np.array_equal(ga[1], gb[1]) or not np.array_equal(ga[2], gb[2]):
+                print("MISMATCH search_by_bow", n1, n2, nn, kf)
+                sys.exit(1)
+        # grid + windows on random (partly out-of-grid) points
+        m = int(rng.integers(0, 3000))
+        k = np.zeros(m, KP_DTYPE)
+        k["x"], k["y"] = rng.uniform(-50, 900, m), rng.uniform(-50, 700, m)
+        k["octave"] = rng.integers(0, 8, m)
+        gp = guided.grid_params(float(rng.uniform(-10, 30)), float(rng.uniform(600, 860)), float(rng.uniform(-10, 30)), float(rng.uniform(400, 660)))
+        if m:
+            goff, gidx = guided.AssignFeaturesToGrid(ex, k, gp)
+            roff, ridx = oracle.grid_build(k, gp)
+            if not (np.array_equal(goff, roff) and np.array_equal(gidx, ridx)):
+                print("MISMATCH grid", m)
+                sys.exit(1)
+            nw = 50
+            x, y, r = rng.uniform(-100, 1000, nw).astype(np.float32), rng.uniform(-100, 800, nw).astype(np.float32), rng.uniform(0.5, 300, nw).astype(np.float32)
+            lv = np.array([(-1, -1), (0, 3), (2, -1), (3, 4), (0, -1), (5, 5)])[rng.integers(0, 6, nw)]
+            qoff, qidx = guided.GetFeaturesInArea(ex, k, gp, x, y, r, lv[:, 0], lv[:, 1])
+            for i in range(nw):
+                ref = oracle.features_in_area(k, (roff, ridx), gp, x[i], y[i], r[i], int(lv[i, 0]), int(lv[i, 1]))
+                if not np.array_equal(qidx[qoff[i]:qoff[i + 1]], ref):
+                    print("MISMATCH area", m, i)
+                    sys.exit(1)
+        n += 1
+    M.close()
+    print("soak matcher primitives ok: %d random configurations in %.0f s" % (n, time.time() - t0))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    if len(sys.argv) > 3 and sys.argv[3] == "match":
+        soak_match(budget, np.random.default_rng(int(sys.argv[2])))
+        return
     if len(sys.argv) > 3 and sys.argv[3] == "stereo":
         soak_stereo(budget, np.random.default_rng(int(sys.argv[2])))
         return
