@@ -202,7 +202,8 @@ int orbhip_vocab_transform_device(orbhip_ctx *ctx, const void *d_desc, int n, in
  * orbhip_vocab_transform_device; d_valid [B*cap] bytes ("has a good MapPoint") or NULL = all valid.
  * For b >= lag side 1 is set b-lag (the key frame) and side 2 is set b; d_match12[b*cap + i1] = matched
  * side-2 feature or -1, d_match21[b*cap + i2] = matched side-1 feature or -1, d_nmatches[b] = the
- * reference routine's return value.  TH_LOW = 50.  One launch for all B pairs. */
+ * reference routine's return value.  TH_LOW = 50.  One launch for all B pairs.  cap <= 4096 (ORBHIP_E_SIZE beyond: the
+ * per-pair tables live in LDS). */
 int orbhip_search_by_bow_seq_device(orbhip_ctx *ctx, const void *d_desc, const void *d_kps, const void *d_counts,
                                     const void *d_node, const void *d_weight, const void *d_valid, int cap,
                                     int B, int lag, int th_mode, float nnratio, int check_ori, void *d_match12,

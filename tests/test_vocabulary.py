@@ -150,3 +150,19 @@ def test_hip_batched_search_by_bow_matches_oracle(oracle, th_mode, k, Lv, levels
     ex.close()
     for x in (d_img, d_kps, d_desc, d_cnt, d_word, d_wt, d_node, d_m12, d_m21, d_nm, d_valid):
         x.free()
+
+
+@pytest.mark.gpu
+def test_hip_batched_search_by_bow_rejects_more_than_4096_slots():
+    """The per-pair tables of k_bow_seq live in LDS: a clear error, not a failed launch."""
+    import ctypes as C
+    import hiprt
+    from orbhip.capi import OrbHipError, check
+    from orbhip.extractor import ORBextractor
+    ex = ORBextractor(500, max_w=320, max_h=240)
+    d = hiprt.DevBuf(4096)
+    with pytest.raises(OrbHipError, match="4096 feature slots"):
+        check(ex._L.orbhip_search_by_bow_seq_device(ex.handle, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, None, 5000, 2, 1, 0, C.c_float(0.7), 1,
+                                                    d.ptr, d.ptr, d.ptr), ex.handle, "search_by_bow_seq")
+    d.free()
+    ex.close()

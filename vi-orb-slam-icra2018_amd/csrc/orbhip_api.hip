@@ -908,9 +908,12 @@ extern "C" int orbhip_search_by_bow_seq_device(orbhip_ctx *c, const void *d_desc
                                                const void *d_valid, int cap, int B, int lag, int th_mode, float nnratio,
                                                int check_ori, void *d_match12, void *d_match21, void *d_nmatches)
 {
-    if (!c || !d_desc || !d_kps || !d_counts || !d_node || !d_weight || cap <= 0 || cap > 16384 || B <= 0 || lag < 0 ||
+    if (!c || !d_desc || !d_kps || !d_counts || !d_node || !d_weight || cap <= 0 || B <= 0 || lag < 0 ||
         !d_match12 || !d_match21 || !d_nmatches)
         return fail(c, ORBHIP_E_ARG, "orbhip_search_by_bow_seq_device: bad argument");
+    if (cap > 4096)   // the sorted keys, match table and work items of a frame pair live in LDS: 36 bytes per slot
+        return fail(c, ORBHIP_E_SIZE, "orbhip_search_by_bow_seq_device: more than 4096 feature slots per frame (the per-pair "
+                                      "tables exceed the 160 KB of LDS); use orbhip_search_by_bow per pair");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     launch_bow_seq(c->stream, (const uint8_t *)d_desc, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts,
