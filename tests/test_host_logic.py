@@ -125,3 +125,35 @@ def test_synth_frames_are_deterministic_and_textured():
     b = synth.make_frames(5, 320, 240, 2)
     assert np.array_equal(a, b) and a.dtype == np.uint8 and a.shape == (2, 240, 320)
     assert a.std() > 20 and not np.array_equal(a[0], a[1])
+
+
+def test_kernel_index_division_tricks_are_exact():
+    """The kernels split flat indices with floor((n + 0.5) * (1.0f / d)) (float32) or a 16-bit reciprocal; every use must be
+    exact over the whole range it can see (a 20-bit reciprocal in k_fast's fallback once was not: memory fault found by the
+    soak).  Ranges: k_fast items / dword groups per row, staging chunks, fallback pixels / run width; k_resize staging chunks;
+    k_fast cell-of-column and row-of-(cell,row) with 16-bit reciprocals; k_describe idx / 10."""
+    f32 = np.float32
+
+    def float_trick(maxd, maxn):
+        for d in range(1, maxd + 1):
+            n = np.arange(0, maxn, dtype=np.int64)
+            r = ((n.astype(np.float32) + f32(0.5)) * (f32(1.0) / f32(d))).astype(np.int32)
+            assert np.array_equal(r, n // d), d
+    float_trick(130, 70 * 130)      # item / GPR
+    float_trick(24, 72 * 24)        # i / nchunk
+    float_trick(330, 66 * 330)      # px / TW
+    float_trick(16, 1024)           # k_resize: i / nch
+    for wcell in range(20, 100):    # cellMagic: column -> cell, columns < 400
+        m = 65536 // wcell + 1
+        c = np.arange(400)
+        assert np.array_equal((c * m) >> 16, c // wcell)
+    for dh in range(1, 70):         # dhMagic: (cell, row) index -> cell, up to 8 cells
+        m = 65536 // dh + 1
+        i = np.arange(8 * dh)
+        assert np.array_equal((i * m) >> 16, i // dh)
+    for spw in range(5, 81):        # spwMagic: score words per row
+        m = (1 << 20) // spw + 1
+        i = np.arange(66 * spw)
+        assert np.array_equal((i * m) >> 20, i // spw)
+    idx = np.arange(384)
+    assert np.array_equal((idx * 6554) >> 16, idx // 10)
