@@ -284,6 +284,26 @@ int orbhip_search_by_projection_device(orbhip_ctx *ctx, const void *d_kps_un, co
                                        const void *d_qdesc, const void *d_nq, int cap_q, int use_ratio,
                                        float nnratio, int check_ori, int th_high, void *d_match, void *d_nmatches);
 
+/* Replaces the per-point inner loop of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:887-950), Fuse(KeyFrame*, cv::Mat Scw, ...) (:1044-1075) and both directions of SearchBySim3
+ * (:1190-1224, :1270-1304): for every projected point, KeyFrame::GetFeaturesInArea(u, v, radius) (src/KeyFrame.cc:1138-1177),
+ * features on levels outside [min_level, max_level] (= [predicted - 1, predicted]) skipped, the first feature of smallest
+ * Hamming distance wins.  inv_level_sigma2 != NULL (host array, nlevels <= 16 entries = KeyFrame::mvInvLevelSigma2) turns on
+ * the first Fuse's chi-square gate on the reprojection error: 7.8 over (u, v, proj_xr) when u_right[idx] >= 0, else 5.99
+ * over (u, v) (:908-934).  Points do not close features to each other here, so best_idx[q] / best_dist[q] are per query:
+ * -1 / 256 when the query is not ORBHIP_Q_ACTIVE or no feature is closer than 256; the caller applies <= TH_LOW (50) /
+ * TH_HIGH (100) and the map updates.  Only u, v, radius, proj_xr, min_level, max_level and flags of a query are read. */
+int orbhip_window_best(orbhip_ctx *ctx, const orbhip_keypoint *kps_un, const uint8_t *desc, int n, const float *u_right,
+                       const float *inv_level_sigma2, int nlevels, float min_x, float min_y, float inv_w, float inv_h,
+                       const orbhip_proj_query *queries, const uint8_t *qdesc, int nq, int32_t *best_idx,
+                       int32_t *best_dist);
+/* Batched, device-resident form (layouts as orbhip_search_by_projection_device); d_best_idx / d_best_dist [B][cap_q]. */
+int orbhip_window_best_device(orbhip_ctx *ctx, const void *d_kps_un, const void *d_desc, int cap, int B,
+                              const void *d_u_right, const float *inv_level_sigma2, int nlevels, float min_x, float min_y,
+                              float inv_w, float inv_h, const void *d_cell_off, const void *d_cell_idx,
+                              const void *d_queries, const void *d_qdesc, const void *d_nq, int cap_q, void *d_best_idx,
+                              void *d_best_dist);
+
 /* Replaces the body of ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
  * vector<int> &vnMatches12, int windowSize) (src/ORBmatcher.cc:405-520; the monocular initialiser, called at
  * src/Tracking.cc MonocularInitialization with nnratio 0.9, windowSize 100).  kps1_un / kps2_un are mvKeysUn of the two

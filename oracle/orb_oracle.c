@@ -1589,6 +1589,60 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
     return nmatches;
 }
 
+/* The per-point inner loop shared by ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:887-950:
+ * chi-square gate on the reprojection error when inv_level_sigma2 != NULL), Fuse(KeyFrame*, Scw, ...) (:1044-1075) and
+ * SearchBySim3 (:1190-1224, :1270-1304; the gate is off there): KeyFrame::GetFeaturesInArea(u, v, radius)
+ * (src/KeyFrame.cc:1138-1177), levels outside [min_level, max_level] = [predicted - 1, predicted] skipped, the first
+ * feature of smallest distance wins (strict '<').  Every query is independent of the others.
+ * best_idx[q] = -1 / best_dist[q] = 256 when the query is inactive or nothing is closer than 256 (the reference starts
+ * from 256 in Fuse and INT_MAX in SearchBySim3; both then require <= TH_LOW / TH_HIGH, so the outcome is the same). */
+void orbo_window_best(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *u_right,
+                      const float *inv_level_sigma2, float minX, float minY, float invW, float invH,
+                      const orbo_proj_query *q, const uint8_t *qdesc, int nq, int32_t *best_idx, int32_t *best_dist)
+{
+    int32_t *cell_off = (int32_t *)malloc(sizeof(int32_t) * (GRID_COLS * GRID_ROWS + 1));
+    int32_t *cell_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    orbo_grid_build(kps, n, minX, minY, invW, invH, cell_off, cell_idx);
+    for (int iq = 0; iq < nq; iq++) {
+        best_idx[iq] = -1;
+        best_dist[iq] = 256;
+        if (!(q[iq].flags & ORBO_Q_ACTIVE)) continue;
+        const float u = q[iq].u, v = q[iq].v, ur = q[iq].proj_xr;
+        /* the KeyFrame grid query has no level filter; the loop below applies it */
+        const int nc = orbo_features_in_area(kps, cell_off, cell_idx, minX, minY, invW, invH, u, v, q[iq].radius, -1, -1,
+                                             cand, n);
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            const int kpLevel = kps[idx].octave;
+            if (kpLevel < q[iq].min_level || kpLevel > q[iq].max_level) continue;
+            if (inv_level_sigma2) {
+                const float kpx = kps[idx].x, kpy = kps[idx].y;
+                const float ex = u - kpx, ey = v - kpy;
+                if (u_right && u_right[idx] >= 0) { /* :911-923 */
+                    const float er = ur - u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else { /* :925-934 */
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = orbo_descriptor_distance(qdesc + (size_t)iq * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        best_idx[iq] = bestIdx;
+        best_dist[iq] = bestDist;
+    }
+    free(cell_off);
+    free(cell_idx);
+    free(cand);
+}
+
 /* ORBmatcher::SearchForInitialization (ref: src/ORBmatcher.cc:405-520), the monocular initialiser's matcher
  * (src/Tracking.cc MonocularInitialization): level-0 features of frame 1 in index order, window search around
  * prev_matched[i1] among the level-0 features of frame 2 (:424), a feature of frame 2 already matched at a

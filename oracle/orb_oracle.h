@@ -174,6 +174,13 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
                               const orbo_proj_query *q, const uint8_t *qdesc, int nq, int use_ratio, float nnratio,
                               int check_ori, int th_high, int32_t *match);
 
+/* inner loop of ORBmatcher::Fuse (src/ORBmatcher.cc:887-950; :1044-1075) and SearchBySim3 (:1190-1224): the first
+ * feature of smallest distance in the window on levels [min_level, max_level]; inv_level_sigma2 != NULL adds Fuse's
+ * chi-square gate (7.8 with a right coordinate >= 0, else 5.99).  -1 / 256 when none. */
+void orbo_window_best(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *u_right,
+                      const float *inv_level_sigma2, float minX, float minY, float invW, float invH,
+                      const orbo_proj_query *q, const uint8_t *qdesc, int nq, int32_t *best_idx, int32_t *best_dist);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520); prev_matched n1 x 2 floats, in/out */
 int orbo_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const orbo_keypoint *kps2,
                                    const uint8_t *desc2, int n2, float minX, float minY, float invW, float invH,

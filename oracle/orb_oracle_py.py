@@ -448,6 +448,27 @@ def search_by_projection(kps, desc, gp, queries, qdesc, u_right=None, occupied=N
     return n, match[:len(kps)].copy()
 
 
+def window_best(kps, desc, gp, queries, qdesc, u_right=None, inv_level_sigma2=None):
+    """Per-query best feature in the window: the inner loop of ORBmatcher::Fuse (src/ORBmatcher.cc:887-950 with the
+    chi-square gate = inv_level_sigma2 given; :1044-1075 without) and SearchBySim3 (:1190-1224).
+    Returns (best_idx[nq], best_dist[nq])."""
+    L = lib()
+    L.orbo_window_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + \
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.orbo_window_best.restype = None
+    kps = np.ascontiguousarray(kps)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    bi = np.empty(max(len(queries), 1), np.int32)
+    bd = np.empty(max(len(queries), 1), np.int32)
+    L.orbo_window_best(_p(kps), _p(desc), len(kps), None if ur is None else _p(ur), None if sg is None else _p(sg),
+                       gp[0], gp[1], gp[2], gp[3], _p(queries), _p(qdesc), len(queries), _p(bi), _p(bd))
+    return bi[:len(queries)].copy(), bd[:len(queries)].copy()
+
+
 def search_for_initialization(kps1, desc1, kps2, desc2, gp, prev_matched, window_size=100, nnratio=0.9, check_ori=True,
                               th_low=50):
     """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520).  Returns (nmatches, matches12, prev_matched')."""

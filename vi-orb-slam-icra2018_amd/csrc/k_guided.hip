@@ -227,6 +227,68 @@ __global__ __launch_bounds__(256) void k_proj_cands(const orbhip_keypoint *__res
     tcount[(size_t)b * capQpad + iq] = count;
 }
 
+// ---- per-query best feature of a KeyFrame window: the inner loop of ORBmatcher::Fuse (ref: src/ORBmatcher.cc:887-950 with
+// the chi-square gate on the reprojection error, :1044-1075 without) and of SearchBySim3 (:1190-1224, :1270-1304).  The
+// queries are independent (no feature is closed by an earlier point), so one thread walks one window; the first feature
+// of smallest distance wins.  -1 / 256 when the query is inactive or nothing is closer than 256.
+struct LevelGate {
+    float invSigma2[16];
+    int on;
+};
+
+__global__ __launch_bounds__(256) void k_window_best(const uint8_t *__restrict__ desc, int cap,
+                                                     const float *__restrict__ uRight, const LevelGate gate,
+                                                     const GridParams gp, const int32_t *__restrict__ cellOff,
+                                                     const float4 *__restrict__ rec,
+                                                     const orbhip_proj_query *__restrict__ queries,
+                                                     const uint8_t *__restrict__ qdesc, const int32_t *__restrict__ nq,
+                                                     int capQ, int32_t *__restrict__ bestIdx, int32_t *__restrict__ bestDist)
+{
+    const int b = blockIdx.y, iq = blockIdx.x * 256 + threadIdx.x;
+    if (iq >= capQ) return;
+    int bd = 256, bi = -1;
+    if (iq < nq[b]) {
+        const orbhip_proj_query q = queries[(size_t)b * capQ + iq];
+        int x0, x1, y0, y1;
+        if ((q.flags & ORBHIP_Q_ACTIVE) && window_cells(gp, q.u, q.v, q.radius, x0, x1, y0, y1)) {
+            const uint4 *qd = reinterpret_cast<const uint4 *>(qdesc + ((size_t)b * capQ + iq) * 32);
+            const uint4 a0 = qd[0], a1 = qd[1];
+            const uint4 *D = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
+            const float *UR = uRight ? uRight + (size_t)b * cap : nullptr;
+            const float4 *R = rec + (size_t)b * cap;
+            const int32_t *O = cellOff + (size_t)b * (GCELLS + 1);
+            for (int ix = x0; ix <= x1; ix++) {
+                const int s = O[ix * GROWS + y0], e = O[ix * GROWS + y1 + 1];
+                for (int j = s; j < e; j++) {
+                    const float4 r = R[j];
+                    const int w = __float_as_int(r.z), oct = w & 255, idx = w >> 8;
+                    if (!(fabsf(__fsub_rn(r.x, q.u)) < q.radius && fabsf(__fsub_rn(r.y, q.v)) < q.radius)) continue;
+                    if (oct < q.min_level || oct > q.max_level) continue;
+                    if (gate.on) {
+                        const float ex = __fsub_rn(q.u, r.x), ey = __fsub_rn(q.v, r.y);
+                        float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                        const float ur = UR ? UR[idx] : -1.0f;
+                        double lim = 5.99;
+                        if (ur >= 0) {
+                            const float er = __fsub_rn(q.proj_xr, ur);
+                            e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                            lim = 7.8;
+                        }
+                        if ((double)__fmul_rn(e2, gate.invSigma2[oct & 15]) > lim) continue;
+                    }
+                    const int d = hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]);
+                    if (d < bd) {
+                        bd = d;
+                        bi = idx;
+                    }
+                }
+            }
+        }
+    }
+    bestIdx[(size_t)b * capQ + iq] = bi;
+    bestDist[(size_t)b * capQ + iq] = bd;
+}
+
 __device__ __forceinline__ int wave_min_i(int v)
 {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
@@ -838,6 +900,24 @@ int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, floa
     const GridParams gp = {minX, minY, invW, invH};
     hipLaunchKernelGGL(k_area_list, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, kps, gp, cellOff, cellIdx, queries, nq,
                        slots, outCnt, outIdx);
+    return ORBHIP_OK;
+}
+
+size_t window_best_scratch_bytes(int B, int cap) { return (size_t)B * cap * 16 + 256; }
+
+int launch_window_best(hipStream_t s, const orbhip_keypoint *kps, const uint8_t *desc, int cap, int B, const float *uRight,
+                       const float *invLevelSigma2, int nlevels, float minX, float minY, float invW, float invH,
+                       const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries,
+                       const uint8_t *qdesc, const int32_t *nq, int capQ, int32_t *bestIdx, int32_t *bestDist, void *scratch)
+{
+    const GridParams gp = {minX, minY, invW, invH};
+    LevelGate gate;
+    gate.on = invLevelSigma2 != nullptr;
+    for (int i = 0; i < 16; i++) gate.invSigma2[i] = (gate.on && i < nlevels) ? invLevelSigma2[i] : 0.f;
+    float4 *rec = (float4 *)scratch;
+    hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
+    hipLaunchKernelGGL(k_window_best, dim3((capQ + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gate, gp,
+                       cellOff, rec, queries, qdesc, nq, capQ, bestIdx, bestDist);
     return ORBHIP_OK;
 }
 

@@ -1150,6 +1150,74 @@ extern "C" int orbhip_search_by_projection(orbhip_ctx *c, const orbhip_keypoint 
     return ORBHIP_OK;
 }
 
+extern "C" int orbhip_window_best_device(orbhip_ctx *c, const void *d_kps, const void *d_desc, int cap, int B,
+                                         const void *d_u_right, const float *inv_level_sigma2, int nlevels, float min_x,
+                                         float min_y, float inv_w, float inv_h, const void *d_cell_off, const void *d_cell_idx,
+                                         const void *d_queries, const void *d_qdesc, const void *d_nq, int cap_q,
+                                         void *d_best_idx, void *d_best_dist)
+{
+    if (!c || !d_kps || !d_desc || cap <= 0 || B <= 0 || !d_cell_off || !d_cell_idx || !d_queries || !d_qdesc || !d_nq ||
+        cap_q <= 0 || !d_best_idx || !d_best_dist || !grid_params_ok(inv_w, inv_h) || cap >= (1 << 23) ||
+        (inv_level_sigma2 && (nlevels <= 0 || nlevels > 16)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_window_best_device: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = match_scratch(c, window_best_scratch_bytes(B, cap)))) return rc;
+    launch_window_best(c->stream, (const orbhip_keypoint *)d_kps, (const uint8_t *)d_desc, cap, B, (const float *)d_u_right,
+                       inv_level_sigma2, nlevels, min_x, min_y, inv_w, inv_h, (const int32_t *)d_cell_off,
+                       (const int32_t *)d_cell_idx, (const orbhip_proj_query *)d_queries, (const uint8_t *)d_qdesc,
+                       (const int32_t *)d_nq, cap_q, (int32_t *)d_best_idx, (int32_t *)d_best_dist, c->d_match);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_window_best(orbhip_ctx *c, const orbhip_keypoint *kps, const uint8_t *desc, int n, const float *u_right,
+                                  const float *inv_level_sigma2, int nlevels, float min_x, float min_y, float inv_w,
+                                  float inv_h, const orbhip_proj_query *queries, const uint8_t *qdesc, int nq,
+                                  int32_t *best_idx, int32_t *best_dist)
+{
+    if (!c || n < 0 || nq < 0 || (n > 0 && (!kps || !desc)) || (nq > 0 && (!queries || !qdesc || !best_idx || !best_dist)) ||
+        !grid_params_ok(inv_w, inv_h) || (inv_level_sigma2 && (nlevels <= 0 || nlevels > 16)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_window_best: bad argument");
+    for (int i = 0; i < nq; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+    }
+    if (n == 0 || nq == 0) return ORBHIP_OK;
+    if (inv_level_sigma2)
+        for (int i = 0; i < n; i++)
+            if (kps[i].octave < 0 || kps[i].octave >= nlevels)
+                return fail(c, ORBHIP_E_ARG, "orbhip_window_best: a keypoint's octave has no entry in inv_level_sigma2");
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)n * (28 + 32 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (64 + 8) + 16384))) return rc;
+    orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)n * 28);
+    uint8_t *dd = (uint8_t *)T.take((size_t)n * 32);
+    float *dur = u_right ? (float *)T.take((size_t)n * 4) : nullptr;
+    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
+            *didx = (int32_t *)T.take((size_t)n * 4);
+    orbhip_proj_query *dq = (orbhip_proj_query *)T.take((size_t)nq * sizeof(orbhip_proj_query));
+    uint8_t *dqd = (uint8_t *)T.take((size_t)nq * 32);
+    int32_t *dbi = (int32_t *)T.take((size_t)nq * 4), *dbd = (int32_t *)T.take((size_t)nq * 4);
+    const int32_t cnts[2] = {n, nq};
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(dk, kps, (size_t)n * 28, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    if (dur) HIPCHK(c, hipMemcpyAsync(dur, u_right, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dc, cnts, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if ((rc = orbhip_grid_build_device(c, dk, dc, n, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
+    if ((rc = orbhip_window_best_device(c, dk, dd, n, 1, dur, inv_level_sigma2, nlevels, min_x, min_y, inv_w, inv_h, doff, didx,
+                                        dq, dqd, dc + 1, nq, dbi, dbd)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(best_idx, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(best_dist, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return ORBHIP_OK;
+}
+
 extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *c, const void *d_kps1, const void *d_desc1,
                                                        const void *d_counts1, int cap1, const void *d_kps2,
                                                        const void *d_desc2, const void *d_counts2, int cap2, int B,

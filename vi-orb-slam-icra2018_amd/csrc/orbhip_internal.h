@@ -272,6 +272,11 @@ int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *
 int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, float minY, float invW, float invH,
                      const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries, int nq, int slots,
                      int32_t *outCnt, int32_t *outIdx);
+size_t window_best_scratch_bytes(int B, int cap);
+int launch_window_best(hipStream_t s, const orbhip_keypoint *kps, const uint8_t *desc, int cap, int B, const float *uRight,
+                       const float *invLevelSigma2, int nlevels, float minX, float minY, float invW, float invH,
+                       const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries,
+                       const uint8_t *qdesc, const int32_t *nq, int capQ, int32_t *bestIdx, int32_t *bestDist, void *scratch);
 size_t proj_scratch_bytes(int B, int capQ, int cap);
 size_t proj_assign_lds(int cap);
 int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const uint8_t *desc, const int32_t *cnt, int cap,

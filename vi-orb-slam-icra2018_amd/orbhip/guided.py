@@ -96,6 +96,25 @@ def SearchByProjection(ctx, kps_un, desc, gp, queries, qdesc, u_right=None, occu
     return nm.value, match[:len(kps_un)].copy()
 
 
+def WindowBest(ctx, kps_un, desc, gp, queries, qdesc, u_right=None, inv_level_sigma2=None):
+    """Per-point best feature of a KeyFrame window, the inner loop of ORBmatcher::Fuse (src/ORBmatcher.cc:887-950; the
+    chi-square gate when inv_level_sigma2 is given), Fuse(Scw) (:1044-1075) and SearchBySim3 (:1190-1224):
+    (best_idx[nq], best_dist[nq]), -1 / 256 when none."""
+    kps_un = np.ascontiguousarray(kps_un, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, f32)
+    sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, f32)
+    bi = np.empty(max(len(queries), 1), np.int32)
+    bd = np.empty(max(len(queries), 1), np.int32)
+    check(capi.load().orbhip_window_best(ctx.handle, _p(kps_un), _p(desc), len(kps_un), _p(ur), _p(sg),
+                                         0 if sg is None else len(sg), gp[0], gp[1], gp[2], gp[3], _p(queries), _p(qdesc),
+                                         len(queries), _p(bi), _p(bd)),
+          ctx.handle, "orbhip_window_best")
+    return bi[:len(queries)].copy(), bd[:len(queries)].copy()
+
+
 def SearchForInitialization(ctx, kps1_un, desc1, kps2_un, desc2, gp, prev_matched, window_size=100, nnratio=0.9,
                             check_ori=True):
     """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520).  Returns (nmatches, vnMatches12,
