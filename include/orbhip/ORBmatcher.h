@@ -76,6 +76,20 @@ public:
     int SearchForTriangulation(KeyFrame *pKF1, KeyFrame* pKF2, cv::Mat F12,
                                std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo);
 
+    // Project MapPoints using a Similarity Transformation and search matches.
+    // Used in loop detection (Loop Closing) (ref: src/ORBmatcher.cc:290-403)
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*> &vpPoints, std::vector<MapPoint*> &vpMatched, int th);
+
+    // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]
+    // In the stereo and RGB-D case, s12=1 (ref: src/ORBmatcher.cc:1102-1326)
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th);
+
+    // Project MapPoints into KeyFrame and search for duplicated MapPoints. (ref: src/ORBmatcher.cc:825-975)
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint *> &vpMapPoints, const float th=3.0);
+
+    // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints. (ref: src/ORBmatcher.cc:977-1100)
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint);
+
     // Device context used for matching.  By default one small context per thread is created on
     // first use (matchers are stack objects in the reference and are used from three threads).
     static void SetDevice(int device);

@@ -34,12 +34,13 @@ namespace ORB_SLAM2
 {
 
 class Frame;
+class KeyFrame;
 
 class MapPoint
 {
 public:
     MapPoint() : mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
-                 mTrackViewCos(0), nObs(0), mfMinDistance(0), mfMaxDistance(0), mbBad(false) {}
+                 mTrackViewCos(0), nObs(0), mfMinDistance(0), mfMaxDistance(0), mpReplaced(0), mbBad(false) {}
     bool isBad() { return mbBad; }          // ref: include/MapPoint.h
     void SetBadFlag() { mbBad = true; }
     int Observations() { return nObs; }
@@ -48,6 +49,19 @@ public:
     float GetMinDistanceInvariance() { return 0.8f*mfMinDistance; }   // ref: src/MapPoint.cc:388-398
     float GetMaxDistanceInvariance() { return 1.2f*mfMaxDistance; }
     int PredictScale(const float &currentDist, Frame *pF);           // ref: src/MapPoint.cc:417-432 (body below Frame)
+    int PredictScale(const float &currentDist, KeyFrame *pKF);       // ref: src/MapPoint.cc:400-415 (body below KeyFrame)
+
+    // the map operations ORBmatcher::Fuse / SearchBySim3 call (ref: src/MapPoint.cc:113-124, 192-230, 366-386; bodies
+    // below KeyFrame).  Replace moves the observations and marks this point bad; the reference's Replace also merges the
+    // found / visible counters, recomputes the survivor's descriptor and erases the point from the Map, which have no
+    // twin here (none of it is read again inside the matcher).
+    cv::Mat GetNormal() { return mNormalVector.clone(); }
+    std::map<KeyFrame *, size_t> GetObservations() { return mObservations; }
+    bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }
+    int GetIndexInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
+    void AddObservation(KeyFrame *pKF, size_t idx);
+    void Replace(MapPoint *pMP);
+    MapPoint *GetReplaced() { return mpReplaced; }
 
     // Variables used by the tracking (ref: include/MapPoint.h:102-107), read by SearchByProjection
     float mTrackProjX;
@@ -62,6 +76,9 @@ public:
     cv::Mat mDescriptor;                     // 1 x 32 CV_8U
     cv::Mat mWorldPos;                       // 3 x 1 CV_32F
     float mfMinDistance, mfMaxDistance;      // scale invariance distances
+    cv::Mat mNormalVector;                   // 3 x 1 CV_32F, mean viewing direction
+    std::map<KeyFrame *, size_t> mObservations;
+    MapPoint *mpReplaced;
 protected:
     bool mbBad;
 };
@@ -125,7 +142,8 @@ inline int MapPoint::PredictScale(const float &currentDist, Frame *pF)
 class KeyFrame
 {
 public:
-    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0), mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
+    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0), mbf(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0),
+                 mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
                  mfGridElementWidthInv(0), mfGridElementHeightInv(0), mnMinX(0), mnMinY(0), mnMaxX(0), mnMaxY(0) {}
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;   // ref: include/KeyFrame.h (const members there)
     cv::Mat mDescriptors;
@@ -139,6 +157,22 @@ public:
     std::vector<float> mvuRight;                  // negative value for monocular points
     std::vector<float> mvScaleFactors, mvLevelSigma2;
     MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
+    // read / written by ORBmatcher::Fuse, SearchBySim3 and SearchByProjection(KeyFrame*, Scw, ...) (ref: src/ORBmatcher.cc:
+    // 290-403, 825-1326; src/KeyFrame.cc:643-681)
+    float mbf;
+    int mnScaleLevels;
+    float mfScaleFactor, mfLogScaleFactor;
+    std::vector<float> mvInvLevelSigma2;
+    void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
+    void EraseMapPointMatch(const size_t &idx) { mvpMapPoints[idx] = static_cast<MapPoint *>(NULL); }
+    void ReplaceMapPointMatch(const size_t &idx, MapPoint *pMP) { mvpMapPoints[idx] = pMP; }
+    std::set<MapPoint *> GetMapPoints()
+    {
+        std::set<MapPoint *> s;
+        for (size_t i = 0, iend = mvpMapPoints.size(); i < iend; i++)
+            if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]);
+        return s;
+    }
     cv::Mat GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }     // ref: src/KeyFrame.cc
     cv::Mat GetTranslation()
     {
@@ -160,6 +194,49 @@ public:
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r) const;
     bool IsInImage(const float &x, const float &y) const { return (x>=mnMinX && x<mnMaxX && y>=mnMinY && y<mnMaxY); }
 };
+
+inline int MapPoint::PredictScale(const float &currentDist, KeyFrame *pKF)
+{
+    const float ratio = mfMaxDistance/currentDist;
+    int nScale = std::ceil(std::log(ratio)/pKF->mfLogScaleFactor);
+    if(nScale<0)
+        nScale = 0;
+    else if(nScale>=pKF->mnScaleLevels)
+        nScale = pKF->mnScaleLevels-1;
+    return nScale;
+}
+
+inline void MapPoint::AddObservation(KeyFrame *pKF, size_t idx)
+{
+    if(mObservations.count(pKF))
+        return;
+    mObservations[pKF]=idx;
+    if(idx<pKF->mvuRight.size() && pKF->mvuRight[idx]>=0)
+        nObs+=2;
+    else
+        nObs++;
+}
+
+inline void MapPoint::Replace(MapPoint *pMP)
+{
+    if(pMP==this)
+        return;
+    std::map<KeyFrame *, size_t> obs = mObservations;
+    mObservations.clear();
+    mbBad = true;
+    mpReplaced = pMP;
+    for(std::map<KeyFrame *, size_t>::iterator mit=obs.begin(), mend=obs.end(); mit!=mend; mit++)
+    {
+        KeyFrame *pKF = mit->first;
+        if(!pMP->IsInKeyFrame(pKF))
+        {
+            pKF->ReplaceMapPointMatch(mit->second, pMP);
+            pMP->AddObservation(pKF,mit->second);
+        }
+        else
+            pKF->EraseMapPointMatch(mit->second);
+    }
+}
 
 }  // namespace ORB_SLAM2
 

@@ -1,0 +1,473 @@
+// test_fuse_dropin.cpp -- the KeyFrame-side searches of LocalMapping / LoopClosing through the drop-in classes:
+// ORBmatcher::Fuse (both forms), SearchByProjection(KeyFrame*, Scw, ...) and SearchBySim3 (ref: src/ORBmatcher.cc:290-403,
+// 825-1326; callers src/LocalMapping.cc SearchInNeighbors, src/LoopClosing.cc ComputeSim3 / SearchAndFuse).
+// Two identical worlds are built; one runs the drop-in (HIP), the other the loops below, which restate the routines on
+// the host with KeyFrame::GetFeaturesInArea and ORBmatcher::DescriptorDistance; the resulting map states must be equal.
+// Self-checking: exit code 0 and one "ok" line per routine.
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+using namespace ORB_SLAM2;
+using std::vector;
+
+static unsigned long long g_rng = 88172645463325252ull;
+static double urand()   // xorshift64*, [0, 1)
+{
+    g_rng ^= g_rng >> 12; g_rng ^= g_rng << 25; g_rng ^= g_rng >> 27;
+    return (double)((g_rng * 2685821657736338717ull) >> 11) / 9007199254740992.0;
+}
+
+struct Shared {                    // one extraction, shared by every key frame of both worlds
+    vector<cv::KeyPoint> keys;
+    cv::Mat desc;
+    vector<float> scale, sigma2, invSigma2;
+    Frame F;                       // holds the grid
+    int w, h;
+};
+
+struct World {
+    KeyFrame kf[3];                // kf[0], kf[1]: the pair; kf[2]: a third observer
+    vector<MapPoint> pts;
+    vector<MapPoint *> cand;       // fuse candidates (points of kf[0] and of kf[2])
+};
+
+static cv::Mat pose(float ax, float ay, float tx, float ty, float tz)
+{
+    cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
+    const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay);
+    const float R[9] = {cy, 0, sy, sx * sy, cx, -sx * cy, -cx * sy, sx, cx * cy};   // Rx(ax) * Ry(ay)
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) T.at<float>(r, c) = R[r * 3 + c];
+    T.at<float>(0, 3) = tx; T.at<float>(1, 3) = ty; T.at<float>(2, 3) = tz; T.at<float>(3, 3) = 1.f;
+    return T;
+}
+
+static void mul3(const cv::Mat &R, const float x[3], const float *t, float out[3], bool transpose = false, double alpha = 1.0)
+{
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)(transpose ? R.at<float>(k, r) : R.at<float>(r, k)) * (double)x[k];
+        out[r] = (float)(alpha * s + (t ? (double)t[r] : 0.0));
+    }
+}
+
+static void setupKF(KeyFrame &K, const Shared &S, const cv::Mat &Tcw, float stereoShare)
+{
+    K.mvKeys = S.keys; K.mvKeysUn = S.keys; K.mDescriptors = S.desc; K.N = (int)S.keys.size();
+    K.fx = 517.3f; K.fy = 516.5f; K.cx = 318.6f; K.cy = 255.3f; K.mbf = 40.f;
+    K.mvScaleFactors = S.scale; K.mvLevelSigma2 = S.sigma2; K.mvInvLevelSigma2 = S.invSigma2;
+    K.mnScaleLevels = 8; K.mfScaleFactor = 1.2f; K.mfLogScaleFactor = logf(1.2f);
+    K.Tcw = Tcw.clone();
+    K.Ow = cv::Mat(3, 1, CV_32F);
+    float t[3] = {Tcw.at<float>(0, 3), Tcw.at<float>(1, 3), Tcw.at<float>(2, 3)}, o[3];
+    mul3(Tcw, t, NULL, o, true, -1.0);
+    for (int r = 0; r < 3; r++) K.Ow.at<float>(r, 0) = o[r];
+    K.mvuRight.assign(K.N, -1.f);
+    for (int i = 0; i < K.N; i++)
+        if (urand() < stereoShare) K.mvuRight[i] = S.keys[i].pt.x - (float)(2 + 30 * urand());
+    K.mvpMapPoints.assign(K.N, static_cast<MapPoint *>(NULL));
+    K.CopyGridFrom(S.F);
+}
+
+// a point seen by K at feature i: back-projected at a random depth, descriptor of the feature with a few bits flipped
+static void makePoint(MapPoint &p, KeyFrame &K, int i, const Shared &S, float pixelNoise, int flips)
+{
+    const cv::KeyPoint &kp = K.mvKeysUn[i];
+    const float z = (float)(2 + 8 * urand());
+    const float xc[3] = {(kp.pt.x + pixelNoise * (float)(urand() - 0.5) - K.cx) / K.fx * z,
+                         (kp.pt.y + pixelNoise * (float)(urand() - 0.5) - K.cy) / K.fy * z, z};
+    float t[3] = {K.Tcw.at<float>(0, 3), K.Tcw.at<float>(1, 3), K.Tcw.at<float>(2, 3)}, d[3], xw[3];
+    for (int k = 0; k < 3; k++) d[k] = xc[k] - t[k];
+    mul3(K.Tcw, d, NULL, xw, true);                             // Xw = R^T (Xc - t)
+    p.mWorldPos = cv::Mat(3, 1, CV_32F);
+    p.mNormalVector = cv::Mat(3, 1, CV_32F);
+    float po[3], n = 0;
+    for (int k = 0; k < 3; k++) { p.mWorldPos.at<float>(k, 0) = xw[k]; po[k] = xw[k] - K.Ow.at<float>(k, 0); n += po[k] * po[k]; }
+    n = sqrtf(n);
+    const bool sideways = urand() < 0.04;                       // fails the viewing-angle test
+    for (int k = 0; k < 3; k++) p.mNormalVector.at<float>(k, 0) = sideways ? (k == 0 ? 1.f : 0.f) : po[k] / n;
+    p.mfMaxDistance = n * S.scale[kp.octave] * (float)(0.86 + 0.1 * urand());
+    p.mfMinDistance = p.mfMaxDistance / S.scale[7];
+    if (urand() < 0.04) p.mfMaxDistance *= 0.05f;               // out of the scale-invariance range
+    p.mDescriptor = cv::Mat(1, 32, CV_8U);
+    memcpy(p.mDescriptor.ptr(0), K.mDescriptors.ptr(i), 32);
+    for (int f = 0; f < flips; f++) { const int b = (int)(256 * urand()); p.mDescriptor.ptr(0)[b >> 3] ^= 1 << (b & 7); }
+    if (urand() < 0.03) p.SetBadFlag();
+}
+
+static void buildWorld(World &W, const Shared &S, unsigned long long seed)
+{
+    g_rng = seed;
+    setupKF(W.kf[0], S, pose(0.f, 0.f, 0.f, 0.f, 0.f), 0.f);
+    setupKF(W.kf[1], S, pose(0.0012f, -0.0015f, 0.012f, -0.007f, 0.02f), 0.5f);
+    setupKF(W.kf[2], S, pose(-0.002f, 0.001f, -0.01f, 0.004f, -0.015f), 0.3f);
+    const int N = W.kf[0].N;
+    W.pts.assign((size_t)3 * N, MapPoint());
+    int np = 0;
+    for (int k = 0; k < 3; k++)
+        for (int i = 0; i < N; i++) {
+            if (urand() > (k == 1 ? 0.45 : 0.7)) continue;
+            MapPoint &p = W.pts[np++];
+            makePoint(p, W.kf[k], i, S, k == 1 ? 0.f : 3.f, (int)(40 * urand() * urand()));
+            p.AddObservation(&W.kf[k], i);
+            W.kf[k].mvpMapPoints[i] = &p;
+            if (k == 0 && urand() < 0.3) p.nObs += (int)(3 * urand());   // more observers elsewhere: decides who replaces whom
+            if (k != 1 && !(k == 0 && urand() < 0.1)) W.cand.push_back(&p);
+        }
+    W.cand.push_back(static_cast<MapPoint *>(NULL));
+    if (W.kf[1].mvpMapPoints[7]) W.cand.push_back(W.kf[1].mvpMapPoints[7]);   // already in the key frame -> skipped
+}
+
+// ---------------- the routines restated on the host ----------------
+static bool window(KeyFrame *pKF, MapPoint *pMP, const float p3Dc[3], const float *PO, float dist3D, float th, float &u, float &v,
+                   float &ur, int &level, float &radius)
+{
+    if (p3Dc[2] < 0.0f) return false;
+    const float invz = 1.0 / p3Dc[2];
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    u = pKF->fx * x + pKF->cx;
+    v = pKF->fy * y + pKF->cy;
+    if (!pKF->IsInImage(u, v)) return false;
+    ur = u - pKF->mbf * invz;
+    if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) return false;
+    if (PO) {
+        cv::Mat Pn = pMP->GetNormal();
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn.at<float>(k, 0);
+        if (dot < 0.5 * dist3D) return false;
+    }
+    level = pMP->PredictScale(dist3D, pKF);
+    radius = th * pKF->mvScaleFactors[level];
+    return true;
+}
+
+static float norm3(const float a[3])
+{
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)a[k] * (double)a[k];
+    return std::sqrt(s);
+}
+
+// best feature of the window (gate: Fuse's chi-square test); vpClosed != NULL: features holding a match are skipped
+static int bestInWindow(KeyFrame *pKF, MapPoint *pMP, float u, float v, float ur, int level, float radius, bool gate,
+                        const vector<MapPoint *> *vpClosed, int &bestDist)
+{
+    const vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);
+    const cv::Mat dMP = pMP->GetDescriptor();
+    bestDist = 256;
+    int bestIdx = -1;
+    for (size_t c = 0; c < vIndices.size(); c++) {
+        const size_t idx = vIndices[c];
+        if (vpClosed && (*vpClosed)[idx]) continue;
+        const cv::KeyPoint &kp = pKF->mvKeysUn[idx];
+        const int kpLevel = kp.octave;
+        if (kpLevel < level - 1 || kpLevel > level) continue;
+        if (gate) {
+            const float ex = u - kp.pt.x, ey = v - kp.pt.y;
+            if (pKF->mvuRight[idx] >= 0) {
+                const float er = ur - pKF->mvuRight[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
+            }
+        }
+        const int dist = ORBmatcher::DescriptorDistance(dMP, pKF->mDescriptors.row((int)idx));
+        if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+    return bestIdx;
+}
+
+static void worldPos(MapPoint *p, float xw[3])
+{
+    cv::Mat m = p->GetWorldPos();
+    for (int k = 0; k < 3; k++) xw[k] = m.at<float>(k, 0);
+}
+
+static void kfPose(KeyFrame *K, cv::Mat &R, float t[3], float o[3])
+{
+    R = K->GetRotation();
+    cv::Mat tm = K->GetTranslation(), om = K->GetCameraCenter();
+    for (int k = 0; k < 3; k++) { t[k] = tm.at<float>(k, 0); o[k] = om.at<float>(k, 0); }
+}
+
+static void sim3Pose(const cv::Mat &Scw, cv::Mat &Rcw, float tcw[3], float Ow[3])
+{
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)Scw.at<float>(0, k) * (double)Scw.at<float>(0, k);
+    const float scw = sqrt(dot);
+    Rcw = cv::Mat(3, 3, CV_32F);
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) Rcw.at<float>(r, k) = (float)((double)Scw.at<float>(r, k) * (1.0 / scw));
+        tcw[r] = (float)((double)Scw.at<float>(r, 3) * (1.0 / scw));
+    }
+    mul3(Rcw, tcw, NULL, Ow, true, -1.0);
+}
+
+static int refFuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, float th)
+{
+    cv::Mat Rcw; float tcw[3], Ow[3];
+    kfPose(pKF, Rcw, tcw, Ow);
+    int nFused = 0;
+    for (size_t i = 0; i < vpMapPoints.size(); i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        float xw[3], pc[3], PO[3], u, v, ur, radius; int level, bestDist;
+        worldPos(pMP, xw);
+        mul3(Rcw, xw, tcw, pc);
+        for (int k = 0; k < 3; k++) PO[k] = xw[k] - Ow[k];
+        if (!window(pKF, pMP, pc, PO, norm3(PO), th, u, v, ur, level, radius)) continue;
+        const int bestIdx = bestInWindow(pKF, pMP, u, v, ur, level, radius, true, NULL, bestDist);
+        if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_LOW) {
+            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx);
+                pKF->AddMapPoint(pMP, bestIdx);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+static int refFuseScw(KeyFrame *pKF, const cv::Mat &Scw, const vector<MapPoint *> &vpPoints, float th, vector<MapPoint *> &vpReplacePoint)
+{
+    cv::Mat Rcw; float tcw[3], Ow[3];
+    sim3Pose(Scw, Rcw, tcw, Ow);
+    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();
+    int nFused = 0;
+    for (size_t i = 0; i < vpPoints.size(); i++) {
+        MapPoint *pMP = vpPoints[i];
+        if (!pMP || pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        float xw[3], pc[3], PO[3], u, v, ur, radius; int level, bestDist;
+        worldPos(pMP, xw);
+        mul3(Rcw, xw, tcw, pc);
+        for (int k = 0; k < 3; k++) PO[k] = xw[k] - Ow[k];
+        if (!window(pKF, pMP, pc, PO, norm3(PO), th, u, v, ur, level, radius)) continue;
+        const int bestIdx = bestInWindow(pKF, pMP, u, v, ur, level, radius, false, NULL, bestDist);
+        if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_LOW) {
+            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF, bestIdx);
+                pKF->AddMapPoint(pMP, bestIdx);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+static int refProjScw(KeyFrame *pKF, const cv::Mat &Scw, const vector<MapPoint *> &vpPoints, vector<MapPoint *> &vpMatched, int th)
+{
+    cv::Mat Rcw; float tcw[3], Ow[3];
+    sim3Pose(Scw, Rcw, tcw, Ow);
+    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
+    int nmatches = 0;
+    for (size_t i = 0; i < vpPoints.size(); i++) {
+        MapPoint *pMP = vpPoints[i];
+        if (!pMP || pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        float xw[3], pc[3], PO[3], u, v, ur, radius; int level, bestDist;
+        worldPos(pMP, xw);
+        mul3(Rcw, xw, tcw, pc);
+        for (int k = 0; k < 3; k++) PO[k] = xw[k] - Ow[k];
+        if (!window(pKF, pMP, pc, PO, norm3(PO), (float)th, u, v, ur, level, radius)) continue;
+        const int bestIdx = bestInWindow(pKF, pMP, u, v, ur, level, radius, false, &vpMatched, bestDist);
+        if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_LOW) { vpMatched[bestIdx] = pMP; nmatches++; }
+    }
+    return nmatches;
+}
+
+static int refSim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12, float s12, const cv::Mat &R12, const cv::Mat &t12, float th)
+{
+    cv::Mat R1w, R2w; float t1w[3], t2w[3], o[3];
+    kfPose(pKF1, R1w, t1w, o);
+    kfPose(pKF2, R2w, t2w, o);
+    cv::Mat sR12(3, 3, CV_32F), sR21(3, 3, CV_32F);
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) {
+            sR12.at<float>(r, k) = (float)((double)s12 * (double)R12.at<float>(r, k));
+            sR21.at<float>(r, k) = (float)((1.0 / s12) * (double)R12.at<float>(k, r));
+        }
+    float t12v[3] = {t12.at<float>(0, 0), t12.at<float>(1, 0), t12.at<float>(2, 0)}, t21[3];
+    mul3(sR21, t12v, NULL, t21, false, -1.0);
+    const vector<MapPoint *> vp1 = pKF1->GetMapPointMatches(), vp2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)vp1.size(), N2 = (int)vp2.size();
+    vector<bool> done1(N1, false), done2(N2, false);
+    for (int i = 0; i < N1; i++)
+        if (vpMatches12[i]) {
+            done1[i] = true;
+            const int idx2 = vpMatches12[i]->GetIndexInKeyFrame(pKF2);
+            if (idx2 >= 0 && idx2 < N2) done2[idx2] = true;
+        }
+    vector<int> m1(N1, -1), m2(N2, -1);
+    for (int dir = 0; dir < 2; dir++) {
+        const vector<MapPoint *> &vp = dir ? vp2 : vp1;
+        for (int i = 0; i < (int)vp.size(); i++) {
+            MapPoint *pMP = vp[i];
+            if (!pMP || (dir ? done2[i] : done1[i]) || pMP->isBad()) continue;
+            float xw[3], pa[3], pb[3], u, v, ur, radius; int level, bestDist;
+            worldPos(pMP, xw);
+            if (!dir) { mul3(R1w, xw, t1w, pa); mul3(sR21, pa, t21, pb); }
+            else { mul3(R2w, xw, t2w, pa); mul3(sR12, pa, t12v, pb); }
+            KeyFrame *dst = dir ? pKF1 : pKF2;
+            if (!window(dst, pMP, pb, NULL, norm3(pb), th, u, v, ur, level, radius)) continue;
+            const int bestIdx = bestInWindow(dst, pMP, u, v, ur, level, radius, false, NULL, bestDist);
+            if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_HIGH) (dir ? m2 : m1)[i] = bestIdx;
+        }
+    }
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++)
+        if (m1[i1] >= 0 && m2[m1[i1]] == i1) { vpMatches12[i1] = vp2[m1[i1]]; nFound++; }
+    return nFound;
+}
+
+// ---------------- state comparison ----------------
+static long idx(const World &W, const MapPoint *p) { return p ? (long)(p - &W.pts[0]) : -1; }
+
+static bool sameState(World &A, World &B, const char *what)
+{
+    for (int k = 0; k < 3; k++)
+        for (int i = 0; i < A.kf[k].N; i++)
+            if (idx(A, A.kf[k].mvpMapPoints[i]) != idx(B, B.kf[k].mvpMapPoints[i])) {
+                printf("%s: kf[%d].mvpMapPoints[%d] differs: %ld vs %ld\n", what, k, i, idx(A, A.kf[k].mvpMapPoints[i]), idx(B, B.kf[k].mvpMapPoints[i]));
+                return false;
+            }
+    for (size_t i = 0; i < A.pts.size(); i++) {
+        MapPoint &a = A.pts[i], &b = B.pts[i];
+        bool same = a.isBad() == b.isBad() && a.Observations() == b.Observations() && idx(A, a.GetReplaced()) == idx(B, b.GetReplaced()) &&
+                    a.mObservations.size() == b.mObservations.size();
+        for (int k = 0; same && k < 3; k++) same = a.GetIndexInKeyFrame(&A.kf[k]) == b.GetIndexInKeyFrame(&B.kf[k]);
+        if (!same) { printf("%s: point %zu differs\n", what, i); return false; }
+    }
+    return true;
+}
+
+static bool sameVec(const World &A, const vector<MapPoint *> &a, const World &B, const vector<MapPoint *> &b, const char *what)
+{
+    if (a.size() != b.size()) { printf("%s: sizes differ\n", what); return false; }
+    for (size_t i = 0; i < a.size(); i++)
+        if (idx(A, a[i]) != idx(B, b[i])) { printf("%s: entry %zu differs: %ld vs %ld\n", what, i, idx(A, a[i]), idx(B, b[i])); return false; }
+    return true;
+}
+
+static int count(const vector<MapPoint *> &v) { int n = 0; for (size_t i = 0; i < v.size(); i++) n += v[i] != NULL; return n; }
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) { fprintf(stderr, "usage: %s w h nfeatures frame.raw\n", argv[0]); return 2; }
+    Shared S;
+    S.w = atoi(argv[1]); S.h = atoi(argv[2]);
+    const int nf = atoi(argv[3]);
+    vector<unsigned char> raw((size_t)S.w * S.h);
+    FILE *f = fopen(argv[4], "rb");
+    if (!f || fread(raw.data(), 1, raw.size(), f) != raw.size()) { perror(argv[4]); return 2; }
+    fclose(f);
+
+    ORBextractor ex(nf, 1.2f, 8, 20, 7);
+    ex.SetPyramidDownload(false);
+    cv::Mat im(S.h, S.w, CV_8UC1, raw.data());
+    ex(im, cv::Mat(), S.keys, S.desc);
+    S.scale = ex.GetScaleFactors(); S.sigma2 = ex.GetScaleSigmaSquares(); S.invSigma2 = ex.GetInverseScaleSigmaSquares();
+    Frame::mnMinX = 0; Frame::mnMaxX = (float)S.w; Frame::mnMinY = 0; Frame::mnMaxY = (float)S.h;
+    Frame::mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / (Frame::mnMaxX - Frame::mnMinX);
+    Frame::mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / (Frame::mnMaxY - Frame::mnMinY);
+    S.F.mvKeys = S.keys; S.F.mvKeysUn = S.keys; S.F.N = (int)S.keys.size();
+    S.F.mpORBextractorLeft = &ex;
+    S.F.AssignFeaturesToGrid();
+    printf("features %d\n", S.F.N);
+
+    int fails = 0;
+    for (int round = 0; round < 3; round++) {
+        const unsigned long long seed = 1234567ull + 7919ull * round;
+        // ---- Fuse(pKF, vpMapPoints, th): LocalMapping::SearchInNeighbors ----
+        {
+            World A, B;
+            buildWorld(A, S, seed); buildWorld(B, S, seed);
+            ORBmatcher matcher;
+            const float th = round == 2 ? 6.f : 3.f;
+            const int na = matcher.Fuse(&A.kf[1], A.cand, th), nb = refFuse(&B.kf[1], B.cand, th);
+            int replaced = 0;
+            for (size_t i = 0; i < A.pts.size(); i++) replaced += A.pts[i].GetReplaced() != NULL;
+            const bool ok = na == nb && sameState(A, B, "Fuse") && na > 100 && replaced > 20;
+            printf("Fuse round %d: %s fused %d (ref %d) of %zu candidates, %d replaced\n", round, ok ? "ok" : "FAILED", na, nb, A.cand.size(), replaced);
+            fails += !ok;
+        }
+        const cv::Mat T1 = pose(0.0012f, -0.0015f, 0.012f, -0.007f, 0.02f);
+        cv::Mat Scw = T1.clone();
+        const float s = round == 0 ? 1.f : 1.f + 0.002f * round;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) Scw.at<float>(r, c) = s * T1.at<float>(r, c) + (c == 3 ? 0.002f * round : 0.f);
+        // ---- Fuse(pKF, Scw, vpPoints, th, vpReplacePoint): LoopClosing::SearchAndFuse ----
+        {
+            World A, B;
+            buildWorld(A, S, seed); buildWorld(B, S, seed);
+            vector<MapPoint *> pa, pb;
+            for (size_t i = 0; i < A.cand.size(); i++)
+                if (A.cand[i]) { pa.push_back(A.cand[i]); pb.push_back(B.cand[i]); }
+            vector<MapPoint *> ra(pa.size(), static_cast<MapPoint *>(NULL)), rb(pb.size(), static_cast<MapPoint *>(NULL));
+            ORBmatcher matcher(0.8f);
+            const int na = matcher.Fuse(&A.kf[1], Scw, pa, 4.f, ra), nb = refFuseScw(&B.kf[1], Scw, pb, 4.f, rb);
+            const bool ok = na == nb && sameState(A, B, "Fuse(Scw)") && sameVec(A, ra, B, rb, "vpReplacePoint") && na > 100 && count(ra) > 20;
+            printf("Fuse(Scw) round %d: %s fused %d (ref %d), %d to replace\n", round, ok ? "ok" : "FAILED", na, nb, count(ra));
+            fails += !ok;
+        }
+        // ---- SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): LoopClosing::ComputeSim3 ----
+        {
+            World A, B;
+            buildWorld(A, S, seed); buildWorld(B, S, seed);
+            vector<MapPoint *> pa, pb;
+            for (size_t i = 0; i < A.cand.size(); i++)
+                if (A.cand[i]) { pa.push_back(A.cand[i]); pb.push_back(B.cand[i]); }
+            vector<MapPoint *> ma(A.kf[1].N, static_cast<MapPoint *>(NULL)), mb(B.kf[1].N, static_cast<MapPoint *>(NULL));
+            for (int i = 0; i < A.kf[1].N; i += 5) { ma[i] = pa[(size_t)i % pa.size()]; mb[i] = pb[(size_t)i % pb.size()]; }   // found earlier
+            const int before = count(ma);
+            ORBmatcher matcher(0.75f, true);
+            const int na = matcher.SearchByProjection(&A.kf[1], Scw, pa, ma, 10), nb = refProjScw(&B.kf[1], Scw, pb, mb, 10);
+            const bool ok = na == nb && sameVec(A, ma, B, mb, "vpMatched") && na > 100 && count(ma) == before + na;
+            printf("SearchByProjection(Scw) round %d: %s matches %d (ref %d)\n", round, ok ? "ok" : "FAILED", na, nb);
+            fails += !ok;
+        }
+        // ---- SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): LoopClosing::ComputeSim3 ----
+        {
+            World A, B;
+            buildWorld(A, S, seed); buildWorld(B, S, seed);
+            // camera 1 = kf[0] (identity), camera 2 = kf[1]: S12 maps camera-2 coordinates to camera 1
+            cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F);
+            float t[3] = {T1.at<float>(0, 3), T1.at<float>(1, 3), T1.at<float>(2, 3)}, o[3];
+            mul3(T1, t, NULL, o, true, -1.0);
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) R12.at<float>(r, c) = T1.at<float>(c, r);
+                t12.at<float>(r, 0) = o[r] + 0.001f * round;
+            }
+            vector<MapPoint *> ma(A.kf[0].N, static_cast<MapPoint *>(NULL)), mb(B.kf[0].N, static_cast<MapPoint *>(NULL));
+            for (int i = 3; i < A.kf[0].N; i += 11)
+                if (A.kf[1].mvpMapPoints[i]) { ma[i] = A.kf[1].mvpMapPoints[i]; mb[i] = B.kf[1].mvpMapPoints[i]; }   // from SearchByBoW
+            const int before = count(ma);
+            ORBmatcher matcher(0.75f, true);
+            const int na = matcher.SearchBySim3(&A.kf[0], &A.kf[1], ma, s, R12, t12, 7.5f), nb = refSim3(&B.kf[0], &B.kf[1], mb, s, R12, t12, 7.5f);
+            const bool ok = na == nb && sameVec(A, ma, B, mb, "vpMatches12") && na > 50 && count(ma) == before + na;
+            printf("SearchBySim3 round %d: %s found %d (ref %d), %d given\n", round, ok ? "ok" : "FAILED", na, nb, before);
+            fails += !ok;
+        }
+    }
+    printf(fails ? "FAILED (%d)\n" : "all ok\n", fails);
+    return fails ? 1 : 0;
+}

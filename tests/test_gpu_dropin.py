@@ -346,3 +346,19 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
         assert n3 == rn3 and rn3 > 100 and np.array_equal(take(n0), rm3)
         assert take(2 * n0).view(f32).tobytes() == prev.tobytes()
     assert pos == len(buf)
+
+
+@pytest.mark.gpu
+def test_cpp_fuse_sim3_and_keyframe_projection_match_host_restatement(tmp_path):
+    """ORBmatcher::Fuse (both forms), SearchByProjection(KeyFrame*, Scw, ...) and SearchBySim3 through the drop-in
+    classes (tests/native/test_fuse_dropin.cpp): two identical worlds, one through the HIP path and one through the
+    routines restated on the host in that program (src/ORBmatcher.cc:290-403, 825-1326); map states must be equal."""
+    from orbhip import synth
+    exe = os.path.join(ROOT, "tests", "native", "test_fuse_dropin")
+    assert os.path.exists(exe), "tests/native/test_fuse_dropin is not built (run __graft_entry__.build())"
+    W, H = 640, 480
+    frame = synth.make_frames(90, W, H, 1)[0]
+    (tmp_path / "frame.raw").write_bytes(frame.tobytes())
+    r = subprocess.run([exe, str(W), str(H), "1500", str(tmp_path / "frame.raw")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": ok") == 12 and "all ok" in r.stdout, r.stdout

@@ -371,6 +371,351 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
     return run_projection_search(CurrentFrame, q, qdesc, vpMPs, false, mfNNratio, mbCheckOrientation, ORBdist, true, false);
 }
 
+namespace {
+// ---- the KeyFrame-side searches of LocalMapping / LoopClosing (ref: src/ORBmatcher.cc:290-403, 825-1326) ----
+// The wrappers project the points on the host exactly as the reference's loops do (cv::gemm arithmetic: double
+// accumulation, one rounding), hand the windows to the device and apply the map updates in the reference's order.
+
+// out = float(alpha * R) (or R transposed): what OpenCV materialises for s*R, R/s and (1/s)*R.t()
+void scale3(const cv::Mat &R, double alpha, bool transpose, cv::Mat &out)
+{
+    out = cv::Mat(3, 3, CV_32F);
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++)
+            out.at<float>(r, k) = (float)(alpha * (double)(transpose ? R.at<float>(k, r) : R.at<float>(r, k)));
+}
+
+// Scw -> Rcw, tcw, Ow (ref: :299-303, :989-993)
+void decompose_sim3(const cv::Mat &Scw, cv::Mat &Rcw, float tcw[3], float Ow[3])
+{
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)Scw.at<float>(0, k) * (double)Scw.at<float>(0, k);
+    const float scw = sqrt(dot);
+    const cv::Mat sRcw = Scw.rowRange(0,3).colRange(0,3);
+    scale3(sRcw, 1.0 / scw, false, Rcw);
+    for (int r = 0; r < 3; r++) tcw[r] = (float)((double)Scw.at<float>(r, 3) * (1.0 / scw));
+    affine3(Rcw, tcw, NULL, Ow, true, -1.0);                   // Ow = -Rcw.t()*tcw
+}
+
+inline void world_pos(MapPoint *pMP, float xw[3])
+{
+    const cv::Mat p = pMP->GetWorldPos();
+    xw[0] = p.at<float>(0, 0); xw[1] = p.at<float>(1, 0); xw[2] = p.at<float>(2, 0);
+}
+
+inline float norm3(const float a[3])                           // cv::norm of a float vector sums the squares in double
+{
+    double sq = 0;
+    for (int k = 0; k < 3; k++) sq += (double)a[k]*(double)a[k];
+    return std::sqrt(sq);
+}
+
+// The window of one point in pKF from its camera coordinates (ref: :851-893, :330-369, :1163-1192).  PO != NULL adds
+// the viewing-angle test against the point's normal.  Returns false where the reference's loop says continue.
+bool kf_window(KeyFrame *pKF, MapPoint *pMP, const float p3Dc[3], const float *PO, float dist3D, float th, bool bf,
+               orbhip_proj_query &e, uint8_t *qdesc)
+{
+    if(p3Dc[2]<0.0f)
+        return false;
+    const float invz = 1.0/p3Dc[2];
+    const float x = p3Dc[0]*invz;
+    const float y = p3Dc[1]*invz;
+    const float u = pKF->fx*x+pKF->cx;
+    const float v = pKF->fy*y+pKF->cy;
+    if(!pKF->IsInImage(u,v))
+        return false;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    if(dist3D<minDistance || dist3D>maxDistance)
+        return false;
+    if(PO)
+    {
+        const cv::Mat Pn = pMP->GetNormal();
+        double dot = 0;
+        for (int k = 0; k < 3; k++) dot += (double)PO[k]*(double)Pn.at<float>(k, 0);
+        if(dot<0.5*dist3D)
+            return false;
+    }
+    const int nPredictedLevel = pMP->PredictScale(dist3D,pKF);
+    e.u = u;
+    e.v = v;
+    e.radius = th*pKF->mvScaleFactors[nPredictedLevel];
+    e.proj_xr = bf ? u-pKF->mbf*invz : 0.f;
+    e.min_level = nPredictedLevel-1;
+    e.max_level = nPredictedLevel;
+    e.flags = ORBHIP_Q_ACTIVE | ORBHIP_Q_OBSERVED;
+    const cv::Mat dMP = pMP->GetDescriptor();
+    memcpy(qdesc, dMP.ptr(0), 32);
+    return true;
+}
+
+void run_window_best(KeyFrame *pKF, const vector<orbhip_proj_query> &q, const vector<uint8_t> &qdesc, bool gate,
+                     vector<int32_t> &bestIdx, vector<int32_t> &bestDist)
+{
+    const int n = (int)pKF->mvKeysUn.size(), nq = (int)q.size();
+    bestIdx.assign(nq, -1);
+    bestDist.assign(nq, 256);
+    if (n == 0 || nq == 0) return;
+    const vector<uint8_t> d = contiguous(pKF->mDescriptors);
+    const int rc = orbhip_window_best(
+        tls.get(), reinterpret_cast<const orbhip_keypoint *>(pKF->mvKeysUn.data()), d.data(), n,
+        (gate && (int)pKF->mvuRight.size() == n) ? pKF->mvuRight.data() : NULL, gate ? pKF->mvInvLevelSigma2.data() : NULL,
+        gate ? (int)pKF->mvInvLevelSigma2.size() : 0, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
+        pKF->mfGridElementHeightInv, q.data(), qdesc.data(), nq, bestIdx.data(), bestDist.data());
+    if (rc != ORBHIP_OK) throw std::runtime_error(std::string("ORBmatcher (KeyFrame window search): ") + orbhip_last_error(tls.get()));
+}
+}  // namespace
+
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)
+{
+    // ref: src/ORBmatcher.cc:290-403.  Best only on levels [predicted-1, predicted], a feature that holds a match is
+    // closed (:372-373), threshold TH_LOW: the frame-side search with every point closing its feature.
+    cv::Mat Rcw;
+    float tcw[3], Ow[3];
+    decompose_sim3(Scw, Rcw, tcw, Ow);
+
+    set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+
+    const int nq = (int)vpPoints.size(), n = (int)pKF->mvKeysUn.size();
+    vector<orbhip_proj_query> q(nq);
+    vector<uint8_t> qdesc((size_t)nq * 32, 0);
+    for(int iMP=0; iMP<nq; iMP++)
+    {
+        memset(&q[iMP], 0, sizeof(q[iMP]));
+        MapPoint* pMP = vpPoints[iMP];
+        if(!pMP || pMP->isBad() || spAlreadyFound.count(pMP))
+            continue;
+        float xw[3], p3Dc[3], PO[3];
+        world_pos(pMP, xw);
+        affine3(Rcw, xw, tcw, p3Dc);
+        for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
+        kf_window(pKF, pMP, p3Dc, PO, norm3(PO), (float)th, false, q[iMP], &qdesc[(size_t)iMP * 32]);
+    }
+    if (n == 0 || nq == 0) return 0;
+    vector<uint8_t> occupied(n, 0);
+    for (int i = 0; i < n && i < (int)vpMatched.size(); i++) occupied[i] = vpMatched[i] ? 1 : 0;
+    const vector<uint8_t> d = contiguous(pKF->mDescriptors);
+    vector<int32_t> match(n);
+    int nmatches = 0;
+    const int rc = orbhip_search_by_projection(
+        tls.get(), reinterpret_cast<const orbhip_keypoint *>(pKF->mvKeysUn.data()), d.data(), n, NULL, occupied.data(),
+        pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, q.data(), qdesc.data(), nq, 0,
+        mfNNratio, 0, TH_LOW, match.data(), &nmatches);
+    if (rc != ORBHIP_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection: ") + orbhip_last_error(tls.get()));
+    for (int i = 0; i < n; i++)
+        if (match[i] >= 0) vpMatched[i] = vpPoints[match[i]];
+    return nmatches;
+}
+
+int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th)
+{
+    // ref: src/ORBmatcher.cc:825-975.  The window of a point does not depend on the points before it; whether it is
+    // skipped (isBad / IsInKeyFrame, :847-848) and what its feature holds (:953) do, so those are read in the loop
+    // that applies the results, in the reference's order.
+    const cv::Mat Rcw = pKF->GetRotation();
+    const cv::Mat tcwM = pKF->GetTranslation();
+    const cv::Mat OwM = pKF->GetCameraCenter();
+    float tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { tcw[r] = tcwM.at<float>(r, 0); Ow[r] = OwM.at<float>(r, 0); }
+
+    const int nMPs = vpMapPoints.size();
+    vector<orbhip_proj_query> q(nMPs);
+    vector<uint8_t> qdesc((size_t)nMPs * 32, 0);
+    for(int i=0; i<nMPs; i++)
+    {
+        memset(&q[i], 0, sizeof(q[i]));
+        MapPoint* pMP = vpMapPoints[i];
+        if(!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF))
+            continue;
+        float xw[3], p3Dc[3], PO[3];
+        world_pos(pMP, xw);
+        affine3(Rcw, xw, tcw, p3Dc);
+        for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
+        kf_window(pKF, pMP, p3Dc, PO, norm3(PO), th, true, q[i], &qdesc[(size_t)i * 32]);
+    }
+    vector<int32_t> bestIdx, bestDist;
+    run_window_best(pKF, q, qdesc, true, bestIdx, bestDist);
+
+    int nFused=0;
+    for(int i=0; i<nMPs; i++)
+    {
+        MapPoint* pMP = vpMapPoints[i];
+        if(!pMP)
+            continue;
+        if(pMP->isBad() || pMP->IsInKeyFrame(pKF))
+            continue;
+        // If there is already a MapPoint replace otherwise add new measurement
+        if(bestIdx[i]>=0 && bestDist[i]<=TH_LOW)
+        {
+            MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+            if(pMPinKF)
+            {
+                if(!pMPinKF->isBad())
+                {
+                    if(pMPinKF->Observations()>pMP->Observations())
+                        pMP->Replace(pMPinKF);
+                    else
+                        pMPinKF->Replace(pMP);
+                }
+            }
+            else
+            {
+                pMP->AddObservation(pKF,bestIdx[i]);
+                pKF->AddMapPoint(pMP,bestIdx[i]);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, float th, vector<MapPoint *> &vpReplacePoint)
+{
+    // ref: src/ORBmatcher.cc:977-1100
+    cv::Mat Rcw;
+    float tcw[3], Ow[3];
+    decompose_sim3(Scw, Rcw, tcw, Ow);
+
+    // Set of MapPoints already found in the KeyFrame
+    const set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+
+    const int nPoints = vpPoints.size();
+    vector<orbhip_proj_query> q(nPoints);
+    vector<uint8_t> qdesc((size_t)nPoints * 32, 0);
+    for(int iMP=0; iMP<nPoints; iMP++)
+    {
+        memset(&q[iMP], 0, sizeof(q[iMP]));
+        MapPoint* pMP = vpPoints[iMP];
+        if(!pMP || pMP->isBad() || spAlreadyFound.count(pMP))
+            continue;
+        float xw[3], p3Dc[3], PO[3];
+        world_pos(pMP, xw);
+        affine3(Rcw, xw, tcw, p3Dc);
+        for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
+        kf_window(pKF, pMP, p3Dc, PO, norm3(PO), th, false, q[iMP], &qdesc[(size_t)iMP * 32]);
+    }
+    vector<int32_t> bestIdx, bestDist;
+    run_window_best(pKF, q, qdesc, false, bestIdx, bestDist);
+
+    int nFused=0;
+    for(int iMP=0; iMP<nPoints; iMP++)
+    {
+        if(bestIdx[iMP]<0 || bestDist[iMP]>TH_LOW)
+            continue;
+        MapPoint* pMP = vpPoints[iMP];
+        MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[iMP]);
+        if(pMPinKF)
+        {
+            if(!pMPinKF->isBad())
+                vpReplacePoint[iMP] = pMPinKF;
+        }
+        else
+        {
+            pMP->AddObservation(pKF,bestIdx[iMP]);
+            pKF->AddMapPoint(pMP,bestIdx[iMP]);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
+int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12,
+                             const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)
+{
+    // ref: src/ORBmatcher.cc:1102-1326
+    //Camera 1 from world
+    const cv::Mat R1w = pKF1->GetRotation();
+    const cv::Mat t1wM = pKF1->GetTranslation();
+    //Camera 2 from world
+    const cv::Mat R2w = pKF2->GetRotation();
+    const cv::Mat t2wM = pKF2->GetTranslation();
+
+    //Transformation between cameras
+    cv::Mat sR12, sR21;
+    scale3(R12, (double)s12, false, sR12);                     // s12*R12
+    scale3(R12, 1.0/s12, true, sR21);                          // (1.0/s12)*R12.t()
+    float t1w[3], t2w[3], t12v[3], t21[3];
+    for (int r = 0; r < 3; r++) { t1w[r] = t1wM.at<float>(r, 0); t2w[r] = t2wM.at<float>(r, 0); t12v[r] = t12.at<float>(r, 0); }
+    affine3(sR21, t12v, NULL, t21, false, -1.0);               // t21 = -sR21*t12
+
+    const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = vpMapPoints1.size();
+
+    const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N2 = vpMapPoints2.size();
+
+    vector<bool> vbAlreadyMatched1(N1,false);
+    vector<bool> vbAlreadyMatched2(N2,false);
+
+    for(int i=0; i<N1; i++)
+    {
+        MapPoint* pMP = vpMatches12[i];
+        if(pMP)
+        {
+            vbAlreadyMatched1[i]=true;
+            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+            if(idx2>=0 && idx2<N2)
+                vbAlreadyMatched2[idx2]=true;
+        }
+    }
+
+    // Transform from KF1 to KF2 and search; then from KF2 to KF1
+    vector<int32_t> vnMatch1, vnMatch2, dist1, dist2;
+    for (int dir = 0; dir < 2; dir++)
+    {
+        const vector<MapPoint*> &vpMPs = dir == 0 ? vpMapPoints1 : vpMapPoints2;
+        const vector<bool> &vbAlready = dir == 0 ? vbAlreadyMatched1 : vbAlreadyMatched2;
+        KeyFrame *pKFdst = dir == 0 ? pKF2 : pKF1;
+        const int N = vpMPs.size();
+        vector<orbhip_proj_query> q(N);
+        vector<uint8_t> qdesc((size_t)N * 32, 0);
+        for(int i=0; i<N; i++)
+        {
+            memset(&q[i], 0, sizeof(q[i]));
+            MapPoint* pMP = vpMPs[i];
+            if(!pMP || vbAlready[i])
+                continue;
+            if(pMP->isBad())
+                continue;
+            float xw[3], pa[3], pb[3];
+            world_pos(pMP, xw);
+            if (dir == 0) {
+                affine3(R1w, xw, t1w, pa);                     // p3Dc1 = R1w*p3Dw + t1w
+                affine3(sR21, pa, t21, pb);                    // p3Dc2 = sR21*p3Dc1 + t21
+            } else {
+                affine3(R2w, xw, t2w, pa);                     // p3Dc2 = R2w*p3Dw + t2w
+                affine3(sR12, pa, t12v, pb);                   // p3Dc1 = sR12*p3Dc2 + t12
+            }
+            kf_window(pKFdst, pMP, pb, NULL, norm3(pb), th, false, q[i], &qdesc[(size_t)i * 32]);
+        }
+        run_window_best(pKFdst, q, qdesc, false, dir == 0 ? vnMatch1 : vnMatch2, dir == 0 ? dist1 : dist2);
+    }
+    for(int i1=0; i1<N1; i1++) if(dist1[i1]>TH_HIGH) vnMatch1[i1] = -1;
+    for(int i2=0; i2<N2; i2++) if(dist2[i2]>TH_HIGH) vnMatch2[i2] = -1;
+
+    // Check agreement
+    int nFound = 0;
+
+    for(int i1=0; i1<N1; i1++)
+    {
+        int idx2 = vnMatch1[i1];
+
+        if(idx2>=0)
+        {
+            int idx1 = vnMatch2[idx2];
+            if(idx1==i1)
+            {
+                vpMatches12[i1] = vpMapPoints2[idx2];
+                nFound++;
+            }
+        }
+    }
+
+    return nFound;
+}
+
 int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
                                        vector<pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo)
 {
