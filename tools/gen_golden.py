@@ -164,8 +164,37 @@ def gen_triangulation():
     print("triangulation", n)
 
 
+def gen_window_best():
+    """The Fuse / SearchBySim3 window search: the right image's features as projected points into the left key frame."""
+    from orbhip.capi import QUERY_DTYPE, Q_ACTIVE
+    L, R = synth.make_stereo_pair(203, 376, 241, disparity=14)
+    ex = oracle.Extractor(400, 1.2, 6)
+    kL, dL = ex(L)
+    kR, dR = ex(R)
+    rng = np.random.default_rng(207)
+    nq = len(kR)
+    q = np.zeros(nq, QUERY_DTYPE)
+    q["u"] = (kR["x"] + np.float32(14) * np.float32(1.2) ** kR["octave"] + rng.normal(0, 1.0, nq)).astype(np.float32)
+    q["v"] = (kR["y"] + rng.normal(0, 1.0, nq)).astype(np.float32)
+    pred = np.clip(kR["octave"] + rng.integers(0, 2, nq), 0, 5).astype(np.int32)
+    q["radius"] = (np.float32(3) * np.float32(1.2) ** pred).astype(np.float32)
+    q["proj_xr"] = (q["u"] - np.float32(14)).astype(np.float32)
+    q["min_level"], q["max_level"] = pred - 1, pred
+    q["flags"] = np.where(rng.random(nq) < 0.1, 0, Q_ACTIVE)
+    ur = np.where(rng.random(len(kL)) < 0.5, kL["x"] - np.float32(14), -1).astype(np.float32)
+    inv_s2 = (1.0 / np.array(list(ex.params.mvLevelSigma2)[:6], np.float32)).astype(np.float32)
+    gp = oracle.grid_params(0, 376, 0, 241)
+    bi, bd = oracle.window_best(kL, dL, gp, q, dR)
+    gi, gd = oracle.window_best(kL, dL, gp, q, dR, ur, inv_s2)
+    np.savez_compressed(os.path.join(OUT, "window_best_376x241.npz"), kps=kL, desc=dL, grid=np.array(gp, np.float32), queries=q,
+                        qdesc=dR, u_right=ur, inv_level_sigma2=inv_s2, best_idx=bi, best_dist=bd, gated_idx=gi, gated_dist=gd)
+    print("window_best", int((bi >= 0).sum()), int((gi >= 0).sum()), int((bd <= 50).sum()), int((gd <= 50).sum()))
+
+
 if __name__ == "__main__":
-    if "triangulation" in sys.argv[1:]:
+    if "window_best" in sys.argv[1:]:
+        gen_window_best()
+    elif "triangulation" in sys.argv[1:]:
         gen_triangulation()
     elif "init_search" in sys.argv[1:]:
         gen_init_search()
@@ -173,3 +202,4 @@ if __name__ == "__main__":
         main()
         gen_init_search()
         gen_triangulation()
+        gen_window_best()

@@ -251,7 +251,7 @@ def main():
     blob = D.make_synthetic_vocabulary(99, k=6, L=4)
     V = oracle.Vocabulary(blob)
     n = 0
-    stats = {"frames": 0, "kps": 0, "bow": 0, "proj": 0, "init": 0, "tri": 0}
+    stats = {"frames": 0, "kps": 0, "bow": 0, "proj": 0, "init": 0, "tri": 0, "fuse": 0}
     while time.time() - t0 < budget:
         w = int(rng.integers(200, 900))
         h = int(rng.integers(160, 700))
@@ -348,6 +348,26 @@ def main():
                 print("MISMATCH tri", w, h, nf, seed)
                 sys.exit(1)
             stats["tri"] += a[0]
+            # the Fuse / SearchBySim3 window search: frame 0's features as points projected into frame 1
+            nq = len(k0)
+            qw = np.zeros(nq, guided.QUERY_DTYPE)
+            qw["u"] = (k0["x"] + rng.normal(0, 2, nq)).astype(np.float32)
+            qw["v"] = (k0["y"] + rng.normal(0, 2, nq)).astype(np.float32)
+            pred = np.clip(k0["octave"] + rng.integers(-1, 2, nq), 0, nlev - 1).astype(np.int32)
+            qw["radius"] = (np.float32(rng.choice([3, 4, 7.5])) * sf[pred]).astype(np.float32)
+            qw["proj_xr"] = (qw["u"] - rng.uniform(0, 30, nq)).astype(np.float32)
+            qw["min_level"], qw["max_level"] = pred - 1, pred
+            qw["flags"] = np.where(rng.random(nq) < 0.1, 0, 1)
+            gate = rng.random() < 0.6
+            ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - rng.uniform(0, 30, len(k1)), -1).astype(np.float32) \
+                if rng.random() < 0.5 else None
+            isg = (np.float32(1) / s2).astype(np.float32) if gate else None
+            a = guided.WindowBest(ex, k1, d1, gp, qw, d0, ur, isg)
+            b_ = oracle.window_best(k1, d1, gp, qw, d0, ur, isg)
+            if not np.array_equal(a[0], b_[0]) or not np.array_equal(a[1], b_[1]):
+                print("MISMATCH window_best", w, h, nf, seed, gate, ur is not None)
+                sys.exit(1)
+            stats["fuse"] += int((a[1] <= 50).sum())
         ex.close()
         n += 1
     print("soak ok: %d random configurations in %.0f s, %s" % (n, time.time() - t0, stats))
