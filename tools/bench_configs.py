@@ -237,6 +237,68 @@ def run_host_batch(W, H, nfeat, B):
     return B / dt, dt * 1e3, float(n.mean())
 
 
+def run_fuse(W, H, nfeat, B, iters=30):
+    """LocalMapping::SearchInNeighbors' matcher step for B key frames at once: the points seen by key frame b-1 projected into
+    key frame b (constant-position guess + noise), th = 3, levels [predicted - 1, predicted], chi-square gate (mono):
+    orbhip_grid_build_device + orbhip_window_best_device on resident data.  Returns (key frames/s, points/s, fused/frame)."""
+    from orbhip import guided
+    frames_u = synth.make_frames(5, W, H, 16)
+    frames = np.concatenate([frames_u] * ((B + 15) // 16))[:B]
+    stride = (W + 15) // 16 * 16
+    host = np.zeros((B, H, stride), np.uint8)
+    host[:, :, :W] = frames
+    d_img = torch.from_numpy(host).cuda()
+    ex = ORBextractor(nfeat, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B)
+    cap = ex.cap
+    i32 = dict(dtype=torch.int32, device="cuda")
+    d_kps = torch.empty((B, cap, 7), **i32)
+    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, **i32)
+    ex.extract_batch_device(d_img.data_ptr(), B, W, H, stride, H * stride, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_cnt.data_ptr())
+    ex.sync()
+    gp = guided.grid_params(0, W, 0, H)
+    d_off = torch.empty((B, 64 * 48 + 1), **i32)
+    d_idx = torch.empty((B, cap), **i32)
+    sf = torch.tensor([float(np.float32(1.2) ** l) for l in range(8)], dtype=torch.float32, device="cuda")
+    k = d_kps.roll(1, 0)
+    octv = k[:, :, 5].clamp(0, 7).long()
+    d_q = torch.zeros((B, cap, 8), **i32)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    d_q[:, :, 0] = (k[:, :, 0].view(torch.float32) + torch.randn((B, cap), device="cuda", generator=g)).view(torch.int32)
+    d_q[:, :, 1] = (k[:, :, 1].view(torch.float32) + torch.randn((B, cap), device="cuda", generator=g)).view(torch.int32)
+    d_q[:, :, 2] = (3.0 * sf[octv]).view(torch.int32)
+    d_q[:, :, 4] = k[:, :, 5] - 1
+    d_q[:, :, 5] = k[:, :, 5]
+    d_q[:, :, 7] = 1
+    d_qd = d_desc.roll(1, 0).contiguous()
+    d_nq = d_cnt.roll(1, 0).contiguous()
+    d_bi = torch.empty((B, cap), **i32)
+    d_bd = torch.empty((B, cap), **i32)
+    inv_s2 = (np.float32(1) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    L = ex._L
+    torch.cuda.synchronize()
+
+    def step():
+        assert L.orbhip_grid_build_device(ex.handle, d_kps.data_ptr(), d_cnt.data_ptr(), cap, B, gp[0], gp[1], gp[2], gp[3],
+                                          d_off.data_ptr(), d_idx.data_ptr()) == 0
+        assert L.orbhip_window_best_device(ex.handle, d_kps.data_ptr(), d_desc.data_ptr(), cap, B, None,
+                                           inv_s2.ctypes.data_as(C.c_void_p), 8, gp[0], gp[1], gp[2], gp[3], d_off.data_ptr(),
+                                           d_idx.data_ptr(), d_q.data_ptr(), d_qd.data_ptr(), d_nq.data_ptr(), cap,
+                                           d_bi.data_ptr(), d_bd.data_ptr()) == 0
+    for _ in range(3):
+        step()
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    ex.sync()
+    dt = time.perf_counter() - t0
+    npts = int(d_nq.sum().item())
+    fused = float((d_bd <= 50).sum().item()) / B
+    ex.close()
+    return iters * B / dt, iters * npts / dt, fused
+
+
 def run_big_knn(nq, ndb):
     db = torch.randint(0, 256, (ndb, 32), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, ndb, (nq,), device="cuda")
@@ -282,6 +344,10 @@ def main():
         fps, dt, kp, ms = run_extract(640, 480, 2000, 256, 2048, "init", seed=1)
         print("| 1c | init | %.0f frames/s | %.1f matches per pair |" % (fps, kp))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "fuse":            # profiling aid
+        kfs, pts, fused = run_fuse(640, 480, 1000, 256)
+        print("| 1e | fuse | %.0f key frames/s | %.1f M points/s, %.1f fused per key frame |" % (kfs, pts / 1e6, fused))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "rectify":         # profiling aid
         pps, st, good = run_stereo(752, 480, 1200, 128, 1024, 0.11, 47.9, rectify=True)
         print("| 3c | rectify+stereo | %.0f pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
@@ -318,6 +384,8 @@ def main():
     print("| 5c: few-query regime | 8 queries x 1 000 000 rows | - | %.3f ms, %.1f GB/s database stream |" % (dt * 1e3, 32e6 / dt / 1e9))
     fps, ms, kp = run_host_batch(640, 480, 1000, 256)
     print("| 1d: batch through host pointers (incl. PCIe) | 256 frames 640x480, 1000 feat, orbhip_extract_batch from pageable host memory: H2D images, extraction, D2H keypoints + descriptors | %.0f | %.2f ms per 256-frame call, %.1f kp/frame |" % (fps, ms, kp))
+    kfs, pts, fused = run_fuse(640, 480, 1000, 256)
+    print("| 1e: Fuse window search (LocalMapping::SearchInNeighbors' matcher step) | 256 resident key frames 640x480, 1000 feat: AssignFeaturesToGrid + the points of key frame b-1 projected into key frame b, th 3, levels [l-1, l], chi-square gate (orbhip_window_best_device) | %.0f key frames/s | %.1f M points/s, %.1f fused per key frame |" % (kfs, pts / 1e6, fused))
     lat, t = run_single_frame_latency(640, 480, 1000)
     print("| 1: single frame (host pointers, incl. PCIe) | 640x480, 1000 feat, orbhip_extract per call | %.0f | %.3f ms per call; device stage times pyramid %.3f / keypoints %.3f / descriptors %.3f ms |" % (1e3 / lat, lat, t[0], t[1], t[2]))
 
