@@ -284,6 +284,17 @@ int orbhip_search_by_projection_device(orbhip_ctx *ctx, const void *d_kps_un, co
                                        const void *d_qdesc, const void *d_nq, int cap_q, int use_ratio,
                                        float nnratio, int check_ori, int th_high, void *d_match, void *d_nmatches);
 
+/* Replaces the body of MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:283-349; the remaining caller of
+ * ORBmatcher::DescriptorDistance, run by LocalMapping on every point of a new key frame and after every fusion) for P map
+ * points at once: point p's observed descriptors (rows of the key frames that see it, in the order of its observation map)
+ * are rows off[p] .. off[p + 1] of desc; off[0] = 0.  best[p] = the row within that list with the least median distance
+ * to the list (the reference's sorted_row[0.5 * (N - 1)], self-distance included; the first such row), -1 for an empty
+ * list; best_median[p] (may be NULL in the host form) = that median, INT_MAX for an empty list. */
+int orbhip_distinctive_descriptors(orbhip_ctx *ctx, const uint8_t *desc, const int32_t *off, int P, int32_t *best,
+                                   int32_t *best_median);
+int orbhip_distinctive_descriptors_device(orbhip_ctx *ctx, const void *d_desc, const void *d_off, int P, void *d_best,
+                                          void *d_best_median);
+
 /* Replaces the per-point inner loop of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th)
  * (src/ORBmatcher.cc:887-950), Fuse(KeyFrame*, cv::Mat Scw, ...) (:1044-1075) and both directions of SearchBySim3
  * (:1190-1224, :1270-1304): for every projected point, KeyFrame::GetFeaturesInArea(u, v, radius) (src/KeyFrame.cc:1138-1177),

@@ -1589,6 +1589,51 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
     return nmatches;
 }
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:283-349) for P points at once: point p's observed descriptors
+ * are rows off[p] .. off[p+1] of desc (the order of its observation map); all pair distances, per row the median
+ * vDists[0.5*(N-1)] of the sorted row (self-distance 0 included), the first row of least median wins.
+ * best[p] = row index within the point's list (-1 for an empty list), best_median[p] its median. */
+void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int P, int32_t *best, int32_t *best_median)
+{
+    for (int p = 0; p < P; p++) {
+        const int N = off[p + 1] - off[p];
+        const uint8_t *D = desc + (size_t)off[p] * 32;
+        best[p] = -1;
+        best_median[p] = INT_MAX;
+        if (N <= 0) continue;
+        int *dist = (int *)malloc(sizeof(int) * (size_t)N * (size_t)N);
+        int *row = (int *)malloc(sizeof(int) * (size_t)N);
+        for (int i = 0; i < N; i++) {
+            dist[(size_t)i * N + i] = 0;
+            for (int j = i + 1; j < N; j++) {
+                const int d = orbo_descriptor_distance(D + (size_t)i * 32, D + (size_t)j * 32);
+                dist[(size_t)i * N + j] = d;
+                dist[(size_t)j * N + i] = d;
+            }
+        }
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            for (int j = 0; j < N; j++) { /* insertion sort of row i */
+                int v = dist[(size_t)i * N + j], k = j;
+                while (k > 0 && row[k - 1] > v) {
+                    row[k] = row[k - 1];
+                    k--;
+                }
+                row[k] = v;
+            }
+            const int median = row[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) {
+                BestMedian = median;
+                BestIdx = i;
+            }
+        }
+        best[p] = BestIdx;
+        best_median[p] = BestMedian;
+        free(dist);
+        free(row);
+    }
+}
+
 /* The per-point inner loop shared by ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:887-950:
  * chi-square gate on the reprojection error when inv_level_sigma2 != NULL), Fuse(KeyFrame*, Scw, ...) (:1044-1075) and
  * SearchBySim3 (:1190-1224, :1270-1304; the gate is off there): KeyFrame::GetFeaturesInArea(u, v, radius)

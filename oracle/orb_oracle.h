@@ -174,6 +174,10 @@ int orbo_search_by_projection(const orbo_keypoint *kps, const uint8_t *desc, int
                               const orbo_proj_query *q, const uint8_t *qdesc, int nq, int use_ratio, float nnratio,
                               int check_ori, int th_high, int32_t *match);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:283-349), P points in CSR form; best[p] = row of least median
+ * distance to the others (first wins), -1 for an empty list */
+void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *off, int P, int32_t *best, int32_t *best_median);
+
 /* inner loop of ORBmatcher::Fuse (src/ORBmatcher.cc:887-950; :1044-1075) and SearchBySim3 (:1190-1224): the first
  * feature of smallest distance in the window on levels [min_level, max_level]; inv_level_sigma2 != NULL adds Fuse's
  * chi-square gate (7.8 with a right coordinate >= 0, else 5.99).  -1 / 256 when none. */

@@ -448,6 +448,23 @@ def search_by_projection(kps, desc, gp, queries, qdesc, u_right=None, occupied=N
     return n, match[:len(kps)].copy()
 
 
+def distinctive_descriptors(desc, off):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:283-349) for the points whose observed descriptors are
+    rows off[p]..off[p+1] of desc: (best row within each list or -1, its median distance)."""
+    L = lib()
+    L.orbo_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.orbo_distinctive_descriptors.restype = None
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.int32)
+    P = len(off) - 1
+    best = np.empty(max(P, 1), np.int32)
+    med = np.empty(max(P, 1), np.int32)
+    if len(desc) == 0:
+        desc = np.zeros((1, 32), np.uint8)
+    L.orbo_distinctive_descriptors(_p(desc), _p(off), P, _p(best), _p(med))
+    return best[:P].copy(), med[:P].copy()
+
+
 def window_best(kps, desc, gp, queries, qdesc, u_right=None, inv_level_sigma2=None):
     """Per-query best feature in the window: the inner loop of ORBmatcher::Fuse (src/ORBmatcher.cc:887-950 with the
     chi-square gate = inv_level_sigma2 given; :1044-1075 without) and SearchBySim3 (:1190-1224).

@@ -533,3 +533,59 @@ void launch_tri_match(hipStream_t s, const orbhip_keypoint *kps1, const uint8_t 
     hipLaunchKernelGGL(k_tri_match, dim3((npairs + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, kps1, desc1, skip1, ur1, off1, idx1, kps2,
                        desc2, skip2, ur2, off2, idx2, reinterpret_cast<const int2 *>(pairs), npairs, P, scale2, sigma2, match12);
 }
+
+// ---- MapPoint::ComputeDistinctiveDescriptors (ref: src/MapPoint.cc:283-349) for many points at once ----------------
+// One wave per point: lane i owns row i of the N x N distance matrix (rows beyond 64 in further rounds).  The median the
+// reference reads, sorted_row[(size_t)(0.5 * (N - 1))], is the k-th smallest of the row; distances are integers in
+// 0..256, so it is found by bisection on the value (9 counts of "row entries <= v", the row's distances recomputed from
+// the descriptors each time: they are broadcast reads of a few hundred bytes, cheaper than parking rows in LDS and
+// without a bound on N).  The first row of least median wins: min over median << 20 | row.
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__ desc, const int32_t *__restrict__ off, int P,
+                                                     int32_t *__restrict__ best, int32_t *__restrict__ bestMedian)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= P) return;
+    const int s = off[p], N = off[p + 1] - s;
+    if (N <= 0) {
+        if (lane == 0) {
+            best[p] = -1;
+            bestMedian[p] = 0x7fffffff;
+        }
+        return;
+    }
+    const uint4 *D = reinterpret_cast<const uint4 *>(desc) + (size_t)s * 2;
+    const int k = (int)(0.5 * (double)(N - 1));
+    unsigned key = 0xffffffffu;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < N) {
+            const uint4 a0 = D[2 * i], a1 = D[2 * i + 1];
+            int lo = 0, hi = 256;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                int cnt = 0;
+                for (int j = 0; j < N; j++) {
+                    const uint4 b0 = D[2 * j], b1 = D[2 * j + 1];
+                    const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                                  __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+                    cnt += d <= mid;
+                }
+                if (cnt > k) hi = mid;
+                else lo = mid + 1;
+            }
+            key = min(key, ((unsigned)lo << 20) | (unsigned)i);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, d));
+    if (lane == 0) {
+        best[p] = (int)(key & 0xfffffu);
+        bestMedian[p] = (int)(key >> 20);
+    }
+}
+
+void launch_distinctive(hipStream_t s, const uint8_t *desc, const int32_t *off, int P, int32_t *best, int32_t *bestMedian)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_distinctive, dim3((P + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, desc, off, P, best, bestMedian);
+}

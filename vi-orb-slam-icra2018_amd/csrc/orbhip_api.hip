@@ -1150,6 +1150,52 @@ extern "C" int orbhip_search_by_projection(orbhip_ctx *c, const orbhip_keypoint 
     return ORBHIP_OK;
 }
 
+extern "C" int orbhip_distinctive_descriptors_device(orbhip_ctx *c, const void *d_desc, const void *d_off, int P, void *d_best,
+                                                    void *d_best_median)
+{
+    if (!c || P < 0 || (P > 0 && (!d_desc || !d_off || !d_best || !d_best_median)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors_device: bad argument");
+    if (P == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_distinctive(c->stream, (const uint8_t *)d_desc, (const int32_t *)d_off, P, (int32_t *)d_best, (int32_t *)d_best_median);
+    HIPCHK(c, hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_distinctive_descriptors(orbhip_ctx *c, const uint8_t *desc, const int32_t *off, int P, int32_t *best,
+                                             int32_t *best_median)
+{
+    if (!c || P < 0 || (P > 0 && (!off || !best)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors: bad argument");
+    if (P == 0) return ORBHIP_OK;
+    if (off[0] != 0) return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors: off[0] must be 0");
+    for (int p = 0; p < P; p++)
+        if (off[p + 1] < off[p] || off[p + 1] - off[p] >= (1 << 20))
+            return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors: offsets must ascend, a list holds fewer than 2^20 rows");
+    const int total = off[P];
+    if (total > 0 && !desc) return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDev T(c);
+    int rc;
+    if ((rc = T.reserve((size_t)total * 32 + (size_t)(P + 1) * 4 + (size_t)P * 8 + 4096))) return rc;
+    uint8_t *dd = (uint8_t *)T.take((size_t)total * 32 + 32);
+    int32_t *doff = (int32_t *)T.take((size_t)(P + 1) * 4), *db = (int32_t *)T.take((size_t)P * 4),
+            *dm = (int32_t *)T.take((size_t)P * 4);
+    hipStream_t s = c->stream;
+    if (total > 0) HIPCHK(c, hipMemcpyAsync(dd, desc, (size_t)total * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(doff, off, (size_t)(P + 1) * 4, hipMemcpyHostToDevice, s));
+    if ((rc = orbhip_distinctive_descriptors_device(c, dd, doff, P, db, dm))) return rc;
+    HIPCHK(c, hipMemcpyAsync(best, db, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> med;
+    if (!best_median) {
+        med.resize(P);
+        best_median = med.data();
+    }
+    HIPCHK(c, hipMemcpyAsync(best_median, dm, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return ORBHIP_OK;
+}
+
 extern "C" int orbhip_window_best_device(orbhip_ctx *c, const void *d_kps, const void *d_desc, int cap, int B,
                                          const void *d_u_right, const float *inv_level_sigma2, int nlevels, float min_x,
                                          float min_y, float inv_w, float inv_h, const void *d_cell_off, const void *d_cell_idx,

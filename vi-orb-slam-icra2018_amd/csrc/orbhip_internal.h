@@ -284,6 +284,7 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
                                 float invH, const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries,
                                 const uint8_t *qdesc, const int32_t *nq, int capQ, int use_ratio, float nnratio,
                                 int check_ori, int th_high, int32_t *match, int32_t *nmatches, void *scratch);
+void launch_distinctive(hipStream_t s, const uint8_t *desc, const int32_t *off, int P, int32_t *best, int32_t *bestMedian);
 void launch_tri_match(hipStream_t s, const orbhip_keypoint *kps1, const uint8_t *desc1, const uint8_t *skip1, const float *ur1,
                       const int32_t *off1, const int32_t *idx1, const orbhip_keypoint *kps2, const uint8_t *desc2,
                       const uint8_t *skip2, const float *ur2, const int32_t *off2, const int32_t *idx2, const int32_t *pairs,

@@ -32,6 +32,7 @@ SYMBOLS = [
     "orbhip_features_in_area", "orbhip_search_by_projection", "orbhip_search_by_projection_device",
     "orbhip_search_for_initialization", "orbhip_search_for_initialization_device",
     "orbhip_search_for_triangulation", "orbhip_window_best", "orbhip_window_best_device",
+    "orbhip_distinctive_descriptors", "orbhip_distinctive_descriptors_device",
     "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
     "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
 ]
@@ -108,6 +109,8 @@ def load():
                                               vp, ip]
     L.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, vp,
                                                      i32, i32, f32, i32, i32, vp, vp]
+    L.orbhip_distinctive_descriptors.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.orbhip_distinctive_descriptors_device.argtypes = [vp, vp, vp, i32, vp, vp]
     L.orbhip_window_best.argtypes = [vp, vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp, vp, i32, vp, vp]
     L.orbhip_window_best_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp, i32,
                                             vp, vp]

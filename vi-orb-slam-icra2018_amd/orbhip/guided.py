@@ -96,6 +96,19 @@ def SearchByProjection(ctx, kps_un, desc, gp, queries, qdesc, u_right=None, occu
     return nm.value, match[:len(kps_un)].copy()
 
 
+def ComputeDistinctiveDescriptors(ctx, desc, off):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:283-349) for the points whose observed descriptors are rows
+    off[p]..off[p+1] of desc: (best row within each list or -1, its median)."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.int32)
+    P = len(off) - 1
+    best = np.empty(max(P, 1), np.int32)
+    med = np.empty(max(P, 1), np.int32)
+    check(capi.load().orbhip_distinctive_descriptors(ctx.handle, _p(desc) if len(desc) else None, _p(off), P, _p(best), _p(med)),
+          ctx.handle, "orbhip_distinctive_descriptors")
+    return best[:P].copy(), med[:P].copy()
+
+
 def WindowBest(ctx, kps_un, desc, gp, queries, qdesc, u_right=None, inv_level_sigma2=None):
     """Per-point best feature of a KeyFrame window, the inner loop of ORBmatcher::Fuse (src/ORBmatcher.cc:887-950; the
     chi-square gate when inv_level_sigma2 is given), Fuse(Scw) (:1044-1075) and SearchBySim3 (:1190-1224):
