@@ -110,6 +110,14 @@ protected:
     bool mbCheckOrientation;
 };
 
+// MapPoint::ComputeDistinctiveDescriptors (ref: src/MapPoint.cc:283-349) for many map points in one device call -- the
+// batched form of the loops LocalMapping runs over a key frame's points (src/LocalMapping.cc ProcessNewKeyFrame,
+// CreateNewMapPoints, SearchInNeighbors: "pMP->ComputeDistinctiveDescriptors()" per point).  Bad points, points without
+// observations and points whose observers are all bad are left alone, as in the reference.  Returns the number of points
+// whose descriptor was set.  Inside the reference tree MapPoint needs a setter for its protected mDescriptor
+// (INTEGRATION.md).
+int ComputeDistinctiveDescriptors(const std::vector<MapPoint*> &vpMapPoints);
+
 }// namespace ORB_SLAM
 
 #endif // ORBMATCHER_H

@@ -62,6 +62,7 @@ public:
     void AddObservation(KeyFrame *pKF, size_t idx);
     void Replace(MapPoint *pMP);
     MapPoint *GetReplaced() { return mpReplaced; }
+    void SetDescriptor(const cv::Mat &d) { mDescriptor = d.clone(); }   // mDescriptor is protected in the reference
 
     // Variables used by the tracking (ref: include/MapPoint.h:102-107), read by SearchByProjection
     float mTrackProjX;
@@ -142,9 +143,11 @@ inline int MapPoint::PredictScale(const float &currentDist, Frame *pF)
 class KeyFrame
 {
 public:
-    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0), mbf(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0),
+    KeyFrame() : mbBad(false), N(0), fx(0), fy(0), cx(0), cy(0), mbf(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0),
                  mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
                  mfGridElementWidthInv(0), mfGridElementHeightInv(0), mnMinX(0), mnMinY(0), mnMaxX(0), mnMaxY(0) {}
+    bool isBad() { return mbBad; }                // ref: src/KeyFrame.cc (read by MapPoint::ComputeDistinctiveDescriptors)
+    bool mbBad;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;   // ref: include/KeyFrame.h (const members there)
     cv::Mat mDescriptors;
     DBoW2::FeatureVector mFeatVec;

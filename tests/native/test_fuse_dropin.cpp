@@ -4,7 +4,9 @@
 // Two identical worlds are built; one runs the drop-in (HIP), the other the loops below, which restate the routines on
 // the host with KeyFrame::GetFeaturesInArea and ORBmatcher::DescriptorDistance; the resulting map states must be equal.
 // Self-checking: exit code 0 and one "ok" line per routine.
+#include <algorithm>
 #include <climits>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -467,6 +469,56 @@ int main(int argc, char **argv)
             printf("SearchBySim3 round %d: %s found %d (ref %d), %d given\n", round, ok ? "ok" : "FAILED", na, nb, before);
             fails += !ok;
         }
+    }
+    // ---- ComputeDistinctiveDescriptors over the points of a fused world (LocalMapping::SearchInNeighbors' last loop) ----
+    {
+        World A, B;
+        buildWorld(A, S, 424242ull); buildWorld(B, S, 424242ull);
+        ORBmatcher matcher;
+        matcher.Fuse(&A.kf[1], A.cand, 3.f);                     // gives many points two or three observers
+        refFuse(&B.kf[1], B.cand, 3.f);
+        A.kf[2].mbBad = B.kf[2].mbBad = true;                    // a bad observer's descriptor is not used
+        // the observers share one image here; make their descriptor rows differ so that the choice matters
+        for (int k = 0; k < 3; k++)
+            for (int i = 0; i < A.kf[k].N; i++)
+                for (int f = 0; f < 3 * k; f++) {
+                    const int b = (i * 31 + f * 97 + k * 7) & 255;
+                    A.kf[k].mDescriptors.ptr(i)[b >> 3] ^= 1 << (b & 7);
+                    B.kf[k].mDescriptors.ptr(i)[b >> 3] ^= 1 << (b & 7);
+                }
+        vector<MapPoint *> va, vb;
+        for (size_t i = 0; i < A.pts.size(); i++) { va.push_back(&A.pts[i]); vb.push_back(&B.pts[i]); }
+        va.push_back(static_cast<MapPoint *>(NULL));
+        const int na = ComputeDistinctiveDescriptors(va);
+        int nb = 0, multi = 0, diff = 0;
+        for (size_t i = 0; i < vb.size(); i++) {                 // src/MapPoint.cc:283-349 restated
+            MapPoint *pMP = vb[i];
+            if (pMP->isBad()) continue;
+            const std::map<KeyFrame *, size_t> obs = pMP->GetObservations();
+            vector<cv::Mat> vDescriptors;
+            for (std::map<KeyFrame *, size_t>::const_iterator it = obs.begin(); it != obs.end(); it++)
+                if (!it->first->isBad()) vDescriptors.push_back(it->first->mDescriptors.row((int)it->second));
+            if (vDescriptors.empty()) continue;
+            const size_t N = vDescriptors.size();
+            int BestMedian = INT_MAX, BestIdx = 0;
+            for (size_t r = 0; r < N; r++) {
+                vector<int> vDists(N);
+                for (size_t c = 0; c < N; c++) vDists[c] = r == c ? 0 : ORBmatcher::DescriptorDistance(vDescriptors[r], vDescriptors[c]);
+                std::sort(vDists.begin(), vDists.end());
+                const int median = vDists[0.5 * (N - 1)];
+                if (median < BestMedian) { BestMedian = median; BestIdx = (int)r; }
+            }
+            pMP->SetDescriptor(vDescriptors[BestIdx]);
+            nb++;
+            multi += N > 1;
+        }
+        for (size_t i = 0; i < A.pts.size(); i++) {
+            const cv::Mat da = A.pts[i].GetDescriptor(), db = B.pts[i].GetDescriptor();
+            if ((da.data == NULL) != (db.data == NULL) || (da.data && memcmp(da.ptr(0), db.ptr(0), 32))) diff++;
+        }
+        const bool ok = na == nb && diff == 0 && multi > 100;
+        printf("ComputeDistinctiveDescriptors: %s %d points (ref %d), %d with several observers, %d differ\n", ok ? "ok" : "FAILED", na, nb, multi, diff);
+        fails += !ok;
     }
     printf(fails ? "FAILED (%d)\n" : "all ok\n", fails);
     return fails ? 1 : 0;

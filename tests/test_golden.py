@@ -20,7 +20,7 @@ def _fv(node):
 def test_golden_files_present():
     assert len(EXTRACT) == 3 and os.path.exists(os.path.join(GOLD, "matching_q250_db600.npz"))
     for name in ("vocab_k5_L3.npz", "stereo_376x241_f400_l6.npz", "guided_376x241.npz", "rectify_376x241.npz",
-                 "init_search_376x241.npz", "triangulation_376x241.npz", "window_best_376x241.npz"):
+                 "init_search_376x241.npz", "triangulation_376x241.npz", "window_best_376x241.npz", "distinctive_p80.npz"):
         assert os.path.exists(os.path.join(GOLD, name)), name
 
 
@@ -125,6 +125,9 @@ def test_oracle_reproduces_golden_next_rows(oracle):
     assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_dist"])
     bi, bd = oracle.window_best(g["kps"], g["desc"], tuple(g["grid"]), g["queries"], g["qdesc"], g["u_right"], g["inv_level_sigma2"])
     assert np.array_equal(bi, g["gated_idx"]) and np.array_equal(bd, g["gated_dist"])
+    g = _g("distinctive_p80.npz")
+    best, med = oracle.distinctive_descriptors(g["desc"], g["off"])
+    assert np.array_equal(best, g["best"]) and np.array_equal(med, g["median"])
     g = _g("rectify_376x241.npz")
     mx, my = oracle.init_undistort_rectify_map(g["K"], g["D"], g["R"], g["P"], 376, 241)
     assert float(mx.astype(np.float64).sum()) == float(g["map_x_sum"]) and np.array_equal(mx[120], g["map_x_row"])
@@ -177,6 +180,9 @@ def test_hip_reproduces_golden_next_rows():
     assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_dist"])
     bi, bd = guided.WindowBest(ex, g["kps"], g["desc"], tuple(g["grid"]), g["queries"], g["qdesc"], g["u_right"], g["inv_level_sigma2"])
     assert np.array_equal(bi, g["gated_idx"]) and np.array_equal(bd, g["gated_dist"])
+    g = _g("distinctive_p80.npz")
+    best, med = guided.ComputeDistinctiveDescriptors(ex, g["desc"], g["off"])
+    assert np.array_equal(best, g["best"]) and np.array_equal(med, g["median"])
     g = _g("rectify_376x241.npz")
     mx, my = rectify.initUndistortRectifyMap(g["K"], g["D"], g["R"], g["P"], 376, 241)
     assert float(mx.astype(np.float64).sum()) == float(g["map_x_sum"]) and np.array_equal(mx[120], g["map_x_row"])

@@ -352,7 +352,8 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
 def test_cpp_fuse_sim3_and_keyframe_projection_match_host_restatement(tmp_path):
     """ORBmatcher::Fuse (both forms), SearchByProjection(KeyFrame*, Scw, ...) and SearchBySim3 through the drop-in
     classes (tests/native/test_fuse_dropin.cpp): two identical worlds, one through the HIP path and one through the
-    routines restated on the host in that program (src/ORBmatcher.cc:290-403, 825-1326); map states must be equal."""
+    routines restated on the host in that program (src/ORBmatcher.cc:290-403, 825-1326); map states must be equal.
+    Also the batched ComputeDistinctiveDescriptors helper against src/MapPoint.cc:283-349 restated."""
     from orbhip import synth
     exe = os.path.join(ROOT, "tests", "native", "test_fuse_dropin")
     assert os.path.exists(exe), "tests/native/test_fuse_dropin is not built (run __graft_entry__.build())"
@@ -361,4 +362,4 @@ def test_cpp_fuse_sim3_and_keyframe_projection_match_host_restatement(tmp_path):
     (tmp_path / "frame.raw").write_bytes(frame.tobytes())
     r = subprocess.run([exe, str(W), str(H), "1500", str(tmp_path / "frame.raw")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(": ok") == 12 and "all ok" in r.stdout, r.stdout
+    assert r.stdout.count(": ok") == 13 and "all ok" in r.stdout, r.stdout

@@ -191,8 +191,28 @@ def gen_window_best():
     print("window_best", int((bi >= 0).sum()), int((gi >= 0).sum()), int((bd <= 50).sum()), int((gd <= 50).sum()))
 
 
+def gen_distinctive():
+    """MapPoint::ComputeDistinctiveDescriptors over 80 points with 0..14 observations each."""
+    rng = np.random.default_rng(208)
+    n = rng.integers(0, 15, 80)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    desc = np.zeros((off[-1], 32), np.uint8)
+    for p in range(80):
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        for r in range(off[p], off[p + 1]):
+            d = base.copy()
+            for b in rng.integers(0, 256, rng.integers(0, 25)):
+                d[b >> 3] ^= 1 << (b & 7)
+            desc[r] = d
+    best, med = oracle.distinctive_descriptors(desc, off)
+    np.savez_compressed(os.path.join(OUT, "distinctive_p80.npz"), desc=desc, off=off, best=best, median=med)
+    print("distinctive", int((best >= 0).sum()), int(med[best >= 0].mean()))
+
+
 if __name__ == "__main__":
-    if "window_best" in sys.argv[1:]:
+    if "distinctive" in sys.argv[1:]:
+        gen_distinctive()
+    elif "window_best" in sys.argv[1:]:
         gen_window_best()
     elif "triangulation" in sys.argv[1:]:
         gen_triangulation()
@@ -203,3 +223,4 @@ if __name__ == "__main__":
         gen_init_search()
         gen_triangulation()
         gen_window_best()
+        gen_distinctive()

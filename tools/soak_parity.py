@@ -230,6 +230,16 @@ def soak_match(budget, rng):
                 if not np.array_equal(qidx[qoff[i]:qoff[i + 1]], ref):
                     print("MISMATCH area", m, i)
                     sys.exit(1)
+        # MapPoint::ComputeDistinctiveDescriptors over random lists of the same low-entropy descriptors
+        P = int(rng.choice([1, 40, 600]))
+        cnt = rng.integers(0, int(rng.choice([3, 20, 90, 300])) + 1, P)
+        loff = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        ld = mk(int(loff[-1])) if loff[-1] else np.zeros((0, 32), np.uint8)
+        a = guided.ComputeDistinctiveDescriptors(ex, ld, loff)
+        b_ = oracle.distinctive_descriptors(ld, loff)
+        if not (np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1])):
+            print("MISMATCH distinctive", P, int(loff[-1]))
+            sys.exit(1)
         n += 1
     M.close()
     print("soak matcher primitives ok: %d random configurations in %.0f s" % (n, time.time() - t0))

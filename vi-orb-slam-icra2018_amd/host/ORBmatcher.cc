@@ -716,6 +716,49 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
     return nFound;
 }
 
+int ComputeDistinctiveDescriptors(const vector<MapPoint*> &vpMapPoints)
+{
+    // ref: src/MapPoint.cc:283-349, gathered for every point first
+    vector<uint8_t> desc;
+    vector<int32_t> off(1, 0);
+    vector<MapPoint*> pts;
+    for(size_t i=0; i<vpMapPoints.size(); i++)
+    {
+        MapPoint* pMP = vpMapPoints[i];
+        if(!pMP || pMP->isBad())
+            continue;
+        const map<KeyFrame*,size_t> observations = pMP->GetObservations();
+        if(observations.empty())
+            continue;
+        const size_t before = desc.size();
+        for(map<KeyFrame*,size_t>::const_iterator mit=observations.begin(), mend=observations.end(); mit!=mend; mit++)
+        {
+            KeyFrame* pKF = mit->first;
+            if(!pKF->isBad())
+            {
+                const uint8_t *row = pKF->mDescriptors.ptr((int)mit->second);
+                desc.insert(desc.end(), row, row+32);
+            }
+        }
+        if(desc.size()==before)
+            continue;
+        off.push_back((int32_t)(desc.size()/32));
+        pts.push_back(pMP);
+    }
+    const int P = (int)pts.size();
+    if (P == 0) return 0;
+    vector<int32_t> best(P);
+    const int rc = orbhip_distinctive_descriptors(tls.get(), desc.data(), off.data(), P, best.data(), NULL);
+    if (rc != ORBHIP_OK) throw std::runtime_error(std::string("ComputeDistinctiveDescriptors: ") + orbhip_last_error(tls.get()));
+    for (int p = 0; p < P; p++)
+    {
+        cv::Mat d(1, 32, CV_8U);
+        memcpy(d.ptr(0), &desc[(size_t)(off[p]+best[p])*32], 32);
+        pts[p]->SetDescriptor(d);
+    }
+    return P;
+}
+
 int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
                                        vector<pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo)
 {
