@@ -81,6 +81,23 @@ int main(void)
             if (nt <= 0) return 10;
             free(skip);
             free(prev);
+            /* Fuse / SearchBySim3 window search (gate off, mono gate, stereo gate) and ComputeDistinctiveDescriptors */
+            int32_t *bi = (int32_t *)malloc(4 * (size_t)n), *bd = (int32_t *)malloc(4 * (size_t)n);
+            float inv_s2[8];
+            for (int l = 0; l < 8; l++) inv_s2[l] = 1.f / P->mvLevelSigma2[l < P->nlevels ? l : 0];
+            for (int i = 0; i < n; i++) q[i].max_level = k[i].octave;
+            orbo_window_best(k, d, n, NULL, NULL, 0.f, 0.f, invW, invH, q, d, n, bi, bd);
+            int found = 0;
+            for (int i = 0; i < n; i++) found += bi[i] >= 0;
+            orbo_window_best(k, d, n, NULL, inv_s2, 0.f, 0.f, invW, invH, q, d, n, bi, bd);
+            orbo_window_best(k, d, n, ur, inv_s2, 0.f, 0.f, invW, invH, q, d, n, bi, bd);
+            orbo_window_best(k, d, 0, NULL, NULL, 0.f, 0.f, invW, invH, q, d, n, bi, bd);
+            if (found <= 0 || bi[0] != -1 || bd[0] != 256) return 12;
+            int32_t loff[5] = {0, 0, 1, 7, n};
+            orbo_distinctive_descriptors(d, loff, 4, bi, bd);
+            if (bi[0] != -1 || bi[1] != 0 || bd[1] != 0 || bi[2] < 0 || bi[2] >= 6 || bi[3] < 0 || bi[3] >= n - 7) return 13;
+            free(bi);
+            free(bd);
         }
         double K[9] = {300, 0, 200, 0, 300, 150, 0, 0, 1}, Dd[5] = {-0.2, 0.05, 1e-4, -1e-4, 0.0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Pm[9] = {280, 0, 205, 0, 280, 148, 0, 0, 1};
