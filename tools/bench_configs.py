@@ -299,6 +299,34 @@ def run_fuse(W, H, nfeat, B, iters=30):
     return iters * B / dt, iters * npts / dt, fused
 
 
+def run_distinctive(P=100000, nmax=16, iters=30):
+    """MapPoint::ComputeDistinctiveDescriptors for P map points with 1..nmax observations each, resident on the device."""
+    rng = np.random.default_rng(12)
+    cnt = rng.integers(1, nmax + 1, P)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    desc = rng.integers(0, 256, (int(off[-1]), 32), dtype=np.uint8)
+    ex = ORBextractor(500, 1.2, 8, 20, 7, max_w=320, max_h=240)
+    d_desc, d_off = torch.from_numpy(desc).cuda(), torch.from_numpy(off).cuda()
+    d_best = torch.empty(P, dtype=torch.int32, device="cuda")
+    d_med = torch.empty(P, dtype=torch.int32, device="cuda")
+    L = ex._L
+    torch.cuda.synchronize()
+
+    def step():
+        assert L.orbhip_distinctive_descriptors_device(ex.handle, d_desc.data_ptr(), d_off.data_ptr(), P, d_best.data_ptr(),
+                                                       d_med.data_ptr()) == 0
+    for _ in range(3):
+        step()
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    ex.sync()
+    dt = (time.perf_counter() - t0) / iters
+    ex.close()
+    return P / dt, dt * 1e3, float(cnt.mean())
+
+
 def run_big_knn(nq, ndb):
     db = torch.randint(0, 256, (ndb, 32), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, ndb, (nq,), device="cuda")
@@ -348,6 +376,10 @@ def main():
         kfs, pts, fused = run_fuse(640, 480, 1000, 256)
         print("| 1e | fuse | %.0f key frames/s | %.1f M points/s, %.1f fused per key frame |" % (kfs, pts / 1e6, fused))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "distinctive":     # profiling aid
+        pps, ms, avg = run_distinctive()
+        print("| 1f | distinctive | %.1f M points/s | %.3f ms per 100000 points, %.1f observations per point |" % (pps / 1e6, ms, avg))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "rectify":         # profiling aid
         pps, st, good = run_stereo(752, 480, 1200, 128, 1024, 0.11, 47.9, rectify=True)
         print("| 3c | rectify+stereo | %.0f pairs/s | stereo stage %.3f ms per 128 pairs, %.0f depth points per pair |" % (pps, st, good))
@@ -386,6 +418,8 @@ def main():
     print("| 1d: batch through host pointers (incl. PCIe) | 256 frames 640x480, 1000 feat, orbhip_extract_batch from pageable host memory: H2D images, extraction, D2H keypoints + descriptors | %.0f | %.2f ms per 256-frame call, %.1f kp/frame |" % (fps, ms, kp))
     kfs, pts, fused = run_fuse(640, 480, 1000, 256)
     print("| 1e: Fuse window search (LocalMapping::SearchInNeighbors' matcher step) | 256 resident key frames 640x480, 1000 feat: AssignFeaturesToGrid + the points of key frame b-1 projected into key frame b, th 3, levels [l-1, l], chi-square gate (orbhip_window_best_device) | %.0f key frames/s | %.1f M points/s, %.1f fused per key frame |" % (kfs, pts / 1e6, fused))
+    pps, ms, avg = run_distinctive()
+    print("| 1f: ComputeDistinctiveDescriptors (LocalMapping, per point of a key frame) | 100000 resident map points with 1..16 observations (orbhip_distinctive_descriptors_device) | %.1f M points/s | %.3f ms per launch, %.1f observations per point |" % (pps / 1e6, ms, avg))
     lat, t = run_single_frame_latency(640, 480, 1000)
     print("| 1: single frame (host pointers, incl. PCIe) | 640x480, 1000 feat, orbhip_extract per call | %.0f | %.3f ms per call; device stage times pyramid %.3f / keypoints %.3f / descriptors %.3f ms |" % (1e3 / lat, lat, t[0], t[1], t[2]))
 
