@@ -535,15 +535,16 @@ void launch_tri_match(hipStream_t s, const orbhip_keypoint *kps1, const uint8_t 
 }
 
 // ---- MapPoint::ComputeDistinctiveDescriptors (ref: src/MapPoint.cc:283-349) for many points at once ----------------
-// One wave per point: lane i owns row i of the N x N distance matrix (rows beyond 64 in further rounds).  The median the
+// Sixteen lanes per point (most points have 2..16 observers, so four points share a wave): lane i owns row i of the N x N
+// distance matrix (rows beyond 16 in further rounds).  The median the
 // reference reads, sorted_row[(size_t)(0.5 * (N - 1))], is the k-th smallest of the row; distances are integers in
 // 0..256, so it is found by bisection on the value (9 counts of "row entries <= v", the row's distances recomputed from
 // the descriptors each time: they are broadcast reads of a few hundred bytes, cheaper than parking rows in LDS and
-// without a bound on N).  The first row of least median wins: min over median << 20 | row.
+// without a bound on N).  The first row of least median wins: min over median << 20 | row within the 16 lanes.
 __global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__ desc, const int32_t *__restrict__ off, int P,
                                                      int32_t *__restrict__ best, int32_t *__restrict__ bestMedian)
 {
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
     if (p >= P) return;
     const int s = off[p], N = off[p + 1] - s;
     if (N <= 0) {
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__
     const uint4 *D = reinterpret_cast<const uint4 *>(desc) + (size_t)s * 2;
     const int k = (int)(0.5 * (double)(N - 1));
     unsigned key = 0xffffffffu;
-    for (int i0 = 0; i0 < N; i0 += 64) {
+    for (int i0 = 0; i0 < N; i0 += 16) {
         const int i = i0 + lane;
         if (i < N) {
             const uint4 a0 = D[2 * i], a1 = D[2 * i + 1];
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, d));
+    for (int d = 8; d >= 1; d >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, d));
     if (lane == 0) {
         best[p] = (int)(key & 0xfffffu);
         bestMedian[p] = (int)(key >> 20);
@@ -587,5 +588,5 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__
 void launch_distinctive(hipStream_t s, const uint8_t *desc, const int32_t *off, int P, int32_t *best, int32_t *bestMedian)
 {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_distinctive, dim3((P + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, desc, off, P, best, bestMedian);
+    hipLaunchKernelGGL(k_distinctive, dim3((P + 15) / 16, 1, 1), dim3(256, 1, 1), 0, s, desc, off, P, best, bestMedian);
 }
