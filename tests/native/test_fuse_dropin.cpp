@@ -374,7 +374,8 @@ static int count(const vector<MapPoint *> &v) { int n = 0; for (size_t i = 0; i 
 
 int main(int argc, char **argv)
 {
-    if (argc < 5) { fprintf(stderr, "usage: %s w h nfeatures frame.raw\n", argv[0]); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: %s w h nfeatures frame.raw [seed]\n", argv[0]); return 2; }
+    const unsigned long long seed0 = argc > 5 ? strtoull(argv[5], NULL, 10) : 0ull;
     Shared S;
     S.w = atoi(argv[1]); S.h = atoi(argv[2]);
     const int nf = atoi(argv[3]);
@@ -398,7 +399,7 @@ int main(int argc, char **argv)
 
     int fails = 0;
     for (int round = 0; round < 3; round++) {
-        const unsigned long long seed = 1234567ull + 7919ull * round;
+        const unsigned long long seed = 1234567ull + 7919ull * round + 104729ull * seed0;
         // ---- Fuse(pKF, vpMapPoints, th): LocalMapping::SearchInNeighbors ----
         {
             World A, B;
@@ -473,7 +474,7 @@ int main(int argc, char **argv)
     // ---- ComputeDistinctiveDescriptors over the points of a fused world (LocalMapping::SearchInNeighbors' last loop) ----
     {
         World A, B;
-        buildWorld(A, S, 424242ull); buildWorld(B, S, 424242ull);
+        buildWorld(A, S, 424242ull + seed0); buildWorld(B, S, 424242ull + seed0);
         ORBmatcher matcher;
         matcher.Fuse(&A.kf[1], A.cand, 3.f);                     // gives many points two or three observers
         refFuse(&B.kf[1], B.cand, 3.f);
