@@ -203,7 +203,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
-                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps};
+                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -596,19 +596,29 @@ extern "C" int orbhip_hamming_knn2_seq_device(orbhip_ctx *c, const void *d_desc,
 }
 
 // Bump allocator over one temporary device block (host-pointer matching entry points).
+// Device staging for the host-pointer entry points: one grow-only block per context.  Calls on a context are serialised
+// on its stream and every such entry point synchronises before it returns, so the block is free again at the next call.
 struct TmpDev {
     orbhip_ctx *c;
     uint8_t *base = nullptr;
     size_t used = 0, cap = 0;
     explicit TmpDev(orbhip_ctx *ctx) : c(ctx) {}
-    ~TmpDev()
-    {
-        if (base) (void)hipFree(base);
-    }
     int reserve(size_t bytes)
     {
-        HIPCHK(c, hipMalloc((void **)&base, bytes + 4096));
-        cap = bytes + 4096;
+        bytes += 4096;
+        if (bytes > c->d_tmp_bytes || !c->d_tmp) {
+            if (c->d_tmp) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, hipFree(c->d_tmp));
+            }
+            c->d_tmp = nullptr;
+            c->d_tmp_bytes = 0;
+            const size_t want = bytes + bytes / 2;
+            HIPCHK(c, hipMalloc(&c->d_tmp, want));
+            c->d_tmp_bytes = want;
+        }
+        base = (uint8_t *)c->d_tmp;
+        cap = c->d_tmp_bytes;
         return ORBHIP_OK;
     }
     void *take(size_t bytes)
@@ -1238,29 +1248,37 @@ extern "C" int orbhip_window_best(orbhip_ctx *c, const orbhip_keypoint *kps, con
     TmpDev T(c);
     int rc;
     if ((rc = T.reserve((size_t)n * (28 + 32 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (64 + 8) + 16384))) return rc;
+    // one staging block, one copy in and one copy out: a call moves ~100 KB and is latency-bound
+    uint8_t *d0 = (uint8_t *)T.take(0);
     orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)n * 28);
     uint8_t *dd = (uint8_t *)T.take((size_t)n * 32);
     float *dur = u_right ? (float *)T.take((size_t)n * 4) : nullptr;
-    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
-            *didx = (int32_t *)T.take((size_t)n * 4);
+    int32_t *dc = (int32_t *)T.take(16);
     orbhip_proj_query *dq = (orbhip_proj_query *)T.take((size_t)nq * sizeof(orbhip_proj_query));
     uint8_t *dqd = (uint8_t *)T.take((size_t)nq * 32);
-    int32_t *dbi = (int32_t *)T.take((size_t)nq * 4), *dbd = (int32_t *)T.take((size_t)nq * 4);
+    const size_t span = (size_t)((uint8_t *)dqd + (size_t)nq * 32 - d0);
+    int32_t *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4), *didx = (int32_t *)T.take((size_t)n * 4);
+    int32_t *dout = (int32_t *)T.take((size_t)nq * 8);
+    int32_t *dbi = dout, *dbd = dout + nq;
+    std::vector<uint8_t> h(span);
     const int32_t cnts[2] = {n, nq};
+    memcpy(&h[(uint8_t *)dk - d0], kps, (size_t)n * 28);
+    memcpy(&h[dd - d0], desc, (size_t)n * 32);
+    if (dur) memcpy(&h[(uint8_t *)dur - d0], u_right, (size_t)n * 4);
+    memcpy(&h[(uint8_t *)dc - d0], cnts, 8);
+    memcpy(&h[(uint8_t *)dq - d0], queries, (size_t)nq * sizeof(orbhip_proj_query));
+    memcpy(&h[dqd - d0], qdesc, (size_t)nq * 32);
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(dk, kps, (size_t)n * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    if (dur) HIPCHK(c, hipMemcpyAsync(dur, u_right, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dc, cnts, 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d0, h.data(), span, hipMemcpyHostToDevice, s));
     if ((rc = orbhip_grid_build_device(c, dk, dc, n, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
     if ((rc = orbhip_window_best_device(c, dk, dd, n, 1, dur, inv_level_sigma2, nlevels, min_x, min_y, inv_w, inv_h, doff, didx,
                                         dq, dqd, dc + 1, nq, dbi, dbd)))
         return rc;
-    HIPCHK(c, hipMemcpyAsync(best_idx, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(best_dist, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> out((size_t)nq * 2);
+    HIPCHK(c, hipMemcpyAsync(out.data(), dout, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    memcpy(best_idx, out.data(), (size_t)nq * 4);
+    memcpy(best_dist, out.data() + nq, (size_t)nq * 4);
     return ORBHIP_OK;
 }
 

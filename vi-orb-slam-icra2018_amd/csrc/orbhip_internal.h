@@ -158,6 +158,9 @@ struct orbhip_ctx {
     // matching scratch
     void *d_match = nullptr;
     size_t d_match_bytes = 0;
+    // staging block of the host-pointer entry points (grow-only; they used to hipMalloc / hipFree per call)
+    void *d_tmp = nullptr;
+    size_t d_tmp_bytes = 0;
 
     // timing
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
