@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Cross-check of the oracle's OpenCV-side kernels against independent implementations.
+
+The reference calls OpenCV 2.4 for resize / FAST / GaussianBlur / fastAtan2 / remap / undistortPoints
+(src/ORBextractor.cc:1141, 811, 816, 1104, 105); OpenCV is in neither image, so oracle/orb_oracle.c restates those
+kernels.  This tool compares the restatement with whatever independent implementation the interpreter it runs under
+can import, and writes a diff table (markdown) to stdout or --out:
+
+  * cv2 (any version): resize INTER_LINEAR, FAST(9_16, nonmax) keypoints + responses, GaussianBlur 7x7 sigma 2,
+    fastAtan2 (cv2.phase, degrees), remap INTER_LINEAR, undistortPoints.  GaussianBlur is EXPECTED to differ on
+    OpenCV >= 3.4.1 (different fixed-point scheme); it is recorded, not chased.
+  * scikit-image (0.18.3 ships with /opt/conda/bin/python3.9 in this image, on the build box and on the GPU box):
+    an independent FAST implementation (skimage.feature.corner_fast) pins the segment test -- the 16-pixel circle,
+    "n = 9 contiguous", strict inequalities -- and through it the SCORE ("largest threshold at which the pixel is
+    still a corner"); skimage's intensity-centroid orientation pins the disc (umax) and the moments of IC_Angle up to
+    fastAtan2's documented 0.3 degree accuracy; skimage's copy of the rBRIEF test pattern pins table T0; its float
+    bilinear resize / Gaussian check the sampling convention and the kernel taps to within the fixed-point error.
+  * numpy only: fastAtan2 against atan2 over a dense sweep (OpenCV documents ~0.3 degrees accuracy).
+
+Nothing from /root/reference is read.  Run:  python3 tools/crosscheck_opencv.py [--out FILE]
+                                         /opt/conda/bin/python3.9 tools/crosscheck_opencv.py [--out FILE]
+Exit code 0 = every EXACT row matched (tolerance rows are reported with their measured maximum).
+"""
+import argparse
+import os
+import sys
+import warnings
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "vi-orb-slam-icra2018_amd"))
+
+import numpy as np  # noqa: E402
+import orb_oracle_py as oracle  # noqa: E402
+from orbhip import synth  # noqa: E402
+
+ROWS = []
+FAILED = []
+
+
+def row(name, against, kind, result, ok=True):
+    ROWS.append((name, against, kind, result, "ok" if ok else "MISMATCH"))
+    if not ok:
+        FAILED.append(name)
+
+
+def fixture_images():
+    """The committed-fixture geometry (tests/golden is made from the same generator and seeds)."""
+    a = synth.make_frames(11, 320, 240, 1)[0]
+    b = synth.make_frames(12, 200, 160, 1)[0]
+    rng = np.random.default_rng(5)
+    c = rng.integers(0, 256, (96, 128), dtype=np.uint8)            # white noise: ties and dense corners
+    return [("synth320", a), ("synth200", b), ("noise128", c)]
+
+
+def oracle_score_map(img, t):
+    """Oracle FAST score of every interior pixel that is a corner at threshold t (0 elsewhere), without NMS."""
+    h, w = img.shape
+    out = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            out[y, x] = oracle.fast_corner_score(img, x, y, t)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def check_numpy():
+    # fastAtan2 vs atan2: OpenCV documents "accuracy is about 0.3 degrees"
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    pts = [(y, x) for y in (-300, -7, -1, 0, 1, 5, 300) for x in (-300, -9, -1, 0, 1, 4, 300)]
+    pts += [tuple(v) for v in rng.integers(-40000, 40000, (20000, 2))]
+    for y, x in pts:
+        got = oracle.fast_atan2(y, x)
+        want = np.degrees(np.arctan2(float(y), float(x))) % 360.0 if (x or y) else 0.0
+        d = abs(got - want)
+        d = min(d, 360.0 - d)
+        worst = max(worst, d)
+    row("fastAtan2 (orbo_fast_atan2)", "numpy arctan2, 20049 points", "tolerance 0.3 deg (OpenCV's documented accuracy)",
+        "max |diff| = %.4f deg" % worst, worst <= 0.3)
+
+
+# ------------------------------------------------------------------------------------------------
+def check_skimage():
+    import skimage
+    from skimage.feature import corner_fast, corner_orientations
+    from skimage.feature.orb import OFAST_MASK
+    ver = "scikit-image %s" % skimage.__version__
+
+    # 1. FAST-9/16 detection set at the two thresholds of the path and the whole score map by its definition
+    for name, img in fixture_images():
+        f = img.astype(np.float64)                     # integer-valued doubles: skimage's comparisons are exact
+        h, w = img.shape
+        for t in (7, 20):
+            resp = corner_fast(f, 9, float(t))
+            theirs = resp[3:h - 3, 3:w - 3] > 0
+            mine = oracle_score_map(img, t)[3:h - 3, 3:w - 3] >= t
+            nd = int((theirs != mine).sum())
+            row("FAST-9/16 corner set, t=%d, %s" % (t, name), ver + " corner_fast(n=9)", "exact",
+                "%d corners, %d differing pixels" % (int(mine.sum()), nd), nd == 0)
+    # the score = largest threshold at which the pixel is still a corner (fast_score.cpp's definition): for every t the
+    # detection set of skimage must be {score >= t}
+    name, img = fixture_images()[1]
+    small = img[20:100, 30:130]
+    f = small.astype(np.float64)
+    h, w = small.shape
+    sc = oracle_score_map(small, 1)[3:h - 3, 3:w - 3]
+    bad = 0
+    tmax = int(sc.max()) + 2
+    for t in range(1, tmax + 1):
+        theirs = corner_fast(f, 9, float(t))[3:h - 3, 3:w - 3] > 0
+        bad += int((theirs != (sc >= t)).sum())
+    row("FAST score map (cornerScore<16>), %s crop %dx%d" % (name, w, h), ver + " corner_fast at every t in 1..%d" % tmax,
+        "exact: {score >= t} = detection set at t", "%d differing (pixel, t) pairs, max score %d" % (bad, int(sc.max())), bad == 0)
+
+    # 2. IC_Angle: the disc and the moments, to fastAtan2's accuracy
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    mask_rows = [int(r.sum()) for r in OFAST_MASK]
+    disc_ok = mask_rows == [2 * umax[abs(v)] + 1 for v in range(-15, 16)]
+    row("IC_Angle disc (umax table, 749 px)", ver + " OFAST_MASK", "exact", "row widths %s" % ("equal" if disc_ok else "differ"), disc_ok)
+    name, img = fixture_images()[0]
+    rng = np.random.default_rng(2)
+    pts = np.stack([rng.integers(20, img.shape[0] - 20, 400), rng.integers(20, img.shape[1] - 20, 400)], 1)
+    theirs = np.degrees(corner_orientations(img.astype(np.float64), pts, OFAST_MASK)) % 360.0
+    worst = 0.0
+    for (r, c), th in zip(pts, theirs):
+        got = oracle.ic_angle(img, int(c), int(r), umax)
+        d = abs(got - th)
+        worst = max(worst, min(d, 360.0 - d))
+    row("IC_Angle orientation, 400 points of %s" % name, ver + " corner_orientations (exact atan2)",
+        "tolerance 0.3 deg (fastAtan2)", "max |diff| = %.4f deg" % worst, worst <= 0.3)
+
+    # 3. rBRIEF pattern (bit_pattern_31_): skimage ships the same 256 test pairs as (row, col) offsets
+    pos = np.loadtxt(os.path.join(os.path.dirname(skimage.__file__), "feature", "orb_descriptor_positions.txt"))
+    mine = oracle_pattern()
+    theirs = np.rint(pos).astype(np.int32)          # skimage keeps OpenCV's column order (x0, y0, x1, y1)
+    same = mine.shape == theirs.shape and bool((mine == theirs).all())
+    row("rBRIEF pattern table T0 (256 pairs)", ver + " orb_descriptor_positions.txt", "exact", "equal" if same else "differ", same)
+
+    # 4. resize: sampling convention (float bilinear, no anti-aliasing) -- fixed point differs by at most 1 level
+    from skimage.transform import resize as sk_resize
+    for name, img in fixture_images()[:2]:
+        h, w = img.shape
+        dw, dh = int(round(w / 1.2)), int(round(h / 1.2))
+        mine = oracle.resize_linear(img, dw, dh).astype(np.int32)
+        theirs = sk_resize(img.astype(np.float64), (dh, dw), order=1, mode="edge", anti_aliasing=False, preserve_range=True)
+        d = np.abs(mine - np.rint(theirs)).max()
+        dfloat = np.abs(mine - theirs).max()
+        row("resize INTER_LINEAR %s -> %dx%d" % (name, dw, dh), ver + " transform.resize(order=1, no anti-aliasing), float",
+            "tolerance 1 level (11-bit fixed point)", "max |diff| = %d (vs unrounded float %.3f)" % (int(d), dfloat), d <= 1)
+
+    # 5. Gaussian 7x7 sigma 2, reflect-101.  The 8-bit taps are getGaussianKernel's floats rounded at 8 fractional bits
+    #    (they sum to 257, not renormalised); scipy's correlate1d supplies an independent separable filter and an independent
+    #    mirror (= BORDER_REFLECT_101) border.  With the same taps the only freedom left is the final rounding: <= 0.5 level.
+    from scipy.ndimage import correlate1d
+    g = np.exp(-(np.arange(7) - 3.0) ** 2 / 8.0)
+    g /= g.sum()
+    taps = np.rint(g * 256.0)
+    row("GaussianBlur taps: round(getGaussianKernel(7, 2) * 256)", "numpy", "exact", "%s, sum %d" % (taps.astype(int).tolist(), int(taps.sum())),
+        taps.astype(int).tolist() == [18, 34, 49, 55, 49, 34, 18])
+    for name, img in fixture_images()[:2]:
+        mine = oracle.gaussian_blur7(img).astype(np.float64)
+        fx = correlate1d(correlate1d(img.astype(np.float64), taps, 1, mode="mirror"), taps, 0, mode="mirror") / 65536.0
+        d = np.abs(mine - np.minimum(fx, 255.0)).max()
+        ideal = correlate1d(correlate1d(img.astype(np.float64), g, 1, mode="mirror"), g, 0, mode="mirror")
+        row("GaussianBlur 7x7 sigma 2 %s" % name, "scipy correlate1d with the 8-bit taps, mode mirror (= REFLECT_101)",
+            "tolerance 0.5 level (final rounding only)", "max |diff| = %.4f (vs the float Gaussian: %.3f)"
+            % (d, np.abs(mine - ideal).max()), d <= 0.5 + 1e-9)
+
+
+def oracle_pattern():
+    """The 256 x (x0, y0, x1, y1) test pairs the oracle uses (oracle/orb_pattern_data.h)."""
+    import re
+    txt = open(os.path.join(ROOT, "oracle", "orb_pattern_data.h")).read()
+    body = txt[txt.index("{", txt.index("[")):]
+    vals = [int(v) for v in re.findall(r"-?\d+", body[:body.index("}")])]
+    return np.array(vals[:1024], np.int32).reshape(256, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+def check_cv2():
+    import cv2
+    ver = "cv2 %s" % cv2.__version__
+    for name, img in fixture_images():
+        h, w = img.shape
+        dw, dh = int(round(w / 1.2)), int(round(h / 1.2))
+        mine = oracle.resize_linear(img, dw, dh)
+        theirs = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR)
+        nd = int((mine != theirs).sum())
+        row("resize INTER_LINEAR %s" % name, ver, "exact", "%d differing pixels of %d" % (nd, mine.size), nd == 0)
+        for t in (7, 20):
+            det = cv2.FastFeatureDetector_create(threshold=t, nonmaxSuppression=True, type=cv2.FAST_FEATURE_DETECTOR_TYPE_9_16)
+            kps = det.detect(img, None)
+            theirs = sorted((int(k.pt[1]), int(k.pt[0]), int(k.response)) for k in kps)
+            o = oracle.fast9_16(img, t)
+            mine = sorted((int(y), int(x), int(s)) for x, y, s in zip(o["x"], o["y"], o["score"]))
+            row("FAST(9_16, nonmax) t=%d %s" % (t, name), ver, "exact (x, y, response)", "%d vs %d keypoints, %d in common"
+                % (len(mine), len(theirs), len(set(mine) & set(theirs))), mine == theirs)
+        mine = oracle.gaussian_blur7(img)
+        theirs = cv2.GaussianBlur(img, (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
+        nd = int((mine != theirs).sum())
+        row("GaussianBlur 7x7 sigma 2 %s" % name, ver, "exact on OpenCV 2.4 / < 3.4.1; expected to differ later (recorded only)",
+            "%d differing pixels, max |diff| %d" % (nd, int(np.abs(mine.astype(int) - theirs.astype(int)).max())), True)
+    rng = np.random.default_rng(3)
+    xy = rng.integers(-5000, 5000, (4000, 2)).astype(np.float32)
+    theirs = cv2.phase(xy[:, 0], xy[:, 1], angleInDegrees=True).ravel()
+    mine = np.array([oracle.fast_atan2(float(y), float(x)) for x, y in xy], np.float32)
+    nd = int((mine != theirs).sum())
+    row("fastAtan2 (cv2.phase, degrees)", ver, "exact on builds without the AVX2/NEON polynomial variants",
+        "%d of 4000 differ, max |diff| %.6f" % (nd, float(np.abs(mine - theirs).max())), True)
+    # remap / undistortPoints
+    K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]], np.float64)
+    D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float64)
+    pts = rng.uniform(0, 700, (500, 2)).astype(np.float32)
+    theirs = cv2.undistortPoints(pts.reshape(-1, 1, 2), K, D, None, K).reshape(-1, 2)
+    mine = oracle.undistort_points(pts, K.astype(np.float32), D.astype(np.float32), K.astype(np.float32))
+    d = float(np.abs(mine - theirs).max())
+    row("undistortPoints (EuRoC cam0)", ver, "exact on OpenCV 2.4 (5 fixed iterations); later versions iterate to a tolerance",
+        "max |diff| %.6f px" % d, True)
+    name, img = fixture_images()[0]
+    h, w = img.shape
+    mx = (np.tile(np.arange(w, dtype=np.float32), (h, 1)) * 0.97 + 3.3).astype(np.float32)
+    my = (np.tile(np.arange(h, dtype=np.float32)[:, None], (1, w)) * 1.02 - 2.6).astype(np.float32)
+    theirs = cv2.remap(img, mx, my, cv2.INTER_LINEAR)
+    mine = oracle.remap_linear(img, mx, my)
+    nd = int((mine != theirs).sum())
+    row("remap INTER_LINEAR %s" % name, ver, "exact", "%d differing pixels of %d" % (nd, mine.size), nd == 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    oracle.build()
+    have = []
+    check_numpy()
+    try:
+        import cv2  # noqa: F401
+        have.append("cv2")
+        check_cv2()
+    except ImportError:
+        row("cv2", "-", "-", "not importable under %s: the OpenCV rows (resize / FAST responses / GaussianBlur / remap / "
+            "undistortPoints bit for bit) cannot be produced on this image" % sys.executable, True)
+    try:
+        import skimage  # noqa: F401
+        have.append("skimage")
+        check_skimage()
+    except ImportError:
+        row("scikit-image", "-", "-", "not importable under %s (try /opt/conda/bin/python3.9)" % sys.executable, True)
+    lines = ["# Oracle cross-check against independent implementations", "",
+             "Interpreter: `%s` (numpy %s); libraries found: %s." % (sys.executable, np.__version__, ", ".join(have) or "none"),
+             "Produced by `tools/crosscheck_opencv.py`; nothing from the reference tree is read.", "",
+             "| oracle kernel | compared with | bar | result | status |", "|---|---|---|---|---|"]
+    lines += ["| %s | %s | %s | %s | %s |" % r for r in ROWS]
+    text = "\n".join(lines) + "\n"
+    if args.out:
+        with open(args.out, "w") as fh:
+            fh.write(text)
+    print(text)
+    if FAILED:
+        print("MISMATCH in: " + "; ".join(FAILED), file=sys.stderr)
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
