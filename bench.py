@@ -46,34 +46,79 @@ def fast_algorithmic_bytes(w, h, nlevels, level_size):
     return tot
 
 
-def cpu_baseline(frames, nsample, match, blob):
-    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(frames, nsample, match, blob, keep=0):
+    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload.  The outputs of the first
+    `keep` frames (keypoints, descriptors, SearchByBoW / knn2 results against the previous frame) are returned too:
+    main() compares the GPU's outputs for the same frames with them (`verified_frames`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orb_oracle_py as oracle
     ex = oracle.Extractor(NFEAT, 1.2, 8, 20, 7)
     voc = oracle.Vocabulary(blob) if match in ("bow", "both") else None
     ex(frames[0])  # warm up (page in)
+    kept = []
     t0 = time.perf_counter()
     prev = None
     for i in range(nsample):
         k, d = ex(frames[i % len(frames)])
         cur = {"k": k, "d": d}
+        rec = {"k": k, "d": d} if i < keep else None
         if voc is not None:
             w, wt, nid = voc.transform(d, LEVELSUP)
             cur["fv"] = oracle.feature_vector(nid, wt)
         if prev is not None:
             if voc is not None:
-                oracle.search_by_bow(prev["d"], np.ones(len(prev["d"]), np.uint8), prev["k"]["angle"], prev["fv"], d,
-                                     None, k["angle"], cur["fv"], th=50, th_mode=0, nnratio=NNRATIO, check_ori=True)
+                r = oracle.search_by_bow(prev["d"], np.ones(len(prev["d"]), np.uint8), prev["k"]["angle"], prev["fv"], d,
+                                         None, k["angle"], cur["fv"], th=50, th_mode=0, nnratio=NNRATIO, check_ori=True)
+                if rec is not None:
+                    rec["bow"] = r
             if match in ("brute", "both"):
-                oracle.knn2(d, prev["d"])
+                r = oracle.knn2(d, prev["d"])
+                if rec is not None:
+                    rec["knn2"] = r
+        if rec is not None:
+            kept.append(rec)
         prev = cur
     dt = time.perf_counter() - t0
     what = {"bow": "vocabulary transform + SearchByBoW", "brute": "brute-force knn2",
             "both": "vocabulary transform + SearchByBoW + brute-force knn2"}[match]
-    return {"value": round(nsample / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames %dx%d, %d features, extract + %s vs previous frame, oracle/liborb_oracle.so "
-                      "(gcc -O3 -march=x86-64-v3), %.1f s" % (nsample, W, H, NFEAT, what, dt)}
+    res = {"value": round(nsample / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames %dx%d, %d features, extract + %s vs previous frame, oracle/liborb_oracle.so "
+                     "(gcc -O3 -march=x86-64-v3), %.1f s" % (nsample, W, H, NFEAT, what, dt)}
+    return (res, kept) if keep else res
+
+
+def verify_against_oracle(kept, bufs, cap, match):
+    """GPU outputs of the first len(kept) frames of the timed batch against the oracle's, bit for bit: the 28-byte
+    keypoint records, the descriptors, SearchByBoW's match12 / match21 / count and the brute-force triples.
+    Returns the number of frames verified; raises SystemExit(3) on the first difference."""
+    n = len(kept)
+    cnt = bufs["cnt"][:n].cpu().numpy()
+    kps = bufs["kps"][:n].cpu().numpy()
+    desc = bufs["desc"][:n].cpu().numpy()
+    get = {name: bufs[name][:n].cpu().numpy() for name in ("m12", "m21", "nm", "bi", "bd", "sd") if name in bufs}
+
+    def bad(what, b):
+        print("bench.py: GPU output differs from the oracle: %s of frame %d" % (what, b), file=sys.stderr)
+        raise SystemExit(3)
+    for b, rec in enumerate(kept):
+        k, d = rec["k"], rec["d"]
+        if cnt[b] != len(k):
+            bad("keypoint count (%d vs %d)" % (cnt[b], len(k)), b)
+        if kps[b, :len(k)].tobytes() != k.tobytes():
+            bad("keypoints", b)
+        if not np.array_equal(desc[b, :len(k)], d):
+            bad("descriptors", b)
+        if "bow" in rec:
+            nm, m12, m21 = rec["bow"]
+            if int(get["nm"][b]) != nm or not np.array_equal(get["m12"][b, :len(m12)], m12) or \
+                    not np.array_equal(get["m21"][b, :len(m21)], m21):
+                bad("SearchByBoW matches", b)
+        if "knn2" in rec:
+            bi, bd, sd = rec["knn2"]
+            if not (np.array_equal(get["bi"][b, :len(bi)], bi) and np.array_equal(get["bd"][b, :len(bd)], bd)
+                    and np.array_equal(get["sd"][b, :len(sd)], sd)):
+                bad("brute-force best / second", b)
+    return n
 
 
 def cpu_worker(path, nsample, match):
@@ -181,19 +226,49 @@ def main():
                     "contexts (0 = skip); supplementary, never `value`")
     ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--verify", type=int, default=8, help="frames of the timed batch whose GPU outputs are compared with "
+                    "the oracle outside the timed region (0 = skip); a difference ends the run with exit code 3")
     args = ap.parse_args()
     if args.cpu_worker:
         cpu_worker(args.cpu_worker, args.cpu_frames, args.match)
         return
 
-    import torch
+    # ---- one process per GPU ----
+    # Under a launcher (torch.distributed.run sets RANK / WORLD_SIZE) this process is one rank.  Without one,
+    # `--gpus N` starts the N ranks itself as fresh child processes -- before this process imports torch or touches
+    # the GPU (a process that has initialised HIP must not be replaced or forked into another program on this pool).
+    from orbhip import distributed as D
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            rc, out0 = D.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+            sys.stdout.write(out0)
+            sys.stdout.flush()
+            raise SystemExit(rc)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    assert world == args.gpus
+
+    if os.environ.get("ORBHIP_BENCH_LAUNCH_SELFTEST"):
+        # CPU test of the launcher / rank plumbing (tests/test_bench_contract.py): gloo, no GPU, no product code
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(t.item()), "gpus_arg": args.gpus}), flush=True)
+        return
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("ORBHIP_BENCH_FORCE_DIST"):   # the env var exercises the N>1 code path on one GPU
@@ -202,7 +277,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from orbhip import distributed as D, synth
+    from orbhip import synth
     from orbhip.extractor import ORBextractor
     from orbhip.vocabulary import ORBVocabulary
 
@@ -312,7 +387,7 @@ def main():
         traffic, traffic_src = committed_traffic(B, NC)
         out = {
             "metric": "ORB extract+match frames/sec @640x480/1000 feat",
-            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
@@ -336,10 +411,21 @@ def main():
         }
         if world == 1 and args.pipelined > 1 and B % args.pipelined == 0:
             out["pipelined"] = pipelined_throughput(args, d_img, blob if use_bow else None, local_rank, cap)
+        # the GPU's outputs for the first frames of the timed batch against the oracle, outside the timed region
+        nver = max(0, min(args.verify, Bc))
+        kept = []
         if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(uniq, args.cpu_frames, args.match, blob)
+            nver = min(nver, args.cpu_frames)
+            res = cpu_baseline(uniq, args.cpu_frames, args.match, blob, keep=nver)
+            out["cpu_baseline"], kept = res if nver else (res, [])
             out["speedup_vs_cpu_1core"] = round(fps / out["cpu_baseline"]["value"], 1)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(uniq, args.cpu_frames, args.match, blob)
+        elif nver:
+            kept = cpu_baseline(uniq, nver, args.match, blob, keep=nver)[1]
+        out["verified_frames"] = verify_against_oracle(kept, ctxs[0][1], cap, args.match) if kept else 0
+        out["verified_against"] = "oracle/liborb_oracle.so: keypoints (28-byte records), descriptors, " + \
+            {"bow": "SearchByBoW match12/match21/count", "brute": "brute-force best/second",
+             "both": "SearchByBoW and brute-force results"}[args.match] + " of frames 0..n-1 of the timed batch, bit for bit"
     for ex, _ in ctxs:
         ex.close()
     if dist is not None:

@@ -383,15 +383,36 @@ int orbhip_remap_device(orbhip_ctx *ctx, const void *d_src, int B, int src_w, in
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */
 int orbhip_get_stage_times(orbhip_ctx *ctx, float ms[6]);
 
-/* ---- multi-GPU (one process per GPU) ---- */
+/* ---- multi-GPU (one process per GPU) ----
+ * The reference is a single process (no distributed back end); these entry points are what a
+ * multi-GPU host adds around the unchanged per-frame path: frames or whole sequences are sharded over ranks with no
+ * per-frame collective, the vocabulary travels once, and database-sharded brute force has one exchange step. */
 /* RCCL communicator over the ranks of one node.  uid: 128-byte ncclUniqueId produced by
- * orbhip_comm_unique_id() on rank 0 and distributed by the caller (file, env, torch store). */
+ * orbhip_comm_unique_id() on rank 0 and distributed by the caller (file, env, torch store).  nranks = 1 is valid (the
+ * collectives then run on a one-rank communicator).  The communicator is destroyed by orbhip_comm_destroy or
+ * orbhip_destroy. */
 int orbhip_comm_unique_id(uint8_t uid[128]);
 int orbhip_comm_init(orbhip_ctx *ctx, int rank, int nranks, const uint8_t uid[128]);
+int orbhip_comm_destroy(orbhip_ctx *ctx);
 /* Broadcast of the ORB vocabulary blob (binary format of
  * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1727-1751, loaded at src/System.cc:331-346)
- * from `root` to every rank over xGMI.  d_buf: device pointer, nbytes on every rank. */
+ * from `root` to every rank over xGMI.  d_buf: device pointer, nbytes on every rank.  Asynchronous on the context
+ * stream. */
 int orbhip_bcast_blob_device(orbhip_ctx *ctx, void *d_buf, size_t nbytes, int root);
+/* Database-sharded brute force (the bookkeeping of src/ORBmatcher.cc:205-226 over a database
+ * split by rows): every rank runs orbhip_hamming_knn2_device of the same nq queries against ITS rows (shard_offset =
+ * global index of its first row; ranks hold increasing row ranges), then this call all-gathers the nq x 3 int32 results
+ * (ncclAllGather, 12 bytes per query per rank) and min-merges them on the device with the reference's tie rule (strict
+ * '<': lowest global row wins).  Outputs as orbhip_hamming_knn2_device, global indices, identical on every rank.
+ * Asynchronous on the context stream.  Without a communicator (nranks = 1) it reduces to the index shift. */
+int orbhip_knn2_allgather_merge_device(orbhip_ctx *ctx, const void *d_best_idx_local, const void *d_best_d_local,
+                                       const void *d_second_d_local, int nq, int shard_offset, void *d_best_idx,
+                                       void *d_best_d, void *d_second_d);
+/* The merge alone, for hosts that exchange through their own collective (torch.distributed in bench.py / the tests):
+ * d_parts = nshards consecutive parts of 3 * nq + 1 int32 each: best_idx[nq] | best_d[nq] | second_d[nq] | shard_offset,
+ * in order of increasing shard_offset. */
+int orbhip_knn2_merge_device(orbhip_ctx *ctx, const void *d_parts, int nshards, int nq, void *d_best_idx, void *d_best_d,
+                             void *d_second_d);
 
 #ifdef __cplusplus
 }

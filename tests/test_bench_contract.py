@@ -30,3 +30,58 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 1 and c["unit"] == "frames/s" and c["sample"]
     assert d["cpu_baseline_all_cores"]["cores"] >= 1
+    assert d["verified_frames"] == 8                             # GPU outputs of the first frames equal the oracle's
+
+
+def _bench(args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, env=e)
+
+
+def test_gpus_n_starts_n_ranks_itself_cpu_gloo():
+    """`bench.py --gpus 2` without a launcher starts two fresh rank processes (RANK / WORLD_SIZE / MASTER_* set,
+    127.0.0.1 rendezvous) before touching any GPU; checked here on CPU with the launcher self-test (gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ORBHIP_BENCH_LAUNCH_SELFTEST"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert d == {"selftest": "launcher", "n_gpus": 2, "ranks_seen": 2, "gpus_arg": 2}
+
+
+def test_gpus_must_match_the_launchers_world_size():
+    out = _bench(["--gpus", "4"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "ORBHIP_BENCH_LAUNCH_SELFTEST": "1"},
+                 timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_launch_ranks_reports_a_failing_rank():
+    from orbhip import distributed as D
+    rc, out = D.launch_ranks([sys.executable, "-c", "import os,sys; print('r'+os.environ['RANK']); sys.exit(int(os.environ['RANK']))"], 2,
+                             timeout=60)
+    assert rc == 1 and out.strip() == "r0"
+    env = D.rank_env(1, 2, 12345, base={})
+    assert env["RANK"] == "1" and env["WORLD_SIZE"] == "2" and env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "12345"
+
+
+@pytest.mark.gpu
+def test_bench_distributed_code_path_on_one_gpu():
+    """ORBHIP_BENCH_FORCE_DIST=1: process group (nccl = RCCL, world 1), vocabulary broadcast into a device buffer and
+    the vocabulary load from that buffer -- the N > 1 code path of bench.py on the one GPU the box has."""
+    out = _bench(["--steps", "2", "--warmup", "1", "--batch", "64", "--cpu-frames", "0", "--pipelined", "0"],
+                 env={"ORBHIP_BENCH_FORCE_DIST": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 1000 and d["verified_frames"] == 8 and d["bow_matches_per_frame"] > 50
+
+
+@pytest.mark.gpu
+def test_bench_brute_match_is_verified_too():
+    out = _bench(["--steps", "1", "--warmup", "1", "--batch", "16", "--cpu-frames", "0", "--pipelined", "0", "--match", "both",
+                  "--verify", "6"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert d["verified_frames"] == 6

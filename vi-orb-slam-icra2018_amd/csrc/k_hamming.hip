@@ -299,6 +299,52 @@ void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, 
                        best_idx, best_d, second_d);
 }
 
+// Min-merge of per-shard brute-force results (database rows sharded over ranks): parts[s] =
+// best_idx[nq] | best_d[nq] | second_d[nq] | shard_offset, indices local to the shard.  Shards are visited in order of
+// increasing rank = increasing database rows, so strict '<' keeps the lowest global index on ties, as one pass over the
+// whole database would (src/ORBmatcher.cc:205-226 bookkeeping).
+__global__ __launch_bounds__(256) void k_knn2_merge(const int32_t *__restrict__ parts, int nshards, int nq,
+                                                    int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
+                                                    int32_t *__restrict__ second_d)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    const size_t part = (size_t)3 * nq + 1;
+    int bi = -1, bd = 256, sd = 256;
+    for (int s = 0; s < nshards; s++) {
+        const int32_t *P = parts + (size_t)s * part;
+        const int li = P[qi], ld = P[nq + qi], ls = P[2 * (size_t)nq + qi], off = P[3 * (size_t)nq];
+        if (ld < bd) {
+            sd = min(bd, ls);
+            bd = ld;
+            bi = li >= 0 ? li + off : -1;
+        } else {
+            sd = min(sd, ld);
+        }
+    }
+    best_idx[qi] = bi;
+    best_d[qi] = bd;
+    second_d[qi] = sd;
+}
+
+void launch_knn2_merge(hipStream_t s, const int32_t *parts, int nshards, int nq, int32_t *best_idx, int32_t *best_d,
+                       int32_t *second_d)
+{
+    hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, parts, nshards, nq, best_idx, best_d,
+                       second_d);
+}
+
+__global__ void k_fill_i32(int32_t *p, int32_t v, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void launch_fill_i32(hipStream_t s, int32_t *p, int32_t v, int n)
+{
+    hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, p, v, n);
+}
+
 __global__ __launch_bounds__(256) void k_knn2_lists(const uint8_t *__restrict__ q, int nq,
                                                     const uint8_t *__restrict__ db,
                                                     const int32_t *__restrict__ off,

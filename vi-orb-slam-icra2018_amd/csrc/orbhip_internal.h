@@ -215,6 +215,9 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
 size_t knn2_scratch_bytes(int nq, int ndb);
 void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, int cap, int B, int lag,
                      int32_t *best_idx, int32_t *best_d, int32_t *second_d);
+void launch_knn2_merge(hipStream_t s, const int32_t *parts, int nshards, int nq, int32_t *best_idx, int32_t *best_d,
+                       int32_t *second_d);
+void launch_fill_i32(hipStream_t s, int32_t *p, int32_t v, int n);
 void launch_knn2_lists(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, const int32_t *off,
                        const int32_t *cand, int32_t *best_idx, int32_t *best_d, int32_t *second_d);
 void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1, const int32_t *off1,

@@ -1,11 +1,12 @@
 // FrameGrid.cc -- Frame::UndistortKeyPoints / ComputeImageBounds (ref: src/Frame.cc:748-808) through
 // orbhip_undistort_keypoints, and Frame::AssignFeaturesToGrid / GetFeaturesInArea (:574-589, :671-724) on the
 // device grid of liborbhip (orbhip_grid_build, orbhip_features_in_area).  mGrid keeps the
-// reference's public layout (a vector of feature indices per cell).  No CPU path: errors throw.
+// reference's public layout (a vector of feature indices per cell).  No CPU path and no exceptions (hiperror.h):
+// a failed device call is reported and leaves the "nothing there" result.
 #include <algorithm>
-#include <stdexcept>
 #include <string>
 
+#include "hiperror.h"
 #include "orbhip.h"
 #include "ORBextractor.h"
 #include "slamlite.h"
@@ -20,7 +21,10 @@ float Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
 static orbhip_ctx *frame_ctx(const Frame *F, const char *who)
 {
     if (!F->mpORBextractorLeft || !F->mpORBextractorLeft->Context())
-        throw std::runtime_error(std::string(who) + ": the frame's extractor has no device context yet");
+    {
+        hipdetail::Fail(who, "the frame's extractor has no device context yet");
+        return nullptr;
+    }
     return F->mpORBextractorLeft->Context();
 }
 
@@ -49,7 +53,10 @@ void Frame::UndistortKeyPoints()
     // cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) on (pt.x, pt.y); the other fields are copied
     if (orbhip_undistort_keypoints(ctx, reinterpret_cast<const orbhip_keypoint *>(mvKeys.data()), N, K, D.data(), (int)D.size(),
                                    K, reinterpret_cast<orbhip_keypoint *>(mvKeysUn.data())) != ORBHIP_OK)
-        throw std::runtime_error(std::string("Frame::UndistortKeyPoints: ") + orbhip_last_error(ctx));
+    {
+        hipdetail::Fail("Frame::UndistortKeyPoints", orbhip_last_error(ctx));
+        mvKeysUn=mvKeys;          // the frame keeps its distorted coordinates
+    }
 }
 
 void Frame::ComputeImageBounds(const cv::Mat &imLeft)
@@ -67,7 +74,10 @@ void Frame::ComputeImageBounds(const cv::Mat &imLeft)
         corner[3].pt = cv::Point2f((float)imLeft.cols, (float)imLeft.rows);
         if (orbhip_undistort_keypoints(ctx, reinterpret_cast<const orbhip_keypoint *>(corner), 4, K, D.data(), (int)D.size(), K,
                                        reinterpret_cast<orbhip_keypoint *>(un)) != ORBHIP_OK)
-            throw std::runtime_error(std::string("Frame::ComputeImageBounds: ") + orbhip_last_error(ctx));
+        {
+            hipdetail::Fail("Frame::ComputeImageBounds", orbhip_last_error(ctx));
+            for (int i = 0; i < 4; i++) un[i] = corner[i];   // bounds of the distorted image
+        }
         mnMinX = std::min(un[0].pt.x, un[2].pt.x);
         mnMaxX = std::max(un[1].pt.x, un[3].pt.x);
         mnMinY = std::min(un[0].pt.y, un[1].pt.y);
@@ -91,7 +101,10 @@ void Frame::AssignFeaturesToGrid()
     std::vector<int32_t> off(ORBHIP_GRID_CELLS + 1), idx(N);
     if (orbhip_grid_build(ctx, reinterpret_cast<const orbhip_keypoint *>(mvKeysUn.data()), N, mnMinX, mnMinY,
                           mfGridElementWidthInv, mfGridElementHeightInv, off.data(), idx.data()) != ORBHIP_OK)
-        throw std::runtime_error(std::string("Frame::AssignFeaturesToGrid: ") + orbhip_last_error(ctx));
+    {
+        hipdetail::Fail("Frame::AssignFeaturesToGrid", orbhip_last_error(ctx));
+        return;                   // empty grid
+    }
     for (int i = 0; i < FRAME_GRID_COLS; i++)
         for (int j = 0; j < FRAME_GRID_ROWS; j++) {
             const int c = i * FRAME_GRID_ROWS + j;
@@ -110,7 +123,7 @@ std::vector<size_t> Frame::GetFeaturesInArea(const float &x, const float &y, con
     int32_t off[2] = {0, 0};
     if (orbhip_features_in_area(ctx, reinterpret_cast<const orbhip_keypoint *>(mvKeysUn.data()), N, mnMinX, mnMinY,
                                 mfGridElementWidthInv, mfGridElementHeightInv, &q, 1, off, idx.data(), N) != ORBHIP_OK)
-        throw std::runtime_error(std::string("Frame::GetFeaturesInArea: ") + orbhip_last_error(ctx));
+        return hipdetail::Fail("Frame::GetFeaturesInArea", orbhip_last_error(ctx)), vIndices;
     vIndices.assign(idx.begin(), idx.begin() + off[1]);
     return vIndices;
 }

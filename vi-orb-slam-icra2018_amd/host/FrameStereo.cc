@@ -2,11 +2,12 @@
 // the row-band descriptor search (:848-893), the 11-shift SAD refinement on the two image pyramids
 // (:895-955) and the median cut (:966-983) all run on the device, on the pyramid levels the two
 // extractor contexts still hold from the operator() calls of this frame -- mvImagePyramid never
-// crosses PCIe.  There is no CPU path: errors throw.
+// crosses PCIe.  There is no CPU path and no exception (hiperror.h): on a failed
+// device call no keypoint gets a depth.
 #include <cstring>
-#include <stdexcept>
 #include <string>
 
+#include "hiperror.h"
 #include "orbhip.h"
 #include "ORBextractor.h"
 #include "slamlite.h"
@@ -30,7 +31,10 @@ void Frame::ComputeStereoMatches()
     if (N == 0) return;
     if (!mpORBextractorLeft || !mpORBextractorRight || !mpORBextractorLeft->Context() ||
         !mpORBextractorRight->Context())
-        throw std::runtime_error("Frame::ComputeStereoMatches: both extractors must have run on this frame");
+    {
+        hipdetail::Fail("Frame::ComputeStereoMatches", "both extractors must have run on this frame");
+        return;
+    }
     std::vector<unsigned char> tl, tr;
     int nmatch = 0;
     const int rc = orbhip_stereo_match(mpORBextractorLeft->Context(), mpORBextractorRight->Context(),
@@ -39,8 +43,11 @@ void Frame::ComputeStereoMatches()
                                        rows32(mDescriptorsRight, tr), (int)mvKeysRight.size(), mb, mbf, mvuRight.data(),
                                        mvDepth.data(), &nmatch);
     if (rc != ORBHIP_OK)
-        throw std::runtime_error(std::string("Frame::ComputeStereoMatches: ") +
-                                 orbhip_last_error(mpORBextractorLeft->Context()));
+    {
+        hipdetail::Fail("Frame::ComputeStereoMatches", orbhip_last_error(mpORBextractorLeft->Context()));
+        mvuRight.assign(N, -1.0f);
+        mvDepth.assign(N, -1.0f);
+    }
 }
 
 }  // namespace ORB_SLAM2

@@ -3,8 +3,8 @@
 
 #include <cmath>
 #include <cstdio>
-#include <stdexcept>
 
+#include "hiperror.h"
 #include "orbhip.h"
 
 namespace ORB_SLAM2
@@ -24,7 +24,7 @@ bool ORBVocabulary::loadFromBinaryBlob(const void *blob, size_t nbytes)
 {
     if (!mpCtx) {
         mpCtx = orbhip_create(g_voc_device, 50, 1.2f, 1, 20, 7, 128, 128, 1);
-        if (!mpCtx) throw std::runtime_error(std::string("ORBVocabulary: ") + orbhip_last_error(nullptr));
+        if (!mpCtx) return hipdetail::Fail("ORBVocabulary (device context)", orbhip_last_error(nullptr));   // = "failed to load", src/System.cc:340-346
     }
     if (orbhip_vocab_load(mpCtx, blob, nbytes) != ORBHIP_OK) return false;
     orbhip_vocab_info(mpCtx, &mK, &mL, &mScoring, &mWeighting, &mnNodes, &mnWords);
@@ -56,7 +56,10 @@ void ORBVocabulary::transform(const std::vector<cv::Mat> &features, DBoW2::BowVe
     std::vector<int32_t> word(n), node(n);
     std::vector<float> weight(n);
     if (orbhip_vocab_transform(mpCtx, desc.data(), n, levelsup, word.data(), weight.data(), node.data()) != ORBHIP_OK)
-        throw std::runtime_error(std::string("ORBVocabulary::transform: ") + orbhip_last_error(mpCtx));
+    {
+        hipdetail::Fail("ORBVocabulary::transform", orbhip_last_error(mpCtx));
+        return;                   // empty BowVector / FeatureVector
+    }
     // BowVector.h: WeightingType TF_IDF=0, TF=1, IDF=2, BINARY=3; ScoringType L1_NORM=0, L2_NORM=1,
     // CHI_SQUARE=2, KL=3, BHATTACHARYYA=4, DOT_PRODUCT=5
     const bool accumulate = (mWeighting == 0 || mWeighting == 1);

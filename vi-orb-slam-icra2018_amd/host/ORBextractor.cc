@@ -6,9 +6,9 @@
 
 #include <cassert>
 #include <cstdio>
-#include <stdexcept>
 #include <string>
 
+#include "hiperror.h"
 #include "orbhip.h"
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint must be the 28-byte OpenCV layout");
@@ -35,11 +35,13 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels,
     mvInvLevelSigma2.resize(nlevels);
     mnFeaturesPerLevel.resize(nlevels);
     umax.resize(16);
-    if (orbhip_tables(nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, mvScaleFactor.data(),
-                      mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
-                      mnFeaturesPerLevel.data(), umax.data()) != ORBHIP_OK)
-        throw std::invalid_argument("ORBextractor: bad parameters");
-    mvImagePyramid.resize(nlevels);
+    // (the reference's constructor accepts anything; parameters liborbhip cannot run -- nlevels outside 1..16,
+    // scaleFactor <= 1 -- leave an extractor that reports the error and returns no keypoints)
+    mbBadParams = orbhip_tables(nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, mvScaleFactor.data(),
+                                mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
+                                mnFeaturesPerLevel.data(), umax.data()) != ORBHIP_OK;
+    if (mbBadParams) hipdetail::Fail("ORBextractor::ORBextractor", orbhip_last_error(nullptr));
+    mvImagePyramid.resize(nlevels > 0 ? nlevels : 0);
 }
 
 ORBextractor::~ORBextractor()
@@ -47,7 +49,7 @@ ORBextractor::~ORBextractor()
     if (mpCtx) orbhip_destroy(mpCtx);
 }
 
-const char *ORBextractor::LastError() const { return orbhip_last_error(mpCtx); }
+const char *ORBextractor::LastError() const { return mpCtx ? orbhip_last_error(mpCtx) : OrbHipLastError(); }
 
 bool ORBextractor::EnsureContext(int w, int h)
 {
@@ -69,8 +71,15 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1 );                        // ref: :1052
 
-    if (!EnsureContext(image.cols, image.rows))
-        throw std::runtime_error(std::string("ORBextractor: ") + orbhip_last_error(nullptr));
+    // every failure below leaves the caller with what the reference leaves for a frame without corners: no keypoints,
+    // released descriptors (ref: :1080-1081) -- never an exception (hiperror.h)
+    _keypoints.clear();
+    if (mbBadParams || !EnsureContext(image.cols, image.rows))
+    {
+        _descriptors.release();
+        hipdetail::Fail("ORBextractor::operator()", mbBadParams ? "constructed with parameters liborbhip rejects" : orbhip_last_error(nullptr));
+        return;
+    }
 
     const int cap = orbhip_max_keypoints(mpCtx);
     mvKpStage.resize(cap);
@@ -80,7 +89,11 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
     const int rc = orbhip_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step,
                                   reinterpret_cast<orbhip_keypoint *>(mvKpStage.data()), descStage.data, cap, &n, t);
     if (rc != ORBHIP_OK)
-        throw std::runtime_error(std::string("ORBextractor: ") + orbhip_last_error(mpCtx));
+    {
+        _descriptors.release();
+        hipdetail::Fail("ORBextractor::operator()", orbhip_last_error(mpCtx));
+        return;
+    }
     mTimeOfComputePyramid = t[0];
     mTimeOfComputeKeyPointsOctTree = t[1];
     mTimeOfComputeDescriptor = t[2];
@@ -106,7 +119,10 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
             mvImagePyramid[level].create(h, w, CV_8UC1);
             if (orbhip_get_pyramid_level(mpCtx, 0, level, mvImagePyramid[level].data, (int)mvImagePyramid[level].step,
                                          &w, &h) != ORBHIP_OK)
-                throw std::runtime_error(std::string("ORBextractor: ") + orbhip_last_error(mpCtx));
+            {
+                hipdetail::Fail("ORBextractor::operator() (mvImagePyramid download)", orbhip_last_error(mpCtx));
+                return;
+            }
         }
     }
 }

@@ -6,9 +6,9 @@
 #include "ORBmatcher.h"
 
 #include <cstring>
-#include <stdexcept>
 #include <string>
 
+#include "hiperror.h"
 #include "orbhip.h"
 
 using namespace std;
@@ -33,7 +33,7 @@ struct ThreadCtx {
     {
         if (!ctx) {
             ctx = orbhip_create(g_match_device, 50, 1.2f, 1, 20, 7, 128, 128, 1);
-            if (!ctx) throw std::runtime_error(std::string("ORBmatcher: ") + orbhip_last_error(nullptr));
+            if (!ctx) hipdetail::Fail("ORBmatcher (device context)", orbhip_last_error(nullptr));   // every C call rejects a null context
         }
         return ctx;
     }
@@ -92,7 +92,7 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF,Frame &F, vector<MapPoint*> &vpMapPoin
                                         a2.data(), c2.node.data(), c2.off.data(), c2.idx.data(), (int)c2.node.size(),
                                         TH_LOW, 0, mfNNratio, mbCheckOrientation ? 1 : 0, m12.data(), m21.data(),
                                         &nmatches);
-    if (rc != ORBHIP_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByBoW: ") + orbhip_last_error(tls.get()));
+    if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
     for (int i2 = 0; i2 < n2 && i2 < F.N; i2++)
         if (m21[i2] >= 0) vpMapPointMatches[i2] = vpMapPointsKF[m21[i2]];   // ref: :232
     return nmatches;
@@ -127,7 +127,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
                                         valid2.data(), a2.data(), c2.node.data(), c2.off.data(), c2.idx.data(),
                                         (int)c2.node.size(), TH_LOW, 1, mfNNratio, mbCheckOrientation ? 1 : 0,
                                         m12.data(), m21.data(), &nmatches);
-    if (rc != ORBHIP_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByBoW: ") + orbhip_last_error(tls.get()));
+    if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
     for (int i1 = 0; i1 < n1 && i1 < (int)vpMatches12.size(); i1++)
         if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];           // ref: :602
     return nmatches;
@@ -163,8 +163,7 @@ int run_projection_search(Frame &F, const vector<orbhip_proj_query> &q, const ve
         (useRight && (int)F.mvuRight.size() == n) ? F.mvuRight.data() : NULL, occupied.data(), Frame::mnMinX, Frame::mnMinY,
         Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv, q.data(), qdesc.data(), nq, use_ratio ? 1 : 0, nnratio,
         check_ori ? 1 : 0, th_high, match.data(), &nmatches);
-    if (rc != ORBHIP_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection: ") + orbhip_last_error(tls.get()));
+    if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByProjection", orbhip_last_error(tls.get())), 0;
     for (int i = 0; i < n; i++) {
         if (match[i] >= 0)
             F.mvpMapPoints[i] = source[match[i]];
@@ -462,7 +461,11 @@ void run_window_best(KeyFrame *pKF, const vector<orbhip_proj_query> &q, const ve
         (gate && (int)pKF->mvuRight.size() == n) ? pKF->mvuRight.data() : NULL, gate ? pKF->mvInvLevelSigma2.data() : NULL,
         gate ? (int)pKF->mvInvLevelSigma2.size() : 0, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
         pKF->mfGridElementHeightInv, q.data(), qdesc.data(), nq, bestIdx.data(), bestDist.data());
-    if (rc != ORBHIP_OK) throw std::runtime_error(std::string("ORBmatcher (KeyFrame window search): ") + orbhip_last_error(tls.get()));
+    if (rc != ORBHIP_OK) {
+        hipdetail::Fail("ORBmatcher::Fuse / SearchBySim3 (KeyFrame window search)", orbhip_last_error(tls.get()));
+        bestIdx.assign(nq, -1);      // no point finds a feature: the callers fuse / match nothing
+        bestDist.assign(nq, 256);
+    }
 }
 }  // namespace
 
@@ -502,8 +505,7 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapP
         tls.get(), reinterpret_cast<const orbhip_keypoint *>(pKF->mvKeysUn.data()), d.data(), n, NULL, occupied.data(),
         pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, q.data(), qdesc.data(), nq, 0,
         mfNNratio, 0, TH_LOW, match.data(), &nmatches);
-    if (rc != ORBHIP_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection: ") + orbhip_last_error(tls.get()));
+    if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByProjection", orbhip_last_error(tls.get())), 0;
     for (int i = 0; i < n; i++)
         if (match[i] >= 0) vpMatched[i] = vpPoints[match[i]];
     return nmatches;
@@ -749,7 +751,7 @@ int ComputeDistinctiveDescriptors(const vector<MapPoint*> &vpMapPoints)
     if (P == 0) return 0;
     vector<int32_t> best(P);
     const int rc = orbhip_distinctive_descriptors(tls.get(), desc.data(), off.data(), P, best.data(), NULL);
-    if (rc != ORBHIP_OK) throw std::runtime_error(std::string("ComputeDistinctiveDescriptors: ") + orbhip_last_error(tls.get()));
+    if (rc != ORBHIP_OK) return hipdetail::Fail("ComputeDistinctiveDescriptors", orbhip_last_error(tls.get())), 0;   // descriptors stay as they were
     for (int p = 0; p < P; p++)
     {
         cv::Mat d(1, 32, CV_8U);
@@ -798,7 +800,7 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
         F, ex, ey, pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(), (int)pKF2->mvScaleFactors.size(),
         bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, vMatches12.data(), &nmatches);
     if(rc != ORBHIP_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation: ") + orbhip_last_error(tls.get()));
+        return hipdetail::Fail("ORBmatcher::SearchForTriangulation", orbhip_last_error(tls.get())), 0;
 
     vMatchedPairs.reserve(nmatches);
     for(size_t i=0, iend=vMatches12.size(); i<iend; i++)
@@ -818,7 +820,7 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f
     if(n1==0 || n2==0)
         return 0;
     if((int)vbPrevMatched.size()<n1)
-        throw std::runtime_error("ORBmatcher::SearchForInitialization: vbPrevMatched is shorter than F1.mvKeysUn");
+        return hipdetail::Fail("ORBmatcher::SearchForInitialization", "vbPrevMatched is shorter than F1.mvKeysUn"), 0;
     int nmatches=0;
     const int rc = orbhip_search_for_initialization(tls.get(), (const orbhip_keypoint *)F1.mvKeysUn.data(), F1.mDescriptors.ptr(0), n1,
                                                     (const orbhip_keypoint *)F2.mvKeysUn.data(), F2.mDescriptors.ptr(0), n2,
@@ -826,7 +828,10 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f
                                                     Frame::mfGridElementHeightInv, (float *)vbPrevMatched.data(), windowSize,
                                                     mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches);
     if(rc != ORBHIP_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization: ") + orbhip_last_error(tls.get()));
+    {
+        vnMatches12.assign(n1,-1);
+        return hipdetail::Fail("ORBmatcher::SearchForInitialization", orbhip_last_error(tls.get())), 0;
+    }
     return nmatches;
 }
 
@@ -859,7 +864,7 @@ vector<size_t> KeyFrame::GetFeaturesInArea(const float &x, const float &y, const
     int32_t off[2] = {0, 0};
     if(orbhip_features_in_area(tls.get(), reinterpret_cast<const orbhip_keypoint *>(mvKeysUn.data()), n, mnMinX, mnMinY,
                                mfGridElementWidthInv, mfGridElementHeightInv, &q, 1, off, idx.data(), n) != ORBHIP_OK)
-        throw std::runtime_error(std::string("KeyFrame::GetFeaturesInArea: ") + orbhip_last_error(tls.get()));
+        return hipdetail::Fail("KeyFrame::GetFeaturesInArea", orbhip_last_error(tls.get())), vIndices;
     vIndices.assign(idx.begin(), idx.begin() + off[1]);
     return vIndices;
 }

@@ -4,6 +4,7 @@ stream, or whole streams -- so there is NO per-frame collective; the only exchan
 one-off broadcast of the ORB vocabulary and (brute-force relocalisation) a min-merge of per-shard
 (best, index, second) triples.  SURVEY.md section 8e.
 """
+import os
 import struct
 
 import numpy as np
@@ -121,7 +122,8 @@ def merge_knn2_shards(best_idx, best_d, second_d, shard_offsets):
 
 
 def allgather_knn2(best_idx, best_d, second_d, shard_offset):
-    """The one exchange step of sharded brute force: all-gather Q x 3 int32 and merge."""
+    """The one exchange step of sharded brute force with host arrays (gloo / CPU tests): all-gather Q x 3 int32
+    and merge on the host.  The GPU path is allgather_knn2_device."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
@@ -133,3 +135,77 @@ def allgather_knn2(best_idx, best_d, second_d, shard_offset):
     arrs = [o.cpu().numpy() for o in outs]
     return merge_knn2_shards([a[0] for a in arrs], [a[1] for a in arrs], [a[2] for a in arrs],
                              [int(a[3][0]) if a.shape[1] else 0 for a in arrs])
+
+
+def allgather_knn2_device(ex, best_idx, best_d, second_d, shard_offset):
+    """The same exchange step with everything resident on the GPU: per-rank results are torch int32 CUDA tensors
+    [nq] (outputs of orbhip_hamming_knn2_device on this rank's database rows); one all-gather of 3 * nq + 1 int32 per
+    rank (RCCL), then the min-merge kernel of liborbhip (orbhip_knn2_merge_device) -- nothing returns to the host.
+    Works without an initialised process group (world 1).  Returns three CUDA tensors with global indices."""
+    import torch
+    import torch.distributed as dist
+    nq = int(best_idx.numel())
+    dev = best_idx.device
+    part = torch.cat([best_idx.to(torch.int32).reshape(-1), best_d.to(torch.int32).reshape(-1),
+                      second_d.to(torch.int32).reshape(-1),
+                      torch.tensor([int(shard_offset)], dtype=torch.int32, device=dev)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        allp = torch.empty((world, part.numel()), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allp, part)
+    else:
+        world, allp = 1, part.reshape(1, -1).contiguous()
+    out = [torch.empty(nq, dtype=torch.int32, device=dev) for _ in range(3)]
+    torch.cuda.current_stream().synchronize()      # torch's stream -> the context's stream
+    rc = ex._L.orbhip_knn2_merge_device(ex.handle, allp.data_ptr(), world, nq, out[0].data_ptr(), out[1].data_ptr(),
+                                        out[2].data_ptr())
+    if rc != 0:
+        raise RuntimeError("orbhip_knn2_merge_device failed (%d)" % rc)
+    ex.sync()
+    return out
+
+
+# ---- launching one process per GPU ------------------------------------------------------------
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_env(rank, world, port, base=None):
+    """Environment of rank `rank` of a one-node job (what torch.distributed.run would set)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL needs it)
+    return env
+
+
+def launch_ranks(argv, world, timeout=None, env=None):
+    """Start `world` fresh child processes of `argv` (one per GPU), rank r with rank_env(r, ...), and wait for them.
+    The caller must not have touched the GPU: a process that has initialised HIP must never be replaced or forked
+    into another program on this pool, so the launcher runs BEFORE anything imports torch.cuda state.  Rank 0's
+    stdout is returned (its last line is the JSON line); the other ranks' stdout is discarded, stderr is inherited.
+    Returns (max return code, rank-0 stdout)."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(argv, env=rank_env(r, world, port, env),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    rc = 0
+    try:
+        out0 = procs[0].communicate(timeout=timeout)[0]
+        for p in procs:
+            rc = max(rc, abs(p.wait(timeout=timeout)))
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()          # exactly the processes started here
+    return rc, out0.decode(errors="replace")
