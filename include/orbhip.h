@@ -186,6 +186,17 @@ int orbhip_search_by_bow(orbhip_ctx *ctx, const uint8_t *desc1, int n1, const ui
  * orbhip_bcast_blob_device); it is copied back once for parsing. */
 int orbhip_vocab_load(orbhip_ctx *ctx, const void *blob, size_t nbytes);
 int orbhip_vocab_load_device(orbhip_ctx *ctx, const void *d_blob, size_t nbytes);
+/* Replaces ORBVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1564-1647; chosen by
+ * src/System.cc:335-336 for a ".txt" vocabulary such as the stock ORBvoc.txt): host-only conversion of the text (first
+ * line "k L scoring weighting", then per node "parent is_leaf d0 .. d31 weight") to the binary layout above, which
+ * orbhip_vocab_load takes.  Call with blob = NULL to get *blob_bytes = 24 + 41 * nodes, then with a buffer.  node_weight
+ * (may be NULL; (*blob_bytes - 24) / 41 entries, node ids 1..n) receives the weights as the doubles the reference's text
+ * loader keeps (Node::weight is a double; the binary format narrows it to float, so BowVector values of a text-loaded
+ * vocabulary come from this array).  Lines without a token are skipped (the reference turns the empty line after the final
+ * newline into a node built from uninitialised memory).  ORBHIP_E_ARG for a malformed text, ORBHIP_E_CAPACITY for a
+ * buffer that is too small. */
+int orbhip_vocab_text_to_binary(const char *text, size_t nbytes, void *blob, size_t blob_cap, size_t *blob_bytes,
+                                double *node_weight, size_t weight_cap);
 int orbhip_vocab_info(const orbhip_ctx *ctx, int *k, int *L, int *scoring, int *weighting, int *nnodes,
                       int *nwords);
 /* Replaces the per-feature ORBVocabulary::transform (TemplatedVocabulary.h:1443-1485) as used by

@@ -35,6 +35,11 @@ public:
     ORBVocabulary(const ORBVocabulary &) = delete;
     ORBVocabulary &operator=(const ORBVocabulary &) = delete;
 
+    // ref: TemplatedVocabulary.h:1564-1647 -- the loader src/System.cc:335-336 picks for a ".txt" vocabulary (the stock
+    // ORBvoc.txt).  Returns false if the file cannot be read or is malformed.  Node weights are kept as the doubles of
+    // the text (Node::weight), so BowVector values equal the reference's for a text-loaded vocabulary.
+    bool loadFromTextFile(const std::string &filename);
+    bool loadFromText(const char *text, size_t nbytes);
     // ref: TemplatedVocabulary.h:1680 -- returns false if the file cannot be read or is malformed
     bool loadFromBinaryFile(const std::string &filename);
     // same from memory (e.g. the blob received through orbhip_bcast_blob_device)
@@ -51,6 +56,7 @@ public:
 private:
     orbhip_ctx *mpCtx;
     int mnNodes, mnWords, mK, mL, mScoring, mWeighting;
+    std::vector<double> mvWordWeight;   // by word id; only for a text-loaded vocabulary (empty otherwise)
 };
 
 }  // namespace ORB_SLAM2

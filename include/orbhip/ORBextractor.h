@@ -68,7 +68,8 @@ public:
 
     // device selection for multi-GPU processes (one process per GPU); default device 0
     static void SetDevice(int device);
-    // last error text of the underlying context (empty if none)
+    // last error text of the underlying context (empty if none).  The drop-in never throws (hiperror.h): a failed
+    // operator() leaves no keypoints and released descriptors, like a frame without corners
     const char *LastError() const;
     orbhip_ctx *Context() { return mpCtx; }
 
@@ -97,6 +98,7 @@ private:
     orbhip_ctx *mpCtx;
     int mCtxW, mCtxH;
     bool mbDownloadPyramid;
+    bool mbBadParams;     // the constructor arguments are outside what liborbhip runs: operator() reports and returns nothing
     std::vector<cv::KeyPoint> mvKpStage;
 };
 

@@ -350,6 +350,67 @@ class Vocabulary:
         return ow[:m].copy(), ov[:m].copy()
 
 
+def vocabulary_text_to_blob(text):
+    """Restatement of ORBVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1564-1647) followed by
+    saveToBinaryFile (:1727-1751) -- the conversion tools/bin_vocabulary.cc performs: returns (blob, weights) with the
+    weights as the doubles the text loader stores in Node::weight (node ids 1..n).  Pure Python; test sizes only.
+    Canonical choice: a line without tokens is skipped (the reference's `while(!f.eof())` loop turns the empty string
+    after the last newline into a node made of uninitialised memory).  Raises ValueError where the reference returns
+    false (:1585-1589) or would index out of range."""
+    import struct
+    lines = bytes(text).decode("ascii").split("\n")
+    head = lines[0].split()
+    k, L, n1, n2 = (int(t) for t in head[:4])                          # :1576-1583
+    if k < 0 or k > 20 or L < 1 or L > 10 or n1 < 0 or n1 > 5 or n2 < 0 or n2 > 3:
+        raise ValueError("Vocabulary loading failure: This is not a correct text file!")   # :1585-1589
+    recs, weights = [], []
+    for ln in lines[1:]:
+        tok = ln.split()
+        if not tok:
+            continue
+        pid, leaf = int(tok[0]), int(tok[1])                           # :1611-1617
+        if pid < 0 or pid > len(recs):
+            raise ValueError("parent id out of range")
+        d = bytes(int(t) & 0xFF for t in tok[2:34])                    # FORB::fromString, FORB.cpp:117-131
+        w = float(tok[34])                                             # ssnode >> m_nodes[nid].weight (double), :1628
+        recs.append(struct.pack("<i32sfB", pid, d, np.float32(w), 1 if leaf > 0 else 0))
+        weights.append(w)
+    blob = struct.pack("<IIiiii", len(recs) + 1, 41, k, L, n1, n2) + b"".join(recs)
+    return blob, np.array(weights, np.float64)
+
+
+def bow_vector64(word, weight64, scoring, weighting):
+    """BowVector of TemplatedVocabulary::transform (:1167-1258) from per-feature word ids and DOUBLE weights (a
+    text-loaded vocabulary), features in ascending index order: the same steps as orbo_vocab_bow."""
+    acc = {}
+    accumulate = weighting in (0, 1)
+    for w, v in zip(word, weight64):
+        if not v > 0:
+            continue
+        if int(w) in acc:
+            if accumulate:
+                acc[int(w)] += float(v)
+        else:
+            acc[int(w)] = float(v)
+    keys = sorted(acc)
+    vals = [acc[k] for k in keys]
+    must = scoring != 5
+    if accumulate and vals and not must:
+        vals = [v / float(len(vals)) for v in vals]
+    if must and vals:
+        norm = 0.0
+        if scoring == 1:
+            for v in vals:
+                norm += v * v
+            norm = norm ** 0.5
+        else:
+            for v in vals:
+                norm += abs(v)
+        if norm > 0.0:
+            vals = [v / norm for v in vals]
+    return np.array(keys, np.int32), np.array(vals, np.float64)
+
+
 def feature_vector(node_id, weight=None):
     """DBoW2::FeatureVector in CSR form from per-feature node ids (ascending index inside a node);
     features with weight <= 0 are "stopped" and left out (TemplatedVocabulary.h:1334-1338)."""

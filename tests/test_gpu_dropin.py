@@ -363,3 +363,45 @@ def test_cpp_fuse_sim3_and_keyframe_projection_match_host_restatement(tmp_path):
     r = subprocess.run([exe, str(W), str(H), "1500", str(tmp_path / "frame.raw")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": ok") == 13 and "all ok" in r.stdout, r.stdout
+
+
+def test_cpp_dropins_do_not_throw_and_load_text_vocabularies(oracle, tmp_path):
+    """hiperror.h: a failed device call becomes "nothing found" + a message, never an exception (the reference's callers
+    have no try block); ORBVocabulary::loadFromTextFile + transform against the committed text fixture."""
+    from orbhip import distributed as D, synth
+    exe = os.path.join(ROOT, "tests", "native", "test_nothrow_dropin")
+    assert os.path.exists(exe), "tests/native/test_nothrow_dropin is not built (run __graft_entry__.build())"
+    W, H = 640, 480
+    frame = synth.make_frames(53, W, H, 1)[0]
+    (tmp_path / "frame.raw").write_bytes(frame.tobytes())
+    gold = os.path.join(ROOT, "tests", "golden")
+    g = np.load(os.path.join(gold, "vocab_k4_L2_text.npz"))
+    (tmp_path / "desc.bin").write_bytes(g["desc"].tobytes())
+    r = subprocess.run([exe, str(W), str(H), str(tmp_path / "frame.raw"), os.path.join(gold, "vocab_k4_L2.txt"),
+                        str(tmp_path / "desc.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    kv, bow, fv = {}, [], {}
+    for line in r.stdout.splitlines():
+        key, _, val = line.partition("=")
+        if key == "bow":
+            w, v = val.split()
+            bow.append((int(w), float(v)))
+        elif key == "fv":
+            t = [int(x) for x in val.split()]
+            fv[t[0]] = t[1:]
+        else:
+            kv[key] = val
+    assert kv["done"] == "1"
+    assert (kv["tiny_keys"], kv["tiny_desc_rows"], kv["tiny_errors"]) == ("0", "0", "1") and "ORBextractor" in kv["tiny_msg"]
+    assert "[orbhip]" in r.stderr                                   # logged once on stderr
+    rk, rd = oracle.Extractor(1000)(frame)
+    assert int(kv["good_keys"]) == len(rk) == int(kv["good_desc_rows"]) and kv["empty_keys_unchanged"] == "1"
+    assert (kv["bad_keys"], kv["bad_desc_rows"]) == ("0", "0")
+    assert (kv["init_short_prev"], kv["init_assigned"]) == ("0", "0") and int(kv["init_size"]) == len(rk)
+    assert (kv["voc_missing"], kv["voc_missing_txt"], kv["voc_bad_txt"], kv["voc_text"], kv["voc_words"]) == ("0", "0", "0", "1", "16")
+    assert [w for w, _ in bow] == g["bow_word"].tolist() and np.array_equal(np.array([v for _, v in bow]), g["bow_value"])
+    ofv = oracle.feature_vector(g["node"])
+    assert sorted(fv) == ofv[0].tolist()
+    for i, nid in enumerate(ofv[0]):
+        assert fv[int(nid)] == ofv[2][ofv[1][i]:ofv[1][i + 1]].tolist()
+    assert int(kv["errors_total"]) >= 3

@@ -166,3 +166,78 @@ def test_hip_batched_search_by_bow_rejects_more_than_4096_slots():
                                                     d.ptr, d.ptr, d.ptr), ex.handle, "search_by_bow_seq")
     d.free()
     ex.close()
+
+
+# ---- text vocabularies: ORBVocabulary::loadFromTextFile (TemplatedVocabulary.h:1564-1647; src/System.cc:335-336) ----
+def _golden(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+
+
+def test_text_vocabulary_conversion_oracle_c_abi_and_fixture(oracle):
+    """The committed text fixture through the oracle's restatement and through the C ABI's host-only converter: the same
+    binary blob (= what tools/bin_vocabulary.cc would write) and the same double weights; edge cases of the format."""
+    from orbhip import distributed as D
+    from orbhip.vocabulary import text_to_binary
+    text = open(_golden("vocab_k4_L2.txt"), "rb").read()
+    g = np.load(_golden("vocab_k4_L2_text.npz"))
+    ob, ow = oracle.vocabulary_text_to_blob(text)
+    cb, cw = text_to_binary(text)
+    assert ob == cb == g["blob"].tobytes() and np.array_equal(ow, cw) and np.array_equal(ow, g["node_weight64"])
+    voc = D.unpack_vocabulary(cb)
+    assert (voc["k"], voc["L"], len(voc["nodes"])) == (4, 2, 20) and int(voc["nodes"]["leaf"].sum()) == 16
+    # the text keeps 6 significant digits: the double is NOT the float of the tree the text was written from
+    src = D.unpack_vocabulary(D.make_synthetic_vocabulary(211, k=4, L=2))["nodes"]
+    assert np.array_equal(voc["nodes"]["desc"], src["desc"]) and np.array_equal(voc["nodes"]["parent"], src["parent"])
+    assert np.allclose(cw, src["weight"], rtol=1e-5) and not np.array_equal(cw.astype(np.float32), src["weight"])
+    assert np.array_equal(voc["nodes"]["weight"], cw.astype(np.float32))         # saveToBinaryFile narrows to float
+    # oracle transform + BowVector with the double weights reproduce the golden values
+    V = oracle.Vocabulary(ob)
+    w, wt, nid = V.transform(g["desc"], 1)
+    assert np.array_equal(w, g["word"]) and np.array_equal(nid, g["node"])
+    bw, bv = oracle.bow_vector64(w, ow[voc["nodes"]["leaf"] != 0][w], V.scoring, V.weighting)
+    assert np.array_equal(bw, g["bow_word"]) and np.array_equal(bv, g["bow_value"])
+    # format edge cases: no final newline, blank lines, CRLF, leaf flag > 1 -- all the same tree
+    for variant in (text.rstrip(b"\n"), text + b"\n\n", text.replace(b"\n", b"\r\n"), text.replace(b"\n0 1 ", b"\n0 7 ")):
+        vb, vw = text_to_binary(variant)
+        assert vb == cb and np.array_equal(vw, cw)
+        assert oracle.vocabulary_text_to_blob(variant.replace(b"\r", b""))[0] == cb
+    # malformed: header out of the ranges of :1585-1589, a parent that does not exist yet, a truncated node line
+    lines = text.split(b"\n")
+    for bad in (b"25 2  0 0\n" + b"\n".join(lines[1:]), b"4 0  0 0\n" + b"\n".join(lines[1:]), b"4 2  6 0\n" + b"\n".join(lines[1:]),
+                lines[0] + b"\n" + lines[1].replace(b"0 0 ", b"9 0 ", 1) + b"\n", lines[0] + b"\n" + b" ".join(lines[1].split()[:20]) + b"\n",
+                b""):
+        assert text_to_binary(bad) == (None, None)
+    with pytest.raises(ValueError):
+        oracle.vocabulary_text_to_blob(b"25 2  0 0\n")
+
+
+@pytest.mark.gpu
+def test_hip_text_vocabulary_matches_oracle(oracle, tmp_path):
+    from orbhip import distributed as D, synth
+    from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    ex = ORBextractor(300, max_w=320, max_h=240)
+    g = np.load(_golden("vocab_k4_L2_text.npz"))
+    voc = ORBVocabulary(ex)
+    assert voc.loadFromTextFile(_golden("vocab_k4_L2.txt")) and (voc.k, voc.L, voc.nnodes, voc.nwords) == (4, 2, 21, 16)
+    (bw, bv), fv = voc.transform(g["desc"], 1)
+    assert np.array_equal(bw, g["bow_word"]) and np.array_equal(bv, g["bow_value"])       # doubles from the text
+    w, wt, nid = voc.transform_raw(g["desc"], 1)
+    assert np.array_equal(w, g["word"]) and np.array_equal(nid, g["node"])
+    # a larger tree written as text: k = 10, L = 3, weights with few digits
+    blob = D.make_synthetic_vocabulary(61, k=10, L=3)
+    text = D.vocabulary_to_text(blob)
+    (tmp_path / "voc.txt").write_bytes(text)
+    assert voc.loadFromTextFile(str(tmp_path / "voc.txt")) and voc.nnodes == 1111
+    ob, ow = oracle.vocabulary_text_to_blob(text)
+    V = oracle.Vocabulary(ob)
+    desc = synth.make_descriptor_db(62, 1500)
+    (bw, bv), fv = voc.transform(desc, 2)
+    rw, rwt, rnid = V.transform(desc, 2)
+    leaf = np.frombuffer(ob, D.VOC_NODE_DTYPE, offset=24)["leaf"] != 0
+    obw, obv = oracle.bow_vector64(rw, ow[leaf][rw], V.scoring, V.weighting)
+    assert np.array_equal(bw, obw) and np.array_equal(bv, obv)
+    assert all(np.array_equal(a, b) for a, b in zip(fv, oracle.feature_vector(rnid, ow[leaf][rw])))
+    assert not voc.loadFromText(b"not a vocabulary")
+    ex.close()

@@ -83,6 +83,20 @@ def gen_next_rows():
     bw, bv = V.bow(w, wt)
     np.savez_compressed(os.path.join(OUT, "vocab_k5_L3.npz"), blob=np.frombuffer(blob, np.uint8), desc=desc, word=w, weight=wt,
                         node=nid, bow_word=bw, bow_value=bv)
+    # row 1b: the same kind of tree in the TEXT format of saveToTextFile / loadFromTextFile (TemplatedVocabulary.h:1564-1672;
+    # src/System.cc:335-336 loads ".txt" vocabularies this way): the fixture is the text file itself
+    blob_t = D.make_synthetic_vocabulary(211, k=4, L=2)
+    text = D.vocabulary_to_text(blob_t)
+    with open(os.path.join(OUT, "vocab_k4_L2.txt"), "wb") as fh:
+        fh.write(text)
+    tb, tw = oracle.vocabulary_text_to_blob(text)
+    Vt = oracle.Vocabulary(tb)
+    desc_t = synth.make_descriptor_db(212, 120)
+    w, wt, nid = Vt.transform(desc_t, 1)
+    leaf = np.frombuffer(tb, D.VOC_NODE_DTYPE, offset=24)["leaf"] != 0
+    bw, bv = oracle.bow_vector64(w, tw[leaf][w], Vt.scoring, Vt.weighting)
+    np.savez_compressed(os.path.join(OUT, "vocab_k4_L2_text.npz"), blob=np.frombuffer(tb, np.uint8), node_weight64=tw, desc=desc_t,
+                        word=w, node=nid, bow_word=bw, bow_value=bv)
     # row 2: stereo
     L, R = synth.make_stereo_pair(203, 376, 241, disparity=14)
     exL, exR = oracle.Extractor(400, 1.2, 6), oracle.Extractor(400, 1.2, 6)

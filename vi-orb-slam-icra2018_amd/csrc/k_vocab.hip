@@ -13,7 +13,10 @@
 // k * L = 60 Hamming distances per feature for the stock vocabulary (k = 10, L = 6).
 #include "orbhip_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 int orb_vocab_parse(const uint8_t *blob, size_t nbytes, OrbVocabHost &V, std::string &err)
 {
@@ -93,6 +96,92 @@ int orb_vocab_parse(const uint8_t *blob, size_t nbytes, OrbVocabHost &V, std::st
         V.eword[e] = V.word[id];
         V.eweight[e] = V.weight[id];
     }
+    return ORBHIP_OK;
+}
+
+// ORBVocabulary::loadFromTextFile (ref: Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1564-1647; System::System picks it for
+// a ".txt" vocabulary, src/System.cc:335-336 -- the stock ORBvoc.txt): first line "k L scoring weighting", then one line per
+// node in id order 1, 2, ...: "parent is_leaf d0 ... d31 weight" (the 32 descriptor bytes as decimal integers,
+// FORB::fromString; the weight as a decimal double).  The text is converted to the binary layout of saveToBinaryFile
+// (:1727-1751) -- which is what tools/bin_vocabulary.cc produces from the same file -- plus the weights as the doubles the
+// text loader keeps (Node::weight is a double; the binary file narrows it to float).
+// Canonical choice: a line without any token (the empty string getline returns after the file's final newline) is
+// skipped.  The reference does not skip it: its `while(!f.eof())` loop runs once more and appends a node whose parent,
+// leaf flag and descriptor are whatever the previous iteration and cv::Mat::create left in memory (:1607-1640 with failed
+// extractions) -- not a function of the file.
+extern "C" int orbhip_vocab_text_to_binary(const char *text, size_t nbytes, void *blob, size_t blob_cap, size_t *blob_bytes,
+                                           double *node_weight, size_t weight_cap)
+{
+    if (!text || !blob_bytes) return ORBHIP_E_ARG;
+    const char *p = text, *end = text + nbytes;
+    auto next_line = [&](const char *&b, const char *&e) {
+        if (p >= end) return false;
+        b = p;
+        while (p < end && *p != '\n') p++;
+        e = p;
+        if (p < end) p++;
+        return true;
+    };
+    // tokens of a line: the extraction operators skip white space (std::isspace in the "C" locale)
+    auto skip_ws = [](const char *&b, const char *e) {
+        while (b < e && (*b == ' ' || *b == '\t' || *b == '\r' || *b == '\v' || *b == '\f')) b++;
+    };
+    auto get_long = [&](const char *&b, const char *e, long &v) {
+        skip_ws(b, e);
+        if (b >= e) return false;
+        std::string tok(b, std::min<size_t>((size_t)(e - b), 40));
+        char *q = nullptr;
+        v = strtol(tok.c_str(), &q, 10);
+        if (q == tok.c_str()) return false;
+        b += q - tok.c_str();
+        return true;
+    };
+    const char *b, *e;
+    if (!next_line(b, e)) return ORBHIP_E_ARG;
+    long k, L, n1, n2;
+    if (!get_long(b, e, k) || !get_long(b, e, L) || !get_long(b, e, n1) || !get_long(b, e, n2)) return ORBHIP_E_ARG;
+    if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) return ORBHIP_E_ARG;   // :1585-1589
+    uint8_t *out = (uint8_t *)blob;
+    size_t n = 0;   // nodes written (ids 1..n)
+    while (next_line(b, e)) {
+        skip_ws(b, e);
+        if (b >= e) continue;                                   // canonical: no token on the line
+        long pid, leaf;
+        if (!get_long(b, e, pid) || !get_long(b, e, leaf)) return ORBHIP_E_ARG;
+        if (pid < 0 || pid > (long)n) return ORBHIP_E_ARG;      // m_nodes[pid] must exist (:1614)
+        uint8_t d[32];
+        for (int i = 0; i < 32; i++) {
+            long v;
+            if (!get_long(b, e, v)) return ORBHIP_E_ARG;
+            d[i] = (uint8_t)v;                                  // FORB::fromString: (unsigned char)n
+        }
+        skip_ws(b, e);
+        if (b >= e) return ORBHIP_E_ARG;
+        std::string tok(b, (size_t)(e - b));
+        char *q = nullptr;
+        const double w = strtod(tok.c_str(), &q);
+        if (q == tok.c_str()) return ORBHIP_E_ARG;
+        const size_t off = 24 + n * 41;
+        if (out && off + 41 <= blob_cap) {
+            const int32_t p32 = (int32_t)pid;
+            const float wf = (float)w;                          // saveToBinaryFile: _weight = node.weight
+            memcpy(out + off, &p32, 4);
+            memcpy(out + off + 4, d, 32);
+            memcpy(out + off + 36, &wf, 4);
+            out[off + 40] = leaf > 0 ? 1 : 0;                   // :1630
+        }
+        if (node_weight && n < weight_cap) node_weight[n] = w;
+        n++;
+    }
+    *blob_bytes = 24 + n * 41;
+    if (out) {
+        if (blob_cap < *blob_bytes) return ORBHIP_E_CAPACITY;
+        const uint32_t hdr[2] = {(uint32_t)(n + 1), 41u};
+        const int32_t h2[4] = {(int32_t)k, (int32_t)L, (int32_t)n1, (int32_t)n2};
+        memcpy(out, hdr, 8);
+        memcpy(out + 8, h2, 16);
+    }
+    if (node_weight && weight_cap < n) return ORBHIP_E_CAPACITY;
     return ORBHIP_OK;
 }
 

@@ -25,7 +25,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels,
     nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels),
     iniThFAST(_iniThFAST), minThFAST(_minThFAST),
     mTimeOfComputePyramid(0), mTimeOfComputeKeyPointsOctTree(0), mTimeOfComputeDescriptor(0),
-    mpCtx(nullptr), mCtxW(0), mCtxH(0), mbDownloadPyramid(true)
+    mpCtx(nullptr), mCtxW(0), mCtxH(0), mbDownloadPyramid(true), mbBadParams(false)
 {
     // scale tables, per-level quotas and umax (ref: src/ORBextractor.cc:417-471) -- host arithmetic
     // inside liborbhip, no device needed yet

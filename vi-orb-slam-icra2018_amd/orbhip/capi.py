@@ -25,7 +25,7 @@ SYMBOLS = [
     "orbhip_get_pyramid_level", "orbhip_debug_get_blurred_level", "orbhip_debug_get_candidates",
     "orbhip_debug_get_level_keypoints", "orbhip_hamming_knn2", "orbhip_hamming_knn2_device",
     "orbhip_hamming_knn2_seq_device", "orbhip_get_stage_times", "orbhip_vocab_load", "orbhip_vocab_load_device",
-    "orbhip_vocab_info", "orbhip_vocab_transform", "orbhip_vocab_transform_device",
+    "orbhip_vocab_info", "orbhip_vocab_text_to_binary", "orbhip_vocab_transform", "orbhip_vocab_transform_device",
     "orbhip_search_by_bow_seq_device", "orbhip_stereo_match", "orbhip_stereo_match_device",
     "orbhip_hamming_knn2_lists", "orbhip_search_by_bow", "orbhip_comm_unique_id",
     "orbhip_comm_init", "orbhip_comm_destroy", "orbhip_bcast_blob_device", "orbhip_knn2_allgather_merge_device",
@@ -96,6 +96,7 @@ def load():
     L.orbhip_vocab_load.argtypes = [vp, vp, C.c_size_t]
     L.orbhip_vocab_load_device.argtypes = [vp, vp, C.c_size_t]
     L.orbhip_vocab_info.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    L.orbhip_vocab_text_to_binary.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t]
     L.orbhip_vocab_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_vocab_transform_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_search_by_bow_seq_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp]

@@ -44,6 +44,18 @@ def unpack_vocabulary(blob):
     return {"k": k, "L": L, "scoring": scoring, "weighting": weighting, "nodes": nodes}
 
 
+def vocabulary_to_text(blob):
+    """The text form of a vocabulary (ref: saveToTextFile, TemplatedVocabulary.h:1651-1672): "k L  scoring weighting"
+    (the reference writes two spaces there), then per node "parent leaf d0 .. d31 weight"; the weight goes through an
+    ostream at its default precision (6 significant digits, %g)."""
+    v = unpack_vocabulary(blob)
+    lines = ["%d %d  %d %d" % (v["k"], v["L"], v["scoring"], v["weighting"])]
+    for nd in v["nodes"]:
+        lines.append("%d %d %s %s" % (nd["parent"], 1 if nd["leaf"] else 0, " ".join(str(int(b)) for b in nd["desc"]) + " ",
+                                      "%g" % float(nd["weight"])))
+    return ("\n".join(lines) + "\n").encode()
+
+
 def make_synthetic_vocabulary(seed, k=10, L=3):
     """A complete k-ary tree of depth L with random 256-bit node descriptors, nodes numbered level by
     level (the stock ORBvoc is k=10, L=6, ~1.08 M nodes, ~44 MB; the file is not in the reference

@@ -14,6 +14,7 @@ class ORBVocabulary:
         self._ctx = ctx
         self._L = capi.load()
         self.k = self.L = self.scoring = self.weighting = self.nnodes = self.nwords = 0
+        self._word_weight64 = None      # text-loaded vocabularies keep double weights (Node::weight), by word id
 
     def _info(self):
         v = [C.c_int() for _ in range(6)]
@@ -22,6 +23,7 @@ class ORBVocabulary:
 
     def loadFromBinaryBlob(self, blob):
         blob = bytes(blob)
+        self._word_weight64 = None
         check(self._L.orbhip_vocab_load(self._ctx.handle, blob, len(blob)), self._ctx.handle, "orbhip_vocab_load")
         self._info()
         return True
@@ -30,7 +32,22 @@ class ORBVocabulary:
         with open(filename, "rb") as f:
             return self.loadFromBinaryBlob(f.read())
 
+    def loadFromTextFile(self, filename):             # ref: TemplatedVocabulary.h:1564-1647 (src/System.cc:335-336)
+        with open(filename, "rb") as f:
+            return self.loadFromText(f.read())
+
+    def loadFromText(self, text):
+        blob, w64 = text_to_binary(text)
+        if blob is None:
+            return False
+        self.loadFromBinaryBlob(blob)
+        nodes = np.frombuffer(blob, np.dtype([("parent", "<i4"), ("desc", "u1", 32), ("weight", "<f4"), ("leaf", "u1")]),
+                              offset=24)
+        self._word_weight64 = w64[nodes["leaf"] != 0]   # words are numbered in leaf order (:1633-1640)
+        return True
+
     def loadFromDeviceBlob(self, d_ptr, nbytes):
+        self._word_weight64 = None
         check(self._L.orbhip_vocab_load_device(self._ctx.handle, d_ptr, nbytes), self._ctx.handle,
               "orbhip_vocab_load_device")
         self._info()
@@ -51,6 +68,8 @@ class ORBVocabulary:
         """(BowVector as (word ids, values), FeatureVector as CSR) -- TemplatedVocabulary.h:1167-1258 with
         features visited in ascending index order (canonical)."""
         w, wt, nid = self.transform_raw(desc, levelsup)
+        if self._word_weight64 is not None:                            # text-loaded: the doubles of the text file
+            wt = self._word_weight64[w]
         keep = np.nonzero(wt > 0)[0]                                   # "not stopped"
         accumulate = self.weighting in (0, 1)                          # TF_IDF, TF
         words = np.unique(w[keep])
@@ -85,3 +104,20 @@ class ORBVocabulary:
         off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
         idx = (np.concatenate(lists) if lists else np.zeros(0)).astype(np.int32)
         return (words.astype(np.int32), vals), (np.array(ids, np.int32), off, idx)
+
+
+def text_to_binary(text):
+    """orbhip_vocab_text_to_binary: the text vocabulary -> (binary blob, double weight per node id 1..n), or
+    (None, None) for a malformed text.  Host only (no device, no context)."""
+    L = capi.load()
+    text = bytes(text)
+    need = C.c_size_t()
+    if L.orbhip_vocab_text_to_binary(text, len(text), None, 0, C.byref(need), None, 0) != 0:
+        return None, None
+    n = (need.value - 24) // 41
+    blob = (C.c_uint8 * need.value)()
+    w64 = np.zeros(max(n, 1), np.float64)
+    rc = L.orbhip_vocab_text_to_binary(text, len(text), blob, need.value, C.byref(need), _p(w64), n)
+    if rc != 0:
+        return None, None
+    return bytes(blob), w64[:n]
