@@ -213,6 +213,54 @@ def pipelined_throughput(args, d_img, blob, device, cap):
             "note": "same step, batch split over independent contexts / HIP streams, no per-step stage readout"}
 
 
+def host_fed_throughput(args, uniq, blob, device):
+    """The same step fed from HOST memory (the reference's frames always arrive from host memory): pinned frame buffers,
+    orbhip_pipe_* ring -- batch n + 1 crosses PCIe while batch n computes and batch n - 1's keypoints / descriptors /
+    matches come back.  Supplementary figure, never `value`."""
+    from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    Bp, depth = args.host_batch, 3
+    ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=Bp, device=device)
+    if blob is not None:
+        ORBVocabulary(ex).loadFromBinaryBlob(blob)
+    ex.pipe_create(depth, Bp, W, H)
+    if blob is not None:
+        ex.pipe_enable_bow(LEVELSUP, NNRATIO, True)
+    reps = (Bp + len(uniq) - 1) // len(uniq)
+    src = np.concatenate([uniq] * reps)[:Bp]
+    pinned = [ex.host_frames((Bp, H, W)) for _ in range(depth)]
+    for b in pinned:
+        b[:] = src
+    nb = max(2 * depth, (args.steps * args.batch + Bp - 1) // Bp)
+
+    def run(nbatches):
+        nkp = 0
+        for n in range(nbatches):
+            if n >= depth:
+                _, _, cnt = ex.pipe_wait(copy=False)
+                nkp += int(cnt.sum())
+            ex.pipe_submit(pinned[n % depth])
+        for _ in range(min(depth, nbatches)):
+            _, _, cnt = ex.pipe_wait(copy=False)
+            nkp += int(cnt.sum())
+        return nkp
+    run(depth)                                             # warm up: first-touch of the slots, clocks
+    t0 = time.perf_counter()
+    nkp = run(nb)
+    dt = time.perf_counter() - t0
+    for b in pinned:
+        ex.host_free(b)
+    ex.close()
+    fps = nb * Bp / dt
+    return {"value": round(fps, 1), "unit": "frames/s", "pinned": True, "frames_per_batch": Bp, "ring_depth": depth,
+            "batches": nb, "h2d_GBps": round(fps * W * H / 1e9, 2),
+            "d2h_GBps": round(fps * (ex.cap * (28 + 32 + (8 if blob is not None else 0)) + 8) / 1e9, 2),
+            "keypoints_per_frame": round(nkp / (nb * Bp), 1),
+            "note": "orbhip_pipe_submit / orbhip_pipe_wait: frames in pinned host memory, copy-in, kernels (extract"
+                    + (" + vocabulary transform + SearchByBoW" if blob is not None else "") + ") and copy-out of every "
+                    "batch overlapped with its neighbours'; PCIe Gen5 x16 is 63 GB/s per direction by specification"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +274,7 @@ def main():
                     "contexts (0 = skip); supplementary, never `value`")
     ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--host-batch", type=int, default=256, help="frames per batch of the host-fed pipeline figure (0 = skip)")
     ap.add_argument("--verify", type=int, default=8, help="frames of the timed batch whose GPU outputs are compared with "
                     "the oracle outside the timed region (0 = skip); a difference ends the run with exit code 3")
     args = ap.parse_args()
@@ -411,6 +460,8 @@ def main():
         }
         if world == 1 and args.pipelined > 1 and B % args.pipelined == 0:
             out["pipelined"] = pipelined_throughput(args, d_img, blob if use_bow else None, local_rank, cap)
+        if world == 1 and args.host_batch > 0:
+            out["host_fed"] = host_fed_throughput(args, uniq, blob if use_bow else None, local_rank)
         # the GPU's outputs for the first frames of the timed batch against the oracle, outside the timed region
         nver = max(0, min(args.verify, Bc))
         kept = []

@@ -117,6 +117,37 @@ int orbhip_extract_batch_device(orbhip_ctx *ctx, const void *d_imgs, int B, int 
                                 int stride, size_t frame_stride, void *d_kps, void *d_desc, int cap,
                                 void *d_counts);
 
+/* ---- host-fed pipeline (new; the reference's frames always arrive from host memory: cv::imread at
+ * Examples/Monocular/mono_euroc.cc:73, then ORBextractor::operator() via src/Frame.cc:591-597) ----
+ * A ring of `depth` (2..8) slots per context: batch n + 1 is copied to the device and batch n - 1's keypoints /
+ * descriptors are copied back while batch n computes (one copy-in stream, the context's compute stream, one copy-out
+ * stream; the results land in pinned host memory owned by the context).  Frames of w x h, up to B per batch.
+ *   orbhip_pipe_submit  enqueues one batch and returns at once.  `frames`: B images, image b at frames + b * frame_stride,
+ *                       rows `stride` bytes apart.  The copy is one asynchronous DMA when the memory is pinned
+ *                       (orbhip_host_alloc, or the caller's own hipHostMalloc / hipHostRegister); pageable memory works
+ *                       but is staged by the driver.  The caller must leave the frames alone until the batch's wait returns.
+ *                       ORBHIP_E_CAPACITY when `depth` batches are in flight and none was collected.
+ *   orbhip_pipe_wait    blocks until the OLDEST outstanding batch is complete and returns pointers into that slot's pinned
+ *                       result block: kps[b * cap + i], desc[(b * cap + i) * 32], n_out[b].  They stay valid until `depth`
+ *                       further batches have been submitted.
+ * Results are those of orbhip_extract_batch for the same frames (same kernels, same order). */
+void *orbhip_host_alloc(size_t nbytes);
+void orbhip_host_free(void *p);
+int orbhip_pipe_create(orbhip_ctx *ctx, int depth, int B, int w, int h);
+int orbhip_pipe_destroy(orbhip_ctx *ctx);
+int orbhip_pipe_submit(orbhip_ctx *ctx, const uint8_t *frames, int B, int stride, size_t frame_stride);
+int orbhip_pipe_wait(orbhip_ctx *ctx, const orbhip_keypoint **kps, const uint8_t **desc, const int32_t **n_out, int *B,
+                     int *cap);
+/* Optional matching stage of the pipeline: after the extraction of a batch, Frame::ComputeBoW (src/Frame.cc:739-746,
+ * orbhip_vocab_transform_device with `levelsup`) and ORBmatcher(nnratio, check_ori)::SearchByBoW of every frame b >= 1
+ * against frame b - 1 of the same batch (Tracking::TrackReferenceKeyFrame, src/Tracking.cc:1881-1885;
+ * orbhip_search_by_bow_seq_device with lag 1, th_mode 0) run on the device-resident outputs and their results travel back
+ * with the keypoints.  Needs a vocabulary in the context.  orbhip_pipe_matches returns, for the batch the last
+ * orbhip_pipe_wait returned, match12[b * cap + i1] (feature of frame b matched by feature i1 of frame b - 1, or -1),
+ * match21[b * cap + i2] and nmatches[b] (frame 0 of a batch: all -1 / 0). */
+int orbhip_pipe_enable_bow(orbhip_ctx *ctx, int levelsup, float nnratio, int check_ori);
+int orbhip_pipe_matches(orbhip_ctx *ctx, const int32_t **match12, const int32_t **match21, const int32_t **nmatches);
+
 /* Replaces reads of the public member std::vector<cv::Mat> mvImagePyramid
  * (include/ORBextractor.h:103; read by src/Frame.cc:817,907,919,924).  Copies level `level`
  * of frame `frame` of the last extract call to dst (rows dst_stride apart). */

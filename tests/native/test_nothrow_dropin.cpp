@@ -81,7 +81,8 @@ int main(int argc, char **argv)
     printf("voc_missing=%d\n", voc.loadFromBinaryFile("/nonexistent/ORBvoc.bin") ? 1 : 0);
     printf("voc_missing_txt=%d\n", voc.loadFromTextFile("/nonexistent/ORBvoc.txt") ? 1 : 0);
     printf("voc_bad_txt=%d\n", voc.loadFromText("42 1  0 0\n", 10) ? 1 : 0);
-    printf("voc_text=%d\nvoc_words=%u\n", voc.loadFromTextFile(argv[4]) ? 1 : 0, voc.size());
+    const bool textOk = voc.loadFromTextFile(argv[4]);
+    printf("voc_text=%d\nvoc_words=%u\n", textOk ? 1 : 0, voc.size());
     const int nd = (int)(dsc.size() / 32);
     std::vector<cv::Mat> feats(nd);
     for (int i = 0; i < nd; i++) feats[i] = cv::Mat(1, 32, CV_8U, dsc.data() + (size_t)i * 32);

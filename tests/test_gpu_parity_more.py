@@ -17,6 +17,15 @@ def _same(a, b):
     (2.0, 3, 25, 5, 500, 752, 480),
     (1.2, 1, 20, 7, 300, 320, 240),        # a single level: no resize at all
     (1.3, 3, 40, 12, 200, 400, 300),       # high thresholds: many cells fall back to minThFAST
+    # the whole threshold domain the reference's constructor accepts (cv::FAST clamps to [0, 255]):
+    (1.2, 4, 20, 0, 400, 400, 300),        # minThFAST 0 = 1: a zero-score corner never survives the strict suppression
+    (1.2, 4, 0, -5, 400, 320, 240),        # both below 1
+    (1.2, 4, 7, 20, 400, 400, 300),        # iniThFAST < minThFAST: the second run cannot add anything
+    (1.2, 4, 20, 20, 400, 400, 300),       # equal
+    (1.2, 3, 255, 30, 300, 400, 300),      # nothing can pass 255: every cell takes the second threshold
+    (1.2, 3, 300, 254, 300, 400, 300),     # clamped to 255 / almost nothing passes 254
+    (1.2, 3, 21, 8, 300, 400, 300),        # thresholds of the other parities (the byte-compare constants depend on t & 1)
+    (1.2, 3, 33, 11, 300, 400, 300),
 ])
 def test_unusual_pyramid_parameters(oracle, scale, nlev, ini, mn, nf, w, h):
     from orbhip import synth
@@ -28,7 +37,10 @@ def test_unusual_pyramid_parameters(oracle, scale, nlev, ini, mn, nf, w, h):
     rk, rd = ref(frames[0])
     for l in range(nlev):
         assert np.array_equal(ex.image_pyramid(l), ref.pyramid(l)), "pyramid level %d" % l
-    assert _same(k, rk) and np.array_equal(d, rd) and len(rk) > 50
+    assert _same(k, rk) and np.array_equal(d, rd) and (len(rk) > 50 or ini >= 254)
+    for l in range(nlev):
+        gc, rc = ex.level_candidates(l), ref.level_cands(l)
+        assert len(gc) == len(rc) and gc.tobytes() == rc.tobytes(), "FAST candidates level %d" % l
     ex.close()
     # the same through the batch kernels (>= 8 frames)
     exb = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=8)

@@ -157,3 +157,26 @@ def test_kernel_index_division_tricks_are_exact():
         assert np.array_equal((i * m) >> 20, i // spw)
     idx = np.arange(384)
     assert np.array_equal((idx * 6554) >> 16, idx // 10)
+
+
+def test_lerp_compass_formulas_are_exact_for_every_q_v_t():
+    """csrc/k_fast.hip compass4: the bytewise compare built from v_lerp_u8 ((a + b + (c & 1)) >> 1 per byte).  Emulated
+    here for every pixel pair and every threshold 1..254: bright <=> q - v > t, dark <=> q - v < -t, bit for bit."""
+    q, v = np.meshgrid(np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), indexing="ij")
+
+    def lerp(a, b, c):
+        return (a + b + (c & 1)) >> 1
+
+    for t in range(1, 255):
+        c, c2 = t & 1, (t & 1) ^ 1
+        KB = ((t + c) >> 1) + 128
+        KD = (253 + c2 - t) >> 1
+        assert 128 <= KB <= 255 and 0 <= KD <= 127
+        nv = 255 - v
+        m = lerp(q, nv, c)
+        assert m.min() >= 0 and m.max() <= 255
+        bright = lerp(m, 255 - KB, 1) >= 128
+        m2 = lerp(q, nv, c2)
+        notdark = lerp(m2, 255 - (KD + 1), 1) >= 128
+        assert np.array_equal(bright, q - v > t), t
+        assert np.array_equal(~notdark, q - v < -t), t

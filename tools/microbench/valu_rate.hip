@@ -67,6 +67,21 @@ DEF_KERNEL(k_dpp_add, "v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask
 DEF_KERNEL(k_sdwa_add, "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
 DEF_KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x36")
 DEF_KERNEL(k_cmp, "v_cmp_lt_u32 vcc, %0, %1")
+DEF_KERNEL(k_lerp, "v_lerp_u8 %0, %0, %1, %2")
+DEF_KERNEL(k_not, "v_not_b32 %0, %0")
+DEF_KERNEL(k_or, "v_or_b32 %0, %0, %1")
+DEF_KERNEL(k_and, "v_and_b32 %0, %0, %1")
+DEF_KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2")
+DEF_KERNEL(k_lshrrev, "v_lshrrev_b32 %0, 3, %0")
+DEF_KERNEL(k_pk_max_i16, "v_pk_max_i16 %0, %0, %1")
+DEF_KERNEL(k_msad, "v_msad_u8 %0, %1, %2, %0")
+DEF_KERNEL(k_sub, "v_sub_u32 %0, %0, %1")
+DEF_KERNEL(k_mov, "v_mov_b32 %0, %1")
+DEF_KERNEL(k_max_u16, "v_max_u16 %0, %0, %1")
+DEF_KERNEL(k_max_i32, "v_max_i32 %0, %0, %1")
+DEF_KERNEL(k_max_f32, "v_max_f32 %0, %0, %1")
+DEF_KERNEL(k_min3_f32, "v_min3_f32 %0, %0, %1, %2")
+DEF_KERNEL(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
 
 struct Entry {
     const char *name;
@@ -75,7 +90,8 @@ struct Entry {
 
 int main()
 {
-    Entry tab[] = {{"v_add_u32", k_add}, {"v_xor_b32", k_xor}, {"v_add3_u32", k_add3}, {"v_lshl_or_b32", k_lshl_or},
+    Entry tab[] = {{"v_lerp_u8", k_lerp}, {"v_not_b32", k_not}, {"v_or_b32", k_or}, {"v_and_b32", k_and}, {"v_or3_b32", k_or3}, {"v_lshrrev_b32", k_lshrrev}, {"v_pk_max_i16", k_pk_max_i16}, {"v_msad_u8", k_msad}, {"v_sub_u32", k_sub}, {"v_mov_b32", k_mov}, {"v_max_u16", k_max_u16}, {"v_max_i32", k_max_i32}, {"v_max_f32", k_max_f32}, {"v_min3_f32", k_min3_f32}, {"v_mad_u32_u24", k_mad_u32_u24},
+                   {"v_add_u32", k_add}, {"v_xor_b32", k_xor}, {"v_add3_u32", k_add3}, {"v_lshl_or_b32", k_lshl_or},
                    {"v_and_or_b32", k_and_or}, {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_alignbyte_b32", k_alignbyte},
                    {"v_min3_i32", k_min3_i32}, {"v_max3_i32", k_max3_i32}, {"v_min_i32", k_min_i32},
                    {"v_mad_i32_i24", k_mad_i24}, {"v_mul_i32_i24", k_mul_i24}, {"v_mul_lo_u32", k_mul_lo},

@@ -212,7 +212,7 @@ __device__ __forceinline__ uint32_t nms_key(const uint8_t *s_score, int SP, int 
     return ((uint32_t)cj << 28) | ((uint32_t)r << 21) | ((uint32_t)c << 8) | (uint32_t)s;
 }
 
-__global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *__restrict__ lvl0,
+__global__ __launch_bounds__(256) void k_fast_v1(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                               int stride0, unsigned long long frame0,
                                               const uint8_t *__restrict__ pyr,
                                               unsigned long long pyrFrame,
@@ -484,12 +484,417 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevels G, const uint8_t *
     if (tid < T.ncells) cnt[tid] = (uint16_t)s_cellCnt[tid];
 }
 
+
+// =====================================================================================================================
+// k_fast (r02): the reference's own control flow -- FAST at iniThFAST first, FAST at minThFAST only for the cells the first
+// run left empty (src/ORBextractor.cc:811-818) -- on the whole-level formulation.
+//
+// Exactness: the score of a pixel does not depend on the detection threshold and "corner at t" <=>
+// "score >= t", so cv::FAST(cell, t, nonmax) = { p : s(p) >= t and s(p) > s(q) for the 8 neighbours q of the same cell with
+// s(q) >= t }, and a neighbour below t is smaller than s(p) anyway: the suppression at threshold t only needs the scores
+// >= t.  Pass 0 therefore computes only the scores >= iniThFAST (compass test, work list, arc score: all at iniThFAST),
+// suppresses among them, and the survivors are final: their cell is not empty.  Pass 1 repeats the three steps at
+// minThFAST for the pixels of the cells without a survivor (NOT "without a corner": two equal neighbouring maxima suppress
+// each other, and the reference then reruns the cell) and every survivor of it is final as well.  On textured frames pass 0
+// scores 14 % of the pixels instead of 24-28 %, and pass 1 touches a fifth of the cells (low contrast: 6 % of their pixels
+// pass the compass test).
+//
+// Phases of a pass (one 256-thread workgroup per run of <= 5 cells, as before):
+//   2. compass test, 4 pixels per item.  A thread keeps ONE dword column of the tile and walks down the rows in steps of
+//      RS = 256 / (active dword columns): no division per item, the domain / active-cell mask is a per-thread constant, the
+//      list entry of a survivor is a multiply-add of its bit position (r01 parked an entry per item in LDS and read it back
+//      per survivor: a dependent LDS round trip in a divergent loop).  Bytes are split into even / odd halves with one
+//      v_and and one v_perm per dword instead of two v_perm.
+//   3. arc score on the work list (fast_score_pol: packed halves, v_pk_minimum3/maximum3_f16), corners -> score tile +
+//      corner list.
+//   4. suppression over the corner list; a survivor sets its bit in the per-(cell, row) bitmap directly -- every survivor
+//      of either pass is kept, so the keyed survivor list and the per-cell threshold of r01 are gone.
+//   5. (after both passes) row prefix of the bitmap, survivors written to their cell's slots in raster order.
+// Bounded lists with exact fallbacks as before (dense scoring of the active cells; scan of the score tile).
+// =====================================================================================================================
+
+// ---- compass test of the 4 pixels of an aligned dword in byte arithmetic (v_lerp_u8) ----
+// v_lerp_u8 d, a, b, c computes per byte (a + b + (c & 1)) >> 1 in 9 bits: with b = ~v it is floor((q - v + 255 + c) / 2), a
+// monotone map of the difference d = q - v into a byte, and with b = ~K, c = 1 it is (m - K + 256) >> 1 whose bit 7 says
+// m >= K -- a bytewise unsigned compare in one instruction.  Halving loses the parity of d, so the rounding bit is chosen
+// per threshold such that the cut falls between two values of the halved quantity:
+//   bright  q - v > t   <=>  d + 255 + c  >= t + 256 + c (even for c = t & 1)        <=>  floor((d + 255 + c) / 2)  >= KB
+//   dark    q - v < -t  <=>  d + 255 + c' <= 254 + c' - t (odd for c' = (t + 1) & 1)  <=>  floor((d + 255 + c') / 2) <= KD
+// (exhaustive check over all q, v, t: tests/test_host_logic.py).  Four instructions per neighbour dword instead of the
+// unpack / packed-16-bit sequence of r01 (16 v_lerp + 5 bit operations per 4 pixels instead of 22 v_pk + 10 unpack).
+struct CompassK {
+    uint32_t cb, cd;     // rounding bits (0x01010101 or 0) of the bright / dark map
+    uint32_t nkb, nkd;   // ~KB, ~(KD + 1) in every byte
+};
+__device__ __forceinline__ CompassK compass_consts(int t)
+{
+    // 1 <= t <= 254 (t = 255 admits no corner; the caller skips the pass)
+    const uint32_t ONES = 0x01010101u;
+    const int c = t & 1, c2 = c ^ 1;
+    const int KB = ((t + c) >> 1) + 128;          // <= 255
+    const int KD = (253 + c2 - t) >> 1;           // >= 0
+    CompassK K;
+    K.cb = c ? ONES : 0u;
+    K.cd = c2 ? ONES : 0u;
+    K.nkb = ~((uint32_t)KB * ONES);
+    K.nkd = ~((uint32_t)(KD + 1) * ONES);
+    return K;
+}
+// bit 7 of byte k of the result <=> pixel k of Cw passes the compass test (before the domain mask)
+__device__ __forceinline__ uint32_t compass4(uint32_t Cw, uint32_t Tw, uint32_t Bw, uint32_t lft, uint32_t rgt, const CompassK &K)
+{
+    const uint32_t ONES = 0x01010101u;
+    const uint32_t nv = ~Cw;
+#define ORB_BRIGHT(q) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp((q), nv, K.cb), K.nkb, ONES)   /* bit 7: q - v > t      */
+#define ORB_NOTDARK(q) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp((q), nv, K.cd), K.nkd, ONES)  /* bit 7: !(q - v < -t) */
+    const uint32_t bT = ORB_BRIGHT(Tw), bB = ORB_BRIGHT(Bw), bL = ORB_BRIGHT(lft), bR = ORB_BRIGHT(rgt);
+    const uint32_t dT = ORB_NOTDARK(Tw), dB = ORB_NOTDARK(Bw), dL = ORB_NOTDARK(lft), dR = ORB_NOTDARK(rgt);
+#undef ORB_BRIGHT
+#undef ORB_NOTDARK
+    const uint32_t bright = (bT | bB) & (bL | bR);
+    const uint32_t notdark = (dT & dB) | (dL & dR);
+    return bright | ~notdark;
+}
+
+__device__ __forceinline__ bool nms_survives(const uint8_t *s_score, int SP, int r, int c, int DH, int TW, int wCell, int cj)
+{
+    const uint8_t *sp = s_score + r * SP + c;
+    const int s = sp[0];
+    const int cx0 = cj * wCell;
+    int cx1 = cx0 + wCell;
+    if (cx1 > TW) cx1 = TW;
+    const bool up = r > 0, dn = r < DH - 1, lf = c > cx0, rt = c < cx1 - 1;
+    int m = 0;
+    if (lf) m = max(m, (int)sp[-1]);
+    if (rt) m = max(m, (int)sp[1]);
+    if (up) {
+        m = max(m, (int)sp[-SP]);
+        if (lf) m = max(m, (int)sp[-SP - 1]);
+        if (rt) m = max(m, (int)sp[-SP + 1]);
+    }
+    if (dn) {
+        m = max(m, (int)sp[SP]);
+        if (lf) m = max(m, (int)sp[SP - 1]);
+        if (rt) m = max(m, (int)sp[SP + 1]);
+    }
+    return s > m;
+}
+
+__global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_t *__restrict__ lvl0, int stride0,
+                                              unsigned long long frame0, const uint8_t *__restrict__ pyr,
+                                              unsigned long long pyrFrame, const FastTile *__restrict__ tiles,
+                                              uint32_t *__restrict__ cand, uint16_t *__restrict__ cellCnt, int pixBytes,
+                                              int scoreBytes, int listBytes, int cornerBytes, int bitsBytes, int listCap,
+                                              int cornerCap, int phases, int xcdMap, int ntiles)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_cellAny[FAST_TILE_CELLS];
+    __shared__ int s_cellCnt[FAST_TILE_CELLS];
+    __shared__ int s_listCount, s_cornerCount, s_nAct;
+    __shared__ uint8_t s_grp[FAST_MAX_TILE_W / 4 + 8];
+
+    const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
+    if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
+    const FastTile T = tiles[tileId];
+    const OrbLevel &L = G.lv[T.level];
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    const int maxBX = L.w - ORB_MIN_BORDER, maxBY = L.h - ORB_MIN_BORDER;
+    const int iniY = ORB_MIN_BORDER + T.row * L.hCell;
+    const int X0 = ORB_MIN_BORDER + T.c0 * L.wCell;
+    int maxY = iniY + L.hCell + 6;
+    if (maxY > maxBY) maxY = maxBY;
+    int X1 = ORB_MIN_BORDER + (T.c0 + T.ncells) * L.wCell + 6;
+    if (X1 > maxBX) X1 = maxBX;
+    // :797-798 / :805-806 -- rows and columns the reference skips produce nothing
+    const bool rowLive = iniY < maxBY - 3;
+    const int DH = rowLive ? maxY - iniY - 6 : 0;       // domain rows
+    const int TW = X1 - X0 - 6;                          // domain columns of the whole run
+    uint16_t *cnt = cellCnt + (size_t)frame * G.totalCells + L.cellBase + T.row * L.nCols + T.c0;
+    if (DH <= 0 || TW <= 0) {
+        if (tid < T.ncells) cnt[tid] = 0;
+        return;
+    }
+    int stride;
+    const uint8_t *img = level_ptr(G, T.level, frame, lvl0, stride0, frame0, pyr, pyrFrame, stride);
+
+    // ---- 1. stage pixels [iniY, maxY) x [XA, X1) into LDS, 16 bytes per lane per load; clear the score tile and the bitmap ----
+    const int XA = X0 & ~15;
+    const int nchunk = (X1 - XA + 15) >> 4;
+    const int pitch = nchunk << 4;
+    const int RH = maxY - iniY;
+    uint8_t *s_pix = smem;
+    uint8_t *s_score = smem + pixBytes;
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(smem + pixBytes + scoreBytes);
+    uint16_t *s_corner = reinterpret_cast<uint16_t *>(smem + pixBytes + scoreBytes + listBytes);
+    unsigned long long *s_bits = reinterpret_cast<unsigned long long *>(smem + pixBytes + scoreBytes + listBytes + cornerBytes);   // [ncells][DH]; wCell < 64
+    int *s_pre = reinterpret_cast<int *>(smem + pixBytes + scoreBytes + listBytes + cornerBytes + bitsBytes);                       // [ncells][DH]
+    const int SP = (TW + 3) & ~3;
+    const float invNchunk = 1.0f / (float)nchunk;   // i / nchunk = floor((i + 0.5) * invNchunk), exact for i < 2^16
+    for (int i = tid; i < RH * nchunk; i += 256) {
+        const int r = (int)(((float)i + 0.5f) * invNchunk), c = i - r * nchunk;
+        const uint4 v = *reinterpret_cast<const uint4 *>(img + (size_t)(iniY + r) * stride + XA + (c << 4));
+        *reinterpret_cast<uint4 *>(s_pix + r * pitch + (c << 4)) = v;
+    }
+    const int nrowsAll = T.ncells * DH;
+    for (int i = tid; i < (DH * SP + 15) >> 4; i += 256) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);   // scoreBytes is a multiple of 16
+    for (int i = tid; i < nrowsAll; i += 256) s_bits[i] = 0ull;
+    if (tid < FAST_TILE_CELLS) {
+        s_cellAny[tid] = 0;
+        s_cellCnt[tid] = 0;
+    }
+    if (tid == 0) {
+        s_listCount = 0;
+        s_cornerCount = 0;
+        s_nAct = 0;
+    }
+    __syncthreads();
+    if (phases < 2) return;   // timing ablation only (ORBHIP_FAST_PHASES), results are then invalid
+
+    const int j0 = X0 + 3 - XA;            // LDS column of domain column 0
+    const int jd0 = j0 & ~3;               // first aligned dword column touching the domain
+    const int GPR = ((j0 + TW + 3) >> 2) - (j0 >> 2);   // dword groups per row
+    const int wCell = L.wCell;
+    const unsigned cellMagic = 65536u / (unsigned)wCell + 1u;   // c / wCell for c < 65536 / wCell
+    const unsigned allCells = (1u << T.ncells) - 1u;
+
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: every cell at iniThFAST; pass 1: the cells without a survivor at minThFAST (block-uniform decisions)
+        const int t = pass == 0 ? G.iniTh : G.minTh;
+        unsigned cellMask = allCells;
+        if (pass == 1) {
+            if (G.minTh >= G.iniTh) break;   // FAST(ini) empty => FAST(min >= ini) empty
+            cellMask = 0;
+            for (int cj = 0; cj < T.ncells; cj++)
+                if (!s_cellAny[cj]) cellMask |= 1u << cj;
+            if (cellMask == 0) break;
+        }
+        if (t >= 255) continue;   // no pixel differs from its centre by more than 255: no corner at all (block-uniform)
+        const CompassK CK = compass_consts(t);
+
+        // ---- 2. compass pre-test, 4 pixels per item; survivors -> work list ----
+        int nAct = GPR;
+        if (pass == 1) {
+            // dword groups that hold a domain pixel of an active cell (any order)
+            for (int g = tid; g < GPR; g += 256) {
+                bool act = false;
+                for (int k = 0; k < 4; k++) {
+                    const int c = jd0 + (g << 2) + k - j0;
+                    if (c >= 0 && c < TW && ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u)) act = true;
+                }
+                if (act) s_grp[atomicAdd(&s_nAct, 1)] = (uint8_t)g;
+            }
+            if (tid == 0) {
+                s_listCount = 0;
+                s_cornerCount = 0;
+            }
+            __syncthreads();
+            nAct = s_nAct;
+        }
+        // threads taking part: all of them in pass 0; in pass 1 about one per five items (whole waves), so that a tile with one
+        // empty cell does not pay four waves' worth of fixed cost (scan, masks) for 300 items
+        int nthr = 256;
+        if (pass == 1) {
+            const int want = (__mul24(nAct, DH) + 319) / 320;            // waves at ~5 items per thread
+            const int need = (nAct + 63) >> 6;                           // at least one thread per column
+            nthr = min(4, max(want, need)) << 6;
+        }
+        if ((tid & ~63) < nthr) {
+            // thread -> (dword column, first row): tid = r0 * nAct + slot; rows r0, r0 + RS, ... (RS = nthr / nAct >= 1)
+            const float invAct = 1.0f / (float)nAct;
+            const int r0 = (int)(((float)tid + 0.5f) * invAct);
+            const int slot = tid - r0 * nAct;
+            const int RS = (int)(((float)nthr + 0.5f) * invAct);
+            const bool mine = r0 < RS;
+            const int g = pass == 0 ? slot : (int)s_grp[mine ? slot : 0];
+            const int jd = jd0 + (g << 2);
+            // domain / active-cell mask of my four pixels (pixel k at bit 8k + 7)
+            uint32_t dom = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = jd + k - j0;
+                bool in = c >= 0 && c < TW;
+                if (pass == 1) in = in && ((cellMask >> ((unsigned)(in ? c : 0) * cellMagic >> 16)) & 1u);
+                if (in) dom |= 0x80u << (8 * k);
+            }
+            const int rowStep = __mul24(RS, pitch);
+            const int RSsh = RS << 9;
+            const uint32_t listCountAddr = (uint32_t)(uintptr_t)&s_listCount;   // LDS byte address (low half of the flat address)
+            for (int rbase = 0; rbase < DH; rbase += 8 * RS) {
+                // acc: bit (8 * k + i) = pixel k of this thread's i-th row of the chunk
+                uint32_t acc = 0;
+                const uint8_t *row = s_pix + __mul24(rbase + r0 + 3, pitch) + jd;
+                const int rlim = mine ? DH - rbase - r0 : 0;   // item i exists <=> i * RS < rlim
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (__mul24(i, RS) < rlim) {
+                        const uint32_t Cw = *reinterpret_cast<const uint32_t *>(row);
+                        const uint32_t Lw = *reinterpret_cast<const uint32_t *>(row - 4);
+                        const uint32_t Rw = *reinterpret_cast<const uint32_t *>(row + 4);
+                        const uint32_t Tw = *reinterpret_cast<const uint32_t *>(row - 3 * pitch);
+                        const uint32_t Bw = *reinterpret_cast<const uint32_t *>(row + 3 * pitch);
+                        const uint32_t lft = __builtin_amdgcn_alignbyte(Cw, Lw, 1);   // bytes L1 L2 L3 C0 (column - 3)
+                        const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
+                        const uint32_t z = compass4(Cw, Tw, Bw, lft, rgt, CK);
+                        acc |= (z & dom) >> (7 - i);
+                    }
+                    row += rowStep;
+                }
+                // append this thread's survivors to the work list (order is irrelevant): one returning LDS add per thread
+                // claims its range (r01 ran a DPP wave scan + one add per wave: ~45 vector instructions per chunk; the LDS
+                // unit serialises the 64 adds instead, and it has the cycles to spare).  A thread whose entries do not all
+                // fit writes none: s_listCount then exceeds listCap and phase 3 takes the fallback.
+                const int n = __popc(acc);
+                if (n > 0) {
+                    // (inline asm: hipcc's atomic optimiser would turn a plain atomicAdd of a per-lane value back into a DPP scan)
+                    int base;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(listCountAddr), "v"(n) : "memory");
+                    if (base + n <= listCap) {
+                        uint16_t *dst = s_list + base;
+                        const int entBase = ((rbase + r0) << 9) | jd;
+                        while (acc) {
+                            const int b = __ffs(acc) - 1;
+                            acc &= acc - 1;
+                            *dst++ = (uint16_t)(entBase + (int)__umul24((unsigned)(b & 7), (unsigned)RSsh) + (b >> 3));   // (row << 9) | LDS column
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (phases < 3 + 3 * pass) return;   // ablation stops: 2-4 = phases of pass 0, 5-7 = of pass 1
+
+        // ---- 3. full score on the work list; corners (score >= t) -> score tile + corner list ----
+        // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel of the
+        // active cells is scored instead (the compass test is the early-out of fast_score_pol); if it has more corners
+        // than the corner list holds, phase 4 scans the score tile.  Both fallbacks produce the same result.
+        const int nlist = s_listCount;
+        if (nlist <= listCap) {
+            for (int e = tid; e < nlist; e += 256) {
+                const int ent = s_list[e];
+                const int r = ent >> 9, j = ent & 511;
+                const int s = fast_score_pol(s_pix + __mul24(r + 3, pitch) + j, pitch, t);
+                if (s > 0) {
+                    s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
+                    const int slot = atomicAdd(&s_cornerCount, 1);   // hipcc aggregates this per wave
+                    if (slot < cornerCap) s_corner[slot] = (uint16_t)ent;
+                }
+            }
+        } else {
+            const float invTW = 1.0f / (float)TW;   // px / TW = floor((px + 0.5) * invTW): exact for every px < DH * TW (a 20-bit
+                                                     // integer reciprocal is NOT: it fails from px ~ 2^20 / TW on, e.g. TW 155, DH 45)
+            for (int p0 = 0; p0 < DH * TW; p0 += 256) {
+                const int px = p0 + tid;
+                int ent = 0, s = 0;
+                if (px < DH * TW) {
+                    const int r = (int)(((float)px + 0.5f) * invTW);
+                    const int c = px - r * TW;
+                    if ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u) {
+                        s = fast_score_pol(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
+                        if (s > 0) s_score[r * SP + c] = (uint8_t)s;
+                    }
+                    ent = (r << 9) | (j0 + c);
+                }
+                const int slot = wave_append(s > 0, &s_cornerCount, lane);
+                if (slot >= 0 && slot < cornerCap) s_corner[slot] = (uint16_t)ent;
+            }
+        }
+        __syncthreads();
+        if (phases < 4 + 3 * pass) return;
+
+        // ---- 4. NMS over the corners (cell-local neighbourhood); every survivor is final: set its bit ----
+        const int ncorner = s_cornerCount;
+        if (ncorner <= cornerCap) {
+            for (int e = tid; e < ncorner; e += 256) {
+                const int ent = s_corner[e];
+                const int r = ent >> 9, c = (ent & 511) - j0;
+                const int cj = (int)(((unsigned)c * cellMagic) >> 16);
+                if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) {
+                    atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * wCell));
+                    s_cellAny[cj] = 1;   // benign race: every writer stores 1
+                }
+            }
+        } else {
+            // fallback: scan the score tile, 4 pixels per dword; only the active cells' corners of this pass (score >= t)
+            const int SPW = SP >> 2;                                       // score dwords per row
+            const unsigned spwMagic = (1u << 20) / (unsigned)SPW + 1u;
+            const int nwords = DH * SPW;
+            for (int i = tid; i < nwords; i += 256) {
+                const uint32_t w = reinterpret_cast<const uint32_t *>(s_score)[i];
+                if (w == 0) continue;
+                const int r = (int)(((unsigned)i * spwMagic) >> 20);
+                const int cb = (i - r * SPW) << 2;
+                for (int k = 0; k < 4; k++) {
+                    const int s = (w >> (8 * k)) & 0xFF;
+                    const int c = cb + k;
+                    if (s < t || c >= TW) continue;
+                    const int cj = (int)(((unsigned)c * cellMagic) >> 16);
+                    if (!((cellMask >> cj) & 1u)) continue;
+                    if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) {
+                        atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * wCell));
+                        s_cellAny[cj] = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (phases < 5 + 3 * pass) return;
+    }
+
+    // ---- 5. rank inside the cell (= raster order) from the bitmap, write the slots ----
+    // The rank of a survivor is the number of bits before it: a prefix over the rows of its cell plus a popcount inside its
+    // row -- no survivor is ever compared with another one.
+    if (DH <= 64) {
+        // one wave per cell, one lane per row: the row prefix is a wave scan of the row popcounts
+        for (int cj = tid >> 6; cj < T.ncells; cj += 4) {
+            const int n = lane < DH ? __popcll(s_bits[cj * DH + lane]) : 0;
+            const int incl = wave_incl_scan_dpp(n);
+            if (lane < DH) s_pre[cj * DH + lane] = incl - n;
+            if (lane == 63) s_cellCnt[cj] = incl;
+        }
+    } else {
+        const unsigned dhMagic = 65536u / (unsigned)DH + 1u;   // i / DH for i < 65536 / DH
+        for (int i = tid; i < nrowsAll; i += 256) {
+            const int cj = (int)(((unsigned)i * dhMagic) >> 16), r = i - cj * DH;
+            int pre = 0;
+            for (int rr = 0; rr < r; rr++) pre += __popcll(s_bits[cj * DH + rr]);
+            s_pre[i] = pre;
+            if (r == DH - 1) s_cellCnt[cj] = pre + __popcll(s_bits[i]);
+        }
+    }
+    __syncthreads();
+    const size_t candFrame = (size_t)frame * G.totalCands + L.candBase;
+    {
+        const unsigned dhMagic = 65536u / (unsigned)DH + 1u;
+        for (int i = tid; i < nrowsAll; i += 256) {
+            unsigned long long bits = s_bits[i];
+            if (bits == 0ull) continue;
+            const int cj = (int)(((unsigned)i * dhMagic) >> 16), r = i - cj * DH;
+            int rank = s_pre[i];
+            uint32_t *slot = cand + candFrame + (size_t)(T.row * L.nCols + T.c0 + cj) * L.cellCap;
+            const int py = iniY + 3 + r - ORB_MIN_BORDER;                     // relative to (16,16), :824-825
+            const int pxBase = X0 + 3 + cj * wCell - ORB_MIN_BORDER;
+            const uint8_t *sc = s_score + r * SP + cj * wCell;
+            while (bits) {
+                const int cl = __ffsll((long long)bits) - 1;
+                bits &= bits - 1ull;
+                slot[rank++] = (uint32_t)(pxBase + cl) | ((uint32_t)py << 12) | ((uint32_t)sc[cl] << 24);
+            }
+        }
+    }
+    // cells whose iniX >= maxBorderX-6 are skipped by the reference (:805): their domain is empty -> 0
+    if (tid < T.ncells) cnt[tid] = (uint16_t)s_cellCnt[tid];
+}
+
 void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
                  uint32_t *cand, uint16_t *cellCnt, int B)
 {
+    // the r01 kernel (A/B runs only: ORBHIP_FAST_V1=1) assumes 1 <= minThFAST <= iniThFAST < 255
+    static const int v1env = getenv("ORBHIP_FAST_V1") ? atoi(getenv("ORBHIP_FAST_V1")) : 0;
+    const int v1 = v1env && G.minTh <= G.iniTh && G.iniTh < 255;
     // LDS: pixel tile + score tile + work list of the largest run over all levels
-    int pixBytes = 0, scoreBytes = 0, listBytes = 0, survBytes = 0;
+    int pixBytes = 0, scoreBytes = 0, listBytes = 0, survBytes = 0, bitsRows = 0;
     for (int l = 0; l < G.nlevels; l++) {
         const OrbLevel &L = G.lv[l];
         int tileCells = fast_tile_cells();
@@ -504,22 +909,36 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
         // a quarter of the pixels plus cell seams) reuses the same storage
         listBytes = std::max(listBytes, sp * L.hCell * 2);
         survBytes = std::max(survBytes, tileCells * L.cellCap * 4);
+        bitsRows = std::max(bitsRows, tileCells * L.hCell);
     }
     pixBytes = (pixBytes + 15) & ~15;
     scoreBytes = (scoreBytes + 15) & ~15;
-    // fixed list budgets (entries): work list = half of the tile's pixels, corner list = an eighth;
-    // tiles that exceed them take the exact fallback paths.  ORBHIP_FAST_LISTCAP forces tiny lists
-    // (tests exercise the fallbacks with it).
     static const int forced = getenv("ORBHIP_FAST_LISTCAP") ? atoi(getenv("ORBHIP_FAST_LISTCAP")) : 0;
-    int listCap = listBytes / 4, cornerCap = listBytes / 16;
-    if (forced > 0) listCap = cornerCap = forced;
-    // the survivor list (u32 per strict local maximum, at most survBytes/4 of them) shares the work list
-    listBytes = std::max(listCap * 2, survBytes);
-    listBytes = (listBytes + 15) & ~15;
-    const int cornerBytes = (cornerCap * 2 + 15) & ~15;
-    static const int phases = getenv("ORBHIP_FAST_PHASES") ? atoi(getenv("ORBHIP_FAST_PHASES")) : 5;
+    static const int phases = getenv("ORBHIP_FAST_PHASES") ? atoi(getenv("ORBHIP_FAST_PHASES")) : 99;
     dim3 grid(orb_xcd_grid(ntiles), B, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(k_fast, grid, block, (size_t)(pixBytes + scoreBytes + listBytes + cornerBytes), s, G, lvl0, stride0,
-                       (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tiles, cand, cellCnt,
-                       pixBytes, scoreBytes, listBytes, listCap, cornerCap, phases, orb_xcd_arg(), ntiles);
+    if (v1) {
+        // fixed list budgets (entries): work list = half of the tile's pixels, corner list = an eighth;
+        // tiles that exceed them take the exact fallback paths.  ORBHIP_FAST_LISTCAP forces tiny lists
+        // (tests exercise the fallbacks with it).
+        int listCap = listBytes / 4, cornerCap = listBytes / 16;
+        if (forced > 0) listCap = cornerCap = forced;
+        // the survivor list (u32 per strict local maximum, at most survBytes/4 of them) shares the work list
+        listBytes = std::max(listCap * 2, survBytes);
+        listBytes = (listBytes + 15) & ~15;
+        const int cornerBytes = (cornerCap * 2 + 15) & ~15;
+        hipLaunchKernelGGL(k_fast_v1, grid, block, (size_t)(pixBytes + scoreBytes + listBytes + cornerBytes), s, G, lvl0, stride0,
+                           (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tiles, cand, cellCnt,
+                           pixBytes, scoreBytes, listBytes, listCap, cornerCap, phases, orb_xcd_arg(), ntiles);
+        return;
+    }
+    // r02 kernel: work list = a quarter of the tile's pixels (the first pass runs at iniThFAST), corner list = a sixteenth;
+    // bitmap and row prefix per (cell, row).  Tiles that exceed the lists take the exact fallback paths.
+    const int px = listBytes / 2;                      // sp * hCell of the largest tile
+    int listCap = px / 4, cornerCap = px / 16;
+    if (forced > 0) listCap = cornerCap = forced;
+    const int lBytes = (listCap * 2 + 15) & ~15, cBytes = (cornerCap * 2 + 15) & ~15;
+    const int bitsBytes = (bitsRows * 8 + 15) & ~15, preBytes = (bitsRows * 4 + 15) & ~15;
+    hipLaunchKernelGGL(k_fast, grid, block, (size_t)(pixBytes + scoreBytes + lBytes + cBytes + bitsBytes + preBytes), s, G, lvl0,
+                       stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tiles, cand, cellCnt, pixBytes,
+                       scoreBytes, lBytes, cBytes, bitsBytes, listCap, cornerCap, phases, orb_xcd_arg(), ntiles);
 }

@@ -26,11 +26,15 @@ int fast_tile_cells()
 int orb_init_tables(orbhip_ctx *c, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh)
 {
     if (nfeatures < 1 || nlevels < 1 || nlevels > ORBHIP_MAX_LEVELS || !(scaleFactor > 1.0f)) return ORBHIP_E_ARG;
-    if (minTh < 1 || iniTh < minTh || iniTh > 255) return ORBHIP_E_ARG;
+    // FAST thresholds: the reference passes whatever the settings file holds to cv::FAST, which clamps to [0, 255]
+    // (OpenCV 2.4 fast.cpp: threshold = min(max(threshold, 0), 255)).  Threshold 0 equals threshold 1 here: a corner of
+    // score 0 never beats its neighbours' 0 in the strict non-maximum suppression.  iniThFAST < minThFAST is legal too (the
+    // second run then finds nothing the first did not) -- k_fast's passes handle every combination.
+    auto eff = [](int t) { return std::max(std::min(std::max(t, 0), 255), 1); };
     c->nfeatures = nfeatures;
     c->nlevels = nlevels;
-    c->iniTh = iniTh;
-    c->minTh = minTh;
+    c->iniTh = eff(iniTh);
+    c->minTh = eff(minTh);
     c->scaleFactor = (double)scaleFactor;  // the member is a double (include/ORBextractor.h:116)
     c->mvScaleFactor[0] = 1.0f;
     c->mvLevelSigma2[0] = 1.0f;

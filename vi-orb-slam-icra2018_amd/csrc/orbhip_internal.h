@@ -94,6 +94,25 @@ struct OrbVocabDev {
     float *eweight = nullptr;
 };
 
+// Host-fed pipeline (orbhip_pipe_*): a ring of `depth` device input slots and device / pinned-host output slots, a
+// copy-in and a copy-out stream beside the context's compute stream.
+struct OrbPipe {
+    int depth = 0, B = 0, w = 0, h = 0, stride = 0, dcap = 0;
+    size_t frameBytes = 0, inBytes = 0, outBytes = 0, koff = 0, doff = 0, coff = 0;
+    hipStream_t sIn = nullptr, sOut = nullptr;
+    std::vector<uint8_t *> d_in, d_out, h_out;
+    std::vector<hipEvent_t> evIn, evK, evOut;
+    std::vector<int> slotB;
+    long submitted = 0, waited = 0;
+    // optional matching stage (orbhip_pipe_enable_bow): vocabulary transform + SearchByBoW of frame b against frame b - 1
+    bool bow = false;
+    int levelsup = 4, check_ori = 1;
+    float nnratio = 0.7f;
+    size_t m12off = 0, m21off = 0, nmoff = 0;   // inside an output slot, behind the counts
+    uint8_t *d_bowScratch = nullptr;            // word | weight | node, B * dcap entries each
+    int lastWaited = -1;
+};
+
 struct orbhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -173,6 +192,9 @@ struct orbhip_ctx {
     // vocabulary
     OrbVocabDev voc;
     void *d_vocBlock = nullptr;
+
+    // host-fed pipeline
+    OrbPipe *pipe = nullptr;
 
     // RCCL
     void *comm = nullptr;

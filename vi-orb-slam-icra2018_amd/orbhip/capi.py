@@ -21,7 +21,8 @@ MAX_LEVELS = 16
 SYMBOLS = [
     "orbhip_device_count", "orbhip_create", "orbhip_destroy", "orbhip_last_error", "orbhip_sync",
     "orbhip_stream", "orbhip_get_tables", "orbhip_tables", "orbhip_max_keypoints", "orbhip_level_size",
-    "orbhip_extract", "orbhip_extract_batch", "orbhip_extract_batch_device",
+    "orbhip_extract", "orbhip_extract_batch", "orbhip_extract_batch_device", "orbhip_host_alloc", "orbhip_host_free",
+    "orbhip_pipe_create", "orbhip_pipe_destroy", "orbhip_pipe_submit", "orbhip_pipe_wait", "orbhip_pipe_enable_bow", "orbhip_pipe_matches",
     "orbhip_get_pyramid_level", "orbhip_debug_get_blurred_level", "orbhip_debug_get_candidates",
     "orbhip_debug_get_level_keypoints", "orbhip_hamming_knn2", "orbhip_hamming_knn2_device",
     "orbhip_hamming_knn2_seq_device", "orbhip_get_stage_times", "orbhip_vocab_load", "orbhip_vocab_load_device",
@@ -83,6 +84,16 @@ def load():
     L.orbhip_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, ip, vp]
     L.orbhip_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     L.orbhip_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, C.c_size_t, vp, vp, i32, vp]
+    L.orbhip_host_alloc.argtypes = [C.c_size_t]
+    L.orbhip_host_alloc.restype = vp
+    L.orbhip_host_free.argtypes = [vp]
+    L.orbhip_host_free.restype = None
+    L.orbhip_pipe_create.argtypes = [vp, i32, i32, i32, i32]
+    L.orbhip_pipe_destroy.argtypes = [vp]
+    L.orbhip_pipe_submit.argtypes = [vp, vp, i32, i32, C.c_size_t]
+    L.orbhip_pipe_wait.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip, ip]
+    L.orbhip_pipe_enable_bow.argtypes = [vp, i32, f32, i32]
+    L.orbhip_pipe_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.orbhip_get_pyramid_level.argtypes = [vp, i32, i32, vp, i32, ip, ip]
     L.orbhip_debug_get_blurred_level.argtypes = [vp, i32, i32, vp, i32, ip, ip]
     L.orbhip_debug_get_candidates.argtypes = [vp, i32, i32, vp, i32, ip]

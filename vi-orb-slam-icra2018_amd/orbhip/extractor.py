@@ -111,6 +111,65 @@ class ORBextractor:
                                                   cap, d_counts), self._h, "orbhip_extract_batch_device")
         self._shape = (H, W)
 
+    # -- host-fed pipeline (orbhip_pipe_*): batches from host memory, copies overlapped with the kernels --
+    def pipe_create(self, depth, B, W, H):
+        check(self._L.orbhip_pipe_create(self._h, depth, B, W, H), self._h, "orbhip_pipe_create")
+        self._shape = (H, W)
+
+    def pipe_destroy(self):
+        check(self._L.orbhip_pipe_destroy(self._h), self._h, "orbhip_pipe_destroy")
+
+    def pipe_submit(self, frames):
+        """frames: (B, H, W) uint8 array (pinned: see host_frames) or (address, B, stride, frame_stride)."""
+        if isinstance(frames, tuple):
+            addr, B, stride, fs = frames
+        else:
+            assert frames.dtype == np.uint8 and frames.ndim == 3 and frames.strides[2] == 1
+            addr, B, stride, fs = frames.ctypes.data, frames.shape[0], frames.strides[1], frames.strides[0]
+        check(self._L.orbhip_pipe_submit(self._h, addr, B, stride, fs), self._h, "orbhip_pipe_submit")
+
+    def pipe_wait(self, copy=True):
+        """Results of the oldest outstanding batch: lists of per-frame keypoints / descriptors (copies), or with
+        copy=False the raw views (kps (B, cap), desc (B, cap, 32), counts (B,)) into the slot's pinned block."""
+        k, d, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        B, cap = C.c_int(), C.c_int()
+        check(self._L.orbhip_pipe_wait(self._h, C.byref(k), C.byref(d), C.byref(n), C.byref(B), C.byref(cap)), self._h,
+              "orbhip_pipe_wait")
+        B, cap = B.value, cap.value
+        cnt = np.frombuffer((C.c_int32 * B).from_address(n.value), np.int32)
+        kps = np.frombuffer((C.c_uint8 * (B * cap * 28)).from_address(k.value), KP_DTYPE).reshape(B, cap)
+        desc = np.frombuffer((C.c_uint8 * (B * cap * 32)).from_address(d.value), np.uint8).reshape(B, cap, 32)
+        if not copy:
+            return kps, desc, cnt
+        return [kps[b, :cnt[b]].copy() for b in range(B)], [desc[b, :cnt[b]].copy() for b in range(B)]
+
+    def pipe_enable_bow(self, levelsup=4, nnratio=0.7, check_ori=True):
+        check(self._L.orbhip_pipe_enable_bow(self._h, levelsup, nnratio, 1 if check_ori else 0), self._h, "orbhip_pipe_enable_bow")
+
+    def pipe_matches(self, B, cap):
+        """(match12 (B, cap), match21 (B, cap), nmatches (B,)) views for the batch the last pipe_wait returned."""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self._L.orbhip_pipe_matches(self._h, C.byref(a), C.byref(b), C.byref(n)), self._h, "orbhip_pipe_matches")
+        m12 = np.frombuffer((C.c_int32 * (B * cap)).from_address(a.value), np.int32).reshape(B, cap)
+        m21 = np.frombuffer((C.c_int32 * (B * cap)).from_address(b.value), np.int32).reshape(B, cap)
+        return m12, m21, np.frombuffer((C.c_int32 * B).from_address(n.value), np.int32)
+
+    def host_frames(self, shape):
+        """A pinned (page-locked) uint8 array of the given shape (orbhip_host_alloc); free with host_free(array)."""
+        nbytes = int(np.prod(shape))
+        ptr = self._L.orbhip_host_alloc(nbytes)
+        if not ptr:
+            raise OrbHipError("orbhip_host_alloc(%d) failed" % nbytes)
+        arr = np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), np.uint8).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = ptr
+        return arr
+
+    def host_free(self, arr):
+        ptr = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if ptr:
+            self._L.orbhip_host_free(ptr)
+
     def sync(self):
         check(self._L.orbhip_sync(self._h), self._h, "orbhip_sync")
 
