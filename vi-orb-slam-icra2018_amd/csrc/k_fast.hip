@@ -745,6 +745,10 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
                 // unit serialises the 64 adds instead, and it has the cycles to spare).  A thread whose entries do not all
                 // fit writes none: s_listCount then exceeds listCap and phase 3 takes the fallback.
                 const int n = __popc(acc);
+                if (phases == 12) {   // ablation only: the compass items without the list
+                    if (n == 77) s_list[0] = (uint16_t)n;
+                    continue;
+                }
                 if (n > 0) {
                     // (inline asm: hipcc's atomic optimiser would turn a plain atomicAdd of a per-lane value back into a DPP scan)
                     int base;
@@ -762,13 +766,14 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
             }
         }
         __syncthreads();
-        if (phases < 3 + 3 * pass) return;   // ablation stops: 2-4 = phases of pass 0, 5-7 = of pass 1
+        if (phases < 3 + 3 * pass || phases == 12) return;   // ablation stops: 2-4 = phases of pass 0, 5-7 = of pass 1
 
         // ---- 3. full score on the work list; corners (score >= t) -> score tile + corner list ----
         // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel of the
         // active cells is scored instead (the compass test is the early-out of fast_score_pol); if it has more corners
         // than the corner list holds, phase 4 scans the score tile.  Both fallbacks produce the same result.
         const int nlist = s_listCount;
+        const uint32_t cornerCountAddr = (uint32_t)(uintptr_t)&s_cornerCount;
         if (nlist <= listCap) {
             for (int e = tid; e < nlist; e += 256) {
                 const int ent = s_list[e];
@@ -776,7 +781,10 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
                 const int s = fast_score_pol(s_pix + __mul24(r + 3, pitch) + j, pitch, t);
                 if (s > 0) {
                     s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
-                    const int slot = atomicAdd(&s_cornerCount, 1);   // hipcc aggregates this per wave
+                    // one returning LDS add per corner (a fifth of the lanes; hipcc's wave aggregation of atomicAdd(p, 1) costs
+                    // a dozen vector instructions per iteration for every lane)
+                    int slot;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cornerCountAddr), "v"(1) : "memory");
                     if (slot < cornerCap) s_corner[slot] = (uint16_t)ent;
                 }
             }
