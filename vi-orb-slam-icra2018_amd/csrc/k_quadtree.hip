@@ -9,7 +9,7 @@
 #include <cstdlib>
 
 struct QtBlock {
-    int *wtot;  // [4] LDS
+    int *wtot;  // [waves] LDS
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ int nth() const { return blockDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -50,15 +50,21 @@ struct QtBlock {
     }
 };
 
-__global__ __launch_bounds__(256) void k_quadtree(const OrbLevels G, const uint32_t *__restrict__ cand,
+// LDSPTS: the variant for a frame or two (single-frame latency: the level-0 workgroup's chain of ~70 barrier-separated steps
+// is the longest kernel of the call).  Its compact candidate array and the per-point node labels live in LDS when the level
+// has at most `ldsPts` candidates, so that a step costs an LDS round trip instead of a trip to L2; larger levels use the
+// global arrays as the batch variant always does (there the quadtree runs beside the blur and LDS is what it must not hog).
+template <bool LDSPTS>
+__global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevels G, const uint32_t *__restrict__ cand,
                                                   const uint16_t *__restrict__ cellCnt,
                                                   uint32_t *__restrict__ pts, uint32_t *__restrict__ pnode,
                                                   int32_t *__restrict__ lvlCandCnt,
                                                   uint32_t *__restrict__ lvlKp,
-                                                  int32_t *__restrict__ lvlKpCnt, int maxNodes, int qtBytes)
+                                                  int32_t *__restrict__ lvlKpCnt, int maxNodes, int qtBytes, int cellBytes,
+                                                  int ldsPts)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_wtot[4];
+    __shared__ int s_wtot[16];
     // level = blockIdx.y: workgroups are dispatched x-fastest, so every frame's level 0 (the longest chain) starts first
     // and the short upper levels fill the tail
     const int l = blockIdx.y, frame = blockIdx.x;
@@ -77,6 +83,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbLevels G, const uint3
     const uint32_t *slots = cand + (size_t)frame * G.totalCands + L.candBase;
     uint32_t *P = pts + (size_t)frame * G.totalPts + L.ptBase;
     uint32_t *PN = pnode + (size_t)frame * G.totalPts + L.ptBase;
+    if (LDSPTS && n <= ldsPts) {   // block-uniform
+        P = reinterpret_cast<uint32_t *>(smem + qtBytes + cellBytes);
+        PN = P + ldsPts;
+    }
     for (int c = tid; c < ncells; c += blockDim.x) {
         const int k = cc[c], o = cellOff[c];
         const uint32_t *src = slots + (size_t)c * L.cellCap;
@@ -123,6 +133,22 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     static const int forced = getenv("ORBHIP_QT_THREADS") ? atoi(getenv("ORBHIP_QT_THREADS")) : 256;
     const int nthreads = forced >= 64 && forced <= 256 && forced % 64 == 0 ? forced : 256;
     dim3 grid(B, G.nlevels, 1), block(nthreads, 1, 1);
-    hipLaunchKernelGGL(k_quadtree, grid, block, quadtree_lds_bytes(G), s, G, cand, cellCnt, pts, pnode,
-                       lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes);
+    const size_t base = quadtree_lds_bytes(G);
+    const int cellBytes = (int)(base - (size_t)qtBytes);
+    if (B < 8) {
+        // a frame or two: candidates and labels in LDS (8 bytes per candidate) for levels of up to 6144 candidates
+        static const int forcedPts = getenv("ORBHIP_QT_LDSPTS") ? atoi(getenv("ORBHIP_QT_LDSPTS")) : 6144;
+        int ldsPts = forcedPts;
+        while (ldsPts > 0 && base + (size_t)ldsPts * 8 > 150 * 1024) ldsPts -= 256;
+        if (ldsPts > 0) {
+            // ... and 1024 threads: the steps are loops over a few thousand candidates between barriers
+            static const int smallThreads = getenv("ORBHIP_QT_THREADS_SMALL") ? atoi(getenv("ORBHIP_QT_THREADS_SMALL")) : 1024;
+            block = dim3(smallThreads >= 64 && smallThreads <= 1024 && smallThreads % 64 == 0 ? smallThreads : 1024, 1, 1);
+            hipLaunchKernelGGL(k_quadtree<true>, grid, block, base + (size_t)ldsPts * 8, s, G, cand, cellCnt, pts, pnode, lvlCandCnt,
+                               lvlKp, lvlKpCnt, maxNodes, qtBytes, cellBytes, ldsPts);
+            return;
+        }
+    }
+    hipLaunchKernelGGL(k_quadtree<false>, grid, block, base, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp, lvlKpCnt, maxNodes,
+                       qtBytes, cellBytes, 0);
 }

@@ -16,6 +16,7 @@ static std::mutex g_err_mutex;
 
 static void comm_release(orbhip_ctx *c);
 static void pipe_release(orbhip_ctx *c);
+static void graph_release(orbhip_ctx *c);
 
 static int fail(orbhip_ctx *c, int code, const std::string &msg)
 {
@@ -206,6 +207,8 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     comm_release(c);
     pipe_release(c);
+    graph_release(c);
+    if (c->h_in) (void)hipHostFree(c->h_in);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
                     c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
@@ -277,7 +280,10 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
 {
     const OrbLevels &G = c->G;
     hipStream_t s = c->stream;
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    // (timing events are not recorded into a graph capture: events recorded by a graph node cannot be read back with
+    // hipEventElapsedTime on this runtime; the graph path refreshes the stage times with an eager run now and then)
+    const bool ev = !c->capturing;
+    if (ev) HIPCHK(c, hipEventRecord(c->ev[0], s));
     // E2 pyramid: level l from level l-1 (sequential dependency), all frames per launch
     for (int l = 1; l < G.nlevels; l++) {
         const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
@@ -289,7 +295,7 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
                       c->d_resizeTab + c->resizeTabOff[l][1],
                       c->resizeGroups[l] ? c->d_resizeTab + c->resizeTabOff[l][2] : nullptr, c->resizeHint[l][B >= 8 ? 0 : 1], B);
     }
-    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (ev) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // E3 FAST alone on the device (it is the kernel whose roofline is reported), then the quadtree
     // (latency-bound, a few thousand workgroups) and the blur (streaming) run CONCURRENTLY on two
     // streams: both only depend on the pyramid / the FAST output; the describe kernel joins them.
@@ -301,7 +307,7 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
     else
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (ev) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (B >= 8) {
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
         HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
@@ -310,26 +316,26 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
         HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
         launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
                         c->d_lvlKpCnt, B);
-        HIPCHK(c, hipEventRecord(c->ev[3], s));
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
         HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
     } else {
         // a frame or two: the blur takes a few microseconds, a cross-stream hand-over costs more than it hides
         launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
                         c->d_lvlKpCnt, B);
-        HIPCHK(c, hipEventRecord(c->ev[3], s));
-        HIPCHK(c, hipEventRecord(c->evx[1], s));
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
+        if (ev) HIPCHK(c, hipEventRecord(c->evx[1], s));
         launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
                     c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
-        HIPCHK(c, hipEventRecord(c->evx[2], s));
+        if (ev) HIPCHK(c, hipEventRecord(c->evx[2], s));
     }
-    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
     // E5+E7+E8 describe
     launch_describe(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
                     c->lvl0FrameBytes + c->pyrFrameBytes, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, d_kps,
                     d_desc, d_counts, cap, B);
-    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    if (ev) HIPCHK(c, hipEventRecord(c->ev[5], s));
     HIPCHK(c, hipGetLastError());
-    c->haveStageEvents = true;
+    if (ev) c->haveStageEvents = true;
     c->last_lvl0 = lvl0;
     c->last_stride0 = stride0;
     c->last_frame0 = frame0;
@@ -393,6 +399,86 @@ static int host_stage(orbhip_ctx *c, size_t bytes)
     return ORBHIP_OK;
 }
 
+static void graph_release(orbhip_ctx *c)
+{
+    if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
+    if (c->g_graph) (void)hipGraphDestroy(c->g_graph);
+    c->g_exec = nullptr;
+    c->g_graph = nullptr;
+    c->g_w = c->g_h = c->g_B = 0;
+}
+
+// A frame or two through host pointers (how Tracking.cc calls the extractor, src/Frame.cc:591-597): the whole chain -- copy
+// in, seven resize launches, FAST, quadtree, blur, describe, copy out -- is ONE hipGraph launch.  Issued one by one the twelve
+// launches cost the host ~3.5 us each and the device waits for them; the graph is captured from the very same call sequence
+// (run_pipeline) at the first call of a geometry and replayed afterwards.  ORBHIP_NO_GRAPH=1 keeps the eager sequence.
+static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B, int w, int h, int stride, int s0, size_t kbytes,
+                               size_t dbytes, size_t cbytes, size_t koff, size_t doff, size_t coff, int dcap)
+{
+    const size_t inBytes = (size_t)B * c->lvl0FrameBytes;
+    if (inBytes > c->h_in_bytes) {
+        graph_release(c);
+        if (c->h_in) HIPCHK(c, hipHostFree(c->h_in));
+        c->h_in = nullptr;
+        c->h_in_bytes = 0;
+        void *p = nullptr;
+        HIPCHK(c, hipHostMalloc(&p, inBytes, hipHostMallocDefault));
+        c->h_in = (uint8_t *)p;
+        c->h_in_bytes = inBytes;
+    }
+    int rc;
+    if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
+    for (int b = 0; b < B; b++) {
+        if (!imgs[b]) return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: null image");
+        uint8_t *dst = c->h_in + (size_t)b * c->lvl0FrameBytes;
+        if (stride == s0)
+            memcpy(dst, imgs[b], (size_t)s0 * (h - 1) + w);
+        else
+            for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * s0, imgs[b] + (size_t)y * stride, (size_t)w);
+    }
+    uint8_t *blk = reinterpret_cast<uint8_t *>(c->d_kps);
+    const void *key[4] = {c->d_lvl0, blk, c->h_in, c->h_stage};
+    const bool same = c->g_exec && c->g_w == w && c->g_h == h && c->g_B == B && memcmp(key, c->g_key, sizeof(key)) == 0;
+    if (!same) {
+        graph_release(c);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->capturing = true;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(c->d_lvl0, c->h_in, inBytes, hipMemcpyHostToDevice, c->stream);
+        rc = e == hipSuccess ? run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
+                                            (int32_t *)(blk + coff), dcap)
+                             : ORBHIP_E_HIP;
+        if (rc == ORBHIP_OK) e = hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+        c->capturing = false;
+        if (rc != ORBHIP_OK || e != hipSuccess || e2 != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            return fail(c, ORBHIP_E_HIP, std::string("graph capture of the single-frame chain failed: ") +
+                                             hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        c->g_graph = g;
+        HIPCHK(c, hipGraphInstantiate(&c->g_exec, g, nullptr, nullptr, 0));
+        c->g_w = w; c->g_h = h; c->g_B = B;
+        memcpy(c->g_key, key, sizeof(key));
+        c->g_calls = 0;
+    }
+    if ((c->g_calls++ & 255u) == 0) {
+        // the first call of a geometry and every 256th one run the same chain eagerly: that refreshes the stage times behind
+        // GetTimeOfComputePyramid / ...KeyPointsOctTree / ...Descriptor (include/ORBextractor.h:51-53)
+        HIPCHK(c, hipMemcpyAsync(c->d_lvl0, c->h_in, inBytes, hipMemcpyHostToDevice, c->stream));
+        if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
+                               (int32_t *)(blk + coff), dcap)))
+            return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(c, hipGraphLaunch(c->g_exec, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)kbytes; (void)dbytes;
+    return ORBHIP_OK;
+}
+
 extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, int B, int w, int h, int stride,
                                     orbhip_keypoint *kps, uint8_t *desc, int cap, int *n_out)
 {
@@ -402,11 +488,6 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
     const int s0 = (int)align_up((size_t)w, 64);
     int rc;
     if ((rc = configure(c, w, h, s0, B))) return rc;
-    for (int b = 0; b < B; b++) {
-        if (!imgs[b]) return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: null image");
-        HIPCHK(c, hipMemcpy2DAsync(c->d_lvl0 + (size_t)b * c->lvl0FrameBytes, s0, imgs[b], stride, w, h,
-                                   hipMemcpyHostToDevice, c->stream));
-    }
     const int dcap = (int)c->cap_out;
     // results: keypoints | descriptors | counts of the B frames are one device block that goes to pinned staging in ONE
     // asynchronous copy behind the kernels and ONE synchronisation (every extra copy or wait is a device round trip --
@@ -414,12 +495,22 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
     const size_t kbytes = (size_t)B * dcap * sizeof(orbhip_keypoint), dbytes = (size_t)B * dcap * 32, cbytes = (size_t)B * 4;
     const size_t koff = 0, doff = align_up(kbytes, 256), coff = doff + align_up(dbytes, 256);
     uint8_t *blk = reinterpret_cast<uint8_t *>(c->d_kps);
-    if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
-                           (int32_t *)(blk + coff), dcap)))
-        return rc;
-    if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    static const bool noGraph = getenv("ORBHIP_NO_GRAPH") && atoi(getenv("ORBHIP_NO_GRAPH")) != 0;
+    if (B < 8 && !noGraph) {
+        if ((rc = extract_small_graph(c, imgs, B, w, h, stride, s0, kbytes, dbytes, cbytes, koff, doff, coff, dcap))) return rc;
+    } else {
+        for (int b = 0; b < B; b++) {
+            if (!imgs[b]) return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: null image");
+            HIPCHK(c, hipMemcpy2DAsync(c->d_lvl0 + (size_t)b * c->lvl0FrameBytes, s0, imgs[b], stride, w, h,
+                                       hipMemcpyHostToDevice, c->stream));
+        }
+        if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
+                               (int32_t *)(blk + coff), dcap)))
+            return rc;
+        if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     memcpy(n_out, c->h_stage + coff, cbytes);
     for (int b = 0; b < B; b++) {
         const int n = n_out[b];

@@ -173,6 +173,16 @@ struct orbhip_ctx {
     // pinned host staging for the host API
     uint8_t *h_stage = nullptr;
     size_t h_stage_bytes = 0;
+    // the host-pointer call of a frame or two as ONE hipGraph launch (copy in, the twelve kernels, copy out): captured at the
+    // first call of a geometry, replayed while (w, h, B, buffers) stay the same
+    uint8_t *h_in = nullptr;          // pinned input staging, rows s0 apart
+    size_t h_in_bytes = 0;
+    hipGraphExec_t g_exec = nullptr;
+    hipGraph_t g_graph = nullptr;
+    int g_w = 0, g_h = 0, g_B = 0;
+    bool capturing = false;           // run_pipeline leaves the timing events out of a capture
+    unsigned g_calls = 0;
+    const void *g_key[4] = {nullptr, nullptr, nullptr, nullptr};   // d_lvl0, d_kps block, h_in, h_stage at capture time
 
     // matching scratch
     void *d_match = nullptr;

@@ -236,15 +236,25 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             for (int p = x.tid(); p < S; p += x.nth())
                 if (sh.cnt[p] > 1) sh.order[sh.scan[p]] = p; // temporarily: candidates in list order
             x.sync();
-            for (int c = x.tid(); c < C; c += x.nth()) {
-                const int p = sh.order[c];
-                const int mycnt = sh.cnt[p];
-                int r = 0;
-                for (int d = 0; d < C; ++d) {
-                    const int pc = sh.cnt[sh.order[d]];
-                    r += (pc > mycnt) || (pc == mycnt && d < c);
+            // rank of candidate c = number of candidates that go before it: an all-pairs count, C * C comparisons.  One thread
+            // per candidate made this a serial loop of C steps whatever the workgroup size (a third of the single-frame
+            // quadtree time at C ~ 150); the comparisons of a candidate are now dealt to SPLIT threads that add up their parts.
+            for (int c = x.tid(); c < C; c += x.nth()) sh.rank[sh.order[c]] = 0;
+            x.sync();
+            {
+                const int SPLIT = C > 0 && x.nth() > C ? x.nth() / C : 1;
+                for (int idx = x.tid(); idx < C * SPLIT; idx += x.nth()) {
+                    const int c = idx / SPLIT, part = idx - c * SPLIT;
+                    const int d0 = (part * C) / SPLIT, d1 = ((part + 1) * C) / SPLIT;
+                    const int p = sh.order[c];
+                    const int mycnt = sh.cnt[p];
+                    int r = 0;
+                    for (int d = d0; d < d1; ++d) {
+                        const int pc = sh.cnt[sh.order[d]];
+                        r += (pc > mycnt) || (pc == mycnt && d < c);
+                    }
+                    if (r) x.atomic_add(&sh.rank[p], r);
                 }
-                sh.rank[p] = r;
             }
             x.sync();
             // (the rank loops above read order[] of every candidate: rewrite it only after the sync)
