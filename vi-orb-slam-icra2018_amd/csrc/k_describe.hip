@@ -18,6 +18,8 @@
 #include "orb_pattern_data.h"
 #include "orb_trig.h"
 
+#include <cstdlib>
+
 __constant__ __attribute__((aligned(16))) signed char c_pattern[1024] = {ORB_PATTERN_VALUES};
 
 __device__ __forceinline__ float fast_atan2_dev(float y, float x)
@@ -71,12 +73,20 @@ __device__ __forceinline__ int wave_sum(int v)
 //      sequence is evaluated once per keypoint by one lane instead of once per wave by 64 lanes;
 //   C. wave per keypoint again: the lane's four test pairs are decoded once (16 floats), then per keypoint 4 x
 //      (rotate, round, two byte gathers from the blurred level, compare, ballot).
-// DS_KP = slots per workgroup: 64 for batches (throughput), 8 for a single frame or two (more workgroups,
-// shorter serial chains per wave: latency)
+// DS_KP = slots per workgroup: 16 for batches (see DESCRIBE_DEFAULT_MAP below), 8 for a single frame or two (more
+// workgroups, shorter serial chains per wave: latency); 32 / 64 remain for A/B runs (ORBHIP_DESCRIBE_KPW)
 #define DS_R 18                       // pattern radius <= 18.385, so a rotated, rounded coordinate is at most 18
 #define DS_ROWS (2 * DS_R + 1)        // 37 patch rows
 #define DS_PDW 10                     // dwords per staged row: 37 bytes + up to 3 bytes of alignment
 #define DS_TRIPS ((DS_ROWS * DS_PDW + 63) / 64)   // 6
+
+// Default placement: a whole frame per XCD (xcd_frame_tile) with 16 keypoint slots per workgroup, so that the workgroups
+// resident on one XCD at a time (224 of them) work on three or four frames and the raw + blurred pyramids of those frames
+// (1.9 MB each) are served by that XCD's 4 MB L2: L2 hit rate 51 % -> ~70 %, fabric reads 5.1 GB -> ~2.4 GB per 1024-frame
+// launch, 0.79 -> 0.74 ms (profiles/r02a/describe.md).  Fewer slots per workgroup cut the traffic further (8: 1.95 GB =
+// every pyramid byte once) but cost more in per-workgroup set-up than they gain: the kernel is bound by the number of
+// 128-byte lines its row gathers touch (~88 per keypoint), not by where they come from.
+#define DESCRIBE_DEFAULT_MAP 4
 
 template <int DS_KP>
 __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
                                                   float *__restrict__ lvlAngle,
                                                   orbhip_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int32_t *__restrict__ counts,
-                                                  int cap, int xcdMap)
+                                                  int cap, int xcdMap, int phases)
 {
     __shared__ int s_pos[DS_KP];      // cx | cy << 12 | level << 24, -1 = empty slot
     __shared__ int s_out[DS_KP];      // output index
@@ -101,7 +111,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
     __shared__ unsigned s_ioff[DS_KP], s_boff[DS_KP];
     __shared__ int s_istride[DS_KP], s_bstride[DS_KP];
     __shared__ uint32_t s_patch[4][DS_ROWS * DS_PDW + 3];
-    const int blk = xcd_tile(xcdMap), frame = blockIdx.y;
+    int blk = xcd_tile(xcdMap), frame = blockIdx.y;
+    if ((xcdMap & 255) == 4) xcd_frame_tile((int)gridDim.y, blk, frame);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g0 = blk * DS_KP;
     if (g0 >= G.totalKps) return;
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         s_bstride[tid] = l == 0 ? G.bstride0 : G.lv[l].stride;
     }
     __syncthreads();
+    if (phases < 1) return;   // timing ablation only (ORBHIP_DESCRIBE_PHASES): results are then invalid
 
     // ---- A. E5: IC_Angle moments on the un-blurred level ----
     // software pipeline: the five row dwords of the wave's next keypoint are in flight while the current one is
@@ -172,11 +184,18 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
             dmax[it] = G.umax[min(v < 0 ? -v : v, ORB_HALF_PATCH)];
         }
         const int kp0 = wave * (DS_KP / 4);
-        uint32_t cur[5], nxt[5];
-        load5(kp0, cur);
-        for (int q = 0; q < DS_KP / 4; q++) {
+        // ring of three row sets, prefetch distance two: the loads of keypoints q + 1 and q + 2 are in flight while q is
+        // reduced (the kernel waits on memory latency, not on issue slots or bandwidth: profiles/r02*/describe.md); the
+        // keypoint loop is unrolled so that the ring is indexed statically
+        constexpr int NQ = DS_KP / 4;
+        uint32_t ring[3][5];
+        load5(kp0, ring[0]);
+        if (NQ > 1) load5(kp0 + 1, ring[1]);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
             const int kp = kp0 + q;
-            if (q + 1 < DS_KP / 4) load5(kp + 1, nxt);
+            if (q + 2 < NQ) load5(kp + 2, ring[(q + 2) % 3]);
+            const uint32_t *cur = ring[q % 3];
             const int pos = s_pos[kp];
             if (pos >= 0) {   // wave-uniform
                 const int cx = pos & 0xFFF;
@@ -204,11 +223,10 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
                     s_m01[kp] = m01;
                 }
             }
-#pragma unroll
-            for (int it = 0; it < 5; it++) cur[it] = nxt[it];
         }
     }
     __syncthreads();
+    if (phases < 2) return;
 
     // ---- B. angle, cos / sin, keypoint record: one thread per keypoint ----
     if (tid < DS_KP) {
@@ -239,6 +257,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         }
     }
     __syncthreads();
+    if (phases < 3) return;
 
     // ---- C. E7: steered BRIEF on the blurred level ----
     // The 37 x 37 neighbourhood of the keypoint (the rotated pattern stays within 18 pixels) is staged per wave in
@@ -276,10 +295,14 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         }
     };
     const int kp0 = wave * (DS_KP / 4);
-    uint32_t cur[DS_TRIPS], nxt[DS_TRIPS];
-    load7(kp0, cur);
-    for (int q = 0; q < DS_KP / 4; q++) {
+    constexpr int NQ = DS_KP / 4;
+    uint32_t ring[3][DS_TRIPS];       // as in phase A: two keypoints' patches in flight behind the one in LDS
+    load7(kp0, ring[0]);
+    if (NQ > 1) load7(kp0 + 1, ring[1]);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
         const int kp = kp0 + q;
+        const uint32_t *cur = ring[q % 3];
         const int pos = s_pos[kp];
         if (pos >= 0) {
 #pragma unroll
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (q + 1 < DS_KP / 4) load7(kp + 1, nxt);
+        if (q + 2 < NQ) load7(kp + 2, ring[(q + 2) % 3]);
         const int o = s_out[kp];
         if (pos >= 0 && o < cap) {   // wave-uniform
             const int cx = pos & 0xFFF;
@@ -314,8 +337,6 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int it = 0; it < DS_TRIPS; it++) cur[it] = nxt[it];
     }
 }
 
@@ -324,14 +345,25 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
 {
-    const int kpw = B >= 8 ? 64 : 8;
-    dim3 grid(orb_xcd_grid((G.totalKps + kpw - 1) / kpw, 1), B, 1), block(256, 1, 1);
+    static const int kpwEnv = getenv("ORBHIP_DESCRIBE_KPW") ? atoi(getenv("ORBHIP_DESCRIBE_KPW")) : 0;
+    const int kpw = kpwEnv == 8 || kpwEnv == 16 || kpwEnv == 32 || kpwEnv == 64 ? kpwEnv : (B >= 8 ? 16 : 8);
+    // workgroup -> (slot block, frame): ORBHIP_DESCRIBE_MAP overrides this kernel's mapping alone (A/B runs)
+    static const int dmap = getenv("ORBHIP_DESCRIBE_MAP") ? atoi(getenv("ORBHIP_DESCRIBE_MAP")) : -1;
+    const int mapArg = dmap >= 0 ? (dmap | (orb_xcd_chunk() << 8)) : orb_xcd_arg(DESCRIBE_DEFAULT_MAP);
+    static const int phases = getenv("ORBHIP_DESCRIBE_PHASES") ? atoi(getenv("ORBHIP_DESCRIBE_PHASES")) : 3;
+    const int nblk = (G.totalKps + kpw - 1) / kpw;
+    dim3 grid((mapArg & 255) ? (nblk + 7) / 8 * 8 : nblk, B, 1), block(256, 1, 1);
+#define ORB_LAUNCH_DESCRIBE(K)                                                                                                  \
+    hipLaunchKernelGGL(k_describe<K>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
+                       (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc, \
+                       counts, cap, mapArg, phases)
     if (kpw == 64)
-        hipLaunchKernelGGL(k_describe<64>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
-                           (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc,
-                           counts, cap, orb_xcd_arg(1));
+        ORB_LAUNCH_DESCRIBE(64);
+    else if (kpw == 32)
+        ORB_LAUNCH_DESCRIBE(32);
+    else if (kpw == 16)
+        ORB_LAUNCH_DESCRIBE(16);
     else
-        hipLaunchKernelGGL(k_describe<8>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
-                       (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt,
-                       lvlAngle, kps, desc, counts, cap, orb_xcd_arg(1));
+        ORB_LAUNCH_DESCRIBE(8);
+#undef ORB_LAUNCH_DESCRIBE
 }

@@ -289,6 +289,26 @@ static inline int orb_xcd_grid(int ntiles, int dflt = 0)
 }
 static inline int orb_xcd_arg(int dflt) { return orb_xcd_map(dflt) | (orb_xcd_chunk() << 8); }
 #ifdef __HIPCC__
+// mode 4 (k_describe): a whole FRAME per XCD.  Workgroups are dealt round-robin over the XCDs by linear id
+// L = blockIdx.y * gridDim.x + blockIdx.x, so XCD k receives the ids L = k, k + 8, ...; the i-th of them (i = L / 8) works on
+// tile i % gridDim.x of frame k + 8 * (i / gridDim.x): every workgroup that touches a frame's raw and blurred pyramids
+// (1.9 MB at 640 x 480) shares one 4 MB L2, and the eight XCDs hold eight different frames.  Placement affects speed only.
+__device__ __forceinline__ void xcd_frame_tile(int nframes, int &tile, int &frame)
+{
+    const unsigned T = gridDim.x, L = blockIdx.y * T + blockIdx.x;
+    const unsigned full = ((unsigned)nframes >> 3) << 3;   // frames in complete groups of 8
+    if (L < full * T) {
+        // the ids below full * T: residue class k holds (full / 8) * T of them, one per (tile, frame = k + 8 q)
+        const unsigned k = L & 7u, i = L >> 3, q = i / T;
+        tile = (int)(i - q * T);
+        frame = (int)(k + 8u * q);
+    } else {
+        // the last nframes % 8 frames: in id order (their workgroups spread over the XCDs)
+        const unsigned t = L - full * T, f = t / T;
+        frame = (int)(full + f);
+        tile = (int)(t - f * T);
+    }
+}
 // mode 1: band (x % 8 + frame) % 8 -- every XCD sees every band over 8 consecutive frames (tile cost differs
 // between pyramid levels); mode 2: band x % 8; mode 3: chunks of xcdMap >> 8 tiles dealt round-robin.
 __device__ __forceinline__ int xcd_tile(int xcdMap)
