@@ -153,8 +153,6 @@ def test_errors_are_reported(hip):
         ex(np.zeros((600, 800), np.uint8))           # larger than the context
     with pytest.raises(OrbHipError):
         ORBextractor(1000, 1.0, 8, 20, 7, max_w=640, max_h=480)   # scale factor 1: the reference's own quota formula is 0 / 0
-    with pytest.raises(OrbHipError, match="too large for this number of levels"):
-        ORBextractor(3500, 1.75, 2, max_w=483, max_h=276)   # 2200 features on level 0: the quadtree tables exceed the LDS
     k, d = ex(np.zeros((480, 640), np.uint8))        # flat image: no corners at all
     assert len(k) == 0 and d.shape == (0, 32)
     k, d = ex(np.zeros((0, 0), np.uint8))            # empty image: silent return (src/ORBextractor.cc:1048)

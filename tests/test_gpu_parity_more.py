@@ -108,3 +108,26 @@ def test_tall_cells_with_dense_corners_in_a_batch(oracle):
     for b in range(8):
         assert _same(ks[b], want[b % 2][0]) and np.array_equal(ds[b], want[b % 2][1])
     ex.close()
+
+
+@pytest.mark.parametrize("nf,scale,nlev,w,h", [(3500, 1.75, 2, 483, 276), (2500, 1.2, 1, 640, 480)])
+def test_large_per_level_quota_uses_the_global_memory_quadtree_tables(oracle, nf, scale, nlev, w, h):
+    """More than ~2000 features on ONE level: the quadtree's node tables no longer fit the 160 KB of LDS and live in a
+    global scratch block (k_quadtree<.., true>).  The reference has no such limit; same results."""
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    rng = np.random.default_rng(9)
+    frames = synth.make_frames(310, w, h, 2)
+    frames[1] = rng.integers(0, 256, (h, w), dtype=np.uint8)          # noise: enough corners to fill the quota
+    ref = oracle.Extractor(nf, scale, nlev, 20, 7)
+    ex = ORBextractor(nf, scale, nlev, 20, 7, max_w=w, max_h=h, max_batch=8)
+    for f in frames:
+        k, d = ex(f)
+        rk, rd = ref(f)
+        assert _same(k, rk) and np.array_equal(d, rd)
+    assert len(rk) > 2000
+    ks, ds = ex.extract_batch(np.stack([frames[0], frames[1]] * 4))     # batch kernels
+    for b in range(8):
+        rk, rd = ref(frames[b % 2])
+        assert _same(ks[b], rk) and np.array_equal(ds[b], rd)
+    ex.close()

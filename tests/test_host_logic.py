@@ -180,3 +180,20 @@ def test_lerp_compass_formulas_are_exact_for_every_q_v_t():
         notdark = lerp(m2, 255 - (KD + 1), 1) >= 128
         assert np.array_equal(bright, q - v > t), t
         assert np.array_equal(~notdark, q - v < -t), t
+
+
+def test_dropin_sources_compile_against_opencv_declarations():
+    """include/orbhip/cvlite.h has two branches: its own minimal cv:: types (what both boxes use: no OpenCV installed) and
+    `#ifdef ORBHIP_USE_OPENCV` -> <opencv2/core/core.hpp>, the branch a build inside the reference tree takes.  That branch is
+    syntax-checked here against tests/native/opencv_stub (declarations of the few OpenCV 2.4 names used, written from the API
+    and labelled as a stub -- it pins nothing about OpenCV, it catches drift such as relying on headers cvlite.h happens to
+    include or on Mat::step being a size_t)."""
+    import glob
+    import subprocess
+    srcs = sorted(glob.glob(os.path.join(ROOT, "vi-orb-slam-icra2018_amd", "host", "*.cc")))
+    assert len(srcs) >= 6
+    for src in srcs:
+        r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-DORBHIP_USE_OPENCV",
+                            "-I" + os.path.join(ROOT, "tests", "native", "opencv_stub"), "-I" + os.path.join(ROOT, "include"),
+                            "-I" + os.path.join(ROOT, "include", "orbhip"), src], capture_output=True, text=True)
+        assert r.returncode == 0, os.path.basename(src) + ":\n" + r.stderr[:3000]

@@ -8,6 +8,8 @@
 
 #include <cstdlib>
 
+#define QT_LDS_LIMIT ((size_t)156 * 1024)   // node tables beyond this go to global memory (k_quadtree<.., true>)
+
 struct QtBlock {
     int *wtot;  // [waves] LDS
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
@@ -54,14 +56,18 @@ struct QtBlock {
 // is the longest kernel of the call).  Its compact candidate array and the per-point node labels live in LDS when the level
 // has at most `ldsPts` candidates, so that a step costs an LDS round trip instead of a trip to L2; larger levels use the
 // global arrays as the batch variant always does (there the quadtree runs beside the blur and LDS is what it must not hog).
-template <bool LDSPTS>
+// GLOBALT: the node tables of a (frame, level) live in a global scratch block instead of LDS -- the slow path for feature
+// quotas whose tables exceed the 160 KB of LDS (more than ~2000 features on ONE level, e.g. nfeatures 2500 with nlevels 1;
+// the reference has no such limit).  Same algorithm, same results; the workgroup's barriers order the global accesses
+// (one CU: its L1 is write-through, __syncthreads fences at workgroup scope).
+template <bool LDSPTS, bool GLOBALT>
 __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevels G, const uint32_t *__restrict__ cand,
                                                   const uint16_t *__restrict__ cellCnt,
                                                   uint32_t *__restrict__ pts, uint32_t *__restrict__ pnode,
                                                   int32_t *__restrict__ lvlCandCnt,
                                                   uint32_t *__restrict__ lvlKp,
                                                   int32_t *__restrict__ lvlKpCnt, int maxNodes, int qtBytes, int cellBytes,
-                                                  int ldsPts)
+                                                  int ldsPts, uint8_t *__restrict__ tableScratch)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_wtot[16];
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
     x.wtot = s_wtot;
 
     // ---- gather: per-cell slots -> compact array in canonical order ----
-    int *cellOff = reinterpret_cast<int *>(smem + qtBytes);
+    int *cellOff = reinterpret_cast<int *>(smem + (GLOBALT ? 0 : qtBytes));
     const int ncells = L.nCols * L.nRows;
     const uint16_t *cc = cellCnt + (size_t)frame * G.totalCells + L.cellBase;
     for (int c = tid; c < ncells; c += blockDim.x) cellOff[c] = cc[c];
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
     uint32_t *P = pts + (size_t)frame * G.totalPts + L.ptBase;
     uint32_t *PN = pnode + (size_t)frame * G.totalPts + L.ptBase;
     if (LDSPTS && n <= ldsPts) {   // block-uniform
-        P = reinterpret_cast<uint32_t *>(smem + qtBytes + cellBytes);
+        P = reinterpret_cast<uint32_t *>(smem + (GLOBALT ? 0 : qtBytes) + cellBytes);
         PN = P + ldsPts;
     }
     for (int c = tid; c < ncells; c += blockDim.x) {
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
     __syncthreads();
 
     QtShared sh;
-    qt_carve(sh, smem, maxNodes);
+    qt_carve(sh, GLOBALT ? tableScratch + ((size_t)frame * gridDim.y + l) * (size_t)qtBytes : smem, maxNodes);
     QtParams Q;
     Q.N = L.N;
     Q.nIni = L.nIni;
@@ -121,9 +127,17 @@ size_t quadtree_lds_bytes(const OrbLevels &G)
     return ((qt_shared_bytes(maxNodes) + 15) & ~(size_t)15) + (size_t)maxCells * 4 + 16;
 }
 
+size_t quadtree_table_scratch_bytes(const OrbLevels &G, int B)
+{
+    if (quadtree_lds_bytes(G) <= QT_LDS_LIMIT) return 0;
+    int maxNodes = 0;
+    for (int l = 0; l < G.nlevels; l++) maxNodes = std::max(maxNodes, G.lv[l].kpCap);
+    return (size_t)B * G.nlevels * ((qt_shared_bytes(maxNodes) + 15) & ~(size_t)15);
+}
+
 void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, const uint16_t *cellCnt,
                      uint32_t *pts, uint32_t *pnode, int32_t *lvlCandCnt, uint32_t *lvlKp,
-                     int32_t *lvlKpCnt, int B)
+                     int32_t *lvlKpCnt, int B, uint8_t *tableScratch)
 {
     int maxNodes = 0;
     for (int l = 0; l < G.nlevels; l++) maxNodes = std::max(maxNodes, G.lv[l].kpCap);
@@ -135,6 +149,12 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     dim3 grid(B, G.nlevels, 1), block(nthreads, 1, 1);
     const size_t base = quadtree_lds_bytes(G);
     const int cellBytes = (int)(base - (size_t)qtBytes);
+    if (base > QT_LDS_LIMIT) {
+        // tables in global memory (tableScratch sized by quadtree_table_scratch_bytes); LDS holds the cell offsets only
+        hipLaunchKernelGGL((k_quadtree<false, true>), grid, block, (size_t)cellBytes, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp,
+                           lvlKpCnt, maxNodes, qtBytes, cellBytes, 0, tableScratch);
+        return;
+    }
     if (B < 8) {
         // a frame or two: candidates and labels in LDS (8 bytes per candidate) for levels of up to 6144 candidates
         static const int forcedPts = getenv("ORBHIP_QT_LDSPTS") ? atoi(getenv("ORBHIP_QT_LDSPTS")) : 6144;
@@ -144,11 +164,11 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
             // ... and 1024 threads: the steps are loops over a few thousand candidates between barriers
             static const int smallThreads = getenv("ORBHIP_QT_THREADS_SMALL") ? atoi(getenv("ORBHIP_QT_THREADS_SMALL")) : 1024;
             block = dim3(smallThreads >= 64 && smallThreads <= 1024 && smallThreads % 64 == 0 ? smallThreads : 1024, 1, 1);
-            hipLaunchKernelGGL(k_quadtree<true>, grid, block, base + (size_t)ldsPts * 8, s, G, cand, cellCnt, pts, pnode, lvlCandCnt,
-                               lvlKp, lvlKpCnt, maxNodes, qtBytes, cellBytes, ldsPts);
+            hipLaunchKernelGGL((k_quadtree<true, false>), grid, block, base + (size_t)ldsPts * 8, s, G, cand, cellCnt, pts, pnode,
+                               lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes, cellBytes, ldsPts, nullptr);
             return;
         }
     }
-    hipLaunchKernelGGL(k_quadtree<false>, grid, block, base, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp, lvlKpCnt, maxNodes,
-                       qtBytes, cellBytes, 0);
+    hipLaunchKernelGGL((k_quadtree<false, false>), grid, block, base, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp, lvlKpCnt,
+                       maxNodes, qtBytes, cellBytes, 0, nullptr);
 }

@@ -80,13 +80,6 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
             return fail(c, rc, "image too small for the 30-px cell grid / quadtree roots of some level, "
                                "or larger than the supported tile bounds");
         }
-        // the quadtree keeps the node lists of a (frame, level) in LDS: a level's feature quota must fit (about 2000 features
-        // on ONE level; 4000 features over 8 levels need 868 on level 0)
-        if (quadtree_lds_bytes(c->G) > 156 * 1024) {
-            c->cur_w = c->cur_h = 0;
-            return fail(c, ORBHIP_E_SIZE, "nfeatures is too large for this number of levels: the per-level quadtree tables exceed "
-                                          "the 160 KB of LDS (at most ~2000 features on one level)");
-        }
         // resize tables
         std::vector<int32_t> all;
         for (int l = 1; l < c->nlevels; l++) {
@@ -132,6 +125,9 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
     if ((rc = ensure(c, c->d_lvlCandCnt, c->cap_cnt1, Bm * ORBHIP_MAX_LEVELS * 4))) return rc;
     if ((rc = ensure(c, c->d_lvlKpCnt, c->cap_cnt2, Bm * ORBHIP_MAX_LEVELS * 4))) return rc;
     if ((rc = ensure(c, c->d_lvl0, c->cap_lvl0, Bm * c->lvl0FrameBytes))) return rc;
+    // quadtree node tables of levels whose feature quota exceeds what the LDS holds (about 2000 features on one level)
+    if (const size_t qt = quadtree_table_scratch_bytes(G, (int)Bm))
+        if ((rc = ensure(c, c->d_qtTables, c->cap_qtTables, qt))) return rc;
     if ((size_t)G.outCap > c->cap_out) {
         size_t d1 = 0, d2 = 0;
         if (c->d_kps) HIPCHK(c, hipFree(c->d_kps));
@@ -211,7 +207,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->h_in) (void)hipHostFree(c->h_in);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
-                    c->d_counts, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
+                    c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -315,13 +311,13 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
                     c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
         HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
         launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
-                        c->d_lvlKpCnt, B);
+                        c->d_lvlKpCnt, B, c->d_qtTables);
         if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
         HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
     } else {
         // a frame or two: the blur takes a few microseconds, a cross-stream hand-over costs more than it hides
         launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
-                        c->d_lvlKpCnt, B);
+                        c->d_lvlKpCnt, B, c->d_qtTables);
         if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
         if (ev) HIPCHK(c, hipEventRecord(c->evx[1], s));
         launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
@@ -911,7 +907,16 @@ struct TmpDev {
     orbhip_ctx *c;
     uint8_t *base = nullptr;
     size_t used = 0, cap = 0;
+    std::vector<void *> extra;   // blocks taken beyond the reserved size (a reserve() total that undercounts must not
+                                 // become a null pointer handed to a copy: ADVICE r01)
     explicit TmpDev(orbhip_ctx *ctx) : c(ctx) {}
+    ~TmpDev()
+    {
+        // Every entry point synchronises before its normal return; an early error return may leave asynchronous copies from
+        // the caller's (or this frame's stack) memory in flight -- drain them before that memory goes away.
+        if (c && c->stream && hipStreamQuery(c->stream) != hipSuccess) (void)hipStreamSynchronize(c->stream);
+        for (void *p : extra) (void)hipFree(p);
+    }
     int reserve(size_t bytes)
     {
         bytes += 4096;
@@ -933,9 +938,19 @@ struct TmpDev {
     void *take(size_t bytes)
     {
         used = align_up(used, 256);
-        void *p = base + used;
-        used += bytes;
-        return used <= cap ? p : nullptr;
+        if (used + bytes <= cap) {
+            void *p = base + used;
+            used += bytes;
+            return p;
+        }
+        // beyond the reservation: a block of its own (slow, but never a null or overlapping pointer)
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+            fprintf(stderr, "[orbhip] staging allocation of %zu bytes failed\n", bytes);
+            abort();   // an entry point that continued would copy through a null pointer
+        }
+        extra.push_back(p);
+        return p;
     }
 };
 

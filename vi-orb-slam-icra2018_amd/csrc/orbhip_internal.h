@@ -150,6 +150,8 @@ struct orbhip_ctx {
     int32_t *d_lvlCandCnt = nullptr; // candidates per (frame, level)         [B][16]
     uint32_t *d_lvlKp = nullptr;   // quadtree winners (packed)               [B][totalKps]
     int32_t *d_lvlKpCnt = nullptr; // winners per (frame, level)              [B][16]
+    uint8_t *d_qtTables = nullptr; // quadtree node tables when they exceed the LDS (large per-level quotas)
+    size_t cap_qtTables = 0;
     float *d_lvlAngle = nullptr;   // orientation per winner                  [B][totalKps]
     orbhip_keypoint *d_kps = nullptr; // output staging (host API)            [B][outCap]
     uint8_t *d_desc = nullptr;     //                                          [B][outCap][32]
@@ -232,7 +234,8 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
                  uint32_t *cand, uint16_t *cellCnt, int B);
 void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, const uint16_t *cellCnt,
                      uint32_t *pts, uint32_t *pnode, int32_t *lvlCandCnt, uint32_t *lvlKp,
-                     int32_t *lvlKpCnt, int B);
+                     int32_t *lvlKpCnt, int B, uint8_t *tableScratch);
+size_t quadtree_table_scratch_bytes(const OrbLevels &G, int B);   // 0 when the node tables fit in LDS
 void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, uint8_t *blur, size_t blurFrame,
                  const BlurTile *tiles, int ntiles, int B);

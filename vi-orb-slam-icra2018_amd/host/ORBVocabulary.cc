@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 
 #include "hiperror.h"
 #include "orbhip.h"
