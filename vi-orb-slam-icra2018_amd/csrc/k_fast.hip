@@ -119,13 +119,18 @@ __device__ __forceinline__ int arcs_score(const uint32_t P[8], uint32_t C, int v
 
 // FAST score of the pixel at p, 0 if it is not a corner at threshold t (t >= 1).  bright (q - v > t): max_arcs min_arc (q - v) - 1 = (max_arcs min_arc q) - v - 1; dark: the same
 // on the complemented bytes, v - q = (255 - q) - (255 - v).
-__device__ __forceinline__ int fast_score_pol(const uint8_t *p, int pitch, int t)
+__device__ __forceinline__ int fast_score_win(const uint8_t *pix, int off, int pitch, int t)
 {
-    const uint8_t *rm3 = p - 3 * pitch - 3, *rm2 = p - 2 * pitch - 3, *rm1 = p - pitch - 3, *r0 = p - 3;
-    const uint8_t *rp1 = p + pitch - 3, *rp2 = p + 2 * pitch - 3, *rp3 = p + 3 * pitch - 3;
+    // pix + off = top-left corner of the pixel's 7x7 window.  Every ring pixel as a non-negative offset from the top-left corner of the 7x7 window: with a compile-time pitch the 17
+    // loads share one address register (ds_read_u8 offset:imm), with a run-time pitch they need one add per window row.
+    // (the empty asm keeps the compiler from re-deriving the addresses from p, which costs an add per negative offset)
+    // (on the offset, not the pointer: an asm on the pointer would lose its LDS address space and the loads would be flat loads)
+    asm volatile("" : "+v"(off));
+    const uint8_t *w = pix + off;
+    const int P1 = pitch, P2 = 2 * pitch, P3 = 3 * pitch, P4 = 4 * pitch, P5 = 5 * pitch, P6 = 6 * pitch;
     // ring pixel k (OpenCV's order: k = 0 at (0, +3), then clockwise in image coordinates) paired with pixel k + 8
-    const int v0 = p[0];
-    const int q0 = rp3[3], q8 = rm3[3], q4 = r0[6], q12 = r0[0];
+    const int v0 = w[P3 + 3];
+    const int q0 = w[P6 + 3], q8 = w[3], q4 = w[P3 + 6], q12 = w[P3];
     // polarity that can hold a 9-arc (it contains ring pixel 0 or 8 and ring pixel 4 or 12)
     const bool pb = min(max(q0, q8), max(q4, q12)) > v0 + t;    // bright: q - v > t
     const bool pd = max(min(q0, q8), min(q4, q12)) < v0 - t;    // dark:   v - q > t
@@ -133,17 +138,22 @@ __device__ __forceinline__ int fast_score_pol(const uint8_t *p, int pitch, int t
     const bool dark = !pb;
     const uint32_t C = dark ? 0x40FF40FFu : 0x40004000u;
     uint32_t P[8];
-    P[0] = ((uint32_t)q0 | ((uint32_t)q8 << 16));               // (0, +3)  | (0, -3)
-    P[1] = ((uint32_t)rp3[4] | ((uint32_t)rm3[2] << 16));       // (+1, +3) | (-1, -3)
-    P[2] = ((uint32_t)rp2[5] | ((uint32_t)rm2[1] << 16));       // (+2, +2) | (-2, -2)
-    P[3] = ((uint32_t)rp1[6] | ((uint32_t)rm1[0] << 16));       // (+3, +1) | (-3, -1)
-    P[4] = ((uint32_t)q4 | ((uint32_t)q12 << 16));              // (+3, 0)  | (-3, 0)
-    P[5] = ((uint32_t)rm1[6] | ((uint32_t)rp1[0] << 16));       // (+3, -1) | (-3, +1)
-    P[6] = ((uint32_t)rm2[5] | ((uint32_t)rp2[1] << 16));       // (+2, -2) | (-2, +2)
-    P[7] = ((uint32_t)rm3[4] | ((uint32_t)rp3[2] << 16));       // (+1, -3) | (-1, +3)
+    P[0] = ((uint32_t)q0 | ((uint32_t)q8 << 16));                       // (0, +3)  | (0, -3)
+    P[1] = ((uint32_t)w[P6 + 4] | ((uint32_t)w[2] << 16));              // (+1, +3) | (-1, -3)
+    P[2] = ((uint32_t)w[P5 + 5] | ((uint32_t)w[P1 + 1] << 16));         // (+2, +2) | (-2, -2)
+    P[3] = ((uint32_t)w[P4 + 6] | ((uint32_t)w[P2] << 16));             // (+3, +1) | (-3, -1)
+    P[4] = ((uint32_t)q4 | ((uint32_t)q12 << 16));                      // (+3, 0)  | (-3, 0)
+    P[5] = ((uint32_t)w[P2 + 6] | ((uint32_t)w[P4] << 16));             // (+3, -1) | (-3, +1)
+    P[6] = ((uint32_t)w[P1 + 5] | ((uint32_t)w[P5 + 1] << 16));         // (+2, -2) | (-2, +2)
+    P[7] = ((uint32_t)w[4] | ((uint32_t)w[P6 + 2] << 16));              // (+1, -3) | (-1, +3)
     int sc = arcs_score(P, C, v0 ^ (dark ? 0xFF : 0));
     if (pb && pd) sc = max(sc, arcs_score(P, 0x40FF40FFu, v0 ^ 0xFF));   // both possible (rare): the dark one as well
     return sc >= t ? sc : 0;
+}
+
+__device__ __forceinline__ int fast_score_pol(const uint8_t *p, int pitch, int t)
+{
+    return fast_score_win(p, -3 * pitch - 3, pitch, t);
 }
 
 // inclusive wave prefix sum
@@ -264,11 +274,20 @@ __global__ __launch_bounds__(256) void k_fast_v1(const OrbLevels G, const uint8_
     uint32_t *s_surv = reinterpret_cast<uint32_t *>(smem + pixBytes + scoreBytes);
     const int SP = (TW + 3) & ~3;
     uint16_t *s_ent = reinterpret_cast<uint16_t *>(s_score);   // phase 2 only: u16 per item (2 * items <= DH * SP)
-    const float invNchunk = 1.0f / (float)nchunk;   // i / nchunk = floor((i + 0.5) * invNchunk), exact for i < 2^16
-    for (int i = tid; i < RH * nchunk; i += 256) {
-        const int r = (int)(((float)i + 0.5f) * invNchunk), c = i - r * nchunk;
-        const uint4 v = *reinterpret_cast<const uint4 *>(img + (size_t)(iniY + r) * stride + XA + (c << 4));
-        *reinterpret_cast<uint4 *>(s_pix + r * pitch + (c << 4)) = v;
+    // i / nchunk = floor((i + 0.5) * invNchunk): v_rcp_f32 is within 1 ulp, the product is off by < 2^-9 for i < 2^13, the
+    // quotient is >= 1 / (2 nchunk) >= 2^-6 away from an integer
+    const float invNchunk = __builtin_amdgcn_rcpf((float)nchunk);
+    const uint8_t *img0 = img + (size_t)iniY * stride + XA;   // workgroup-uniform base, 32-bit offsets from it
+    const int nstage = RH * nchunk;
+    for (int i = tid; i < nstage; i += 512) {
+        // two loads in flight per thread (a tile of the usual grid is 1.8 x 256 chunks)
+        const int ib = min(i + 256, nstage - 1);
+        const int ra = (int)(((float)i + 0.5f) * invNchunk), ca = i - ra * nchunk;
+        const int rb = (int)(((float)ib + 0.5f) * invNchunk), cb = ib - rb * nchunk;
+        const uint4 va = *reinterpret_cast<const uint4 *>(img0 + (unsigned)(__mul24(ra, stride) + (ca << 4)));
+        const uint4 vb = *reinterpret_cast<const uint4 *>(img0 + (unsigned)(__mul24(rb, stride) + (cb << 4)));
+        *reinterpret_cast<uint4 *>(s_pix + __mul24(ra, pitch) + (ca << 4)) = va;
+        if (i + 256 < nstage) *reinterpret_cast<uint4 *>(s_pix + __mul24(rb, pitch) + (cb << 4)) = vb;
     }
     if (tid < FAST_TILE_CELLS) {
         s_cellAny[tid] = 0;
@@ -580,6 +599,9 @@ __device__ __forceinline__ bool nms_survives(const uint8_t *s_score, int SP, int
     return s > m;
 }
 
+// PITCH: the LDS row pitch of the pixel tile as a compile-time constant (0 = from the tile's width at run time).  With it the
+// five dwords of a compass item and the 17 bytes of a score window are loads at immediate offsets from one address register.
+template <int PITCH>
 __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_t *__restrict__ lvl0, int stride0,
                                               unsigned long long frame0, const uint8_t *__restrict__ pyr,
                                               unsigned long long pyrFrame, const FastTile *__restrict__ tiles,
@@ -592,6 +614,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
     __shared__ int s_cellCnt[FAST_TILE_CELLS];
     __shared__ int s_listCount, s_cornerCount, s_nAct;
     __shared__ uint8_t s_grp[FAST_MAX_TILE_W / 4 + 8];
+    __shared__ uint32_t s_dom[FAST_MAX_TILE_W / 4 + 8];   // per dword group of the pass: which of its 4 pixels are tested (bit 8k + 7)
 
     const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
     if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
@@ -621,7 +644,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
     // ---- 1. stage pixels [iniY, maxY) x [XA, X1) into LDS, 16 bytes per lane per load; clear the score tile and the bitmap ----
     const int XA = X0 & ~15;
     const int nchunk = (X1 - XA + 15) >> 4;
-    const int pitch = nchunk << 4;
+    const int pitch = PITCH ? PITCH : nchunk << 4;
     const int RH = maxY - iniY;
     uint8_t *s_pix = smem;
     uint8_t *s_score = smem + pixBytes;
@@ -630,15 +653,35 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
     unsigned long long *s_bits = reinterpret_cast<unsigned long long *>(smem + pixBytes + scoreBytes + listBytes + cornerBytes);   // [ncells][DH]; wCell < 64
     int *s_pre = reinterpret_cast<int *>(smem + pixBytes + scoreBytes + listBytes + cornerBytes + bitsBytes);                       // [ncells][DH]
     const int SP = (TW + 3) & ~3;
-    const float invNchunk = 1.0f / (float)nchunk;   // i / nchunk = floor((i + 0.5) * invNchunk), exact for i < 2^16
-    for (int i = tid; i < RH * nchunk; i += 256) {
-        const int r = (int)(((float)i + 0.5f) * invNchunk), c = i - r * nchunk;
-        const uint4 v = *reinterpret_cast<const uint4 *>(img + (size_t)(iniY + r) * stride + XA + (c << 4));
-        *reinterpret_cast<uint4 *>(s_pix + r * pitch + (c << 4)) = v;
+    // i / nchunk = floor((i + 0.5) * invNchunk): v_rcp_f32 is within 1 ulp, the product is off by < 2^-9 for i < 2^13, the
+    // quotient is >= 1 / (2 nchunk) >= 2^-6 away from an integer
+    const float invNchunk = __builtin_amdgcn_rcpf((float)nchunk);
+    const uint8_t *img0 = img + (size_t)iniY * stride + XA;   // workgroup-uniform base, 32-bit offsets from it
+    const int nstage = RH * nchunk;
+    for (int i = tid; i < nstage; i += 512) {
+        // two loads in flight per thread (a tile of the usual grid is 1.8 x 256 chunks)
+        const int ib = min(i + 256, nstage - 1);
+        const int ra = (int)(((float)i + 0.5f) * invNchunk), ca = i - ra * nchunk;
+        const int rb = (int)(((float)ib + 0.5f) * invNchunk), cb = ib - rb * nchunk;
+        const uint4 va = *reinterpret_cast<const uint4 *>(img0 + (unsigned)(__mul24(ra, stride) + (ca << 4)));
+        const uint4 vb = *reinterpret_cast<const uint4 *>(img0 + (unsigned)(__mul24(rb, stride) + (cb << 4)));
+        *reinterpret_cast<uint4 *>(s_pix + __mul24(ra, pitch) + (ca << 4)) = va;
+        if (i + 256 < nstage) *reinterpret_cast<uint4 *>(s_pix + __mul24(rb, pitch) + (cb << 4)) = vb;
     }
     const int nrowsAll = T.ncells * DH;
     for (int i = tid; i < (DH * SP + 15) >> 4; i += 256) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);   // scoreBytes is a multiple of 16
     for (int i = tid; i < nrowsAll; i += 256) s_bits[i] = 0ull;
+    const int j0 = X0 + 3 - XA;            // LDS column of domain column 0
+    const int jd0 = j0 & ~3;               // first aligned dword column touching the domain
+    const int GPR = ((j0 + TW + 3) >> 2) - (j0 >> 2);   // dword groups per row
+    // pass 0 tests every domain pixel: the mask of a group is its overlap with [0, TW)
+    for (int g = 255 - tid; g < GPR; g += 256) {   // (the last wave: it has the fewest staging loads)
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((unsigned)(jd0 + (g << 2) + k - j0) < (unsigned)TW) m |= 0x80u << (8 * k);
+        s_dom[g] = m;
+    }
     if (tid < FAST_TILE_CELLS) {
         s_cellAny[tid] = 0;
         s_cellCnt[tid] = 0;
@@ -651,9 +694,6 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
     __syncthreads();
     if (phases < 2) return;   // timing ablation only (ORBHIP_FAST_PHASES), results are then invalid
 
-    const int j0 = X0 + 3 - XA;            // LDS column of domain column 0
-    const int jd0 = j0 & ~3;               // first aligned dword column touching the domain
-    const int GPR = ((j0 + TW + 3) >> 2) - (j0 >> 2);   // dword groups per row
     const int wCell = L.wCell;
     const unsigned cellMagic = 65536u / (unsigned)wCell + 1u;   // c / wCell for c < 65536 / wCell
     const unsigned allCells = (1u << T.ncells) - 1u;
@@ -677,12 +717,17 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
         if (pass == 1) {
             // dword groups that hold a domain pixel of an active cell (any order)
             for (int g = tid; g < GPR; g += 256) {
-                bool act = false;
+                uint32_t m = 0;
+#pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int c = jd0 + (g << 2) + k - j0;
-                    if (c >= 0 && c < TW && ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u)) act = true;
+                    if ((unsigned)c < (unsigned)TW && ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u)) m |= 0x80u << (8 * k);
                 }
-                if (act) s_grp[atomicAdd(&s_nAct, 1)] = (uint8_t)g;
+                if (m) {
+                    const int a = atomicAdd(&s_nAct, 1);
+                    s_grp[a] = (uint8_t)g;
+                    s_dom[a] = m;
+                }
             }
             if (tid == 0) {
                 s_listCount = 0;
@@ -701,44 +746,38 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
         }
         if ((tid & ~63) < nthr) {
             // thread -> (dword column, first row): tid = r0 * nAct + slot; rows r0, r0 + RS, ... (RS = nthr / nAct >= 1)
-            const float invAct = 1.0f / (float)nAct;
+            // (v_rcp_f32 is within 1 ulp: the products below are off by < 2^-13, the quotients are >= 1 / (2 nAct) away from an integer)
+            const float invAct = __builtin_amdgcn_rcpf((float)nAct);
             const int r0 = (int)(((float)tid + 0.5f) * invAct);
             const int slot = tid - r0 * nAct;
             const int RS = (int)(((float)nthr + 0.5f) * invAct);
             const bool mine = r0 < RS;
-            const int g = pass == 0 ? slot : (int)s_grp[mine ? slot : 0];
+            const int g = pass == 0 ? slot : (int)s_grp[slot];
             const int jd = jd0 + (g << 2);
-            // domain / active-cell mask of my four pixels (pixel k at bit 8k + 7)
-            uint32_t dom = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int c = jd + k - j0;
-                bool in = c >= 0 && c < TW;
-                if (pass == 1) in = in && ((cellMask >> ((unsigned)(in ? c : 0) * cellMagic >> 16)) & 1u);
-                if (in) dom |= 0x80u << (8 * k);
-            }
+            const uint32_t dom = s_dom[slot];   // domain / active-cell mask of my four pixels (pixel k at bit 8k + 7)
             const int rowStep = __mul24(RS, pitch);
             const int RSsh = RS << 9;
             const uint32_t listCountAddr = (uint32_t)(uintptr_t)&s_listCount;   // LDS byte address (low half of the flat address)
             for (int rbase = 0; rbase < DH; rbase += 8 * RS) {
                 // acc: bit (8 * k + i) = pixel k of this thread's i-th row of the chunk
                 uint32_t acc = 0;
-                const uint8_t *row = s_pix + __mul24(rbase + r0 + 3, pitch) + jd;
+                // the item's five dwords at non-negative offsets from (row - 3, column - 4): top | left, centre, right | bottom
+                const uint8_t *win = s_pix + __mul24(rbase + r0, pitch) + (jd - 4);
                 const int rlim = mine ? DH - rbase - r0 : 0;   // item i exists <=> i * RS < rlim
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     if (__mul24(i, RS) < rlim) {
-                        const uint32_t Cw = *reinterpret_cast<const uint32_t *>(row);
-                        const uint32_t Lw = *reinterpret_cast<const uint32_t *>(row - 4);
-                        const uint32_t Rw = *reinterpret_cast<const uint32_t *>(row + 4);
-                        const uint32_t Tw = *reinterpret_cast<const uint32_t *>(row - 3 * pitch);
-                        const uint32_t Bw = *reinterpret_cast<const uint32_t *>(row + 3 * pitch);
+                        const uint32_t Tw = *reinterpret_cast<const uint32_t *>(win + 4);
+                        const uint32_t Lw = *reinterpret_cast<const uint32_t *>(win + 3 * pitch);
+                        const uint32_t Cw = *reinterpret_cast<const uint32_t *>(win + 3 * pitch + 4);
+                        const uint32_t Rw = *reinterpret_cast<const uint32_t *>(win + 3 * pitch + 8);
+                        const uint32_t Bw = *reinterpret_cast<const uint32_t *>(win + 6 * pitch + 4);
                         const uint32_t lft = __builtin_amdgcn_alignbyte(Cw, Lw, 1);   // bytes L1 L2 L3 C0 (column - 3)
                         const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
                         const uint32_t z = compass4(Cw, Tw, Bw, lft, rgt, CK);
                         acc |= (z & dom) >> (7 - i);
                     }
-                    row += rowStep;
+                    win += rowStep;
                 }
                 // append this thread's survivors to the work list (order is irrelevant): one returning LDS add per thread
                 // claims its range (r01 ran a DPP wave scan + one add per wave: ~45 vector instructions per chunk; the LDS
@@ -778,7 +817,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
             for (int e = tid; e < nlist; e += 256) {
                 const int ent = s_list[e];
                 const int r = ent >> 9, j = ent & 511;
-                const int s = fast_score_pol(s_pix + __mul24(r + 3, pitch) + j, pitch, t);
+                const int s = fast_score_win(s_pix, __mul24(r, pitch) + (j - 3), pitch, t);
                 if (s > 0) {
                     s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
                     // one returning LDS add per corner (a fifth of the lanes; hipcc's wave aggregation of atomicAdd(p, 1) costs
@@ -902,7 +941,7 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     static const int v1env = getenv("ORBHIP_FAST_V1") ? atoi(getenv("ORBHIP_FAST_V1")) : 0;
     const int v1 = v1env && G.minTh <= G.iniTh && G.iniTh < 255;
     // LDS: pixel tile + score tile + work list of the largest run over all levels
-    int pixBytes = 0, scoreBytes = 0, listBytes = 0, survBytes = 0, bitsRows = 0;
+    int pixBytes = 0, scoreBytes = 0, listBytes = 0, survBytes = 0, bitsRows = 0, maxPitch = 0, maxRh = 0;
     for (int l = 0; l < G.nlevels; l++) {
         const OrbLevel &L = G.lv[l];
         int tileCells = fast_tile_cells();
@@ -912,6 +951,8 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
         const int rh = L.hCell + 6;
         const int sp = (tileCells * L.wCell + 3) & ~3;
         pixBytes = std::max(pixBytes, pitch * rh);
+        maxPitch = std::max(maxPitch, pitch);
+        maxRh = std::max(maxRh, rh);
         scoreBytes = std::max(scoreBytes, sp * L.hCell);
         // work list: u16 per domain pixel; the survivor list (u32 per strict local maximum, at most
         // a quarter of the pixels plus cell seams) reuses the same storage
@@ -946,7 +987,21 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     if (forced > 0) listCap = cornerCap = forced;
     const int lBytes = (listCap * 2 + 15) & ~15, cBytes = (cornerCap * 2 + 15) & ~15;
     const int bitsBytes = (bitsRows * 8 + 15) & ~15, preBytes = (bitsRows * 4 + 15) & ~15;
-    hipLaunchKernelGGL(k_fast, grid, block, (size_t)(pixBytes + scoreBytes + lBytes + cBytes + bitsBytes + preBytes), s, G, lvl0,
-                       stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tiles, cand, cellCnt, pixBytes,
-                       scoreBytes, lBytes, cBytes, bitsBytes, listCap, cornerCap, phases, orb_xcd_arg(), ntiles);
+    // the kernel with a compile-time pitch (176 / 192 / 208: five cells of 31..36 pixels + halo + alignment, i.e. every level of
+    // the usual 30-pixel cell grid) when no level needs more, the run-time pitch otherwise (ORBHIP_FAST_PITCH=0 forces the latter)
+    static const int pitchEnv = getenv("ORBHIP_FAST_PITCH") ? atoi(getenv("ORBHIP_FAST_PITCH")) : 1;
+    const int fixed = pitchEnv == 0 ? 0 : maxPitch <= 176 ? 176 : maxPitch <= 192 ? 192 : maxPitch <= 208 ? 208 : 0;
+    if (fixed) pixBytes = (fixed * maxRh + 15) & ~15;
+    const size_t lds = (size_t)(pixBytes + scoreBytes + lBytes + cBytes + bitsBytes + preBytes);
+#define ORB_LAUNCH_FAST(P)                                                                                                   \
+    hipLaunchKernelGGL(k_fast<P>, grid, block, lds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                    \
+                       (unsigned long long)pyrFrame, tiles, cand, cellCnt, pixBytes, scoreBytes, lBytes, cBytes, bitsBytes,  \
+                       listCap, cornerCap, phases, orb_xcd_arg(), ntiles)
+    switch (fixed) {
+    case 176: ORB_LAUNCH_FAST(176); break;
+    case 192: ORB_LAUNCH_FAST(192); break;
+    case 208: ORB_LAUNCH_FAST(208); break;
+    default: ORB_LAUNCH_FAST(0); break;
+    }
+#undef ORB_LAUNCH_FAST
 }
