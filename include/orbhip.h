@@ -154,6 +154,16 @@ int orbhip_pipe_matches(orbhip_ctx *ctx, const int32_t **match12, const int32_t 
 int orbhip_get_pyramid_level(orbhip_ctx *ctx, int frame, int level, uint8_t *dst, int dst_stride,
                              int *w, int *h);
 
+/* The same member without a copy per level: with orbhip_set_host_pyramid(ctx, 1) every following orbhip_extract /
+ * orbhip_extract_batch also lands levels 1.. of its frames in page-locked host memory (one device-to-host copy that runs
+ * beside the kernels), and orbhip_host_pyramid_level returns a pointer into that block (rows *stride apart); level 0 is
+ * the page-locked copy of the caller's frame that the single-frame path uploads from.  The pointers stay valid until the
+ * next extract call on this context or orbhip_destroy -- the drop-in's mvImagePyramid[level] are headers on them, read
+ * right after the extraction as src/Frame.cc:817 does.  Returns ORBHIP_E_ARG when a level is not staged (host pyramid
+ * off, device-pointer entry points, or level 0 of a batch of 8 or more frames: use the caller's image). */
+int orbhip_set_host_pyramid(orbhip_ctx *ctx, int on);
+int orbhip_host_pyramid_level(orbhip_ctx *ctx, int frame, int level, const uint8_t **ptr, int *stride, int *w, int *h);
+
 /* ---- parity/debug access to stage outputs of the last extract call ---- */
 /* blurred level (cv::GaussianBlur at src/ORBextractor.cc:1103-1104) */
 int orbhip_debug_get_blurred_level(orbhip_ctx *ctx, int frame, int level, uint8_t *dst,

@@ -61,8 +61,9 @@ public:
     }
 
     // ref: include/ORBextractor.h:103 -- read directly by Frame::ComputeStereoMatches.
-    // Filled after every operator() call (device -> host copy of the 8 levels); switch off with
-    // SetPyramidDownload(false) when the caller never reads it (monocular).
+    // Valid after every operator() call until the next one: headers on a page-locked host copy of the levels that
+    // liborbhip fills beside the kernels (orbhip_host_pyramid_level) -- level 0 is the staged copy of the caller's image.
+    // Clone a level to keep it longer.  SetPyramidDownload(false) when the caller never reads it (monocular).
     std::vector<cv::Mat> mvImagePyramid;
     void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
 

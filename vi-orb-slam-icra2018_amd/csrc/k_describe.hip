@@ -351,10 +351,12 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
     static const int dmap = getenv("ORBHIP_DESCRIBE_MAP") ? atoi(getenv("ORBHIP_DESCRIBE_MAP")) : -1;
     const int mapArg = dmap >= 0 ? (dmap | (orb_xcd_chunk() << 8)) : orb_xcd_arg(DESCRIBE_DEFAULT_MAP);
     static const int phases = getenv("ORBHIP_DESCRIBE_PHASES") ? atoi(getenv("ORBHIP_DESCRIBE_PHASES")) : 3;
+    // occupancy experiment only: unused dynamic LDS caps the workgroups per CU
+    static const int padLds = getenv("ORBHIP_DESCRIBE_PADLDS") ? atoi(getenv("ORBHIP_DESCRIBE_PADLDS")) : 0;
     const int nblk = (G.totalKps + kpw - 1) / kpw;
     dim3 grid((mapArg & 255) ? (nblk + 7) / 8 * 8 : nblk, B, 1), block(256, 1, 1);
 #define ORB_LAUNCH_DESCRIBE(K)                                                                                                  \
-    hipLaunchKernelGGL(k_describe<K>, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
+    hipLaunchKernelGGL(k_describe<K>, grid, block, (size_t)padLds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc, \
                        counts, cap, mapArg, phases)
     if (kpw == 64)

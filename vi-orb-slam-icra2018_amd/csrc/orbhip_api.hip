@@ -183,6 +183,8 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int i = 0; i < 3; i++)
         if ((e = hipEventCreate(&c->evx[i])) != hipSuccess) return bail("hipEventCreate", e);
+    for (int i = 0; i < 2; i++)
+        if ((e = hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (int i = 0; i < 8; i++)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
     // size everything for the largest image now, so per-frame calls never allocate
@@ -205,6 +207,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     pipe_release(c);
     graph_release(c);
     if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_pyr) (void)hipHostFree(c->h_pyr);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
                     c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
@@ -215,6 +218,8 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 3; i++)
         if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+    for (int i = 0; i < 2; i++)
+        if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -272,7 +277,7 @@ extern "C" int orbhip_level_size(const orbhip_ctx *c, int w, int h, int level, i
 // The launch sequence of one batch.  lvl0: device pointer of frame 0 / level 0.
 // Stage boundaries are marked with HIP events on the context stream (ev[0..5]).
 static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t frame0, int B,
-                        orbhip_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts, int cap)
+                        orbhip_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts, int cap, uint8_t *h_pyr_dst = nullptr)
 {
     const OrbLevels &G = c->G;
     hipStream_t s = c->stream;
@@ -292,6 +297,16 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
                       c->resizeGroups[l] ? c->d_resizeTab + c->resizeTabOff[l][2] : nullptr, c->resizeHint[l][B >= 8 ? 0 : 1], B);
     }
     if (ev) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    // host copy of levels 1.. (orbhip_set_host_pyramid): one copy of the B frames' pyramid block into pinned memory.  A
+    // frame or two: on the second stream, beside FAST / quadtree / blur / describe (those do not use it then); the main
+    // stream joins it at the end.  Batches (the second stream carries the blur): behind the describe kernel.
+    const bool pyrFork = h_pyr_dst && B < 8 && G.nlevels > 1;
+    if (pyrFork) {
+        HIPCHK(c, hipEventRecord(c->evp[0], s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evp[0], 0));
+        HIPCHK(c, hipMemcpyAsync(h_pyr_dst, c->d_pyr, (size_t)B * c->pyrFrameBytes, hipMemcpyDeviceToHost, c->stream2));
+        HIPCHK(c, hipEventRecord(c->evp[1], c->stream2));
+    }
     // E3 FAST alone on the device (it is the kernel whose roofline is reported), then the quadtree
     // (latency-bound, a few thousand workgroups) and the blur (streaming) run CONCURRENTLY on two
     // streams: both only depend on the pyramid / the FAST output; the describe kernel joins them.
@@ -330,6 +345,10 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
                     c->lvl0FrameBytes + c->pyrFrameBytes, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, d_kps,
                     d_desc, d_counts, cap, B);
     if (ev) HIPCHK(c, hipEventRecord(c->ev[5], s));
+    if (pyrFork)
+        HIPCHK(c, hipStreamWaitEvent(s, c->evp[1], 0));
+    else if (h_pyr_dst && G.nlevels > 1)
+        HIPCHK(c, hipMemcpyAsync(h_pyr_dst, c->d_pyr, (size_t)B * c->pyrFrameBytes, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipGetLastError());
     if (ev) c->haveStageEvents = true;
     c->last_lvl0 = lvl0;
@@ -395,6 +414,26 @@ static int host_stage(orbhip_ctx *c, size_t bytes)
     return ORBHIP_OK;
 }
 
+// pinned block for the host copy of the pyramid (levels 1..) of B frames; nullptr when the copy is not asked for
+static int host_pyr_stage(orbhip_ctx *c, int B, uint8_t **dst)
+{
+    *dst = nullptr;
+    c->h_pyr_B = 0;
+    if (!c->hostPyr || c->G.nlevels < 2) return ORBHIP_OK;
+    const size_t bytes = (size_t)B * c->pyrFrameBytes;
+    if (bytes > c->h_pyr_bytes) {
+        if (c->h_pyr) HIPCHK(c, hipHostFree(c->h_pyr));
+        c->h_pyr = nullptr;
+        c->h_pyr_bytes = 0;
+        void *p = nullptr;
+        HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        c->h_pyr = (uint8_t *)p;
+        c->h_pyr_bytes = bytes;
+    }
+    *dst = c->h_pyr;
+    return ORBHIP_OK;
+}
+
 static void graph_release(orbhip_ctx *c)
 {
     if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
@@ -424,6 +463,9 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
     }
     int rc;
     if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
+    uint8_t *hpyr = nullptr;
+    if ((rc = host_pyr_stage(c, B, &hpyr))) return rc;
+    c->h_in_valid = false;
     for (int b = 0; b < B; b++) {
         if (!imgs[b]) return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: null image");
         uint8_t *dst = c->h_in + (size_t)b * c->lvl0FrameBytes;
@@ -433,7 +475,7 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
             for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * s0, imgs[b] + (size_t)y * stride, (size_t)w);
     }
     uint8_t *blk = reinterpret_cast<uint8_t *>(c->d_kps);
-    const void *key[4] = {c->d_lvl0, blk, c->h_in, c->h_stage};
+    const void *key[5] = {c->d_lvl0, blk, c->h_in, c->h_stage, hpyr};
     const bool same = c->g_exec && c->g_w == w && c->g_h == h && c->g_B == B && memcmp(key, c->g_key, sizeof(key)) == 0;
     if (!same) {
         graph_release(c);
@@ -442,7 +484,7 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         hipError_t e = hipMemcpyAsync(c->d_lvl0, c->h_in, inBytes, hipMemcpyHostToDevice, c->stream);
         rc = e == hipSuccess ? run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
-                                            (int32_t *)(blk + coff), dcap)
+                                            (int32_t *)(blk + coff), dcap, hpyr)
                              : ORBHIP_E_HIP;
         if (rc == ORBHIP_OK) e = hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream);
         hipGraph_t g = nullptr;
@@ -464,13 +506,15 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
         // GetTimeOfComputePyramid / ...KeyPointsOctTree / ...Descriptor (include/ORBextractor.h:51-53)
         HIPCHK(c, hipMemcpyAsync(c->d_lvl0, c->h_in, inBytes, hipMemcpyHostToDevice, c->stream));
         if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
-                               (int32_t *)(blk + coff), dcap)))
+                               (int32_t *)(blk + coff), dcap, hpyr)))
             return rc;
         HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
     } else {
         HIPCHK(c, hipGraphLaunch(c->g_exec, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_in_valid = true;
+    c->h_pyr_B = hpyr ? B : 0;
     (void)kbytes; (void)dbytes;
     return ORBHIP_OK;
 }
@@ -500,12 +544,16 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
             HIPCHK(c, hipMemcpy2DAsync(c->d_lvl0 + (size_t)b * c->lvl0FrameBytes, s0, imgs[b], stride, w, h,
                                        hipMemcpyHostToDevice, c->stream));
         }
+        uint8_t *hpyr = nullptr;
+        if ((rc = host_pyr_stage(c, B, &hpyr))) return rc;
+        c->h_in_valid = false;
         if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
-                               (int32_t *)(blk + coff), dcap)))
+                               (int32_t *)(blk + coff), dcap, hpyr)))
             return rc;
         if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->h_pyr_B = hpyr ? B : 0;
     }
     memcpy(n_out, c->h_stage + coff, cbytes);
     for (int b = 0; b < B; b++) {
@@ -768,6 +816,36 @@ extern "C" int orbhip_get_pyramid_level(orbhip_ctx *c, int frame, int level, uin
     if (level == 0)
         return copy_level(c, c->last_lvl0 + (size_t)frame * c->last_frame0, c->last_stride0, L.w, L.h, dst, dst_stride);
     return copy_level(c, c->d_pyr + (size_t)frame * c->pyrFrameBytes + L.imgOff, L.stride, L.w, L.h, dst, dst_stride);
+}
+
+extern "C" int orbhip_set_host_pyramid(orbhip_ctx *c, int on)
+{
+    if (!c) return fail(c, ORBHIP_E_ARG, "orbhip_set_host_pyramid: null context");
+    c->hostPyr = on != 0;
+    if (!c->hostPyr) c->h_pyr_B = 0;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_host_pyramid_level(orbhip_ctx *c, int frame, int level, const uint8_t **ptr, int *stride, int *w, int *h)
+{
+    if (!c || !ptr || !stride || frame < 0 || level < 0 || level >= c->nlevels)
+        return fail(c, ORBHIP_E_ARG, "orbhip_host_pyramid_level: bad argument");
+    const OrbLevel &L = c->G.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (level == 0) {
+        // the pinned copy of the caller's frame that the single-frame path uploads from (rows last_stride0 apart)
+        if (!c->h_in_valid || frame >= c->last_B || c->last_lvl0 != c->d_lvl0)
+            return fail(c, ORBHIP_E_ARG, "orbhip_host_pyramid_level: level 0 is not staged on the host for this call (use the caller's image)");
+        *ptr = c->h_in + (size_t)frame * c->lvl0FrameBytes;
+        *stride = c->last_stride0;
+        return ORBHIP_OK;
+    }
+    if (frame >= c->h_pyr_B)
+        return fail(c, ORBHIP_E_ARG, "orbhip_host_pyramid_level: no host pyramid for this frame (orbhip_set_host_pyramid before orbhip_extract*)");
+    *ptr = c->h_pyr + (size_t)frame * c->pyrFrameBytes + L.imgOff;
+    *stride = L.stride;
+    return ORBHIP_OK;
 }
 
 extern "C" int orbhip_debug_get_blurred_level(orbhip_ctx *c, int frame, int level, uint8_t *dst, int dst_stride,

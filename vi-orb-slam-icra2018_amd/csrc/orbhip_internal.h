@@ -179,12 +179,20 @@ struct orbhip_ctx {
     // first call of a geometry, replayed while (w, h, B, buffers) stay the same
     uint8_t *h_in = nullptr;          // pinned input staging, rows s0 apart
     size_t h_in_bytes = 0;
+    // host copy of the pyramid levels 1.. (pinned), filled beside the kernels when orbhip_set_host_pyramid is on: the
+    // drop-in's mvImagePyramid (Frame.cc:817) are headers into it and into h_in (level 0)
+    bool hostPyr = false;
+    uint8_t *h_pyr = nullptr;
+    size_t h_pyr_bytes = 0;
+    int h_pyr_B = 0;                  // frames of the last call that are valid in h_pyr (0 = none)
+    bool h_in_valid = false;          // h_in holds the frames of the last call
+    hipEvent_t evp[2] = {nullptr, nullptr};   // pyramid built | pyramid copied out
     hipGraphExec_t g_exec = nullptr;
     hipGraph_t g_graph = nullptr;
     int g_w = 0, g_h = 0, g_B = 0;
     bool capturing = false;           // run_pipeline leaves the timing events out of a capture
     unsigned g_calls = 0;
-    const void *g_key[4] = {nullptr, nullptr, nullptr, nullptr};   // d_lvl0, d_kps block, h_in, h_stage at capture time
+    const void *g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // d_lvl0, d_kps block, h_in, h_stage, h_pyr (or null) at capture time
 
     // matching scratch
     void *d_match = nullptr;

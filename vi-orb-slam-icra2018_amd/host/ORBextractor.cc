@@ -82,6 +82,7 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
         return;
     }
 
+    orbhip_set_host_pyramid(mpCtx, mbDownloadPyramid ? 1 : 0);
     const int cap = orbhip_max_keypoints(mpCtx);
     mvKpStage.resize(cap);
     cv::Mat descStage(cap, 32, CV_8U);
@@ -113,10 +114,20 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
 
     if (mbDownloadPyramid)
     {
+        // mvImagePyramid[level] (ref: include/ORBextractor.h:103, read by src/Frame.cc:817): headers on the page-locked host
+        // copy that liborbhip filled beside the kernels -- valid until the next call of this extractor, which is how the
+        // reference's callers use them.  A level that is not staged there (ORBHIP_NO_GRAPH runs) is copied instead.
         for (int level = 0; level < nlevels; ++level)
         {
-            int w = 0, h = 0;
+            const uint8_t *p = nullptr;
+            int st = 0, w = 0, h = 0;
+            if (orbhip_host_pyramid_level(mpCtx, 0, level, &p, &st, &w, &h) == ORBHIP_OK)
+            {
+                mvImagePyramid[level] = cv::Mat(h, w, CV_8UC1, (void *)p, (size_t)st);
+                continue;
+            }
             orbhip_get_pyramid_level(mpCtx, 0, level, nullptr, 0, &w, &h);
+            mvImagePyramid[level].release();                 // (it may be a header on the page-locked block of an earlier call)
             mvImagePyramid[level].create(h, w, CV_8UC1);
             if (orbhip_get_pyramid_level(mpCtx, 0, level, mvImagePyramid[level].data, (int)mvImagePyramid[level].step,
                                          &w, &h) != ORBHIP_OK)

@@ -23,7 +23,7 @@ SYMBOLS = [
     "orbhip_stream", "orbhip_get_tables", "orbhip_tables", "orbhip_max_keypoints", "orbhip_level_size",
     "orbhip_extract", "orbhip_extract_batch", "orbhip_extract_batch_device", "orbhip_host_alloc", "orbhip_host_free",
     "orbhip_pipe_create", "orbhip_pipe_destroy", "orbhip_pipe_submit", "orbhip_pipe_wait", "orbhip_pipe_enable_bow", "orbhip_pipe_matches",
-    "orbhip_get_pyramid_level", "orbhip_debug_get_blurred_level", "orbhip_debug_get_candidates",
+    "orbhip_get_pyramid_level", "orbhip_set_host_pyramid", "orbhip_host_pyramid_level", "orbhip_debug_get_blurred_level", "orbhip_debug_get_candidates",
     "orbhip_debug_get_level_keypoints", "orbhip_hamming_knn2", "orbhip_hamming_knn2_device",
     "orbhip_hamming_knn2_seq_device", "orbhip_get_stage_times", "orbhip_vocab_load", "orbhip_vocab_load_device",
     "orbhip_vocab_info", "orbhip_vocab_text_to_binary", "orbhip_vocab_transform", "orbhip_vocab_transform_device",
@@ -95,6 +95,8 @@ def load():
     L.orbhip_pipe_enable_bow.argtypes = [vp, i32, f32, i32]
     L.orbhip_pipe_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.orbhip_get_pyramid_level.argtypes = [vp, i32, i32, vp, i32, ip, ip]
+    L.orbhip_set_host_pyramid.argtypes = [vp, i32]
+    L.orbhip_host_pyramid_level.argtypes = [vp, i32, i32, C.POINTER(vp), ip, ip, ip]
     L.orbhip_debug_get_blurred_level.argtypes = [vp, i32, i32, vp, i32, ip, ip]
     L.orbhip_debug_get_candidates.argtypes = [vp, i32, i32, vp, i32, ip]
     L.orbhip_debug_get_level_keypoints.argtypes = [vp, i32, i32, vp, i32, ip]

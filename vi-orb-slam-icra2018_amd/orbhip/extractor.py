@@ -187,6 +187,19 @@ class ORBextractor:
     def image_pyramid(self, level, frame=0):
         return self._level(self._L.orbhip_get_pyramid_level, level, frame)
 
+    def set_host_pyramid(self, on=True):
+        """Following host-pointer extract calls also land levels 1.. in page-locked host memory (orbhip_set_host_pyramid)."""
+        check(self._L.orbhip_set_host_pyramid(self._h, 1 if on else 0), self._h, "set_host_pyramid")
+
+    def host_pyramid(self, level, frame=0):
+        """Level `level` of frame `frame` of the last extract call as a copy of the page-locked block the drop-in's
+        mvImagePyramid headers point into (orbhip_host_pyramid_level); raises if the level is not staged on the host."""
+        ptr, st, w, h = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        check(self._L.orbhip_host_pyramid_level(self._h, frame, level, C.byref(ptr), C.byref(st), C.byref(w), C.byref(h)),
+              self._h, "host_pyramid_level")
+        rows = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h.value * st.value,))
+        return rows.reshape(h.value, st.value)[:, :w.value].copy()
+
     @property
     def mvImagePyramid(self):
         return [self.image_pyramid(l) for l in range(self.nlevels)]
