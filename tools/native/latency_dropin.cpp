@@ -1,13 +1,18 @@
 // latency_dropin.cpp -- per-call latency of the extractor as a C++ caller sees it (no Python in the loop):
 //   (a) orbhip_extract through the C ABI (host image in, keypoints + descriptors out),
 //   (b) ORB_SLAM2::ORBextractor::operator() without and with mvImagePyramid on the host (Tracking.cc / Frame.cc usage).
-// usage: latency_dropin w h nfeatures frame.raw [iterations]
+//   (c) with a vocabulary file and a second frame: what Tracking::TrackReferenceKeyFrame adds per frame --
+//       ORBVocabulary::transform (Frame::ComputeBoW, src/Frame.cc:739-746) and ORBmatcher::SearchByBoW(KF, F)
+//       (src/Tracking.cc:1881-1885).
+// usage: latency_dropin w h nfeatures frames.raw [iterations [voc.bin]]      (frames.raw: one frame, or two for (c))
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#include "ORBVocabulary.h"
 #include "ORBextractor.h"
+#include "ORBmatcher.h"
 #include "orbhip.h"
 
 using namespace ORB_SLAM2;
@@ -19,9 +24,10 @@ int main(int argc, char **argv)
 {
     if (argc < 5) { fprintf(stderr, "usage: %s w h nfeatures frame.raw [iterations]\n", argv[0]); return 2; }
     const int w = atoi(argv[1]), h = atoi(argv[2]), nf = atoi(argv[3]), iters = argc > 5 ? atoi(argv[5]) : 2000;
-    std::vector<unsigned char> pix((size_t)w * h);
+    std::vector<unsigned char> pix((size_t)w * h), pix2((size_t)w * h);
     FILE *f = fopen(argv[4], "rb");
     if (!f || fread(pix.data(), 1, pix.size(), f) != pix.size()) { perror(argv[4]); return 2; }
+    const bool two = fread(pix2.data(), 1, pix2.size(), f) == pix2.size();
     fclose(f);
 
     // (a) C ABI
@@ -55,7 +61,46 @@ int main(int argc, char **argv)
         nk = (int)keys.size();
     }
     printf("{\"w\": %d, \"h\": %d, \"nfeatures\": %d, \"keypoints\": %d, \"iterations\": %d, \"orbhip_extract_ms\": %.4f, "
-           "\"dropin_operator_ms\": %.4f, \"dropin_operator_with_pyramid_ms\": %.4f}\n",
+           "\"dropin_operator_ms\": %.4f, \"dropin_operator_with_pyramid_ms\": %.4f",
            w, h, nf, nk, iters, capi, cls[0], cls[1]);
+    if (argc > 6 && two) {
+        ORBVocabulary voc;
+        if (!voc.loadFromBinaryFile(argv[6])) { fprintf(stderr, "cannot load %s\n", argv[6]); return 1; }
+        ORBextractor ex(nf, 1.2f, 8, 20, 7);
+        ex.SetPyramidDownload(false);
+        KeyFrame kf;
+        Frame F;
+        std::vector<MapPoint> points(8192);
+        {
+            cv::Mat im1(h, w, CV_8UC1, (void *)pix.data()), im2(h, w, CV_8UC1, (void *)pix2.data());
+            ex(im1, cv::Mat(), kf.mvKeys, kf.mDescriptors);
+            kf.mvKeysUn = kf.mvKeys;
+            kf.mvpMapPoints.resize(kf.mvKeys.size());
+            for (size_t i = 0; i < kf.mvKeys.size(); i++) kf.mvpMapPoints[i] = &points[i];
+            ex(im2, cv::Mat(), F.mvKeys, F.mDescriptors);
+            F.mvKeysUn = F.mvKeys;
+            F.N = (int)F.mvKeys.size();
+        }
+        // Converter::toDescriptorVector (src/Converter.cc:163-171): one 1x32 Mat per descriptor row
+        std::vector<cv::Mat> d1, d2;
+        for (int j = 0; j < kf.mDescriptors.rows; j++) d1.push_back(kf.mDescriptors.row(j));
+        for (int j = 0; j < F.mDescriptors.rows; j++) d2.push_back(F.mDescriptors.row(j));
+        DBoW2::BowVector bv;
+        voc.transform(d1, bv, kf.mFeatVec, 4);
+        const int it2 = iters / 4 > 0 ? iters / 4 : 1;
+        for (int i = 0; i < 5; i++) voc.transform(d2, bv, F.mFeatVec, 4);
+        t0 = Clock::now();
+        for (int i = 0; i < it2; i++) voc.transform(d2, bv, F.mFeatVec, 4);
+        const double tr = ms_since(t0) / it2;
+        ORBmatcher matcher(0.7, true);
+        std::vector<MapPoint *> vpMapPointMatches;
+        int nm = 0;
+        for (int i = 0; i < 5; i++) nm = matcher.SearchByBoW(&kf, F, vpMapPointMatches);
+        t0 = Clock::now();
+        for (int i = 0; i < it2; i++) nm = matcher.SearchByBoW(&kf, F, vpMapPointMatches);
+        const double sb = ms_since(t0) / it2;
+        printf(", \"vocabulary_words\": %u, \"transform_ms\": %.4f, \"search_by_bow_ms\": %.4f, \"bow_matches\": %d", voc.size(), tr, sb, nm);
+    }
+    printf("}\n");
     return n == nk ? 0 : 1;
 }

@@ -220,3 +220,286 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
                            reinterpret_cast<const int4 *>(ytab), reinterpret_cast<const int4 *>(gtab), sw, sh, winx, winy,
                            orb_xcd_arg(1));
 }
+
+// =====================================================================================================================
+// Chained pyramid for a frame or two (single-frame latency).  Seven dependent k_resize launches cost ~4.7 us each although
+// the arithmetic of a whole 640x480 pyramid is a few microseconds of the chip: the chain is launch-to-launch latency.
+// k_pyramid_chain builds several levels per launch: a workgroup owns a CHAIN_TW x CHAIN_TH tile of level `top` and
+// recomputes, inside LDS, the regions of the levels between `base` and `top` that the tile depends on (each level is a
+// deterministic function of the previous one, so the recomputed pixels are the pixels k_resize writes -- same tap tables,
+// same integer formula).  Every level's tiles are independent workgroups of the same launch; the redundant arithmetic (a
+// level-4 tile recomputes ~9x its own pixel count) is noise next to the launches saved.  All global reads of a
+// workgroup -- the base region, the tap-table slices of every level of its chain -- are issued before the first wait.
+// Host side: chain_plan() groups the levels (ORBHIP_CHAIN_DEPTH levels per launch, default 4) and sizes the LDS;
+// resize_hint_pointwise() proves per level that the computed source windows contain the taps.  Batches keep k_resize.
+// =====================================================================================================================
+#define CH_NT 1024 // threads of a workgroup: a pixel of a chain step is a chain of dependent LDS reads (tap entry -> source
+                   // bytes -> store), so the steps are latency, and many short per-thread loops hide it better than few long ones
+#define CH_KX 2    // column-tap entries staged per thread (2048 over the levels of a chain)
+#define CH_KY 1    // row-tap entries per thread (1024)
+#define CH_KP 2    // 16-byte chunks of the base region per thread (2048 = 32 KB)
+
+// the region of level l - 1 read by the region [x0, x1] x [y0, y1] of level l: the window hint of k_resize
+__host__ __device__ inline void chain_source_region(int &x0, int &x1, int &y0, int &y1, float winx, float winy, int sw, int sh)
+{
+    int a = (int)((float)x0 * winx) - 1, b = (int)((float)(x1 + 1) * winx) + 1;
+    x0 = a < 0 ? 0 : a;
+    x1 = b > sw - 1 ? sw - 1 : b;
+    a = (int)((float)y0 * winy) - 1;
+    b = (int)((float)(y1 + 1) * winy) + 1;
+    y0 = a < 0 ? 0 : a;
+    y1 = b > sh - 1 ? sh - 1 : b;
+}
+
+__global__ __launch_bounds__(CH_NT) void k_pyramid_chain(const OrbLevels G, const ChainLevels CL, const ChainTile *__restrict__ tiles,
+                                                       const uint8_t *__restrict__ lvl0, int stride0, unsigned long long frame0,
+                                                       uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
+                                                       const int32_t *__restrict__ tab, int bufA, int bufB, int xtabBytes)
+{
+    extern __shared__ __align__(16) uint8_t smem[];   // [buffer A | buffer B | column taps | row taps]
+    __shared__ int s_r[ORBHIP_MAX_LEVELS][4];          // region of every level of the chain: x0, x1, y0, y1 (inclusive)
+    __shared__ int s_xo[ORBHIP_MAX_LEVELS], s_yo[ORBHIP_MAX_LEVELS];   // first staged entry of the level's tap slices
+    __shared__ unsigned s_xoff[ORBHIP_MAX_LEVELS], s_yoff[ORBHIP_MAX_LEVELS];
+    __shared__ int s_tot[2];
+    ChainTile T;
+    *reinterpret_cast<uint2 *>(&T) = *reinterpret_cast<const uint2 *>(tiles + blockIdx.x);   // one 8-byte load
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    const int top = T.level, base = T.base;
+    if (tid == 0) {
+        int x0 = T.tx * CHAIN_TW, y0 = T.ty * CHAIN_TH;
+        int x1 = min(x0 + CHAIN_TW, G.lv[top].w) - 1, y1 = min(y0 + CHAIN_TH, G.lv[top].h) - 1;
+        int sx = 0, sy = 0;
+        for (int l = top; l > base; l--) {
+            s_r[l][0] = x0; s_r[l][1] = x1; s_r[l][2] = y0; s_r[l][3] = y1;
+            s_xo[l] = sx; s_yo[l] = sy;
+            s_xoff[l] = CL.xoff[l]; s_yoff[l] = CL.yoff[l];
+            sx += x1 - x0 + 1;
+            sy += y1 - y0 + 1;
+            chain_source_region(x0, x1, y0, y1, CL.winx[l], CL.winy[l], G.lv[l - 1].w, G.lv[l - 1].h);
+        }
+        s_r[base][0] = x0; s_r[base][1] = x1; s_r[base][2] = y0; s_r[base][3] = y1;
+        s_tot[0] = sx; s_tot[1] = sy;
+    }
+    __syncthreads();
+    uint8_t *bA = smem, *bB = smem + bufA;
+    int2 *s_xt = reinterpret_cast<int2 *>(smem + bufA + bufB);
+    int4 *s_yt = reinterpret_cast<int4 *>(smem + bufA + bufB + xtabBytes);
+
+    // ---- stage: base region (16-byte row-coalesced chunks) and the tap slices of every level; loads first, stores after ----
+    const int bx0 = s_r[base][0], bx1 = s_r[base][1], by0 = s_r[base][2], by1 = s_r[base][3];
+    const int XA = bx0 & ~15, nch = ((bx1 - XA) >> 4) + 1, nrows = by1 - by0 + 1, pS = nch << 4;
+    const uint8_t *S = base == 0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + G.lv[base].imgOff;
+    const int sstride = base == 0 ? stride0 : G.lv[base].stride;
+    const int npix = nrows * nch, sumx = s_tot[0], sumy = s_tot[1];
+    const float invNch = __builtin_amdgcn_rcpf((float)nch);   // i / nch = floor((i + 0.5) * invNch) for i < 2^13 (see k_fast)
+    uint4 pv[CH_KP];
+    int2 xv[CH_KX];
+    int4 yv[CH_KY];
+    const uint8_t *S0 = S + (size_t)by0 * sstride + XA;
+#pragma unroll
+    for (int k = 0; k < CH_KP; k++) {
+        const int i = min(tid + CH_NT * k, npix - 1);
+        const int r = (int)(((float)i + 0.5f) * invNch), c = i - r * nch;
+        pv[k] = *reinterpret_cast<const uint4 *>(S0 + (unsigned)(r * sstride + (c << 4)));
+    }
+#pragma unroll
+    for (int k = 0; k < CH_KX; k++) {
+        int rem = min(tid + CH_NT * k, sumx - 1), l = top;
+        while (l > base + 1 && rem >= s_r[l][1] - s_r[l][0] + 1) {
+            rem -= s_r[l][1] - s_r[l][0] + 1;
+            l--;
+        }
+        xv[k] = reinterpret_cast<const int2 *>(tab + s_xoff[l])[s_r[l][0] + rem];
+    }
+#pragma unroll
+    for (int k = 0; k < CH_KY; k++) {
+        int rem = min(tid + CH_NT * k, sumy - 1), l = top;
+        while (l > base + 1 && rem >= s_r[l][3] - s_r[l][2] + 1) {
+            rem -= s_r[l][3] - s_r[l][2] + 1;
+            l--;
+        }
+        yv[k] = reinterpret_cast<const int4 *>(tab + s_yoff[l])[s_r[l][2] + rem];
+    }
+    // (the empty asm pins every loaded value here: without it the compiler sinks each load into the conditional store below
+    // and the workgroup waits for them one by one)
+#pragma unroll
+    for (int k = 0; k < CH_KP; k++) asm volatile("" : "+v"(pv[k].x), "+v"(pv[k].y), "+v"(pv[k].z), "+v"(pv[k].w));
+#pragma unroll
+    for (int k = 0; k < CH_KX; k++) asm volatile("" : "+v"(xv[k].x), "+v"(xv[k].y));
+#pragma unroll
+    for (int k = 0; k < CH_KY; k++) asm volatile("" : "+v"(yv[k].x), "+v"(yv[k].y), "+v"(yv[k].z), "+v"(yv[k].w));
+#pragma unroll
+    for (int k = 0; k < CH_KP; k++) {
+        const int i = tid + CH_NT * k;
+        if (i < npix) {
+            const int r = (int)(((float)i + 0.5f) * invNch), c = i - r * nch;
+            *reinterpret_cast<uint4 *>(bA + r * pS + (c << 4)) = pv[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CH_KX; k++)
+        if (tid + CH_NT * k < sumx) s_xt[tid + CH_NT * k] = xv[k];
+#pragma unroll
+    for (int k = 0; k < CH_KY; k++)
+        if (tid + CH_NT * k < sumy) s_yt[tid + CH_NT * k] = yv[k];
+    __syncthreads();
+
+    // ---- level by level inside LDS; the last level goes to memory ----
+    const uint8_t *src = bA;
+    uint8_t *dst = bB;
+    int ox = XA, oy = by0, ps = pS;
+    uint8_t *D = pyr + (size_t)frame * pyrFrame + G.lv[top].imgOff;
+    const int dstride = G.lv[top].stride;
+    for (int l = base + 1; l <= top; l++) {
+        const int x0 = s_r[l][0], y0 = s_r[l][2];
+        const int nx = s_r[l][1] - x0 + 1, ny = s_r[l][3] - y0 + 1, pd = (nx + 3) & ~3;
+        const int2 *xt = s_xt + s_xo[l];
+        const int4 *yt = s_yt + s_yo[l];
+        const float invNx = __builtin_amdgcn_rcpf((float)nx);
+        const bool last = l == top;
+        // two pixels per trip: their LDS round trips overlap
+        auto pixel = [&](int i) -> int {
+            const int ry = (int)(((float)i + 0.5f) * invNx), rx = i - ry * nx;
+            const int4 t = yt[ry];
+            const int2 u = xt[rx];
+            const int sx0 = (u.x & 0xFFFF) - ox, sx1 = (int)((unsigned)u.x >> 16) - ox;
+            const int a0 = (short)(u.y & 0xFFFF), a1 = u.y >> 16;
+            const uint8_t *L0 = src + (t.x - oy) * ps, *L1 = src + (t.y - oy) * ps;
+            // the integers of k_resize's generic path
+            const int r0 = L0[sx0] * a0 + L0[sx1] * a1;
+            const int r1 = L1[sx0] * a0 + L1[sx1] * a1;
+            return (((t.z * (r0 >> 4)) >> 16) + ((t.w * (r1 >> 4)) >> 16) + 2) >> 2;
+        };
+        auto put = [&](int i, int v) {
+            const int ry = (int)(((float)i + 0.5f) * invNx), rx = i - ry * nx;
+            if (last)
+                D[(size_t)(y0 + ry) * dstride + x0 + rx] = (uint8_t)v;
+            else
+                dst[ry * pd + rx] = (uint8_t)v;
+        };
+        const int n = nx * ny;
+        for (int i = tid; i < n; i += 2 * CH_NT) {
+            const int j = i + CH_NT;
+            const int va = pixel(i), vb = pixel(min(j, n - 1));
+            put(i, va);
+            if (j < n) put(j, vb);
+        }
+        __syncthreads();
+        uint8_t *nd = const_cast<uint8_t *>(src);
+        src = dst;
+        dst = nd;
+        ox = x0;
+        oy = y0;
+        ps = pd;
+    }
+}
+
+// Does the window that chain_source_region / k_resize derive from the scale factors contain the taps of EVERY output
+// column and row taken alone?  (Then it contains the taps of any interval: the bounds and the taps are monotone.)
+bool resize_hint_pointwise(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh)
+{
+    const float winx = (float)sw / (float)dw, winy = (float)sh / (float)dh;
+    int prev = -1;
+    for (int o = 0; o < dw; o++) {
+        const int lo = std::max((int)((float)o * winx) - 1, 0), hi = std::min((int)((float)(o + 1) * winx) + 1, sw - 1);
+        const int s0 = xt[2 * o] & 0xFFFF, s1 = (int)((uint32_t)xt[2 * o] >> 16);
+        if (lo > s0 || hi < s1 || s0 < prev) return false;
+        prev = s0;
+    }
+    prev = -1;
+    for (int o = 0; o < dh; o++) {
+        const int lo = std::max((int)((float)o * winy) - 1, 0), hi = std::min((int)((float)(o + 1) * winy) + 1, sh - 1);
+        if (lo > yt[4 * o] || hi < yt[4 * o + 1] || yt[4 * o] < prev) return false;
+        prev = yt[4 * o];
+    }
+    return true;
+}
+
+struct ChainNeed {
+    int bufA = 0, bufB = 0, sumx = 0, sumy = 0;
+    bool ok = true;
+};
+
+// LDS and staging needs of the tiles of level `top` chained from level `base`
+static void chain_need(const OrbLevels &G, const ChainLevels &CL, int base, int top, ChainNeed &N)
+{
+    const int tilesX = (G.lv[top].w + CHAIN_TW - 1) / CHAIN_TW, tilesY = (G.lv[top].h + CHAIN_TH - 1) / CHAIN_TH;
+    for (int ty = 0; ty < tilesY; ty++)
+        for (int tx = 0; tx < tilesX; tx++) {
+            int x0 = tx * CHAIN_TW, y0 = ty * CHAIN_TH;
+            int x1 = std::min(x0 + CHAIN_TW, G.lv[top].w) - 1, y1 = std::min(y0 + CHAIN_TH, G.lv[top].h) - 1;
+            int sx = 0, sy = 0;
+            for (int l = top; l > base; l--) {
+                const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, bytes = ((nx + 3) & ~3) * ny;
+                if (nx * ny >= 32768) N.ok = false;
+                // level l is written by step l - base: odd steps into buffer B, even steps into buffer A
+                if ((l - base) & 1) N.bufB = std::max(N.bufB, bytes); else N.bufA = std::max(N.bufA, bytes);
+                sx += nx;
+                sy += ny;
+                chain_source_region(x0, x1, y0, y1, CL.winx[l], CL.winy[l], G.lv[l - 1].w, G.lv[l - 1].h);
+            }
+            const int nch = ((x1 - (x0 & ~15)) >> 4) + 1, nrows = y1 - y0 + 1;
+            if (nch * nrows > CH_NT * CH_KP || nch * nrows >= 8192) N.ok = false;
+            N.bufA = std::max(N.bufA, nch * 16 * nrows);
+            N.sumx = std::max(N.sumx, sx);
+            N.sumy = std::max(N.sumy, sy);
+        }
+    if (N.sumx > CH_NT * CH_KX || N.sumy > CH_NT * CH_KY) N.ok = false;
+}
+
+bool chain_plan(const OrbLevels &G, const bool *levelOk, const ChainLevels &CL, std::vector<ChainTile> &tiles,
+                std::vector<ChainGroup> &groups)
+{
+    static const int depthEnv = getenv("ORBHIP_CHAIN_DEPTH") ? atoi(getenv("ORBHIP_CHAIN_DEPTH")) : 4;
+    const int maxDepth = depthEnv < 1 ? 1 : depthEnv;
+    const int ldsCap = 64 * 1024;
+    tiles.clear();
+    groups.clear();
+    int base = 0;
+    while (base < G.nlevels - 1) {
+        int top = base;
+        ChainNeed need;
+        while (top + 1 < G.nlevels && top + 1 - base <= maxDepth && levelOk[top + 1]) {
+            ChainNeed n = need;
+            chain_need(G, CL, base, top + 1, n);
+            const int lds = ((n.bufA + 15) & ~15) + ((n.bufB + 15) & ~15) + ((n.sumx * 8 + 15) & ~15) + n.sumy * 16;
+            if (!n.ok || lds > ldsCap) break;
+            need = n;
+            top++;
+        }
+        if (top == base) {
+            tiles.clear();
+            groups.clear();
+            return false;
+        }
+        ChainGroup g;
+        g.firstTile = (int)tiles.size();
+        for (int l = top; l > base; l--)   // the deepest chains first
+            for (int ty = 0; ty < (G.lv[l].h + CHAIN_TH - 1) / CHAIN_TH; ty++)
+                for (int tx = 0; tx < (G.lv[l].w + CHAIN_TW - 1) / CHAIN_TW; tx++) {
+                    ChainTile t;
+                    t.level = (short)l;
+                    t.base = (short)base;
+                    t.tx = (short)tx;
+                    t.ty = (short)ty;
+                    tiles.push_back(t);
+                }
+        g.ntiles = (int)tiles.size() - g.firstTile;
+        g.bufA = (need.bufA + 15) & ~15;
+        g.bufB = (need.bufB + 15) & ~15;
+        g.xtabBytes = (need.sumx * 8 + 15) & ~15;
+        g.ytabBytes = need.sumy * 16;
+        groups.push_back(g);
+        base = top;
+    }
+    return true;
+}
+
+void launch_pyramid_chain(hipStream_t s, const OrbLevels &G, const ChainLevels &CL, const ChainGroup &grp, const ChainTile *tiles,
+                          const uint8_t *lvl0, int stride0, size_t frame0, uint8_t *pyr, size_t pyrFrame, const int32_t *tab, int B)
+{
+    dim3 grid(grp.ntiles, B, 1), block(CH_NT, 1, 1);
+    hipLaunchKernelGGL(k_pyramid_chain, grid, block, (size_t)(grp.bufA + grp.bufB + grp.xtabBytes + grp.ytabBytes), s, G, CL,
+                       tiles + grp.firstTile, lvl0, stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tab,
+                       grp.bufA, grp.bufB, grp.xtabBytes);
+}

@@ -82,6 +82,7 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
         }
         // resize tables
         std::vector<int32_t> all;
+        bool chainOk[ORBHIP_MAX_LEVELS] = {};
         for (int l = 1; l < c->nlevels; l++) {
             std::vector<int32_t> xt, yt;
             orb_build_resize_tables(c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, xt, yt);
@@ -98,11 +99,25 @@ static int configure(orbhip_ctx *c, int w, int h, int stride0, int B)
             while (all.size() % 4) all.push_back(0);
             c->resizeTabOff[l][2] = all.size();
             if (c->resizeGroups[l]) all.insert(all.end(), gt.begin(), gt.end());
+            // chained pyramid of the single-frame path (k_pyramid_chain)
+            chainOk[l] = resize_hint_pointwise(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h);
+            c->chainLevels.winx[l] = (float)c->G.lv[l - 1].w / (float)c->G.lv[l].w;
+            c->chainLevels.winy[l] = (float)c->G.lv[l - 1].h / (float)c->G.lv[l].h;
+            c->chainLevels.xoff[l] = (uint32_t)c->resizeTabOff[l][0];
+            c->chainLevels.yoff[l] = (uint32_t)c->resizeTabOff[l][1];
+        }
+        if (c->nlevels < 2 || !chain_plan(c->G, chainOk, c->chainLevels, c->chainTiles, c->chainGroups)) {
+            c->chainTiles.clear();
+            c->chainGroups.clear();
         }
         int rc2;
         if ((rc2 = ensure(c, c->d_resizeTab, c->cap_resize, all.size() * 4 + 16))) return rc2;
         if ((rc2 = ensure(c, c->d_fastTiles, c->cap_fastTiles, c->fastTiles.size() * sizeof(FastTile)))) return rc2;
         if ((rc2 = ensure(c, c->d_blurTiles, c->cap_blurTiles, c->blurTiles.size() * sizeof(BlurTile)))) return rc2;
+        if ((rc2 = ensure(c, c->d_chainTiles, c->cap_chainTiles, c->chainTiles.size() * sizeof(ChainTile) + 16))) return rc2;
+        if (!c->chainTiles.empty())
+            HIPCHK(c, hipMemcpyAsync(c->d_chainTiles, c->chainTiles.data(), c->chainTiles.size() * sizeof(ChainTile),
+                                     hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_resizeTab, all.data(), all.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_fastTiles, c->fastTiles.data(), c->fastTiles.size() * sizeof(FastTile),
                                  hipMemcpyHostToDevice, c->stream));
@@ -210,7 +225,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
-                    c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
+                    c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_chainTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -285,8 +300,15 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
     // hipEventElapsedTime on this runtime; the graph path refreshes the stage times with an eager run now and then)
     const bool ev = !c->capturing;
     if (ev) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    // E2 pyramid: level l from level l-1 (sequential dependency), all frames per launch
-    for (int l = 1; l < G.nlevels; l++) {
+    // E2 pyramid.  A frame or two: several levels per launch (k_pyramid_chain; ORBHIP_NO_CHAIN=1 keeps one launch per level)
+    static const bool noChain = getenv("ORBHIP_NO_CHAIN") && atoi(getenv("ORBHIP_NO_CHAIN")) != 0;
+    const bool chained = B < 8 && !noChain && !c->chainGroups.empty();
+    if (chained)
+        for (const ChainGroup &grp : c->chainGroups)
+            launch_pyramid_chain(s, G, c->chainLevels, grp, c->d_chainTiles, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes,
+                                 c->d_resizeTab, B);
+    // batches: level l from level l-1 (sequential dependency), all frames per launch
+    for (int l = 1; l < G.nlevels && !chained; l++) {
         const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
         const uint8_t *src = (l == 1) ? lvl0 : c->d_pyr + S.imgOff;
         const int sstride = (l == 1) ? stride0 : S.stride;

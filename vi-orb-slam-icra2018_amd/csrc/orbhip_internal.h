@@ -69,6 +69,21 @@ struct BlurTile {
     short level, tx, ty, pad;
 };
 
+// One workgroup of the chained pyramid (k_pyramid_chain, a frame or two): a CHAIN_TW x CHAIN_TH tile of level `level`,
+// built from level `base` through the levels between, all of them inside LDS.
+#define CHAIN_TW 64
+#define CHAIN_TH 16
+struct ChainTile {
+    short level, base, tx, ty;
+};
+struct ChainLevels {                       // by value: per level l (built from l - 1)
+    float winx[ORBHIP_MAX_LEVELS], winy[ORBHIP_MAX_LEVELS];      // source / destination size ratios (window hint)
+    uint32_t xoff[ORBHIP_MAX_LEVELS], yoff[ORBHIP_MAX_LEVELS];   // int32 offsets of the column / row tap tables in the table block
+};
+struct ChainGroup {                        // one launch: the tiles of levels base + 1 .. top
+    int firstTile, ntiles, bufA, bufB, xtabBytes, ytabBytes;   // LDS: buffer A | buffer B | column taps | row taps
+};
+
 // ORB vocabulary: host-side parse result and the device tables.  The device tables are indexed
 // by EDGE (position in the children CSR: the children of a node are consecutive, in file order), so that a
 // descent step is two memory round trips: the child range of the current node, then all its children's
@@ -136,6 +151,11 @@ struct orbhip_ctx {
     std::vector<FastTile> fastTiles;              // runs of up to 5 cells (batches), then runs of 1 cell (a frame or two)
     int nFastTilesBatch = 0;
     std::vector<BlurTile> blurTiles;
+    std::vector<ChainTile> chainTiles;            // chained pyramid of the single-frame path (empty = not available)
+    std::vector<ChainGroup> chainGroups;
+    ChainLevels chainLevels;
+    ChainTile *d_chainTiles = nullptr;
+    size_t cap_chainTiles = 0;
     size_t pyrFrameBytes = 0;      // bytes of one frame's levels 1..n-1 (level 0 separate)
     size_t lvl0FrameBytes = 0;
 
@@ -237,6 +257,12 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
                    uint8_t *dst, int dw, int dh, int dstride, size_t dframe, const int32_t *xtab,
                    const int32_t *ytab, const int32_t *gtab, bool hint, int B);
 bool resize_hint_fits(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, int th);
+bool resize_hint_pointwise(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh);
+// plans the chained pyramid (groups of levels per launch, their tiles and LDS sizes); false = some level cannot be chained
+bool chain_plan(const OrbLevels &G, const bool *levelOk, const ChainLevels &CL, std::vector<ChainTile> &tiles,
+                std::vector<ChainGroup> &groups);
+void launch_pyramid_chain(hipStream_t s, const OrbLevels &G, const ChainLevels &CL, const ChainGroup &grp, const ChainTile *tiles,
+                          const uint8_t *lvl0, int stride0, size_t frame0, uint8_t *pyr, size_t pyrFrame, const int32_t *tab, int B);
 void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
                  uint32_t *cand, uint16_t *cellCnt, int B);
