@@ -10,29 +10,73 @@
 
 #define QT_LDS_LIMIT ((size_t)156 * 1024)   // node tables beyond this go to global memory (k_quadtree<.., true>)
 
+// inclusive prefix sum over the 64 lanes on the DPP network (row shifts, then the totals of the lower rows)
+__device__ __forceinline__ int qt_wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+
+// LAT: the single-frame variant (a handful of workgroups on the whole chip: every step is latency); the batch variant runs
+// thousands of workgroups beside the blur and wants the fewest instructions instead
+template <bool LAT>
 struct QtBlock {
-    int *wtot;  // [waves] LDS
+    int *wtot;  // [waves + 2] LDS: wave totals, then two alternating result slots of the one-wave scan
+    mutable int flip = 0;
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ int nth() const { return blockDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int atomic_add(int *p, int v) const { return atomicAdd(p, v); }
     __device__ __forceinline__ void atomic_min(int *p, int v) const { atomicMin(p, v); }
     __device__ __forceinline__ void atomic_max(unsigned *p, unsigned v) const { atomicMax(p, v); }
+    // *p += sum of v over the workgroup; called by every thread (the wave sums go to the counter, one atomic per wave)
+    __device__ __forceinline__ void reduce_add(int *p, int v) const
+    {
+        const int incl = qt_wave_incl_scan(v);
+        if ((threadIdx.x & 63) == 63 && incl != 0) atomicAdd(p, incl);
+    }
     // In-place exclusive scan of a[0..n) (LDS); returns the total.  Called by all threads.
     __device__ int scan_exclusive(int *a, int n) const
     {
         const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+        if (LAT && n <= 512) {
+            // the node lists of a level (up to ~250 entries) and the cell counts: ONE wave scans K consecutive entries per
+            // lane, the others only wait -- one barrier instead of two and no walk over the wave totals (a third of the
+            // single-frame quadtree time went into the general path below: ~1.3 us per scan, a dozen scans per level)
+            const int slot = 16 + (flip & 1);
+            flip++;
+            if (wave == 0) {
+                const int K = (n + 63) >> 6;
+                const int beg = min(lane * K, n), end = min(beg + K, n);
+                int v[8], sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    v[k] = beg + k < end ? a[beg + k] : 0;
+                    sum += v[k];
+                }
+                const int incl = qt_wave_incl_scan(sum);
+                int run = incl - sum;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (beg + k < end) a[beg + k] = run;
+                    run += v[k];
+                }
+                if (lane == 63) wtot[slot] = incl;
+            }
+            __syncthreads();
+            return wtot[slot];
+        }
         const int nt = blockDim.x;
         const int K = (n + nt - 1) / nt;
         const int beg = min(t * K, n), end = min(beg + K, n);
         int sum = 0;
         for (int i = beg; i < end; i++) sum += a[i];
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
-        }
+        const int incl = qt_wave_incl_scan(sum);
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
         int base = 0, total = 0;
@@ -70,33 +114,71 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
                                                   int ldsPts, uint8_t *__restrict__ tableScratch)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_wtot[16];
+    __shared__ int s_wtot[18];
     // level = blockIdx.y: workgroups are dispatched x-fastest, so every frame's level 0 (the longest chain) starts first
     // and the short upper levels fill the tail
     const int l = blockIdx.y, frame = blockIdx.x;
     const OrbLevel &L = G.lv[l];
     const int tid = threadIdx.x;
-    QtBlock x;
+    QtBlock<LDSPTS> x;
     x.wtot = s_wtot;
 
     // ---- gather: per-cell slots -> compact array in canonical order ----
     int *cellOff = reinterpret_cast<int *>(smem + (GLOBALT ? 0 : qtBytes));
     const int ncells = L.nCols * L.nRows;
     const uint16_t *cc = cellCnt + (size_t)frame * G.totalCells + L.cellBase;
+    const uint32_t *slots = cand + (size_t)frame * G.totalCands + L.candBase;
+    // a frame or two: sixteen lanes per cell (a cell holds a dozen candidates on average, up to cellCap), and the first slot of
+    // every (cell, lane) pair is requested together with the cell counts -- its latency passes during the scan instead of
+    // after it (the gather was two dependent trips to memory)
+    constexpr int QT_PRE = 6;
+    uint32_t pre[QT_PRE];
+    const int npairs = ncells * 16;
+    if (LDSPTS) {
+#pragma unroll
+        for (int k = 0; k < QT_PRE; k++) {
+            const int idx = min(tid + k * (int)blockDim.x, npairs - 1);
+            pre[k] = slots[(size_t)(idx >> 4) * L.cellCap + min(idx & 15, L.cellCap - 1)];
+        }
+    }
     for (int c = tid; c < ncells; c += blockDim.x) cellOff[c] = cc[c];
+    if (LDSPTS) {
+        // (pins the prefetched values above the barrier: the compiler would otherwise sink each load to its use)
+#pragma unroll
+        for (int k = 0; k < QT_PRE; k++) asm volatile("" : "+v"(pre[k]));
+    }
     __syncthreads();
     const int n = x.scan_exclusive(cellOff, ncells);
-    const uint32_t *slots = cand + (size_t)frame * G.totalCands + L.candBase;
     uint32_t *P = pts + (size_t)frame * G.totalPts + L.ptBase;
     uint32_t *PN = pnode + (size_t)frame * G.totalPts + L.ptBase;
     if (LDSPTS && n <= ldsPts) {   // block-uniform
         P = reinterpret_cast<uint32_t *>(smem + (GLOBALT ? 0 : qtBytes) + cellBytes);
         PN = P + ldsPts;
     }
-    for (int c = tid; c < ncells; c += blockDim.x) {
-        const int k = cc[c], o = cellOff[c];
-        const uint32_t *src = slots + (size_t)c * L.cellCap;
-        for (int j = 0; j < k; j++) P[o + j] = src[j];
+    if (LDSPTS) {
+#pragma unroll
+        for (int k = 0; k < QT_PRE; k++) {
+            const int idx = tid + k * (int)blockDim.x;
+            if (idx < npairs) {
+                const int c = idx >> 4, j = idx & 15, o = cellOff[c];
+                const int kk = (c + 1 < ncells ? cellOff[c + 1] : n) - o;
+                if (j < kk) P[o + j] = pre[k];
+                const uint32_t *src = slots + (size_t)c * L.cellCap;
+                for (int jj = j + 16; jj < kk; jj += 16) P[o + jj] = src[jj];
+            }
+        }
+        for (int idx = tid + QT_PRE * (int)blockDim.x; idx < npairs; idx += blockDim.x) {   // more than 6 x 64 cells per workgroup thread set
+            const int c = idx >> 4, o = cellOff[c];
+            const int kk = (c + 1 < ncells ? cellOff[c + 1] : n) - o;
+            const uint32_t *src = slots + (size_t)c * L.cellCap;
+            for (int jj = idx & 15; jj < kk; jj += 16) P[o + jj] = src[jj];
+        }
+    } else {
+        for (int c = tid; c < ncells; c += blockDim.x) {
+            const int k = cc[c], o = cellOff[c];
+            const uint32_t *src = slots + (size_t)c * L.cellCap;
+            for (int j = 0; j < k; j++) P[o + j] = src[j];
+        }
     }
     if (tid == 0) lvlCandCnt[frame * ORBHIP_MAX_LEVELS + l] = n;
     // make the compact array visible to the whole workgroup (global memory, same CU)

@@ -144,11 +144,17 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
     // ---- roots (:549-587): nIni nodes side by side, points by x/hX, empty roots erased ----
     for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.ccnt[i] = 0;
     x.sync();
-    for (int i = x.tid(); i < n; i += x.nth()) {
-        int r = (int)((float)QT_X(pts[i]) / P.hX);
-        r = r < 0 ? 0 : (r >= P.nIni ? P.nIni - 1 : r);
-        pnode[i] = (uint32_t)r;
-        x.atomic_add(&sh.ccnt[r], 1);
+    if (P.nIni == 1) {
+        // one root (every image less than 1.5 times as wide as high): all points are its points
+        for (int i = x.tid(); i < n; i += x.nth()) pnode[i] = 0u;
+        if (x.tid() == 0) sh.ccnt[0] = n;
+    } else {
+        for (int i = x.tid(); i < n; i += x.nth()) {
+            int r = (int)((float)QT_X(pts[i]) / P.hX);
+            r = r < 0 ? 0 : (r >= P.nIni ? P.nIni - 1 : r);
+            pnode[i] = (uint32_t)r;
+            x.atomic_add(&sh.ccnt[r], 1);
+        }
     }
     x.sync();
     for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.scan[i] = sh.ccnt[i] > 0 ? 1 : 0;
@@ -168,6 +174,7 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
     }
     x.sync();
     for (int i = x.tid(); i < n; i += x.nth()) pnode[i] = (uint32_t)sh.npos[pnode[i]];
+    for (int i = x.tid(); i < 4 * S; i += x.nth()) sh.ccnt[i] = 0;   // (the root counts were consumed before the last sync)
     x.sync();
 
     bool careful = false; // inside the final phase (:675-739)
@@ -175,8 +182,7 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
         // ---- which nodes are split candidates: every node holding more than one point ----
         // (after a full pass, and after a completed careful pass, all such nodes are children
         //  created by the previous pass, i.e. exactly vSizeAndPointerToNode)
-        for (int i = x.tid(); i < 4 * S; i += x.nth()) sh.ccnt[i] = 0;
-        x.sync();
+        // (ccnt[0 .. 4 S) is zero here: cleared before the loop and at the end of every pass)
         // ---- children point counts (speculative for every candidate) ----
         for (int i = x.tid(); i < n; i += x.nth()) {
             const uint32_t pn = pnode[i] & 0x3FFFFFFFu;
@@ -191,6 +197,7 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
 
         int jstar = -1; // careful phase: last rank that is processed
         int C = 0;      // number of candidates
+        int newS = 0;   // size of the next list
         if (!careful) {
             // full pass: every candidate is split, in list order
             // scan value packs (#non-empty children << 16) | (node survives unsplit)
@@ -207,6 +214,7 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             x.sync();
             const int tot = x.scan_exclusive(sh.scan, S);
             const int totalCh = tot >> 16;
+            newS = totalCh + (tot & 0xFFFF);   // children created + nodes that stay
             for (int p = x.tid(); p < S; p += x.nth()) {
                 const int pre = sh.scan[p];
                 if (sh.cnt[p] > 1) {
@@ -233,8 +241,12 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             for (int p = x.tid(); p < S; p += x.nth()) sh.scan[p] = sh.cnt[p] > 1 ? 1 : 0;
             x.sync();
             C = x.scan_exclusive(sh.scan, S); // compact candidate index
+            int *ccand = reinterpret_cast<int *>(sh.best);   // point counts of the candidates in list order (best[] is free until the winners)
             for (int p = x.tid(); p < S; p += x.nth())
-                if (sh.cnt[p] > 1) sh.order[sh.scan[p]] = p; // temporarily: candidates in list order
+                if (sh.cnt[p] > 1) {
+                    sh.order[sh.scan[p]] = p; // temporarily: candidates in list order
+                    ccand[sh.scan[p]] = sh.cnt[p];
+                }
             x.sync();
             // rank of candidate c = number of candidates that go before it: an all-pairs count, C * C comparisons.  One thread
             // per candidate made this a serial loop of C steps whatever the workgroup size (a third of the single-frame
@@ -242,18 +254,26 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             for (int c = x.tid(); c < C; c += x.nth()) sh.rank[sh.order[c]] = 0;
             x.sync();
             {
-                const int SPLIT = C > 0 && x.nth() > C ? x.nth() / C : 1;
+                // SPLIT = the largest power of two with C * SPLIT <= threads: the index arithmetic is shifts (three integer
+                // divisions per thread were most of this step -- one workgroup runs ~5 cycles per instruction and wave)
+                int sl = 0;
+                while (C > 0 && ((C << (sl + 1)) <= x.nth())) sl++;
+                const int SPLIT = 1 << sl;
                 for (int idx = x.tid(); idx < C * SPLIT; idx += x.nth()) {
-                    const int c = idx / SPLIT, part = idx - c * SPLIT;
-                    const int d0 = (part * C) / SPLIT, d1 = ((part + 1) * C) / SPLIT;
-                    const int p = sh.order[c];
-                    const int mycnt = sh.cnt[p];
+                    const int c = idx >> sl, part = idx & (SPLIT - 1);
+                    const int d0 = (part * C) >> sl, d1 = ((part + 1) * C) >> sl;
+                    const int mycnt = ccand[c];
                     int r = 0;
+                    // (one read per comparison from the compact array, four in flight; through order[] and cnt[] it was a
+                    // chain of two dependent reads)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 4
+#endif
                     for (int d = d0; d < d1; ++d) {
-                        const int pc = sh.cnt[sh.order[d]];
+                        const int pc = ccand[d];
                         r += (pc > mycnt) || (pc == mycnt && d < c);
                     }
-                    if (r) x.atomic_add(&sh.rank[p], r);
+                    if (r) x.atomic_add(&sh.rank[sh.order[c]], r);
                 }
             }
             x.sync();
@@ -276,8 +296,11 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
                 const int p = sh.order[r];
                 int nz = (sh.ccnt[4 * p] > 0) + (sh.ccnt[4 * p + 1] > 0) + (sh.ccnt[4 * p + 2] > 0) +
                          (sh.ccnt[4 * p + 3] > 0);
+                // the running size never shrinks (nz >= 1), so exactly one rank crosses N first: it alone writes (an atomic
+                // minimum over all ranks beyond it was ~150 same-address atomics in the final pass)
                 const int sizeAfter = S + (sh.scan[r] + nz) - (r + 1);
-                if (sizeAfter >= P.N) x.atomic_min(&sh.scal[QT_S_JSTAR], r);
+                const int sizeBefore = S + sh.scan[r] - r;
+                if (sizeAfter >= P.N && (r == 0 || sizeBefore < P.N)) sh.scal[QT_S_JSTAR] = r;
             }
             x.sync();
             jstar = sh.scal[QT_S_JSTAR];
@@ -320,41 +343,40 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             x.sync();
             for (int p = x.tid(); p < S; p += x.nth()) sh.scan[p] = sh.npos[p] < 0 ? 0 : 1;
             x.sync();
-            x.scan_exclusive(sh.scan, S);
+            const int stay = x.scan_exclusive(sh.scan, S);
+            newS = totalCh + stay;
             for (int p = x.tid(); p < S; p += x.nth())
                 if (sh.npos[p] >= 0) sh.npos[p] = totalCh + sh.scan[p];
             x.sync();
         }
 
         // ---- build the next list ----
-        if (x.tid() == 0) {
-            sh.scal[QT_S_SIZE] = 0;
-            sh.scal[QT_S_NEXP] = 0;
-        }
+        // (the size of the next list is known from the scans above; the number of expandable children is summed per wave
+        // before it touches the shared counter -- one atomic per node on two counters was the longest step of a pass)
+        if (x.tid() == 0) sh.scal[QT_S_NEXP] = 0;
         x.sync();
-        for (int p = x.tid(); p < S; p += x.nth()) {
-            if (sh.npos[p] >= 0) {
+        for (int p0 = 0; p0 < S; p0 += x.nth()) {
+            const int p = p0 + x.tid();
+            int nexp = 0;
+            if (p >= S) {
+            } else if (sh.npos[p] >= 0) {
                 const int s = sh.npos[p];
                 sh.n_ulx[s] = sh.ulx[p];
                 sh.n_uly[s] = sh.uly[p];
                 sh.n_brx[s] = sh.brx[p];
                 sh.n_bry[s] = sh.bry[p];
                 sh.n_cnt[s] = sh.cnt[p];
-                x.atomic_add(&sh.scal[QT_S_SIZE], 1);
             } else {
-                int nexp = 0, created = 0;
                 for (int q = 0; q < 4; ++q) {
                     const int s = sh.cpos[4 * p + q];
                     if (s < 0) continue;
                     qt_child_box(q, sh.ulx[p], sh.uly[p], sh.brx[p], sh.bry[p], sh.n_ulx[s], sh.n_uly[s],
                                  sh.n_brx[s], sh.n_bry[s]);
                     sh.n_cnt[s] = sh.ccnt[4 * p + q];
-                    created++;
                     nexp += sh.ccnt[4 * p + q] > 1;
                 }
-                x.atomic_add(&sh.scal[QT_S_SIZE], created);
-                x.atomic_add(&sh.scal[QT_S_NEXP], nexp);
             }
+            x.reduce_add(&sh.scal[QT_S_NEXP], nexp);   // called by every thread of the workgroup
         }
         x.sync();
         // ---- relabel the points ----
@@ -364,7 +386,8 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             const int np = sh.npos[pn];
             pnode[i] = (uint32_t)(np >= 0 ? np : sh.cpos[4 * pn + (v >> 30)]);
         }
-        const int newS = sh.scal[QT_S_SIZE];
+        // the child counts of this pass were consumed by the list build above: clear them for the next pass's list
+        for (int i = x.tid(); i < 4 * newS; i += x.nth()) sh.ccnt[i] = 0;
         const int nToExpand = sh.scal[QT_S_NEXP];
         x.sync();
         // swap list buffers
@@ -413,6 +436,7 @@ struct QtSerial {
     {
         if (v < *p) *p = v;
     }
+    QT_HD void reduce_add(int *p, int v) const { *p += v; }
     QT_HD void atomic_max(unsigned *p, unsigned v) const
     {
         if (v > *p) *p = v;
