@@ -25,20 +25,22 @@ s=s.replace('''    x.wtot = s_wtot;''','''    x.wtot = s_wtot;
     x.lvl = l;
     x.ns = 0;
     if (tid == 0 && blockIdx.x == 0) g_qt_stamps[l][x.ns++] = wall_clock64() & 0xFFFFFFFFFFull;''')
-s=s.replace('''    if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
-}''','''    if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
-    if (tid == 0 && blockIdx.x == 0) {
-        g_qt_stamps[l][x.ns++] = wall_clock64() & 0xFFFFFFFFFFull;
-        g_qt_nstamps[l] = x.ns;
-    }
-}
-
-extern "C" int orbhip_debug_qt_stamps(unsigned long long *stamps, int *n)
+s=s.replace('''        if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
+    };''','''        if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
+        if (tid == 0 && blockIdx.x == 0) {
+            g_qt_stamps[l][x.ns++] = wall_clock64() & 0xFFFFFFFFFFull;
+            g_qt_nstamps[l] = x.ns;
+        }
+    };''')
+s=s.replace('''size_t quadtree_lds_bytes(const OrbLevels &G)''','''extern "C" int orbhip_debug_qt_stamps(unsigned long long *stamps, int *n)
 {
     if (hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_qt_stamps), sizeof(unsigned long long) * 16 * 512) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_qt_nstamps), sizeof(int) * 16) != hipSuccess) return -1;
     return 0;
-}''')
+}
+
+size_t quadtree_lds_bytes(const OrbLevels &G)''')
+assert 'orbhip_debug_qt_stamps' in s
 open(p,'w').write(s)
 PY
 make 2>&1 | grep -E "error" || true

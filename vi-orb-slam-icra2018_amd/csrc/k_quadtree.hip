@@ -40,6 +40,12 @@ struct QtBlock {
         const int incl = qt_wave_incl_scan(v);
         if ((threadIdx.x & 63) == 63 && incl != 0) atomicAdd(p, incl);
     }
+    // sum of v over each aligned group of 2^sl adjacent threads (sl <= 6: a group lies inside one wave); called by every thread
+    __device__ __forceinline__ int group_sum(int v, int sl) const
+    {
+        for (int o = 1; o < (1 << sl); o <<= 1) v += __shfl_xor(v, o);
+        return v;
+    }
     // In-place exclusive scan of a[0..n) (LDS); returns the total.  Called by all threads.
     __device__ int scan_exclusive(int *a, int n) const
     {
@@ -149,54 +155,59 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
     }
     __syncthreads();
     const int n = x.scan_exclusive(cellOff, ncells);
-    uint32_t *P = pts + (size_t)frame * G.totalPts + L.ptBase;
-    uint32_t *PN = pnode + (size_t)frame * G.totalPts + L.ptBase;
-    if (LDSPTS && n <= ldsPts) {   // block-uniform
-        P = reinterpret_cast<uint32_t *>(smem + (GLOBALT ? 0 : qtBytes) + cellBytes);
-        PN = P + ldsPts;
-    }
-    if (LDSPTS) {
+    // The rest of the workgroup's work as a function of where the candidates live.  It is instantiated twice in the
+    // single-frame variant -- candidates in LDS / in memory -- instead of switching two pointers: a pointer that may be either
+    // makes every access to the candidates a FLAT instruction (slower than both, and it waits on both counters).
+    auto rest = [&](uint32_t *P, uint32_t *PN) {
+        if (LDSPTS) {
 #pragma unroll
-        for (int k = 0; k < QT_PRE; k++) {
-            const int idx = tid + k * (int)blockDim.x;
-            if (idx < npairs) {
-                const int c = idx >> 4, j = idx & 15, o = cellOff[c];
+            for (int k = 0; k < QT_PRE; k++) {
+                const int idx = tid + k * (int)blockDim.x;
+                if (idx < npairs) {
+                    const int c = idx >> 4, j = idx & 15, o = cellOff[c];
+                    const int kk = (c + 1 < ncells ? cellOff[c + 1] : n) - o;
+                    if (j < kk) P[o + j] = pre[k];
+                    const uint32_t *src = slots + (size_t)c * L.cellCap;
+                    for (int jj = j + 16; jj < kk; jj += 16) P[o + jj] = src[jj];
+                }
+            }
+            for (int idx = tid + QT_PRE * (int)blockDim.x; idx < npairs; idx += blockDim.x) {   // more cells than 64 x 6 per 1024 threads
+                const int c = idx >> 4, o = cellOff[c];
                 const int kk = (c + 1 < ncells ? cellOff[c + 1] : n) - o;
-                if (j < kk) P[o + j] = pre[k];
                 const uint32_t *src = slots + (size_t)c * L.cellCap;
-                for (int jj = j + 16; jj < kk; jj += 16) P[o + jj] = src[jj];
+                for (int jj = idx & 15; jj < kk; jj += 16) P[o + jj] = src[jj];
+            }
+        } else {
+            for (int c = tid; c < ncells; c += blockDim.x) {
+                const int k = cc[c], o = cellOff[c];
+                const uint32_t *src = slots + (size_t)c * L.cellCap;
+                for (int j = 0; j < k; j++) P[o + j] = src[j];
             }
         }
-        for (int idx = tid + QT_PRE * (int)blockDim.x; idx < npairs; idx += blockDim.x) {   // more than 6 x 64 cells per workgroup thread set
-            const int c = idx >> 4, o = cellOff[c];
-            const int kk = (c + 1 < ncells ? cellOff[c + 1] : n) - o;
-            const uint32_t *src = slots + (size_t)c * L.cellCap;
-            for (int jj = idx & 15; jj < kk; jj += 16) P[o + jj] = src[jj];
-        }
-    } else {
-        for (int c = tid; c < ncells; c += blockDim.x) {
-            const int k = cc[c], o = cellOff[c];
-            const uint32_t *src = slots + (size_t)c * L.cellCap;
-            for (int j = 0; j < k; j++) P[o + j] = src[j];
-        }
-    }
-    if (tid == 0) lvlCandCnt[frame * ORBHIP_MAX_LEVELS + l] = n;
-    // make the compact array visible to the whole workgroup (global memory, same CU)
-    __threadfence_block();
-    __syncthreads();
+        if (tid == 0) lvlCandCnt[frame * ORBHIP_MAX_LEVELS + l] = n;
+        // make the compact array visible to the whole workgroup (global memory, same CU)
+        __threadfence_block();
+        __syncthreads();
 
-    QtShared sh;
-    qt_carve(sh, GLOBALT ? tableScratch + ((size_t)frame * gridDim.y + l) * (size_t)qtBytes : smem, maxNodes);
-    QtParams Q;
-    Q.N = L.N;
-    Q.nIni = L.nIni;
-    Q.hX = L.hX;
-    Q.regw = L.regw;
-    Q.regh = L.regh;
-    Q.maxNodes = L.kpCap;
-    uint32_t *out = lvlKp + (size_t)frame * G.totalKps + L.kpBase;
-    const int S = qt_distribute(x, Q, n, P, PN, sh, out);
-    if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
+        QtShared sh;
+        qt_carve(sh, GLOBALT ? tableScratch + ((size_t)frame * gridDim.y + l) * (size_t)qtBytes : smem, maxNodes);
+        QtParams Q;
+        Q.N = L.N;
+        Q.nIni = L.nIni;
+        Q.hX = L.hX;
+        Q.regw = L.regw;
+        Q.regh = L.regh;
+        Q.maxNodes = L.kpCap;
+        uint32_t *out = lvlKp + (size_t)frame * G.totalKps + L.kpBase;
+        const int S = qt_distribute(x, Q, n, P, PN, sh, out);
+        if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
+    };
+    if (LDSPTS && n <= ldsPts) {   // block-uniform
+        uint32_t *P = reinterpret_cast<uint32_t *>(smem + (GLOBALT ? 0 : qtBytes) + cellBytes);
+        rest(P, P + ldsPts);
+    } else {
+        rest(pts + (size_t)frame * G.totalPts + L.ptBase, pnode + (size_t)frame * G.totalPts + L.ptBase);
+    }
 }
 
 size_t quadtree_lds_bytes(const OrbLevels &G)

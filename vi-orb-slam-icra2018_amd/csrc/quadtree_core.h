@@ -251,17 +251,19 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             // rank of candidate c = number of candidates that go before it: an all-pairs count, C * C comparisons.  One thread
             // per candidate made this a serial loop of C steps whatever the workgroup size (a third of the single-frame
             // quadtree time at C ~ 150); the comparisons of a candidate are now dealt to SPLIT threads that add up their parts.
-            for (int c = x.tid(); c < C; c += x.nth()) sh.rank[sh.order[c]] = 0;
-            x.sync();
             {
-                // SPLIT = the largest power of two with C * SPLIT <= threads: the index arithmetic is shifts (three integer
-                // divisions per thread were most of this step -- one workgroup runs ~5 cycles per instruction and wave)
+                // SPLIT = the largest power of two (<= 64) with C * SPLIT <= threads: the index arithmetic is shifts (three integer
+                // divisions per thread were most of this step -- one workgroup runs ~5 cycles per instruction and wave), and the
+                // SPLIT partial counts of a candidate sit in adjacent lanes of one wave: they are summed there (group_sum) and
+                // one lane stores the rank -- a thousand atomics on C addresses took longer than the comparisons
                 int sl = 0;
-                while (C > 0 && ((C << (sl + 1)) <= x.nth())) sl++;
+                while (C > 0 && sl < 6 && ((C << (sl + 1)) <= x.nth())) sl++;
                 const int SPLIT = 1 << sl;
-                for (int idx = x.tid(); idx < C * SPLIT; idx += x.nth()) {
-                    const int c = idx >> sl, part = idx & (SPLIT - 1);
-                    const int d0 = (part * C) >> sl, d1 = ((part + 1) * C) >> sl;
+                for (int i0 = 0; i0 < C * SPLIT; i0 += x.nth()) {
+                    const int idx = i0 + x.tid();
+                    const bool live = idx < C * SPLIT;
+                    const int c = live ? idx >> sl : 0, part = idx & (SPLIT - 1);
+                    const int d0 = live ? (part * C) >> sl : 0, d1 = live ? ((part + 1) * C) >> sl : 0;
                     const int mycnt = ccand[c];
                     int r = 0;
                     // (one read per comparison from the compact array, four in flight; through order[] and cnt[] it was a
@@ -273,7 +275,8 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
                         const int pc = ccand[d];
                         r += (pc > mycnt) || (pc == mycnt && d < c);
                     }
-                    if (r) x.atomic_add(&sh.rank[sh.order[c]], r);
+                    r = x.group_sum(r, sl);   // called by every thread of the workgroup
+                    if (live && part == 0) sh.rank[sh.order[c]] = r;
                 }
             }
             x.sync();
@@ -437,6 +440,7 @@ struct QtSerial {
         if (v < *p) *p = v;
     }
     QT_HD void reduce_add(int *p, int v) const { *p += v; }
+    QT_HD int group_sum(int v, int) const { return v; }   // groups of 2^sl adjacent threads: one thread, groups of one
     QT_HD void atomic_max(unsigned *p, unsigned v) const
     {
         if (v > *p) *p = v;
