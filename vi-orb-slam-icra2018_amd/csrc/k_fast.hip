@@ -798,7 +798,11 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
                         while (acc) {
                             const int b = __ffs(acc) - 1;
                             acc &= acc - 1;
-                            *dst++ = (uint16_t)(entBase + (int)__umul24((unsigned)(b & 7), (unsigned)RSsh) + (b >> 3));   // (row << 9) | LDS column
+                            // (row << 9) | LDS column = entBase + (b & 7) * (RS << 9) + (b >> 3); one v_mad_u32_u24 (the compiler
+                            // picks the 64-bit multiply-add for the plain expression)
+                            int ent;
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ent) : "v"(b & 7), "v"(RSsh), "v"(entBase));
+                            *dst++ = (uint16_t)(ent | (b >> 3));
                         }
                     }
                 }
