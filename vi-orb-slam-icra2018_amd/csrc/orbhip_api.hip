@@ -229,6 +229,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_pack) (void)hipHostFree(c->h_pack);
     for (int i = 0; i < 8; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 3; i++)
@@ -1054,6 +1055,79 @@ struct TmpDev {
     }
 };
 
+// The small host-pointer calls (one frame's descriptors, index lists, a few KB of results -- the per-frame calls of
+// Tracking) used to issue one copy per argument: nine pageable host-to-device copies and two back for a SearchByBoW, each
+// ~8 us of runtime work, around a 25 us kernel.  Packed mirrors ONE device block in ONE page-locked host block: inputs are
+// memcpy'd to the offsets of their device twins and travel in one copy, outputs come back in one copy.
+struct Packed {
+    orbhip_ctx *c;
+    TmpDev T;
+    uint8_t *h = nullptr, *d = nullptr;
+    size_t off = 0, inEnd = 0, outBeg = 0, cap = 0;
+    explicit Packed(orbhip_ctx *ctx) : c(ctx), T(ctx) {}
+    int begin(size_t total)
+    {
+        total += 8192;
+        int rc;
+        if ((rc = T.reserve(total))) return rc;
+        if (total > c->h_pack_bytes) {
+            if (c->h_pack) HIPCHK(c, hipHostFree(c->h_pack));
+            c->h_pack = nullptr;
+            c->h_pack_bytes = 0;
+            void *p = nullptr;
+            HIPCHK(c, hipHostMalloc(&p, total + total / 2, hipHostMallocDefault));
+            c->h_pack = (uint8_t *)p;
+            c->h_pack_bytes = total + total / 2;
+        }
+        d = (uint8_t *)T.take(total);
+        h = c->h_pack;
+        cap = total;
+        return ORBHIP_OK;
+    }
+    // device twin of `bytes` bytes copied from src (inputs first, outputs after)
+    void *in(const void *src, size_t bytes)
+    {
+        off = align_up(off, 256);
+        if (bytes) memcpy(h + off, src, bytes);
+        void *p = d + off;
+        off += bytes;
+        inEnd = off;
+        return p;
+    }
+    void *in_fill(int byte, size_t bytes)
+    {
+        off = align_up(off, 256);
+        memset(h + off, byte, bytes);
+        void *p = d + off;
+        off += bytes;
+        inEnd = off;
+        return p;
+    }
+    void *out(size_t bytes)
+    {
+        off = align_up(off, 256);
+        if (!outBeg) outBeg = off;
+        void *p = d + off;
+        off += bytes;
+        return p;
+    }
+    const void *host(const void *dev) const { return h + ((const uint8_t *)dev - d); }
+    int upload()
+    {
+        if (off > cap) return fail(c, ORBHIP_E_SIZE, "internal: packed staging block undersized");
+        HIPCHK(c, hipMemcpyAsync(d, h, inEnd, hipMemcpyHostToDevice, c->stream));
+        return ORBHIP_OK;
+    }
+    // everything from the first output (or `from`, for in/out regions) to the end of the block, then the stream is idle
+    int download(const void *from = nullptr)
+    {
+        const size_t b = from ? (size_t)((const uint8_t *)from - d) : outBeg;
+        if (off > b) HIPCHK(c, hipMemcpyAsync(h + b, d + b, off - b, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return ORBHIP_OK;
+    }
+};
+
 extern "C" int orbhip_hamming_knn2(orbhip_ctx *c, const uint8_t *q, int nq, const uint8_t *db, int ndb,
                                    int32_t *best_idx, int32_t *best_d, int32_t *second_d)
 {
@@ -1176,34 +1250,26 @@ extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1,
     for (int t = 0; t < m2; t++)
         if (idx2[t] < 0 || idx2[t] >= n2) return fail(c, ORBHIP_E_ARG, "idx2 out of range");
     HIPCHK(c, hipSetDevice(c->device));
-    TmpDev T(c);
+    Packed P(c);
     int rc;
-    size_t total = (size_t)n1 * 33 + (size_t)n2 * 33 + (size_t)(ng1 + ng2 + 2) * 4 + (size_t)(m1 + m2) * 4 +
-                   pairs.size() * 4 + (size_t)(n1 + n2) * 4 + 16 * 256;
-    if ((rc = T.reserve(total))) return rc;
-    uint8_t *dd1 = (uint8_t *)T.take((size_t)n1 * 32), *dd2 = (uint8_t *)T.take((size_t)n2 * 32);
-    uint8_t *dv1 = (uint8_t *)T.take((size_t)n1), *dv2 = valid2 ? (uint8_t *)T.take((size_t)n2) : nullptr;
-    int32_t *do1 = (int32_t *)T.take((size_t)(ng1 + 1) * 4), *do2 = (int32_t *)T.take((size_t)(ng2 + 1) * 4);
-    int32_t *di1 = (int32_t *)T.take((size_t)m1 * 4 + 4), *di2 = (int32_t *)T.take((size_t)m2 * 4 + 4);
-    int32_t *dp = (int32_t *)T.take(pairs.size() * 4);
-    int32_t *dm12 = (int32_t *)T.take((size_t)n1 * 4), *dm21 = (int32_t *)T.take((size_t)n2 * 4);
-    hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dv1, valid1, (size_t)n1, hipMemcpyHostToDevice, s));
-    if (valid2) HIPCHK(c, hipMemcpyAsync(dv2, valid2, (size_t)n2, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(do1, off1, (size_t)(ng1 + 1) * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(do2, off2, (size_t)(ng2 + 1) * 4, hipMemcpyHostToDevice, s));
-    if (m1) HIPCHK(c, hipMemcpyAsync(di1, idx1, (size_t)m1 * 4, hipMemcpyHostToDevice, s));
-    if (m2) HIPCHK(c, hipMemcpyAsync(di2, idx2, (size_t)m2 * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(dm12, 0xFF, (size_t)n1 * 4, s));
-    HIPCHK(c, hipMemsetAsync(dm21, 0xFF, (size_t)n2 * 4, s));
-    launch_bow_match(s, dd1, dv1, do1, di1, dd2, dv2, do2, di2, dp, npairs, th, th_mode, nnratio, dm12, dm21);
+    const size_t total = (size_t)n1 * 32 + (size_t)n2 * 32 + (size_t)n1 + (size_t)n2 + (size_t)(ng1 + ng2 + 2) * 4 +
+                         (size_t)(m1 + m2 + 2) * 4 + pairs.size() * 4 + (size_t)(n1 + n2) * 4 + 16 * 256;
+    if ((rc = P.begin(total))) return rc;
+    const uint8_t *dd1 = (const uint8_t *)P.in(desc1, (size_t)n1 * 32), *dd2 = (const uint8_t *)P.in(desc2, (size_t)n2 * 32);
+    const uint8_t *dv1 = (const uint8_t *)P.in(valid1, (size_t)n1);
+    const uint8_t *dv2 = valid2 ? (const uint8_t *)P.in(valid2, (size_t)n2) : nullptr;
+    const int32_t *do1 = (const int32_t *)P.in(off1, (size_t)(ng1 + 1) * 4), *do2 = (const int32_t *)P.in(off2, (size_t)(ng2 + 1) * 4);
+    const int32_t *di1 = (const int32_t *)P.in(idx1, (size_t)m1 * 4), *di2 = (const int32_t *)P.in(idx2, (size_t)m2 * 4);
+    const int32_t *dp = (const int32_t *)P.in(pairs.data(), pairs.size() * 4);
+    // match12 | match21 start as -1 (part of the upload) and come back together
+    int32_t *dm12 = (int32_t *)P.in_fill(0xFF, (size_t)n1 * 4);
+    int32_t *dm21 = (int32_t *)P.in_fill(0xFF, (size_t)n2 * 4);
+    if ((rc = P.upload())) return rc;
+    launch_bow_match(c->stream, dd1, dv1, do1, di1, dd2, dv2, do2, di2, dp, npairs, th, th_mode, nnratio, dm12, dm21);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(match12, dm12, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(match21, dm21, (size_t)n2 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if ((rc = P.download(dm12))) return rc;
+    memcpy(match12, P.host(dm12), (size_t)n1 * 4);
+    memcpy(match21, P.host(dm21), (size_t)n2 * 4);
     // rotation consistency (ref: :236-246, :267-285): histogram in the reference's visiting order
     int nm = 0;
     std::vector<int> hist[30];
@@ -1322,18 +1388,18 @@ extern "C" int orbhip_vocab_transform(orbhip_ctx *c, const uint8_t *desc, int n,
         return fail(c, ORBHIP_E_ARG, "orbhip_vocab_transform: bad argument");
     if (n == 0) return ORBHIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    TmpDev T(c);
+    Packed P(c);
     int rc;
-    if ((rc = T.reserve((size_t)n * 44 + 2048))) return rc;
-    uint8_t *dd = (uint8_t *)T.take((size_t)n * 32);
-    int32_t *dw = (int32_t *)T.take((size_t)n * 4), *dn = (int32_t *)T.take((size_t)n * 4);
-    float *dwt = (float *)T.take((size_t)n * 4);
-    HIPCHK(c, hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = P.begin((size_t)n * 44 + 4 * 256))) return rc;
+    const uint8_t *dd = (const uint8_t *)P.in(desc, (size_t)n * 32);
+    int32_t *dw = (int32_t *)P.out((size_t)n * 4), *dn = (int32_t *)P.out((size_t)n * 4);
+    float *dwt = (float *)P.out((size_t)n * 4);
+    if ((rc = P.upload())) return rc;
     if ((rc = orbhip_vocab_transform_device(c, dd, n, levelsup, dw, dwt, dn))) return rc;
-    HIPCHK(c, hipMemcpyAsync(word_id, dw, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(weight, dwt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(node_id, dn, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = P.download())) return rc;
+    memcpy(word_id, P.host(dw), (size_t)n * 4);
+    memcpy(weight, P.host(dwt), (size_t)n * 4);
+    memcpy(node_id, P.host(dn), (size_t)n * 4);
     return ORBHIP_OK;
 }
 

@@ -195,6 +195,8 @@ struct orbhip_ctx {
     // pinned host staging for the host API
     uint8_t *h_stage = nullptr;
     size_t h_stage_bytes = 0;
+    uint8_t *h_pack = nullptr;        // page-locked twin of d_tmp for the small host-pointer calls (struct Packed, orbhip_api.hip)
+    size_t h_pack_bytes = 0;
     // the host-pointer call of a frame or two as ONE hipGraph launch (copy in, the twelve kernels, copy out): captured at the
     // first call of a geometry, replayed while (w, h, B, buffers) stay the same
     uint8_t *h_in = nullptr;          // pinned input staging, rows s0 apart
