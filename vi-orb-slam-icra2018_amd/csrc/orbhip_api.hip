@@ -1618,35 +1618,30 @@ extern "C" int orbhip_search_by_projection(orbhip_ctx *c, const orbhip_keypoint 
     for (int i = 0; i < n; i++) match[i] = -1;
     if (n == 0 || nq == 0) return ORBHIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    TmpDev T(c);
+    Packed P(c);
     int rc;
-    if ((rc = T.reserve((size_t)n * (28 + 32 + 4 + 1 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * 64 + 16384))) return rc;
-    orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)n * 28);
-    uint8_t *dd = (uint8_t *)T.take((size_t)n * 32);
-    float *dur = u_right ? (float *)T.take((size_t)n * 4) : nullptr;
-    uint8_t *docc = occupied ? (uint8_t *)T.take((size_t)n) : nullptr;
-    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
-            *didx = (int32_t *)T.take((size_t)n * 4), *dm = (int32_t *)T.take((size_t)n * 4);
-    orbhip_proj_query *dq = (orbhip_proj_query *)T.take((size_t)nq * sizeof(orbhip_proj_query));
-    uint8_t *dqd = (uint8_t *)T.take((size_t)nq * 32);
-    const int32_t cnts[3] = {n, nq, 0};
-    hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(dk, kps, (size_t)n * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    if (dur) HIPCHK(c, hipMemcpyAsync(dur, u_right, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (docc) HIPCHK(c, hipMemcpyAsync(docc, occupied, (size_t)n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dc, cnts, 12, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if ((rc = P.begin((size_t)n * (28 + 32 + 4 + 1 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (sizeof(orbhip_proj_query) + 32) + 16 * 256)))
+        return rc;
+    const int32_t cnts[4] = {n, nq, 0, 0};
+    const orbhip_keypoint *dk = (const orbhip_keypoint *)P.in(kps, (size_t)n * 28);
+    const uint8_t *dd = (const uint8_t *)P.in(desc, (size_t)n * 32);
+    const float *dur = u_right ? (const float *)P.in(u_right, (size_t)n * 4) : nullptr;
+    const uint8_t *docc = occupied ? (const uint8_t *)P.in(occupied, (size_t)n) : nullptr;
+    const orbhip_proj_query *dq = (const orbhip_proj_query *)P.in(queries, (size_t)nq * sizeof(orbhip_proj_query));
+    const uint8_t *dqd = (const uint8_t *)P.in(qdesc, (size_t)nq * 32);
+    int32_t *dc = (int32_t *)P.in(cnts, 16);                    // n | nq | number of matches (comes back with the matches)
+    int32_t *dm = (int32_t *)P.out((size_t)n * 4);
+    int32_t *doff = (int32_t *)P.out((ORBHIP_GRID_CELLS + 1) * 4), *didx = (int32_t *)P.out((size_t)n * 4);   // device scratch
+    if ((rc = P.upload())) return rc;
     if ((rc = orbhip_grid_build_device(c, dk, dc, n, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
     if ((rc = orbhip_search_by_projection_device(c, dk, dd, dc, n, 1, dur, docc, min_x, min_y, inv_w, inv_h, doff, didx, dq, dqd,
                                                  dc + 1, nq, use_ratio, nnratio, check_ori, th_high, dm, dc + 2)))
         return rc;
-    int nm = 0;
-    HIPCHK(c, hipMemcpyAsync(match, dm, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&nm, dc + 2, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (nmatches) *nmatches = nm;
+    // counts | matches are adjacent: one copy back
+    P.off = (size_t)((uint8_t *)dm - P.d) + (size_t)n * 4;
+    if ((rc = P.download(dc))) return rc;
+    memcpy(match, P.host(dm), (size_t)n * 4);
+    if (nmatches) *nmatches = ((const int32_t *)P.host(dc))[2];
     return ORBHIP_OK;
 }
 
@@ -1735,40 +1730,31 @@ extern "C" int orbhip_window_best(orbhip_ctx *c, const orbhip_keypoint *kps, con
             if (kps[i].octave < 0 || kps[i].octave >= nlevels)
                 return fail(c, ORBHIP_E_ARG, "orbhip_window_best: a keypoint's octave has no entry in inv_level_sigma2");
     HIPCHK(c, hipSetDevice(c->device));
-    TmpDev T(c);
+    Packed P(c);
     int rc;
-    if ((rc = T.reserve((size_t)n * (28 + 32 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (64 + 8) + 16384))) return rc;
-    // one staging block, one copy in and one copy out: a call moves ~100 KB and is latency-bound
-    uint8_t *d0 = (uint8_t *)T.take(0);
-    orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)n * 28);
-    uint8_t *dd = (uint8_t *)T.take((size_t)n * 32);
-    float *dur = u_right ? (float *)T.take((size_t)n * 4) : nullptr;
-    int32_t *dc = (int32_t *)T.take(16);
-    orbhip_proj_query *dq = (orbhip_proj_query *)T.take((size_t)nq * sizeof(orbhip_proj_query));
-    uint8_t *dqd = (uint8_t *)T.take((size_t)nq * 32);
-    const size_t span = (size_t)((uint8_t *)dqd + (size_t)nq * 32 - d0);
-    int32_t *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4), *didx = (int32_t *)T.take((size_t)n * 4);
-    int32_t *dout = (int32_t *)T.take((size_t)nq * 8);
+    if ((rc = P.begin((size_t)n * (28 + 32 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (sizeof(orbhip_proj_query) + 32 + 8) + 16 * 256)))
+        return rc;
+    // one page-locked staging block, one copy in and one copy out: a call moves ~100 KB and is latency-bound
+    const int32_t cnts[4] = {n, nq, 0, 0};
+    const orbhip_keypoint *dk = (const orbhip_keypoint *)P.in(kps, (size_t)n * 28);
+    const uint8_t *dd = (const uint8_t *)P.in(desc, (size_t)n * 32);
+    const float *dur = u_right ? (const float *)P.in(u_right, (size_t)n * 4) : nullptr;
+    const int32_t *dc = (const int32_t *)P.in(cnts, 16);
+    const orbhip_proj_query *dq = (const orbhip_proj_query *)P.in(queries, (size_t)nq * sizeof(orbhip_proj_query));
+    const uint8_t *dqd = (const uint8_t *)P.in(qdesc, (size_t)nq * 32);
+    int32_t *dout = (int32_t *)P.out((size_t)nq * 8);
     int32_t *dbi = dout, *dbd = dout + nq;
-    std::vector<uint8_t> h(span);
-    const int32_t cnts[2] = {n, nq};
-    memcpy(&h[(uint8_t *)dk - d0], kps, (size_t)n * 28);
-    memcpy(&h[dd - d0], desc, (size_t)n * 32);
-    if (dur) memcpy(&h[(uint8_t *)dur - d0], u_right, (size_t)n * 4);
-    memcpy(&h[(uint8_t *)dc - d0], cnts, 8);
-    memcpy(&h[(uint8_t *)dq - d0], queries, (size_t)nq * sizeof(orbhip_proj_query));
-    memcpy(&h[dqd - d0], qdesc, (size_t)nq * 32);
-    hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(d0, h.data(), span, hipMemcpyHostToDevice, s));
+    const size_t backEnd = (size_t)((uint8_t *)dout - P.d) + (size_t)nq * 8;
+    int32_t *doff = (int32_t *)P.out((ORBHIP_GRID_CELLS + 1) * 4), *didx = (int32_t *)P.out((size_t)n * 4);   // device scratch
+    if ((rc = P.upload())) return rc;
     if ((rc = orbhip_grid_build_device(c, dk, dc, n, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
     if ((rc = orbhip_window_best_device(c, dk, dd, n, 1, dur, inv_level_sigma2, nlevels, min_x, min_y, inv_w, inv_h, doff, didx,
                                         dq, dqd, dc + 1, nq, dbi, dbd)))
         return rc;
-    std::vector<int32_t> out((size_t)nq * 2);
-    HIPCHK(c, hipMemcpyAsync(out.data(), dout, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    memcpy(best_idx, out.data(), (size_t)nq * 4);
-    memcpy(best_dist, out.data() + nq, (size_t)nq * 4);
+    P.off = backEnd;
+    if ((rc = P.download(dout))) return rc;
+    memcpy(best_idx, P.host(dbi), (size_t)nq * 4);
+    memcpy(best_dist, P.host(dbd), (size_t)nq * 4);
     return ORBHIP_OK;
 }
 
@@ -1810,32 +1796,28 @@ extern "C" int orbhip_search_for_initialization(orbhip_ctx *c, const orbhip_keyp
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBHIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    TmpDev T(c);
+    Packed P(c);
     int rc;
-    if ((rc = T.reserve((size_t)n1 * (28 + 32 + 8 + 4) + (size_t)n2 * (28 + 32 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + 16384))) return rc;
-    orbhip_keypoint *dk1 = (orbhip_keypoint *)T.take((size_t)n1 * 28), *dk2 = (orbhip_keypoint *)T.take((size_t)n2 * 28);
-    uint8_t *dd1 = (uint8_t *)T.take((size_t)n1 * 32), *dd2 = (uint8_t *)T.take((size_t)n2 * 32);
-    float *dpm = (float *)T.take((size_t)n1 * 8);
-    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
-            *didx = (int32_t *)T.take((size_t)n2 * 4), *dm = (int32_t *)T.take((size_t)n1 * 4);
-    const int32_t cnts[3] = {n1, n2, 0};
-    hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(dk1, kps1, (size_t)n1 * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dk2, kps2, (size_t)n2 * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dpm, prev_matched, (size_t)n1 * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dc, cnts, 12, hipMemcpyHostToDevice, s));
+    if ((rc = P.begin((size_t)n1 * (28 + 32 + 8 + 4) + (size_t)n2 * (28 + 32 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + 16 * 256))) return rc;
+    const int32_t cnts[4] = {n1, n2, 0, 0};
+    const orbhip_keypoint *dk1 = (const orbhip_keypoint *)P.in(kps1, (size_t)n1 * 28), *dk2 = (const orbhip_keypoint *)P.in(kps2, (size_t)n2 * 28);
+    const uint8_t *dd1 = (const uint8_t *)P.in(desc1, (size_t)n1 * 32), *dd2 = (const uint8_t *)P.in(desc2, (size_t)n2 * 32);
+    // counts (incl. the number of matches) | vbPrevMatched (in and out) | matches: adjacent, one copy back
+    int32_t *dc = (int32_t *)P.in(cnts, 16);
+    float *dpm = (float *)P.in(prev_matched, (size_t)n1 * 8);
+    int32_t *dm = (int32_t *)P.out((size_t)n1 * 4);
+    const size_t backEnd = (size_t)((uint8_t *)dm - P.d) + (size_t)n1 * 4;
+    int32_t *doff = (int32_t *)P.out((ORBHIP_GRID_CELLS + 1) * 4), *didx = (int32_t *)P.out((size_t)n2 * 4);   // device scratch
+    if ((rc = P.upload())) return rc;
     if ((rc = orbhip_grid_build_device(c, dk2, dc + 1, n2, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
     if ((rc = orbhip_search_for_initialization_device(c, dk1, dd1, dc, n1, dk2, dd2, dc + 1, n2, 1, min_x, min_y, inv_w, inv_h, doff,
                                                       didx, dpm, window_size, nnratio, check_ori, dm, dc + 2)))
         return rc;
-    int nm = 0;
-    HIPCHK(c, hipMemcpyAsync(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(prev_matched, dpm, (size_t)n1 * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&nm, dc + 2, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (nmatches) *nmatches = nm;
+    P.off = backEnd;
+    if ((rc = P.download(dc))) return rc;
+    memcpy(matches12, P.host(dm), (size_t)n1 * 4);
+    memcpy(prev_matched, P.host(dpm), (size_t)n1 * 8);
+    if (nmatches) *nmatches = ((const int32_t *)P.host(dc))[2];
     return ORBHIP_OK;
 }
 
@@ -1877,41 +1859,27 @@ extern "C" int orbhip_search_for_triangulation(orbhip_ctx *c, const orbhip_keypo
     for (int i = 0; i < n2; i++)
         if (kps2[i].octave < 0 || kps2[i].octave >= nlevels2) return fail(c, ORBHIP_E_ARG, "octave of key frame 2 out of range");
     HIPCHK(c, hipSetDevice(c->device));
-    TmpDev T(c);
+    Packed P(c);
     int rc;
     const size_t total = (size_t)(n1 + n2) * (28 + 32 + 1 + 4) + (size_t)(ng1 + ng2 + 2) * 4 + (size_t)(m1 + m2 + 2) * 4 +
                          pairs.size() * 4 + (size_t)n1 * 4 + 512 + 20 * 256;
-    if ((rc = T.reserve(total))) return rc;
-    orbhip_keypoint *dk1 = (orbhip_keypoint *)T.take((size_t)n1 * 28), *dk2 = (orbhip_keypoint *)T.take((size_t)n2 * 28);
-    uint8_t *dd1 = (uint8_t *)T.take((size_t)n1 * 32), *dd2 = (uint8_t *)T.take((size_t)n2 * 32);
-    uint8_t *ds1 = (uint8_t *)T.take((size_t)n1), *ds2 = (uint8_t *)T.take((size_t)n2);
-    float *du1 = u_right1 ? (float *)T.take((size_t)n1 * 4) : nullptr, *du2 = u_right2 ? (float *)T.take((size_t)n2 * 4) : nullptr;
-    int32_t *do1 = (int32_t *)T.take((size_t)(ng1 + 1) * 4), *do2 = (int32_t *)T.take((size_t)(ng2 + 1) * 4);
-    int32_t *di1 = (int32_t *)T.take((size_t)m1 * 4 + 4), *di2 = (int32_t *)T.take((size_t)m2 * 4 + 4);
-    int32_t *dp = (int32_t *)T.take(pairs.size() * 4), *dm = (int32_t *)T.take((size_t)n1 * 4);
-    float *dsf = (float *)T.take(256), *dsg = (float *)T.take(256);
-    hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(dk1, kps1, (size_t)n1 * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dk2, kps2, (size_t)n2 * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(ds1, skip1, (size_t)n1, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(ds2, skip2, (size_t)n2, hipMemcpyHostToDevice, s));
-    if (du1) HIPCHK(c, hipMemcpyAsync(du1, u_right1, (size_t)n1 * 4, hipMemcpyHostToDevice, s));
-    if (du2) HIPCHK(c, hipMemcpyAsync(du2, u_right2, (size_t)n2 * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(do1, off1, (size_t)(ng1 + 1) * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(do2, off2, (size_t)(ng2 + 1) * 4, hipMemcpyHostToDevice, s));
-    if (m1) HIPCHK(c, hipMemcpyAsync(di1, idx1, (size_t)m1 * 4, hipMemcpyHostToDevice, s));
-    if (m2) HIPCHK(c, hipMemcpyAsync(di2, idx2, (size_t)m2 * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dsf, scale_factors2, (size_t)nlevels2 * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dsg, level_sigma2_2, (size_t)nlevels2 * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(dm, 0xFF, (size_t)n1 * 4, s));
-    launch_tri_match(s, dk1, dd1, ds1, du1, do1, di1, dk2, dd2, ds2, du2, do2, di2, dp, npairs, F12, ex, ey, only_stereo ? 1 : 0,
-                     /*TH_LOW*/ 50, dsf, dsg, dm);
+    if ((rc = P.begin(total))) return rc;
+    const orbhip_keypoint *dk1 = (const orbhip_keypoint *)P.in(kps1, (size_t)n1 * 28), *dk2 = (const orbhip_keypoint *)P.in(kps2, (size_t)n2 * 28);
+    const uint8_t *dd1 = (const uint8_t *)P.in(desc1, (size_t)n1 * 32), *dd2 = (const uint8_t *)P.in(desc2, (size_t)n2 * 32);
+    const uint8_t *ds1 = (const uint8_t *)P.in(skip1, (size_t)n1), *ds2 = (const uint8_t *)P.in(skip2, (size_t)n2);
+    const float *du1 = u_right1 ? (const float *)P.in(u_right1, (size_t)n1 * 4) : nullptr;
+    const float *du2 = u_right2 ? (const float *)P.in(u_right2, (size_t)n2 * 4) : nullptr;
+    const int32_t *do1 = (const int32_t *)P.in(off1, (size_t)(ng1 + 1) * 4), *do2 = (const int32_t *)P.in(off2, (size_t)(ng2 + 1) * 4);
+    const int32_t *di1 = (const int32_t *)P.in(idx1, (size_t)m1 * 4), *di2 = (const int32_t *)P.in(idx2, (size_t)m2 * 4);
+    const int32_t *dp = (const int32_t *)P.in(pairs.data(), pairs.size() * 4);
+    const float *dsf = (const float *)P.in(scale_factors2, (size_t)nlevels2 * 4), *dsg = (const float *)P.in(level_sigma2_2, (size_t)nlevels2 * 4);
+    int32_t *dm = (int32_t *)P.in_fill(0xFF, (size_t)n1 * 4);
+    if ((rc = P.upload())) return rc;
+    launch_tri_match(c->stream, dk1, dd1, ds1, du1, do1, di1, dk2, dd2, ds2, du2, do2, di2, dp, npairs, F12, ex, ey,
+                     only_stereo ? 1 : 0, /*TH_LOW*/ 50, dsf, dsg, dm);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if ((rc = P.download(dm))) return rc;
+    memcpy(matches12, P.host(dm), (size_t)n1 * 4);
     // rotation consistency (ref: :745-755, :775-794)
     int nm = 0;
     std::vector<int> hist[30];
