@@ -1,0 +1,78 @@
+"""Per-call latency of the host-pointer entry points at the reference's call granularity (ONE frame / ONE key-frame pair per
+call, as Tracking / LocalMapping issue them): liborbhip on the GPU beside the oracle on one host core, same inputs.  Through
+the Python wrappers (about 10-15 us of ctypes / numpy per call on both sides); tools/native/latency_dropin.cpp has the C++
+view of the first three rows.  Prints a markdown table.   usage (on the GPU box): python tools/percall_latency.py"""
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "vi-orb-slam-icra2018_amd"), os.path.join(ROOT, "oracle")]
+import numpy as np
+import orb_oracle_py as O
+from orbhip import distributed as D
+from orbhip import guided, synth
+from orbhip.capi import QUERY_DTYPE
+from orbhip.extractor import ORBextractor, ORBmatcher
+from orbhip.vocabulary import ORBVocabulary
+
+
+def bench(f, n):
+    for _ in range(max(3, n // 10)):
+        f()
+    t = time.perf_counter()
+    for _ in range(n):
+        f()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+W, H, NF = 640, 480, 1000
+fr = synth.make_frames(5, W, H, 2)
+ex = ORBextractor(NF, max_w=W, max_h=H)
+ref = O.Extractor(NF)
+(k0, d0), (k1, d1) = ex(fr[0]), ex(fr[1])
+rng = np.random.default_rng(0)
+rows = [("`ORBextractor::operator()` 640x480, 1000 features", bench(lambda: ex(fr[0]), 500), bench(lambda: ref(fr[0]), 10))]
+
+blob = D.make_synthetic_vocabulary(52, k=10, L=6)
+voc = ORBVocabulary(ex)
+voc.loadFromBinaryBlob(blob)
+ovoc = O.Vocabulary(blob)
+rows.append(("`ORBVocabulary::transform` descent, 1000 descriptors (k 10, L 6, levelsup 4)", bench(lambda: voc.transform_raw(d1, 4), 300),
+             bench(lambda: ovoc.transform(d1, 4), 20)))
+
+fv = []
+for d in (d0, d1):
+    w, wt, nid = ovoc.transform(d, 4)
+    fv.append(O.feature_vector(nid, wt))
+M = ORBmatcher(0.7, True, ctx=ex)
+v0 = np.ones(len(d0), np.uint8)
+rows.append(("`SearchByBoW(KF, F)` 1000 x 1000 features", bench(lambda: M.SearchByBoW(d0, v0, k0["angle"], fv[0], d1, None, k1["angle"], fv[1]), 300),
+             bench(lambda: O.search_by_bow(d0, v0, k0["angle"], fv[0], d1, None, k1["angle"], fv[1], th=50, th_mode=0, nnratio=0.7, check_ori=True), 30)))
+
+# SearchByProjection(CurrentFrame, LastFrame, th 15, mono): the points of the last frame near where they were
+gp = guided.grid_params(0, W, 0, H)
+sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+u = k0["x"] + rng.normal(0, 2, len(k0)).astype(np.float32)
+v = k0["y"] + rng.normal(0, 2, len(k0)).astype(np.float32)
+q = guided.queries_for_last_frame(u, v, np.full(len(k0), -1, np.float32), k0["octave"], k0["angle"], np.ones(len(k0), bool),
+                                  np.zeros(len(k0), bool), 15, sf)
+rows.append(("`SearchByProjection(CurrentFrame, LastFrame, 15)` 1000 points, 1000 features",
+             bench(lambda: guided.SearchByProjection(ex, k1, d1, gp, q, d0, use_ratio=False, th_high=100), 300),
+             bench(lambda: O.search_by_projection(k1, d1, gp, q, d0, use_ratio=False, th_high=100), 30)))
+
+prev = np.stack([k0["x"], k0["y"]], 1).astype(np.float32)
+rows.append(("`SearchForInitialization` window 100", bench(lambda: guided.SearchForInitialization(ex, k0, d0, k1, d1, gp, prev, 100), 200),
+             bench(lambda: O.search_for_initialization(k0, d0, k1, d1, gp, prev, 100), 10)))
+
+sig = (1 / sf ** 2).astype(np.float32)
+qf = np.zeros(len(k0), QUERY_DTYPE)
+qf["u"], qf["v"] = u, v
+qf["radius"] = 3 * sf[k0["octave"]]
+qf["min_level"], qf["max_level"], qf["flags"] = k0["octave"] - 1, k0["octave"], 1
+rows.append(("`Fuse` window search (1000 points into one key frame)", bench(lambda: guided.WindowBest(ex, k1, d1, gp, qf, d0, None, sig), 300),
+             bench(lambda: O.window_best(k1, d1, gp, qf, d0, None, sig), 30)))
+
+print("| call (one per frame / key-frame pair) | liborbhip per call (ms) | oracle, one host core (ms) |")
+print("|---|---|---|")
+for name, g, c in rows:
+    print("| %s | %.3f | %.3f |" % (name, g, c))
