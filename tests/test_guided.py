@@ -162,9 +162,13 @@ def test_hip_search_by_projection_matches_oracle(oracle, mode):
 
 
 @pytest.mark.gpu
-def test_hip_search_by_projection_list_overflow_rescans_exactly(oracle, tmp_path):
+@pytest.mark.parametrize("env", [{"ORBHIP_PROJ_K": "2"}, {"ORBHIP_PROJ_ROUNDS": "1"}, {"ORBHIP_PROJ_ROUNDS": "2"},
+                                 {"ORBHIP_PROJ_SEQ": "1"}])
+def test_hip_search_by_projection_list_overflow_rescans_exactly(oracle, tmp_path, env):
     """ORBHIP_PROJ_K=2: almost every point has more candidates than its list holds (child process: the
-    variable is read once)."""
+    variable is read once).  ORBHIP_PROJ_ROUNDS=1 / 2: the parallel fixed-point kernel of the single-frame call may only
+    run that many rounds -- a frame with any conflict between points is handed over to the sequential kernel;
+    ORBHIP_PROJ_SEQ=1: sequential kernel only.  Same results in every case."""
     import os
     import subprocess
     import sys
@@ -179,7 +183,7 @@ def test_hip_search_by_projection_list_overflow_rescans_exactly(oracle, tmp_path
             "n, m = guided.SearchByProjection(ex, z['k1'], z['d1'], gp, z['q'], z['d0'], use_ratio=False, check_ori=True)\n"
             "n2, m2 = guided.SearchByProjection(ex, z['k1'], z['d1'], gp, z['q'], z['d0'], use_ratio=True, nnratio=0.8)\n"
             "np.savez(%r, n=n, m=m, n2=n2, m2=m2)\n" % (pkg, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
-    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, ORBHIP_PROJ_K="2"))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, **env))
     got = np.load(tmp_path / "out.npz")
     rn, rm = oracle.search_by_projection(k1, d1, gp, q, d0, use_ratio=False, check_ori=True)
     rn2, rm2 = oracle.search_by_projection(k1, d1, gp, q, d0, use_ratio=True, nnratio=0.8)

@@ -338,10 +338,12 @@ __global__ __launch_bounds__(64) void k_proj_assign(const orbhip_keypoint *__res
                                                     int capQ, int capQpad, int keff, const uint32_t *__restrict__ tuples,
                                                     const int32_t *__restrict__ tcount, int32_t *__restrict__ qfeat,
                                                     int use_ratio, float nnratio, int check_ori, int th_high,
-                                                    int32_t *__restrict__ match, int32_t *__restrict__ nmatches)
+                                                    int32_t *__restrict__ match, int32_t *__restrict__ nmatches,
+                                                    const int32_t *__restrict__ fallback)
 {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_tup[64 * PROJ_K];
+    if (fallback && fallback[blockIdx.x] == 0) return;   // k_proj_assign_par has done this frame
     __shared__ int s_hist[30];
     __shared__ int s_keep[3];
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -575,6 +577,184 @@ __global__ __launch_bounds__(64) void k_proj_assign(const orbhip_keypoint *__res
     }
     for (int i = lane; i < cap; i += 64) match[(size_t)b * cap + i] = s_match[i];
     if (lane == 0) nmatches[b] = nm;
+}
+
+// ---- the same assignment for ONE frame per call (a frame or two per launch): parallel fixed point ----------------------
+// k_proj_assign walks the points of a frame in order in one wave: ~0.28 us per point, 281 us for the 1000 points of a
+// SearchByProjection(CurrentFrame, LastFrame) -- fine beside 511 other frames, slower than a host core when it is the only
+// frame.  The order only matters through the features that EARLIER points closed (a point whose MapPoint has observations
+// keeps its feature, :1411-1413).  So every point first picks its best / second as if nothing were closed, in parallel (one
+// point per 16-lane row, 64 points per trip of a 1024-thread workgroup); then, round after round, close[f] = the first point
+// that holds feature f (observed points only) and every point picks again among the features with close[f] >= its own index.
+// When a round changes nothing the state is the sequential result: the first point whose pick could be wrong has only
+// correct points before it, and then its pick is the sequential one by construction -- so each round fixes at least the first
+// wrong point, and a fixed point has none.  Conflicts are rare (a few per cent of the points), chains short: 2-4 rounds.
+// Frames with a point of more than 32 candidates, or without a fixed point after PAR_ROUNDS rounds, are left to
+// k_proj_assign (fallback[b] = 1); the tail (last writer per feature, rotation histogram) is the same.
+#define PAR_ROUNDS 48
+__global__ __launch_bounds__(1024) void k_proj_assign_par(const orbhip_keypoint *__restrict__ kps, const int32_t *__restrict__ cnt,
+                                                          int cap, const uint8_t *__restrict__ occupied,
+                                                          const orbhip_proj_query *__restrict__ queries,
+                                                          const int32_t *__restrict__ nq, int capQ, int capQpad, int keff,
+                                                          const uint32_t *__restrict__ tuples, const int32_t *__restrict__ tcount,
+                                                          int32_t *__restrict__ qfeat, int use_ratio, float nnratio, int check_ori,
+                                                          int th_high, int32_t *__restrict__ match, int32_t *__restrict__ nmatches,
+                                                          int32_t *__restrict__ fallback, int maxRounds)
+{
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ int s_hist[30];
+    __shared__ int s_keep[3];
+    __shared__ int s_flag[3];   // changed | leave the frame to k_proj_assign | accepted matches
+    const int b = blockIdx.x, tid = threadIdx.x, gl = tid & 15, row = tid >> 4, nth = blockDim.x;
+    const int n = min(cnt[b], cap), NQ = min(nq[b], capQ);
+    int32_t *s_match = reinterpret_cast<int32_t *>(s_dyn);      // [cap]   last point that took the feature
+    int32_t *s_close = s_match + cap;                           // [cap]   first observed point holding the feature
+    int32_t *s_feat = s_close + cap;                            // [capQpad] feature picked by the point, -1 = none
+    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_feat + capQpad);   // [(cap + 31) / 32] features closed on entry
+    const orbhip_keypoint *K = kps + (size_t)b * cap;
+    const orbhip_proj_query *Q = queries + (size_t)b * capQ;
+    const uint32_t *T = tuples + (size_t)b * capQpad * PROJ_K;
+    const int32_t *TC = tcount + (size_t)b * capQpad;
+    for (int i = tid; i < cap; i += nth) {
+        s_match[i] = -1;
+        s_close[i] = 0x7FFFFFFF;
+    }
+    for (int i = tid; i < capQpad; i += nth) s_feat[i] = -1;
+    for (int w = tid; w < (cap + 31) / 32; w += nth) {
+        uint32_t bits = 0;
+        if (occupied)
+            for (int k = 0; k < 32; k++) {
+                const int i = w * 32 + k;
+                if (i < n && occupied[(size_t)b * cap + i]) bits |= 1u << k;
+            }
+        s_occ[w] = bits;
+    }
+    if (tid < 30) s_hist[tid] = 0;
+    if (tid < 3) s_flag[tid] = 0;
+    __syncthreads();
+    for (int q = tid; q < NQ; q += nth)
+        if (TC[q] > min(keff, 32)) s_flag[1] = 1;
+    __syncthreads();
+    bool done = false;
+    for (int round = 0; round < maxRounds && !s_flag[1]; round++) {
+        bool changed = false;
+        for (int q0 = 0; q0 < NQ; q0 += (nth >> 4)) {
+            const int q = q0 + row;
+            const bool live = q < NQ;
+            const int c = live ? TC[q] : 0;
+            const uint32_t t0 = gl < c ? T[(size_t)q * PROJ_K + gl] : 0u, t1 = gl + 16 < c ? T[(size_t)q * PROJ_K + gl + 16] : 0u;
+            const int i0 = (int)(t0 >> 13), i1 = (int)(t1 >> 13);
+            const bool ok0 = gl < c && !((s_occ[i0 >> 5] >> (i0 & 31)) & 1u) && s_close[i0] >= q;
+            const bool ok1 = gl + 16 < c && !((s_occ[i1 >> 5] >> (i1 & 31)) & 1u) && s_close[i1] >= q;
+            // (distance, position in the reference's visiting order): the first feature of smallest distance wins
+            const int key0 = ok0 ? (int)(((t0 & 511u) << 6) | (uint32_t)gl) : 0x7FFFFFFF;
+            const int key1 = ok1 ? (int)(((t1 & 511u) << 6) | (uint32_t)(gl + 16)) : 0x7FFFFFFF;
+            const int mine = min(key0, key1), other = max(key0, key1);
+            const int k1 = row_min_i(mine);
+            const int k2 = row_min_i(mine == k1 ? other : mine);       // keys are unique (position bits) unless both are "none"
+            const int p1 = k1 & 31, p2 = k2 & 31;
+            const uint32_t w1 = (uint32_t)__shfl((int)(p1 >= 16 ? t1 : t0), (tid & 48) + (p1 & 15));
+            const uint32_t w2 = (uint32_t)__shfl((int)(p2 >= 16 ? t1 : t0), (tid & 48) + (p2 & 15));
+            const int bDist = k1 == 0x7FFFFFFF ? 256 : (k1 >> 6), bLevel = (int)((w1 >> 9) & 15u), bIdx = (int)(w1 >> 13);
+            const int bDist2 = k2 == 0x7FFFFFFF ? 256 : (k2 >> 6), bLevel2 = k2 == 0x7FFFFFFF ? -1 : (int)((w2 >> 9) & 15u);
+            const bool acc = live && k1 != 0x7FFFFFFF && bDist <= th_high &&
+                             !(use_ratio && bLevel == bLevel2 && (float)bDist > __fmul_rn(nnratio, (float)bDist2));
+            const int f = acc ? bIdx : -1;
+            if (live && gl == 0 && s_feat[q] != f) {
+                s_feat[q] = f;
+                changed = true;
+            }
+        }
+        if (changed) s_flag[0] = 1;
+        __syncthreads();
+        const bool any = s_flag[0] != 0;
+        __syncthreads();
+        if (!any) {
+            done = true;
+            break;
+        }
+        if (tid == 0) s_flag[0] = 0;
+        for (int i = tid; i < cap; i += nth) s_close[i] = 0x7FFFFFFF;
+        __syncthreads();
+        for (int q = tid; q < NQ; q += nth) {
+            const int f = s_feat[q];
+            if (f >= 0 && (Q[q].flags & ORBHIP_Q_OBSERVED)) atomicMin(&s_close[f], q);
+        }
+        __syncthreads();
+    }
+    if (!done) {   // a point with more candidates than a row holds, or no fixed point yet: the sequential kernel does this frame
+        if (tid == 0) fallback[b] = 1;
+        return;
+    }
+    if (tid == 0) fallback[b] = 0;
+    // the last point that took a feature is the one the reference's vector ends up with; every accepted pick counts (:1461-1463)
+    int mine = 0;
+    for (int q = tid; q < capQpad; q += nth) {
+        const int f = q < NQ ? s_feat[q] : -1;
+        if (f >= 0) {
+            atomicMax(&s_match[f], q);
+            mine++;
+        }
+        qfeat[(size_t)b * capQpad + q] = f;
+    }
+    if (mine) atomicAdd(&s_flag[2], mine);
+    __syncthreads();
+    // rotation consistency (:1467-1494): bins of the accepted matches, the three maxima, removal
+    if (!use_ratio && check_ori) {
+        for (int iq = tid; iq < NQ; iq += nth) {
+            const int f = s_feat[iq];
+            if (f < 0) continue;
+            float rot = __fsub_rn(Q[iq].angle, K[f].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            if (bin >= 0 && bin < 30) atomicAdd(&s_hist[bin], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < 30; i++) {
+                const int s = s_hist[i];
+                if (s > max1) {
+                    max3 = max2; max2 = max1; max1 = s;
+                    i3 = i2; i2 = i1; i1 = i;
+                } else if (s > max2) {
+                    max3 = max2; max2 = s;
+                    i3 = i2; i2 = i;
+                } else if (s > max3) {
+                    max3 = s;
+                    i3 = i;
+                }
+            }
+            if ((float)max2 < 0.1f * (float)max1) {
+                i2 = -1;
+                i3 = -1;
+            } else if ((float)max3 < 0.1f * (float)max1) {
+                i3 = -1;
+            }
+            s_keep[0] = i1;
+            s_keep[1] = i2;
+            s_keep[2] = i3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int iq = tid; iq < NQ; iq += nth) {
+            const int f = s_feat[iq];
+            if (f < 0) continue;
+            float rot = __fsub_rn(Q[iq].angle, K[f].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            if (bin >= 0 && bin < 30 && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                s_match[f] = -2;   // assigned, then removed: the reference stores NULL here (:1489)
+                removed++;
+            }
+        }
+        if (removed) atomicSub(&s_flag[2], removed);
+        __syncthreads();
+    }
+    for (int i = tid; i < cap; i += nth) match[(size_t)b * cap + i] = s_match[i];
+    if (tid == 0) nmatches[b] = s_flag[2];
 }
 
 // ---- ORBmatcher::SearchForInitialization (ref: src/ORBmatcher.cc:405-520) ----------------------------------
@@ -924,8 +1104,10 @@ int launch_window_best(hipStream_t s, const orbhip_keypoint *kps, const uint8_t 
 size_t proj_scratch_bytes(int B, int capQ, int cap)
 {
     const size_t capQpad = ((size_t)capQ + 63) / 64 * 64;
-    return (size_t)B * capQpad * (PROJ_K * 4 + 4 + 4) + (size_t)B * cap * 16 + 256;
+    return (size_t)B * capQpad * (PROJ_K * 4 + 4 + 4) + (size_t)B * cap * 16 + (size_t)B * 4 + 512;
 }
+
+size_t proj_assign_par_lds(int cap, int capQpad) { return (size_t)cap * 8 + (size_t)capQpad * 4 + (size_t)((cap + 31) / 32) * 4; }
 
 size_t proj_assign_lds(int cap) { return (size_t)cap * 4 + (size_t)((cap + 31) / 32) * 4; }
 
@@ -945,11 +1127,24 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
     hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
     hipLaunchKernelGGL(k_proj_cands, dim3((capQpad + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, desc, cap, uRight, gp,
                        cellOff, rec, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
+    // a frame or two per call: the parallel fixed-point kernel first; frames it cannot do (a point with more than 32
+    // candidates, no fixed point yet) are left to the sequential one through fallback[] (ORBHIP_PROJ_SEQ=1: sequential only)
+    static const bool seqOnly = getenv("ORBHIP_PROJ_SEQ") && atoi(getenv("ORBHIP_PROJ_SEQ")) != 0;
+    static const int maxRounds = getenv("ORBHIP_PROJ_ROUNDS") ? atoi(getenv("ORBHIP_PROJ_ROUNDS")) : PAR_ROUNDS;   // tests force the hand-over with 1
+    int32_t *fallback = nullptr;
+    const size_t parLds = proj_assign_par_lds(cap, capQpad);
+    if (B < 8 && !seqOnly && parLds <= 150 * 1024) {
+        fallback = (int32_t *)(((uintptr_t)(qfeat + (size_t)B * capQpad) + 255) & ~(uintptr_t)255);
+        if (parLds > 32 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_proj_assign_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)parLds);
+        hipLaunchKernelGGL(k_proj_assign_par, dim3(B, 1, 1), dim3(1024, 1, 1), parLds, s, kps, cnt, cap, occupied, queries, nq, capQ,
+                           capQpad, keff, tuples, tcount, qfeat, use_ratio, nnratio, check_ori, th_high, match, nmatches, fallback, maxRounds);
+    }
     if (proj_assign_lds(cap) > 32 * 1024)
         (void)hipFuncSetAttribute((const void *)k_proj_assign, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)proj_assign_lds(cap));
     hipLaunchKernelGGL(k_proj_assign, dim3(B, 1, 1), dim3(64, 1, 1), proj_assign_lds(cap), s, kps, desc, cnt, cap, uRight,
                        occupied, gp, cellOff, cellIdx, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount, qfeat,
-                       use_ratio, nnratio, check_ori, th_high, match, nmatches);
+                       use_ratio, nnratio, check_ori, th_high, match, nmatches, fallback);
     return ORBHIP_OK;
 }
