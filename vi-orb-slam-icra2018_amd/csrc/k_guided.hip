@@ -23,6 +23,13 @@
 #define GCELLS ORBHIP_GRID_CELLS
 #define PROJ_K 32   // candidate slots per point (one 64-point chunk of lists = 8 KB of LDS)
 
+#define WAVE_LDS_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
 struct GridParams {
     float minX, minY, invW, invH;
 };
@@ -227,6 +234,81 @@ __global__ __launch_bounds__(256) void k_proj_cands(const orbhip_keypoint *__res
     tcount[(size_t)b * capQpad + iq] = count;
 }
 
+// The same lists for ONE frame per call: a 16-lane row per point instead of a thread.  A thread walks its window record by
+// record (20-40 dependent trips to memory: 85 us for the 1000 points of a frame, however few of them there are); a row reads
+// the cell ranges of up to 16 window columns at once, flattens them (row prefix sum) and examines 16 records per trip; the
+// records that pass keep their visiting order through a row ballot.  Same tuples, same counts.
+__global__ __launch_bounds__(256) void k_proj_cands_row(const uint8_t *__restrict__ desc, int cap, const float *__restrict__ uRight,
+                                                        const GridParams gp, const int32_t *__restrict__ cellOff,
+                                                        const float4 *__restrict__ rec,
+                                                        const orbhip_proj_query *__restrict__ queries,
+                                                        const uint8_t *__restrict__ qdesc, const int32_t *__restrict__ nq,
+                                                        int capQ, int capQpad, int keff, uint32_t *__restrict__ tuples,
+                                                        int32_t *__restrict__ tcount)
+{
+    __shared__ int s_start[16][16], s_excl[16][17];
+    const int b = blockIdx.y, tid = threadIdx.x, gl = tid & 15, row = tid >> 4;
+    const int iq = blockIdx.x * 16 + row;
+    if (iq >= capQpad) return;   // row-uniform
+    int count = 0;
+    if (iq < min(nq[b], capQ)) {
+        const orbhip_proj_query q = queries[(size_t)b * capQ + iq];
+        int x0, x1, y0, y1;
+        if ((q.flags & ORBHIP_Q_ACTIVE) && window_cells(gp, q.u, q.v, q.radius, x0, x1, y0, y1)) {
+            const uint4 *qd = reinterpret_cast<const uint4 *>(qdesc + ((size_t)b * capQ + iq) * 32);
+            const uint4 a0 = qd[0], a1 = qd[1];
+            const uint4 *D = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
+            const float *UR = uRight ? uRight + (size_t)b * cap : nullptr;
+            const float4 *R = rec + (size_t)b * cap;
+            const int32_t *O = cellOff + (size_t)b * (GCELLS + 1);
+            uint32_t *T = tuples + ((size_t)b * capQpad + iq) * PROJ_K;
+            for (int cb = x0; cb <= x1; cb += 16) {
+                const int ix = cb + gl;
+                const int s = ix <= x1 ? O[ix * GROWS + y0] : 0, e = ix <= x1 ? O[ix * GROWS + y1 + 1] : 0;
+                int incl = e - s;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+                s_start[row][gl] = s;
+                s_excl[row][gl + 1] = incl;
+                if (gl == 0) s_excl[row][0] = 0;
+                WAVE_LDS_SYNC();
+                const int total = s_excl[row][16];
+                for (int rb = 0; rb < total; rb += 16) {
+                    const int r = rb + gl;
+                    bool pass = false;
+                    uint32_t tup = 0;
+                    if (r < total) {
+                        int c = 0;                               // the column whose range holds record r
+#pragma unroll
+                        for (int h = 8; h > 0; h >>= 1)
+                            if (s_excl[row][c + h] <= r) c += h;
+                        const float4 rr = R[s_start[row][c] + (r - s_excl[row][c])];
+                        const int w = __float_as_int(rr.z), oct = w & 255, idx = w >> 8;
+                        pass = !(oct < q.min_level) && !(q.max_level >= 0 && oct > q.max_level) &&
+                               fabsf(__fsub_rn(rr.x, q.u)) < q.radius && fabsf(__fsub_rn(rr.y, q.v)) < q.radius;
+                        if (pass && UR) {
+                            const float ur = UR[idx];
+                            if (ur > 0 && fabsf(__fsub_rn(q.proj_xr, ur)) > q.radius) pass = false;   // :92-97, :1418-1424
+                        }
+                        if (pass) {
+                            const int d = hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]);
+                            tup = (uint32_t)d | (((uint32_t)oct & 15u) << 9) | ((uint32_t)idx << 13);
+                        }
+                    }
+                    const unsigned m = (unsigned)((__ballot(pass) >> (tid & 48)) & 0xFFFFull);
+                    const int pos = count + __popc(m & ((1u << gl) - 1u));
+                    if (pass && pos < keff) T[pos] = tup;
+                    count += __popc(m);
+                }
+                WAVE_LDS_SYNC();
+            }
+        }
+    }
+    if (gl == 0) tcount[(size_t)b * capQpad + iq] = count;
+}
+
 // ---- per-query best feature of a KeyFrame window: the inner loop of ORBmatcher::Fuse (ref: src/ORBmatcher.cc:887-950 with
 // the chi-square gate on the reprojection error, :1044-1075 without) and of SearchBySim3 (:1190-1224, :1270-1304).  The
 // queries are independent (no feature is closed by an earlier point), so one thread walks one window; the first feature
@@ -319,12 +401,6 @@ __device__ __forceinline__ int wave_sum_g(int v)
            __builtin_amdgcn_readlane(v, 48);
 }
 
-#define WAVE_LDS_SYNC()                                        \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
 
 __global__ __launch_bounds__(64) void k_proj_assign(const orbhip_keypoint *__restrict__ kps,
                                                     const uint8_t *__restrict__ desc,
@@ -1125,11 +1201,15 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
     int32_t *qfeat = tcount + (size_t)B * capQpad;
     const int keff = proj_keff();
     hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
-    hipLaunchKernelGGL(k_proj_cands, dim3((capQpad + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, desc, cap, uRight, gp,
-                       cellOff, rec, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
+    static const bool seqOnly = getenv("ORBHIP_PROJ_SEQ") && atoi(getenv("ORBHIP_PROJ_SEQ")) != 0;
+    if (B < 8 && !seqOnly)   // a frame or two: a 16-lane row per point
+        hipLaunchKernelGGL(k_proj_cands_row, dim3((capQpad + 15) / 16, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gp, cellOff, rec,
+                           queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
+    else
+        hipLaunchKernelGGL(k_proj_cands, dim3((capQpad + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, desc, cap, uRight, gp,
+                           cellOff, rec, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
     // a frame or two per call: the parallel fixed-point kernel first; frames it cannot do (a point with more than 32
     // candidates, no fixed point yet) are left to the sequential one through fallback[] (ORBHIP_PROJ_SEQ=1: sequential only)
-    static const bool seqOnly = getenv("ORBHIP_PROJ_SEQ") && atoi(getenv("ORBHIP_PROJ_SEQ")) != 0;
     static const int maxRounds = getenv("ORBHIP_PROJ_ROUNDS") ? atoi(getenv("ORBHIP_PROJ_ROUNDS")) : PAR_ROUNDS;   // tests force the hand-over with 1
     int32_t *fallback = nullptr;
     const size_t parLds = proj_assign_par_lds(cap, capQpad);
