@@ -41,16 +41,34 @@ __device__ __forceinline__ int grid_cell(const GridParams &gp, float x, float y)
     return (px < 0 || px >= GCOLS || py < 0 || py >= GROWS) ? -1 : px * GROWS + py;
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP network
+__device__ __forceinline__ int grid_wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+
+// LDSIDX: the cell entries are sorted in LDS (cap * 4 bytes of dynamic LDS) and written out once -- the insertion sort on the
+// global array was a chain of dependent memory trips per cell (most of the 24 us a single frame's grid took); frames with
+// more features than fit keep the in-place form.
+template <bool LDSIDX>
 __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__restrict__ kps,
                                                     const int32_t *__restrict__ cnt, int cap, const GridParams gp,
                                                     int32_t *__restrict__ cellOff, int32_t *__restrict__ cellIdx)
 {
+    extern __shared__ int s_idx[];
     __shared__ int s_cnt[GCELLS];
-    __shared__ int s_part[256];
+    __shared__ int s_wtot[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = min(cnt[b], cap);
     const orbhip_keypoint *K = kps + (size_t)b * cap;
     int32_t *O = cellOff + (size_t)b * (GCELLS + 1), *I = cellIdx + (size_t)b * cap;
+    int *E = LDSIDX ? s_idx : I;
     for (int c = tid; c < GCELLS; c += 256) s_cnt[c] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
@@ -65,17 +83,12 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
         c[k] = s_cnt[tid * PER + k];
         sum += c[k];
     }
-    s_part[tid] = sum;
+    const int incl = grid_wave_incl_scan(sum);
+    if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const int v = tid >= d ? s_part[tid - d] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int run = s_part[tid] - sum;
-    if (tid == 255) O[GCELLS] = s_part[255];
-    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (tid >> 6); w++) run += s_wtot[w];
+    if (tid == 255) O[GCELLS] = run + sum;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         s_cnt[tid * PER + k] = run;   // fill cursor
@@ -85,22 +98,27 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         const int cc = grid_cell(gp, K[i].x, K[i].y);
-        if (cc >= 0) I[atomicAdd(&s_cnt[cc], 1)] = i;
+        if (cc >= 0) E[atomicAdd(&s_cnt[cc], 1)] = i;
     }
-    __threadfence_block();
+    if (!LDSIDX) __threadfence_block();
     __syncthreads();
     // ascending feature index inside each cell (cells hold a handful of features)
     for (int cc = tid; cc < GCELLS; cc += 256) {
         const int s = cc ? s_cnt[cc - 1] : 0, e = s_cnt[cc];   // cursors now sit at the cell ends
         for (int a = s + 1; a < e; a++) {
-            const int v = I[a];
+            const int v = E[a];
             int p = a - 1;
-            while (p >= s && I[p] > v) {
-                I[p + 1] = I[p];
+            while (p >= s && E[p] > v) {
+                E[p + 1] = E[p];
                 p--;
             }
-            I[p + 1] = v;
+            E[p + 1] = v;
         }
+    }
+    if (LDSIDX) {
+        __syncthreads();
+        const int total = s_cnt[GCELLS - 1];
+        for (int j = tid; j < total; j += 256) I[j] = s_idx[j];
     }
 }
 
@@ -371,6 +389,98 @@ __global__ __launch_bounds__(256) void k_window_best(const uint8_t *__restrict__
     bestDist[(size_t)b * capQ + iq] = bd;
 }
 
+// minimum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ int row_min_i(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return v;
+}
+
+// k_window_best for ONE key frame per call: a 16-lane row per point (see k_proj_cands_row); the first feature of smallest
+// distance in visiting order = the minimum of (distance, position).
+__global__ __launch_bounds__(256) void k_window_best_row(const uint8_t *__restrict__ desc, int cap, const float *__restrict__ uRight,
+                                                         const LevelGate gate, const GridParams gp,
+                                                         const int32_t *__restrict__ cellOff, const float4 *__restrict__ rec,
+                                                         const orbhip_proj_query *__restrict__ queries,
+                                                         const uint8_t *__restrict__ qdesc, const int32_t *__restrict__ nq, int capQ,
+                                                         int32_t *__restrict__ bestIdx, int32_t *__restrict__ bestDist)
+{
+    __shared__ int s_start[16][16], s_excl[16][17];
+    const int b = blockIdx.y, tid = threadIdx.x, gl = tid & 15, row = tid >> 4;
+    const int iq = blockIdx.x * 16 + row;
+    if (iq >= capQ) return;   // row-uniform
+    int key = 0x7FFFFFFF, myIdx = -1;   // (distance << 20 | position), feature of this lane's best
+    if (iq < nq[b]) {
+        const orbhip_proj_query q = queries[(size_t)b * capQ + iq];
+        int x0, x1, y0, y1;
+        if ((q.flags & ORBHIP_Q_ACTIVE) && window_cells(gp, q.u, q.v, q.radius, x0, x1, y0, y1)) {
+            const uint4 *qd = reinterpret_cast<const uint4 *>(qdesc + ((size_t)b * capQ + iq) * 32);
+            const uint4 a0 = qd[0], a1 = qd[1];
+            const uint4 *D = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
+            const float *UR = uRight ? uRight + (size_t)b * cap : nullptr;
+            const float4 *R = rec + (size_t)b * cap;
+            const int32_t *O = cellOff + (size_t)b * (GCELLS + 1);
+            int seen = 0;
+            for (int cb = x0; cb <= x1; cb += 16) {
+                const int ix = cb + gl;
+                const int s = ix <= x1 ? O[ix * GROWS + y0] : 0, e = ix <= x1 ? O[ix * GROWS + y1 + 1] : 0;
+                int incl = e - s;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+                s_start[row][gl] = s;
+                s_excl[row][gl + 1] = incl;
+                if (gl == 0) s_excl[row][0] = 0;
+                WAVE_LDS_SYNC();
+                const int total = s_excl[row][16];
+                for (int r = gl; r < total; r += 16) {
+                    int c = 0;
+#pragma unroll
+                    for (int h = 8; h > 0; h >>= 1)
+                        if (s_excl[row][c + h] <= r) c += h;
+                    const float4 rr = R[s_start[row][c] + (r - s_excl[row][c])];
+                    const int w = __float_as_int(rr.z), oct = w & 255, idx = w >> 8;
+                    if (!(fabsf(__fsub_rn(rr.x, q.u)) < q.radius && fabsf(__fsub_rn(rr.y, q.v)) < q.radius)) continue;
+                    if (oct < q.min_level || oct > q.max_level) continue;
+                    if (gate.on) {
+                        const float ex = __fsub_rn(q.u, rr.x), ey = __fsub_rn(q.v, rr.y);
+                        float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                        const float ur = UR ? UR[idx] : -1.0f;
+                        double lim = 5.99;
+                        if (ur >= 0) {
+                            const float er = __fsub_rn(q.proj_xr, ur);
+                            e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                            lim = 7.8;
+                        }
+                        if ((double)__fmul_rn(e2, gate.invSigma2[oct & 15]) > lim) continue;
+                    }
+                    const int d = hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]);
+                    const int k = (d << 20) | (seen + r);
+                    if (d < 256 && k < key) {
+                        key = k;
+                        myIdx = idx;
+                    }
+                }
+                seen += total;
+                WAVE_LDS_SYNC();
+            }
+        }
+    }
+    const int k1 = row_min_i(key);
+    if (key == k1 && k1 != 0x7FFFFFFF) {   // one lane: positions are unique
+        bestIdx[(size_t)b * capQ + iq] = myIdx;
+        bestDist[(size_t)b * capQ + iq] = k1 >> 20;
+    }
+    if (k1 == 0x7FFFFFFF && gl == 0) {
+        bestIdx[(size_t)b * capQ + iq] = -1;
+        bestDist[(size_t)b * capQ + iq] = 256;
+    }
+}
+
 __device__ __forceinline__ int wave_min_i(int v)
 {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
@@ -381,15 +491,6 @@ __device__ __forceinline__ int wave_min_i(int v)
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// minimum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ int row_min_i(int v)
-{
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
-    return v;
-}
 
 __device__ __forceinline__ int wave_sum_g(int v)
 {
@@ -1145,7 +1246,10 @@ int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *
                       float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx)
 {
     const GridParams gp = {minX, minY, invW, invH};
-    hipLaunchKernelGGL(k_grid_build, dim3(B, 1, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, gp, cellOff, cellIdx);
+    if ((size_t)cap * 4 <= 48 * 1024)
+        hipLaunchKernelGGL(k_grid_build<true>, dim3(B, 1, 1), dim3(256, 1, 1), (size_t)cap * 4, s, kps, cnt, cap, gp, cellOff, cellIdx);
+    else
+        hipLaunchKernelGGL(k_grid_build<false>, dim3(B, 1, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, gp, cellOff, cellIdx);
     return ORBHIP_OK;
 }
 
@@ -1172,8 +1276,13 @@ int launch_window_best(hipStream_t s, const orbhip_keypoint *kps, const uint8_t 
     for (int i = 0; i < 16; i++) gate.invSigma2[i] = (gate.on && i < nlevels) ? invLevelSigma2[i] : 0.f;
     float4 *rec = (float4 *)scratch;
     hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
-    hipLaunchKernelGGL(k_window_best, dim3((capQ + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gate, gp,
-                       cellOff, rec, queries, qdesc, nq, capQ, bestIdx, bestDist);
+    static const bool seqOnly = getenv("ORBHIP_PROJ_SEQ") && atoi(getenv("ORBHIP_PROJ_SEQ")) != 0;
+    if (B < 8 && !seqOnly && cap < (1 << 20))   // one key frame per call: a 16-lane row per point
+        hipLaunchKernelGGL(k_window_best_row, dim3((capQ + 15) / 16, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gate, gp,
+                           cellOff, rec, queries, qdesc, nq, capQ, bestIdx, bestDist);
+    else
+        hipLaunchKernelGGL(k_window_best, dim3((capQ + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gate, gp,
+                           cellOff, rec, queries, qdesc, nq, capQ, bestIdx, bestDist);
     return ORBHIP_OK;
 }
 
