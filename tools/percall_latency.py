@@ -72,6 +72,18 @@ qf["min_level"], qf["max_level"], qf["flags"] = k0["octave"] - 1, k0["octave"], 
 rows.append(("`Fuse` window search (1000 points into one key frame)", bench(lambda: guided.WindowBest(ex, k1, d1, gp, qf, d0, None, sig), 300),
              bench(lambda: O.window_best(k1, d1, gp, qf, d0, None, sig), 30)))
 
+# Frame::ComputeStereoMatches on the pyramids the two extractors hold (EuRoC stereo geometry, 1200 features)
+from orbhip.extractor import ComputeStereoMatches
+SL, SR = synth.make_stereo_pair(7, 752, 480, disparity=21)
+exL, exR = ORBextractor(1200, max_w=752, max_h=480), ORBextractor(1200, max_w=752, max_h=480)
+oL, oR = O.Extractor(1200), O.Extractor(1200)
+(kL, dL), (kR, dR) = exL(SL), exR(SR)
+oL(SL), oR(SR)
+mb, mbf = 0.11, 47.9
+rows.append(("`Frame::ComputeStereoMatches` 752x480 pair, 1200 features a side (pyramids resident)",
+             bench(lambda: ComputeStereoMatches(exL, kL, dL, exR, kR, dR, mb, mbf), 300),
+             bench(lambda: O.stereo_matches(oL, kL, dL, oR, kR, dR, mb, mbf), 20)))
+
 print("| call (one per frame / key-frame pair) | liborbhip per call (ms) | oracle, one host core (ms) |")
 print("|---|---|---|")
 for name, g, c in rows:

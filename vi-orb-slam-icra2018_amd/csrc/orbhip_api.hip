@@ -1467,27 +1467,28 @@ extern "C" int orbhip_stereo_match(orbhip_ctx *L, orbhip_ctx *R, const orbhip_ke
     if (nL == 0 || nR == 0) return ORBHIP_OK;
     HIPCHK(L, hipSetDevice(L->device));
     const int cap = std::max(nL, nR);
-    TmpDev T(L);
+    Packed P(L);
     int rc;
-    if ((rc = T.reserve((size_t)cap * (28 + 32) * 2 + (size_t)cap * 8 + 4096))) return rc;
-    orbhip_keypoint *dkL = (orbhip_keypoint *)T.take((size_t)cap * 28), *dkR = (orbhip_keypoint *)T.take((size_t)cap * 28);
-    uint8_t *ddL = (uint8_t *)T.take((size_t)cap * 32), *ddR = (uint8_t *)T.take((size_t)cap * 32);
-    float *du = (float *)T.take((size_t)cap * 4), *dz = (float *)T.take((size_t)cap * 4);
-    int32_t *dc = (int32_t *)T.take(16);
-    const int32_t cnts[3] = {nL, nR, 0};
-    hipStream_t s = L->stream;
-    HIPCHK(L, hipMemcpyAsync(dkL, kpsL, (size_t)nL * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(L, hipMemcpyAsync(dkR, kpsR, (size_t)nR * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(L, hipMemcpyAsync(ddL, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(L, hipMemcpyAsync(ddR, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(L, hipMemcpyAsync(dc, cnts, 12, hipMemcpyHostToDevice, s));
+    if ((rc = P.begin((size_t)cap * (28 + 32) * 2 + (size_t)cap * 8 + 16 * 256))) return rc;
+    // (device arrays of `cap` slots each; only the first nL / nR entries travel)
+    const int32_t cnts[4] = {nL, nR, 0, 0};
+    const orbhip_keypoint *dkL = (const orbhip_keypoint *)P.in(kpsL, (size_t)nL * 28);
+    P.off += (size_t)(cap - nL) * 28;
+    const orbhip_keypoint *dkR = (const orbhip_keypoint *)P.in(kpsR, (size_t)nR * 28);
+    P.off += (size_t)(cap - nR) * 28;
+    const uint8_t *ddL = (const uint8_t *)P.in(descL, (size_t)nL * 32);
+    P.off += (size_t)(cap - nL) * 32;
+    const uint8_t *ddR = (const uint8_t *)P.in(descR, (size_t)nR * 32);
+    P.off += (size_t)(cap - nR) * 32;
+    int32_t *dc = (int32_t *)P.in(cnts, 16);                     // nL | nR | matches before the median cut (comes back)
+    float *du = (float *)P.out((size_t)cap * 4), *dz = (float *)P.out((size_t)cap * 4);
+    P.inEnd = (size_t)((uint8_t *)dc - P.d) + 16;
+    if ((rc = P.upload())) return rc;
     if ((rc = orbhip_stereo_match_device(L, R, dkL, ddL, dc, dkR, ddR, dc + 1, cap, 1, mb, mbf, du, dz, dc + 2))) return rc;
-    int nm = 0;
-    HIPCHK(L, hipMemcpyAsync(mvuRight, du, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(L, hipMemcpyAsync(mvDepth, dz, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(L, hipMemcpyAsync(&nm, dc + 2, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(L, hipStreamSynchronize(s));
-    if (nmatch) *nmatch = nm;
+    if ((rc = P.download(dc))) return rc;
+    memcpy(mvuRight, P.host(du), (size_t)nL * 4);
+    memcpy(mvDepth, P.host(dz), (size_t)nL * 4);
+    if (nmatch) *nmatch = ((const int32_t *)P.host(dc))[2];
     return ORBHIP_OK;
 }
 
