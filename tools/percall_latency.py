@@ -84,6 +84,15 @@ rows.append(("`Frame::ComputeStereoMatches` 752x480 pair, 1200 features a side (
              bench(lambda: ComputeStereoMatches(exL, kL, dL, exR, kR, dR, mb, mbf), 300),
              bench(lambda: O.stereo_matches(oL, kL, dL, oR, kR, dR, mb, mbf), 20)))
 
+# the two small steps of the Frame constructor (src/Frame.cc:574-589, :748-778)
+from orbhip import rectify
+Kc = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]], np.float32)
+Dc = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)
+rows.append(("`Frame::UndistortKeyPoints` 1000 keypoints (EuRoC cam0 coefficients)", bench(lambda: rectify.UndistortKeyPoints(ex, k1, Kc, Dc), 300),
+             bench(lambda: O.undistort_points(np.stack([k1["x"], k1["y"]], 1), Kc, Dc, Kc), 50)))
+rows.append(("`Frame::AssignFeaturesToGrid` 1000 keypoints", bench(lambda: guided.AssignFeaturesToGrid(ex, k1, gp), 300),
+             bench(lambda: O.grid_build(k1, gp), 50)))
+
 print("| call (one per frame / key-frame pair) | liborbhip per call (ms) | oracle, one host core (ms) |")
 print("|---|---|---|")
 for name, g, c in rows:

@@ -1516,20 +1516,20 @@ extern "C" int orbhip_grid_build(orbhip_ctx *c, const orbhip_keypoint *kps, int 
         return fail(c, ORBHIP_E_ARG, "orbhip_grid_build: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     const int cap = std::max(n, 1);
-    TmpDev T(c);
+    Packed P(c);
     int rc;
-    if ((rc = T.reserve((size_t)cap * (28 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + 4096))) return rc;
-    orbhip_keypoint *dk = (orbhip_keypoint *)T.take((size_t)cap * 28);
-    int32_t *dc = (int32_t *)T.take(16), *doff = (int32_t *)T.take((ORBHIP_GRID_CELLS + 1) * 4),
-            *didx = (int32_t *)T.take((size_t)cap * 4);
-    hipStream_t s = c->stream;
-    if (n) HIPCHK(c, hipMemcpyAsync(dk, kps, (size_t)n * 28, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dc, &n, 4, hipMemcpyHostToDevice, s));
+    if ((rc = P.begin((size_t)cap * (28 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + 8 * 256))) return rc;
+    const int32_t cnt[4] = {n, 0, 0, 0};
+    const orbhip_keypoint *dk = (const orbhip_keypoint *)P.in(kps, (size_t)n * 28);
+    P.off += (size_t)(cap - n) * 28;
+    const int32_t *dc = (const int32_t *)P.in(cnt, 16);
+    int32_t *doff = (int32_t *)P.out((ORBHIP_GRID_CELLS + 1) * 4), *didx = (int32_t *)P.out((size_t)cap * 4);
+    if ((rc = P.upload())) return rc;
     if ((rc = orbhip_grid_build_device(c, dk, dc, cap, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
-    HIPCHK(c, hipMemcpyAsync(cell_off, doff, (ORBHIP_GRID_CELLS + 1) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if ((rc = P.download())) return rc;   // offsets | entries in one copy (the entries are at most n)
+    memcpy(cell_off, P.host(doff), (ORBHIP_GRID_CELLS + 1) * 4);
     const int total = cell_off[ORBHIP_GRID_CELLS];
-    if (total) HIPCHK(c, hipMemcpy(cell_idx, didx, (size_t)total * 4, hipMemcpyDeviceToHost));
+    if (total) memcpy(cell_idx, P.host(didx), (size_t)total * 4);
     return ORBHIP_OK;
 }
 
