@@ -254,8 +254,12 @@ __host__ __device__ inline void chain_source_region(int &x0, int &x1, int &y0, i
 __global__ __launch_bounds__(CH_NT) void k_pyramid_chain(const OrbLevels G, const ChainLevels CL, const ChainTile *__restrict__ tiles,
                                                        const uint8_t *__restrict__ lvl0, int stride0, unsigned long long frame0,
                                                        uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
-                                                       const int32_t *__restrict__ tab, int bufA, int bufB, int xtabBytes)
+                                                       const int32_t *__restrict__ tab, int bufA, int bufB, int xtabBytes,
+                                                       uint8_t *__restrict__ hostPyr)
 {
+    // hostPyr: page-locked host twin of `pyr` (orbhip_set_host_pyramid) or null.  The finished pixels of a tile are stored to it
+    // as well: the level arrives on the host with the kernel, over PCIe as posted 64-byte writes, instead of through a copy
+    // node of the graph that the FAST kernel ends up queued behind (measured: 12 us + 6 us of gaps per call).
     extern __shared__ __align__(16) uint8_t smem[];   // [buffer A | buffer B | column taps | row taps]
     __shared__ int s_r[ORBHIP_MAX_LEVELS][4];          // region of every level of the chain: x0, x1, y0, y1 (inclusive)
     __shared__ int s_xo[ORBHIP_MAX_LEVELS], s_yo[ORBHIP_MAX_LEVELS];   // first staged entry of the level's tap slices
@@ -349,6 +353,7 @@ __global__ __launch_bounds__(CH_NT) void k_pyramid_chain(const OrbLevels G, cons
     uint8_t *dst = bB;
     int ox = XA, oy = by0, ps = pS;
     uint8_t *D = pyr + (size_t)frame * pyrFrame + G.lv[top].imgOff;
+    uint8_t *HD = hostPyr ? hostPyr + (size_t)frame * pyrFrame + G.lv[top].imgOff : nullptr;
     const int dstride = G.lv[top].stride;
     for (int l = base + 1; l <= top; l++) {
         const int x0 = s_r[l][0], y0 = s_r[l][2];
@@ -372,9 +377,10 @@ __global__ __launch_bounds__(CH_NT) void k_pyramid_chain(const OrbLevels G, cons
         };
         auto put = [&](int i, int v) {
             const int ry = (int)(((float)i + 0.5f) * invNx), rx = i - ry * nx;
-            if (last)
+            if (last) {
                 D[(size_t)(y0 + ry) * dstride + x0 + rx] = (uint8_t)v;
-            else
+                if (HD) HD[(size_t)(y0 + ry) * dstride + x0 + rx] = (uint8_t)v;
+            } else
                 dst[ry * pd + rx] = (uint8_t)v;
         };
         const int n = nx * ny;
@@ -496,10 +502,11 @@ bool chain_plan(const OrbLevels &G, const bool *levelOk, const ChainLevels &CL, 
 }
 
 void launch_pyramid_chain(hipStream_t s, const OrbLevels &G, const ChainLevels &CL, const ChainGroup &grp, const ChainTile *tiles,
-                          const uint8_t *lvl0, int stride0, size_t frame0, uint8_t *pyr, size_t pyrFrame, const int32_t *tab, int B)
+                          const uint8_t *lvl0, int stride0, size_t frame0, uint8_t *pyr, size_t pyrFrame, const int32_t *tab, int B,
+                          uint8_t *hostPyr)
 {
     dim3 grid(grp.ntiles, B, 1), block(CH_NT, 1, 1);
     hipLaunchKernelGGL(k_pyramid_chain, grid, block, (size_t)(grp.bufA + grp.bufB + grp.xtabBytes + grp.ytabBytes), s, G, CL,
                        tiles + grp.firstTile, lvl0, stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tab,
-                       grp.bufA, grp.bufB, grp.xtabBytes);
+                       grp.bufA, grp.bufB, grp.xtabBytes, hostPyr);
 }

@@ -307,7 +307,7 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
     if (chained)
         for (const ChainGroup &grp : c->chainGroups)
             launch_pyramid_chain(s, G, c->chainLevels, grp, c->d_chainTiles, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes,
-                                 c->d_resizeTab, B);
+                                 c->d_resizeTab, B, h_pyr_dst);   // (the host copy of the pyramid is written by the kernel itself)
     // batches: level l from level l-1 (sequential dependency), all frames per launch
     for (int l = 1; l < G.nlevels && !chained; l++) {
         const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
@@ -323,7 +323,7 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
     // host copy of levels 1.. (orbhip_set_host_pyramid): one copy of the B frames' pyramid block into pinned memory.  A
     // frame or two: on the second stream, beside FAST / quadtree / blur / describe (those do not use it then); the main
     // stream joins it at the end.  Batches (the second stream carries the blur): behind the describe kernel.
-    const bool pyrFork = h_pyr_dst && B < 8 && G.nlevels > 1;
+    const bool pyrFork = h_pyr_dst && B < 8 && G.nlevels > 1 && !chained;
     if (pyrFork) {
         HIPCHK(c, hipEventRecord(c->evp[0], s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evp[0], 0));
@@ -370,7 +370,7 @@ static int run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t 
     if (ev) HIPCHK(c, hipEventRecord(c->ev[5], s));
     if (pyrFork)
         HIPCHK(c, hipStreamWaitEvent(s, c->evp[1], 0));
-    else if (h_pyr_dst && G.nlevels > 1)
+    else if (h_pyr_dst && G.nlevels > 1 && !chained)
         HIPCHK(c, hipMemcpyAsync(h_pyr_dst, c->d_pyr, (size_t)B * c->pyrFrameBytes, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipGetLastError());
     if (ev) c->haveStageEvents = true;

@@ -264,7 +264,8 @@ bool resize_hint_pointwise(const int32_t *xt, const int32_t *yt, int sw, int sh,
 bool chain_plan(const OrbLevels &G, const bool *levelOk, const ChainLevels &CL, std::vector<ChainTile> &tiles,
                 std::vector<ChainGroup> &groups);
 void launch_pyramid_chain(hipStream_t s, const OrbLevels &G, const ChainLevels &CL, const ChainGroup &grp, const ChainTile *tiles,
-                          const uint8_t *lvl0, int stride0, size_t frame0, uint8_t *pyr, size_t pyrFrame, const int32_t *tab, int B);
+                          const uint8_t *lvl0, int stride0, size_t frame0, uint8_t *pyr, size_t pyrFrame, const int32_t *tab, int B,
+                          uint8_t *hostPyr);
 void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
                  uint32_t *cand, uint16_t *cellCnt, int B);
