@@ -498,6 +498,7 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
             for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * s0, imgs[b] + (size_t)y * stride, (size_t)w);
     }
     uint8_t *blk = reinterpret_cast<uint8_t *>(c->d_kps);
+    static const bool directOut = !(getenv("ORBHIP_COPY_OUT") && atoi(getenv("ORBHIP_COPY_OUT")) != 0);   // A/B: 1 = result copy node
     const void *key[5] = {c->d_lvl0, blk, c->h_in, c->h_stage, hpyr};
     const bool same = c->g_exec && c->g_w == w && c->g_h == h && c->g_B == B && memcmp(key, c->g_key, sizeof(key)) == 0;
     if (!same) {
@@ -505,11 +506,14 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->capturing = true;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        // the describe kernel writes keypoints, descriptors and counts straight into the page-locked result block (posted PCIe
+        // writes of a few dozen KB that overlap the kernel): no copy node behind it -- that node started 8 us after describe ended
+        uint8_t *out = directOut ? c->h_stage : blk;
         hipError_t e = hipMemcpyAsync(c->d_lvl0, c->h_in, inBytes, hipMemcpyHostToDevice, c->stream);
-        rc = e == hipSuccess ? run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
-                                            (int32_t *)(blk + coff), dcap, hpyr)
+        rc = e == hipSuccess ? run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(out + koff), out + doff,
+                                            (int32_t *)(out + coff), dcap, hpyr)
                              : ORBHIP_E_HIP;
-        if (rc == ORBHIP_OK) e = hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream);
+        if (rc == ORBHIP_OK && !directOut) e = hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream);
         hipGraph_t g = nullptr;
         const hipError_t e2 = hipStreamEndCapture(c->stream, &g);
         c->capturing = false;
@@ -527,11 +531,12 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
     if ((c->g_calls++ & 255u) == 0) {
         // the first call of a geometry and every 256th one run the same chain eagerly: that refreshes the stage times behind
         // GetTimeOfComputePyramid / ...KeyPointsOctTree / ...Descriptor (include/ORBextractor.h:51-53)
+        uint8_t *out = directOut ? c->h_stage : blk;
         HIPCHK(c, hipMemcpyAsync(c->d_lvl0, c->h_in, inBytes, hipMemcpyHostToDevice, c->stream));
-        if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
-                               (int32_t *)(blk + coff), dcap, hpyr)))
+        if ((rc = run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(out + koff), out + doff,
+                               (int32_t *)(out + coff), dcap, hpyr)))
             return rc;
-        HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
+        if (!directOut) HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
     } else {
         HIPCHK(c, hipGraphLaunch(c->g_exec, c->stream));
     }
