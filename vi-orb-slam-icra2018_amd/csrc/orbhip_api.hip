@@ -1116,6 +1116,21 @@ struct Packed {
         off += bytes;
         return p;
     }
+    // Outputs that the kernels only WRITE (plain stores, a few KB) can live in the page-locked block itself: the device
+    // stores to it over PCIe while the kernel runs and no copy follows -- the pointer is valid on both sides.
+    void *out_host(size_t bytes)
+    {
+        off = align_up(off, 256);
+        void *p = h + off;
+        off += bytes;
+        return p;
+    }
+    void *out_host_fill(int byte, size_t bytes)
+    {
+        void *p = out_host(bytes);
+        memset(p, byte, bytes);
+        return p;
+    }
     const void *host(const void *dev) const { return h + ((const uint8_t *)dev - d); }
     int upload()
     {
@@ -1267,14 +1282,32 @@ extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1,
     const int32_t *di1 = (const int32_t *)P.in(idx1, (size_t)m1 * 4), *di2 = (const int32_t *)P.in(idx2, (size_t)m2 * 4);
     const int32_t *dp = (const int32_t *)P.in(pairs.data(), pairs.size() * 4);
     // match12 | match21 start as -1 (part of the upload) and come back together
-    int32_t *dm12 = (int32_t *)P.in_fill(0xFF, (size_t)n1 * 4);
-    int32_t *dm21 = (int32_t *)P.in_fill(0xFF, (size_t)n2 * 4);
+    // match12 | match21 start as -1; the kernel only stores the matches.  Nodes of up to 128 features (the register path of
+    // k_bow_match) never read them back, so they live in the page-locked block and no copy follows; a frame with a larger node
+    // keeps them on the device (that path polls match21)
+    bool hostOut = true;
+    for (int p = 0; p < npairs && hostOut; p++)
+        if (off2[pairs[2 * p + 1] + 1] - off2[pairs[2 * p + 1]] > 128) hostOut = false;
+    int32_t *dm12, *dm21;
+    if (hostOut) {
+        dm12 = (int32_t *)P.out_host_fill(0xFF, (size_t)n1 * 4);
+        dm21 = (int32_t *)P.out_host_fill(0xFF, (size_t)n2 * 4);
+    } else {
+        dm12 = (int32_t *)P.in_fill(0xFF, (size_t)n1 * 4);
+        dm21 = (int32_t *)P.in_fill(0xFF, (size_t)n2 * 4);
+    }
     if ((rc = P.upload())) return rc;
     launch_bow_match(c->stream, dd1, dv1, do1, di1, dd2, dv2, do2, di2, dp, npairs, th, th_mode, nnratio, dm12, dm21);
     HIPCHK(c, hipGetLastError());
-    if ((rc = P.download(dm12))) return rc;
-    memcpy(match12, P.host(dm12), (size_t)n1 * 4);
-    memcpy(match21, P.host(dm21), (size_t)n2 * 4);
+    if (hostOut) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(match12, dm12, (size_t)n1 * 4);
+        memcpy(match21, dm21, (size_t)n2 * 4);
+    } else {
+        if ((rc = P.download(dm12))) return rc;
+        memcpy(match12, P.host(dm12), (size_t)n1 * 4);
+        memcpy(match21, P.host(dm21), (size_t)n2 * 4);
+    }
     // rotation consistency (ref: :236-246, :267-285): histogram in the reference's visiting order
     int nm = 0;
     std::vector<int> hist[30];
@@ -1397,14 +1430,14 @@ extern "C" int orbhip_vocab_transform(orbhip_ctx *c, const uint8_t *desc, int n,
     int rc;
     if ((rc = P.begin((size_t)n * 44 + 4 * 256))) return rc;
     const uint8_t *dd = (const uint8_t *)P.in(desc, (size_t)n * 32);
-    int32_t *dw = (int32_t *)P.out((size_t)n * 4), *dn = (int32_t *)P.out((size_t)n * 4);
-    float *dwt = (float *)P.out((size_t)n * 4);
+    int32_t *dw = (int32_t *)P.out_host((size_t)n * 4), *dn = (int32_t *)P.out_host((size_t)n * 4);   // written by the kernel over PCIe
+    float *dwt = (float *)P.out_host((size_t)n * 4);
     if ((rc = P.upload())) return rc;
     if ((rc = orbhip_vocab_transform_device(c, dd, n, levelsup, dw, dwt, dn))) return rc;
-    if ((rc = P.download())) return rc;
-    memcpy(word_id, P.host(dw), (size_t)n * 4);
-    memcpy(weight, P.host(dwt), (size_t)n * 4);
-    memcpy(node_id, P.host(dn), (size_t)n * 4);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(word_id, dw, (size_t)n * 4);
+    memcpy(weight, dwt, (size_t)n * 4);
+    memcpy(node_id, dn, (size_t)n * 4);
     return ORBHIP_OK;
 }
 
