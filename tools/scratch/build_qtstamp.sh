@@ -6,6 +6,13 @@ cd /root/repo
 rm -rf build_ab/csrc_stamp && mkdir -p build_ab && cp -r vi-orb-slam-icra2018_amd/csrc build_ab/csrc_stamp
 cd build_ab/csrc_stamp && rm -f *.o *.so
 sed -i 's/x\.sync()/x.sync_id(__LINE__)/g' quadtree_core.h
+python3 - <<'PY2'
+p='quadtree_core.h'
+s=open(p).read()
+s=s.replace('                    r = x.group_sum(r, sl);   // called by every thread of the workgroup','                    x.sync_id(9001);\n                    r = x.group_sum(r, sl);   // called by every thread of the workgroup\n                    x.sync_id(9002);')
+s=s.replace('                const int SPLIT = 1 << sl;\n                for (int i0 = 0;','                const int SPLIT = 1 << sl;\n                x.sync_id(9000);\n                for (int i0 = 0;')
+open(p,'w').write(s)
+PY2
 python3 - <<'PY'
 p='k_quadtree.hip'
 s=open(p).read()

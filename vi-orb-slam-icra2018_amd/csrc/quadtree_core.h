@@ -241,11 +241,16 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             for (int p = x.tid(); p < S; p += x.nth()) sh.scan[p] = sh.cnt[p] > 1 ? 1 : 0;
             x.sync();
             C = x.scan_exclusive(sh.scan, S); // compact candidate index
-            int *ccand = reinterpret_cast<int *>(sh.best);   // point counts of the candidates in list order (best[] is free until the winners)
+            // sort keys of the candidates in list order (best[] is free until the winners): candidate d goes before candidate c
+            // <=> more points, or as many and earlier in the list <=> key_d > key_c with key = count << 12 | (4095 - index).
+            // (lists of more than 4096 nodes or levels of 2^19 candidates keep the two-part comparison)
+            unsigned *ccand = sh.best;
+            const bool keyed = S <= 4096 && n < (1 << 19);
             for (int p = x.tid(); p < S; p += x.nth())
                 if (sh.cnt[p] > 1) {
-                    sh.order[sh.scan[p]] = p; // temporarily: candidates in list order
-                    ccand[sh.scan[p]] = sh.cnt[p];
+                    const int ci = sh.scan[p];
+                    sh.order[ci] = p; // temporarily: candidates in list order
+                    ccand[ci] = keyed ? ((unsigned)sh.cnt[p] << 12) | (unsigned)(4095 - ci) : (unsigned)sh.cnt[p];
                 }
             x.sync();
             // rank of candidate c = number of candidates that go before it: an all-pairs count, C * C comparisons.  One thread
@@ -264,16 +269,20 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
                     const bool live = idx < C * SPLIT;
                     const int c = live ? idx >> sl : 0, part = idx & (SPLIT - 1);
                     const int d0 = live ? (part * C) >> sl : 0, d1 = live ? ((part + 1) * C) >> sl : 0;
-                    const int mycnt = ccand[c];
+                    const unsigned mykey = ccand[c];
                     int r = 0;
-                    // (one read per comparison from the compact array, four in flight; through order[] and cnt[] it was a
-                    // chain of two dependent reads)
+                    // (one read and one comparison per pair from the compact key array, four in flight; through order[] and
+                    // cnt[] it was a chain of two dependent reads and ten instructions)
+                    if (keyed) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 4
 #endif
-                    for (int d = d0; d < d1; ++d) {
-                        const int pc = ccand[d];
-                        r += (pc > mycnt) || (pc == mycnt && d < c);
+                        for (int d = d0; d < d1; ++d) r += ccand[d] > mykey;
+                    } else {
+                        for (int d = d0; d < d1; ++d) {
+                            const unsigned pc = ccand[d];
+                            r += (pc > mykey) || (pc == mykey && d < c);
+                        }
                     }
                     r = x.group_sum(r, sl);   // called by every thread of the workgroup
                     if (live && part == 0) sh.rank[sh.order[c]] = r;
