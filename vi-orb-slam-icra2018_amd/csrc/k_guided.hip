@@ -1311,18 +1311,18 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
     const int keff = proj_keff();
     hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
     static const bool seqOnly = getenv("ORBHIP_PROJ_SEQ") && atoi(getenv("ORBHIP_PROJ_SEQ")) != 0;
-    if (B < 8 && !seqOnly)   // a frame or two: a 16-lane row per point
+    if (!seqOnly)   // a 16-lane row per point (written for the single-frame call; 512-frame batches gain 3-4 % from it too)
         hipLaunchKernelGGL(k_proj_cands_row, dim3((capQpad + 15) / 16, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gp, cellOff, rec,
                            queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
     else
         hipLaunchKernelGGL(k_proj_cands, dim3((capQpad + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, desc, cap, uRight, gp,
                            cellOff, rec, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
-    // a frame or two per call: the parallel fixed-point kernel first; frames it cannot do (a point with more than 32
+    // the parallel fixed-point kernel first; frames it cannot do (a point with more than 32
     // candidates, no fixed point yet) are left to the sequential one through fallback[] (ORBHIP_PROJ_SEQ=1: sequential only)
     static const int maxRounds = getenv("ORBHIP_PROJ_ROUNDS") ? atoi(getenv("ORBHIP_PROJ_ROUNDS")) : PAR_ROUNDS;   // tests force the hand-over with 1
     int32_t *fallback = nullptr;
     const size_t parLds = proj_assign_par_lds(cap, capQpad);
-    if (B < 8 && !seqOnly && parLds <= 150 * 1024) {
+    if (!seqOnly && parLds <= 150 * 1024) {   // (batches: +2 % on the tracking front-end row of configs.md)
         fallback = (int32_t *)(((uintptr_t)(qfeat + (size_t)B * capQpad) + 255) & ~(uintptr_t)255);
         if (parLds > 32 * 1024)
             (void)hipFuncSetAttribute((const void *)k_proj_assign_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)parLds);
