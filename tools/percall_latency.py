@@ -72,6 +72,14 @@ qf["min_level"], qf["max_level"], qf["flags"] = k0["octave"] - 1, k0["octave"], 
 rows.append(("`Fuse` window search (1000 points into one key frame)", bench(lambda: guided.WindowBest(ex, k1, d1, gp, qf, d0, None, sig), 300),
              bench(lambda: O.window_best(k1, d1, gp, qf, d0, None, sig), 30)))
 
+# LocalMapping::CreateNewMapPoints: SearchForTriangulation of a key-frame pair (FeatureVectors of levelsup 4 -> ~100 nodes)
+F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+sg2 = (sf ** 2).astype(np.float32)
+sk0, sk1 = np.zeros(len(k0), np.uint8), np.zeros(len(k1), np.uint8)
+rows.append(("`SearchForTriangulation` key-frame pair, 1000 x 1000 features",
+             bench(lambda: guided.SearchForTriangulation(ex, k0, d0, sk0, fv[0], k1, d1, sk1, fv[1], F12, 320.0, 240.0, sf, sg2), 300),
+             bench(lambda: O.search_for_triangulation(k0, d0, sk0, fv[0], k1, d1, sk1, fv[1], F12, 320.0, 240.0, sf, sg2), 30)))
+
 # Frame::ComputeStereoMatches on the pyramids the two extractors hold (EuRoC stereo geometry, 1200 features)
 from orbhip.extractor import ComputeStereoMatches
 SL, SR = synth.make_stereo_pair(7, 752, 480, disparity=21)

@@ -589,6 +589,89 @@ __global__ __launch_bounds__(256) void k_tri_match(const orbhip_keypoint *__rest
     const int2 pr = pairs[pi];
     const int a0 = off1[pr.x], a1 = off1[pr.x + 1];
     const int b0 = off2[pr.y], n2 = off2[pr.y + 1] - b0;
+    if (n2 <= 0 || a1 <= a0) return;
+    if (n2 <= 128) {
+        // The usual node: the side-2 features (descriptor, position, octave thresholds) are loaded ONCE into registers, lane p
+        // holding candidates p and p + 64; the side-1 features of the node are loaded 64 at a time, one per lane, and
+        // broadcast; the next side-1 descriptor is requested while the current one is reduced.  (A call for one key-frame
+        // pair was a chain of dependent trips to memory per side-1 feature: ~90 us for ~100 nodes of ten features.)
+        uint32_t R[2][8];
+        float x2[2], y2[2], thr2[2];
+        double lim2[2];
+        bool live[2], st2[2];
+        int I2[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int p = c * 64 + lane;
+            live[c] = p < n2;
+            I2[c] = idx2[b0 + min(p, n2 - 1)];
+            if (skip2[I2[c]]) live[c] = false;
+            st2[c] = ur2 && ur2[I2[c]] >= 0.f;
+            if (P.only_stereo && !st2[c]) live[c] = false;
+            const uint4 r0 = reinterpret_cast<const uint4 *>(desc2 + (size_t)I2[c] * 32)[0];
+            const uint4 r1 = reinterpret_cast<const uint4 *>(desc2 + (size_t)I2[c] * 32)[1];
+            R[c][0] = r0.x; R[c][1] = r0.y; R[c][2] = r0.z; R[c][3] = r0.w;
+            R[c][4] = r1.x; R[c][5] = r1.y; R[c][6] = r1.z; R[c][7] = r1.w;
+            const orbhip_keypoint k2 = kps2[I2[c]];
+            x2[c] = k2.x;
+            y2[c] = k2.y;
+            thr2[c] = __fmul_rn(100.f, scale2[k2.octave]);
+            lim2[c] = __dmul_rn(3.84, (double)sigma2[k2.octave]);
+        }
+        for (int abase = a0; abase < a1; abase += 64) {
+            const int n1c = min(64, a1 - abase);
+            const int myI1 = idx1[abase + min(lane, n1c - 1)];
+            const int mySkip = skip1[myI1];
+            const int mySt1 = (ur1 && ur1[myI1] >= 0.f) ? 1 : 0;
+            const float myX1 = kps1[myI1].x, myY1 = kps1[myI1].y;
+            int i1n = __builtin_amdgcn_readlane(myI1, 0);
+            uint4 q0n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[0];
+            uint4 q1n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[1];
+            for (int k = 0; k < n1c; k++) {
+                const int i1 = i1n;
+                const uint32_t Q[8] = {q0n.x, q0n.y, q0n.z, q0n.w, q1n.x, q1n.y, q1n.z, q1n.w};
+                const int skip = __shfl(mySkip, k);
+                const bool stereo1 = __shfl(mySt1, k) != 0;
+                const float x1 = __shfl(myX1, k), y1 = __shfl(myY1, k);
+                if (k + 1 < n1c) {
+                    i1n = __shfl(myI1, k + 1);
+                    q0n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[0];
+                    q1n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[1];
+                }
+                if (skip) continue;                              // wave-uniform
+                if (P.only_stereo && !stereo1) continue;
+                const float la = __fadd_rn(__fadd_rn(__fmul_rn(x1, P.F[0]), __fmul_rn(y1, P.F[3])), P.F[6]);
+                const float lb = __fadd_rn(__fadd_rn(__fmul_rn(x1, P.F[1]), __fmul_rn(y1, P.F[4])), P.F[7]);
+                const float lc = __fadd_rn(__fadd_rn(__fmul_rn(x1, P.F[2]), __fmul_rn(y1, P.F[5])), P.F[8]);
+                const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+                int key = 0x7FFFFFFF;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    if (!live[c]) continue;
+                    const int d = hamming256(Q, R[c]);
+                    if (d > P.th_low) continue;
+                    if (!stereo1 && !st2[c]) {
+                        const float dx = __fsub_rn(P.ex, x2[c]), dy = __fsub_rn(P.ey, y2[c]);
+                        if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < thr2[c]) continue;
+                    }
+                    const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2[c]), __fmul_rn(lb, y2[c])), lc);
+                    if (den == 0.f) continue;
+                    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                    if (!((double)dsqr < lim2[c])) continue;
+                    key = min(key, (d << 16) | (0xFFFF - (c * 64 + lane)));
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));
+                if (key != 0x7FFFFFFF) {
+                    const int pos = 0xFFFF - (key & 0xFFFF);
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+                        if (pos == c * 64 + lane) match12[i1] = I2[c];
+                }
+            }
+        }
+        return;
+    }
     for (int a = a0; a < a1; a++) {
         const int i1 = idx1[a];
         if (skip1[i1]) continue;   // wave-uniform
