@@ -289,7 +289,7 @@ def main():
     from orbhip import distributed as D
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
-            rc, out0 = D.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+            rc, out0 = D.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=float(os.environ.get("ORBHIP_BENCH_TIMEOUT", "1800")))
             sys.stdout.write(out0)
             sys.stdout.flush()
             raise SystemExit(rc)

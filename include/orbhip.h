@@ -64,9 +64,8 @@ int orbhip_device_count(void);
  * max_w/max_h bound the image size, max_batch the frames per batched call; all device
  * buffers are allocated here, none in the per-frame calls.  Returns NULL on failure
  * (orbhip_last_error(NULL) has the reason).  Limits (ORBHIP_E_SIZE): every pyramid level must hold at least one
- * 30-pixel cell and one quadtree root (the reference divides by zero there); levels up to 4128 x 4128; a level's
- * feature quota up to about 2000 (the quadtree tables of a level live in LDS: e.g. 4000 features over 8 levels is
- * fine, 3500 over 2 levels is not). */
+ * 30-pixel cell and one quadtree root (the reference divides by zero there); levels up to 4128 x 4128; scaleFactor > 1.
+ * There is no bound on a level's feature quota (node tables beyond the LDS move to a device scratch block). */
 orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFactor, int nlevels,
                           int iniThFAST, int minThFAST, int max_w, int max_h, int max_batch);
 void orbhip_destroy(orbhip_ctx *ctx);
@@ -128,8 +127,10 @@ int orbhip_extract_batch_device(orbhip_ctx *ctx, const void *d_imgs, int B, int 
  *                       but is staged by the driver.  The caller must leave the frames alone until the batch's wait returns.
  *                       ORBHIP_E_CAPACITY when `depth` batches are in flight and none was collected.
  *   orbhip_pipe_wait    blocks until the OLDEST outstanding batch is complete and returns pointers into that slot's pinned
- *                       result block: kps[b * cap + i], desc[(b * cap + i) * 32], n_out[b].  They stay valid until `depth`
- *                       further batches have been submitted.
+ *                       result block: kps[b * cap + i], desc[(b * cap + i) * 32], n_out[b].  They stay valid until the
+ *                       NEXT orbhip_pipe_wait (or orbhip_pipe_destroy) on this context, however many batches are submitted
+ *                       in between: the ring has depth + 1 host result blocks, and no submit it admits reuses the block
+ *                       the last wait returned.
  * Results are those of orbhip_extract_batch for the same frames (same kernels, same order). */
 void *orbhip_host_alloc(size_t nbytes);
 void orbhip_host_free(void *p);

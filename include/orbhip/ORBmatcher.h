@@ -14,10 +14,11 @@
 // SearchForTriangulation (LocalMapping::CreateNewMapPoints, src/ORBmatcher.cc:657-827): node-grouped matching with the
 // epipolar tests, one call (orbhip_search_for_triangulation); the epipole is computed here on the host.
 //
-// The other guided-search routines of the reference (SearchByProjection with a Sim3,
-// SearchBySim3, Fuse x2) are pose/projection logic around
-// the same best/second-best primitive; they stay in the reference's own ORBmatcher.cc (SURVEY.md section 8a,
-// row M3) and can call orbhip_hamming_knn2_lists for their inner loops.
+// SearchByProjection(KeyFrame*, Scw, ...), SearchBySim3 and both Fuse forms (LoopClosing / LocalMapping, src/ORBmatcher.cc:
+// 290-403, 825-1100, 1102-1326): the per-point window search runs on the device (orbhip_window_best /
+// orbhip_search_by_projection), the projection arithmetic and the map edits on the host in the reference's order.
+// With these every public method of the reference class has a drop-in (tools/diff_dropin_headers.py compares the
+// declarations with the reference's header when /root/reference is present).
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 

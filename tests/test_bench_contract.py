@@ -85,3 +85,17 @@ def test_bench_brute_match_is_verified_too():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
     assert d["verified_frames"] == 6
+
+
+def test_launch_ranks_ends_the_job_when_a_nonzero_rank_dies_first():
+    """Rank 1 fails at start-up while rank 0 would sit in its rendezvous for a minute: the launcher must report the failure
+    at once and kill rank 0, not wait for rank 0 first."""
+    import time
+    from orbhip import distributed as D
+    prog = "import os,sys,time; r=int(os.environ['RANK']); print('up', flush=True); sys.exit(7) if r else time.sleep(60)"
+    t0 = time.monotonic()
+    rc, out = D.launch_ranks([sys.executable, "-c", prog], 2, timeout=50)
+    assert rc == 7 and out.strip() == "up" and time.monotonic() - t0 < 20
+    # a rank that never finishes: the timeout is reported as 124
+    rc, _ = D.launch_ranks([sys.executable, "-c", "import time; time.sleep(30)"], 2, timeout=1.0)
+    assert rc == 124

@@ -115,7 +115,9 @@ struct OrbPipe {
     int depth = 0, B = 0, w = 0, h = 0, stride = 0, dcap = 0;
     size_t frameBytes = 0, inBytes = 0, outBytes = 0, koff = 0, doff = 0, coff = 0;
     hipStream_t sIn = nullptr, sOut = nullptr;
-    std::vector<uint8_t *> d_in, d_out, h_out;
+    std::vector<uint8_t *> d_in, d_out;         // `depth` device slots
+    std::vector<uint8_t *> h_out;               // depth + 1 page-locked result blocks (batch n -> block n % (depth + 1)): no
+                                                // submit that the ring admits overwrites the block the last wait returned
     std::vector<hipEvent_t> evIn, evK, evOut;
     std::vector<int> slotB;
     long submitted = 0, waited = 0;
@@ -125,7 +127,7 @@ struct OrbPipe {
     float nnratio = 0.7f;
     size_t m12off = 0, m21off = 0, nmoff = 0;   // inside an output slot, behind the counts
     uint8_t *d_bowScratch = nullptr;            // word | weight | node, B * dcap entries each
-    int lastWaited = -1;
+    int lastWaited = -1;                        // host result block of the batch the last orbhip_pipe_wait returned
 };
 
 struct orbhip_ctx {
@@ -195,7 +197,7 @@ struct orbhip_ctx {
     // pinned host staging for the host API
     uint8_t *h_stage = nullptr;
     size_t h_stage_bytes = 0;
-    uint8_t *h_pack = nullptr;        // page-locked twin of d_tmp for the small host-pointer calls (struct Packed, orbhip_api.hip)
+    uint8_t *h_pack = nullptr;        // page-locked twin of d_tmp for the small host-pointer calls (struct Packed, api_common.h)
     size_t h_pack_bytes = 0;
     // the host-pointer call of a frame or two as ONE hipGraph launch (copy in, the twelve kernels, copy out): captured at the
     // first call of a geometry, replayed while (w, h, B, buffers) stay the same
@@ -215,6 +217,8 @@ struct orbhip_ctx {
     bool capturing = false;           // run_pipeline leaves the timing events out of a capture
     unsigned g_calls = 0;
     const void *g_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // d_lvl0, d_kps block, h_in, h_stage, h_pyr (or null) at capture time
+    unsigned long allocGen = 0;       // bumped whenever a device buffer of the context is reallocated (ensure())
+    unsigned long g_gen = 0;          // allocGen at capture time: part of the replay key (the kernel nodes hold d_pyr, d_cand, ...)
 
     // matching scratch
     void *d_match = nullptr;

@@ -196,28 +196,53 @@ def rank_env(rank, world, port, base=None):
     return env
 
 
-def launch_ranks(argv, world, timeout=None, env=None):
+def launch_ranks(argv, world, timeout=None, env=None, local_ranks=None):
     """Start `world` fresh child processes of `argv` (one per GPU), rank r with rank_env(r, ...), and wait for them.
     The caller must not have touched the GPU: a process that has initialised HIP must never be replaced or forked
     into another program on this pool, so the launcher runs BEFORE anything imports torch.cuda state.  Rank 0's
     stdout is returned (its last line is the JSON line); the other ranks' stdout is discarded, stderr is inherited.
-    Returns (max return code, rank-0 stdout)."""
+    All ranks are polled together: the first rank that exits non-zero ends the job at once (the others -- exactly the
+    processes started here -- are killed) instead of leaving rank 0 in the rendezvous until torch's own timeout.
+    `local_ranks` (optional list) overrides LOCAL_RANK per rank, e.g. [0, 0] runs two ranks on device 0.
+    Returns (return code: 0, the first failing rank's, or 124 on timeout; rank-0 stdout)."""
     import subprocess
+    import threading
+    import time
     port = free_port()
     procs = []
     for r in range(world):
-        procs.append(subprocess.Popen(argv, env=rank_env(r, world, port, env),
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = b""
+        e = rank_env(r, world, port, env)
+        if local_ranks is not None:
+            e["LOCAL_RANK"] = str(local_ranks[r])
+        procs.append(subprocess.Popen(argv, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    chunks = []
+
+    def drain():                       # rank 0's pipe must be emptied while it runs, or it blocks on a full pipe
+        for block in iter(lambda: procs[0].stdout.read(65536), b""):
+            chunks.append(block)
+
+    t = threading.Thread(target=drain, daemon=True)
+    t.start()
     rc = 0
+    deadline = None if timeout is None else time.monotonic() + timeout
     try:
-        out0 = procs[0].communicate(timeout=timeout)[0]
-        for p in procs:
-            rc = max(rc, abs(p.wait(timeout=timeout)))
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = abs(bad[0])
+                break
+            if all(c == 0 for c in codes):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                rc = 124
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()          # exactly the processes started here
-    return rc, out0.decode(errors="replace")
+        for p in procs:
+            p.wait()
+        t.join(timeout=10)
+    return rc, b"".join(chunks).decode(errors="replace")

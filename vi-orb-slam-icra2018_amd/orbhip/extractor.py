@@ -130,7 +130,8 @@ class ORBextractor:
 
     def pipe_wait(self, copy=True):
         """Results of the oldest outstanding batch: lists of per-frame keypoints / descriptors (copies), or with
-        copy=False the raw views (kps (B, cap), desc (B, cap, 32), counts (B,)) into the slot's pinned block."""
+        copy=False the raw views (kps (B, cap), desc (B, cap, 32), counts (B,)) into the pinned result block -- valid until
+        the NEXT pipe_wait on this extractor (submits in between do not touch it: include/orbhip.h)."""
         k, d, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
         B, cap = C.c_int(), C.c_int()
         check(self._L.orbhip_pipe_wait(self._h, C.byref(k), C.byref(d), C.byref(n), C.byref(B), C.byref(cap)), self._h,
