@@ -447,6 +447,8 @@ int orbhip_get_stage_times(orbhip_ctx *ctx, float ms[6]);
 int orbhip_comm_unique_id(uint8_t uid[128]);
 int orbhip_comm_init(orbhip_ctx *ctx, int rank, int nranks, const uint8_t uid[128]);
 int orbhip_comm_destroy(orbhip_ctx *ctx);
+/* Rank and size as the communicator reports them (ncclCommUserRank / ncclCommCount); 0 and 1 without a communicator. */
+int orbhip_comm_info(orbhip_ctx *ctx, int *rank, int *nranks);
 /* Broadcast of the ORB vocabulary blob (binary format of
  * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1727-1751, loaded at src/System.cc:331-346)
  * from `root` to every rank over xGMI.  d_buf: device pointer, nbytes on every rank.  Asynchronous on the context

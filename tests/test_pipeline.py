@@ -112,3 +112,39 @@ def test_pipeline_with_bow_matching_stage(oracle):
             prev = (k, d, fv)
     ex.host_free(buf)
     ex.close()
+
+
+def test_results_of_a_wait_survive_the_submits_that_follow(oracle):
+    """include/orbhip.h: the pointers orbhip_pipe_wait returns stay valid until the NEXT wait.  With a full ring (depth 2:
+    submit 0, 1; wait 0) the next submit used to land in the very block the caller was still reading; the ring
+    now has depth + 1 host result blocks."""
+    import time
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    W, H, NF, B, depth = 640, 480, 1000, 4, 2
+    frames = synth.make_frames(95, W, H, 3 * B)
+    ex = ORBextractor(NF, max_w=W, max_h=H, max_batch=B)
+    ex.pipe_create(depth, B, W, H)
+    bufs = [ex.host_frames((B, H, W)) for _ in range(3)]
+    for i, b in enumerate(bufs):
+        b[:] = frames[i * B:(i + 1) * B]
+    ex.pipe_submit(bufs[0])
+    ex.pipe_submit(bufs[1])
+    kps, desc, cnt = ex.pipe_wait(copy=False)                # views into the pinned block of batch 0
+    snap = (kps.copy(), desc.copy(), cnt.copy())
+    ex.pipe_submit(bufs[2])                                  # the ring admits exactly one more batch
+    ex.sync()
+    time.sleep(0.3)                                          # ... and its copy-out has long finished
+    assert np.array_equal(cnt, snap[2]) and kps.tobytes() == snap[0].tobytes() and np.array_equal(desc, snap[1])
+    ref = oracle.Extractor(NF)
+    for b in range(B):
+        rk, rd = ref(frames[b])
+        assert cnt[b] == len(rk) and kps[b, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(desc[b, :len(rk)], rd)
+    for batch in (1, 2):                                     # the later batches are intact too
+        ks, ds = ex.pipe_wait()
+        for b in range(B):
+            rk, rd = ref(frames[batch * B + b])
+            assert _same(ks[b], rk) and np.array_equal(ds[b], rd)
+    for a in bufs:
+        ex.host_free(a)
+    ex.close()

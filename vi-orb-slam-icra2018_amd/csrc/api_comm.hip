@@ -11,6 +11,7 @@ typedef int (*fn_bcast)(const void *, void *, size_t, int, int, void *, hipStrea
 typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_destroy)(void *);
 typedef const char *(*fn_errstr)(int);
+typedef int (*fn_commint)(void *, int *);
 static struct {
     void *h = nullptr;
     bool tried = false, ok = false;
@@ -20,6 +21,7 @@ static struct {
     fn_allgather allgather = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
+    fn_commint count = nullptr, userrank = nullptr;   // optional (orbhip_comm_info)
 } g_rccl;
 static std::mutex g_rccl_mutex;
 
@@ -41,6 +43,8 @@ static bool rccl_load()
     g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather");
     g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
     g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
+    g_rccl.count = (fn_commint)dlsym(g_rccl.h, "ncclCommCount");
+    g_rccl.userrank = (fn_commint)dlsym(g_rccl.h, "ncclCommUserRank");
     g_rccl.ok = g_rccl.getuid && g_rccl.initrank && g_rccl.bcast && g_rccl.allgather && g_rccl.destroy;
     return g_rccl.ok;
 }
@@ -94,6 +98,21 @@ extern "C" int orbhip_comm_destroy(orbhip_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     orb_comm_release(c);
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_comm_info(orbhip_ctx *c, int *rank, int *nranks)
+{
+    if (!c) return ORBHIP_E_ARG;
+    int r = c->rank, n = c->nranks;
+    if (c->comm && g_rccl.count && g_rccl.userrank) {
+        // what the communicator itself reports (ncclCommCount / ncclCommUserRank), not what the caller passed in
+        int rc = g_rccl.count(c->comm, &n);
+        if (rc == 0) rc = g_rccl.userrank(c->comm, &r);
+        if (rc != 0) return fail(c, ORBHIP_E_COMM, rccl_err("ncclCommCount / ncclCommUserRank", rc));
+    }
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
     return ORBHIP_OK;
 }
 

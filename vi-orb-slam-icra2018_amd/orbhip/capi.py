@@ -29,7 +29,7 @@ SYMBOLS = [
     "orbhip_vocab_info", "orbhip_vocab_text_to_binary", "orbhip_vocab_transform", "orbhip_vocab_transform_device",
     "orbhip_search_by_bow_seq_device", "orbhip_stereo_match", "orbhip_stereo_match_device",
     "orbhip_hamming_knn2_lists", "orbhip_search_by_bow", "orbhip_comm_unique_id",
-    "orbhip_comm_init", "orbhip_comm_destroy", "orbhip_bcast_blob_device", "orbhip_knn2_allgather_merge_device",
+    "orbhip_comm_init", "orbhip_comm_destroy", "orbhip_comm_info", "orbhip_bcast_blob_device", "orbhip_knn2_allgather_merge_device",
     "orbhip_knn2_merge_device", "orbhip_grid_build_device", "orbhip_grid_build",
     "orbhip_features_in_area", "orbhip_search_by_projection", "orbhip_search_by_projection_device",
     "orbhip_search_for_initialization", "orbhip_search_for_initialization_device",
@@ -144,6 +144,7 @@ def load():
     L.orbhip_comm_init.argtypes = [vp, i32, i32, vp]
     L.orbhip_bcast_blob_device.argtypes = [vp, vp, C.c_size_t, i32]
     L.orbhip_comm_destroy.argtypes = [vp]
+    L.orbhip_comm_info.argtypes = [vp, ip, ip]
     L.orbhip_knn2_allgather_merge_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_knn2_merge_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     _lib = L
