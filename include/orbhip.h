@@ -435,6 +435,13 @@ int orbhip_remap_device(orbhip_ctx *ctx, const void *d_src, int B, int src_w, in
  * {pyramid, FAST, quadtree, blur, describe} and, at [5], of the last orbhip_hamming_knn2*_device
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */
 int orbhip_get_stage_times(orbhip_ctx *ctx, float ms[6]);
+/* Scheduling of the batched path (affects speed only, never a result): where the Gaussian blur (ref:
+ * src/ORBextractor.cc:1103-1104) runs.  0 (default): on the context's second stream beside the quadtree, so that FAST --
+ * the kernel whose roofline is reported -- owns the device while it runs; 1: one launch from the end of the pyramid, beside
+ * FAST and the quadtree; 2: alone on the main stream between FAST and the quadtree (every kernel owns the device: per-kernel
+ * counters); 3 / 4: level by level beside the resize launches, with / without FAST waiting for the last one (measured:
+ * slower, profiles/r03*).  Also ORBHIP_BLUR_PLACE at context creation. */
+int orbhip_set_blur_placement(orbhip_ctx *ctx, int place);
 
 /* ---- multi-GPU (one process per GPU) ----
  * The reference is a single process (no distributed back end); these entry points are what a

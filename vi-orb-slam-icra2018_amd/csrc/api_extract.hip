@@ -138,6 +138,7 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
     }
     orbhip_ctx *c = new orbhip_ctx();
     c->device = device;
+    if (const char *bp = getenv("ORBHIP_BLUR_PLACE")) c->blurPlace = std::min(4, std::max(0, atoi(bp)));
     c->max_w = max_w;
     c->max_h = max_h;
     c->max_batch = max_batch;
@@ -166,8 +167,16 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
         if ((e = hipEventCreate(&c->evx[i])) != hipSuccess) return bail("hipEventCreate", e);
     for (int i = 0; i < 2; i++)
         if ((e = hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (int i = 0; i < ORBHIP_MAX_LEVELS; i++)
+        if ((e = hipEventCreateWithFlags(&c->evLvl[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (int i = 0; i < 8; i++)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
+    {
+        uint32_t bands[6 * 64 * 4];
+        blur_band_table(bands);
+        if ((e = hipMalloc((void **)&c->d_blurBands, sizeof(bands))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMemcpy(c->d_blurBands, bands, sizeof(bands), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    }
     // size everything for the largest image now, so per-frame calls never allocate
     const int stride0 = (int)align_up((size_t)max_w, 64);
     int rc = orb_configure(c, max_w, max_h, stride0, max_batch);
@@ -191,7 +200,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
-                    c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_chainTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
+                    c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_blurBands, c->d_chainTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -202,6 +211,8 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
         if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     for (int i = 0; i < 2; i++)
         if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
+    for (int i = 0; i < ORBHIP_MAX_LEVELS; i++)
+        if (c->evLvl[i]) (void)hipEventDestroy(c->evLvl[i]);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -274,6 +285,22 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         for (const ChainGroup &grp : c->chainGroups)
             launch_pyramid_chain(s, G, c->chainLevels, grp, c->d_chainTiles, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes,
                                  c->d_resizeTab, B, h_pyr_dst);   // (the host copy of the pyramid is written by the kernel itself)
+    // Batches, blur placement 3 / 4: the blur of level l starts on the second stream as soon as level l exists -- level 0 at
+    // once, level l behind resize launch l -- so it runs beside the (latency-bound, shrinking) resize launches of the higher
+    // levels instead of beside FAST; 3: FAST waits for the last blur launch (every later kernel owns the device), 4: it does not.
+    const bool blurByLevel = B >= 8 && c->blurPlace >= 3 && !chained;
+    auto blur_level = [&](int l) -> int {
+        HIPCHK(c, hipEventRecord(c->evLvl[l], s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evLvl[l], 0));
+        if (l == 0) HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+        launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur, c->lvl0FrameBytes + c->pyrFrameBytes,
+                    c->d_blurTiles + c->blurLevelFirst[l], c->blurLevelFirst[l + 1] - c->blurLevelFirst[l], c->d_blurBands, B);
+        return ORBHIP_OK;
+    };
+    if (blurByLevel) {
+        int rcb = blur_level(0);
+        if (rcb) return rcb;
+    }
     // batches: level l from level l-1 (sequential dependency), all frames per launch
     for (int l = 1; l < G.nlevels && !chained; l++) {
         const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
@@ -284,6 +311,14 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
                       c->pyrFrameBytes, c->d_resizeTab + c->resizeTabOff[l][0],
                       c->d_resizeTab + c->resizeTabOff[l][1],
                       c->resizeGroups[l] ? c->d_resizeTab + c->resizeTabOff[l][2] : nullptr, c->resizeHint[l][B >= 8 ? 0 : 1], B);
+        if (blurByLevel) {
+            int rcb = blur_level(l);
+            if (rcb) return rcb;
+        }
+    }
+    if (blurByLevel) {
+        HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
+        if (c->blurPlace == 3) HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
     }
     if (ev) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // host copy of levels 1.. (orbhip_set_host_pyramid): one copy of the B frames' pyramid block into pinned memory.  A
@@ -301,6 +336,18 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     // streams: both only depend on the pyramid / the FAST output; the describe kernel joins them.
     // batches: runs of up to 5 cells per workgroup; a frame or two: one cell per workgroup (four times the workgroups,
     // each a shorter chain -- the single-frame FAST time is one workgroup's latency)
+    // Where the blur runs in a batch (ORBHIP_BLUR_PLACE): 1 (default) = on the second stream from the END OF THE PYRAMID, i.e.
+    // beside FAST and the quadtree -- since r03 it computes on the matrix pipe and leaves the vector ALU, which FAST
+    // saturates, nearly alone; 0 = beside the quadtree only (r01 / r02); 2 = alone between FAST and the quadtree (measurement).
+    const int blurPlace = blurByLevel ? 3 : c->blurPlace >= 3 ? 1 : c->blurPlace;
+    if (B >= 8 && blurPlace == 1) {
+        HIPCHK(c, hipEventRecord(c->evx[0], s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evx[0], 0));
+        HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+        launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
+        HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
+    }
     if (B >= 8)
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles, c->nFastTilesBatch, c->d_cand,
                     c->d_cellCnt, B);
@@ -309,15 +356,22 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
     if (ev) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (B >= 8) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
-        HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
-        launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
-        HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
+        if (blurPlace == 0) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
+            HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+            launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                        c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
+            HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
+        } else if (blurPlace == 2) {
+            HIPCHK(c, hipEventRecord(c->evx[1], s));
+            launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
+                        c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
+            HIPCHK(c, hipEventRecord(c->evx[2], s));
+        }
         launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
                         c->d_lvlKpCnt, B, c->d_qtTables);
         if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
-        HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
+        if (blurPlace == 0 || blurPlace == 1 || (blurByLevel && c->blurPlace == 4)) HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
     } else {
         // a frame or two: the blur takes a few microseconds, a cross-stream hand-over costs more than it hides
         launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
@@ -325,7 +379,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
         if (ev) HIPCHK(c, hipEventRecord(c->evx[1], s));
         launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), B);
+                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
         if (ev) HIPCHK(c, hipEventRecord(c->evx[2], s));
     }
     if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -344,6 +398,13 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     c->last_stride0 = stride0;
     c->last_frame0 = frame0;
     c->last_B = B;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_set_blur_placement(orbhip_ctx *c, int place)
+{
+    if (!c || place < 0 || place > 4) return fail(c, ORBHIP_E_ARG, "orbhip_set_blur_placement: 0 .. 4");
+    c->blurPlace = place;
     return ORBHIP_OK;
 }
 

@@ -9,23 +9,45 @@
 // float products/sums there are exact below 256, so the float path is evaluated as an integer
 // tie-break rule -- DESIGN.md "blur".
 //
-// One 256-thread workgroup per 128x32 output tile:
-//   1. raw rows y0-3 .. y0+34 (reflected at the top/bottom), columns x0-16 .. x0+143, into LDS with
-//      16-byte row-coalesced loads; at the left/right image edge the 3 reflected columns are
-//      patched into the halo;
-//   2. row pass: v_dot4_u32_u8 on byte windows cut out with v_alignbyte (7 taps = 2 dot4); the sums
-//      are at most 257*255 = 65535 and two vertically adjacent rows share one LDS dword;
-//   3. column pass: 7 taps = 4 v_dot2_u32_u16 on those row pairs, 4 adjacent outputs per thread
-//      (one dword store).  Integer dot instructions on the vector ALU, not MFMA.
-// Bound: HBM (reads and writes one byte per pixel; halo re-reads 38/32 x 160/128).
+// r03: both passes run on the matrix pipe as banded-Toeplitz products (the VALU is what k_fast and k_describe
+// saturate; r02's dot4 / dot2 formulation cost 27 lane-instructions per pixel, this one ~6).  One 256-thread
+// workgroup per 128 x 58 output tile, one wave per 32-column strip:
+//   1. raw rows y0-3 .. y0+60 (reflected at the top / bottom), columns x0-16 .. x0+175, into LDS with 16-byte
+//      row-coalesced loads, every byte xor 0x80 (pixel - 128 as int8); at the left / right image edge the 3
+//      reflected columns are patched into the halo;
+//   2. row pass, v_mfma_i32_32x32x32_i8: H[row][col] = sum_c (p[row][c] - 128) * Kx[c][col] + 128 * 257, A = 32 rows x
+//      32 input columns straight from LDS (ds_read_b128: the 16 consecutive bytes of a lane ARE its 16 k-slots),
+//      B = the band matrix of the taps (a per-lane constant), two k-steps per 32 x 32 tile, two row tiles (64 rows);
+//      the result tile has its column on the lane and 16 rows in the lane's registers;
+//   3. column pass, v_mfma_f32_32x32x16_f16 with the row-pass tile as the A operand in place (no LDS round trip:
+//      the contraction runs over the tile's ROW index, which lives in the registers): the 16-bit sums are split
+//      into byte planes, each byte becomes the binary16 pattern 0x0400 | byte = (1024 + byte) * 2^-24 -- ONE
+//      v_perm per two values, the 0x04 byte rides in the accumulator's start value -- and the band weights are
+//      tap * 2^8, so a product is tap * (1024 + byte) * 2^-16 and the f32 accumulator (started at minus the
+//      constant part) holds EXACTLY sum_j tap_j * byte_j * 2^-16: every partial sum is a multiple of 2^-16 below 8.
+//      Two accumulators (low-byte plane, high-byte plane); result = fma(high, 256, low) = S * 2^-16 exactly, and
+//      v_cvt_pk_u8_f32 is the SSE2 sequence cvtps2dq + packus (round half to even, unsigned saturation) in one
+//      instruction: two vector instructions per output pixel;
+//   4. the 32 x 32 result tiles (output row on the lane, four adjacent columns per register group) go through an
+//      LDS image of the output tile and leave with 16-byte row-coalesced stores.
+// Bound: HBM (reads and writes one byte per pixel; halo re-reads 64/58 x 160/128).
 #include "orbhip_internal.h"
 
-#define BT_W BLUR_TILE_W
-#define BT_H BLUR_TILE_H
-#define BT_RAWP (BT_W + 32)       // raw pitch: 16 halo bytes each side (16-byte aligned chunks)
-#define BT_ROWS (BT_H + 6)       // 38: even, rows are processed in pairs
+#include <cmath>
+#include <vector>
 
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#define BM_W BLUR_TILE_W          // 128 output columns = 4 waves x 32
+#define BM_H BLUR_TILE_H          // 58 output rows
+#define BM_IN 64                  // raw rows (two 32-row tiles of the row pass)
+#define BM_CH 12                  // 16-byte chunks staged per raw row: 16 halo + 128 + 16 halo, + 2 that only round the tile up to
+                                  // 3 x 256 chunks (every thread stages exactly three, no conditional load or store)
+#define BM_PITCH 208              // raw pitch: 52 dwords, so that 16 rows' 16-byte reads fall into distinct bank groups
+#define BM_OP 144                 // pitch of the output image: 36 dwords (32 would put every row's dword store in one bank)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -35,170 +57,206 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// row of a 32x32 MFMA result tile that register i of a lane with l >> 5 == hh holds (cdna_hip_programming.md section 3)
+__host__ __device__ __forceinline__ int tile_row(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+
+// geometry of one tile, everything block-uniform
+struct BlurGeom {
+    const uint8_t *src;
+    uint8_t *dst;
+    int sstride, dstride, w, h, x0, y0;
+};
+
+__device__ __forceinline__ BlurGeom blur_geom(const OrbLevels &G, const BlurTile T, int frame, const uint8_t *lvl0, int stride0,
+                                              unsigned long long frame0, const uint8_t *pyr, unsigned long long pyrFrame,
+                                              uint8_t *blur, unsigned long long blurFrame)
+{
+    BlurGeom g;
+    const int l = T.level;
+    const OrbLevel &L = G.lv[l];
+    g.w = L.w;
+    g.h = L.h;
+    if (l == 0) {
+        g.src = lvl0 + (size_t)frame * frame0;
+        g.sstride = stride0;
+    } else {
+        g.src = pyr + (size_t)frame * pyrFrame + L.imgOff;
+        g.sstride = L.stride;
+    }
+    g.dst = blur + (size_t)frame * blurFrame + (l == 0 ? 0ull : G.boff1 + L.imgOff);
+    g.dstride = l == 0 ? G.bstride0 : L.stride;
+    g.x0 = T.tx * BM_W;
+    g.y0 = T.ty * BM_H;
+    return g;
+}
+
+#define BM_NIT (BM_IN * BM_CH / 256)
+static_assert(BM_NIT * 256 == BM_IN * BM_CH, "every thread stages the same number of chunks");
+
+// the raw tile's 16-byte chunks of this thread, all loads issued back to back: unconditional loads from a clamped address
+// (a conditional load would be waited for before the next one is issued).  A chunk outside the row holds other pixels of
+// the row: columns beyond the three reflected ones (patched below) only reach outputs outside the image.
+__device__ __forceinline__ void blur_fetch(const BlurGeom &g, int tid, uint4 v[BM_NIT])
+{
+    const int wAl = (g.w + 15) & ~15;   // bytes of a row that may be read with 16-byte loads
+#pragma unroll
+    for (int k = 0; k < BM_NIT; k++) {
+        const int i = tid + k * 256;
+        const int r = i / BM_CH, c = i - r * BM_CH;
+        const int sy = reflect101(min(g.y0 - 3 + r, g.h + 2), g.h);
+        const int sx = g.x0 - 16 + (c << 4);
+        v[k] = *reinterpret_cast<const uint4 *>(g.src + (size_t)sy * g.sstride + min(max(sx, 0), wAl - 16));
+    }
+}
+
+// A workgroup takes BM_TPW consecutive tiles of a frame (same level row first: neighbours share their halo columns in L2) and
+// requests tile k + 1's pixels before it computes tile k.
+#define BM_TPW 1
+
 __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                               int stride0, unsigned long long frame0,
                                               const uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
                                               uint8_t *__restrict__ blur, unsigned long long blurFrame,
-                                              const BlurTile *__restrict__ tiles, int4 kq, int xcdMap, int ntiles)
+                                              const BlurTile *__restrict__ tiles, const uint4 *__restrict__ bands, int xcdMap,
+                                              int ntiles)
 {
-    __shared__ __align__(16) uint8_t s_raw[BT_ROWS][BT_RAWP];
-    __shared__ __align__(16) uint32_t s_pair[BT_ROWS / 2][BT_W];
-    const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
-    if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
-    const BlurTile T = tiles[tileId];
-    const int l = T.level;
-    const OrbLevel &L = G.lv[l];
-    const int w = L.w, h = L.h;
-    const uint8_t *src;
-    int sstride;
-    if (l == 0) {
-        src = lvl0 + (size_t)frame * frame0;
-        sstride = stride0;
-    } else {
-        src = pyr + (size_t)frame * pyrFrame + L.imgOff;
-        sstride = L.stride;
-    }
-    uint8_t *dst = blur + (size_t)frame * blurFrame + (l == 0 ? 0ull : G.boff1 + L.imgOff);
-    const int dstride = l == 0 ? G.bstride0 : L.stride;
-    const int x0 = T.tx * BT_W, y0 = T.ty * BT_H;
-    const int tid = threadIdx.x;
+    __shared__ __align__(16) uint8_t s_raw[BM_IN][BM_PITCH];
+    __shared__ __align__(16) uint8_t s_out[64][BM_OP];         // rows 58..63: the unused part of the second result tile
+    const int tile0 = xcd_tile(xcdMap) * BM_TPW, frame = blockIdx.y;
+    if (tile0 >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
+    const int ntl = min(BM_TPW, ntiles - tile0);
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave's strip, as a scalar
 
-    // ---- 1. raw tile: LDS column j <-> image column x0 - 16 + j ----
-    const int wAl = (w + 15) & ~15;   // bytes of a row that may be read with 16-byte loads
-    // both 16-byte loads of a thread are issued before either is stored (unconditional loads from a clamped
-    // address, zeroed afterwards when the chunk lies outside the row: a conditional load would be waited for
-    // before the next one is issued)
-    {
-        constexpr int NCH = BT_RAWP / 16, NIT = (BT_ROWS * NCH + 255) / 256;
-        uint4 v[NIT];
-        bool ok[NIT];
+    BlurGeom g = blur_geom(G, tiles[tile0], frame, lvl0, stride0, frame0, pyr, pyrFrame, blur, blurFrame);
+    uint4 v[BM_NIT];
+    blur_fetch(g, tid, v);
+
+    // the band operands of this lane (built on the host, launch_blur): 2 k-steps of the row pass, 4 of the column pass
+    uint4 bq[6];
 #pragma unroll
-        for (int k = 0; k < NIT; k++) {
-            const int i = min(tid + k * 256, BT_ROWS * NCH - 1);
-            const int r = i / NCH, c = i - r * NCH;
-            const int sy = reflect101(min(y0 - 3 + r, h + 2), h);
-            const int sx = x0 - 16 + (c << 4);
-            ok[k] = sx >= 0 && sx < wAl;
-            v[k] = *reinterpret_cast<const uint4 *>(src + (size_t)sy * sstride + min(max(sx, 0), wAl - 16));
-        }
+    for (int q = 0; q < 6; q++) bq[q] = bands[q * 64 + lane];
+
+    for (int tl = 0; tl < ntl; tl++) {
+        // ---- 1. raw tile: LDS column j <-> image column x0 - 16 + j, bytes xor 0x80 ----
 #pragma unroll
-        for (int k = 0; k < NIT; k++) {
+        for (int k = 0; k < BM_NIT; k++) {
             const int i = tid + k * 256;
-            if (i < BT_ROWS * NCH) {
-                const int r = i / NCH, c = i - r * NCH;
-                *reinterpret_cast<uint4 *>(&s_raw[r][c << 4]) = ok[k] ? v[k] : make_uint4(0, 0, 0, 0);
-            }
+            const int r = i / BM_CH, c = i - r * BM_CH;
+            uint4 o = v[k];
+            o.x ^= 0x80808080u; o.y ^= 0x80808080u; o.z ^= 0x80808080u; o.w ^= 0x80808080u;
+            *reinterpret_cast<uint4 *>(&s_raw[r][c << 4]) = o;
         }
-    }
-    __syncthreads();
-    // reflected halo columns at the image edges (x = -1,-2,-3 <- 1,2,3 ; x = w,w+1,w+2 <- w-2,w-3,w-4)
-    if (x0 == 0) {
-        for (int i = tid; i < BT_ROWS * 3; i += 256) {
-            const int r = i / 3, k = i - r * 3 + 1;
-            s_raw[r][16 - k] = s_raw[r][16 + k];
+        const BlurGeom cur = g;
+        if (tl + 1 < ntl) {   // (block-uniform) the next tile's pixels travel while this one is computed
+            g = blur_geom(G, tiles[tile0 + tl + 1], frame, lvl0, stride0, frame0, pyr, pyrFrame, blur, blurFrame);
+            blur_fetch(g, tid, v);
         }
-    }
-    if (x0 + BT_W + 3 > w) {
-        for (int i = tid; i < BT_ROWS * 3; i += 256) {
-            const int r = i / 3, k = i - r * 3;
-            s_raw[r][16 + (w + k - x0)] = s_raw[r][16 + (w - 2 - k - x0)];
+        __syncthreads();
+        const int w = cur.w, h = cur.h, x0 = cur.x0, y0 = cur.y0;
+        // reflected halo columns at the image edges (x = -1,-2,-3 <- 1,2,3 ; x = w,w+1,w+2 <- w-2,w-3,w-4): block-uniform
+        const bool edgeL = x0 == 0, edgeR = x0 + BM_W + 3 > w;
+        if (edgeL || edgeR) {
+            if (edgeL)
+                for (int i = tid; i < BM_IN * 3; i += 256) {
+                    const int r = i / 3, k = i - r * 3 + 1;
+                    s_raw[r][16 - k] = s_raw[r][16 + k];
+                }
+            if (edgeR)
+                for (int i = tid; i < BM_IN * 3; i += 256) {
+                    const int r = i / 3, k = i - r * 3;
+                    s_raw[r][16 + (w + k - x0)] = s_raw[r][16 + (w - 2 - k - x0)];
+                }
+            __syncthreads();
         }
-    }
-    __syncthreads();
 
-    // ---- 2. row pass with v_dot4_u32_u8: an item = (pair of raw rows, 4 adjacent columns) ----
-    // the two row sums of a column (each <= 257*255 = 65535) are packed into one dword:
-    // s_pair[rp][x] = H[2rp][x] | H[2rp+1][x] << 16, so that the column pass can use v_dot2_u32_u16
-    const uint32_t k0 = kq.x, k1 = kq.y, k2 = kq.z, k3 = kq.w;  // 18 34 49 55
-    const uint32_t wlo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);   // taps -3..0
-    const uint32_t whi = k2 | (k1 << 8) | (k0 << 16);                // taps +1..+3
-    for (int i = tid; i < (BT_ROWS / 2) * (BT_W / 4); i += 256) {
-        const int rp = i >> 5, g = i & 31;
-        uint32_t h[2][4];
+        const int c0 = x0 + 32 * wv;            // first output column of this wave's strip
+        if (c0 < w) {                           // (wave-uniform; a strip right of the image has nothing to store)
+            // ---- 2. row pass: H[T][i] = 16-bit row sum at (row 32 T + tile_row(i, hh), column c0 + n), + 0x04000000 ----
+            v16i hinit;
+            v16f zinit;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(&s_raw[2 * rp + q][16 + (g << 2)]);
-            const uint32_t A = p[-1], Bw = p[0], C = p[1];   // columns x-4..x-1 | x..x+3 | x+4..x+7
-            // pixel k: taps are bytes k+1..k+7 of the 12-byte stream A|B|C
-            h[q][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Bw, A, 1), wlo,
-                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Bw, 1), whi, 0u, false), false);
-            h[q][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Bw, A, 2), wlo,
-                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Bw, 2), whi, 0u, false), false);
-            h[q][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Bw, A, 3), wlo,
-                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Bw, 3), whi, 0u, false), false);
-            h[q][3] = __builtin_amdgcn_udot4(Bw, wlo, __builtin_amdgcn_udot4(C, whi, 0u, false), false);
+            for (int i = 0; i < 16; i++) {
+                hinit[i] = 128 * 257 + 0x04000000;
+                zinit[i] = -(float)(257 * 1024) / 65536.0f;            // minus sum_j tap_j * 1024 * 2^-16
+            }
+            v16i H[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(&s_raw[32 * t + n][32 * wv + 16 * hh]);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(&s_raw[32 * t + n][32 * wv + 32 + 16 * hh]);
+                H[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a0), __builtin_bit_cast(v4i, bq[0]), hinit, 0, 0, 0);
+                H[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a1), __builtin_bit_cast(v4i, bq[1]), H[t], 0, 0, 0);
+            }
+            // ---- 3. column pass ----
+            // byte planes as binary16 pairs: slot j of k-step s of row tile t is register 8 s + j
+            uint4 lo[2][2], hi[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    uint32_t pl[4], ph[4];
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t a = (uint32_t)H[t][8 * s + 2 * d], b = (uint32_t)H[t][8 * s + 2 * d + 1];
+                        pl[d] = __builtin_amdgcn_perm(b, a, 0x07040300u);   // a.b0 | 0x04 << 8 | b.b0 << 16 | 0x04 << 24
+                        ph[d] = __builtin_amdgcn_perm(b, a, 0x07050301u);   // a.b1 | 0x04 << 8 | b.b1 << 16 | 0x04 << 24
+                    }
+                    lo[t][s] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                    hi[t][s] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                }
+            const int wvec = w - (w & 3);
+            const bool tail = wvec < w && c0 <= wvec && wvec < c0 + 32;   // this strip holds the columns of the scalar tail (wave-uniform)
+            const int gT = (wvec - c0) >> 3, hT = ((wvec - c0) >> 2) & 1; // ... in register group gT of the lanes with hh == hT
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                // result tile t: output rows 32 t + n (centre = raw row 32 t + n + 3); tile 0 draws on both row tiles, tile 1 on
+                // row tile 1 only, with the same band operands (the band only depends on raw row - output row)
+                v16f zl = zinit, zh = zinit;
+#pragma unroll
+                for (int q = 0; q < (t == 0 ? 4 : 2); q++) {
+                    const int rt = t == 0 ? (q >> 1) : 1, s = q & 1;
+                    const v8h bw = __builtin_bit_cast(v8h, bq[2 + q]);
+                    zl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo[rt][s]), bw, zl, 0, 0, 0);
+                    zh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, hi[rt][s]), bw, zh, 0, 0, 0);
+                }
+                // lane (output row 32 t + n, hh), register 4 g + e: column c0 + 8 g + 4 hh + e
+#pragma unroll
+                for (int gg = 0; gg < 4; gg++) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        packed = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]), e, packed);   // S * 2^-16, exact
+                    *reinterpret_cast<uint32_t *>(&s_out[32 * t + n][32 * wv + 8 * gg + 4 * hh]) = packed;
+                }
+                if (tail) {
+                    // scalar tail of the reference's column filter, (S + 32768) >> 16 = floor(S * 2^-16 + 0.5): the four columns
+                    // from wvec on are written once more by the lanes that hold them (a real branch: one strip per level row)
+#pragma unroll
+                    for (int gg = 0; gg < 4; gg++)
+                        if (gg == gT) {
+                            asm volatile("" ::: "memory");
+                            uint32_t packed = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                packed = __builtin_amdgcn_cvt_pk_u8_f32(floorf(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]) + 0.5f), e, packed);
+                            if (hh == hT) *reinterpret_cast<uint32_t *>(&s_out[32 * t + n][32 * wv + 8 * gg + 4 * hh]) = packed;
+                        }
+                }
+            }
         }
-        uint4 o;
-        o.x = h[0][0] | (h[1][0] << 16);
-        o.y = h[0][1] | (h[1][1] << 16);
-        o.z = h[0][2] | (h[1][2] << 16);
-        o.w = h[0][3] | (h[1][3] << 16);
-        *reinterpret_cast<uint4 *>(&s_pair[rp][g << 2]) = o;
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- 3. column pass with v_dot2_u32_u16: an item = (two output rows, 4 adjacent columns) ----
-    // Output rows r (even) and r + 1 read the same four row pairs (r,r+1)(r+2,r+3)(r+4,r+5)(r+6,r+7) with the
-    // constant weight pairs (k0,k1)(k2,k3)(k2,k1)(k0,0) and (0,k0)(k1,k2)(k3,k2)(k1,k0): four LDS reads serve
-    // eight outputs and no weight depends on the lane.
-    const int wvec = w - (w & 3);
-    const us2 wa0 = {(unsigned short)k0, (unsigned short)k1}, wa1 = {(unsigned short)k2, (unsigned short)k3};
-    const us2 wa2 = {(unsigned short)k2, (unsigned short)k1}, wa3 = {(unsigned short)k0, 0};
-    const us2 wb0 = {0, (unsigned short)k0}, wb1 = {(unsigned short)k1, (unsigned short)k2};
-    const us2 wb2 = {(unsigned short)k3, (unsigned short)k2}, wb3 = {(unsigned short)k1, (unsigned short)k0};
-    for (int i = tid; i < (BT_H / 2) * (BT_W / 4); i += 256) {
-        const int rp = i >> 5, g = i & 31;
-        const int y = y0 + 2 * rp, xb = x0 + (g << 2);
-        if (y >= h || xb >= w) continue;
-        const uint4 q0 = *reinterpret_cast<const uint4 *>(&s_pair[rp][g << 2]);
-        const uint4 q1 = *reinterpret_cast<const uint4 *>(&s_pair[rp + 1][g << 2]);
-        const uint4 q2 = *reinterpret_cast<const uint4 *>(&s_pair[rp + 2][g << 2]);
-        const uint4 q3 = *reinterpret_cast<const uint4 *>(&s_pair[rp + 3][g << 2]);
-        const uint32_t c0[4] = {q0.x, q0.y, q0.z, q0.w}, c1[4] = {q1.x, q1.y, q1.z, q1.w};
-        const uint32_t c2[4] = {q2.x, q2.y, q2.z, q2.w}, c3[4] = {q3.x, q3.y, q3.z, q3.w};
-        uint32_t sa[4], sb[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wa0, 0u, false);
-            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wa1, sa[k], false);
-            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wa2, sa[k], false);
-            sa[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wa3, sa[k], false);
-            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c0[k]), wb0, 0u, false);
-            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c1[k]), wb1, sb[k], false);
-            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c2[k]), wb2, sb[k], false);
-            sb[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, c3[k]), wb3, sb[k], false);
+        // ---- 4. the output tile leaves with 16-byte stores (rows are padded to 64 bytes: a chunk that starts inside the
+        //         image may run into the padding) ----
+        for (int i = tid; i < BM_H * (BM_W / 16); i += 256) {
+            const int r = i >> 3, c = i & 7;
+            const int y = y0 + r, x = x0 + (c << 4);
+            if (y < h && x < w)
+                *reinterpret_cast<uint4 *>(cur.dst + (size_t)y * cur.dstride + x) = *reinterpret_cast<const uint4 *>(&s_out[r][c << 4]);
         }
-        // SSE2 body (x < wvec): round half to even = (s + 0x7FFF + bit16(s)) >> 16;
-        // scalar tail: round half up = (s + 0x8000) >> 16
-        uint32_t packedA = 0, packedB = 0;
-        if (xb + 3 < wvec) {   // every pixel of the group is in the body (all but the last group of a row)
-            // exactly what the SSE2 body does: the sum as a float (exact below 2^24) times 2^-16, converted with round
-            // half to even and packed with unsigned saturation -- v_cvt_pk_u8_f32 does the last two in one instruction
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                packedA = __builtin_amdgcn_cvt_pk_u8_f32((float)sa[k] * (1.0f / 65536.0f), k, packedA);
-                packedB = __builtin_amdgcn_cvt_pk_u8_f32((float)sb[k] * (1.0f / 65536.0f), k, packedB);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool even = xb + k < wvec;
-                const uint32_t ba = even ? 0x7FFFu + ((sa[k] >> 16) & 1u) : 0x8000u;
-                const uint32_t bb = even ? 0x7FFFu + ((sb[k] >> 16) & 1u) : 0x8000u;
-                packedA |= min((sa[k] + ba) >> 16, 255u) << (8 * k);
-                packedB |= min((sb[k] + bb) >> 16, 255u) << (8 * k);
-            }
-        }
-        uint8_t *o = dst + (size_t)y * dstride + xb;
-        if (xb + 3 < w) {
-            *reinterpret_cast<uint32_t *>(o) = packedA;
-            if (y + 1 < h) *reinterpret_cast<uint32_t *>(o + dstride) = packedB;
-        } else {
-            for (int k = 0; k < 4 && xb + k < w; k++) {
-                o[k] = (uint8_t)(packedA >> (8 * k));
-                if (y + 1 < h) o[dstride + k] = (uint8_t)(packedB >> (8 * k));
-            }
-        }
+        // (the next iteration writes s_raw, which every wave has finished reading before the barrier above, and s_out only
+        // after its own first barrier)
     }
 }
 
@@ -222,14 +280,50 @@ static void gaussian_taps(int k[4])
     }
 }
 
+// binary16 pattern of tap * 256 (tap < 64: exact)
+static uint16_t half_of_tap256(int tap)
+{
+    if (tap == 0) return 0;
+    int e = 0;
+    while ((tap >> (e + 1)) != 0) e++;                // tap = 1.m * 2^e
+    const int exp = e + 8 + 15;                       // value tap * 2^8
+    const int mant = ((tap << (10 - e)) & 0x3FF);
+    return (uint16_t)((exp << 10) | mant);
+}
+
+// The band operands, per lane (n = lane & 31, hh = lane >> 5), 16 bytes each: [q][lane], q = 0, 1: k-steps of the row pass
+// (int8 taps; slot j of k-step s is input column c0 - 16 + 32 s + 16 hh + j, output column c0 + n); q = 2..5: k-steps of
+// the column pass (binary16 tap * 2^8; slot j of k-step (rt, s) is raw row 32 rt + tile_row(8 s + j, hh), output row n).
+void blur_band_table(uint32_t out[6 * 64 * 4])
+{
+    int k4[4];
+    gaussian_taps(k4);
+    const int tap[7] = {k4[0], k4[1], k4[2], k4[3], k4[2], k4[1], k4[0]};
+    uint8_t *p = reinterpret_cast<uint8_t *>(out);
+    for (int lane = 0; lane < 64; lane++) {
+        const int n = lane & 31, hh = lane >> 5;
+        for (int s = 0; s < 2; s++)
+            for (int j = 0; j < 16; j++) {
+                const int t = (-16 + 32 * s + 16 * hh + j) - n + 3;
+                p[((size_t)s * 64 + lane) * 16 + j] = (uint8_t)((t >= 0 && t < 7) ? tap[t] : 0);
+            }
+        for (int q = 0; q < 4; q++)
+            for (int j = 0; j < 8; j++) {
+                const int rt = q >> 1, s = q & 1;
+                const int t = 32 * rt + tile_row(8 * s + j, hh) - n;
+                const uint16_t hv = (t >= 0 && t < 7) ? half_of_tap256(tap[t]) : 0;
+                p[((size_t)(2 + q) * 64 + lane) * 16 + 2 * j] = (uint8_t)(hv & 0xFF);
+                p[((size_t)(2 + q) * 64 + lane) * 16 + 2 * j + 1] = (uint8_t)(hv >> 8);
+            }
+    }
+}
+
 void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, uint8_t *blur, size_t blurFrame,
-                 const BlurTile *tiles, int ntiles, int B)
+                 const BlurTile *tiles, int ntiles, const uint32_t *bands, int B)
 {
-    int k[4];
-    gaussian_taps(k);
-    dim3 grid(orb_xcd_grid(ntiles, 2), B, 1), block(256, 1, 1);
+    dim3 grid(orb_xcd_grid((ntiles + BM_TPW - 1) / BM_TPW, 2), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_blur, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, tiles,
-                       make_int4(k[0], k[1], k[2], k[3]), orb_xcd_arg(2), ntiles);
+                       reinterpret_cast<const uint4 *>(bands), orb_xcd_arg(2), ntiles);
 }

@@ -227,6 +227,7 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
                 t.ncells = 1;
                 single.push_back(t);
             }
+        c->blurLevelFirst[l] = (int)c->blurTiles.size();
         for (int ty = 0; ty < (L.h + BLUR_TILE_H - 1) / BLUR_TILE_H; ty++)
             for (int tx = 0; tx < (L.w + BLUR_TILE_W - 1) / BLUR_TILE_W; tx++) {
                 BlurTile t;
@@ -237,6 +238,7 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
                 c->blurTiles.push_back(t);
             }
     }
+    c->blurLevelFirst[G.nlevels] = (int)c->blurTiles.size();
     c->nFastTilesBatch = (int)c->fastTiles.size();
     c->fastTiles.insert(c->fastTiles.end(), single.begin(), single.end());   // [batch list | single-frame list]
     G.totalCells = cellBase;

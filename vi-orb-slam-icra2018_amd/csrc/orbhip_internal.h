@@ -62,9 +62,10 @@ struct FastTile {
     short level, row, c0, ncells;
 };
 
-// One blur workgroup's work: BLUR_TILE_W x BLUR_TILE_H output tile.
+// One blur workgroup's work: BLUR_TILE_W x BLUR_TILE_H output tile (k_blur.hip: 64 raw rows = two 32-row MFMA tiles -> 58
+// output rows; four waves of 32 columns).
 #define BLUR_TILE_W 128
-#define BLUR_TILE_H 32
+#define BLUR_TILE_H 58
 struct BlurTile {
     short level, tx, ty, pad;
 };
@@ -134,7 +135,9 @@ struct orbhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // blur runs here, concurrently with the quadtree kernel
-    hipEvent_t evx[3] = {nullptr, nullptr, nullptr};   // FAST done | blur start | blur end
+    hipEvent_t evx[3] = {nullptr, nullptr, nullptr};   // pyramid done (cross-stream hand-over) | blur start | blur end
+    int blurPlace = 0;               // where the blur runs in a batch (orbhip_set_blur_placement, include/orbhip.h)
+    hipEvent_t evLvl[ORBHIP_MAX_LEVELS] = {};   // level l of the pyramid is built (the blur of that level may start)
     std::string err;
 
     // constructor tables (E0)
@@ -152,7 +155,8 @@ struct orbhip_ctx {
     OrbLevels G;
     std::vector<FastTile> fastTiles;              // runs of up to 5 cells (batches), then runs of 1 cell (a frame or two)
     int nFastTilesBatch = 0;
-    std::vector<BlurTile> blurTiles;
+    std::vector<BlurTile> blurTiles;              // level by level
+    int blurLevelFirst[ORBHIP_MAX_LEVELS + 1] = {};   // first tile of every level (and the end)
     std::vector<ChainTile> chainTiles;            // chained pyramid of the single-frame path (empty = not available)
     std::vector<ChainGroup> chainGroups;
     ChainLevels chainLevels;
@@ -180,6 +184,7 @@ struct orbhip_ctx {
     int32_t *d_counts = nullptr;   //                                          [B]
     FastTile *d_fastTiles = nullptr;
     BlurTile *d_blurTiles = nullptr;
+    uint32_t *d_blurBands = nullptr;   // 6 x 64 x 16 bytes: the MFMA band operands of k_blur (blur_band_table)
     int32_t *d_resizeTab = nullptr; // per level: x table [dw] int2, y table [dh] int4
     size_t resizeTabOff[ORBHIP_MAX_LEVELS][3];   // column taps, row taps, 4-pixel groups (k_pyramid.hip)
     bool resizeGroups[ORBHIP_MAX_LEVELS] = {};
@@ -279,7 +284,8 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
 size_t quadtree_table_scratch_bytes(const OrbLevels &G, int B);   // 0 when the node tables fit in LDS
 void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, uint8_t *blur, size_t blurFrame,
-                 const BlurTile *tiles, int ntiles, int B);
+                 const BlurTile *tiles, int ntiles, const uint32_t *bands, int B);
+void blur_band_table(uint32_t out[6 * 64 * 4]);   // per-lane band operands of k_blur's two matrix products
 void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                      const uint8_t *pyr, size_t pyrFrame, const uint8_t *blur, size_t blurFrame,
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
