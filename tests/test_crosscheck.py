@@ -20,6 +20,13 @@ def test_numpy_rows_with_the_test_interpreter(oracle):
     r = _run(sys.executable)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fastAtan2" in r.stdout and "MISMATCH" not in r.stdout
+    # round 3: remap / undistortPoints / initUndistortRectifyMap against scipy (the test interpreter has it)
+    out = r.stdout
+    assert out.count("remap INTER_LINEAR, BORDER_CONSTANT (orbo_remap_linear_u8)") == 2 and "mode=grid-constant" in out
+    assert "five fixed-point iterations" in out and "within 150 px of the principal point" in out
+    assert "initUndistortRectifyMap (orbo_init_undistort_rectify_map)" in out
+    rows = [l for l in out.splitlines() if l.startswith("| remap") or l.startswith("| undistortPoints") or l.startswith("| initUndistort")]
+    assert len(rows) == 6 and all(l.rstrip().endswith("| ok |") for l in rows)
 
 
 @pytest.mark.skipif(not os.path.exists(CONDA), reason="no /opt/conda/bin/python3.9 (scikit-image) on this box")

@@ -179,6 +179,106 @@ def oracle_pattern():
 
 
 # ------------------------------------------------------------------------------------------------
+EUROC_K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]], np.float64)       # Examples/Stereo/EuRoC.yaml LEFT.*
+EUROC_D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0], np.float64)
+EUROC_R = np.array([0.999966347530033, -0.001422739138722922, 0.008079580483432283, 0.001365741834644127, 0.9999741760894847,
+                    0.007055629199258132, -0.008089410156878961, -0.007044357138835809, 0.9999424675829176], np.float64).reshape(3, 3)
+EUROC_P = np.array([[435.2046959714599, 0, 367.4517211914062], [0, 435.2046959714599, 252.2008514404297], [0, 0, 1]], np.float64)
+
+
+def distort_forward(xn, yn, D):
+    """The radial-tangential (plumb-bob) camera model, forward direction, float64: normalised ideal -> normalised distorted."""
+    k1, k2, p1, p2, k3 = D[:5]
+    r2 = xn * xn + yn * yn
+    rad = 1 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    return (xn * rad + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn), yn * rad + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn)
+
+
+def check_scipy_geometry():
+    """remap / undistortPoints / initUndistortRectifyMap (src/Frame.cc:748-778, Examples/Stereo/stereo_euroc.cc:96-98,
+    136-137) against scipy: the two OpenCV kernels of the path that had no independent check in round 2."""
+    import scipy
+    from scipy.ndimage import map_coordinates
+    from scipy.optimize import fsolve
+    ver = "scipy %s" % scipy.__version__
+
+    # 1. remap INTER_LINEAR, BORDER_CONSTANT 0.  OpenCV rounds the map to 1/32 pixel (cvRound(m * 32)) and interpolates with
+    #    a 15-bit weight table; an independent float64 bilinear interpolation AT THOSE 1/32-pixel positions must agree to the
+    #    final rounding (1 level).  The second row is the same comparison at the unrounded positions (information: the
+    #    1/32-pixel grid moves a sample by up to 1/64 pixel per axis, worth |gradient| / 64 levels).
+    for name, img in fixture_images()[:2]:
+        h, w = img.shape
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        mx = (xx * 0.97 + 3.3 + 2.0 * np.sin(yy / 37.0)).astype(np.float32)       # smooth warp with sub-pixel phases, partly
+        my = (yy * 1.02 - 2.6 + 1.5 * np.cos(xx / 29.0)).astype(np.float32)       # outside the image (constant border)
+        mine = oracle.remap_linear(img, mx, my).astype(np.float64)
+        qx = np.rint(mx.astype(np.float32) * np.float32(32)).astype(np.float64) / 32.0       # float product, half to even
+        qy = np.rint(my.astype(np.float32) * np.float32(32)).astype(np.float64) / 32.0
+        theirs_q = map_coordinates(img.astype(np.float64), [qy, qx], order=1, mode="grid-constant", cval=0.0)
+        theirs = map_coordinates(img.astype(np.float64), [my.astype(np.float64), mx.astype(np.float64)], order=1, mode="grid-constant", cval=0.0)
+        dq = float(np.abs(mine - theirs_q).max())
+        d = float(np.abs(mine - theirs).max())
+        row("remap INTER_LINEAR, BORDER_CONSTANT (orbo_remap_linear_u8) %s" % name,
+            ver + " ndimage.map_coordinates(order=1, mode=grid-constant, cval 0) at the 1/32-pixel positions", "tolerance 1 level",
+            "max |diff| = %.4f (at the unrounded positions: %.3f)" % (dq, d), dq <= 1.0)
+
+    # 2. undistortPoints.  OpenCV 2.4 (cvUndistortPoints) runs FIVE fixed-point iterations x <- (x0 - tangential(x)) / radial(x)
+    #    and stops; with the EuRoC lens (k1 = -0.28) that is converged in the middle of the image and not at its corners.  Two
+    #    independent answers: (a) the same published scheme written in numpy float64 -- pins the oracle's arithmetic; (b) the
+    #    true inverse of the forward model from a float64 Newton-type solver -- pins the model, the coefficient order and the
+    #    direction, to the accuracy five iterations reach.
+    rng = np.random.default_rng(8)
+    pts = np.stack([rng.uniform(0, 752, 600), rng.uniform(0, 480, 600)], 1).astype(np.float32)
+    K32, D32 = EUROC_K.astype(np.float32), EUROC_D[:4].astype(np.float32)
+    mine = oracle.undistort_points(pts, K32, D32, K32).astype(np.float64)
+    Kd, Dd = K32.astype(np.float64), np.concatenate([D32.astype(np.float64), [0.0]])
+    x0 = (pts[:, 0].astype(np.float64) - Kd[0, 2]) / Kd[0, 0]
+    y0 = (pts[:, 1].astype(np.float64) - Kd[1, 2]) / Kd[1, 1]
+    x, y = x0.copy(), y0.copy()
+    k1, k2, p1, p2, k3 = Dd
+    for _ in range(5):
+        r2 = x * x + y * y
+        icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x, y = (x0 - dx) * icdist, (y0 - dy) * icdist
+    five = np.stack([x * Kd[0, 0] + Kd[0, 2], y * Kd[1, 1] + Kd[1, 2]], 1)
+    d5 = float(np.abs(five - mine).max())
+    row("undistortPoints (orbo_undistort_points), EuRoC cam0, 600 points over the image", "numpy float64: the published scheme, five "
+        "fixed-point iterations", "tolerance 1e-4 px (float32 output at |x| < 800 resolves 6e-5)", "max |diff| = %.6f px" % d5,
+        d5 <= 1e-4)
+    true = np.empty_like(mine)
+    for i in range(len(pts)):
+        sol = fsolve(lambda z: [distort_forward(z[0], z[1], Dd)[0] - x0[i], distort_forward(z[0], z[1], Dd)[1] - y0[i]],
+                     [x0[i], y0[i]], xtol=1e-14)
+        true[i] = (sol[0] * Kd[0, 0] + Kd[0, 2], sol[1] * Kd[1, 1] + Kd[1, 2])
+    err = np.abs(true - mine).max(1)
+    rad = np.hypot(pts[:, 0] - Kd[0, 2], pts[:, 1] - Kd[1, 2])
+    near = rad < 150
+    row("undistortPoints, points within 150 px of the principal point (%d)" % int(near.sum()), ver + " optimize.fsolve on the forward "
+        "radial-tangential model (float64)", "tolerance 1e-4 px (five iterations have converged there)",
+        "max |diff| = %.6f px" % float(err[near].max()), float(err[near].max()) <= 1e-4)
+    row("undistortPoints, all 600 points (information: what five iterations leave at the corners)", ver + " optimize.fsolve",
+        "recorded, not a bar: the reference's OpenCV stops after five iterations too", "max |diff| = %.4f px at radius %.0f px; "
+        "median %.6f px" % (float(err.max()), float(rad[np.argmax(err)]), float(np.median(err))), True)
+
+    # 3. initUndistortRectifyMap: the closed-form forward model, float64: map(u, v) = K * distort(R^-1 * P^-1 * (u, v, 1))
+    w, h = 752, 480
+    mx, my = oracle.init_undistort_rectify_map(EUROC_K, EUROC_D, EUROC_R, EUROC_P, w, h)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    iR = np.linalg.inv(EUROC_P @ EUROC_R)
+    X = iR[0, 0] * xx + iR[0, 1] * yy + iR[0, 2]
+    Y = iR[1, 0] * xx + iR[1, 1] * yy + iR[1, 2]
+    Wz = iR[2, 0] * xx + iR[2, 1] * yy + iR[2, 2]
+    xd, yd = distort_forward(X / Wz, Y / Wz, EUROC_D)
+    tx, ty = xd * EUROC_K[0, 0] + EUROC_K[0, 2], yd * EUROC_K[1, 1] + EUROC_K[1, 2]
+    d = float(max(np.abs(mx - tx).max(), np.abs(my - ty).max()))
+    row("initUndistortRectifyMap (orbo_init_undistort_rectify_map), EuRoC left camera, 752 x 480", "numpy float64 closed form: "
+        "K * distort(inv(P * R) * (u, v, 1))", "tolerance 1e-3 px (float32 maps, OpenCV's per-row running sums)",
+        "max |diff| = %.6f px" % d, d <= 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
 def check_cv2():
     import cv2
     ver = "cv2 %s" % cv2.__version__
@@ -242,6 +342,12 @@ def main():
     except ImportError:
         row("cv2", "-", "-", "not importable under %s: the OpenCV rows (resize / FAST responses / GaussianBlur / remap / "
             "undistortPoints bit for bit) cannot be produced on this image" % sys.executable, True)
+    try:
+        import scipy  # noqa: F401
+        have.append("scipy")
+        check_scipy_geometry()
+    except ImportError:
+        row("scipy", "-", "-", "not importable under %s" % sys.executable, True)
     try:
         import skimage  # noqa: F401
         have.append("skimage")
