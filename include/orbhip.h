@@ -436,11 +436,11 @@ int orbhip_remap_device(orbhip_ctx *ctx, const void *d_src, int B, int src_w, in
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */
 int orbhip_get_stage_times(orbhip_ctx *ctx, float ms[6]);
 /* Scheduling of the batched path (affects speed only, never a result): where the Gaussian blur (ref:
- * src/ORBextractor.cc:1103-1104) runs.  0 (default): on the context's second stream beside the quadtree, so that FAST --
- * the kernel whose roofline is reported -- owns the device while it runs; 1: one launch from the end of the pyramid, beside
- * FAST and the quadtree; 2: alone on the main stream between FAST and the quadtree (every kernel owns the device: per-kernel
- * counters); 3 / 4: level by level beside the resize launches, with / without FAST waiting for the last one (measured:
- * slower, profiles/r03*).  Also ORBHIP_BLUR_PLACE at context creation. */
+ * src/ORBextractor.cc:1103-1104) runs.  0 (default): on the context's second stream behind FAST -- FAST, the kernel whose
+ * roofline is reported, owns the device while it runs; the quadtree is cut into two half-batches, the first beside the blur,
+ * the second beside the describe kernel of the first half; 1: one launch from the end of the pyramid, beside FAST and the
+ * quadtree; 2: alone on the main stream between FAST and the quadtree (every kernel owns the device: per-kernel counters).
+ * Also ORBHIP_BLUR_PLACE at context creation. */
 int orbhip_set_blur_placement(orbhip_ctx *ctx, int place);
 
 /* ---- multi-GPU (one process per GPU) ----

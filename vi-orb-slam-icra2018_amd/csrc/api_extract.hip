@@ -138,7 +138,7 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
     }
     orbhip_ctx *c = new orbhip_ctx();
     c->device = device;
-    if (const char *bp = getenv("ORBHIP_BLUR_PLACE")) c->blurPlace = std::min(4, std::max(0, atoi(bp)));
+    if (const char *bp = getenv("ORBHIP_BLUR_PLACE")) c->blurPlace = std::min(2, std::max(0, atoi(bp)));
     c->max_w = max_w;
     c->max_h = max_h;
     c->max_batch = max_batch;
@@ -167,8 +167,6 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
         if ((e = hipEventCreate(&c->evx[i])) != hipSuccess) return bail("hipEventCreate", e);
     for (int i = 0; i < 2; i++)
         if ((e = hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    for (int i = 0; i < ORBHIP_MAX_LEVELS; i++)
-        if ((e = hipEventCreateWithFlags(&c->evLvl[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (int i = 0; i < 8; i++)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
     {
@@ -211,8 +209,6 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
         if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     for (int i = 0; i < 2; i++)
         if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
-    for (int i = 0; i < ORBHIP_MAX_LEVELS; i++)
-        if (c->evLvl[i]) (void)hipEventDestroy(c->evLvl[i]);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -285,22 +281,6 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         for (const ChainGroup &grp : c->chainGroups)
             launch_pyramid_chain(s, G, c->chainLevels, grp, c->d_chainTiles, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes,
                                  c->d_resizeTab, B, h_pyr_dst);   // (the host copy of the pyramid is written by the kernel itself)
-    // Batches, blur placement 3 / 4: the blur of level l starts on the second stream as soon as level l exists -- level 0 at
-    // once, level l behind resize launch l -- so it runs beside the (latency-bound, shrinking) resize launches of the higher
-    // levels instead of beside FAST; 3: FAST waits for the last blur launch (every later kernel owns the device), 4: it does not.
-    const bool blurByLevel = B >= 8 && c->blurPlace >= 3 && !chained;
-    auto blur_level = [&](int l) -> int {
-        HIPCHK(c, hipEventRecord(c->evLvl[l], s));
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evLvl[l], 0));
-        if (l == 0) HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
-        launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur, c->lvl0FrameBytes + c->pyrFrameBytes,
-                    c->d_blurTiles + c->blurLevelFirst[l], c->blurLevelFirst[l + 1] - c->blurLevelFirst[l], c->d_blurBands, B);
-        return ORBHIP_OK;
-    };
-    if (blurByLevel) {
-        int rcb = blur_level(0);
-        if (rcb) return rcb;
-    }
     // batches: level l from level l-1 (sequential dependency), all frames per launch
     for (int l = 1; l < G.nlevels && !chained; l++) {
         const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
@@ -311,14 +291,6 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
                       c->pyrFrameBytes, c->d_resizeTab + c->resizeTabOff[l][0],
                       c->d_resizeTab + c->resizeTabOff[l][1],
                       c->resizeGroups[l] ? c->d_resizeTab + c->resizeTabOff[l][2] : nullptr, c->resizeHint[l][B >= 8 ? 0 : 1], B);
-        if (blurByLevel) {
-            int rcb = blur_level(l);
-            if (rcb) return rcb;
-        }
-    }
-    if (blurByLevel) {
-        HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
-        if (c->blurPlace == 3) HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
     }
     if (ev) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // host copy of levels 1.. (orbhip_set_host_pyramid): one copy of the B frames' pyramid block into pinned memory.  A
@@ -331,21 +303,41 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         HIPCHK(c, hipMemcpyAsync(h_pyr_dst, c->d_pyr, (size_t)B * c->pyrFrameBytes, hipMemcpyDeviceToHost, c->stream2));
         HIPCHK(c, hipEventRecord(c->evp[1], c->stream2));
     }
-    // E3 FAST alone on the device (it is the kernel whose roofline is reported), then the quadtree
-    // (latency-bound, a few thousand workgroups) and the blur (streaming) run CONCURRENTLY on two
-    // streams: both only depend on the pyramid / the FAST output; the describe kernel joins them.
-    // batches: runs of up to 5 cells per workgroup; a frame or two: one cell per workgroup (four times the workgroups,
-    // each a shorter chain -- the single-frame FAST time is one workgroup's latency)
-    // Where the blur runs in a batch (ORBHIP_BLUR_PLACE): 1 (default) = on the second stream from the END OF THE PYRAMID, i.e.
-    // beside FAST and the quadtree -- since r03 it computes on the matrix pipe and leaves the vector ALU, which FAST
-    // saturates, nearly alone; 0 = beside the quadtree only (r01 / r02); 2 = alone between FAST and the quadtree (measurement).
-    const int blurPlace = blurByLevel ? 3 : c->blurPlace >= 3 ? 1 : c->blurPlace;
+    // E3 FAST, E4 quadtree, E6 blur, E5 + E7 describe.  FAST runs ALONE on the device (it is the kernel whose roofline is
+    // reported).  Batches, default schedule (blur placement 0): the quadtree is a latency-bound kernel of few long workgroups,
+    // so it is cut in two half-batches that hide behind kernels which do not depend on them -- the first half beside the blur
+    // (second stream), the second half beside the describe kernel of the FIRST half:
+    //     main stream  : FAST(all) | quadtree(A) | describe(A)            | describe(B)
+    //     second stream:           | blur(all)   | quadtree(B)            |
+    // Other placements of the blur (orbhip_set_blur_placement): 1 = one launch from the end of the pyramid, beside FAST and
+    // the quadtree; 2 = alone on the main stream between FAST and the quadtree (every kernel owns the device: counters).
+    // A frame or two: one cell per FAST workgroup (four times the workgroups, each a shorter chain -- the single-frame FAST
+    // time is one workgroup's latency), everything on one stream (a cross-stream hand-over costs more than it hides).
+    const int blurPlace = c->blurPlace;
+    const size_t blurFrame = c->lvl0FrameBytes + c->pyrFrameBytes;
+    auto blur_all = [&](hipStream_t st) {
+        launch_blur(st, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur, blurFrame, c->d_blurTiles,
+                    (int)c->blurTiles.size(), c->d_blurBands, B);
+    };
+    // quadtree / describe of the frames [b0, b0 + nb)
+    const size_t qtPerFrame = B > 0 ? quadtree_table_scratch_bytes(G, 1) : 0;
+    auto quadtree_part = [&](hipStream_t st, int b0, int nb) {
+        launch_quadtree(st, G, c->d_cand + (size_t)b0 * G.totalCands, c->d_cellCnt + (size_t)b0 * G.totalCells,
+                        c->d_pts + (size_t)b0 * G.totalPts, c->d_pnode + (size_t)b0 * G.totalPts,
+                        c->d_lvlCandCnt + (size_t)b0 * ORBHIP_MAX_LEVELS, c->d_lvlKp + (size_t)b0 * G.totalKps,
+                        c->d_lvlKpCnt + (size_t)b0 * ORBHIP_MAX_LEVELS, nb, c->d_qtTables ? c->d_qtTables + (size_t)b0 * qtPerFrame : nullptr);
+    };
+    auto describe_part = [&](hipStream_t st, int b0, int nb) {
+        launch_describe(st, G, lvl0 + (size_t)b0 * frame0, stride0, frame0, c->d_pyr + (size_t)b0 * c->pyrFrameBytes, c->pyrFrameBytes,
+                        c->d_blur + (size_t)b0 * blurFrame, blurFrame, c->d_lvlKp + (size_t)b0 * G.totalKps,
+                        c->d_lvlKpCnt + (size_t)b0 * ORBHIP_MAX_LEVELS, c->d_lvlAngle + (size_t)b0 * G.totalKps, d_kps + (size_t)b0 * cap,
+                        d_desc + (size_t)b0 * cap * 32, d_counts + b0, cap, nb);
+    };
     if (B >= 8 && blurPlace == 1) {
         HIPCHK(c, hipEventRecord(c->evx[0], s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evx[0], 0));
         HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
-        launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
+        blur_all(c->stream2);
         HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
     }
     if (B >= 8)
@@ -355,38 +347,49 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
     if (ev) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (B >= 8) {
+    static const bool noSplit = getenv("ORBHIP_NO_SPLIT") && atoi(getenv("ORBHIP_NO_SPLIT")) != 0;   // A/B: r02 schedule
+    if (B >= 16 && blurPlace == 0 && !noSplit) {
+        const int nA = B / 2, nB = B - nA;
+        if (!ev) HIPCHK(c, hipEventRecord(c->ev[2], s));       // (the hand-over event; the timing path has recorded it)
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
+        HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+        blur_all(c->stream2);
+        HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
+        quadtree_part(c->stream2, nA, nB);                      // behind the blur, i.e. beside describe(A)
+        HIPCHK(c, hipEventRecord(c->evx[0], c->stream2));
+        quadtree_part(s, 0, nA);
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
+        HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));         // the blur is done
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
+        describe_part(s, 0, nA);
+        HIPCHK(c, hipStreamWaitEvent(s, c->evx[0], 0));         // quadtree(B) is done
+        describe_part(s, nA, nB);
+    } else if (B >= 8) {
         if (blurPlace == 0) {
+            if (!ev) HIPCHK(c, hipEventRecord(c->ev[2], s));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
             HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
-            launch_blur(c->stream2, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                        c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
+            blur_all(c->stream2);
             HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
         } else if (blurPlace == 2) {
             HIPCHK(c, hipEventRecord(c->evx[1], s));
-            launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                        c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
+            blur_all(s);
             HIPCHK(c, hipEventRecord(c->evx[2], s));
         }
-        launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
-                        c->d_lvlKpCnt, B, c->d_qtTables);
+        quadtree_part(s, 0, B);
         if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
-        if (blurPlace == 0 || blurPlace == 1 || (blurByLevel && c->blurPlace == 4)) HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
+        if (blurPlace == 0 || blurPlace == 1) HIPCHK(c, hipStreamWaitEvent(s, c->evx[2], 0));
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
+        describe_part(s, 0, B);
     } else {
-        // a frame or two: the blur takes a few microseconds, a cross-stream hand-over costs more than it hides
-        launch_quadtree(s, G, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode, c->d_lvlCandCnt, c->d_lvlKp,
-                        c->d_lvlKpCnt, B, c->d_qtTables);
+        quadtree_part(s, 0, B);
         if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
         if (ev) HIPCHK(c, hipEventRecord(c->evx[1], s));
-        launch_blur(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, B);
+        blur_all(s);
         if (ev) HIPCHK(c, hipEventRecord(c->evx[2], s));
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
+        describe_part(s, 0, B);
     }
-    if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
-    // E5+E7+E8 describe
-    launch_describe(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur,
-                    c->lvl0FrameBytes + c->pyrFrameBytes, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, d_kps,
-                    d_desc, d_counts, cap, B);
     if (ev) HIPCHK(c, hipEventRecord(c->ev[5], s));
     if (pyrFork)
         HIPCHK(c, hipStreamWaitEvent(s, c->evp[1], 0));
@@ -403,7 +406,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
 
 extern "C" int orbhip_set_blur_placement(orbhip_ctx *c, int place)
 {
-    if (!c || place < 0 || place > 4) return fail(c, ORBHIP_E_ARG, "orbhip_set_blur_placement: 0 .. 4");
+    if (!c || place < 0 || place > 2) return fail(c, ORBHIP_E_ARG, "orbhip_set_blur_placement: 0, 1 or 2");
     c->blurPlace = place;
     return ORBHIP_OK;
 }

@@ -137,7 +137,6 @@ struct orbhip_ctx {
     hipStream_t stream2 = nullptr;   // blur runs here, concurrently with the quadtree kernel
     hipEvent_t evx[3] = {nullptr, nullptr, nullptr};   // pyramid done (cross-stream hand-over) | blur start | blur end
     int blurPlace = 0;               // where the blur runs in a batch (orbhip_set_blur_placement, include/orbhip.h)
-    hipEvent_t evLvl[ORBHIP_MAX_LEVELS] = {};   // level l of the pyramid is built (the blur of that level may start)
     std::string err;
 
     // constructor tables (E0)
