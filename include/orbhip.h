@@ -443,6 +443,28 @@ int orbhip_get_stage_times(orbhip_ctx *ctx, float ms[6]);
  * Also ORBHIP_BLUR_PLACE at context creation. */
 int orbhip_set_blur_placement(orbhip_ctx *ctx, int place);
 
+/* ---- resident feature sets (new) ----
+ * A key frame's descriptors, keypoints, FeatureVector and feature grid never change after KeyFrame::KeyFrame / ComputeBoW
+ * (ref: src/KeyFrame.cc:53-87, 392-400), but the reference's matcher entry points take the KeyFrame itself, so a per-call
+ * C entry point has to upload that data again on every call.  A set keeps it on the device under a caller-chosen key
+ * (non-zero; the drop-in classes use the KeyFrame's / Frame's mnId); at most 96 sets per context, least recently used out.
+ *   orbhip_set_put   kps[n] / desc[n * 32]; the FeatureVector as CSR over ascending node ids (node[ng], off[ng + 1], idx[off[ng]];
+ *                    ng may be 0); inv_w, inv_h > 0: the 64 x 48 grid of Frame::AssignFeaturesToGrid is built too (needed
+ *                    by orbhip_window_best_set).  Replaces a set of the same key.
+ *   orbhip_set_has   1 if a set with this key and this number of features is resident, else 0.
+ *   orbhip_set_drop  key 0: all sets. */
+int orbhip_set_put(orbhip_ctx *ctx, uint64_t key, const orbhip_keypoint *kps, const uint8_t *desc, int n, const int32_t *node,
+                   const int32_t *off, const int32_t *idx, int ng, float min_x, float min_y, float inv_w, float inv_h);
+int orbhip_set_has(orbhip_ctx *ctx, uint64_t key, int n);
+int orbhip_set_drop(orbhip_ctx *ctx, uint64_t key);
+/* orbhip_search_by_bow (above) between two resident sets: valid1[n1] (and valid2[n2] or NULL) are the only per-feature
+ * inputs that travel.  Same results as orbhip_search_by_bow on the sets' data. */
+int orbhip_search_by_bow_sets(orbhip_ctx *ctx, uint64_t key1, const uint8_t *valid1, uint64_t key2, const uint8_t *valid2, int th,
+                              int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21, int *nmatches);
+/* orbhip_window_best (above) into a resident set (with a grid): the projected points travel, the key frame does not. */
+int orbhip_window_best_set(orbhip_ctx *ctx, uint64_t key, const float *u_right, const float *inv_level_sigma2, int nlevels,
+                           const orbhip_proj_query *queries, const uint8_t *qdesc, int nq, int32_t *best_idx, int32_t *best_dist);
+
 /* ---- multi-GPU (one process per GPU) ----
  * The reference is a single process (no distributed back end); these entry points are what a
  * multi-GPU host adds around the unchanged per-frame path: frames or whole sequences are sharded over ranks with no

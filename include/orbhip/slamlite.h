@@ -92,8 +92,12 @@ class ORBextractor;
 class Frame
 {
 public:
-    Frame() : N(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0), mpORBextractorLeft(0), mpORBextractorRight(0),
-              mbf(0), mb(0) {}
+    Frame() : mnId(NextId()++), N(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0), mpORBextractorLeft(0),
+              mpORBextractorRight(0), mbf(0), mb(0) {}
+    // ref: include/Frame.h "static long unsigned int nNextId; long unsigned int mnId;" (src/Frame.cc: mnId=nNextId++), the
+    // key under which the drop-in matcher keeps a frame's descriptors resident on the device
+    long unsigned int mnId;
+    static long unsigned int &NextId() { static long unsigned int n = 0; return n; }
     int N;                                   // ref: include/Frame.h
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     cv::Mat mDescriptors;
@@ -143,9 +147,11 @@ inline int MapPoint::PredictScale(const float &currentDist, Frame *pF)
 class KeyFrame
 {
 public:
-    KeyFrame() : mbBad(false), N(0), fx(0), fy(0), cx(0), cy(0), mbf(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0),
+    KeyFrame() : mnId(NextId()++), mbBad(false), N(0), fx(0), fy(0), cx(0), cy(0), mbf(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0),
                  mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
                  mfGridElementWidthInv(0), mfGridElementHeightInv(0), mnMinX(0), mnMinY(0), mnMaxX(0), mnMaxY(0) {}
+    long unsigned int mnId;                       // ref: include/KeyFrame.h (src/KeyFrame.cc:46: mnId=nNextId++)
+    static long unsigned int &NextId() { static long unsigned int n = 0; return n; }
     bool isBad() { return mbBad; }                // ref: src/KeyFrame.cc (read by MapPoint::ComputeDistinctiveDescriptors)
     bool mbBad;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;   // ref: include/KeyFrame.h (const members there)

@@ -49,6 +49,12 @@ v0 = np.ones(len(d0), np.uint8)
 rows.append(("`SearchByBoW(KF, F)` 1000 x 1000 features", bench(lambda: M.SearchByBoW(d0, v0, k0["angle"], fv[0], d1, None, k1["angle"], fv[1]), 300),
              bench(lambda: O.search_by_bow(d0, v0, k0["angle"], fv[0], d1, None, k1["angle"], fv[1], th=50, th_mode=0, nnratio=0.7, check_ori=True), 30)))
 
+# the same call between RESIDENT sets (orbhip_set_put once per key frame / frame; what the C++ drop-in does since r03)
+M.put_set(1, k0, d0, fv[0])
+M.put_set(2, k1, d1, fv[1])
+rows.append(("`SearchByBoW(KF, F)` between resident sets (`orbhip_search_by_bow_sets`)",
+             bench(lambda: M.SearchByBoW_sets(1, v0, len(k0), 2, None, len(k1)), 300), rows[-1][2]))
+
 # SearchByProjection(CurrentFrame, LastFrame, th 15, mono): the points of the last frame near where they were
 gp = guided.grid_params(0, W, 0, H)
 sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
@@ -71,6 +77,10 @@ qf["radius"] = 3 * sf[k0["octave"]]
 qf["min_level"], qf["max_level"], qf["flags"] = k0["octave"] - 1, k0["octave"], 1
 rows.append(("`Fuse` window search (1000 points into one key frame)", bench(lambda: guided.WindowBest(ex, k1, d1, gp, qf, d0, None, sig), 300),
              bench(lambda: O.window_best(k1, d1, gp, qf, d0, None, sig), 30)))
+
+M.put_set(3, k1, d1, None, gp)
+rows.append(("`Fuse` window search into a resident key frame (`orbhip_window_best_set`)",
+             bench(lambda: guided.WindowBestSet(ex, 3, qf, d0, None, sig), 300), rows[-1][2]))
 
 # LocalMapping::CreateNewMapPoints: SearchForTriangulation of a key-frame pair (FeatureVectors of levelsup 4 -> ~100 nodes)
 F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)

@@ -50,6 +50,10 @@ void orb_comm_release(orbhip_ctx *c);
 // api_match.hip
 int orb_match_scratch(orbhip_ctx *c, size_t bytes);
 void orb_three_maxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3);
+int orb_bow_rotation_check(const int32_t *pairs, int npairs, const int32_t *off1, const int32_t *idx1, const float *angle1,
+                           const float *angle2, int check_ori, int32_t *match12, int32_t *match21);
+// api_sets.hip
+void orb_sets_release(orbhip_ctx *c);
 static inline bool grid_params_ok(float inv_w, float inv_h) { return inv_w > 0.f && inv_h > 0.f; }
 
 // Bump allocator over one temporary device block (host-pointer matching entry points).
@@ -155,6 +159,16 @@ struct Packed {
         inEnd = off;
         return p;
     }
+    // A small input that the kernel reads a few times (a byte mask, a list of node pairs): left in the page-locked block and
+    // read over PCIe, which costs a kernel about what one small copy command costs the host -- and there is no copy to wait for.
+    void *in_host(const void *src, size_t bytes)
+    {
+        off = align_up(off, 256);
+        if (bytes) memcpy(h + off, src, bytes);
+        void *p = h + off;
+        off += bytes;
+        return p;
+    }
     void *in_fill(int byte, size_t bytes)
     {
         off = align_up(off, 256);
@@ -191,6 +205,7 @@ struct Packed {
     int upload()
     {
         if (off > cap) return fail(c, ORBHIP_E_SIZE, "internal: packed staging block undersized");
+        if (inEnd == 0) return ORBHIP_OK;   // nothing travels by copy
         HIPCHK(c, hipMemcpyAsync(d, h, inEnd, hipMemcpyHostToDevice, c->stream));
         return ORBHIP_OK;
     }

@@ -193,6 +193,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     orb_comm_release(c);
     orb_pipe_release(c);
+    orb_sets_release(c);
     orb_graph_release(c);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);

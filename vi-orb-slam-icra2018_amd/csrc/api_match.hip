@@ -212,7 +212,15 @@ extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1,
         memcpy(match12, P.host(dm12), (size_t)n1 * 4);
         memcpy(match21, P.host(dm21), (size_t)n2 * 4);
     }
-    // rotation consistency (ref: :236-246, :267-285): histogram in the reference's visiting order
+    *nmatches = orb_bow_rotation_check(pairs.data(), npairs, off1, idx1, angle1, angle2, check_ori, match12, match21);
+    return ORBHIP_OK;
+}
+
+// Rotation consistency of SearchByBoW (ref: src/ORBmatcher.cc:236-246, 267-285): histogram in the reference's visiting order
+// (shared nodes in order, side-1 features in list order), all bins but the three largest are cleared.  Returns the matches left.
+int orb_bow_rotation_check(const int32_t *pairs, int npairs, const int32_t *off1, const int32_t *idx1, const float *angle1,
+                           const float *angle2, int check_ori, int32_t *match12, int32_t *match21)
+{
     int nm = 0;
     std::vector<int> hist[30];
     const float factor = 1.0f / 30;
@@ -244,8 +252,7 @@ extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1,
             }
         }
     }
-    *nmatches = nm;
-    return ORBHIP_OK;
+    return nm;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,282 @@
+// api_sets.hip -- C ABI, part 7: resident feature sets.  A key frame's matching data -- descriptors, keypoint records, the
+// FeatureVector as CSR, the 64 x 48 feature grid -- does not change after the key frame is created, yet every per-call
+// matcher entry point of Tracking / LocalMapping (SearchByBoW(KF, F), Fuse, SearchBySim3, ...; ref: src/ORBmatcher.cc:159-288,
+// 825-975) used to upload it again: a call moved ~100 KB around a 10-25 us kernel and lost to one host core.  A set keeps
+// that data on the device under a caller-chosen 64-bit key (the drop-in classes use KeyFrame::mnId / Frame::mnId); the
+// *_sets entry points then upload only what changes from call to call (validity masks, the node pairs, the projected
+// points) and get their results through page-locked memory.  At most ORB_MAX_SETS sets per context, least recently used out.
+#include "api_common.h"
+
+#define ORB_MAX_SETS 96
+
+struct OrbSet {
+    uint64_t key = 0;
+    int n = 0, ng = 0;
+    bool grid = false;
+    float minX = 0, minY = 0, invW = 0, invH = 0;
+    uint8_t *block = nullptr;          // one device allocation
+    size_t bytes = 0;
+    orbhip_keypoint *d_kps = nullptr;
+    uint8_t *d_desc = nullptr;
+    int32_t *d_off = nullptr, *d_idx = nullptr, *d_cellOff = nullptr, *d_cellIdx = nullptr, *d_cnt = nullptr;
+    // host copies of what the host side of a search walks (merge of the node lists, rotation histogram)
+    std::vector<float> angle;
+    std::vector<int32_t> node, off, idx;
+    unsigned long stamp = 0;
+};
+
+struct OrbSetTable {
+    std::vector<OrbSet *> sets;
+    unsigned long clock = 0;
+};
+
+static OrbSetTable *table(orbhip_ctx *c)
+{
+    if (!c->setTable) c->setTable = new OrbSetTable();
+    return static_cast<OrbSetTable *>(c->setTable);
+}
+
+static void set_free(OrbSet *s)
+{
+    if (s->block) (void)hipFree(s->block);
+    delete s;
+}
+
+void orb_sets_release(orbhip_ctx *c)
+{
+    if (!c->setTable) return;
+    OrbSetTable *T = static_cast<OrbSetTable *>(c->setTable);
+    for (OrbSet *s : T->sets) set_free(s);
+    delete T;
+    c->setTable = nullptr;
+}
+
+static OrbSet *find_set(orbhip_ctx *c, uint64_t key)
+{
+    if (!c->setTable) return nullptr;
+    OrbSetTable *T = static_cast<OrbSetTable *>(c->setTable);
+    for (OrbSet *s : T->sets)
+        if (s->key == key) {
+            s->stamp = ++T->clock;
+            return s;
+        }
+    return nullptr;
+}
+
+extern "C" int orbhip_set_has(orbhip_ctx *c, uint64_t key, int n)
+{
+    if (!c) return 0;
+    OrbSet *s = find_set(c, key);
+    return s && s->n == n ? 1 : 0;
+}
+
+extern "C" int orbhip_set_drop(orbhip_ctx *c, uint64_t key)
+{
+    if (!c) return ORBHIP_E_ARG;
+    if (!c->setTable) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    OrbSetTable *T = static_cast<OrbSetTable *>(c->setTable);
+    for (size_t i = 0; i < T->sets.size();)
+        if (key == 0 || T->sets[i]->key == key) {
+            set_free(T->sets[i]);
+            T->sets.erase(T->sets.begin() + i);
+        } else
+            i++;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_set_put(orbhip_ctx *c, uint64_t key, const orbhip_keypoint *kps, const uint8_t *desc, int n,
+                              const int32_t *node, const int32_t *off, const int32_t *idx, int ng, float min_x, float min_y,
+                              float inv_w, float inv_h)
+{
+    if (!c || key == 0 || n <= 0 || !kps || !desc || ng < 0 || (ng > 0 && (!node || !off || !idx)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_set_put: bad argument");
+    const int m = ng > 0 ? off[ng] : 0;
+    for (int g = 0; g < ng; g++)
+        if (off[g] > off[g + 1] || off[g] < 0 || (g > 0 && node[g] <= node[g - 1]))
+            return fail(c, ORBHIP_E_ARG, "orbhip_set_put: the FeatureVector must be a CSR over ascending node ids");
+    for (int t = 0; t < m; t++)
+        if (idx[t] < 0 || idx[t] >= n) return fail(c, ORBHIP_E_ARG, "orbhip_set_put: feature index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // a set that is replaced or evicted may still be read by a queued kernel
+    OrbSetTable *T = table(c);
+    for (size_t i = 0; i < T->sets.size(); i++)
+        if (T->sets[i]->key == key) {
+            set_free(T->sets[i]);
+            T->sets.erase(T->sets.begin() + i);
+            break;
+        }
+    if (T->sets.size() >= ORB_MAX_SETS) {
+        size_t lru = 0;
+        for (size_t i = 1; i < T->sets.size(); i++)
+            if (T->sets[i]->stamp < T->sets[lru]->stamp) lru = i;
+        set_free(T->sets[lru]);
+        T->sets.erase(T->sets.begin() + lru);
+    }
+    OrbSet *s = new OrbSet();
+    s->key = key;
+    s->n = n;
+    s->ng = ng;
+    s->grid = inv_w > 0.f && inv_h > 0.f;
+    s->minX = min_x; s->minY = min_y; s->invW = inv_w; s->invH = inv_h;
+    // device block: keypoints | descriptors | count | CSR offsets | CSR indices | grid offsets | grid entries
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t oK = carve((size_t)n * sizeof(orbhip_keypoint)), oD = carve((size_t)n * 32 + 32), oC = carve(16),
+                 oO = carve((size_t)(ng + 1) * 4), oI = carve((size_t)m * 4 + 4), oG = carve((ORBHIP_GRID_CELLS + 1) * 4),
+                 oE = carve((size_t)n * 4);
+    void *p = nullptr;
+    if (hipMalloc(&p, o) != hipSuccess) {
+        delete s;
+        return fail(c, ORBHIP_E_HIP, "orbhip_set_put: out of device memory");
+    }
+    s->block = (uint8_t *)p;
+    s->bytes = o;
+    s->d_kps = (orbhip_keypoint *)(s->block + oK);
+    s->d_desc = s->block + oD;
+    s->d_cnt = (int32_t *)(s->block + oC);
+    s->d_off = (int32_t *)(s->block + oO);
+    s->d_idx = (int32_t *)(s->block + oI);
+    s->d_cellOff = (int32_t *)(s->block + oG);
+    s->d_cellIdx = (int32_t *)(s->block + oE);
+    // one packed upload
+    Packed P(c);
+    int rc;
+    if ((rc = P.begin(o + 4096))) {
+        set_free(s);
+        return rc;
+    }
+    memcpy(P.h + oK, kps, (size_t)n * sizeof(orbhip_keypoint));
+    memcpy(P.h + oD, desc, (size_t)n * 32);
+    const int32_t cnt[4] = {n, 0, 0, 0};
+    memcpy(P.h + oC, cnt, 16);
+    if (ng > 0) {
+        memcpy(P.h + oO, off, (size_t)(ng + 1) * 4);
+        memcpy(P.h + oI, idx, (size_t)m * 4);
+    } else {
+        memset(P.h + oO, 0, 4);
+    }
+    hipError_t e = hipMemcpyAsync(s->block, P.h, oG, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && s->grid) {
+        launch_grid_build(c->stream, s->d_kps, s->d_cnt, n, 1, min_x, min_y, inv_w, inv_h, s->d_cellOff, s->d_cellIdx);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        set_free(s);
+        return fail(c, ORBHIP_E_HIP, std::string("orbhip_set_put: ") + hipGetErrorString(e));
+    }
+    s->angle.resize(n);
+    for (int i = 0; i < n; i++) s->angle[i] = kps[i].angle;
+    if (ng > 0) {
+        s->node.assign(node, node + ng);
+        s->off.assign(off, off + ng + 1);
+        s->idx.assign(idx, idx + m);
+    }
+    s->stamp = ++T->clock;
+    T->sets.push_back(s);
+    return ORBHIP_OK;
+}
+
+// SearchByBoW between two resident sets (ref: src/ORBmatcher.cc:159-288 with th_mode 0, :522-655 with th_mode 1): what travels
+// per call is the validity masks and the list of shared nodes; the matches come back through page-locked memory.
+extern "C" int orbhip_search_by_bow_sets(orbhip_ctx *c, uint64_t key1, const uint8_t *valid1, uint64_t key2,
+                                         const uint8_t *valid2, int th, int th_mode, float nnratio, int check_ori,
+                                         int32_t *match12, int32_t *match21, int *nmatches)
+{
+    if (!c || !valid1 || !match12 || !match21 || !nmatches) return fail(c, ORBHIP_E_ARG, "orbhip_search_by_bow_sets: bad argument");
+    OrbSet *s1 = find_set(c, key1), *s2 = find_set(c, key2);
+    if (!s1 || !s2) return fail(c, ORBHIP_E_ARG, "orbhip_search_by_bow_sets: unknown set (orbhip_set_put)");
+    const int n1 = s1->n, n2 = s2->n;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    for (int i = 0; i < n2; i++) match21[i] = -1;
+    *nmatches = 0;
+    std::vector<int32_t> pairs;
+    for (int g1 = 0, g2 = 0; g1 < s1->ng && g2 < s2->ng;) {     // merge walk over the two FeatureVectors (ref: :180-264)
+        if (s1->node[g1] == s2->node[g2]) {
+            pairs.push_back(g1++);
+            pairs.push_back(g2++);
+        } else if (s1->node[g1] < s2->node[g2])
+            g1++;
+        else
+            g2++;
+    }
+    const int npairs = (int)pairs.size() / 2;
+    if (npairs == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Packed P(c);
+    int rc;
+    if ((rc = P.begin((size_t)n1 + (size_t)n2 + pairs.size() * 4 + (size_t)(n1 + n2) * 4 + 12 * 256))) return rc;
+    bool hostOut = true;      // (as in orbhip_search_by_bow: nodes of more than 128 side-2 features poll match21 on the device)
+    for (int p = 0; p < npairs && hostOut; p++)
+        if (s2->off[pairs[2 * p + 1] + 1] - s2->off[pairs[2 * p + 1]] > 128) hostOut = false;
+    // the masks and the node pairs: read by the kernel straight from the page-locked block (no copy command) when the
+    // matches go there too; a frame with a node of more than 128 features keeps everything on the device
+    static const bool zeroCopy = !(getenv("ORBHIP_SETS_COPY") && atoi(getenv("ORBHIP_SETS_COPY")) != 0);
+    const bool hostIn = hostOut && zeroCopy;
+    const uint8_t *dv1 = (const uint8_t *)(hostIn ? P.in_host(valid1, (size_t)n1) : P.in(valid1, (size_t)n1));
+    const uint8_t *dv2 = !valid2 ? nullptr : (const uint8_t *)(hostIn ? P.in_host(valid2, (size_t)n2) : P.in(valid2, (size_t)n2));
+    const int32_t *dp = (const int32_t *)(hostIn ? P.in_host(pairs.data(), pairs.size() * 4) : P.in(pairs.data(), pairs.size() * 4));
+    int32_t *dm12, *dm21;
+    if (hostOut) {
+        dm12 = (int32_t *)P.out_host_fill(0xFF, (size_t)n1 * 4);
+        dm21 = (int32_t *)P.out_host_fill(0xFF, (size_t)n2 * 4);
+    } else {
+        dm12 = (int32_t *)P.in_fill(0xFF, (size_t)n1 * 4);
+        dm21 = (int32_t *)P.in_fill(0xFF, (size_t)n2 * 4);
+    }
+    if ((rc = P.upload())) return rc;
+    launch_bow_match(c->stream, s1->d_desc, dv1, s1->d_off, s1->d_idx, s2->d_desc, dv2, s2->d_off, s2->d_idx, dp, npairs, th, th_mode,
+                     nnratio, dm12, dm21);
+    HIPCHK(c, hipGetLastError());
+    if (hostOut) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(match12, dm12, (size_t)n1 * 4);
+        memcpy(match21, dm21, (size_t)n2 * 4);
+    } else {
+        if ((rc = P.download(dm12))) return rc;
+        memcpy(match12, P.host(dm12), (size_t)n1 * 4);
+        memcpy(match21, P.host(dm21), (size_t)n2 * 4);
+    }
+    *nmatches = orb_bow_rotation_check(pairs.data(), npairs, s1->off.data(), s1->idx.data(), s1->angle.data(), s2->angle.data(),
+                                       check_ori, match12, match21);
+    return ORBHIP_OK;
+}
+
+// The per-point window search of Fuse / SearchBySim3 (ref: src/ORBmatcher.cc:825-975, 1102-1326) into a resident key frame:
+// its keypoints, descriptors and grid stay on the device, the projected points travel.
+extern "C" int orbhip_window_best_set(orbhip_ctx *c, uint64_t key, const float *u_right, const float *inv_level_sigma2, int nlevels,
+                                      const orbhip_proj_query *queries, const uint8_t *qdesc, int nq, int32_t *best_idx,
+                                      int32_t *best_dist)
+{
+    if (!c || nq < 0 || (nq > 0 && (!queries || !qdesc || !best_idx || !best_dist)) ||
+        (inv_level_sigma2 && (nlevels <= 0 || nlevels > 16)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_window_best_set: bad argument");
+    OrbSet *s = find_set(c, key);
+    if (!s || !s->grid) return fail(c, ORBHIP_E_ARG, "orbhip_window_best_set: unknown set, or a set without a grid (orbhip_set_put)");
+    for (int i = 0; i < nq; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+    }
+    if (nq == 0) return ORBHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Packed P(c);
+    int rc;
+    const int n = s->n;
+    if ((rc = P.begin((size_t)n * 4 + (size_t)nq * (sizeof(orbhip_proj_query) + 32 + 8) + 12 * 256))) return rc;
+    const int32_t cnts[4] = {nq, 0, 0, 0};
+    const float *dur = u_right ? (const float *)P.in(u_right, (size_t)n * 4) : nullptr;
+    const int32_t *dc = (const int32_t *)P.in(cnts, 16);
+    const orbhip_proj_query *dq = (const orbhip_proj_query *)P.in(queries, (size_t)nq * sizeof(orbhip_proj_query));
+    const uint8_t *dqd = (const uint8_t *)P.in(qdesc, (size_t)nq * 32);
+    int32_t *dbi = (int32_t *)P.out_host((size_t)nq * 4), *dbd = (int32_t *)P.out_host((size_t)nq * 4);   // written over PCIe, no copy back
+    if ((rc = P.upload())) return rc;
+    if ((rc = orbhip_window_best_device(c, s->d_kps, s->d_desc, n, 1, dur, inv_level_sigma2, nlevels, s->minX, s->minY, s->invW, s->invH,
+                                        s->d_cellOff, s->d_cellIdx, dq, dqd, dc, nq, dbi, dbd)))
+        return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(best_idx, dbi, (size_t)nq * 4);
+    memcpy(best_dist, dbd, (size_t)nq * 4);
+    return ORBHIP_OK;
+}

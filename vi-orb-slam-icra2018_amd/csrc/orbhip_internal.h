@@ -245,6 +245,8 @@ struct orbhip_ctx {
 
     // host-fed pipeline
     OrbPipe *pipe = nullptr;
+    // resident feature sets (api_sets.hip)
+    void *setTable = nullptr;
 
     // RCCL
     void *comm = nullptr;

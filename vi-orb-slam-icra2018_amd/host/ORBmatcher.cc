@@ -5,6 +5,7 @@
 // in liborbhip.so (orbhip_search_by_bow).
 #include "ORBmatcher.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -60,6 +61,39 @@ vector<uint8_t> contiguous(const cv::Mat &d)
     for (int i = 0; i < d.rows; i++) memcpy(&v[(size_t)i * 32], d.ptr(i), 32);
     return v;
 }
+
+// Resident feature sets (include/orbhip.h, orbhip_set_*): descriptors, undistorted keypoints, FeatureVector and feature grid of
+// a key frame or frame do not change once it exists, so they are uploaded the first time a matcher of this thread meets
+// it and stay on the device under its id (mnId is unique per run; a set nobody uses any more ages out of the 96 the
+// context keeps).  ORBHIP_NO_SETS=1 restores the upload-per-call entry points (A/B runs).
+const uint64_t KF_KEY = 1ull << 62, FRAME_KEY = 1ull << 61;
+bool use_sets()
+{
+    static const bool off = getenv("ORBHIP_NO_SETS") && atoi(getenv("ORBHIP_NO_SETS")) != 0;
+    return !off;
+}
+template <class T>
+bool ensure_set(uint64_t key, const T &t, const vector<cv::KeyPoint> &keysUn, float minX, float minY, float invW, float invH)
+{
+    const int n = t.mDescriptors.rows;
+    if (n <= 0 || (int)keysUn.size() != n) return false;
+    orbhip_ctx *c = tls.get();
+    if (orbhip_set_has(c, key, n)) return true;
+    const Csr fv = flatten(t.mFeatVec);
+    const vector<uint8_t> d = contiguous(t.mDescriptors);
+    return orbhip_set_put(c, key, reinterpret_cast<const orbhip_keypoint *>(keysUn.data()), d.data(), n, fv.node.data(),
+                          fv.off.data(), fv.idx.data(), (int)fv.node.size(), minX, minY, invW, invH) == ORBHIP_OK;
+}
+bool ensure_set(KeyFrame *pKF)
+{
+    return ensure_set(KF_KEY | (uint64_t)(pKF->mnId + 1), *pKF, pKF->mvKeysUn, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
+                      pKF->mfGridElementHeightInv);
+}
+bool ensure_set(Frame &F)
+{
+    return ensure_set(FRAME_KEY | (uint64_t)(F.mnId + 1), F, F.mvKeysUn, Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv,
+                      Frame::mfGridElementHeightInv);
+}
 }  // namespace
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri): mfNNratio(nnratio), mbCheckOrientation(checkOri)
@@ -83,10 +117,21 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF,Frame &F, vector<MapPoint*> &vpMapPoin
         a1[i] = pKF->mvKeysUn[i].angle;                        // ref: :234
     }
     for (int i = 0; i < n2; i++) a2[i] = F.mvKeys[i].angle;   // ref: :238
-    const Csr c1 = flatten(pKF->mFeatVec), c2 = flatten(F.mFeatVec);
-    const vector<uint8_t> d1 = contiguous(pKF->mDescriptors), d2 = contiguous(F.mDescriptors);
     vector<int32_t> m12(n1), m21(n2);
     int nmatches = 0;
+    // (the rotation check reads pKF->mvKeysUn[i].angle and F.mvKeys[i].angle: undistortion leaves the angle alone, so the
+    // resident sets -- built from the undistorted keypoints -- hold the same values)
+    if (use_sets() && (int)F.mvKeysUn.size() == n2 && ensure_set(pKF) && ensure_set(F)) {
+        const int rc = orbhip_search_by_bow_sets(tls.get(), KF_KEY | (uint64_t)(pKF->mnId + 1), valid1.data(),
+                                                 FRAME_KEY | (uint64_t)(F.mnId + 1), NULL, TH_LOW, 0, mfNNratio,
+                                                 mbCheckOrientation ? 1 : 0, m12.data(), m21.data(), &nmatches);
+        if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
+        for (int i2 = 0; i2 < n2 && i2 < F.N; i2++)
+            if (m21[i2] >= 0) vpMapPointMatches[i2] = vpMapPointsKF[m21[i2]];   // ref: :232
+        return nmatches;
+    }
+    const Csr c1 = flatten(pKF->mFeatVec), c2 = flatten(F.mFeatVec);
+    const vector<uint8_t> d1 = contiguous(pKF->mDescriptors), d2 = contiguous(F.mDescriptors);
     const int rc = orbhip_search_by_bow(tls.get(), d1.data(), n1, valid1.data(), a1.data(), c1.node.data(),
                                         c1.off.data(), c1.idx.data(), (int)c1.node.size(), d2.data(), n2, NULL,
                                         a2.data(), c2.node.data(), c2.off.data(), c2.idx.data(), (int)c2.node.size(),
@@ -118,10 +163,19 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
         valid2[i] = (p && !p->isBad()) ? 1 : 0;               // ref: :572-578
         a2[i] = pKF2->mvKeysUn[i].angle;
     }
-    const Csr c1 = flatten(pKF1->mFeatVec), c2 = flatten(pKF2->mFeatVec);
-    const vector<uint8_t> d1 = contiguous(pKF1->mDescriptors), d2 = contiguous(pKF2->mDescriptors);
     vector<int32_t> m12(n1), m21(n2);
     int nmatches = 0;
+    if (use_sets() && pKF1 != pKF2 && ensure_set(pKF1) && ensure_set(pKF2)) {
+        const int rc = orbhip_search_by_bow_sets(tls.get(), KF_KEY | (uint64_t)(pKF1->mnId + 1), valid1.data(),
+                                                 KF_KEY | (uint64_t)(pKF2->mnId + 1), valid2.data(), TH_LOW, 1, mfNNratio,
+                                                 mbCheckOrientation ? 1 : 0, m12.data(), m21.data(), &nmatches);
+        if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
+        for (int i1 = 0; i1 < n1 && i1 < (int)vpMatches12.size(); i1++)
+            if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];           // ref: :602
+        return nmatches;
+    }
+    const Csr c1 = flatten(pKF1->mFeatVec), c2 = flatten(pKF2->mFeatVec);
+    const vector<uint8_t> d1 = contiguous(pKF1->mDescriptors), d2 = contiguous(pKF2->mDescriptors);
     const int rc = orbhip_search_by_bow(tls.get(), d1.data(), n1, valid1.data(), a1.data(), c1.node.data(),
                                         c1.off.data(), c1.idx.data(), (int)c1.node.size(), d2.data(), n2,
                                         valid2.data(), a2.data(), c2.node.data(), c2.off.data(), c2.idx.data(),
@@ -455,6 +509,18 @@ void run_window_best(KeyFrame *pKF, const vector<orbhip_proj_query> &q, const ve
     bestIdx.assign(nq, -1);
     bestDist.assign(nq, 256);
     if (n == 0 || nq == 0) return;
+    if (use_sets() && ensure_set(pKF)) {
+        const int rc = orbhip_window_best_set(
+            tls.get(), KF_KEY | (uint64_t)(pKF->mnId + 1), (gate && (int)pKF->mvuRight.size() == n) ? pKF->mvuRight.data() : NULL,
+            gate ? pKF->mvInvLevelSigma2.data() : NULL, gate ? (int)pKF->mvInvLevelSigma2.size() : 0, q.data(), qdesc.data(), nq,
+            bestIdx.data(), bestDist.data());
+        if (rc != ORBHIP_OK) {
+            hipdetail::Fail("ORBmatcher::Fuse / SearchBySim3 (KeyFrame window search)", orbhip_last_error(tls.get()));
+            bestIdx.assign(nq, -1);
+            bestDist.assign(nq, 256);
+        }
+        return;
+    }
     const vector<uint8_t> d = contiguous(pKF->mDescriptors);
     const int rc = orbhip_window_best(
         tls.get(), reinterpret_cast<const orbhip_keypoint *>(pKF->mvKeysUn.data()), d.data(), n,

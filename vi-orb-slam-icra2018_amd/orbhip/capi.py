@@ -37,6 +37,7 @@ SYMBOLS = [
     "orbhip_distinctive_descriptors", "orbhip_distinctive_descriptors_device",
     "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
     "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
+    "orbhip_set_put", "orbhip_set_has", "orbhip_set_drop", "orbhip_search_by_bow_sets", "orbhip_window_best_set",
 ]
 
 
@@ -141,6 +142,11 @@ def load():
     L.orbhip_remap_set_maps.argtypes = [vp, vp, vp, i32, i32]
     L.orbhip_remap.argtypes = [vp, vp, i32, i32, i32, vp, i32]
     L.orbhip_remap_device.argtypes = [vp, vp, i32, i32, i32, i32, C.c_size_t, vp, i32, C.c_size_t]
+    L.orbhip_set_put.argtypes = [vp, C.c_uint64, vp, vp, i32, vp, vp, vp, i32, f32, f32, f32, f32]
+    L.orbhip_set_has.argtypes = [vp, C.c_uint64, i32]
+    L.orbhip_set_drop.argtypes = [vp, C.c_uint64]
+    L.orbhip_search_by_bow_sets.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, i32, i32, f32, i32, vp, vp, ip]
+    L.orbhip_window_best_set.argtypes = [vp, C.c_uint64, vp, vp, i32, vp, vp, i32, vp, vp]
     L.orbhip_comm_unique_id.argtypes = [vp]
     L.orbhip_comm_init.argtypes = [vp, i32, i32, vp]
     L.orbhip_bcast_blob_device.argtypes = [vp, vp, C.c_size_t, i32]

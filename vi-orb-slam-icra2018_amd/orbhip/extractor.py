@@ -308,6 +308,35 @@ class ORBmatcher:
         return nm.value, m12[:n1].copy(), m21[:n2].copy()
 
 
+    # -- resident feature sets (orbhip_set_*): a key frame's data stays on the device across calls --
+    def put_set(self, key, kps, desc, fv=None, gp=None):
+        """Keeps (kps, desc, FeatureVector CSR fv = (node, off, idx), grid of gp = (min_x, min_y, inv_w, inv_h)) under `key`."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        g = [None, None, None] if fv is None else [np.ascontiguousarray(a, np.int32) for a in fv]
+        gp = (0.0, 0.0, 0.0, 0.0) if gp is None else gp
+        check(self._L.orbhip_set_put(self._ctx.handle, key, _p(kps), _p(desc), len(kps), _p(g[0]), _p(g[1]), _p(g[2]),
+                                     0 if fv is None else len(g[0]), gp[0], gp[1], gp[2], gp[3]), self._ctx.handle, "orbhip_set_put")
+
+    def has_set(self, key, n):
+        return bool(self._L.orbhip_set_has(self._ctx.handle, key, n))
+
+    def drop_set(self, key=0):
+        check(self._L.orbhip_set_drop(self._ctx.handle, key), self._ctx.handle, "orbhip_set_drop")
+
+    def SearchByBoW_sets(self, key1, valid1, n1, key2, valid2, n2, kf_kf=False):
+        """SearchByBoW between two resident sets; returns (nmatches, match12, match21) like SearchByBoW."""
+        valid1 = np.ascontiguousarray(valid1, np.uint8)
+        valid2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        m12 = np.empty(max(n1, 1), np.int32)
+        m21 = np.empty(max(n2, 1), np.int32)
+        nm = C.c_int()
+        check(self._L.orbhip_search_by_bow_sets(self._ctx.handle, key1, _p(valid1), key2, _p(valid2), self.TH_LOW, 1 if kf_kf else 0,
+                                                self.mfNNratio, 1 if self.mbCheckOrientation else 0, _p(m12), _p(m21), C.byref(nm)),
+              self._ctx.handle, "orbhip_search_by_bow_sets")
+        return nm.value, m12[:n1].copy(), m21[:n2].copy()
+
+
 def ComputeStereoMatches(exL, kpsL, descL, exR, kpsR, descR, mb, mbf):
     """Frame::ComputeStereoMatches (src/Frame.cc:810-984) on the pyramids the two extractor contexts still
     hold from their last operator() call.  Returns (mvuRight, mvDepth, n_before_median_cut)."""

@@ -128,6 +128,19 @@ def WindowBest(ctx, kps_un, desc, gp, queries, qdesc, u_right=None, inv_level_si
     return bi[:len(queries)].copy(), bd[:len(queries)].copy()
 
 
+def WindowBestSet(ctx, key, queries, qdesc, u_right=None, inv_level_sigma2=None):
+    """WindowBest into a resident set (orbhip_set_put with a grid): only the projected points travel."""
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, f32)
+    sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, f32)
+    bi = np.empty(max(len(queries), 1), np.int32)
+    bd = np.empty(max(len(queries), 1), np.int32)
+    check(capi.load().orbhip_window_best_set(ctx.handle, key, _p(ur), _p(sg), 0 if sg is None else len(sg), _p(queries), _p(qdesc),
+                                             len(queries), _p(bi), _p(bd)), ctx.handle, "orbhip_window_best_set")
+    return bi[:len(queries)].copy(), bd[:len(queries)].copy()
+
+
 def SearchForInitialization(ctx, kps1_un, desc1, kps2_un, desc2, gp, prev_matched, window_size=100, nnratio=0.9,
                             check_ori=True):
     """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520).  Returns (nmatches, vnMatches12,
