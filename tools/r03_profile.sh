@@ -1,0 +1,52 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: everything behind profiles/r03 (one call, one box): the bench line, rocprofv3 kernel stats + HBM counter
+# passes of the same command, SQ / GRBM counter passes (VALU wave-instructions per kernel: roofline_valu), k_fast phase
+# ablation, per-call latencies (Python wrappers and a C++ caller), the blur placements.   usage: bash tools/r03_profile.sh [tag]
+TAG=${1:-r03}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd $REPO
+python bench.py > $OUT/bench_stdout.txt 2> $OUT/bench_stderr.txt
+tail -1 $OUT/bench_stdout.txt > $OUT/bench.json
+# counters first (summarize_prof.py merges fast_valu.json into traffic.json)
+bash tools/pmc_gpu.sh util "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES" 2>&1 | grep -E "^k_" > $OUT/counters_sq.txt
+bash tools/pmc_gpu.sh util2 "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES" 2>&1 | grep -E "^k_" > $OUT/counters_misc.txt
+python3 - "$OUT" <<'PY'
+import ast, json, sys
+d = sys.argv[1]
+def rows(f):
+    out = {}
+    for l in open(f):
+        k, _, v = l.partition(" {")
+        out[k.strip()] = ast.literal_eval("{" + v)
+    return out
+sq, misc = rows(d + "/counters_sq.txt"), rows(d + "/counters_misc.txt")
+fast = [k for k in sq if k.startswith("k_fast")][0]
+kt = None
+json.dump({"valu_wave_insts_per_launch": int(sq[fast]["SQ_INSTS_VALU"]),
+           "grbm_gui_active_per_launch": int(misc[fast]["GRBM_GUI_ACTIVE"]),
+           "valu_source": "profiles/%s/counters_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU ..., own pass)" % d.rsplit("prof_", 1)[-1]},
+          open(d + "/fast_valu.json", "w"), indent=1)
+PY
+bash tools/profile_gpu.sh $TAG > /dev/null 2>&1
+python3 - "$OUT" <<'PY'
+import json, sys
+d = sys.argv[1]
+t = json.load(open(d + "/traffic.json"))
+if "grbm_gui_active_per_launch" in t and t.get("avg_launch_us"):
+    # effective clock = GRBM_GUI_ACTIVE / 8 XCDs / launch time (MI355X_MICROARCH.md, DVFS give-back)
+    t["clock_ghz"] = round(t["grbm_gui_active_per_launch"] / 8.0 / (t["avg_launch_us"] * 1e-6) / 1e9, 3)
+json.dump(t, open(d + "/traffic.json", "w"), indent=1)
+PY
+bash tools/fast_ablate.sh > $OUT/fast_ablate_time.txt 2>&1
+bash tools/fast_ablate_pmc.sh > $OUT/fast_ablate_pmc.txt 2>&1
+bash tools/pmc_gpu.sh l2 "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" 2>&1 | grep -E "^k_" > $OUT/counters_l2.txt
+python tools/percall_latency.py > $OUT/percall_table.md 2> $OUT/percall_stderr.txt
+bash tools/latency_native.sh 3000 > $OUT/latency_native.json 2>&1
+VERIFY=8 bash tools/ab_env.sh 2 "ORBHIP_BLUR_PLACE=0" "ORBHIP_BLUR_PLACE=1" "ORBHIP_BLUR_PLACE=2" "ORBHIP_NO_SPLIT=1" "ORBHIP_NO_FUSE=1" > $OUT/schedules.txt 2>&1
+{ nproc; lscpu | grep 'Model name'; rocm-smi --showclocks 2>/dev/null | head -12; } > $OUT/gpu_box_env.txt 2>&1
+cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+find $OUT -name '*.csv' -size +2M -delete
+find $OUT -name '*.db' -delete
+cat $OUT/bench.json | head -c 1500; echo; cat $OUT/summary.md | head -14; cat $OUT/schedules.txt

@@ -43,11 +43,17 @@ def main(d):
         wa = sum(wt) / len(wt) if wt else float("nan")
         print("| %s | %d | %.2f | %.2f | %.3f | %.1f | %.2f | %.1f |" % (
             k, len(v), sum(tail) / len(tail), min(v), sum(v) / 1e3, fa, 2 * fa * 1024 / 1e6, wa))
-        if k == "k_fast" and ft and wt:
+        if k.startswith("k_fast") and ft and wt:
             # machine-readable copy for bench.py's roofline.traffic (bytes per launch, FETCH_SIZE doubled)
             import json
             with open(os.path.join(d, "traffic.json"), "w") as fh:
-                json.dump({"kernel": "k_fast", "fetch_size_kb_raw": fa, "write_size_kb": wa,
+                extra = {}
+                try:      # VALU wave-instructions and clock of the same kernel from the SQ / GRBM passes (tools/r03_profile.sh)
+                    with open(os.path.join(d, "fast_valu.json")) as vf:
+                        extra = json.load(vf)
+                except (OSError, ValueError):
+                    pass
+                json.dump({**extra, "kernel": "k_fast", "fetch_size_kb_raw": fa, "write_size_kb": wa,
                            "traffic_bytes_per_launch": int(2 * fa * 1024 + wa * 1024), "avg_launch_us": sum(tail) / len(tail),
                            "launches": len(v), "batch": 1024, "contexts": 1,
                            "source": "profiles/%s/summary.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate "

@@ -12,11 +12,12 @@
 // r03: both passes run on the matrix pipe as banded-Toeplitz products (the VALU is what k_fast and k_describe
 // saturate; r02's dot4 / dot2 formulation cost 27 lane-instructions per pixel, this one ~6).  One 256-thread
 // workgroup per 128 x 58 output tile, one wave per 32-column strip:
-//   1. raw rows y0-3 .. y0+60 (reflected at the top / bottom), columns x0-16 .. x0+175, into LDS with 16-byte
-//      row-coalesced loads, every byte xor 0x80 (pixel - 128 as int8); at the left / right image edge the 3
-//      reflected columns are patched into the halo;
+//   1. raw rows y0-3 .. y0+60 (reflected at the top / bottom), columns x0-16 .. x0+175, straight into LDS
+//      (global_load_lds_dwordx4, no registers; two tiles per workgroup, the second one in flight while the first is
+//      computed); at the left / right image edge the 3 reflected columns are patched into the halo;
 //   2. row pass, v_mfma_i32_32x32x32_i8: H[row][col] = sum_c (p[row][c] - 128) * Kx[c][col] + 128 * 257, A = 32 rows x
-//      32 input columns straight from LDS (ds_read_b128: the 16 consecutive bytes of a lane ARE its 16 k-slots),
+//      32 input columns straight from LDS (ds_read_b128: the 16 consecutive bytes of a lane ARE its 16 k-slots; xor 0x80
+//      turns the pixels into int8),
 //      B = the band matrix of the taps (a per-lane constant), two k-steps per 32 x 32 tile, two row tiles (64 rows);
 //      the result tile has its column on the lane and 16 rows in the lane's registers;
 //   3. column pass, v_mfma_f32_32x32x16_f16 with the row-pass tile as the A operand in place (no LDS round trip:
@@ -30,7 +31,11 @@
 //      instruction: two vector instructions per output pixel;
 //   4. the 32 x 32 result tiles (output row on the lane, four adjacent columns per register group) go through an
 //      LDS image of the output tile and leave with 16-byte row-coalesced stores.
-// Bound: HBM (reads and writes one byte per pixel; halo re-reads 64/58 x 160/128).
+// Measured and not kept (profiles/r03): the same staged tile also yielding the pixels of the NEXT pyramid level (one launch
+// per level builds blurred level l and raw level l + 1, every level read once instead of twice: 1 GB less traffic per
+// 1024 frames, bit-exact) -- 1.19-1.35 ms against 0.60 + 0.57 for the separate kernels: neither kernel is bound by bytes.
+// Bound: nominally HBM (reads and writes one byte per pixel; halo re-reads 64/58 x 160/128); measured: the lifetime of a
+// workgroup (load latency + matrix chain + store) at four workgroups per CU.
 #include "orbhip_internal.h"
 
 #include <cmath>
@@ -39,9 +44,8 @@
 #define BM_W BLUR_TILE_W          // 128 output columns = 4 waves x 32
 #define BM_H BLUR_TILE_H          // 58 output rows
 #define BM_IN 64                  // raw rows (two 32-row tiles of the row pass)
-#define BM_CH 12                  // 16-byte chunks staged per raw row: 16 halo + 128 + 16 halo, + 2 that only round the tile up to
-                                  // 3 x 256 chunks (every thread stages exactly three, no conditional load or store)
-#define BM_PITCH 208              // raw pitch: 52 dwords, so that 16 rows' 16-byte reads fall into distinct bank groups
+#define BM_CW 13                  // 16-byte chunks of a raw row in LDS: 16 halo + 128 + 16 halo, 2 spare, 1 pad (see blur_dma)
+#define BM_PITCH (BM_CW * 16)     // 208: 52 dwords, so that 16 rows' 16-byte reads fall into distinct bank groups
 #define BM_OP 144                 // pitch of the output image: 36 dwords (32 would put every row's dword store in one bank)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -90,28 +94,50 @@ __device__ __forceinline__ BlurGeom blur_geom(const OrbLevels &G, const BlurTile
     return g;
 }
 
-#define BM_NIT (BM_IN * BM_CH / 256)
-static_assert(BM_NIT * 256 == BM_IN * BM_CH, "every thread stages the same number of chunks");
+// The raw tile travels global -> LDS without passing through registers (global_load_lds_dwordx4: a wave instruction writes
+// 64 x 16 bytes to CONSECUTIVE LDS addresses, so the LDS image is chunk-linear: chunk id = 13 * row + column chunk, the
+// thirteenth chunk of a row being the pad that keeps the rows' bank groups apart).  832 chunks = 13 wave instructions, dealt
+// to the four waves.  A workgroup takes TWO consecutive tiles of a frame and requests both at once, each into its own LDS
+// buffer: the second tile travels while the first is computed.  Order of one workgroup (no wait ever covers a store):
+//     request tile 0, tile 1, the tables | wait tile 0 | compute 0 | wait tile 1 | store 0 | compute 1 | store 1
+#define BM_TPW 2
+#define BM_WCH (BM_IN * BM_CW / 64)          // wave instructions per tile
+static_assert(BM_WCH * 64 == BM_IN * BM_CW, "the chunk-linear tile is a whole number of wave instructions");
 
-// the raw tile's 16-byte chunks of this thread, all loads issued back to back: unconditional loads from a clamped address
-// (a conditional load would be waited for before the next one is issued).  A chunk outside the row holds other pixels of
-// the row: columns beyond the three reflected ones (patched below) only reach outputs outside the image.
-__device__ __forceinline__ void blur_fetch(const BlurGeom &g, int tid, uint4 v[BM_NIT])
+// one global_load_lds_dwordx4: 16 bytes per lane from its own address to LDS byte address ldsAddr + 16 * lane.  As inline
+// assembly: the builtin makes hipcc wait vmcnt(0) before every LDS access that might alias the destination (here: every
+// read of the OTHER buffer), which serialises the transfers and drains them before the compute phase; the waits are ours.
+// M0 carries the LDS address and is restored.
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t ldsAddr)
 {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(ldsAddr)
+                 : "memory");
+}
+
+__device__ __forceinline__ void blur_dma(const BlurGeom &g, uint8_t *ldsTile, int wv, int lane)
+{
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)ldsTile;   // LDS byte address (low half of the flat address)
     const int wAl = (g.w + 15) & ~15;   // bytes of a row that may be read with 16-byte loads
 #pragma unroll
-    for (int k = 0; k < BM_NIT; k++) {
-        const int i = tid + k * 256;
-        const int r = i / BM_CH, c = i - r * BM_CH;
-        const int sy = reflect101(min(g.y0 - 3 + r, g.h + 2), g.h);
-        const int sx = g.x0 - 16 + (c << 4);
-        v[k] = *reinterpret_cast<const uint4 *>(g.src + (size_t)sy * g.sstride + min(max(sx, 0), wAl - 16));
+    for (int j4 = 0; j4 < (BM_WCH + 3) / 4; j4++) {
+        const int j = wv + 4 * j4;       // wave-uniform: wave 0 issues 4 transfers, the others 3
+        if (j < BM_WCH) {
+            const int i = 64 * j + lane;
+            const int r = i / BM_CW, c = i - r * BM_CW;
+            const int sy = reflect101(min(g.y0 - 3 + r, g.h + 2), g.h);
+            const int sx = g.x0 - 16 + (c << 4);
+            // (a chunk outside the row -- or the pad chunk -- reads other pixels of the row: columns beyond the three reflected
+            // ones, patched below, only reach outputs outside the image)
+            const uint8_t *src = g.src + (size_t)sy * g.sstride + min(max(sx, 0), wAl - 16);
+            glds16(src, __builtin_amdgcn_readfirstlane(ldsBase + 1024u * (uint32_t)j));
+        }
     }
 }
 
-// A workgroup takes BM_TPW consecutive tiles of a frame (same level row first: neighbours share their halo columns in L2) and
-// requests tile k + 1's pixels before it computes tile k.
-#define BM_TPW 1
+#define BM_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                               int stride0, unsigned long long frame0,
@@ -120,144 +146,163 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
                                               const BlurTile *__restrict__ tiles, const uint4 *__restrict__ bands, int xcdMap,
                                               int ntiles)
 {
-    __shared__ __align__(16) uint8_t s_raw[BM_IN][BM_PITCH];
-    __shared__ __align__(16) uint8_t s_out[64][BM_OP];         // rows 58..63: the unused part of the second result tile
+    // ONE shared array (a second __shared__ object can make the compiler wait for the transfers before LDS reads)
+    __shared__ __align__(16) uint8_t smem[2 * BM_IN * BM_PITCH + 64 * BM_OP];
+    uint8_t *const s_out0 = smem + 2 * BM_IN * BM_PITCH;         // [64][BM_OP]; rows 58..63: the unused part of the second result tile
     const int tile0 = xcd_tile(xcdMap) * BM_TPW, frame = blockIdx.y;
     if (tile0 >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
-    const int ntl = min(BM_TPW, ntiles - tile0);
+    const bool two = tile0 + 1 < ntiles;
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave's strip, as a scalar
-
-    BlurGeom g = blur_geom(G, tiles[tile0], frame, lvl0, stride0, frame0, pyr, pyrFrame, blur, blurFrame);
-    uint4 v[BM_NIT];
-    blur_fetch(g, tid, v);
 
     // the band operands of this lane (built on the host, launch_blur): 2 k-steps of the row pass, 4 of the column pass
     uint4 bq[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) bq[q] = bands[q * 64 + lane];
+    // (the tile descriptors are requested AFTER the band operands and needed first -- for the addresses below --, so the wait
+    // the compiler puts in front of their first use retires the band operands too: nothing it knows about is outstanding
+    // once the transfers are in flight, and it adds no wait of its own that would cover them)
+    asm volatile("" ::: "memory");
+    const BlurTile T0 = tiles[tile0], T1 = tiles[min(tile0 + 1, ntiles - 1)];
+    asm volatile("" :: "s"((int)T0.level + (int)T0.tx + (int)T0.ty), "s"((int)T1.level + (int)T1.tx + (int)T1.ty));
+    const BlurGeom g0 = blur_geom(G, T0, frame, lvl0, stride0, frame0, pyr, pyrFrame, blur, blurFrame);
+    const BlurGeom g1 = blur_geom(G, T1, frame, lvl0, stride0, frame0, pyr, pyrFrame, blur, blurFrame);
+    blur_dma(g0, smem, wv, lane);
+    if (two) blur_dma(g1, smem + BM_IN * BM_PITCH, wv, lane);
+    // tile 0 has landed when at most tile 1's transfers (4 on wave 0, 3 on the others) are outstanding (in-order return)
+    if (two) {
+        if (wv == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BM_RAW_BARRIER();
 
-    for (int tl = 0; tl < ntl; tl++) {
-        // ---- 1. raw tile: LDS column j <-> image column x0 - 16 + j, bytes xor 0x80 ----
-#pragma unroll
-        for (int k = 0; k < BM_NIT; k++) {
-            const int i = tid + k * 256;
-            const int r = i / BM_CH, c = i - r * BM_CH;
-            uint4 o = v[k];
-            o.x ^= 0x80808080u; o.y ^= 0x80808080u; o.z ^= 0x80808080u; o.w ^= 0x80808080u;
-            *reinterpret_cast<uint4 *>(&s_raw[r][c << 4]) = o;
-        }
-        const BlurGeom cur = g;
-        if (tl + 1 < ntl) {   // (block-uniform) the next tile's pixels travel while this one is computed
-            g = blur_geom(G, tiles[tile0 + tl + 1], frame, lvl0, stride0, frame0, pyr, pyrFrame, blur, blurFrame);
-            blur_fetch(g, tid, v);
-        }
-        __syncthreads();
-        const int w = cur.w, h = cur.h, x0 = cur.x0, y0 = cur.y0;
-        // reflected halo columns at the image edges (x = -1,-2,-3 <- 1,2,3 ; x = w,w+1,w+2 <- w-2,w-3,w-4): block-uniform
+#define S_RAW(r, c) raw[(r) * BM_PITCH + (c)]
+    // reflected halo columns at the image edges (x = -1,-2,-3 <- 1,2,3 ; x = w,w+1,w+2 <- w-2,w-3,w-4): block-uniform
+    auto edge_patch = [&](uint8_t *raw, const BlurGeom &cur) {
+        const int w = cur.w, x0 = cur.x0;
         const bool edgeL = x0 == 0, edgeR = x0 + BM_W + 3 > w;
         if (edgeL || edgeR) {
             if (edgeL)
                 for (int i = tid; i < BM_IN * 3; i += 256) {
                     const int r = i / 3, k = i - r * 3 + 1;
-                    s_raw[r][16 - k] = s_raw[r][16 + k];
+                    S_RAW(r, 16 - k) = S_RAW(r, 16 + k);
                 }
             if (edgeR)
                 for (int i = tid; i < BM_IN * 3; i += 256) {
                     const int r = i / 3, k = i - r * 3;
-                    s_raw[r][16 + (w + k - x0)] = s_raw[r][16 + (w - 2 - k - x0)];
+                    S_RAW(r, 16 + (w + k - x0)) = S_RAW(r, 16 + (w - 2 - k - x0));
                 }
-            __syncthreads();
+            BM_RAW_BARRIER();
         }
+    };
 
+    // stages 2 and 3: the strip of this wave, raw tile -> s_out
+    auto compute = [&](const uint8_t *raw, const BlurGeom &cur) {
+        const int w = cur.w, x0 = cur.x0;
         const int c0 = x0 + 32 * wv;            // first output column of this wave's strip
-        if (c0 < w) {                           // (wave-uniform; a strip right of the image has nothing to store)
-            // ---- 2. row pass: H[T][i] = 16-bit row sum at (row 32 T + tile_row(i, hh), column c0 + n), + 0x04000000 ----
-            v16i hinit;
-            v16f zinit;
+        if (c0 >= w) return;                    // (wave-uniform; a strip right of the image has nothing to store)
+        // ---- 2. row pass: H[T][i] = 16-bit row sum at (row 32 T + tile_row(i, hh), column c0 + n), + 0x04000000 ----
+        v16i hinit;
+        v16f zinit;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                hinit[i] = 128 * 257 + 0x04000000;
-                zinit[i] = -(float)(257 * 1024) / 65536.0f;            // minus sum_j tap_j * 1024 * 2^-16
+        for (int i = 0; i < 16; i++) {
+            hinit[i] = 128 * 257 + 0x04000000;
+            zinit[i] = -(float)(257 * 1024) / 65536.0f;            // minus sum_j tap_j * 1024 * 2^-16
+        }
+        v16i H[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            uint4 a0 = *reinterpret_cast<const uint4 *>(&S_RAW(32 * t + n, 32 * wv + 16 * hh));
+            uint4 a1 = *reinterpret_cast<const uint4 *>(&S_RAW(32 * t + n, 32 * wv + 32 + 16 * hh));
+            a0.x ^= 0x80808080u; a0.y ^= 0x80808080u; a0.z ^= 0x80808080u; a0.w ^= 0x80808080u;   // pixel - 128 as int8
+            a1.x ^= 0x80808080u; a1.y ^= 0x80808080u; a1.z ^= 0x80808080u; a1.w ^= 0x80808080u;
+            H[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a0), __builtin_bit_cast(v4i, bq[0]), hinit, 0, 0, 0);
+            H[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a1), __builtin_bit_cast(v4i, bq[1]), H[t], 0, 0, 0);
+        }
+        // ---- 3. column pass ----
+        // byte planes as binary16 pairs: slot j of k-step s of row tile t is register 8 s + j
+        uint4 lo[2][2], hi[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                uint32_t pl[4], ph[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t a = (uint32_t)H[t][8 * s + 2 * d], b = (uint32_t)H[t][8 * s + 2 * d + 1];
+                    pl[d] = __builtin_amdgcn_perm(b, a, 0x07040300u);   // a.b0 | 0x04 << 8 | b.b0 << 16 | 0x04 << 24
+                    ph[d] = __builtin_amdgcn_perm(b, a, 0x07050301u);   // a.b1 | 0x04 << 8 | b.b1 << 16 | 0x04 << 24
+                }
+                lo[t][s] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                hi[t][s] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
             }
-            v16i H[2];
+        const int wvec = w - (w & 3);
+        const bool tail = wvec < w && c0 <= wvec && wvec < c0 + 32;   // this strip holds the columns of the scalar tail (wave-uniform)
+        const int gT = (wvec - c0) >> 3, hT = ((wvec - c0) >> 2) & 1; // ... in register group gT of the lanes with hh == hT
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const uint4 a0 = *reinterpret_cast<const uint4 *>(&s_raw[32 * t + n][32 * wv + 16 * hh]);
-                const uint4 a1 = *reinterpret_cast<const uint4 *>(&s_raw[32 * t + n][32 * wv + 32 + 16 * hh]);
-                H[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a0), __builtin_bit_cast(v4i, bq[0]), hinit, 0, 0, 0);
-                H[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a1), __builtin_bit_cast(v4i, bq[1]), H[t], 0, 0, 0);
+        for (int t = 0; t < 2; t++) {
+            // result tile t: output rows 32 t + n (centre = raw row 32 t + n + 3); tile 0 draws on both row tiles, tile 1 on
+            // row tile 1 only, with the same band operands (the band only depends on raw row - output row)
+            v16f zl = zinit, zh = zinit;
+#pragma unroll
+            for (int q = 0; q < (t == 0 ? 4 : 2); q++) {
+                const int rt = t == 0 ? (q >> 1) : 1, s = q & 1;
+                const v8h bw = __builtin_bit_cast(v8h, bq[2 + q]);
+                zl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo[rt][s]), bw, zl, 0, 0, 0);
+                zh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, hi[rt][s]), bw, zh, 0, 0, 0);
             }
-            // ---- 3. column pass ----
-            // byte planes as binary16 pairs: slot j of k-step s of row tile t is register 8 s + j
-            uint4 lo[2][2], hi[2][2];
+            // lane (output row 32 t + n, hh), register 4 g + e: column c0 + 8 g + 4 hh + e
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int gg = 0; gg < 4; gg++) {
+                uint32_t packed = 0;
 #pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    uint32_t pl[4], ph[4];
+                for (int e = 0; e < 4; e++)
+                    packed = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]), e, packed);   // S * 2^-16, exact
+                *reinterpret_cast<uint32_t *>(&s_out0[(32 * t + n) * BM_OP + 32 * wv + 8 * gg + 4 * hh]) = packed;
+            }
+            if (tail) {
+                // scalar tail of the reference's column filter, (S + 32768) >> 16 = floor(S * 2^-16 + 0.5): the four columns
+                // from wvec on are written once more by the lanes that hold them (a real branch: one strip per level row)
 #pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        const uint32_t a = (uint32_t)H[t][8 * s + 2 * d], b = (uint32_t)H[t][8 * s + 2 * d + 1];
-                        pl[d] = __builtin_amdgcn_perm(b, a, 0x07040300u);   // a.b0 | 0x04 << 8 | b.b0 << 16 | 0x04 << 24
-                        ph[d] = __builtin_amdgcn_perm(b, a, 0x07050301u);   // a.b1 | 0x04 << 8 | b.b1 << 16 | 0x04 << 24
+                for (int gg = 0; gg < 4; gg++)
+                    if (gg == gT) {
+                        asm volatile("" ::: "memory");
+                        uint32_t packed = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            packed = __builtin_amdgcn_cvt_pk_u8_f32(floorf(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]) + 0.5f), e, packed);
+                        if (hh == hT) *reinterpret_cast<uint32_t *>(&s_out0[(32 * t + n) * BM_OP + 32 * wv + 8 * gg + 4 * hh]) = packed;
                     }
-                    lo[t][s] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-                    hi[t][s] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-                }
-            const int wvec = w - (w & 3);
-            const bool tail = wvec < w && c0 <= wvec && wvec < c0 + 32;   // this strip holds the columns of the scalar tail (wave-uniform)
-            const int gT = (wvec - c0) >> 3, hT = ((wvec - c0) >> 2) & 1; // ... in register group gT of the lanes with hh == hT
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                // result tile t: output rows 32 t + n (centre = raw row 32 t + n + 3); tile 0 draws on both row tiles, tile 1 on
-                // row tile 1 only, with the same band operands (the band only depends on raw row - output row)
-                v16f zl = zinit, zh = zinit;
-#pragma unroll
-                for (int q = 0; q < (t == 0 ? 4 : 2); q++) {
-                    const int rt = t == 0 ? (q >> 1) : 1, s = q & 1;
-                    const v8h bw = __builtin_bit_cast(v8h, bq[2 + q]);
-                    zl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo[rt][s]), bw, zl, 0, 0, 0);
-                    zh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, hi[rt][s]), bw, zh, 0, 0, 0);
-                }
-                // lane (output row 32 t + n, hh), register 4 g + e: column c0 + 8 g + 4 hh + e
-#pragma unroll
-                for (int gg = 0; gg < 4; gg++) {
-                    uint32_t packed = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        packed = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]), e, packed);   // S * 2^-16, exact
-                    *reinterpret_cast<uint32_t *>(&s_out[32 * t + n][32 * wv + 8 * gg + 4 * hh]) = packed;
-                }
-                if (tail) {
-                    // scalar tail of the reference's column filter, (S + 32768) >> 16 = floor(S * 2^-16 + 0.5): the four columns
-                    // from wvec on are written once more by the lanes that hold them (a real branch: one strip per level row)
-#pragma unroll
-                    for (int gg = 0; gg < 4; gg++)
-                        if (gg == gT) {
-                            asm volatile("" ::: "memory");
-                            uint32_t packed = 0;
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                                packed = __builtin_amdgcn_cvt_pk_u8_f32(floorf(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]) + 0.5f), e, packed);
-                            if (hh == hT) *reinterpret_cast<uint32_t *>(&s_out[32 * t + n][32 * wv + 8 * gg + 4 * hh]) = packed;
-                        }
-                }
             }
         }
-        __syncthreads();
+    };
 
-        // ---- 4. the output tile leaves with 16-byte stores (rows are padded to 64 bytes: a chunk that starts inside the
-        //         image may run into the padding) ----
+    // stage 4: s_out -> blurred level (16-byte stores; rows are padded to 64 bytes: a chunk that starts inside the image may run
+    // into the padding)
+    auto store = [&](const BlurGeom &cur) {
+        const int w = cur.w, h = cur.h, x0 = cur.x0, y0 = cur.y0;
         for (int i = tid; i < BM_H * (BM_W / 16); i += 256) {
             const int r = i >> 3, c = i & 7;
             const int y = y0 + r, x = x0 + (c << 4);
             if (y < h && x < w)
-                *reinterpret_cast<uint4 *>(cur.dst + (size_t)y * cur.dstride + x) = *reinterpret_cast<const uint4 *>(&s_out[r][c << 4]);
+                *reinterpret_cast<uint4 *>(cur.dst + (size_t)y * cur.dstride + x) = *reinterpret_cast<const uint4 *>(&s_out0[r * BM_OP + (c << 4)]);
         }
-        // (the next iteration writes s_raw, which every wave has finished reading before the barrier above, and s_out only
-        // after its own first barrier)
-    }
+    };
+    uint8_t *const raw0 = smem, *const raw1 = smem + BM_IN * BM_PITCH;
+    edge_patch(raw0, g0);
+    compute(raw0, g0);
+    // tile 1 has had a tile's computation to arrive; no store has been issued yet, so this wait covers loads only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BM_RAW_BARRIER();                     // s_out and (all waves' transfers of) tile 1 are complete
+    store(g0);
+    if (!two) return;
+    BM_RAW_BARRIER();                     // s_out is free again
+    edge_patch(raw1, g1);
+    compute(raw1, g1);
+    BM_RAW_BARRIER();
+    store(g1);
+#undef S_RAW
 }
 
 // cv::getGaussianKernel(7, 2, CV_32F) converted to CV_32S with scale 256 (filter.cpp
@@ -322,6 +367,7 @@ void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
                  const uint8_t *pyr, size_t pyrFrame, uint8_t *blur, size_t blurFrame,
                  const BlurTile *tiles, int ntiles, const uint32_t *bands, int B)
 {
+    if (ntiles <= 0) return;
     dim3 grid(orb_xcd_grid((ntiles + BM_TPW - 1) / BM_TPW, 2), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_blur, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, tiles,

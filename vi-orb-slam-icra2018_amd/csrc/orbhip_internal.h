@@ -286,7 +286,7 @@ size_t quadtree_table_scratch_bytes(const OrbLevels &G, int B);   // 0 when the 
 void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, uint8_t *blur, size_t blurFrame,
                  const BlurTile *tiles, int ntiles, const uint32_t *bands, int B);
-void blur_band_table(uint32_t out[6 * 64 * 4]);   // per-lane band operands of k_blur's two matrix products
+void blur_band_table(uint32_t out[6 * 64 * 4]);
 void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                      const uint8_t *pyr, size_t pyrFrame, const uint8_t *blur, size_t blurFrame,
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
