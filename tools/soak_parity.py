@@ -378,6 +378,22 @@ def main():
                 print("MISMATCH window_best", w, h, nf, seed, gate, ur is not None)
                 sys.exit(1)
             stats["fuse"] += int((a[1] <= 50).sum())
+            # the same search into a resident set, and SearchByBoW between resident sets (orbhip_set_*)
+            from orbhip.extractor import ORBmatcher
+            M = ORBmatcher(0.7, True, ctx=ex)
+            M.put_set(11, k1, d1, g[1], gp)
+            M.put_set(12, k0, d0, g[0], gp)
+            a2 = guided.WindowBestSet(ex, 11, qw, d0, ur, isg)
+            if not np.array_equal(a2[0], b_[0]) or not np.array_equal(a2[1], b_[1]):
+                print("MISMATCH window_best_set", w, h, nf, seed)
+                sys.exit(1)
+            v0 = (rng.random(len(k0)) < 0.8).astype(np.uint8)
+            a3 = M.SearchByBoW_sets(12, v0, len(k0), 11, None, len(k1))
+            b3 = oracle.search_by_bow(d0, v0, k0["angle"], g[0], d1, None, k1["angle"], g[1], th=50, th_mode=0, nnratio=0.7, check_ori=True)
+            if a3[0] != b3[0] or not np.array_equal(a3[1], b3[1]) or not np.array_equal(a3[2], b3[2]):
+                print("MISMATCH bow_sets", w, h, nf, seed)
+                sys.exit(1)
+            M.drop_set()
         ex.close()
         n += 1
     print("soak ok: %d random configurations in %.0f s, %s" % (n, time.time() - t0, stats))
