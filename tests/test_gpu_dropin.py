@@ -349,18 +349,21 @@ def test_cpp_grid_and_search_by_projection_match_oracle(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_fuse_sim3_and_keyframe_projection_match_host_restatement(tmp_path):
+@pytest.mark.parametrize("no_sets", ["0", "1"])
+def test_cpp_fuse_sim3_and_keyframe_projection_match_host_restatement(tmp_path, no_sets):
     """ORBmatcher::Fuse (both forms), SearchByProjection(KeyFrame*, Scw, ...) and SearchBySim3 through the drop-in
     classes (tests/native/test_fuse_dropin.cpp): two identical worlds, one through the HIP path and one through the
     routines restated on the host in that program (src/ORBmatcher.cc:290-403, 825-1326); map states must be equal.
-    Also the batched ComputeDistinctiveDescriptors helper against src/MapPoint.cc:283-349 restated."""
+    Also the batched ComputeDistinctiveDescriptors helper against src/MapPoint.cc:283-349 restated.
+    Both with the key frames resident on the device (orbhip_set_*, the default) and with ORBHIP_NO_SETS=1 (upload per call)."""
     from orbhip import synth
     exe = os.path.join(ROOT, "tests", "native", "test_fuse_dropin")
     assert os.path.exists(exe), "tests/native/test_fuse_dropin is not built (run __graft_entry__.build())"
     W, H = 640, 480
     frame = synth.make_frames(90, W, H, 1)[0]
     (tmp_path / "frame.raw").write_bytes(frame.tobytes())
-    r = subprocess.run([exe, str(W), str(H), "1500", str(tmp_path / "frame.raw")], capture_output=True, text=True)
+    r = subprocess.run([exe, str(W), str(H), "1500", str(tmp_path / "frame.raw")], capture_output=True, text=True,
+                       env=dict(os.environ, ORBHIP_NO_SETS=no_sets))
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": ok") == 13 and "all ok" in r.stdout, r.stdout
 
