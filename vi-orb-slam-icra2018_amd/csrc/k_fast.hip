@@ -19,6 +19,7 @@
 #include "orbhip_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 __device__ __forceinline__ const uint8_t *level_ptr(const OrbLevels &G, int l, int frame,
                                                     const uint8_t *lvl0, int stride0,
@@ -81,7 +82,8 @@ __device__ __forceinline__ int arcs_score(const uint32_t P[8], uint32_t C, int v
 
 // FAST score of the pixel at p, 0 if it is not a corner at threshold t (t >= 1).  bright (q - v > t): max_arcs min_arc (q - v) - 1 = (max_arcs min_arc q) - v - 1; dark: the same
 // on the complemented bytes, v - q = (255 - q) - (255 - v).
-__device__ __forceinline__ int fast_score_win(const uint8_t *pix, int off, int pitch, int t)
+template <bool DEFER>
+__device__ __forceinline__ int fast_score_win(const uint8_t *pix, int off, int pitch, int t, bool *other)
 {
     // pix + off = top-left corner of the pixel's 7x7 window.  Every ring pixel as a non-negative offset from the top-left corner of the 7x7 window: with a compile-time pitch the 17
     // loads share one address register (ds_read_u8 offset:imm), with a run-time pitch they need one add per window row.
@@ -109,13 +111,50 @@ __device__ __forceinline__ int fast_score_win(const uint8_t *pix, int off, int p
     P[6] = ((uint32_t)w[P1 + 5] | ((uint32_t)w[P5 + 1] << 16));         // (+2, -2) | (-2, +2)
     P[7] = ((uint32_t)w[4] | ((uint32_t)w[P6 + 2] << 16));              // (+1, -3) | (-1, +3)
     int sc = arcs_score(P, C, v0 ^ (dark ? 0xFF : 0));
-    if (pb && pd) sc = max(sc, arcs_score(P, 0x40FF40FFu, v0 ^ 0xFF));   // both possible (rare): the dark one as well
+    if (DEFER) {
+        // The dark arcs of a pixel whose compass points admit both polarities are left to the caller (a 9-arc of one
+        // polarity excludes one of the other, so a bright corner is final): 7-12 % of the work-list entries are such
+        // pixels, i.e. practically every wave holds one, and evaluating them in place makes every wave pay both polarities.
+        *other = pb && pd && sc < t;
+    } else if (pb && pd)
+        sc = max(sc, arcs_score(P, 0x40FF40FFu, v0 ^ 0xFF));   // both possible: the dark one as well
+    return sc >= t ? sc : 0;
+}
+
+// the dark-polarity score alone (second half of a deferred entry)
+__device__ __forceinline__ int fast_score_dark(const uint8_t *pix, int off, int pitch, int t)
+{
+    asm volatile("" : "+v"(off));
+    const uint8_t *w = pix + off;
+    const int P1 = pitch, P2 = 2 * pitch, P3 = 3 * pitch, P4 = 4 * pitch, P5 = 5 * pitch, P6 = 6 * pitch;
+    const int v0 = w[P3 + 3];
+    uint32_t P[8];
+    P[0] = ((uint32_t)w[P6 + 3] | ((uint32_t)w[3] << 16));
+    P[1] = ((uint32_t)w[P6 + 4] | ((uint32_t)w[2] << 16));
+    P[2] = ((uint32_t)w[P5 + 5] | ((uint32_t)w[P1 + 1] << 16));
+    P[3] = ((uint32_t)w[P4 + 6] | ((uint32_t)w[P2] << 16));
+    P[4] = ((uint32_t)w[P3 + 6] | ((uint32_t)w[P3] << 16));
+    P[5] = ((uint32_t)w[P2 + 6] | ((uint32_t)w[P4] << 16));
+    P[6] = ((uint32_t)w[P1 + 5] | ((uint32_t)w[P5 + 1] << 16));
+    P[7] = ((uint32_t)w[4] | ((uint32_t)w[P6 + 2] << 16));
+    const int sc = arcs_score(P, 0x40FF40FFu, v0 ^ 0xFF);
     return sc >= t ? sc : 0;
 }
 
 __device__ __forceinline__ int fast_score_pol(const uint8_t *p, int pitch, int t)
 {
-    return fast_score_win(p, -3 * pitch - 3, pitch, t);
+    return fast_score_win<false>(p, -3 * pitch - 3, pitch, t, nullptr);
+}
+
+// 16 bytes per lane from global memory straight into LDS at (ldsAddr + 16 * lane): global_load_lds_dwordx4 in assembly (the
+// builtin makes hipcc wait vmcnt(0) at every LDS access that might alias); M0 carries the LDS address and is restored.
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t ldsAddr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(ldsAddr)
+                 : "memory");
 }
 
 // inclusive wave prefix sum on the DPP network (row shifts, then the row totals of the lower rows)
@@ -461,7 +500,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
             for (int e = tid; e < nlist; e += 256) {
                 const int ent = s_list[e];
                 const int r = ent >> 9, j = ent & 511;
-                const int s = fast_score_win(s_pix, __mul24(r, pitch) + (j - 3), pitch, t);
+                const int s = fast_score_win<false>(s_pix, __mul24(r, pitch) + (j - 3), pitch, t, nullptr);
                 if (s > 0) {
                     s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
                     // one returning LDS add per corner (a fifth of the lanes; hipcc's wave aggregation of atomicAdd(p, 1) costs
@@ -577,6 +616,397 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
     if (tid < T.ncells) cnt[tid] = (uint16_t)s_cellCnt[tid];
 }
 
+
+// =====================================================================================================================
+// k_fast_fix (r03): the same algorithm as k_fast above for the usual grid (30-pixel cells: runs of <= 6 cells, staged rows of
+// <= 208 bytes, cells <= 34 rows), written against what the r02 kernel's counters showed in round 3 -- a sixth of its vector
+// instructions were not FAST at all but the prologue: the run's geometry derived in every workgroup, everything invariant
+// hoisted out of the two-pass loop (including the divisions and per-thread tables of paths that hardly ever run) and,
+// because that keeps ~130 uniform values alive, 54 of them parked in lanes of a vector register and fetched back one
+// v_readlane at a time.  Here
+//   * the geometry of the run is read from its FastTile (orb_build_geometry computes it once per image size);
+//   * every LDS array has a compile-time address (only the score tile's extent varies): no base registers, immediate offsets;
+//   * the two passes are two instantiations of one body, and what only pass 1 or a fallback path needs is computed there
+//     (an empty asm on its inputs keeps the compiler from hoisting it into the common path);
+//   * the pixel tile arrives by LDS-DMA (global_load_lds_dwordx4: no registers, no vector work per chunk);
+//   * compass pass: a thread owns one dword column and a SEGMENT of consecutive rows, so every load of every item is at an
+//     immediate offset from one register and "does item i exist" is a workgroup-uniform question; the survivor bits of an
+//     item are gathered into a nibble by v_dot4_u32_u8, which makes a list entry (group << 9 | row << 2 | pixel) the
+//     entry of the thread's first pixel plus the bit position: one add;
+//   * score pass: of a pixel whose compass points admit both polarities only the bright arcs are evaluated in place; if
+//     they make no corner the entry is parked and the dark arcs of all parked entries are evaluated by dense lanes afterwards
+//     (7-12 % of the entries are such pixels, so practically every wave paid for both polarities of all its 64 entries).
+// Tiles outside these bounds (other cell sizes, ORBHIP_FAST_PITCH=0) run k_fast<0>.
+// =====================================================================================================================
+#define FF_RHM 40                      // staged rows (hCell + 6) the fixed layout holds
+#define FF_DHM (FF_RHM - 6)
+#define FF_NCM 5                       // cells per run
+#define FF_LISTCAP 1664                // work list entries  (a third of the largest tile's pixels: 156 x 32 / 3)
+#define FF_CORNERCAP 640               // corner list entries (an eighth)
+#define FF_GRPM 64                     // dword groups per row
+
+template <int PITCH, bool DEFER>
+__global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__ lvl0, int stride0, unsigned long long frame0,
+                                                     const uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
+                                                     const FastTile *__restrict__ tiles, uint32_t *__restrict__ cand,
+                                                     uint16_t *__restrict__ cellCnt, int totalCells, int totalCands, int iniTh,
+                                                     int minTh, int listCap, int cornerCap, int phases, int xcdMap, int ntiles)
+{
+    __shared__ __align__(16) uint8_t s_pix[PITCH * FF_RHM];
+    __shared__ unsigned long long s_bits[FF_NCM * FF_DHM];   // [cell][row]: survivors of the row (wCell < 64)
+    __shared__ uint16_t s_list[FF_LISTCAP];
+    int *const s_pre = reinterpret_cast<int *>(s_list);      // [cell][row] row prefix of phase 5 (the work list is dead by then)
+    static_assert(FF_NCM * FF_DHM * 4 <= FF_LISTCAP * 2, "s_pre aliases s_list");
+    __shared__ uint16_t s_corner[FF_CORNERCAP];
+    __shared__ uint32_t s_dom[FF_GRPM];   // per dword group of the pass: which of its 4 pixels are tested (bit 8k + 7)
+    __shared__ uint8_t s_grp[FF_GRPM];
+    __shared__ int s_cellAny[8], s_cellCnt[8];
+    __shared__ int s_listCount, s_cornerCount, s_nAct, s_deferCount;
+    extern __shared__ __align__(16) uint8_t s_score[];       // [DH][SP]
+
+    const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
+    if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
+    const FastTile &T = tiles[tileId];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int DH = T.DH, TW = T.TW, ncells = T.nc;
+    if (DH == 0) {
+        if (tid < ncells) cellCnt[(size_t)frame * totalCells + T.cntOff + tid] = 0;
+        return;
+    }
+    constexpr int pitch = PITCH;
+    const int RH = T.RH, nchunk = T.nchunk, j0 = T.j0, jd0 = j0 & ~3, GPR = T.GPR;
+    const int SP = (TW + 3) & ~3;
+    const int nrowsAll = ncells * DH;
+
+    // ---- 1. stage pixels [iniY, iniY + RH) x [xa, xa + 16 nchunk) by LDS-DMA; clear the score tile and the bitmap ----
+    {
+        // a wave transfer writes 64 x 16 bytes to consecutive LDS addresses, so with the row pitch a multiple of 16
+        // lane = row * (PITCH / 16) + chunk covers 64 / (PITCH / 16) whole rows; the address per lane is built once, a round
+        // adds a multiple of the stride.  Waited for (vmcnt) before the barrier below: the compiler does not know of them.
+        const bool isL0 = T.lvlOff == 0xFFFFFFFFu;
+        const int stride = isL0 ? stride0 : T.stride;
+        const uint8_t *img = isL0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + T.lvlOff;
+        const uint8_t *img0 = img + (unsigned)(__mul24(T.iniY, stride) + T.xa);
+        constexpr int CPW = PITCH / 16, RPW = 64 / CPW;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int rl = lane / CPW, ch = lane - rl * CPW;
+        const bool laneOk = rl < RPW && ch < nchunk;
+        const uint8_t *src = img0 + (unsigned)(__mul24(rl, stride) + (ch << 4));
+        const uint32_t ldsBase = (uint32_t)(uintptr_t)s_pix;
+        for (int rb = wv * RPW; rb < RH; rb += 4 * RPW)
+            if (laneOk && rb + rl < RH) glds16(src + (unsigned)__mul24(rb, stride), ldsBase + (uint32_t)(rb * PITCH));
+    }
+    for (int i = tid; i < (DH * SP + 15) >> 4; i += 256) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < nrowsAll; i += 256) s_bits[i] = 0ull;
+    // pass 0 tests every domain pixel: the mask of a group is its overlap with [0, TW)
+    if (tid < GPR) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((unsigned)(jd0 + (tid << 2) + k - j0) < (unsigned)TW) m |= 0x80u << (8 * k);
+        s_dom[tid] = m;
+    }
+    if (tid < 8) {
+        s_cellAny[tid] = 0;
+        s_cellCnt[tid] = 0;
+    }
+    if (tid == 0) {
+        s_listCount = 0;
+        s_cornerCount = 0;
+        s_nAct = 0;
+        s_deferCount = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (phases < 2) return;   // timing ablation only (ORBHIP_FAST_PHASES), results are then invalid
+
+    const int wCell = T.wCell;
+    const unsigned cellMagic = (unsigned)T.cellMagic;
+    // list entries (16 bits): (dword group of the row << 9) | (row << 2) | pixel within the group; LDS column = jd0 + 4 group + pixel
+#define ENT_ROW(e) (((e) >> 2) & 127)
+#define ENT_COL(e) (jd0 + (((e) >> 9) << 2) + ((e) & 3))
+#define ENT_MAKE(r, j) (((((j) - jd0) >> 2) << 9) | ((r) << 2) | (((j) - jd0) & 3))
+
+    // One pass: compass test + work list, arc score + corner list, suppression -> bitmap.  Returns false when an ablation stop ends the kernel.
+    auto run_pass = [&](auto passTag, const int t, const unsigned cellMask, const int nAct, const int nthr) -> bool {
+        constexpr int PASS = decltype(passTag)::value;
+        const CompassK CK = compass_consts(t);
+        // ---- 2. compass pre-test, 4 pixels per item; survivors -> work list ----
+        if ((tid & ~63) < nthr) {
+            // thread -> (dword column, segment of consecutive rows): tid = sidx * nAct + slot
+            int sidx, seg;
+            if (PASS == 0) {
+                sidx = (int)(((unsigned)tid * (unsigned)T.grpMagic) >> 16);
+                seg = T.seg;
+            } else {
+                // (v_rcp_f32 is within 1 ulp: the products below are off by < 2^-13, the quotients are >= 1 / (2 n) away from an integer)
+                const float invAct = __builtin_amdgcn_rcpf((float)nAct);
+                sidx = (int)(((float)tid + 0.5f) * invAct);
+                const int S = __builtin_amdgcn_readfirstlane((int)(((float)nthr + 0.5f) * invAct));            // >= 1
+                seg = __builtin_amdgcn_readfirstlane((int)(((float)(DH + S - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)S)));
+            }
+            const int slot = tid - __mul24(sidx, nAct);
+            const int rs = __mul24(sidx, seg);               // first row of my segment
+            const bool mine = rs < DH;
+            const int g = PASS == 0 ? slot : (int)s_grp[slot];
+            const int jd = jd0 + (g << 2);
+            const uint32_t dom = mine ? s_dom[slot] : 0u;   // domain / active-cell mask of my four pixels (pixel k at bit 8k + 7)
+            const uint32_t listCountAddr = (uint32_t)(uintptr_t)&s_listCount;   // LDS byte address (low half of the flat address)
+            // the item's five dwords at non-negative offsets from (row - 3, column - 4): top | left, centre, right | bottom
+            const uint8_t *win = s_pix + __mul24(mine ? rs : 0, pitch) + (jd - 4);
+            if (phases == 11) return false;   // ablation only: the set-up of the compass phase
+            for (int cb = 0; cb < seg; cb += 8) {
+                // survivors of item i as the nibble i of acc (pixel k at bit 4 i + k), gathered from the bits 7 of the four
+                // bytes by v_dot4_u32_u8 with the weights 1 2 4 8 (even items) / 16 32 64 128 (odd): the sum lands 7 bits up
+                uint32_t a01 = 0, a23 = 0, a45 = 0, a67 = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (cb + i < seg) {   // uniform
+                        const uint8_t *wi = win + i * pitch;
+                        const uint32_t Tw = *reinterpret_cast<const uint32_t *>(wi + 4);
+                        const uint32_t Lw = *reinterpret_cast<const uint32_t *>(wi + 3 * pitch);
+                        const uint32_t Cw = *reinterpret_cast<const uint32_t *>(wi + 3 * pitch + 4);
+                        const uint32_t Rw = *reinterpret_cast<const uint32_t *>(wi + 3 * pitch + 8);
+                        const uint32_t Bw = *reinterpret_cast<const uint32_t *>(wi + 6 * pitch + 4);
+                        const uint32_t lft = __builtin_amdgcn_alignbyte(Cw, Lw, 1);   // bytes L1 L2 L3 C0 (column - 3)
+                        const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
+                        const uint32_t z = compass4(Cw, Tw, Bw, lft, rgt, CK) & dom;   // bits 7 of the bytes only
+                        const uint32_t W = (i & 1) ? 0x80402010u : 0x08040201u;
+                        uint32_t &a = i < 2 ? a01 : i < 4 ? a23 : i < 6 ? a45 : a67;
+                        a = __builtin_amdgcn_udot4(z, W, a, false);
+                    }
+                }
+                uint32_t acc = (a01 >> 7) | (a23 << 1) | (a45 << 9) | (a67 << 17);
+                // rows of the last segment below the domain were computed on whatever lies there: drop them
+                const int live = DH - rs - cb;   // (<= 0 only for threads that are not `mine`)
+                if (live < 8) acc &= (1u << (4 * max(live, 0))) - 1u;
+                win += 8 * pitch;
+                // append this thread's survivors to the work list (order is irrelevant): one returning LDS add per thread
+                // claims its range.  A thread whose entries do not all fit writes none: s_listCount then exceeds listCap
+                // and phase 3 takes the fallback.
+                const int n = __popc(acc);
+                if (phases == 12) {   // ablation only: the compass items without the list
+                    if (n == 77) s_list[0] = (uint16_t)n;
+                    continue;
+                }
+                if (n > 0) {
+                    // (inline asm: hipcc's atomic optimiser would turn a plain atomicAdd of a per-lane value back into a DPP scan)
+                    int base;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(listCountAddr), "v"(n) : "memory");
+                    if (base + n <= listCap) {
+                        uint16_t *dst = s_list + base;
+                        const int entBase = (g << 9) | ((rs + cb) << 2);
+                        while (acc) {
+                            const int b = __ffs(acc) - 1;
+                            acc &= acc - 1;
+                            *dst++ = (uint16_t)(entBase + b);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (phases < 3 + 3 * PASS || phases == 12 || phases == 11) return false;   // ablation stops: 2-4 = phases of pass 0, 5-7 = of pass 1
+
+        // ---- 3. full score on the work list; corners (score >= t) -> score tile + corner list ----
+        // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel of the
+        // active cells is scored instead (the compass test is the early-out of fast_score_pol); if it has more corners
+        // than the corner list holds, phase 4 scans the score tile.  Both fallbacks produce the same result.
+        const int nlist = s_listCount;
+#ifdef FAST_DEBUG_PRINT
+        if (tid == 0 && frame == 0) printf("FASTDBG tile %d pass %d nlist %d DH %d TW %d GPR %d seg %d\n", tileId, PASS, nlist, DH, TW, GPR, (int)T.seg);
+#endif
+        const uint32_t cornerCountAddr = (uint32_t)(uintptr_t)&s_cornerCount;
+        auto put_corner = [&](int ent, int r, int j, int s) {
+            s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
+            // one returning LDS add per corner (a fifth of the lanes; hipcc's wave aggregation of atomicAdd(p, 1) costs
+            // a dozen vector instructions per iteration for every lane)
+            int slot;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(cornerCountAddr), "v"(1) : "memory");
+            if (slot < cornerCap) s_corner[slot] = (uint16_t)ent;
+        };
+        if (nlist <= listCap) {
+            if (DEFER) {
+                const uint32_t deferCountAddr = (uint32_t)(uintptr_t)&s_deferCount;
+                for (int e = tid; e < nlist; e += 256) {
+                    const int ent = s_list[e];
+                    const int r = ENT_ROW(ent), j = ENT_COL(ent);
+                    bool other;
+                    int s = fast_score_win<true>(s_pix, __mul24(r, pitch) + (j - 3), pitch, t, &other);
+                    if (other) {
+                        // park the entry at the unused end of the work list (slots >= nlist are never read by this loop);
+                        // if the list is full to that point, finish the pixel here
+                        int d;
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(deferCountAddr), "v"(1) : "memory");
+                        const int idx = listCap - 1 - d;
+                        if (idx >= nlist) s_list[idx] = (uint16_t)ent;
+                        else s = fast_score_dark(s_pix, __mul24(r, pitch) + (j - 3), pitch, t);
+                    }
+                    if (s > 0) put_corner(ent, r, j, s);
+                }
+                __syncthreads();
+                // the parked entries, dark polarity only (dense lanes again)
+                const int ndefer = min(s_deferCount, listCap - nlist);
+                for (int e = tid; e < ndefer; e += 256) {
+                    const int ent = s_list[listCap - 1 - e];
+                    const int r = ENT_ROW(ent), j = ENT_COL(ent);
+                    const int s = fast_score_dark(s_pix, __mul24(r, pitch) + (j - 3), pitch, t);
+                    if (s > 0) put_corner(ent, r, j, s);
+                }
+            } else {
+                for (int e = tid; e < nlist; e += 256) {
+                    const int ent = s_list[e];
+                    const int r = ENT_ROW(ent), j = ENT_COL(ent);
+                    const int s = fast_score_win<false>(s_pix, __mul24(r, pitch) + (j - 3), pitch, t, nullptr);
+                    if (s > 0) put_corner(ent, r, j, s);
+                }
+            }
+        } else {
+            int TWx = TW;
+            asm volatile("" : "+s"(TWx));            // (keeps the division below inside this branch)
+            const float invTW = 1.0f / (float)TWx;   // px / TW = floor((px + 0.5) * invTW): exact for every px < DH * TW (a 20-bit
+                                                      // integer reciprocal is NOT: it fails from px ~ 2^20 / TW on, e.g. TW 155, DH 45)
+            for (int p0 = 0; p0 < DH * TWx; p0 += 256) {
+                const int px = p0 + tid;
+                int ent = 0, s = 0;
+                if (px < DH * TWx) {
+                    const int r = (int)(((float)px + 0.5f) * invTW);
+                    const int c = px - r * TWx;
+                    if ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u) {
+                        s = fast_score_pol(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
+                        if (s > 0) s_score[r * SP + c] = (uint8_t)s;
+                    }
+                    ent = ENT_MAKE(r, j0 + c);
+                }
+                const int slot = wave_append(s > 0, &s_cornerCount, lane);
+                if (slot >= 0 && slot < cornerCap) s_corner[slot] = (uint16_t)ent;
+            }
+        }
+        __syncthreads();
+        if (phases < 4 + 3 * PASS) return false;
+
+        // ---- 4. NMS over the corners (cell-local neighbourhood); every survivor is final: set its bit ----
+        const int ncorner = s_cornerCount;
+#ifdef FAST_DEBUG_PRINT
+        if (tid == 0 && frame == 0) printf("FASTDBG tile %d pass %d ncorner %d ndefer %d\n", tileId, PASS, ncorner, s_deferCount);
+#endif
+        if (ncorner <= cornerCap) {
+            for (int e = tid; e < ncorner; e += 256) {
+                const int ent = s_corner[e];
+                const int r = ENT_ROW(ent), c = ENT_COL(ent) - j0;
+                const int cj = (int)(((unsigned)c * cellMagic) >> 16);
+                if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) {
+                    atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * wCell));
+                    s_cellAny[cj] = 1;   // benign race: every writer stores 1
+                }
+            }
+        } else {
+            // fallback: scan the score tile, 4 pixels per dword; only the active cells' corners of this pass (score >= t)
+            int SPx = SP;
+            asm volatile("" : "+s"(SPx));
+            const int SPW = SPx >> 2;                                       // score dwords per row
+            const unsigned spwMagic = (1u << 20) / (unsigned)SPW + 1u;
+            const int nwords = DH * SPW;
+            for (int i = tid; i < nwords; i += 256) {
+                const uint32_t w = reinterpret_cast<const uint32_t *>(s_score)[i];
+                if (w == 0) continue;
+                const int r = (int)(((unsigned)i * spwMagic) >> 20);
+                const int cb = (i - r * SPW) << 2;
+                for (int k = 0; k < 4; k++) {
+                    const int s = (w >> (8 * k)) & 0xFF;
+                    const int c = cb + k;
+                    if (s < t || c >= TW) continue;
+                    const int cj = (int)(((unsigned)c * cellMagic) >> 16);
+                    if (!((cellMask >> cj) & 1u)) continue;
+                    if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) {
+                        atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * wCell));
+                        s_cellAny[cj] = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        return phases >= 5 + 3 * PASS;
+    };
+
+    // pass 0: every cell at iniThFAST (a threshold of 255 admits no corner: no pixel differs from its centre by more)
+    const unsigned allCells = (1u << ncells) - 1u;
+    if (iniTh < 255)
+        if (!run_pass(std::integral_constant<int, 0>{}, iniTh, allCells, GPR, 256)) return;
+    // pass 1: the cells without a survivor at minThFAST (block-uniform decisions); FAST(ini) empty => FAST(min >= ini) empty
+    if (minTh < iniTh && minTh < 255) {
+        unsigned cellMask = 0;
+        for (int cj = 0; cj < ncells; cj++)
+            if (!s_cellAny[cj]) cellMask |= 1u << cj;
+        if (cellMask) {
+            int tidp = tid;
+            asm volatile("" : "+v"(tidp));   // (what follows is pass 1's alone: not to be hoisted above the branch)
+            // dword groups that hold a domain pixel of an active cell (any order)
+            if (tidp < GPR) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = jd0 + (tidp << 2) + k - j0;
+                    if ((unsigned)c < (unsigned)TW && ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u)) m |= 0x80u << (8 * k);
+                }
+                if (m) {
+                    const int a = atomicAdd(&s_nAct, 1);
+                    s_grp[a] = (uint8_t)tidp;
+                    s_dom[a] = m;
+                }
+            }
+            if (tid == 0) {
+                s_listCount = 0;
+                s_cornerCount = 0;
+                s_deferCount = 0;
+            }
+            __syncthreads();
+            const int nAct = s_nAct;
+            // threads taking part: about one per five items (whole waves), so that a tile with one empty cell does not pay four
+            // waves' worth of fixed cost for 300 items
+            const int want = (__mul24(nAct, DH) + 319) / 320;            // waves at ~5 items per thread
+            const int need = (nAct + 63) >> 6;                           // at least one thread per column
+            const int nthr = min(4, max(want, need)) << 6;
+            if (!run_pass(std::integral_constant<int, 1>{}, minTh, cellMask, nAct, nthr)) return;
+        }
+    }
+
+    // ---- 5. rank inside the cell (= raster order) from the bitmap, write the slots ----
+    // The rank of a survivor is the number of bits before it: a prefix over the rows of its cell plus a popcount inside its
+    // row -- no survivor is ever compared with another one.  (DH <= 34: one wave per cell, one lane per row.)
+    for (int cj = tid >> 6; cj < ncells; cj += 4) {
+        const int n = lane < DH ? __popcll(s_bits[cj * DH + lane]) : 0;
+        const int incl = wave_incl_scan_dpp(n);
+        if (lane < DH) s_pre[cj * DH + lane] = incl - n;
+        if (lane == 63) s_cellCnt[cj] = incl;
+    }
+    __syncthreads();
+    {
+        const unsigned dhMagic = (unsigned)T.dhMagic;
+        uint32_t *candRun = cand + (size_t)frame * totalCands + T.candOff;
+        const int cellCap = T.cellCap, py0 = T.py0, px0 = T.px0;
+        for (int i = tid; i < nrowsAll; i += 256) {
+            unsigned long long bits = s_bits[i];
+            if (bits == 0ull) continue;
+            const int cj = (int)(((unsigned)i * dhMagic) >> 16), r = i - cj * DH;
+            int rank = s_pre[i];
+            uint32_t *slot = candRun + __mul24(cj, cellCap);
+            const int py = py0 + r;                                           // relative to (16,16), :824-825
+            const int pxBase = px0 + cj * wCell;
+            const uint8_t *sc = s_score + r * SP + cj * wCell;
+            while (bits) {
+                const int cl = __ffsll((long long)bits) - 1;
+                bits &= bits - 1ull;
+                slot[rank++] = (uint32_t)(pxBase + cl) | ((uint32_t)py << 12) | ((uint32_t)sc[cl] << 24);
+            }
+        }
+    }
+    if (tid < ncells) cellCnt[(size_t)frame * totalCells + T.cntOff + tid] = (uint16_t)s_cellCnt[tid];
+#undef ENT_ROW
+#undef ENT_COL
+#undef ENT_MAKE
+}
+
 void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
                  uint32_t *cand, uint16_t *cellCnt, int B)
@@ -610,6 +1040,9 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     // bitmap and row prefix per (cell, row).  Tiles that exceed the lists take the exact fallback paths.
     const int px = listBytes / 2;                      // sp * hCell of the largest tile
     int listCap = px / 4, cornerCap = px / 16;
+    // (the fixed-layout kernel: a third and an eighth -- on densely textured frames 5 % of the runs exceeded a quarter /
+    // a sixteenth, and their fallbacks (every pixel scored; score tile scanned) were a third of the kernel's score work)
+    const int listCapFix = std::min(px / 3, FF_LISTCAP), cornerCapFix = std::min(px / 8, FF_CORNERCAP);
     if (forced > 0) listCap = cornerCap = forced;
     const int lBytes = (listCap * 2 + 15) & ~15, cBytes = (cornerCap * 2 + 15) & ~15;
     const int bitsBytes = (bitsRows * 8 + 15) & ~15, preBytes = (bitsRows * 4 + 15) & ~15;
@@ -619,6 +1052,33 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     const int fixed = pitchEnv == 0 ? 0 : maxPitch <= 176 ? 176 : maxPitch <= 192 ? 192 : maxPitch <= 208 ? 208 : 0;
     if (fixed) pixBytes = (fixed * maxRh + 15) & ~15;
     const size_t lds = (size_t)(pixBytes + scoreBytes + lBytes + cBytes + bitsBytes + preBytes);
+    // the fixed-layout kernel when every level fits its bounds (ORBHIP_FAST_FIX=0: the generic kernel)
+    static const int fixEnv = getenv("ORBHIP_FAST_FIX") ? atoi(getenv("ORBHIP_FAST_FIX")) : 1;
+    static const int deferEnv = getenv("ORBHIP_FAST_DEFER") ? atoi(getenv("ORBHIP_FAST_DEFER")) : 1;
+    const int maxCells = fast_tile_cells();   // the configured run length bounds every tile's
+    if (fixEnv && fixed && maxRh <= FF_RHM && maxCells <= FF_NCM) {
+        const int lc = forced > 0 ? std::min(forced, FF_LISTCAP) : listCapFix, cc = forced > 0 ? std::min(forced, FF_CORNERCAP) : cornerCapFix;
+        const size_t ldsScore = (size_t)scoreBytes + 16;
+#define ORB_LAUNCH_FIX(P, D)                                                                                                 \
+    hipLaunchKernelGGL((k_fast_fix<P, D>), grid, block, ldsScore, s, lvl0, stride0, (unsigned long long)frame0, pyr,         \
+                       (unsigned long long)pyrFrame, tiles, cand, cellCnt, G.totalCells, G.totalCands, G.iniTh, G.minTh, lc, \
+                       cc, phases, orb_xcd_arg(), ntiles)
+        if (deferEnv) {
+            switch (fixed) {
+            case 176: ORB_LAUNCH_FIX(176, true); break;
+            case 192: ORB_LAUNCH_FIX(192, true); break;
+            default: ORB_LAUNCH_FIX(208, true); break;
+            }
+        } else {
+            switch (fixed) {
+            case 176: ORB_LAUNCH_FIX(176, false); break;
+            case 192: ORB_LAUNCH_FIX(192, false); break;
+            default: ORB_LAUNCH_FIX(208, false); break;
+            }
+        }
+#undef ORB_LAUNCH_FIX
+        return;
+    }
 #define ORB_LAUNCH_FAST(P)                                                                                                   \
     hipLaunchKernelGGL(k_fast<P>, grid, block, lds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                    \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, pixBytes, scoreBytes, lBytes, cBytes, bitsBytes,  \

@@ -148,6 +148,48 @@ bool orb_build_resize_groups(const std::vector<int32_t> &xtab, const std::vector
     return true;
 }
 
+// The derived fields of a FAST run (same arithmetic as the generic kernel's prologue, k_fast.hip).
+void fast_tile_geometry(const OrbLevels &G, FastTile &t)
+{
+    const OrbLevel &L = G.lv[t.level];
+    const int maxBX = L.w - ORB_MIN_BORDER, maxBY = L.h - ORB_MIN_BORDER;
+    const int iniY = ORB_MIN_BORDER + t.row * L.hCell;
+    const int X0 = ORB_MIN_BORDER + t.c0 * L.wCell;
+    int maxY = iniY + L.hCell + 6;
+    if (maxY > maxBY) maxY = maxBY;
+    int X1 = ORB_MIN_BORDER + (t.c0 + t.ncells) * L.wCell + 6;
+    if (X1 > maxBX) X1 = maxBX;
+    const bool rowLive = iniY < maxBY - 3;
+    int DH = rowLive ? maxY - iniY - 6 : 0, TW = X1 - X0 - 6;
+    if (DH <= 0 || TW <= 0) DH = TW = 0;
+    const int XA = X0 & ~15;
+    t.nc = t.ncells;
+    t.iniY = iniY;
+    t.xa = XA;
+    t.RH = (DH ? maxY - iniY : 0);
+    t.nchunk = (DH ? (X1 - XA + 15) >> 4 : 0);
+    t.DH = DH;
+    t.TW = TW;
+    const int j0 = X0 + 3 - XA;
+    t.j0 = j0;
+    const int GPR = DH ? ((j0 + TW + 3) >> 2) - (j0 >> 2) : 1;
+    t.GPR = GPR;
+    t.wCell = L.wCell;
+    const int S = std::max(1, 256 / GPR);
+    t.seg = (DH ? (DH + S - 1) / S : 1);
+    t.py0 = (iniY + 3 - ORB_MIN_BORDER);
+    t.px0 = (X0 + 3 - ORB_MIN_BORDER);
+    t.cellMagic = (int)(65536u / (unsigned)L.wCell + 1u);
+    t.grpMagic = (int)(65536u / (unsigned)GPR + 1u);
+    t.dhMagic = (int)(65536u / (unsigned)std::max(DH, 1) + 1u);
+    t.cntOff = L.cellBase + t.row * L.nCols + t.c0;
+    t.candOff = L.candBase + (t.row * L.nCols + t.c0) * L.cellCap;
+    t.cellCap = L.cellCap;
+    t.stride = L.stride;
+    t.lvlOff = t.level == 0 ? 0xFFFFFFFFu : (unsigned)L.imgOff;
+    t.pad = 0;
+}
+
 int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
 {
     OrbLevels &G = c->G;
@@ -210,7 +252,7 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
         const int nruns = (L.nCols + tileCells - 1) / tileCells, runBase = L.nCols / nruns, runExtra = L.nCols % nruns;
         for (int i = 0; i < L.nRows; i++)
             for (int r = 0, j = 0; r < nruns; r++) {
-                FastTile t;
+                FastTile t{};
                 t.level = (short)l;
                 t.row = (short)i;
                 t.c0 = (short)j;
@@ -220,7 +262,7 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
             }
         for (int i = 0; i < L.nRows; i++)
             for (int j = 0; j < L.nCols; j++) {
-                FastTile t;
+                FastTile t{};
                 t.level = (short)l;
                 t.row = (short)i;
                 t.c0 = (short)j;
@@ -241,6 +283,7 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
     c->blurLevelFirst[G.nlevels] = (int)c->blurTiles.size();
     c->nFastTilesBatch = (int)c->fastTiles.size();
     c->fastTiles.insert(c->fastTiles.end(), single.begin(), single.end());   // [batch list | single-frame list]
+    for (FastTile &t : c->fastTiles) fast_tile_geometry(G, t);
     G.totalCells = cellBase;
     G.totalCands = candBase;
     G.totalPts = candBase;

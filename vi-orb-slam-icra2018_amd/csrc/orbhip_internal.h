@@ -57,10 +57,31 @@ struct OrbLevels {
     OrbLevel lv[ORBHIP_MAX_LEVELS];
 };
 
-// One FAST workgroup's work: `ncells` consecutive cells starting at column c0 of cell-row `row`.
+// One FAST workgroup's work: `ncells` consecutive cells starting at column c0 of cell-row `row`.  The fields after the first
+// four follow from them and the level (orb_build_geometry fills them, fast_tile_geometry): the fixed-layout kernel reads its
+// whole geometry from here with scalar loads instead of deriving it in every workgroup.
 struct FastTile {
     short level, row, c0, ncells;
+    // (32-bit fields: the kernel reads them with scalar loads)
+    int nc;                // = ncells
+    int iniY, xa;          // first staged row, first staged column (a multiple of 16) of the level image
+    int RH, nchunk;        // staged rows, 16-byte chunks per staged row
+    int DH, TW;            // domain rows / columns (0 rows: the reference skips this run, :797-806)
+    int j0, GPR;           // staged column of domain column 0; aligned dword groups per row that touch the domain
+    int wCell, seg;        // cell width; domain rows per thread of the compass pass over all cells (256 threads)
+    int py0, px0;          // image coordinates relative to (16, 16) of the domain's row 0 / column 0 (:824-825)
+    int cellMagic;         // 65536 / wCell + 1:  c / wCell = (c * cellMagic) >> 16 for c < 65536 / wCell
+    int grpMagic;          // 65536 / GPR + 1
+    int dhMagic;           // 65536 / DH + 1
+    int cntOff;            // index of the run's first cell in the per-frame cell arrays
+    int candOff;           // index of the run's first candidate slot in the per-frame candidate array
+    int cellCap;           // candidate slots per cell
+    int stride;            // row stride of the level image (level 0: the launch argument counts)
+    unsigned lvlOff;       // byte offset of the level inside one frame's pyramid block; level 0: 0xFFFFFFFF
+    int pad;
 };
+static_assert(sizeof(FastTile) == 96, "FastTile layout");
+void fast_tile_geometry(const OrbLevels &G, FastTile &t);
 
 // One blur workgroup's work: BLUR_TILE_W x BLUR_TILE_H output tile (k_blur.hip: 64 raw rows = two 32-row MFMA tiles -> 58
 // output rows; four waves of 32 columns).
