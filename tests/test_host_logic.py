@@ -182,6 +182,26 @@ def test_lerp_compass_formulas_are_exact_for_every_q_v_t():
         assert np.array_equal(~notdark, q - v < -t), t
 
 
+def test_loose_compass_formulas_are_exact_for_bright_and_one_value_wide_for_dark():
+    """csrc/k_fast.hip compass4_loose (the fixed-layout kernel): ONE halving per neighbour, exact for bright; the dark cut may
+    only ADD pixels (the work list is scored exactly afterwards) and adds exactly q - v == -t."""
+    q, v = np.meshgrid(np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), indexing="ij")
+
+    def lerp(a, b, c):
+        return (a + b + (c & 1)) >> 1
+
+    for t in range(1, 255):
+        c = t & 1
+        KB = ((t + c) >> 1) + 128
+        KD = (254 + c - t) >> 1
+        assert 128 <= KB <= 255 and 0 <= KD <= 127
+        a = lerp(q, 255 - v, c)
+        bright = lerp(a, 255 - KB, 1) >= 128
+        notdark = lerp(a, 255 - (KD + 1), 1) >= 128
+        assert np.array_equal(bright, q - v > t), t
+        assert np.array_equal(~notdark, q - v <= -t), t
+
+
 def test_dropin_sources_compile_against_opencv_declarations():
     """include/orbhip/cvlite.h has two branches: its own minimal cv:: types (what both boxes use: no OpenCV installed) and
     `#ifdef ORBHIP_USE_OPENCV` -> <opencv2/core/core.hpp>, the branch a build inside the reference tree takes.  That branch is

@@ -645,6 +645,73 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
 #define FF_CORNERCAP 640               // corner list entries (an eighth)
 #define FF_GRPM 64                     // dword groups per row
 
+// ---- the compass test of k_fast_fix: one halving per neighbour for both polarities ----
+// compass4 (above) halves q - v twice, with the rounding bit that makes each polarity's cut exact.  The compass test only
+// has to be NECESSARY (every entry of the work list is scored exactly, and fast_score_win starts with the exact compass
+// conditions), so here both polarities share the halving that is exact for "bright" (c = t & 1): the dark cut then admits
+// q - v = -t as well as q - v < -t -- one value more -- and an item costs 12 v_lerp_u8 instead of 16.
+// (tests/test_host_logic.py: bright exact, dark a superset by exactly that value, for every q, v, t.)
+struct CompassL {
+    uint32_t c;          // rounding bits (0x01010101 or 0)
+    uint32_t nkb, nkd;   // ~KB, ~(KD + 1) in every byte
+};
+__device__ __forceinline__ CompassL compass_loose_consts(int t)
+{
+    // 1 <= t <= 254
+    const uint32_t ONES = 0x01010101u;
+    const int c = t & 1;
+    const int KB = ((t + c) >> 1) + 128;          // bright <=> floor((d + 255 + c) / 2) >= KB                 (exact)
+    const int KD = (254 + c - t) >> 1;            // dark   =>  floor((d + 255 + c) / 2) <= KD                 (d = -t passes too)
+    CompassL K;
+    K.c = c ? ONES : 0u;
+    K.nkb = ~((uint32_t)KB * ONES);
+    K.nkd = ~((uint32_t)(KD + 1) * ONES);
+    return K;
+}
+__device__ __forceinline__ uint32_t compass4_loose(uint32_t Cw, uint32_t Tw, uint32_t Bw, uint32_t lft, uint32_t rgt, const CompassL &K)
+{
+    const uint32_t ONES = 0x01010101u;
+    const uint32_t nv = ~Cw;
+    const uint32_t aT = __builtin_amdgcn_lerp(Tw, nv, K.c), aB = __builtin_amdgcn_lerp(Bw, nv, K.c);
+    const uint32_t aL = __builtin_amdgcn_lerp(lft, nv, K.c), aR = __builtin_amdgcn_lerp(rgt, nv, K.c);
+    const uint32_t bT = __builtin_amdgcn_lerp(aT, K.nkb, ONES), bB = __builtin_amdgcn_lerp(aB, K.nkb, ONES);
+    const uint32_t bL = __builtin_amdgcn_lerp(aL, K.nkb, ONES), bR = __builtin_amdgcn_lerp(aR, K.nkb, ONES);
+    const uint32_t dT = __builtin_amdgcn_lerp(aT, K.nkd, ONES), dB = __builtin_amdgcn_lerp(aB, K.nkd, ONES);
+    const uint32_t dL = __builtin_amdgcn_lerp(aL, K.nkd, ONES), dR = __builtin_amdgcn_lerp(aR, K.nkd, ONES);
+    const uint32_t bright = (bT | bB) & (bL | bR);
+    const uint32_t notdark = (dT & dB) | (dL & dR);
+    return bright | ~notdark;
+}
+
+// Compass items of one thread: rows [row0 + cb, row0 + cb + min(8, seg - cb)) of the dword column at `win` (= the address of
+// (row0 + cb - 3, column - 4)), PITCH a compile-time constant.  Returns the survivors of item i in nibble i (pixel k at bit
+// 4 i + k), gathered from the bits 7 of the four bytes by v_dot4_u32_u8 with the weights 1 2 4 8 (even items) / 16 32 64 128
+// (odd items): the sum lands 7 bits up.
+template <int PITCH>
+__device__ __forceinline__ uint32_t compass_items(const uint8_t *win, int nitems /* uniform */, uint32_t dom, const CompassL &CK)
+{
+    uint32_t a01 = 0, a23 = 0, a45 = 0, a67 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < nitems) {   // uniform
+            const uint8_t *wi = win + i * PITCH;
+            // the item's five dwords at non-negative offsets from (row - 3, column - 4): top | left, centre, right | bottom
+            const uint32_t Tw = *reinterpret_cast<const uint32_t *>(wi + 4);
+            const uint32_t Lw = *reinterpret_cast<const uint32_t *>(wi + 3 * PITCH);
+            const uint32_t Cw = *reinterpret_cast<const uint32_t *>(wi + 3 * PITCH + 4);
+            const uint32_t Rw = *reinterpret_cast<const uint32_t *>(wi + 3 * PITCH + 8);
+            const uint32_t Bw = *reinterpret_cast<const uint32_t *>(wi + 6 * PITCH + 4);
+            const uint32_t lft = __builtin_amdgcn_alignbyte(Cw, Lw, 1);   // bytes L1 L2 L3 C0 (column - 3)
+            const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
+            const uint32_t z = compass4_loose(Cw, Tw, Bw, lft, rgt, CK) & dom;   // bits 7 of the bytes only
+            const uint32_t W = (i & 1) ? 0x80402010u : 0x08040201u;
+            uint32_t &a = i < 2 ? a01 : i < 4 ? a23 : i < 6 ? a45 : a67;
+            a = __builtin_amdgcn_udot4(z, W, a, false);
+        }
+    }
+    return (a01 >> 7) | (a23 << 1) | (a45 << 9) | (a67 << 17);
+}
+
 template <int PITCH, bool DEFER>
 __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__ lvl0, int stride0, unsigned long long frame0,
                                                      const uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
@@ -655,19 +722,18 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
     __shared__ __align__(16) uint8_t s_pix[PITCH * FF_RHM];
     __shared__ unsigned long long s_bits[FF_NCM * FF_DHM];   // [cell][row]: survivors of the row (wCell < 64)
     __shared__ uint16_t s_list[FF_LISTCAP];
-    int *const s_pre = reinterpret_cast<int *>(s_list);      // [cell][row] row prefix of phase 5 (the work list is dead by then)
-    static_assert(FF_NCM * FF_DHM * 4 <= FF_LISTCAP * 2, "s_pre aliases s_list");
     __shared__ uint16_t s_corner[FF_CORNERCAP];
-    __shared__ uint32_t s_dom[FF_GRPM];   // per dword group of the pass: which of its 4 pixels are tested (bit 8k + 7)
-    __shared__ uint8_t s_grp[FF_GRPM];
-    __shared__ int s_cellAny[8], s_cellCnt[8];
-    __shared__ int s_listCount, s_cornerCount, s_nAct, s_deferCount;
+    __shared__ uint32_t s_dom[FF_GRPM];   // per dword group: which of its 4 pixels lie in the domain (bit 8k + 7)
+    __shared__ int s_cellAny[8];
+    __shared__ int s_listCount, s_cornerCount, s_deferCount;
+    __shared__ int s_wcnt[4][2];          // pass 1, per wave: work-list and corner-list counts
     extern __shared__ __align__(16) uint8_t s_score[];       // [DH][SP]
 
     const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
     if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
     const FastTile &T = tiles[tileId];
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int DH = T.DH, TW = T.TW, ncells = T.nc;
     if (DH == 0) {
         if (tid < ncells) cellCnt[(size_t)frame * totalCells + T.cntOff + tid] = 0;
@@ -688,7 +754,6 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
         const uint8_t *img = isL0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + T.lvlOff;
         const uint8_t *img0 = img + (unsigned)(__mul24(T.iniY, stride) + T.xa);
         constexpr int CPW = PITCH / 16, RPW = 64 / CPW;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int rl = lane / CPW, ch = lane - rl * CPW;
         const bool laneOk = rl < RPW && ch < nchunk;
         const uint8_t *src = img0 + (unsigned)(__mul24(rl, stride) + (ch << 4));
@@ -698,7 +763,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
     }
     for (int i = tid; i < (DH * SP + 15) >> 4; i += 256) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < nrowsAll; i += 256) s_bits[i] = 0ull;
-    // pass 0 tests every domain pixel: the mask of a group is its overlap with [0, TW)
+    // the mask of a group is its overlap with the domain columns [0, TW)
     if (tid < GPR) {
         uint32_t m = 0;
 #pragma unroll
@@ -706,14 +771,10 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             if ((unsigned)(jd0 + (tid << 2) + k - j0) < (unsigned)TW) m |= 0x80u << (8 * k);
         s_dom[tid] = m;
     }
-    if (tid < 8) {
-        s_cellAny[tid] = 0;
-        s_cellCnt[tid] = 0;
-    }
+    if (tid < 8) s_cellAny[tid] = 0;
     if (tid == 0) {
         s_listCount = 0;
         s_cornerCount = 0;
-        s_nAct = 0;
         s_deferCount = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -727,56 +788,26 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
 #define ENT_COL(e) (jd0 + (((e) >> 9) << 2) + ((e) & 3))
 #define ENT_MAKE(r, j) (((((j) - jd0) >> 2) << 9) | ((r) << 2) | (((j) - jd0) & 3))
 
-    // One pass: compass test + work list, arc score + corner list, suppression -> bitmap.  Returns false when an ablation stop ends the kernel.
-    auto run_pass = [&](auto passTag, const int t, const unsigned cellMask, const int nAct, const int nthr) -> bool {
-        constexpr int PASS = decltype(passTag)::value;
-        const CompassK CK = compass_consts(t);
+    // =================================== pass 0: every cell at iniThFAST, the whole workgroup ===================================
+    // (a threshold of 255 admits no corner: no pixel differs from its centre by more)
+    if (iniTh < 255) {
+        const int t = iniTh;
         // ---- 2. compass pre-test, 4 pixels per item; survivors -> work list ----
-        if ((tid & ~63) < nthr) {
-            // thread -> (dword column, segment of consecutive rows): tid = sidx * nAct + slot
-            int sidx, seg;
-            if (PASS == 0) {
-                sidx = (int)(((unsigned)tid * (unsigned)T.grpMagic) >> 16);
-                seg = T.seg;
-            } else {
-                // (v_rcp_f32 is within 1 ulp: the products below are off by < 2^-13, the quotients are >= 1 / (2 n) away from an integer)
-                const float invAct = __builtin_amdgcn_rcpf((float)nAct);
-                sidx = (int)(((float)tid + 0.5f) * invAct);
-                const int S = __builtin_amdgcn_readfirstlane((int)(((float)nthr + 0.5f) * invAct));            // >= 1
-                seg = __builtin_amdgcn_readfirstlane((int)(((float)(DH + S - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)S)));
-            }
-            const int slot = tid - __mul24(sidx, nAct);
+        {
+            const CompassL CK = compass_loose_consts(t);
+            // thread -> (dword column, segment of consecutive rows): tid = sidx * GPR + slot
+            const int sidx = (int)(((unsigned)tid * (unsigned)T.grpMagic) >> 16);
+            const int seg = T.seg;
+            const int slot = tid - __mul24(sidx, GPR);
             const int rs = __mul24(sidx, seg);               // first row of my segment
             const bool mine = rs < DH;
-            const int g = PASS == 0 ? slot : (int)s_grp[slot];
-            const int jd = jd0 + (g << 2);
-            const uint32_t dom = mine ? s_dom[slot] : 0u;   // domain / active-cell mask of my four pixels (pixel k at bit 8k + 7)
+            const int jd = jd0 + (slot << 2);
+            const uint32_t dom = mine ? s_dom[slot] : 0u;   // domain mask of my four pixels (pixel k at bit 8k + 7)
             const uint32_t listCountAddr = (uint32_t)(uintptr_t)&s_listCount;   // LDS byte address (low half of the flat address)
-            // the item's five dwords at non-negative offsets from (row - 3, column - 4): top | left, centre, right | bottom
             const uint8_t *win = s_pix + __mul24(mine ? rs : 0, pitch) + (jd - 4);
-            if (phases == 11) return false;   // ablation only: the set-up of the compass phase
+            if (phases == 11) return;   // ablation only: the set-up of the compass phase
             for (int cb = 0; cb < seg; cb += 8) {
-                // survivors of item i as the nibble i of acc (pixel k at bit 4 i + k), gathered from the bits 7 of the four
-                // bytes by v_dot4_u32_u8 with the weights 1 2 4 8 (even items) / 16 32 64 128 (odd): the sum lands 7 bits up
-                uint32_t a01 = 0, a23 = 0, a45 = 0, a67 = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (cb + i < seg) {   // uniform
-                        const uint8_t *wi = win + i * pitch;
-                        const uint32_t Tw = *reinterpret_cast<const uint32_t *>(wi + 4);
-                        const uint32_t Lw = *reinterpret_cast<const uint32_t *>(wi + 3 * pitch);
-                        const uint32_t Cw = *reinterpret_cast<const uint32_t *>(wi + 3 * pitch + 4);
-                        const uint32_t Rw = *reinterpret_cast<const uint32_t *>(wi + 3 * pitch + 8);
-                        const uint32_t Bw = *reinterpret_cast<const uint32_t *>(wi + 6 * pitch + 4);
-                        const uint32_t lft = __builtin_amdgcn_alignbyte(Cw, Lw, 1);   // bytes L1 L2 L3 C0 (column - 3)
-                        const uint32_t rgt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // bytes C3 R0 R1 R2 (column + 3)
-                        const uint32_t z = compass4(Cw, Tw, Bw, lft, rgt, CK) & dom;   // bits 7 of the bytes only
-                        const uint32_t W = (i & 1) ? 0x80402010u : 0x08040201u;
-                        uint32_t &a = i < 2 ? a01 : i < 4 ? a23 : i < 6 ? a45 : a67;
-                        a = __builtin_amdgcn_udot4(z, W, a, false);
-                    }
-                }
-                uint32_t acc = (a01 >> 7) | (a23 << 1) | (a45 << 9) | (a67 << 17);
+                uint32_t acc = compass_items<PITCH>(win, seg - cb, dom, CK);
                 // rows of the last segment below the domain were computed on whatever lies there: drop them
                 const int live = DH - rs - cb;   // (<= 0 only for threads that are not `mine`)
                 if (live < 8) acc &= (1u << (4 * max(live, 0))) - 1u;
@@ -795,7 +826,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(listCountAddr), "v"(n) : "memory");
                     if (base + n <= listCap) {
                         uint16_t *dst = s_list + base;
-                        const int entBase = (g << 9) | ((rs + cb) << 2);
+                        const int entBase = (slot << 9) | ((rs + cb) << 2);
                         while (acc) {
                             const int b = __ffs(acc) - 1;
                             acc &= acc - 1;
@@ -806,16 +837,13 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             }
         }
         __syncthreads();
-        if (phases < 3 + 3 * PASS || phases == 12 || phases == 11) return false;   // ablation stops: 2-4 = phases of pass 0, 5-7 = of pass 1
+        if (phases < 3 || phases == 12) return;   // ablation stops: 2-4 = phases of pass 0
 
         // ---- 3. full score on the work list; corners (score >= t) -> score tile + corner list ----
-        // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel of the
-        // active cells is scored instead (the compass test is the early-out of fast_score_pol); if it has more corners
-        // than the corner list holds, phase 4 scans the score tile.  Both fallbacks produce the same result.
+        // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel is scored
+        // instead (the compass test is the early-out of fast_score_pol); if it has more corners than the corner list holds,
+        // phase 4 scans the score tile.  Both fallbacks produce the same result.
         const int nlist = s_listCount;
-#ifdef FAST_DEBUG_PRINT
-        if (tid == 0 && frame == 0) printf("FASTDBG tile %d pass %d nlist %d DH %d TW %d GPR %d seg %d\n", tileId, PASS, nlist, DH, TW, GPR, (int)T.seg);
-#endif
         const uint32_t cornerCountAddr = (uint32_t)(uintptr_t)&s_cornerCount;
         auto put_corner = [&](int ent, int r, int j, int s) {
             s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
@@ -872,10 +900,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 if (px < DH * TWx) {
                     const int r = (int)(((float)px + 0.5f) * invTW);
                     const int c = px - r * TWx;
-                    if ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u) {
-                        s = fast_score_pol(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
-                        if (s > 0) s_score[r * SP + c] = (uint8_t)s;
-                    }
+                    s = fast_score_pol(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
+                    if (s > 0) s_score[r * SP + c] = (uint8_t)s;
                     ent = ENT_MAKE(r, j0 + c);
                 }
                 const int slot = wave_append(s > 0, &s_cornerCount, lane);
@@ -883,13 +909,10 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             }
         }
         __syncthreads();
-        if (phases < 4 + 3 * PASS) return false;
+        if (phases < 4) return;
 
         // ---- 4. NMS over the corners (cell-local neighbourhood); every survivor is final: set its bit ----
         const int ncorner = s_cornerCount;
-#ifdef FAST_DEBUG_PRINT
-        if (tid == 0 && frame == 0) printf("FASTDBG tile %d pass %d ncorner %d ndefer %d\n", tileId, PASS, ncorner, s_deferCount);
-#endif
         if (ncorner <= cornerCap) {
             for (int e = tid; e < ncorner; e += 256) {
                 const int ent = s_corner[e];
@@ -901,7 +924,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 }
             }
         } else {
-            // fallback: scan the score tile, 4 pixels per dword; only the active cells' corners of this pass (score >= t)
+            // fallback: scan the score tile, 4 pixels per dword (every non-zero score is a corner of this pass)
             int SPx = SP;
             asm volatile("" : "+s"(SPx));
             const int SPW = SPx >> 2;                                       // score dwords per row
@@ -917,7 +940,6 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                     const int c = cb + k;
                     if (s < t || c >= TW) continue;
                     const int cj = (int)(((unsigned)c * cellMagic) >> 16);
-                    if (!((cellMask >> cj) & 1u)) continue;
                     if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) {
                         atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * wCell));
                         s_cellAny[cj] = 1;
@@ -925,83 +947,143 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 }
             }
         }
-        __syncthreads();
-        return phases >= 5 + 3 * PASS;
-    };
-
-    // pass 0: every cell at iniThFAST (a threshold of 255 admits no corner: no pixel differs from its centre by more)
-    const unsigned allCells = (1u << ncells) - 1u;
-    if (iniTh < 255)
-        if (!run_pass(std::integral_constant<int, 0>{}, iniTh, allCells, GPR, 256)) return;
-    // pass 1: the cells without a survivor at minThFAST (block-uniform decisions); FAST(ini) empty => FAST(min >= ini) empty
-    if (minTh < iniTh && minTh < 255) {
-        unsigned cellMask = 0;
-        for (int cj = 0; cj < ncells; cj++)
-            if (!s_cellAny[cj]) cellMask |= 1u << cj;
-        if (cellMask) {
-            int tidp = tid;
-            asm volatile("" : "+v"(tidp));   // (what follows is pass 1's alone: not to be hoisted above the branch)
-            // dword groups that hold a domain pixel of an active cell (any order)
-            if (tidp < GPR) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int c = jd0 + (tidp << 2) + k - j0;
-                    if ((unsigned)c < (unsigned)TW && ((cellMask >> ((unsigned)c * cellMagic >> 16)) & 1u)) m |= 0x80u << (8 * k);
-                }
-                if (m) {
-                    const int a = atomicAdd(&s_nAct, 1);
-                    s_grp[a] = (uint8_t)tidp;
-                    s_dom[a] = m;
-                }
-            }
-            if (tid == 0) {
-                s_listCount = 0;
-                s_cornerCount = 0;
-                s_deferCount = 0;
-            }
-            __syncthreads();
-            const int nAct = s_nAct;
-            // threads taking part: about one per five items (whole waves), so that a tile with one empty cell does not pay four
-            // waves' worth of fixed cost for 300 items
-            const int want = (__mul24(nAct, DH) + 319) / 320;            // waves at ~5 items per thread
-            const int need = (nAct + 63) >> 6;                           // at least one thread per column
-            const int nthr = min(4, max(want, need)) << 6;
-            if (!run_pass(std::integral_constant<int, 1>{}, minTh, cellMask, nAct, nthr)) return;
-        }
-    }
-
-    // ---- 5. rank inside the cell (= raster order) from the bitmap, write the slots ----
-    // The rank of a survivor is the number of bits before it: a prefix over the rows of its cell plus a popcount inside its
-    // row -- no survivor is ever compared with another one.  (DH <= 34: one wave per cell, one lane per row.)
-    for (int cj = tid >> 6; cj < ncells; cj += 4) {
-        const int n = lane < DH ? __popcll(s_bits[cj * DH + lane]) : 0;
-        const int incl = wave_incl_scan_dpp(n);
-        if (lane < DH) s_pre[cj * DH + lane] = incl - n;
-        if (lane == 63) s_cellCnt[cj] = incl;
     }
     __syncthreads();
-    {
-        const unsigned dhMagic = (unsigned)T.dhMagic;
-        uint32_t *candRun = cand + (size_t)frame * totalCands + T.candOff;
-        const int cellCap = T.cellCap, py0 = T.py0, px0 = T.px0;
-        for (int i = tid; i < nrowsAll; i += 256) {
-            unsigned long long bits = s_bits[i];
-            if (bits == 0ull) continue;
-            const int cj = (int)(((unsigned)i * dhMagic) >> 16), r = i - cj * DH;
-            int rank = s_pre[i];
-            uint32_t *slot = candRun + __mul24(cj, cellCap);
-            const int py = py0 + r;                                           // relative to (16,16), :824-825
-            const int pxBase = px0 + cj * wCell;
-            const uint8_t *sc = s_score + r * SP + cj * wCell;
-            while (bits) {
-                const int cl = __ffsll((long long)bits) - 1;
-                bits &= bits - 1ull;
-                slot[rank++] = (uint32_t)(pxBase + cl) | ((uint32_t)py << 12) | ((uint32_t)sc[cl] << 24);
+    if (phases < 5) return;
+
+    // ============ pass 1 and the output: ONE WAVE PER CELL, no workgroup barrier from here on ============
+    // The cells without a survivor are searched again at minThFAST (:814-818).  A cell's second pass touches nothing outside the
+    // cell -- its pixels' scores, the suppression among them, its rows of the bitmap -- so a wave does all of it alone: compass
+    // test over the cell's dword groups (lane = group x row segment), its own quarter of the work list and of the corner list,
+    // score, suppression; then, for every cell (searched again or not), the ranks and the candidate slots.  (The r02 kernel ran
+    // pass 1 as three more workgroup phases with four barriers: half of the runs have an empty cell, and a run's second pass
+    // is ~300 items -- one wave's worth -- so three waves waited at every one of them.)
+    const bool pass1 = minTh < iniTh && minTh < 255;   // FAST(ini) empty => FAST(min >= ini) empty
+    constexpr int WLCAP = FF_LISTCAP / 4, WCCAP = FF_CORNERCAP / 4;
+    uint16_t *const wlist = s_list + wv * WLCAP;
+    uint16_t *const wcorner = s_corner + wv * WCCAP;
+    const int wlcap = min(listCap, WLCAP), wccap = min(cornerCap, WCCAP);   // (forced small in the tests)
+    uint32_t *candRun = cand + (size_t)frame * totalCands + T.candOff;
+    uint16_t *cntRun = cellCnt + (size_t)frame * totalCells + T.cntOff;
+    for (int cj = wv; cj < ncells; cj += 4) {
+        const int cx0 = __mul24(cj, wCell), cx1 = min(cx0 + wCell, TW);   // the cell's domain columns
+        if (pass1 && !__builtin_amdgcn_readfirstlane(s_cellAny[cj])) {
+            // (empty asm: what follows belongs to this branch -- the compiler otherwise computes the lanes' set-up for every
+            // cell, searched again or not: 40 vector instructions per cell, a twelfth of the kernel)
+            int t = minTh, lanep = lane, cxa = cx0;
+            asm volatile("" : "+s"(t), "+v"(lanep), "+s"(cxa));
+            const CompassL CK = compass_loose_consts(t);
+            // the cell's dword groups (absolute index in the staged row) and the lanes' (group, row segment)
+            const int gA = (j0 + cxa) >> 2, ng = ((j0 + cx1 - 1) >> 2) - gA + 1;
+            const float invNg = __builtin_amdgcn_rcpf((float)ng);
+            // (v_rcp_f32 is within 1 ulp: the products below are off by < 2^-13, the quotients are >= 1 / (2 n) away from an integer)
+            const int S = __builtin_amdgcn_readfirstlane((int)(64.5f * invNg));                                           // >= 1 (ng <= 64 / 4 + 2)
+            const int seg = __builtin_amdgcn_readfirstlane((int)(((float)(DH + S - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)S)));
+            const int sidx = (int)(((float)lanep + 0.5f) * invNg);
+            const int slot = lanep - __mul24(sidx, ng);
+            const int rs = __mul24(sidx, seg);
+            const bool mine = rs < DH;
+            const int jg = (gA + slot) << 2;                  // staged column of my group's pixel 0
+            uint32_t dom = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (mine && jg + k >= j0 + cxa && jg + k < j0 + cx1) dom |= 0x80u << (8 * k);
+            if (lanep == 0) {
+                s_wcnt[wv][0] = 0;
+                s_wcnt[wv][1] = 0;
+            }
+            const uint32_t wlAddr = (uint32_t)(uintptr_t)&s_wcnt[wv][0], wcAddr = (uint32_t)(uintptr_t)&s_wcnt[wv][1];
+            const uint8_t *win = s_pix + __mul24(mine ? rs : 0, pitch) + (jg - 4);
+            for (int cb = 0; cb < seg; cb += 8) {
+                uint32_t acc = compass_items<PITCH>(win, seg - cb, dom, CK);
+                const int live = DH - rs - cb;
+                if (live < 8) acc &= (1u << (4 * max(live, 0))) - 1u;
+                win += 8 * pitch;
+                const int n = __popc(acc);
+                if (n > 0) {
+                    int base;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(wlAddr), "v"(n) : "memory");
+                    if (base + n <= wlcap) {
+                        uint16_t *dst = wlist + base;
+                        const int entBase = ((gA + slot - (jd0 >> 2)) << 9) | ((rs + cb) << 2);
+                        while (acc) {
+                            const int b = __ffs(acc) - 1;
+                            acc &= acc - 1;
+                            *dst++ = (uint16_t)(entBase + b);
+                        }
+                    }
+                }
+            }
+            // (LDS operations of one wave complete in order: the counts read below include every lane's add above)
+            const int nl = __builtin_amdgcn_readfirstlane(s_wcnt[wv][0]);
+            auto put_corner1 = [&](int ent, int r, int j, int s) {
+                s_score[__mul24(r, SP) + (j - j0)] = (uint8_t)s;
+                int slot1;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot1) : "v"(wcAddr), "v"(1) : "memory");
+                if (slot1 < wccap) wcorner[slot1] = (uint16_t)ent;
+            };
+            const int cw = cx1 - cx0;
+            if (nl <= wlcap) {
+                for (int e = lane; e < nl; e += 64) {
+                    const int ent = wlist[e];
+                    const int r = ENT_ROW(ent), j = ENT_COL(ent);
+                    const int s = fast_score_win<false>(s_pix, __mul24(r, pitch) + (j - 3), pitch, t, nullptr);
+                    if (s > 0) put_corner1(ent, r, j, s);
+                }
+            } else {
+                // more survivors than this wave's part of the list holds: every pixel of the cell
+                const float invCw = __builtin_amdgcn_rcpf((float)cw);
+                for (int p0 = 0; p0 < DH * cw; p0 += 64) {
+                    const int px = p0 + lane;
+                    if (px < DH * cw) {
+                        const int r = (int)(((float)px + 0.5f) * invCw);   // (exact: px < 64 * 64, see above)
+                        const int c = cx0 + px - r * cw;
+                        const int s = fast_score_pol(s_pix + (r + 3) * pitch + j0 + c, pitch, t);
+                        if (s > 0) put_corner1(ENT_MAKE(r, j0 + c), r, j0 + c, s);
+                    }
+                }
+            }
+            const int ncor = __builtin_amdgcn_readfirstlane(s_wcnt[wv][1]);
+            if (ncor <= wccap) {
+                for (int e = lane; e < ncor; e += 64) {
+                    const int ent = wcorner[e];
+                    const int r = ENT_ROW(ent), c = ENT_COL(ent) - j0;
+                    if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) atomicOr(&s_bits[cj * DH + r], 1ull << (c - cx0));
+                }
+            } else {
+                // more corners than this wave's part of the corner list holds: scan the cell's scores
+                const float invCw = __builtin_amdgcn_rcpf((float)cw);
+                for (int p0 = 0; p0 < DH * cw; p0 += 64) {
+                    const int px = p0 + lane;
+                    if (px < DH * cw) {
+                        const int r = (int)(((float)px + 0.5f) * invCw);
+                        const int c = cx0 + px - r * cw;
+                        if (s_score[r * SP + c] >= t && nms_survives(s_score, SP, r, c, DH, TW, wCell, cj))
+                            atomicOr(&s_bits[cj * DH + r], 1ull << (c - cx0));
+                    }
+                }
             }
         }
+        if (phases < 8) continue;
+        // ---- 5. rank inside the cell (= raster order) from the bitmap, write the slots: lane = row (DH <= 34) ----
+        // The rank of a survivor is the number of bits before it: a prefix over the rows of its cell plus a popcount inside its
+        // row -- no survivor is ever compared with another one.
+        unsigned long long bits = lane < DH ? s_bits[cj * DH + lane] : 0ull;
+        const int n = __popcll(bits);
+        const int incl = wave_incl_scan_dpp(n);
+        int rank = incl - n;
+        if (lane == 63) cntRun[cj] = (uint16_t)incl;
+        uint32_t *slotp = candRun + __mul24(cj, T.cellCap);
+        const int py = T.py0 + lane;                                      // relative to (16,16), :824-825
+        const int pxBase = T.px0 + cx0;
+        const uint8_t *sc = s_score + lane * SP + cx0;
+        while (bits) {
+            const int cl = __ffsll((long long)bits) - 1;
+            bits &= bits - 1ull;
+            slotp[rank++] = (uint32_t)(pxBase + cl) | ((uint32_t)py << 12) | ((uint32_t)sc[cl] << 24);
+        }
     }
-    if (tid < ncells) cellCnt[(size_t)frame * totalCells + T.cntOff + tid] = (uint16_t)s_cellCnt[tid];
+    if (phases < 8 && tid < ncells) cntRun[tid] = 0;
 #undef ENT_ROW
 #undef ENT_COL
 #undef ENT_MAKE
