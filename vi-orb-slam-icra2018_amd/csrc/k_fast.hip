@@ -683,6 +683,43 @@ __device__ __forceinline__ uint32_t compass4_loose(uint32_t Cw, uint32_t Tw, uin
     return bright | ~notdark;
 }
 
+// The survivors of a thread (bit b of acc set <=> list entry entBase + b) as consecutive 16-bit entries from the LDS byte
+// address dst on.  The loop runs as long as ANY lane of the wave has bits left, so its body is what counts: find-first-bit,
+// clear-lowest (2), entry, store -- two entries per trip so that the pointer moves once for both (the compiler's loop has a
+// pointer increment and a register copy per entry: 7 vector instructions instead of 5.5).  exec is narrowed inside and restored.
+__device__ __forceinline__ void list_write_entries(uint32_t acc, uint32_t dst, uint32_t entBase)
+{
+    uint32_t b, tmp;
+    unsigned long long sx;
+    asm volatile("s_mov_b64 %[sx], exec\n\t"
+                 "v_cmp_ne_u32_e32 vcc, 0, %[acc]\n\t"
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "s_cbranch_execz 2f\n"
+                 "1:\n\t"
+                 "v_ffbl_b32_e32 %[b], %[acc]\n\t"
+                 "v_add_u32_e32 %[tmp], -1, %[acc]\n\t"
+                 "v_add_u32_e32 %[b], %[b], %[eb]\n\t"
+                 "v_and_b32_e32 %[acc], %[tmp], %[acc]\n\t"
+                 "ds_write_b16 %[dst], %[b]\n\t"
+                 "v_cmp_ne_u32_e32 vcc, 0, %[acc]\n\t"
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "s_cbranch_execz 2f\n\t"
+                 "v_ffbl_b32_e32 %[b], %[acc]\n\t"
+                 "v_add_u32_e32 %[tmp], -1, %[acc]\n\t"
+                 "v_add_u32_e32 %[b], %[b], %[eb]\n\t"
+                 "v_and_b32_e32 %[acc], %[tmp], %[acc]\n\t"
+                 "ds_write_b16 %[dst], %[b] offset:2\n\t"
+                 "v_add_u32_e32 %[dst], 4, %[dst]\n\t"
+                 "v_cmp_ne_u32_e32 vcc, 0, %[acc]\n\t"
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "s_cbranch_execnz 1b\n"
+                 "2:\n\t"
+                 "s_mov_b64 exec, %[sx]"
+                 : [acc] "+v"(acc), [dst] "+v"(dst), [b] "=&v"(b), [tmp] "=&v"(tmp), [sx] "=&s"(sx)
+                 : [eb] "v"(entBase)
+                 : "vcc", "memory");
+}
+
 // Compass items of one thread: rows [row0 + cb, row0 + cb + min(8, seg - cb)) of the dword column at `win` (= the address of
 // (row0 + cb - 3, column - 4)), PITCH a compile-time constant.  Returns the survivors of item i in nibble i (pixel k at bit
 // 4 i + k), gathered from the bits 7 of the four bytes by v_dot4_u32_u8 with the weights 1 2 4 8 (even items) / 16 32 64 128
@@ -824,15 +861,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                     // (inline asm: hipcc's atomic optimiser would turn a plain atomicAdd of a per-lane value back into a DPP scan)
                     int base;
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(listCountAddr), "v"(n) : "memory");
-                    if (base + n <= listCap) {
-                        uint16_t *dst = s_list + base;
-                        const int entBase = (slot << 9) | ((rs + cb) << 2);
-                        while (acc) {
-                            const int b = __ffs(acc) - 1;
-                            acc &= acc - 1;
-                            *dst++ = (uint16_t)(entBase + b);
-                        }
-                    }
+                    if (base + n <= listCap)
+                        list_write_entries(acc, (uint32_t)(uintptr_t)s_list + 2u * (uint32_t)base, (uint32_t)((slot << 9) | ((rs + cb) << 2)));
                 }
             }
         }
@@ -1003,15 +1033,9 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 if (n > 0) {
                     int base;
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(wlAddr), "v"(n) : "memory");
-                    if (base + n <= wlcap) {
-                        uint16_t *dst = wlist + base;
-                        const int entBase = ((gA + slot - (jd0 >> 2)) << 9) | ((rs + cb) << 2);
-                        while (acc) {
-                            const int b = __ffs(acc) - 1;
-                            acc &= acc - 1;
-                            *dst++ = (uint16_t)(entBase + b);
-                        }
-                    }
+                    if (base + n <= wlcap)
+                        list_write_entries(acc, (uint32_t)(uintptr_t)wlist + 2u * (uint32_t)base,
+                                           (uint32_t)(((gA + slot - (jd0 >> 2)) << 9) | ((rs + cb) << 2)));
                 }
             }
             // (LDS operations of one wave complete in order: the counts read below include every lane's add above)
@@ -1077,10 +1101,19 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
         const int py = T.py0 + lane;                                      // relative to (16,16), :824-825
         const int pxBase = T.px0 + cx0;
         const uint8_t *sc = s_score + lane * SP + cx0;
-        while (bits) {
-            const int cl = __ffsll((long long)bits) - 1;
-            bits &= bits - 1ull;
-            slotp[rank++] = (uint32_t)(pxBase + cl) | ((uint32_t)py << 12) | ((uint32_t)sc[cl] << 24);
+        // (the row's bits as two 32-bit halves: cells of the usual grid are 31 or 32 pixels wide, the 64-bit walk costs twice)
+        const uint32_t posBase = (uint32_t)pxBase | ((uint32_t)py << 12);
+        uint32_t half = (uint32_t)bits;
+        while (half) {
+            const int cl = __ffs(half) - 1;
+            half &= half - 1u;
+            slotp[rank++] = (posBase + (uint32_t)cl) | ((uint32_t)sc[cl] << 24);
+        }
+        half = (uint32_t)(bits >> 32);
+        while (half) {
+            const int cl = __ffs(half) + 31;
+            half &= half - 1u;
+            slotp[rank++] = (posBase + (uint32_t)cl) | ((uint32_t)sc[cl] << 24);
         }
     }
     if (phases < 8 && tid < ncells) cntRun[tid] = 0;
@@ -1140,7 +1173,8 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     const int maxCells = fast_tile_cells();   // the configured run length bounds every tile's
     if (fixEnv && fixed && maxRh <= FF_RHM && maxCells <= FF_NCM) {
         const int lc = forced > 0 ? std::min(forced, FF_LISTCAP) : listCapFix, cc = forced > 0 ? std::min(forced, FF_CORNERCAP) : cornerCapFix;
-        const size_t ldsScore = (size_t)scoreBytes + 16;
+        static const int ldsPad = getenv("ORBHIP_FAST_LDS_PAD") ? atoi(getenv("ORBHIP_FAST_LDS_PAD")) : 0;   // occupancy experiments
+        const size_t ldsScore = (size_t)scoreBytes + 16 + (size_t)ldsPad;
 #define ORB_LAUNCH_FIX(P, D)                                                                                                 \
     hipLaunchKernelGGL((k_fast_fix<P, D>), grid, block, ldsScore, s, lvl0, stride0, (unsigned long long)frame0, pyr,         \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, G.totalCells, G.totalCands, G.iniTh, G.minTh, lc, \

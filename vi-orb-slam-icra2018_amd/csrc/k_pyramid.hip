@@ -22,6 +22,17 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 #define RZ_MAXCH 16    // 16-byte chunks per staged source row (source span <= 240 px + alignment)
 #define RZ_MAXROWS 44  // staged source rows
 
+// 16 bytes per lane from global memory straight into LDS at (ldsAddr + 16 * lane); M0 carries the LDS address and is restored
+// (assembly: the builtin makes hipcc wait vmcnt(0) at every LDS access that might alias).
+__device__ __forceinline__ void rz_glds16(const void *gsrc, uint32_t ldsAddr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(ldsAddr)
+                 : "memory");
+}
+
 template <int RZ_TH>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sstride,
                                                 unsigned long long sframe, uint8_t *__restrict__ dst,
@@ -62,16 +73,15 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     const int nch = ((sxmax - XA) >> 4) + 1;
     const int nrows = symax - symin + 1;
     if (nch <= RZ_MAXCH && nrows <= RZ_MAXROWS && nrows * nch <= 512) {
-        // at most RZ_MAXROWS * RZ_MAXCH = 384 chunks: two unconditional loads per thread, issued together
-        const int n = nrows * nch;
-        const int i0 = min(tid, n - 1), i1 = min(tid + 256, n - 1);
-        const float invNch = 1.0f / (float)nch;   // i / nch = floor((i + 0.5) * invNch), exact for i < 2^16
-        const int r0 = (int)(((float)i0 + 0.5f) * invNch), c0 = i0 - r0 * nch;
-        const int r1 = (int)(((float)i1 + 0.5f) * invNch), c1 = i1 - r1 * nch;
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(S + (size_t)(symin + r0) * sstride + XA + (c0 << 4));
-        const uint4 v1 = *reinterpret_cast<const uint4 *>(S + (size_t)(symin + r1) * sstride + XA + (c1 << 4));
-        if (tid < n) *reinterpret_cast<uint4 *>(&s_src[r0][c0 << 4]) = v0;
-        if (tid + 256 < n) *reinterpret_cast<uint4 *>(&s_src[r1][c1 << 4]) = v1;
+        // LDS-DMA (global_load_lds_dwordx4): a wave transfer writes 64 x 16 bytes to consecutive LDS addresses = four staged
+        // rows of 16 chunks, so lane = (row of the four) * 16 + chunk; no registers, no division, and the thread's tap
+        // loads below are in flight beside it.  Waited for (vmcnt) before the barrier: the compiler does not know of them.
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int rl = lane >> 4, ch = lane & 15;
+        const uint8_t *sp = S + (size_t)(symin + rl) * sstride + XA + (ch << 4);
+        const uint32_t ldsBase = (uint32_t)(uintptr_t)&s_src[0][0];
+        for (int rb = wv * 4; rb < nrows; rb += 16)
+            if (ch < nch && rb + rl < nrows) rz_glds16(sp + (size_t)rb * sstride, ldsBase + (uint32_t)(rb * (RZ_MAXCH * 16)));
     }
     // this thread's taps are requested before the barrier so that their latency overlaps the staging
     constexpr int NR = RZ_TH / 8;                 // output rows per thread (rows dy, dy + 8, ...)
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
 #pragma unroll
         for (int k = 0; k < 4; k++) xt[k] = xtab[min(gx + k, dw - 1)];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!colLive) return;
     if (grouped) {
