@@ -96,13 +96,11 @@ __device__ __forceinline__ BlurGeom blur_geom(const OrbLevels &G, const BlurTile
 
 // The raw tile travels global -> LDS without passing through registers (global_load_lds_dwordx4: a wave instruction writes
 // 64 x 16 bytes to CONSECUTIVE LDS addresses, so the LDS image is chunk-linear: chunk id = 13 * row + column chunk, the
-// thirteenth chunk of a row being the pad that keeps the rows' bank groups apart).  832 chunks = 13 wave instructions, dealt
-// to the four waves.  A workgroup takes TWO consecutive tiles of a frame and requests both at once, each into its own LDS
+// thirteenth chunk of a row being the pad that keeps the rows' bank groups apart).  16 wave instructions of four rows each,
+// dealt to the four waves (blur_dma).  A workgroup takes TWO consecutive tiles of a frame and requests both at once, each into its own LDS
 // buffer: the second tile travels while the first is computed.  Order of one workgroup (no wait ever covers a store):
 //     request tile 0, tile 1, the tables | wait tile 0 | compute 0 | wait tile 1 | store 0 | compute 1 | store 1
 #define BM_TPW 2
-#define BM_WCH (BM_IN * BM_CW / 64)          // wave instructions per tile
-static_assert(BM_WCH * 64 == BM_IN * BM_CW, "the chunk-linear tile is a whole number of wave instructions");
 
 // one global_load_lds_dwordx4: 16 bytes per lane from its own address to LDS byte address ldsAddr + 16 * lane.  As inline
 // assembly: the builtin makes hipcc wait vmcnt(0) before every LDS access that might alias the destination (here: every
@@ -117,25 +115,39 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t ldsAddr)
                  : "memory");
 }
 
+// A transfer carries FOUR WHOLE ROWS of the chunk-linear image (4 x 13 chunks = 52 of the 64 lanes; 16 transfers per tile, four
+// per wave): a lane's (row of the four, chunk) is then the same for every transfer, the global address of transfer t is the
+// lane's first address plus 4 t rows -- a scalar offset -- and the rows need no reflection unless the tile touches the top or
+// the bottom of the image (block-uniform).  (The first version dealt 64 consecutive chunks to a transfer, 13 transfers per
+// tile: a division by 13, a reflection and two clamps per lane and transfer -- a quarter of the kernel's vector instructions.)
 __device__ __forceinline__ void blur_dma(const BlurGeom &g, uint8_t *ldsTile, int wv, int lane)
 {
     const uint32_t ldsBase = (uint32_t)(uintptr_t)ldsTile;   // LDS byte address (low half of the flat address)
     const int wAl = (g.w + 15) & ~15;   // bytes of a row that may be read with 16-byte loads
+    const int rl = (lane * 5) >> 6;     // lane / 13 for lane < 64
+    const int c = lane - BM_CW * rl;
+    const bool live = lane < 4 * BM_CW;
+    // (a chunk outside the row -- or the pad chunk -- reads other pixels of the row: columns beyond the three reflected
+    // ones, patched below, only reach outputs outside the image)
+    const int xoff = min(max(g.x0 - 16 + (c << 4), 0), wAl - 16);
+    const int yb = g.y0 - 3;            // image row of the tile's row 0
+    if (yb >= 0 && yb + BM_IN <= g.h) {
+        const uint8_t *p = g.src + (size_t)(yb + rl) * g.sstride + xoff;
 #pragma unroll
-    for (int j4 = 0; j4 < (BM_WCH + 3) / 4; j4++) {
-        const int j = wv + 4 * j4;       // wave-uniform: wave 0 issues 4 transfers, the others 3
-        if (j < BM_WCH) {
-            const int i = 64 * j + lane;
-            const int r = i / BM_CW, c = i - r * BM_CW;
-            const int sy = reflect101(min(g.y0 - 3 + r, g.h + 2), g.h);
-            const int sx = g.x0 - 16 + (c << 4);
-            // (a chunk outside the row -- or the pad chunk -- reads other pixels of the row: columns beyond the three reflected
-            // ones, patched below, only reach outputs outside the image)
-            const uint8_t *src = g.src + (size_t)sy * g.sstride + min(max(sx, 0), wAl - 16);
-            glds16(src, __builtin_amdgcn_readfirstlane(ldsBase + 1024u * (uint32_t)j));
+        for (int j4 = 0; j4 < BM_IN / 16; j4++) {
+            const int t = wv + 4 * j4;   // wave-uniform
+            if (live) glds16(p + (size_t)(4 * t) * g.sstride, __builtin_amdgcn_readfirstlane(ldsBase + (uint32_t)(4 * BM_PITCH) * (uint32_t)t));
+        }
+    } else {
+#pragma unroll
+        for (int j4 = 0; j4 < BM_IN / 16; j4++) {
+            const int t = wv + 4 * j4;
+            const int sy = reflect101(min(yb + 4 * t + rl, g.h + 2), g.h);
+            if (live) glds16(g.src + (size_t)sy * g.sstride + xoff, __builtin_amdgcn_readfirstlane(ldsBase + (uint32_t)(4 * BM_PITCH) * (uint32_t)t));
         }
     }
 }
+static_assert(BM_PITCH == 16 * BM_CW && BM_IN % 16 == 0, "four rows of the chunk-linear image per transfer");
 
 #define BM_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -169,9 +181,9 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
     const BlurGeom g1 = blur_geom(G, T1, frame, lvl0, stride0, frame0, pyr, pyrFrame, blur, blurFrame);
     blur_dma(g0, smem, wv, lane);
     if (two) blur_dma(g1, smem + BM_IN * BM_PITCH, wv, lane);
-    // tile 0 has landed when at most tile 1's transfers (4 on wave 0, 3 on the others) are outstanding (in-order return)
+    // tile 0 has landed when at most tile 1's four transfers are outstanding (in-order return)
     if (two) {
-        if (wv == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
