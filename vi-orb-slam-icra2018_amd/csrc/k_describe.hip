@@ -89,7 +89,7 @@ __device__ __forceinline__ int wave_sum(int v)
 #define DESCRIBE_DEFAULT_MAP 4
 
 template <int DS_KP>
-__global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
+__global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                                   int stride0, unsigned long long frame0,
                                                   const uint8_t *__restrict__ pyr,
                                                   unsigned long long pyrFrame,
@@ -163,18 +163,22 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         // +15 -- read a valid neighbouring address and are masked in the arithmetic): a conditional load per
         // trip would compile to five exec-masked regions with a full wait between them.
         const int lrs = min(lane, 62) / 9, ldi = min(lane, 62) - lrs * 9;
+        // A keypoint's position, level and strides are the same for the whole wave: taken as SCALARS (v_readfirstlane of the
+        // LDS broadcast), so that the image address is scalar arithmetic and a load is (scalar base) + (32-bit lane offset):
+        // one v_mad per load instead of a 64-bit multiply-add chain per lane (a sixth of the kernel's vector instructions).
+        int lrow[5];   // this lane's row of the disc in trip it, counted from the top row (clamped to the last one)
+#pragma unroll
+        for (int it = 0; it < 5; it++) lrow[it] = min(it * 7 + lrs, 2 * ORB_HALF_PATCH);
         auto load5 = [&](int kp, uint32_t wd[5]) {
-            const int pos = s_pos[kp];
+            const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
             if (pos >= 0) {
                 const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
-                const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + s_ioff[kp];
-                const int stride = s_istride[kp];
-                const uint8_t *p = img + (size_t)cy * stride + ((cx - ORB_HALF_PATCH) & ~3) + 4 * ldi;
+                const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_ioff[kp]);
+                const int stride = __builtin_amdgcn_readfirstlane(s_istride[kp]);
+                const uint8_t *p = img + (size_t)(cy - ORB_HALF_PATCH) * stride + ((cx - ORB_HALF_PATCH) & ~3);
 #pragma unroll
-                for (int it = 0; it < 5; it++) {
-                    const int v = min(-ORB_HALF_PATCH + it * 7 + lrs, ORB_HALF_PATCH);
-                    wd[it] = *reinterpret_cast<const uint32_t *>(p + v * stride);
-                }
+                for (int it = 0; it < 5; it++)
+                    wd[it] = *reinterpret_cast<const uint32_t *>(p + (unsigned)(__mul24(lrow[it], stride) + 4 * ldi));
             }
         };
         int dmax[5];   // half width of the disc row this lane reads in trip it (umax of |v|), fixed per lane
@@ -185,8 +189,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         }
         const int kp0 = wave * (DS_KP / 4);
         // ring of three row sets, prefetch distance two: the loads of keypoints q + 1 and q + 2 are in flight while q is
-        // reduced (the kernel waits on memory latency, not on issue slots or bandwidth: profiles/r02*/describe.md); the
-        // keypoint loop is unrolled so that the ring is indexed statically
+        // reduced; the keypoint loop is unrolled so that the ring is indexed statically
         constexpr int NQ = DS_KP / 4;
         uint32_t ring[3][5];
         load5(kp0, ring[0]);
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
             const int kp = kp0 + q;
             if (q + 2 < NQ) load5(kp + 2, ring[(q + 2) % 3]);
             const uint32_t *cur = ring[q % 3];
-            const int pos = s_pos[kp];
+            const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
             if (pos >= 0) {   // wave-uniform
                 const int cx = pos & 0xFFF;
                 const int u0 = ((cx - ORB_HALF_PATCH) & ~3) + 4 * di - cx;
@@ -283,15 +286,15 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         pdw[it] = idx - prow[it] * DS_PDW;
     }
     auto load7 = [&](int kp, uint32_t wd[DS_TRIPS]) {
-        const int pos = s_pos[kp];
-        if (pos >= 0) {   // one region, unconditional loads (see phase A)
+        const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+        if (pos >= 0) {   // one region, unconditional loads (see phase A); scalar base + 32-bit lane offset
             const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF;
-            const uint8_t *bimg = blur + (size_t)frame * blurFrame + s_boff[kp];
-            const int bstride = s_bstride[kp];
+            const uint8_t *bimg = blur + (size_t)frame * blurFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_boff[kp]);
+            const int bstride = __builtin_amdgcn_readfirstlane(s_bstride[kp]);
             const uint8_t *p = bimg + (size_t)(cy - DS_R) * bstride + ((cx - DS_R) & ~3);
 #pragma unroll
             for (int it = 0; it < DS_TRIPS; it++)
-                wd[it] = *reinterpret_cast<const uint32_t *>(p + prow[it] * bstride + 4 * pdw[it]);
+                wd[it] = *reinterpret_cast<const uint32_t *>(p + (unsigned)(__mul24(prow[it], bstride) + 4 * pdw[it]));
         }
     };
     const int kp0 = wave * (DS_KP / 4);
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
     for (int q = 0; q < NQ; q++) {
         const int kp = kp0 + q;
         const uint32_t *cur = ring[q % 3];
-        const int pos = s_pos[kp];
+        const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
         if (pos >= 0) {
 #pragma unroll
             for (int it = 0; it < DS_TRIPS; it++)
@@ -313,11 +316,12 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevels G, const uint8
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (q + 2 < NQ) load7(kp + 2, ring[(q + 2) % 3]);
-        const int o = s_out[kp];
+        const int o = __builtin_amdgcn_readfirstlane(s_out[kp]);
         if (pos >= 0 && o < cap) {   // wave-uniform
             const int cx = pos & 0xFFF;
             const uint8_t *bc = patchB + DS_R * (DS_PDW * 4) + DS_R + ((cx - DS_R) & 3);   // the keypoint inside the patch
-            const float a = s_a[kp], b = s_b[kp];
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[kp])));
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[kp])));
             unsigned long long words[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -369,3 +373,4 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
         ORB_LAUNCH_DESCRIBE(8);
 #undef ORB_LAUNCH_DESCRIBE
 }
+
