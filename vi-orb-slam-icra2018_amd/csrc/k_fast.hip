@@ -1165,6 +1165,7 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     // the usual 30-pixel cell grid) when no level needs more, the run-time pitch otherwise (ORBHIP_FAST_PITCH=0 forces the latter)
     static const int pitchEnv = getenv("ORBHIP_FAST_PITCH") ? atoi(getenv("ORBHIP_FAST_PITCH")) : 1;
     const int fixed = pitchEnv == 0 ? 0 : maxPitch <= 176 ? 176 : maxPitch <= 192 ? 192 : maxPitch <= 208 ? 208 : 0;
+    const int fixedFix = fixed && maxPitch <= 160 ? 160 : fixed;   // the fixed-layout kernel also has a 160-byte instance
     if (fixed) pixBytes = (fixed * maxRh + 15) & ~15;
     const size_t lds = (size_t)(pixBytes + scoreBytes + lBytes + cBytes + bitsBytes + preBytes);
     // the fixed-layout kernel when every level fits its bounds (ORBHIP_FAST_FIX=0: the generic kernel)
@@ -1180,13 +1181,15 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, G.totalCells, G.totalCands, G.iniTh, G.minTh, lc, \
                        cc, phases, orb_xcd_arg(), ntiles)
         if (deferEnv) {
-            switch (fixed) {
+            switch (fixedFix) {
+            case 160: ORB_LAUNCH_FIX(160, true); break;
             case 176: ORB_LAUNCH_FIX(176, true); break;
             case 192: ORB_LAUNCH_FIX(192, true); break;
             default: ORB_LAUNCH_FIX(208, true); break;
             }
         } else {
-            switch (fixed) {
+            switch (fixedFix) {
+            case 160: ORB_LAUNCH_FIX(160, false); break;
             case 176: ORB_LAUNCH_FIX(176, false); break;
             case 192: ORB_LAUNCH_FIX(192, false); break;
             default: ORB_LAUNCH_FIX(208, false); break;
