@@ -41,10 +41,10 @@ json.dump(t, open(d + "/traffic.json", "w"), indent=1)
 PY
 bash tools/fast_ablate.sh > $OUT/fast_ablate_time.txt 2>&1
 bash tools/fast_ablate_pmc.sh > $OUT/fast_ablate_pmc.txt 2>&1
-bash tools/pmc_gpu.sh l2 "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" 2>&1 | grep -E "^k_" > $OUT/counters_l2.txt
+timeout 300 bash tools/pmc_gpu.sh l2 "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" 2>&1 | grep -E "^k_" > $OUT/counters_l2.txt
 python tools/percall_latency.py > $OUT/percall_table.md 2> $OUT/percall_stderr.txt
 bash tools/latency_native.sh 3000 > $OUT/latency_native.json 2>&1
-VERIFY=8 bash tools/ab_env.sh 2 "ORBHIP_BLUR_PLACE=0" "ORBHIP_BLUR_PLACE=1" "ORBHIP_BLUR_PLACE=2" "ORBHIP_NO_SPLIT=1" "ORBHIP_NO_FUSE=1" > $OUT/schedules.txt 2>&1
+VERIFY=8 bash tools/ab_env.sh 2 "ORBHIP_BLUR_PLACE=0" "ORBHIP_BLUR_PLACE=1" "ORBHIP_BLUR_PLACE=2" "ORBHIP_NO_SPLIT=1" "ORBHIP_FAST_FIX=0" "ORBHIP_FAST_TILE_CELLS=5" > $OUT/schedules.txt 2>&1
 { nproc; lscpu | grep 'Model name'; rocm-smi --showclocks 2>/dev/null | head -12; } > $OUT/gpu_box_env.txt 2>&1
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 find $OUT -name '*.csv' -size +2M -delete
