@@ -174,3 +174,43 @@ def test_alternative_code_paths_give_the_same_results(env):
     ) % (os.path.join(root, "vi-orb-slam-icra2018_amd"), os.path.join(root, "oracle"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
     assert out.returncode == 0 and "paths ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("env", [
+    {"ORBHIP_FAST_FIX": "0"},                 # the generic FAST kernel (any cell grid) instead of the fixed-layout one
+    {"ORBHIP_FAST_DEFER": "0"},               # fixed-layout kernel: both polarities of a work-list entry in place
+    {"ORBHIP_FAST_TILE_CELLS": "5"},          # runs of five cells (wave 0 finishes two cells)
+    {"ORBHIP_FAST_TILE_CELLS": "2"},
+    {"ORBHIP_FAST_LISTCAP": "24"},            # every list overflows: dense scoring, score-tile scans, the wave-local fallbacks of pass 1
+    {"ORBHIP_FAST_LISTCAP": "24", "ORBHIP_FAST_FIX": "0"},
+    {"ORBHIP_NO_SPLIT": "1"},                 # batch schedules: no half-batch split; blur beside FAST
+    {"ORBHIP_BLUR_PLACE": "1"},
+])
+def test_alternative_batch_code_paths_give_the_same_results(env):
+    """The switchable choices of the BATCH path (read once per process): 16-frame batches of two geometries -- one inside the
+    fixed-layout FAST kernel's bounds, one with a low second threshold and many empty cells -- against the oracle, keypoints and
+    descriptors bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import orb_oracle_py as oracle\n"
+        "from orbhip import synth\n"
+        "from orbhip.extractor import ORBextractor\n"
+        "for (W, H, NF, NL, SF, INI, MN) in [(640, 480, 1000, 8, 1.2, 20, 7), (500, 333, 700, 6, 1.25, 45, 3)]:\n"
+        "    f = synth.make_frames(11, W, H, 4)\n"
+        "    f[3] = (f[3] // 6 + 100).astype(np.uint8)      # a low-contrast frame: most cells go to the second pass\n"
+        "    ex = ORBextractor(NF, SF, NL, INI, MN, max_w=W, max_h=H, max_batch=16); ref = oracle.Extractor(NF, SF, NL, INI, MN)\n"
+        "    want = [ref(x) for x in f]\n"
+        "    ks, ds = ex.extract_batch(np.concatenate([f] * 4))\n"
+        "    for b in range(16):\n"
+        "        rk, rd = want[b %% 4]\n"
+        "        assert ks[b].tobytes() == rk.tobytes() and np.array_equal(ds[b], rd), (W, b)\n"
+        "    ex.close()\n"
+        "print('paths ok')\n"
+    ) % (os.path.join(root, "vi-orb-slam-icra2018_amd"), os.path.join(root, "oracle"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+    assert out.returncode == 0 and "paths ok" in out.stdout, out.stdout + out.stderr
