@@ -187,17 +187,19 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
             const int v = -ORB_HALF_PATCH + it * 7 + rsub;
             dmax[it] = G.umax[min(v < 0 ? -v : v, ORB_HALF_PATCH)];
         }
-        const int kp0 = wave * (DS_KP / 4);
+        const int kp0 = wave;   // wave w takes the slots w, w + 4, w + 8, ...: at any time the four waves work on four ADJACENT slots
+                                // (neighbours in the quadtree's list are mostly neighbours in the image: their rows share cache lines,
+                                // -3.5 % time; sorting a level's keypoints by the Morton code of their position first adds nothing)
         // ring of three row sets, prefetch distance two: the loads of keypoints q + 1 and q + 2 are in flight while q is
         // reduced; the keypoint loop is unrolled so that the ring is indexed statically
         constexpr int NQ = DS_KP / 4;
         uint32_t ring[3][5];
         load5(kp0, ring[0]);
-        if (NQ > 1) load5(kp0 + 1, ring[1]);
+        if (NQ > 1) load5(kp0 + 4, ring[1]);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            const int kp = kp0 + q;
-            if (q + 2 < NQ) load5(kp + 2, ring[(q + 2) % 3]);
+            const int kp = kp0 + 4 * q;
+            if (q + 2 < NQ) load5(kp + 8, ring[(q + 2) % 3]);
             const uint32_t *cur = ring[q % 3];
             const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
             if (pos >= 0) {   // wave-uniform
@@ -297,14 +299,14 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
                 wd[it] = *reinterpret_cast<const uint32_t *>(p + (unsigned)(__mul24(prow[it], bstride) + 4 * pdw[it]));
         }
     };
-    const int kp0 = wave * (DS_KP / 4);
+    const int kp0 = wave;   // (as in phase A)
     constexpr int NQ = DS_KP / 4;
     uint32_t ring[3][DS_TRIPS];       // as in phase A: two keypoints' patches in flight behind the one in LDS
     load7(kp0, ring[0]);
-    if (NQ > 1) load7(kp0 + 1, ring[1]);
+    if (NQ > 1) load7(kp0 + 4, ring[1]);
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const int kp = kp0 + q;
+        const int kp = kp0 + 4 * q;
         const uint32_t *cur = ring[q % 3];
         const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
         if (pos >= 0) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (q + 2 < NQ) load7(kp + 2, ring[(q + 2) % 3]);
+        if (q + 2 < NQ) load7(kp + 8, ring[(q + 2) % 3]);
         const int o = __builtin_amdgcn_readfirstlane(s_out[kp]);
         if (pos >= 0 && o < cap) {   // wave-uniform
             const int cx = pos & 0xFFF;
