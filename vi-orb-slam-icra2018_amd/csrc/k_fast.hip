@@ -9,12 +9,14 @@
 // CELL (other cells' pixels count as 0, exactly like the zeroed score rows/columns outside a
 // sub-image), and per cell keep the survivors >= iniThFAST if there is any, else all survivors.
 //
-// One 256-thread workgroup per (frame, run of <= 5 cells of one cell-row): stage the run's pixels (+3 px halo) into LDS
-// with 16-byte row-coalesced loads, then the passes and phases described above k_fast below.  No global atomics,
-// deterministic.
+// One 256-thread workgroup per (frame, run of <= 4 cells of one cell-row): stage the run's pixels (+3 px halo) into LDS, then
+// the passes and phases described above the kernels below.  No global atomics, deterministic.  Two kernels, same results:
+//   k_fast_fix<PITCH>  the usual cell grid (rows of <= 208 staged bytes, cells of <= 34 rows): fixed LDS layout, geometry from the
+//                      run's descriptor, LDS-DMA staging, second pass and candidate order by one wave per cell (round 3);
+//   k_fast<PITCH>      any grid (round 2); also ORBHIP_FAST_FIX=0.
 // HBM traffic: each level pixel inside [16, w-16) x [16, h-16) is read once per tile that needs it;
 // the 6-row vertical halo (hCell ~ 30) is re-read by the tile below.  Roofline: nominally HBM read
-// (algorithmic bytes = sum_l (w_l-32)(h_l-32) per frame); measured bound is integer VALU + LDS
+// (algorithmic bytes = sum_l (w_l-32)(h_l-32) per frame); measured bound is vector-instruction issue
 // (DESIGN.md section 4).
 #include "orbhip_internal.h"
 
