@@ -157,6 +157,12 @@ def test_kernel_index_division_tricks_are_exact():
         assert np.array_equal((i * m) >> 20, i // spw)
     idx = np.arange(384)
     assert np.array_equal((idx * 6554) >> 16, idx // 10)
+    for gpr in range(1, 129):       # grpMagic (k_fast_fix): thread -> row segment, tid // groups per row
+        m = 65536 // gpr + 1
+        t = np.arange(256)
+        assert np.array_equal((t * m) >> 16, t // gpr)
+    lane = np.arange(64)            # k_blur's LDS-DMA: lane // 13
+    assert np.array_equal((lane * 5) >> 6, lane // 13)
 
 
 def test_lerp_compass_formulas_are_exact_for_every_q_v_t():
