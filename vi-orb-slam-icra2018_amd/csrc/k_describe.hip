@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
     // per-lane level costs a dependent memory round trip every time)
     __shared__ unsigned s_ioff[DS_KP], s_boff[DS_KP];
     __shared__ int s_istride[DS_KP], s_bstride[DS_KP];
-    __shared__ uint32_t s_patch[4][DS_ROWS * DS_PDW + 3];
+    // batches: three patch buffers per wave, filled by LDS-DMA (the next two keypoints' patches travel while one is used)
+    constexpr bool PDMA = DS_KP >= 16;
+    __shared__ __align__(16) uint32_t s_patch[4][PDMA ? 3 : 1][DS_TRIPS * 64];
     int blk = xcd_tile(xcdMap), frame = blockIdx.y;
     if ((xcdMap & 255) == 4) xcd_frame_tile((int)gridDim.y, blk, frame);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -193,14 +195,15 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
         // ring of three row sets, prefetch distance two: the loads of keypoints q + 1 and q + 2 are in flight while q is
         // reduced; the keypoint loop is unrolled so that the ring is indexed statically
         constexpr int NQ = DS_KP / 4;
-        uint32_t ring[3][5];
-        load5(kp0, ring[0]);
-        if (NQ > 1) load5(kp0 + 4, ring[1]);
+        constexpr int RA = NQ <= 4 ? 4 : 3;    // ring entries: with four or fewer keypoints per wave all their rows are requested at once
+        uint32_t ring[RA][5];
+#pragma unroll
+        for (int q = 0; q < RA - 1 && q < NQ; q++) load5(kp0 + 4 * q, ring[q]);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const int kp = kp0 + 4 * q;
-            if (q + 2 < NQ) load5(kp + 8, ring[(q + 2) % 3]);
-            const uint32_t *cur = ring[q % 3];
+            if (q + RA - 1 < NQ) load5(kp + 4 * (RA - 1), ring[(q + RA - 1) % RA]);
+            const uint32_t *cur = ring[q % RA];
             const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
             if (pos >= 0) {   // wave-uniform
                 const int cx = pos & 0xFFF;
@@ -278,8 +281,6 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
         px1[j] = (float)(signed char)((pw >> 16) & 0xFF);
         py1[j] = (float)(signed char)((pw >> 24) & 0xFF);
     }
-    uint32_t *patch = s_patch[wave];
-    const uint8_t *patchB = reinterpret_cast<const uint8_t *>(patch);
     int prow[DS_TRIPS], pdw[DS_TRIPS];     // this lane's (row, dword) of every trip; the tail lanes repeat the last dword
 #pragma unroll
     for (int it = 0; it < DS_TRIPS; it++) {
@@ -287,37 +288,80 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
         prow[it] = (int)(((unsigned)idx * 6554u) >> 16);   // idx / 10 for idx < 384
         pdw[it] = idx - prow[it] * DS_PDW;
     }
+    // the patch of slot kp: scalar base + this lane's 32-bit offsets (one region, unconditional loads, see phase A)
+    auto patch_base = [&](int kp, int pos, int &bstride) -> const uint8_t * {
+        const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF;
+        const uint8_t *bimg = blur + (size_t)frame * blurFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_boff[kp]);
+        bstride = __builtin_amdgcn_readfirstlane(s_bstride[kp]);
+        return bimg + (size_t)(cy - DS_R) * bstride + ((cx - DS_R) & ~3);
+    };
     auto load7 = [&](int kp, uint32_t wd[DS_TRIPS]) {
         const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
-        if (pos >= 0) {   // one region, unconditional loads (see phase A); scalar base + 32-bit lane offset
-            const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF;
-            const uint8_t *bimg = blur + (size_t)frame * blurFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_boff[kp]);
-            const int bstride = __builtin_amdgcn_readfirstlane(s_bstride[kp]);
-            const uint8_t *p = bimg + (size_t)(cy - DS_R) * bstride + ((cx - DS_R) & ~3);
+        if (pos >= 0) {
+            int bstride;
+            const uint8_t *p = patch_base(kp, pos, bstride);
 #pragma unroll
             for (int it = 0; it < DS_TRIPS; it++)
                 wd[it] = *reinterpret_cast<const uint32_t *>(p + (unsigned)(__mul24(prow[it], bstride) + 4 * pdw[it]));
         }
     };
+    // LDS-DMA form (batches): global_load_lds_dword writes lane i's dword to LDS address M0 + 4 i, i.e. trip `it` fills the
+    // dwords 64 it .. 64 it + 63 of the buffer -- the patch image itself (row-major, 10 dwords per row; the tail lanes of the last
+    // trip land beyond it).  No registers, no ds_write; returns whether the transfers were issued (wave-uniform).
+    auto dma7 = [&](int kp, uint32_t *buf) -> bool {
+        const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+        if (pos < 0) return false;
+        int bstride;
+        const uint8_t *p = patch_base(kp, pos, bstride);
+        const uint32_t ldsAddr = (uint32_t)(uintptr_t)buf;
+#pragma unroll
+        for (int it = 0; it < DS_TRIPS; it++) {
+            const uint8_t *src = p + (unsigned)(__mul24(prow[it], bstride) + 4 * pdw[it]);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(__builtin_amdgcn_readfirstlane((int)(ldsAddr + 256u * (uint32_t)it)))
+                         : "memory");
+        }
+        return true;
+    };
     const int kp0 = wave;   // (as in phase A)
     constexpr int NQ = DS_KP / 4;
-    uint32_t ring[3][DS_TRIPS];       // as in phase A: two keypoints' patches in flight behind the one in LDS
-    load7(kp0, ring[0]);
-    if (NQ > 1) load7(kp0 + 4, ring[1]);
+    uint32_t ring[PDMA ? 1 : 3][DS_TRIPS];       // register form: two keypoints' patches in flight behind the one in LDS
+    bool sent[NQ + 2];
+#pragma unroll
+    for (int q = 0; q < NQ + 2; q++) sent[q] = false;
+    if (PDMA) {
+        sent[0] = dma7(kp0, s_patch[wave][0]);
+        if (NQ > 1) sent[1] = dma7(kp0 + 4, s_patch[wave][1]);
+    } else {
+        load7(kp0, ring[0]);
+        if (NQ > 1) load7(kp0 + 4, ring[(PDMA ? 0 : 1)]);
+    }
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         const int kp = kp0 + 4 * q;
-        const uint32_t *cur = ring[q % 3];
         const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
-        if (pos >= 0) {
+        uint32_t *patch = s_patch[wave][PDMA ? q % 3 : 0];
+        if (PDMA) {
+            // this keypoint's transfers have landed when only the next keypoint's six (if any were issued) are outstanding
+            if (sent[q + 1]) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const uint32_t *cur = ring[PDMA ? 0 : q % 3];
+            if (pos >= 0) {
 #pragma unroll
-            for (int it = 0; it < DS_TRIPS; it++)
-                if (it * 64 + lane < DS_ROWS * DS_PDW) patch[it * 64 + lane] = cur[it];
+                for (int it = 0; it < DS_TRIPS; it++)
+                    if (it * 64 + lane < DS_ROWS * DS_PDW) patch[it * 64 + lane] = cur[it];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (q + 2 < NQ) load7(kp + 8, ring[(q + 2) % 3]);
+        if (q + 2 < NQ) {
+            if (PDMA) sent[q + 2] = dma7(kp + 8, s_patch[wave][(q + 2) % 3]);
+            else load7(kp + 8, ring[PDMA ? 0 : (q + 2) % 3]);
+        }
+        const uint8_t *patchB = reinterpret_cast<const uint8_t *>(patch);
         const int o = __builtin_amdgcn_readfirstlane(s_out[kp]);
         if (pos >= 0 && o < cap) {   // wave-uniform
             const int cx = pos & 0xFFF;
