@@ -74,7 +74,7 @@ __device__ __forceinline__ int wave_sum(int v)
 //   C. wave per keypoint again: the lane's four test pairs are decoded once (16 floats), then per keypoint 4 x
 //      (rotate, round, two byte gathers from the blurred level, compare, ballot).
 // DS_KP = slots per workgroup: 16 for batches (see DESCRIBE_DEFAULT_MAP below), 8 for a single frame or two (more
-// workgroups, shorter serial chains per wave: latency); 32 / 64 remain for A/B runs (ORBHIP_DESCRIBE_KPW)
+// workgroups, shorter serial chains per wave: latency); 32 remains for A/B runs (ORBHIP_DESCRIBE_KPW)
 #define DS_R 18                       // pattern radius <= 18.385, so a rotated, rounded coordinate is at most 18
 #define DS_ROWS (2 * DS_R + 1)        // 37 patch rows
 #define DS_PDW 10                     // dwords per staged row: 37 bytes + up to 3 bytes of alignment
@@ -396,7 +396,7 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
 {
     static const int kpwEnv = getenv("ORBHIP_DESCRIBE_KPW") ? atoi(getenv("ORBHIP_DESCRIBE_KPW")) : 0;
-    const int kpw = kpwEnv == 8 || kpwEnv == 16 || kpwEnv == 32 || kpwEnv == 64 ? kpwEnv : (B >= 8 ? 16 : 8);
+    const int kpw = kpwEnv == 8 || kpwEnv == 16 || kpwEnv == 32 ? kpwEnv : (B >= 8 ? 16 : 8);
     // workgroup -> (slot block, frame): ORBHIP_DESCRIBE_MAP overrides this kernel's mapping alone (A/B runs)
     static const int dmap = getenv("ORBHIP_DESCRIBE_MAP") ? atoi(getenv("ORBHIP_DESCRIBE_MAP")) : -1;
     const int mapArg = dmap >= 0 ? (dmap | (orb_xcd_chunk() << 8)) : orb_xcd_arg(DESCRIBE_DEFAULT_MAP);
@@ -409,9 +409,7 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
     hipLaunchKernelGGL(k_describe<K>, grid, block, (size_t)padLds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc, \
                        counts, cap, mapArg, phases)
-    if (kpw == 64)
-        ORB_LAUNCH_DESCRIBE(64);
-    else if (kpw == 32)
+    if (kpw == 32)
         ORB_LAUNCH_DESCRIBE(32);
     else if (kpw == 16)
         ORB_LAUNCH_DESCRIBE(16);
