@@ -64,7 +64,7 @@ __device__ __forceinline__ int wave_sum(int v)
            __builtin_amdgcn_readlane(v, 48);
 }
 
-// One 256-thread workgroup per DS_KP = 64 slots of the per-frame level-keypoint array:
+// One 256-thread workgroup per DS_KP slots (16 for batches) of the per-frame level-keypoint array:
 //   0. thread per slot: level, position, output index (levels concatenated in order, :1094-1122);
 //   A. wave per keypoint (each wave walks 16 slots): the disc rows as aligned dwords, lane -> (row of a group
 //      of 7, dword 0..8 of the row), 5 trips cover the 31 rows; valid bytes are cut out with a mask and summed
