@@ -31,6 +31,16 @@ static int bs_threads()
     return n;
 }
 
+// 16 bytes per lane from global memory straight into LDS at (ldsAddr + 16 * lane); M0 carries the LDS address and is restored
+__device__ __forceinline__ void bs_glds16(const void *gsrc, uint32_t ldsAddr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(ldsAddr)
+                 : "memory");
+}
+
 struct BsBest {
     int b1, pos, b2;
 };
@@ -174,10 +184,6 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
         vbit1[i] = v1;
         vbit2[i] = v2;
     }
-    if (LDSD) {
-        for (int i = tid; i < n1 * 2; i += blockDim.x) ls1[i] = reinterpret_cast<const uint4 *>(d1)[i];
-        for (int i = tid; i < n2 * 2; i += blockDim.x) ls2[i] = reinterpret_cast<const uint4 *>(d2)[i];
-    }
     if (tid < BS_HISTO) s_hist[tid] = 0;
     if (tid == 0) {
         s_n1v = 0;
@@ -188,6 +194,19 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
     }
     __syncthreads();
     if (dbgPhases < 1) return;
+    if (LDSD) {
+        // both descriptor sets travel to LDS by LDS-DMA (16 bytes per lane, 1 KB per wave transfer) WHILE the keys are sorted: the
+        // sort and the item list only touch the key arrays, the descriptors are first read by the greedy phase (waited for before
+        // its barrier).  Issued after the key-building loads above so that no wait of the compiler's covers them.
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int)(blockDim.x >> 6);
+        for (int side = 0; side < 2; side++) {
+            const uint8_t *src = side ? d2 : d1;
+            const int nchunk = (side ? n2 : n1) * 2;
+            const uint32_t ldsBase = (uint32_t)(uintptr_t)(side ? ls2 : ls1);
+            for (int base = wv * 64; base < nchunk; base += nw * 64)
+                if (base + lane < nchunk) bs_glds16(src + (size_t)(base + lane) * 16, ldsBase + (uint32_t)base * 16u);
+        }
+    }
     // only indices < max(n1, n2) hold keys: sort the smallest power of two that covers them
     int NS = 64;
     while (NS < max(n1, n2)) NS <<= 1;
@@ -213,6 +232,7 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
             }
         }
     }
+    if (LDSD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's descriptor transfers have landed
     __syncthreads();
 
     if (dbgPhases < 3) return;
