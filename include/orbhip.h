@@ -435,6 +435,10 @@ int orbhip_remap_device(orbhip_ctx *ctx, const void *d_src, int B, int src_w, in
  * {pyramid, FAST, quadtree, blur, describe} and, at [5], of the last orbhip_hamming_knn2*_device
  * call.  Measured with HIP events on the context's stream; synchronises the stream. */
 int orbhip_get_stage_times(orbhip_ctx *ctx, float ms[6]);
+/* Which of those events the extract / match calls record: 2 (default) all of them, 1 only the pair around the FAST launch
+ * (the other entries read 0), 0 none.  An event between two kernels of a stream costs a few microseconds of device time;
+ * a loop that only wants its throughput (and bench.py, which wants the FAST launch time) narrows the set. */
+int orbhip_set_stage_timing(orbhip_ctx *ctx, int mode);
 /* Scheduling of the batched path (affects speed only, never a result): where the Gaussian blur (ref:
  * src/ORBextractor.cc:1103-1104) runs.  0 (default): on the context's second stream behind FAST -- FAST, the kernel whose
  * roofline is reported, owns the device while it runs; the quadtree is cut into two half-batches, the first beside the blur,

@@ -148,3 +148,30 @@ def test_results_of_a_wait_survive_the_submits_that_follow(oracle):
     for a in bufs:
         ex.host_free(a)
     ex.close()
+
+
+@pytest.mark.gpu
+def test_stage_timing_modes_change_no_result():
+    """orbhip_set_stage_timing: 2 records every stage's events, 1 only the pair around the FAST launch (the other stage times
+    read 0), 0 none; keypoints and descriptors of a batch are the same in all three."""
+    import ctypes as C
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    W, H, B = 400, 300, 16
+    frames = synth.make_frames(5, W, H, B)
+    ex = ORBextractor(600, 1.2, 6, 20, 7, max_w=W, max_h=H, max_batch=B)
+    L = ex._L
+    want = None
+    for mode, nonzero in ((2, {0, 1, 2, 3, 4}), (1, {1}), (0, set())):
+        assert L.orbhip_set_stage_timing(ex.handle, mode) == 0
+        ks, ds = ex.extract_batch(frames)
+        ms = (C.c_float * 6)()
+        assert L.orbhip_get_stage_times(ex.handle, ms) == 0
+        for i in range(5):
+            assert (ms[i] > 0) == (i in nonzero), (mode, i, ms[i])
+        got = [(k.tobytes(), d.tobytes()) for k, d in zip(ks, ds)]
+        if want is None:
+            want = got
+        assert got == want, mode
+    assert L.orbhip_set_stage_timing(ex.handle, 3) != 0
+    ex.close()

@@ -273,7 +273,9 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     hipStream_t s = c->stream;
     // (timing events are not recorded into a graph capture: events recorded by a graph node cannot be read back with
     // hipEventElapsedTime on this runtime; the graph path refreshes the stage times with an eager run now and then)
-    const bool ev = !c->capturing;
+    // (an event record between two kernels of a stream costs ~4 us of device time: orbhip_set_stage_timing narrows the set)
+    const bool ev = !c->capturing && c->stageTiming >= 2;
+    const bool evFast = !c->capturing && c->stageTiming >= 1;
     if (ev) HIPCHK(c, hipEventRecord(c->ev[0], s));
     // E2 pyramid.  A frame or two: several levels per launch (k_pyramid_chain; ORBHIP_NO_CHAIN=1 keeps one launch per level)
     static const bool noChain = getenv("ORBHIP_NO_CHAIN") && atoi(getenv("ORBHIP_NO_CHAIN")) != 0;
@@ -293,7 +295,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
                       c->d_resizeTab + c->resizeTabOff[l][1],
                       c->resizeGroups[l] ? c->d_resizeTab + c->resizeTabOff[l][2] : nullptr, c->resizeHint[l][B >= 8 ? 0 : 1], B);
     }
-    if (ev) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (evFast) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // host copy of levels 1.. (orbhip_set_host_pyramid): one copy of the B frames' pyramid block into pinned memory.  A
     // frame or two: on the second stream, beside FAST / quadtree / blur / describe (those do not use it then); the main
     // stream joins it at the end.  Batches (the second stream carries the blur): behind the describe kernel.
@@ -337,7 +339,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     if (B >= 8 && blurPlace == 1) {
         HIPCHK(c, hipEventRecord(c->evx[0], s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evx[0], 0));
-        HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+        if (ev) HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
         blur_all(c->stream2);
         HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
     }
@@ -347,13 +349,13 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     else
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
-    if (ev) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));
     static const bool noSplit = getenv("ORBHIP_NO_SPLIT") && atoi(getenv("ORBHIP_NO_SPLIT")) != 0;   // A/B: r02 schedule
     if (B >= 16 && blurPlace == 0 && !noSplit) {
         const int nA = B / 2, nB = B - nA;
-        if (!ev) HIPCHK(c, hipEventRecord(c->ev[2], s));       // (the hand-over event; the timing path has recorded it)
+        if (!evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));   // (the hand-over event; the timing path has recorded it)
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
-        HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+        if (ev) HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
         blur_all(c->stream2);
         HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
         quadtree_part(c->stream2, nA, nB);                      // behind the blur, i.e. beside describe(A)
@@ -367,13 +369,13 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         describe_part(s, nA, nB);
     } else if (B >= 8) {
         if (blurPlace == 0) {
-            if (!ev) HIPCHK(c, hipEventRecord(c->ev[2], s));
+            if (!evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
-            HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
+            if (ev) HIPCHK(c, hipEventRecord(c->evx[1], c->stream2));
             blur_all(c->stream2);
             HIPCHK(c, hipEventRecord(c->evx[2], c->stream2));
         } else if (blurPlace == 2) {
-            HIPCHK(c, hipEventRecord(c->evx[1], s));
+            if (ev) HIPCHK(c, hipEventRecord(c->evx[1], s));
             blur_all(s);
             HIPCHK(c, hipEventRecord(c->evx[2], s));
         }
@@ -397,7 +399,11 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     else if (h_pyr_dst && G.nlevels > 1 && !chained)
         HIPCHK(c, hipMemcpyAsync(h_pyr_dst, c->d_pyr, (size_t)B * c->pyrFrameBytes, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipGetLastError());
-    if (ev) c->haveStageEvents = true;
+    if (!c->capturing) {
+        c->haveStageEvents = ev;
+        c->haveFastEvents = evFast;
+        c->haveMatchEvents = false;
+    }
     c->last_lvl0 = lvl0;
     c->last_stride0 = stride0;
     c->last_frame0 = frame0;
@@ -412,12 +418,20 @@ extern "C" int orbhip_set_blur_placement(orbhip_ctx *c, int place)
     return ORBHIP_OK;
 }
 
+extern "C" int orbhip_set_stage_timing(orbhip_ctx *c, int mode)
+{
+    if (!c || mode < 0 || mode > 2) return fail(c, ORBHIP_E_ARG, "orbhip_set_stage_timing: 0, 1 or 2");
+    c->stageTiming = mode;
+    return ORBHIP_OK;
+}
+
 extern "C" int orbhip_get_stage_times(orbhip_ctx *c, float ms[6])
 {
     if (!c || !ms) return fail(c, ORBHIP_E_ARG, "orbhip_get_stage_times: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 6; i++) ms[i] = 0.f;
+    if (c->haveFastEvents && !c->haveStageEvents) HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));    // FAST
     if (c->haveStageEvents) {
         HIPCHK(c, hipStreamSynchronize(c->stream2));
         HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));    // pyramid

@@ -26,12 +26,12 @@ extern "C" int orbhip_hamming_knn2_device(orbhip_ctx *c, const void *d_q, int nq
     int rc;
     const size_t need = knn2_scratch_bytes(nq, ndb);
     if ((rc = orb_match_scratch(c, need))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     launch_knn2(c->stream, (const uint8_t *)d_q, nq, (const uint8_t *)d_db, ndb, (int32_t *)d_best_idx,
                 (int32_t *)d_best_d, (int32_t *)d_second_d, c->d_match, need);
-    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
-    c->haveMatchEvents = true;
+    c->haveMatchEvents = c->stageTiming >= 2;
     return ORBHIP_OK;
 }
 
@@ -41,12 +41,12 @@ extern "C" int orbhip_hamming_knn2_seq_device(orbhip_ctx *c, const void *d_desc,
     if (!c || !d_desc || !d_counts || cap <= 0 || B <= 0 || lag < 0 || !d_best_idx || !d_best_d || !d_second_d)
         return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2_seq_device: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     launch_knn2_seq(c->stream, (const uint8_t *)d_desc, (const int32_t *)d_counts, cap, B, lag,
                     (int32_t *)d_best_idx, (int32_t *)d_best_d, (int32_t *)d_second_d);
-    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
-    c->haveMatchEvents = true;
+    c->haveMatchEvents = c->stageTiming >= 2;
     return ORBHIP_OK;
 }
 
@@ -364,13 +364,13 @@ extern "C" int orbhip_search_by_bow_seq_device(orbhip_ctx *c, const void *d_desc
         return fail(c, ORBHIP_E_SIZE, "orbhip_search_by_bow_seq_device: more than 4096 feature slots per frame (the per-pair "
                                       "tables exceed the 160 KB of LDS); use orbhip_search_by_bow per pair");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     launch_bow_seq(c->stream, (const uint8_t *)d_desc, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts,
                    (const int32_t *)d_node, (const float *)d_weight, (const uint8_t *)d_valid, cap, B, lag, 50, th_mode,
                    nnratio, check_ori, (int32_t *)d_match12, (int32_t *)d_match21, (int32_t *)d_nmatches);
-    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
-    c->haveMatchEvents = true;
+    c->haveMatchEvents = c->stageTiming >= 2;
     return ORBHIP_OK;
 }
 

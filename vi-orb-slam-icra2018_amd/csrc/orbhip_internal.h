@@ -255,6 +255,8 @@ struct orbhip_ctx {
     // timing
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool haveStageEvents = false, haveMatchEvents = false;
+    int stageTiming = 2;     // orbhip_set_stage_timing: 2 = every stage (default), 1 = the FAST launch only, 0 = none
+    bool haveFastEvents = false;
 
     // rectification maps (orbhip_remap_set_maps): mapx then mapy, map_w * map_h floats each
     float *d_maps = nullptr;

@@ -25,7 +25,7 @@ SYMBOLS = [
     "orbhip_pipe_create", "orbhip_pipe_destroy", "orbhip_pipe_submit", "orbhip_pipe_wait", "orbhip_pipe_enable_bow", "orbhip_pipe_matches",
     "orbhip_get_pyramid_level", "orbhip_set_host_pyramid", "orbhip_host_pyramid_level", "orbhip_debug_get_blurred_level", "orbhip_debug_get_candidates",
     "orbhip_debug_get_level_keypoints", "orbhip_hamming_knn2", "orbhip_hamming_knn2_device",
-    "orbhip_hamming_knn2_seq_device", "orbhip_get_stage_times", "orbhip_set_blur_placement", "orbhip_vocab_load", "orbhip_vocab_load_device",
+    "orbhip_hamming_knn2_seq_device", "orbhip_get_stage_times", "orbhip_set_stage_timing", "orbhip_set_blur_placement", "orbhip_vocab_load", "orbhip_vocab_load_device",
     "orbhip_vocab_info", "orbhip_vocab_text_to_binary", "orbhip_vocab_transform", "orbhip_vocab_transform_device",
     "orbhip_search_by_bow_seq_device", "orbhip_stereo_match", "orbhip_stereo_match_device",
     "orbhip_hamming_knn2_lists", "orbhip_search_by_bow", "orbhip_comm_unique_id",
@@ -105,6 +105,7 @@ def load():
     L.orbhip_hamming_knn2_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     L.orbhip_hamming_knn2_seq_device.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.orbhip_get_stage_times.argtypes = [vp, vp]
+    L.orbhip_set_stage_timing.argtypes = [vp, i32]
     L.orbhip_set_blur_placement.argtypes = [vp, i32]
     L.orbhip_stereo_match.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, ip]
     L.orbhip_stereo_match_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp]
