@@ -280,6 +280,22 @@ __device__ __forceinline__ bool nms_survives(const uint8_t *s_score, int SP, int
     return s > m;
 }
 
+// nms_survives for the fixed-layout kernel: the eight neighbours are read unconditionally (one wait instead of one per
+// neighbour; a row above / below the tile lies inside the workgroup's LDS -- the score tile is padded by a row -- and reads
+// whatever is there) and the ones outside the cell or the tile are masked to 0.
+__device__ __forceinline__ bool nms_survives_fix(const uint8_t *s_score, int SP, int r, int c, int DH, int TW, int wCell, int cj)
+{
+    const uint8_t *sp = s_score + r * SP + c;
+    const int s = sp[0];
+    const int cx0 = cj * wCell, cx1 = min(cx0 + wCell, TW);
+    const int a = sp[-1], b = sp[1], u0 = sp[-SP - 1], u1 = sp[-SP], u2 = sp[-SP + 1], d0 = sp[SP - 1], d1 = sp[SP], d2 = sp[SP + 1];
+    const bool up = r > 0, dn = r < DH - 1, lf = c > cx0, rt = c < cx1 - 1;
+    int m = max(lf ? a : 0, rt ? b : 0);
+    m = max(m, up ? max(u1, max(lf ? u0 : 0, rt ? u2 : 0)) : 0);
+    m = max(m, dn ? max(d1, max(lf ? d0 : 0, rt ? d2 : 0)) : 0);
+    return s > m;
+}
+
 // PITCH: the LDS row pitch of the pixel tile as a compile-time constant (0 = from the tile's width at run time).  With it the
 // five dwords of a compass item and the 17 bytes of a score window are loads at immediate offsets from one address register.
 template <int PITCH>
@@ -950,7 +966,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 const int ent = s_corner[e];
                 const int r = ENT_ROW(ent), c = ENT_COL(ent) - j0;
                 const int cj = (int)(((unsigned)c * cellMagic) >> 16);
-                if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) {
+                if (nms_survives_fix(s_score, SP, r, c, DH, TW, wCell, cj)) {
                     atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * wCell));
                     s_cellAny[cj] = 1;   // benign race: every writer stores 1
                 }
@@ -972,7 +988,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                     const int c = cb + k;
                     if (s < t || c >= TW) continue;
                     const int cj = (int)(((unsigned)c * cellMagic) >> 16);
-                    if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) {
+                    if (nms_survives_fix(s_score, SP, r, c, DH, TW, wCell, cj)) {
                         atomicOr(&s_bits[cj * DH + r], 1ull << (c - cj * wCell));
                         s_cellAny[cj] = 1;
                     }
@@ -1074,7 +1090,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 for (int e = lane; e < ncor; e += 64) {
                     const int ent = wcorner[e];
                     const int r = ENT_ROW(ent), c = ENT_COL(ent) - j0;
-                    if (nms_survives(s_score, SP, r, c, DH, TW, wCell, cj)) atomicOr(&s_bits[cj * DH + r], 1ull << (c - cx0));
+                    if (nms_survives_fix(s_score, SP, r, c, DH, TW, wCell, cj)) atomicOr(&s_bits[cj * DH + r], 1ull << (c - cx0));
                 }
             } else {
                 // more corners than this wave's part of the corner list holds: scan the cell's scores
@@ -1084,7 +1100,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                     if (px < DH * cw) {
                         const int r = (int)(((float)px + 0.5f) * invCw);
                         const int c = cx0 + px - r * cw;
-                        if (s_score[r * SP + c] >= t && nms_survives(s_score, SP, r, c, DH, TW, wCell, cj))
+                        if (s_score[r * SP + c] >= t && nms_survives_fix(s_score, SP, r, c, DH, TW, wCell, cj))
                             atomicOr(&s_bits[cj * DH + r], 1ull << (c - cx0));
                     }
                 }
@@ -1177,7 +1193,7 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     if (fixEnv && fixed && maxRh <= FF_RHM && maxCells <= FF_NCM) {
         const int lc = forced > 0 ? std::min(forced, FF_LISTCAP) : listCapFix, cc = forced > 0 ? std::min(forced, FF_CORNERCAP) : cornerCapFix;
         static const int ldsPad = getenv("ORBHIP_FAST_LDS_PAD") ? atoi(getenv("ORBHIP_FAST_LDS_PAD")) : 0;   // occupancy experiments
-        const size_t ldsScore = (size_t)scoreBytes + 16 + (size_t)ldsPad;
+        const size_t ldsScore = (size_t)scoreBytes + 16 + 256 + (size_t)ldsPad;   // + a row: nms_survives_fix reads one below the tile
 #define ORB_LAUNCH_FIX(P, D)                                                                                                 \
     hipLaunchKernelGGL((k_fast_fix<P, D>), grid, block, ldsScore, s, lvl0, stride0, (unsigned long long)frame0, pyr,         \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, G.totalCells, G.totalCands, G.iniTh, G.minTh, lc, \
