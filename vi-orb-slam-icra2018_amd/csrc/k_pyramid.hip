@@ -90,23 +90,48 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     const bool colLive = gx < dw;
     int4 yt[NR];
     int2 xt[4] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
-#pragma unroll
-    for (int j = 0; j < NR; j++) yt[j] = ytab[min(dy0 + 8 * j, dh - 1)];
     const bool staged = nch <= RZ_MAXCH && nrows <= RZ_MAXROWS && nrows * nch <= 512;
     const bool grouped = staged && gtab != nullptr;
+    // batches, grouped taps: the tile's 32 row entries and 32 column-group entries (2 KB) travel to LDS once per workgroup by
+    // LDS-DMA (three wave transfers) instead of seven 16-byte gathers per thread, four times over (every wave wants the same
+    // column groups): the tables were as much L1 traffic as the pixels
+    constexpr bool TABDMA = RZ_TH == 32;
+    __shared__ __align__(16) int4 s_ytab[TABDMA ? 32 : 1];
+    __shared__ __align__(16) int4 s_gtab[TABDMA ? 96 : 1];
     int4 g0 = make_int4(0, 0, 0, 0), gsel = g0, gw = g0;
-    if (grouped) {
-        const int4 *gp = gtab + 3 * (min(gx, dw - 1) >> 2);
-        g0 = gp[0];
-        gsel = gp[1];
-        gw = gp[2];
+    if (TABDMA && grouped) {
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (wv == 1) {
+            if (lane < 32) rz_glds16(ytab + min(oy0 + lane, dh - 1), (uint32_t)(uintptr_t)&s_ytab[0]);
+        } else if (wv >= 2) {
+            const int q = 64 * (wv - 2) + lane;                 // 16-byte chunk of the 32 x 3 group entries
+            const int grp = q / 3, part = q - 3 * grp;
+            if (q < 96) rz_glds16(gtab + 3 * (min(ox0 + 4 * grp, dw - 1) >> 2) + part, (uint32_t)(uintptr_t)&s_gtab[64 * (wv - 2)]);
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) xt[k] = xtab[min(gx + k, dw - 1)];
+        for (int j = 0; j < NR; j++) yt[j] = ytab[min(dy0 + 8 * j, dh - 1)];
+        if (grouped) {
+            const int4 *gp = gtab + 3 * (min(gx, dw - 1) >> 2);
+            g0 = gp[0];
+            gsel = gp[1];
+            gw = gp[2];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) xt[k] = xtab[min(gx + k, dw - 1)];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!colLive) return;
+    if (TABDMA && grouped) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) yt[j] = s_ytab[(tid >> 5) + 8 * j];
+        const int4 *gp = s_gtab + 3 * (tid & 31);
+        g0 = gp[0];
+        gsel = gp[1];
+        gw = gp[2];
+    }
     if (grouped) {
         // Fast path: the 8 source bytes from the group's base column on (three aligned LDS dwords, realigned) hold all
         // eight taps of a row; a pixel's tap pair comes out with one v_perm, the horizontal sum is one v_dot2 with
