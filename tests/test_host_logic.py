@@ -208,6 +208,30 @@ def test_loose_compass_formulas_are_exact_for_bright_and_one_value_wide_for_dark
         assert np.array_equal(~notdark, q - v <= -t), t
 
 
+def test_describe_rounding_and_resize_multiply_tricks_are_exact():
+    """k_describe: cvRound of a rotated pattern coordinate (|x| <= 18.4) is read from the low mantissa bits of x + 1.5 * 2^23, and
+    the LDS offset 40 * row + column is one v_mad_i32_i24 of the two bit patterns (its multiplicand is the low 24 bits, sign-extended)
+    minus a constant.  k_resize: (b * (r >> 4)) >> 16 is the high word of the 24-bit product (b << 12) * (r & ~15)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-18.5, 18.5, 2_000_000).astype(np.float32),
+                        (np.arange(-37, 38) * 0.5).astype(np.float32)])
+    x = np.concatenate([x, np.nextafter(x[-75:], np.float32(100)), np.nextafter(x[-75:], np.float32(-100))])
+    bits = (x + np.float32(12582912.0)).view(np.int32).astype(np.int64)
+    want = np.rint(x).astype(np.int64)                     # round half to even, as cvRound / __float2int_rn
+    assert np.array_equal(bits - 0x4B400000, want)
+    r, c = bits[: len(bits) // 2], bits[len(bits) // 2: 2 * (len(bits) // 2)]
+    low24 = ((r & 0xFFFFFF) ^ 0x800000) - 0x800000          # the operand v_mad_i32_i24 sees
+    off = (low24 * 40 + c - (0x400000 * 40 + 0x4B400000)) & 0xFFFFFFFF
+    off = (off ^ 0x80000000) - 0x80000000
+    assert np.array_equal(off, want[: len(r)] * 40 + want[len(r): 2 * len(r)])
+
+    b = np.arange(0, 2049, dtype=np.int64)[:, None]
+    rr = np.concatenate([rng.integers(0, 255 * 2048 + 1, 4000), [0, 15, 16, 255 * 2048]]).astype(np.int64)[None, :]
+    f0, f1 = b << 12, rr & 0x7FFFF0
+    assert f0.max() < 1 << 24 and f1.max() < 1 << 24
+    assert np.array_equal((f0 * f1) >> 32, (b * (rr >> 4)) >> 16)
+
+
 def test_dropin_sources_compile_against_opencv_declarations():
     """include/orbhip/cvlite.h has two branches: its own minimal cv:: types (what both boxes use: no OpenCV installed) and
     `#ifdef ORBHIP_USE_OPENCV` -> <opencv2/core/core.hpp>, the branch a build inside the reference tree takes.  That branch is

@@ -87,6 +87,7 @@ __device__ __forceinline__ int wave_sum(int v)
 // every pyramid byte once) but cost more in per-workgroup set-up than they gain: the kernel is bound by the number of
 // 128-byte lines its row gathers touch (~88 per keypoint), not by where they come from.
 #define DESCRIBE_DEFAULT_MAP 4
+typedef const __attribute__((address_space(3))) uint8_t *lds_u8p;
 
 template <int DS_KP>
 __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
@@ -365,17 +366,25 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
         const int o = __builtin_amdgcn_readfirstlane(s_out[kp]);
         if (pos >= 0 && o < cap) {   // wave-uniform
             const int cx = pos & 0xFFF;
-            const uint8_t *bc = patchB + DS_R * (DS_PDW * 4) + DS_R + ((cx - DS_R) & 3);   // the keypoint inside the patch
+            // A test pixel's LDS address = keypoint's address in the patch + 40 * row + column, with row / column = the rotated
+            // coordinates rounded to nearest-even (cvRound, :119-122).  x + 1.5 * 2^23 has the rounded integer in its low mantissa
+            // bits (|x| <= 18.4), so the address is one 24-bit multiply-add of the two sums' bit patterns (the multiplicand is the low
+            // 24 bits, 0x400000 + row) plus one scalar that also takes the constants back out.  v_add_f32 issues at twice the rate of
+            // v_rndne_f32 / v_cvt_i32_f32 (profiles/r03/valu_rates.txt), and there are two instructions fewer per pixel.
+            const float RMAGIC = 12582912.f;   // 0x4B400000
+            const uint32_t bcAddr = (uint32_t)(uintptr_t)patchB + (uint32_t)(DS_R * (DS_PDW * 4) + DS_R + ((cx - DS_R) & 3)) -
+                                    (0x400000u * (DS_PDW * 4) + 0x4B400000u);
             const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[kp])));
             const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[kp])));
             unsigned long long words[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[j], b), __fmul_rn(py0[j], a)));
-                const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[j], a), __fmul_rn(py0[j], b)));
-                const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[j], b), __fmul_rn(py1[j], a)));
-                const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[j], a), __fmul_rn(py1[j], b)));
-                const int t0 = bc[r0 * (DS_PDW * 4) + c0], t1 = bc[r1 * (DS_PDW * 4) + c1];
+                const int r0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(px0[j], b), __fmul_rn(py0[j], a)), RMAGIC));
+                const int c0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(px0[j], a), __fmul_rn(py0[j], b)), RMAGIC));
+                const int r1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(px1[j], b), __fmul_rn(py1[j], a)), RMAGIC));
+                const int c1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(px1[j], a), __fmul_rn(py1[j], b)), RMAGIC));
+                const int t0 = *(lds_u8p)(bcAddr + (uint32_t)(__mul24(r0, DS_PDW * 4) + c0));
+                const int t1 = *(lds_u8p)(bcAddr + (uint32_t)(__mul24(r1, DS_PDW * 4) + c1));
                 words[j] = __ballot(t0 < t1);
             }
             if (lane < 4) {

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     if (grouped) {
         // Fast path: the 8 source bytes from the group's base column on (three aligned LDS dwords, realigned) hold all
         // eight taps of a row; a pixel's tap pair comes out with one v_perm, the horizontal sum is one v_dot2 with
-        // the weight pair, and (b * (r >> 4)) >> 16 is the high half of (b << 16) * (r >> 4).  Same integers as the
+        // the weight pair, and (b * (r >> 4)) >> 16 is the high half of a 24-bit product (below).  Same integers as the
         // generic path below.
         const int bcol = g0.x - XA, wb = bcol & ~3, sh = bcol & 3;
         const uint32_t sel[4] = {(uint32_t)gsel.x, (uint32_t)gsel.y, (uint32_t)gsel.z, (uint32_t)gsel.w};
@@ -144,7 +144,9 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
         for (int j = 0; j < NR; j++) {
             const int dy = dy0 + 8 * j;
             if (dy >= dh) break;
-            const uint32_t b0s = (uint32_t)yt[j].z << 16, b1s = (uint32_t)yt[j].w << 16;
+            // (b * (r >> 4)) >> 16 = high word of (b << 12) * (r & ~15): both factors below 2^24 (b <= 2048, r <= 255 * 2048), so
+            // that it is the full-rate v_mul_hi_u32_u24 and the shift of r is gone (v_mul_hi_u32 issues at a quarter of the rate)
+            const uint32_t b0s = ((uint32_t)yt[j].z & 0xFFFu) << 12, b1s = ((uint32_t)yt[j].w & 0xFFFu) << 12;
             const uint32_t *q0 = reinterpret_cast<const uint32_t *>(&s_src[yt[j].x - symin][wb]);
             const uint32_t *q1 = reinterpret_cast<const uint32_t *>(&s_src[yt[j].y - symin][wb]);
             const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], c0 = q1[0], c1 = q1[1], c2 = q1[2];
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
                 const us2 w2 = __builtin_bit_cast(us2, wt[k]);
                 const uint32_t r0 = __builtin_amdgcn_udot2(p0, w2, 0u, false);
                 const uint32_t r1 = __builtin_amdgcn_udot2(p1, w2, 0u, false);
-                v[k] = (__umulhi(b0s, r0 >> 4) + __umulhi(b1s, r1 >> 4) + 2u) >> 2;   // <= 255
+                v[k] = (__umulhi(b0s, r0 & 0x7FFFF0u) + __umulhi(b1s, r1 & 0x7FFFF0u) + 2u) >> 2;   // <= 255
             }
             const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
             uint8_t *o = D + (size_t)dy * dstride + gx;
