@@ -183,6 +183,8 @@ def test_alternative_code_paths_give_the_same_results(env):
     {"ORBHIP_FAST_TILE_CELLS": "2"},
     {"ORBHIP_FAST_LISTCAP": "24"},            # every list overflows: dense scoring, score-tile scans, the wave-local fallbacks of pass 1
     {"ORBHIP_FAST_LISTCAP": "24", "ORBHIP_FAST_FIX": "0"},
+    {"ORBHIP_DESCRIBE_AX4": "0"},             # angle phase of the batch describe kernel: five dword loads + masks instead of one dwordx4 load + constant weights
+    {"ORBHIP_DESCRIBE_KPW": "32"},            # ... 32 slots per workgroup (always the dword form)
     {"ORBHIP_NO_SPLIT": "1"},                 # batch schedules: no half-batch split; blur beside FAST
     {"ORBHIP_BLUR_PLACE": "1"},
 ])

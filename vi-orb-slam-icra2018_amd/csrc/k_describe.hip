@@ -89,7 +89,40 @@ __device__ __forceinline__ int wave_sum(int v)
 #define DESCRIBE_DEFAULT_MAP 4
 typedef const __attribute__((address_space(3))) uint8_t *lds_u8p;
 
-template <int DS_KP>
+// Angle phase, batches: the whole 31 x 31 disc in ONE load instruction -- lane (row = lane >> 1, half = lane & 1) takes the 16 bytes
+// from column cx - 15 + 16 half of disc row `row` (byte-aligned dwordx4; 32 adjacent bytes per row) -- and per-lane constant byte
+// weights instead of per-keypoint masks: the load starts at the disc's own first column, so which bytes of a lane lie inside the
+// disc, and their u, never change.  wu = u + 16 inside the disc (1..31), 0 outside; wm = 1 inside, 0 outside:
+//   S = sum_in p = dot4(p, wm),  m10 = sum_in u p = dot4(p, wu) - 16 S,  m01 = v S        (all unsigned dot4; :79-106 exactly).
+#define ANGLE_UMAX_VALUES 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3   // umax of HALF_PATCH_SIZE 15 (:456-471)
+struct AngleWt {
+    unsigned wu[64][4], wm[64][4];   // [lane][dword of the lane's 16 bytes]
+};
+constexpr AngleWt make_angle_wt()
+{
+    constexpr int um[16] = {ANGLE_UMAX_VALUES};
+    AngleWt w{};
+    for (int lane = 0; lane < 64; lane++)
+        for (int k = 0; k < 4; k++) {
+            unsigned a = 0, m = 0;
+            for (int j = 0; j < 4; j++) {
+                const int row = lane >> 1, u = 16 * (lane & 1) + 4 * k + j - ORB_HALF_PATCH, v = row - ORB_HALF_PATCH;
+                const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+                const bool in = row <= 2 * ORB_HALF_PATCH && au <= ORB_HALF_PATCH && au <= um[av < 16 ? av : 15];
+                a |= (unsigned)(in ? u + 16 : 0) << (8 * j);
+                m |= (unsigned)(in ? 1 : 0) << (8 * j);
+            }
+            w.wu[lane][k] = a;
+            w.wm[lane][k] = m;
+        }
+    return w;
+}
+__constant__ __attribute__((aligned(16))) AngleWt c_angle_wt = make_angle_wt();
+struct __attribute__((packed, aligned(1))) UnalignedU4 {
+    uint4 v;
+};
+
+template <int DS_KP, bool AX4>
 __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                                   int stride0, unsigned long long frame0,
                                                   const uint8_t *__restrict__ pyr,
@@ -158,6 +191,48 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
     if (phases < 1) return;   // timing ablation only (ORBHIP_DESCRIBE_PHASES): results are then invalid
 
     // ---- A. E5: IC_Angle moments on the un-blurred level ----
+    if constexpr (AX4) {
+        const uint4 wu = *reinterpret_cast<const uint4 *>(&c_angle_wt.wu[lane][0]);
+        const uint4 wm = *reinterpret_cast<const uint4 *>(&c_angle_wt.wm[lane][0]);
+        const int rowc = min(lane >> 1, 2 * ORB_HALF_PATCH), half16 = 16 * (lane & 1), vrow = (lane >> 1) - ORB_HALF_PATCH;
+        auto load1 = [&](int kp, uint4 &wd) {
+            const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+            if (pos >= 0) {
+                const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+                const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0 : pyr + (size_t)frame * pyrFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_ioff[kp]);
+                const int stride = __builtin_amdgcn_readfirstlane(s_istride[kp]);
+                const uint8_t *p = img + (size_t)(cy - ORB_HALF_PATCH) * stride + (cx - ORB_HALF_PATCH);
+                wd = reinterpret_cast<const UnalignedU4 *>(p + (unsigned)(__mul24(rowc, stride) + half16))->v;
+            }
+        };
+        const int kp0 = wave;
+        constexpr int NQ = DS_KP / 4;
+        uint4 ring[NQ];   // every keypoint of the wave requested at once
+#pragma unroll
+        for (int q = 0; q < NQ; q++) load1(kp0 + 4 * q, ring[q]);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int kp = kp0 + 4 * q;
+            const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+            if (pos >= 0) {   // wave-uniform
+                const uint4 c = ring[q];
+                unsigned S = __builtin_amdgcn_udot4(c.x, wm.x, 0u, false);
+                S = __builtin_amdgcn_udot4(c.y, wm.y, S, false);
+                S = __builtin_amdgcn_udot4(c.z, wm.z, S, false);
+                S = __builtin_amdgcn_udot4(c.w, wm.w, S, false);
+                unsigned U = __builtin_amdgcn_udot4(c.x, wu.x, 0u, false);
+                U = __builtin_amdgcn_udot4(c.y, wu.y, U, false);
+                U = __builtin_amdgcn_udot4(c.z, wu.z, U, false);
+                U = __builtin_amdgcn_udot4(c.w, wu.w, U, false);
+                const int m10 = wave_sum((int)U - 16 * (int)S);
+                const int m01 = wave_sum(__mul24(vrow, (int)S));
+                if (lane == 0) {
+                    s_m10[kp] = m10;
+                    s_m01[kp] = m01;
+                }
+            }
+        }
+    } else {
     // software pipeline: the five row dwords of the wave's next keypoint are in flight while the current one is
     // reduced
     {
@@ -233,6 +308,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
                 }
             }
         }
+    }
     }
     __syncthreads();
     if (phases < 2) return;
@@ -414,16 +490,23 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
     static const int padLds = getenv("ORBHIP_DESCRIBE_PADLDS") ? atoi(getenv("ORBHIP_DESCRIBE_PADLDS")) : 0;
     const int nblk = (G.totalKps + kpw - 1) / kpw;
     dim3 grid((mapArg & 255) ? (nblk + 7) / 8 * 8 : nblk, B, 1), block(256, 1, 1);
-#define ORB_LAUNCH_DESCRIBE(K)                                                                                                  \
-    hipLaunchKernelGGL(k_describe<K>, grid, block, (size_t)padLds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
+    // the one-load form of the angle phase is written for the umax table of a 31-pixel patch (always what orb_init_tables computes)
+    static const int ax4Env = getenv("ORBHIP_DESCRIBE_AX4") ? atoi(getenv("ORBHIP_DESCRIBE_AX4")) : 1;
+    static const int umaxWant[16] = {ANGLE_UMAX_VALUES};
+    bool ax4 = ax4Env != 0 && kpw == 16;
+    for (int v = 0; v < 16; v++) ax4 = ax4 && G.umax[v] == umaxWant[v];
+#define ORB_LAUNCH_DESCRIBE(KERN)                                                                                               \
+    hipLaunchKernelGGL(KERN, grid, block, (size_t)padLds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc, \
                        counts, cap, mapArg, phases)
     if (kpw == 32)
-        ORB_LAUNCH_DESCRIBE(32);
+        ORB_LAUNCH_DESCRIBE((k_describe<32, false>));
+    else if (kpw == 16 && ax4)
+        ORB_LAUNCH_DESCRIBE((k_describe<16, true>));
     else if (kpw == 16)
-        ORB_LAUNCH_DESCRIBE(16);
+        ORB_LAUNCH_DESCRIBE((k_describe<16, false>));
     else
-        ORB_LAUNCH_DESCRIBE(8);
+        ORB_LAUNCH_DESCRIBE((k_describe<8, false>));
 #undef ORB_LAUNCH_DESCRIBE
 }
 
