@@ -11,7 +11,7 @@ pids=()
 for f in $CS/*.hip; do
   b=$(basename $f .hip)
   extra=""
-  [ $b = k_blur ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+  { [ $b = k_blur ] || [ $b = k_hamming ]; } && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   if [ ! -f $OBJ/$b.o ] || [ $f -nt $OBJ/$b.o ] || [ -n "$(find $CS -name '*.h' -newer $OBJ/$b.o 2>/dev/null)" ]; then
     /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c $f -o $OBJ/$b.o &
     pids+=($!)
