@@ -216,3 +216,58 @@ def test_alternative_batch_code_paths_give_the_same_results(env):
     ) % (os.path.join(root, "vi-orb-slam-icra2018_amd"), os.path.join(root, "oracle"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
     assert out.returncode == 0 and "paths ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_brute_force_matching_on_the_matrix_pipe_and_on_the_vector_pipe(mfma):
+    """k_knn2_mfma / k_knn2_seq_mfma (default) and the scalar k_knn2 / k_knn2_seq (ORBHIP_KNN2_MFMA=0) against the oracle: low-entropy
+    descriptors (few distinct distances: ties decide the index and the second-best), all-zero / all-one rows, duplicate rows, query and
+    database counts around the 128-query workgroup, the 32-row matrix tile and the 64-row staged tile, and the per-frame sequence
+    form with ragged counts."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, ctypes as C, numpy as np\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "import orb_oracle_py as oracle\n"
+        "import hiprt\n"
+        "from orbhip.capi import check\n"
+        "from orbhip.extractor import ORBextractor, ORBmatcher\n"
+        "rng = np.random.default_rng(77)\n"
+        "ex = ORBextractor(1000, max_w=640, max_h=480); m = ORBmatcher(0.7, True, ctx=ex)\n"
+        "def lowent(n):\n"
+        "    d = np.zeros((n, 32), np.uint8)\n"
+        "    d[:, :2] = rng.integers(0, 256, (n, 2), dtype=np.uint8) & rng.integers(0, 256, (n, 2), dtype=np.uint8)\n"
+        "    d[rng.random(n) < 0.05] = 255\n"
+        "    d[rng.random(n) < 0.05] = 0\n"
+        "    return d\n"
+        "for nq, ndb in [(127, 31), (128, 32), (129, 33), (130, 63), (131, 64), (132, 65), (300, 1000), (1000, 4097), (513, 20001)]:\n"
+        "    for kind in (0, 1):\n"
+        "        db = lowent(ndb) if kind == 0 else rng.integers(0, 256, (ndb, 32), dtype=np.uint8)\n"
+        "        q = lowent(nq) if kind == 0 else db[rng.integers(0, ndb, nq)] ^ (rng.integers(0, 256, (nq, 32), dtype=np.uint8) & rng.integers(0, 256, (nq, 32), dtype=np.uint8) & rng.integers(0, 256, (nq, 32), dtype=np.uint8))\n"
+        "        if ndb > 40: db[37] = db[5]\n"
+        "        got = m.knn2(q, db); want = oracle.knn2(q, db)\n"
+        "        for g, w in zip(got, want):\n"
+        "            assert np.array_equal(g, w), (nq, ndb, kind)\n"
+        "# the per-frame sequence form: frame b against frame b - 1, ragged counts (incl. an empty frame)\n"
+        "cap, B = 700, 6\n"
+        "counts = np.array([700, 650, 0, 129, 64, 700], np.int32)\n"
+        "desc = np.stack([lowent(cap) if b %% 2 else rng.integers(0, 256, (cap, 32), dtype=np.uint8) for b in range(B)])\n"
+        "d_desc = hiprt.DevBuf.from_numpy(desc); d_cnt = hiprt.DevBuf.from_numpy(counts)\n"
+        "d_bi, d_bd, d_sd = (hiprt.DevBuf(B * cap * 4) for _ in range(3))\n"
+        "check(ex._L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.ptr, d_cnt.ptr, cap, B, 1, d_bi.ptr, d_bd.ptr, d_sd.ptr), ex.handle)\n"
+        "ex.sync()\n"
+        "bi = d_bi.to_numpy(np.int32, (B, cap)); bd = d_bd.to_numpy(np.int32, (B, cap)); sd = d_sd.to_numpy(np.int32, (B, cap))\n"
+        "for b in range(B):\n"
+        "    n = counts[b]\n"
+        "    if n == 0: continue\n"
+        "    wi, wd, ws = oracle.knn2(desc[b, :n], desc[b - 1, :counts[b - 1]]) if b >= 1 else (np.full(n, -1), np.full(n, 256), np.full(n, 256))\n"
+        "    assert np.array_equal(bi[b, :n], wi) and np.array_equal(bd[b, :n], wd) and np.array_equal(sd[b, :n], ws), b\n"
+        "ex.close()\n"
+        "print('knn2 ok')\n"
+    ) % (os.path.join(root, "vi-orb-slam-icra2018_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ORBHIP_KNN2_MFMA=mfma), capture_output=True, text=True)
+    assert out.returncode == 0 and "knn2 ok" in out.stdout, out.stdout + out.stderr
