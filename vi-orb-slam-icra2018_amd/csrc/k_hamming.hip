@@ -263,8 +263,8 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
     int qt, ns, rows;
     knn2_shape(nq, ndb, &qt, &ns, &rows);
     static const int mfmaEnv = getenv("ORBHIP_KNN2_MFMA") ? atoi(getenv("ORBHIP_KNN2_MFMA")) : 1;
-    if (mfmaEnv && rows <= (1 << 20))   // (a key holds the row's index inside its split in 20 bits)
-        hipLaunchKernelGGL(k_knn2_mfma, dim3((nq + 127) / 128, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
+    if (mfmaEnv)
+        hipLaunchKernelGGL(k_knn2_mfma, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
     else
         hipLaunchKernelGGL(k_knn2, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
     hipLaunchKernelGGL(k_knn2_merge, dim3(qt, 1, 1), dim3(256, 1, 1), 0, s, partial, nq, ns, best_idx, best_d,
@@ -275,116 +275,153 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
 // d(a, b) = |a| + |b| - 2 |a & b|, and |a & b| over 32 bits is a dot product of the bits written out as bytes: one
 // v_mfma_i32_32x32x32_i8 per descriptor word gives the 32 x 32 values |a & b| of 32 database rows (A operand) against 32 queries (B
 // operand), eight of them a tile of 1024 distances -- 8 matrix instructions instead of 1024 x (8 v_xor + 8 v_bcnt + 7 adds).
-//  * a workgroup = 128 queries (32 per wave, their byte form in 32 registers for the whole kernel) x the rows of one split; the byte
-//    form of a 32-row database tile (8 KB) is built once per workgroup in LDS, thread = one word of one row ((x * 0x00204081) &
-//    0x01010101 spreads four bits over four bytes), double-buffered behind one barrier per tile;
-//  * result layout: column = lane & 31 = query, the 16 registers of a lane = 16 of the tile's rows, so a lane folds its own values
-//    into its query's running result with no cross-lane work: key = (d' << 20) + row with d' = |b| - 2 |a & b| (|a| is the same for
-//    all of a query's keys and added at the end), m1 = min, m2 = med3 -- the two smallest keys = (best, lowest index) and the second
-//    smallest distance of the multiset, exactly what the strict '<' loop of the reference leaves (:205-226);
-//  * the two lanes of a query (rows 4h .. 4h + 3 of every eight) merge once at the end; output = the split's partial result in the
-//    format of k_knn2, merged in split order by k_knn2_merge.
+//  * The instruction also builds the comparison key.  A row's set bits are written as 0x40, a query's as 0x80 (= -128): a common bit
+//    contributes -2^13, and with the accumulator started at (|b| << 12) + row (row = index inside a chunk of 4096 database rows) the
+//    result is ((|b| - 2 |a & b|) << 12) + row: ordered by distance, then by index (|a| is the same for all keys of a query and added
+//    at the end).  Per value the vector pipe only keeps the two smallest keys, m2 = med3(m1, m2, key), m1 = min(m1, key) -- (best,
+//    lowest index) and the second smallest distance of the multiset, exactly what the strict '<' loop of the reference leaves (:205-226).
+//  * Result layout: column = lane & 31 = query, the 16 registers of a lane = 16 of the tile's rows (8 g + 4 h + e for register 4 g + e,
+//    h = lane >> 5): a lane folds its own values, no cross-lane work; the two lanes of a query merge once at the end.
+//  * A workgroup = 256 queries (two 32-query tiles per wave: each A fragment read from LDS feeds two matrix instructions, the LDS reads
+//    are what limits this kernel) x the rows of one split; the byte form of a 64-row database tile (16 KB) and the rows' initial keys are
+//    built once per workgroup in LDS, thread = one word of two rows ((x * 0x08102040) & 0x40404040 spreads four bits over four bytes),
+//    double-buffered behind one barrier per tile.  Output = the split's partial result in the format of k_knn2, merged in split order by
+//    k_knn2_merge.
 typedef int v4i_h __attribute__((ext_vector_type(4)));
 typedef int v16i_h __attribute__((ext_vector_type(16)));
 #define KM_NONE 0x3FFFFFFF
+#define KM_SUB 2          // 32-row MFMA tiles per staged tile (one barrier per 64 rows)
+#define KM_CHUNK 4096     // database rows per key range (12 index bits)
 
+// 16 bits of a descriptor word -> 16 bytes, `one` (0x40 / 0x80 in every byte of the mask, 0x08102040 / 0x10204080 as the multiplier) per set bit
+template <uint32_t MUL, uint32_t MASK>
 __device__ __forceinline__ v4i_h bits16_to_bytes(uint32_t word, int h)
 {
     const uint32_t x = word >> (16 * h);
     v4i_h r;
-    r.x = (int)((((x >> 0) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r.y = (int)((((x >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r.z = (int)((((x >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r.w = (int)((((x >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+    r.x = (int)((((x >> 0) & 0xFu) * MUL) & MASK);
+    r.y = (int)((((x >> 4) & 0xFu) * MUL) & MASK);
+    r.z = (int)((((x >> 8) & 0xFu) * MUL) & MASK);
+    r.w = (int)((((x >> 12) & 0xFu) * MUL) & MASK);
     return r;
 }
 
-// 128 queries q[qbase ..] against database rows j0 .. j1 - 1; the result of query qbase + 32 wave + (lane & 31) in lanes < 32
-#define KM_SUB 2   // 32-row MFMA tiles per staged tile (one barrier per 64 rows)
+__device__ __forceinline__ void top2_update(int &m1, int &m2, int key)
+{
+    // The min comes first and the inline instruction takes it as an (unused) operand: the compiler knows how long a matrix result
+    // must not be read after its instruction issued and waits before the v_min; it does not reason about what inline text reads.
+    const int lo = min(m1, key);
+    int med;
+    asm("v_med3_i32 %0, %1, %2, %3 ; after %4" : "=v"(med) : "v"(m1), "v"(m2), "v"(key), "v"(lo));   // second smallest of (m1 <= m2, key)
+    m2 = med;
+    m1 = lo;
+}
+
+// 256 queries q[qbase ..] against database rows j0 .. j1 - 1: query qbase + 64 wave + 32 t + (lane & 31) -> out[t] (valid in lanes < 32)
 __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, int nq, int qbase, const uint8_t *__restrict__ db,
-                                               int j0, int j1, v4i_h (*s_A)[KM_SUB][8][2][32], int (*s_T)[KM_SUB * 32], Best &out,
-                                               int &qiOut)
+                                               int j0, int j1, v4i_h (*s_A)[KM_SUB][8][2][32], int (*s_T)[KM_SUB * 32], Best out[2])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    const int qi = qbase + 32 * wave + c;
-    qiOut = qi;
-    uint32_t Q[8];
-    if (qi < nq) {
-        const uint4 a = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[0];
-        const uint4 b = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[1];
-        Q[0] = a.x; Q[1] = a.y; Q[2] = a.z; Q[3] = a.w;
-        Q[4] = b.x; Q[5] = b.y; Q[6] = b.z; Q[7] = b.w;
-    } else {
+    int pa[2];
+    v4i_h Bq[2][8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) Q[k] = 0;
-    }
-    int pa = 0;
-    v4i_h Bq[8];
+    for (int t = 0; t < 2; t++) {
+        const int qi = qbase + 64 * wave + 32 * t + c;
+        uint32_t Q[8];
+        if (qi < nq) {
+            const uint4 a = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[0];
+            const uint4 b = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[1];
+            Q[0] = a.x; Q[1] = a.y; Q[2] = a.z; Q[3] = a.w;
+            Q[4] = b.x; Q[5] = b.y; Q[6] = b.z; Q[7] = b.w;
+        } else {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        pa += __popc(Q[k]);
-        Bq[k] = bits16_to_bytes(Q[k], h);
+            for (int k = 0; k < 8; k++) Q[k] = 0;
+        }
+        pa[t] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            pa[t] += __popc(Q[k]);
+            Bq[t][k] = bits16_to_bytes<0x10204080u, 0x80808080u>(Q[k], h);
+        }
+        out[t].b1 = 256;
+        out[t].idx = -1;
+        out[t].b2 = 256;
     }
-    // staging role of this thread: word sw of the rows srow, srow + 32, ... of the staged tile
+    // staging role of this thread: word sw of the rows srow, srow + 32 of the staged tile
     const int srow = tid >> 3, sw = tid & 7;
-    auto fetch = [&](int jt, uint32_t word[KM_SUB]) {
-#pragma unroll
-        for (int u = 0; u < KM_SUB; u++) {
-            const int j = jt + 32 * u + srow;
-            word[u] = j < j1 ? reinterpret_cast<const uint32_t *>(db + (size_t)j * 32)[sw] : 0u;
-        }
-    };
-    auto stage = [&](int buf, int jt, const uint32_t word[KM_SUB]) {
-#pragma unroll
-        for (int u = 0; u < KM_SUB; u++) {
-            s_A[buf][u][sw][0][srow] = bits16_to_bytes(word[u], 0);
-            s_A[buf][u][sw][1][srow] = bits16_to_bytes(word[u], 1);
-            int pc = __popc(word[u]);   // |b| of the row: sum over the eight lanes that hold its words
-            pc += __builtin_amdgcn_update_dpp(0, pc, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-            pc += __builtin_amdgcn_update_dpp(0, pc, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-            pc += __builtin_amdgcn_update_dpp(0, pc, 0x141, 0xF, 0xF, true);   // row_half_mirror
-            const int j = jt + 32 * u + srow;
-            if (sw == 0) s_T[buf][32 * u + srow] = j < j1 ? ((pc << 20) | (j - j0)) : KM_NONE;
-        }
-    };
-    int m1 = KM_NONE, m2 = KM_NONE;
     constexpr int TR = 32 * KM_SUB;
-    const int ntiles = (j1 - j0 + TR - 1) / TR;
-    uint32_t word[KM_SUB];
-    if (ntiles > 0) {
-        fetch(j0, word);
-        stage(0, j0, word);
-    }
-    for (int n = 0; n < ntiles; n++) {
-        const int buf = n & 1;
-        __syncthreads();   // tile n is staged; every wave is done with tile n - 1 (whose buffer the staging below overwrites)
-        if (n + 1 < ntiles) fetch(j0 + TR * (n + 1), word);
+    for (int c0 = j0; c0 < j1; c0 += KM_CHUNK) {   // (one trip unless the database has more rows than a key can index)
+        const int c1 = min(j1, c0 + KM_CHUNK);
+        auto fetch = [&](int jt, uint32_t word[KM_SUB]) {
 #pragma unroll
-        for (int u = 0; u < KM_SUB; u++) {
-            v16i_h acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int u = 0; u < KM_SUB; u++) {
+                const int j = jt + 32 * u + srow;
+                word[u] = j < c1 ? reinterpret_cast<const uint32_t *>(db + (size_t)j * 32)[sw] : 0u;
+            }
+        };
+        auto stage = [&](int buf, int jt, const uint32_t word[KM_SUB]) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_A[buf][u][k][h][c], Bq[k], acc, 0, 0, 0);
-            // register 4 g + e of this lane = row 8 g + 4 h + e of the 32-row tile
+            for (int u = 0; u < KM_SUB; u++) {
+                s_A[buf][u][sw][0][srow] = bits16_to_bytes<0x08102040u, 0x40404040u>(word[u], 0);
+                s_A[buf][u][sw][1][srow] = bits16_to_bytes<0x08102040u, 0x40404040u>(word[u], 1);
+                int pc = __popc(word[u]);   // |b| of the row: sum over the eight lanes that hold its words
+                pc += __builtin_amdgcn_update_dpp(0, pc, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                pc += __builtin_amdgcn_update_dpp(0, pc, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                pc += __builtin_amdgcn_update_dpp(0, pc, 0x141, 0xF, 0xF, true);   // row_half_mirror
+                const int j = jt + 32 * u + srow;
+                if (sw == 0) s_T[buf][32 * u + srow] = j < c1 ? ((pc << 12) | (j - c0)) : KM_NONE;
+            }
+        };
+        int m1[2] = {KM_NONE, KM_NONE}, m2[2] = {KM_NONE, KM_NONE};
+        const int ntiles = (c1 - c0 + TR - 1) / TR;
+        uint32_t word[KM_SUB];
+        __syncthreads();   // (a previous chunk's last tile may still be read)
+        fetch(c0, word);
+        stage(0, c0, word);
+        for (int n = 0; n < ntiles; n++) {
+            const int buf = n & 1;
+            __syncthreads();   // tile n is staged; every wave is done with tile n - 1 (whose buffer the staging below overwrites)
+            if (n + 1 < ntiles) fetch(c0 + TR * (n + 1), word);
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const v4i_h T4 = reinterpret_cast<const v4i_h *>(s_T[buf] + 32 * u)[2 * g + h];
+            for (int u = 0; u < KM_SUB; u++) {
+                // the accumulators start at the rows' keys: register 4 g + e of this lane = row 8 g + 4 h + e of the 32-row tile
+                v16i_h acc0, acc1;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int key = __mul24(acc[4 * g + e], -(1 << 21)) + T4[e];
-                    m2 = min(m2, max(m1, key));   // second smallest of (m1 <= m2, key)
-                    m1 = min(m1, key);
+                for (int g = 0; g < 4; g++) {
+                    const v4i_h T4 = reinterpret_cast<const v4i_h *>(s_T[buf] + 32 * u)[2 * g + h];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        acc0[4 * g + e] = T4[e];
+                        acc1[4 * g + e] = T4[e];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const v4i_h a = s_A[buf][u][k][h][c];
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[0][k], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[1][k], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    top2_update(m1[0], m2[0], acc0[r]);
+                    top2_update(m1[1], m2[1], acc1[r]);
                 }
             }
+            if (n + 1 < ntiles) stage(buf ^ 1, c0 + TR * (n + 1), word);
         }
-        if (n + 1 < ntiles) stage(buf ^ 1, j0 + TR * (n + 1), word);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            // the other half of this query's rows, then this chunk behind the earlier ones
+            const int o1 = __shfl_xor(m1[t], 32), o2 = __shfl_xor(m2[t], 32);
+            const int k1 = min(m1[t], o1), k2 = min(max(m1[t], o1), min(m2[t], o2));
+            const int add = pa[t] << 12;
+            Best C;
+            C.b1 = k1 >= KM_NONE ? 256 : (k1 + add) >> 12;
+            C.idx = k1 >= KM_NONE ? -1 : c0 + (k1 & (KM_CHUNK - 1));
+            C.b2 = k2 >= KM_NONE ? 256 : (k2 + add) >> 12;
+            out[t] = best_merge_ordered(out[t], C);
+        }
     }
-    // the other half of this query's rows
-    const int o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
-    const int k1 = min(m1, o1), k2 = min(max(m1, o1), min(m2, o2));
-    const int add = pa << 20;
-    out.b1 = k1 >= KM_NONE ? 256 : (k1 + add) >> 20;
-    out.idx = k1 >= KM_NONE ? -1 : j0 + (k1 & 0xFFFFF);
-    out.b2 = k2 >= KM_NONE ? 256 : (k2 + add) >> 20;
 }
 
 __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ db, int ndb,
@@ -394,10 +431,14 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t *__restrict__ q
     __shared__ __align__(16) int s_T[2][KM_SUB * 32];
     const int split = blockIdx.y;
     const int j0 = split * rowsPerSplit, j1 = min(ndb, j0 + rowsPerSplit);
-    Best B;
-    int qi;
-    knn2_mfma_core(q, nq, blockIdx.x * 128, db, j0, j1, s_A, s_T, B, qi);
-    if ((threadIdx.x & 63) < 32 && qi < nq) partial[(size_t)split * nq + qi] = make_int4(B.b1, B.idx, B.b2, 0);
+    Best B[2];
+    knn2_mfma_core(q, nq, blockIdx.x * 256, db, j0, j1, s_A, s_T, B);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int qi = blockIdx.x * 256 + 64 * (threadIdx.x >> 6) + 32 * t + (lane & 31);
+        if (lane < 32 && qi < nq) partial[(size_t)split * nq + qi] = make_int4(B[t].b1, B[t].idx, B[t].b2, 0);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_knn2_seq_mfma(const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap,
@@ -408,17 +449,21 @@ __global__ __launch_bounds__(256) void k_knn2_seq_mfma(const uint8_t *__restrict
     __shared__ __align__(16) int s_T[2][KM_SUB * 32];
     const int b = blockIdx.y;
     const int nq = min(counts[b], cap);
-    if (blockIdx.x * 128 >= nq) return;   // whole block idle (uniform)
+    if (blockIdx.x * 256 >= nq) return;   // whole block idle (uniform)
     const int ndb = b >= lag ? min(counts[b - lag], cap) : 0;
-    Best B;
-    int qi;
-    knn2_mfma_core(desc + (size_t)b * cap * 32, nq, blockIdx.x * 128, desc + (size_t)(b >= lag ? b - lag : 0) * cap * 32, 0, ndb,
-                   s_A, s_T, B, qi);
-    if ((threadIdx.x & 63) < 32 && qi < nq) {
-        const size_t o = (size_t)b * cap + qi;
-        best_idx[o] = B.idx;
-        best_d[o] = B.b1;
-        second_d[o] = B.b2;
+    Best B[2];
+    knn2_mfma_core(desc + (size_t)b * cap * 32, nq, blockIdx.x * 256, desc + (size_t)(b >= lag ? b - lag : 0) * cap * 32, 0, ndb,
+                   s_A, s_T, B);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int qi = blockIdx.x * 256 + 64 * (threadIdx.x >> 6) + 32 * t + (lane & 31);
+        if (lane < 32 && qi < nq) {
+            const size_t o = (size_t)b * cap + qi;
+            best_idx[o] = B[t].idx;
+            best_d[o] = B[t].b1;
+            second_d[o] = B[t].b2;
+        }
     }
 }
 
@@ -455,8 +500,8 @@ void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, 
 {
     if (B <= 0) return;
     static const int mfmaEnv = getenv("ORBHIP_KNN2_MFMA") ? atoi(getenv("ORBHIP_KNN2_MFMA")) : 1;
-    if (mfmaEnv && cap <= (1 << 20))
-        hipLaunchKernelGGL(k_knn2_seq_mfma, dim3((cap + 127) / 128, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag, best_idx,
+    if (mfmaEnv)
+        hipLaunchKernelGGL(k_knn2_seq_mfma, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag, best_idx,
                            best_d, second_d);
     else
         hipLaunchKernelGGL(k_knn2_seq, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag,
