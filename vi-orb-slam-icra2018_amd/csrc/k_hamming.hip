@@ -1,7 +1,10 @@
 // k_hamming.hip -- M0/M1/M2/M3: 256-bit Hamming matching (ref: src/ORBmatcher.cc:1675-1691
 // DescriptorDistance; :205-226 and the other search routines' best / second-best bookkeeping;
-// :159-288 and :522-655 SearchByBoW).  Integer/bitwise path: XOR + v_bcnt_u32_b32, no MFMA.
+// :159-288 and :522-655 SearchByBoW).  Bitwise path (XOR + v_bcnt_u32_b32) everywhere except the brute force over many queries,
+// which runs on the matrix pipe.
 //
+//  k_knn2_mfma   brute force, many queries: |a & b| as an int8 matrix product of the bits written out as bytes (see the kernel);
+//                k_knn2_seq_mfma the same for the frame sequence form.  ORBHIP_KNN2_MFMA=0 selects the scalar kernels below.
 //  k_knn2        brute force, query tile x database split; a thread owns one query (8 VGPRs),
 //                the database row is wave-uniform and arrives through scalar loads; partial
 //                (best, index, second) per split, merged in split order by k_knn2_merge so that
@@ -424,7 +427,7 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ db, int ndb,
+__global__ __launch_bounds__(256, 4) void k_knn2_mfma(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ db, int ndb,
                                                    int rowsPerSplit, int4 *__restrict__ partial)
 {
     __shared__ v4i_h s_A[2][KM_SUB][8][2][32];
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t *__restrict__ q
     }
 }
 
-__global__ __launch_bounds__(256) void k_knn2_seq_mfma(const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap,
+__global__ __launch_bounds__(256, 4) void k_knn2_seq_mfma(const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap,
                                                        int lag, int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
                                                        int32_t *__restrict__ second_d)
 {
