@@ -278,15 +278,15 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
 // d(a, b) = |a| + |b| - 2 |a & b|, and |a & b| over 32 bits is a dot product of the bits written out as bytes: one
 // v_mfma_i32_32x32x32_i8 per descriptor word gives the 32 x 32 values |a & b| of 32 database rows (A operand) against 32 queries (B
 // operand), eight of them a tile of 1024 distances -- 8 matrix instructions instead of 1024 x (8 v_xor + 8 v_bcnt + 7 adds).
-//  * The instruction also builds the comparison key.  A row's set bits are written as 0x40, a query's as 0x80 (= -128): a common bit
-//    contributes -2^13, and with the accumulator started at (|b| << 12) + row (row = index inside a chunk of 4096 database rows) the
-//    result is ((|b| - 2 |a & b|) << 12) + row: ordered by distance, then by index (|a| is the same for all keys of a query and added
-//    at the end).  Per value the vector pipe only keeps the two smallest keys, m2 = med3(m1, m2, key), m1 = min(m1, key) -- (best,
+//  * The instruction also builds the comparison key.  |b| - 2 |a & b| = sum over the set bits of b of (1 - 2 a_k): a row's set bits
+//    are written as 0x40 (64), a query's bits as +64 (clear) or -64 (set), so a set row bit contributes +-2^12, and with the
+//    accumulator started at the row's index inside a chunk of 4096 database rows the result is ((|b| - 2 |a & b|) << 12) + row:
+//    ordered by distance, then by index (|a| is the same for all keys of a query and added at the end).  Per value the vector pipe only keeps the two smallest keys, m2 = med3(m1, m2, key), m1 = min(m1, key) -- (best,
 //    lowest index) and the second smallest distance of the multiset, exactly what the strict '<' loop of the reference leaves (:205-226).
 //  * Result layout: column = lane & 31 = query, the 16 registers of a lane = 16 of the tile's rows (8 g + 4 h + e for register 4 g + e,
 //    h = lane >> 5): a lane folds its own values, no cross-lane work; the two lanes of a query merge once at the end.
 //  * A workgroup = 256 queries (two 32-query tiles per wave: each A fragment read from LDS feeds two matrix instructions, the LDS reads
-//    are what limits this kernel) x the rows of one split; the byte form of a 64-row database tile (16 KB) and the rows' initial keys are
+//    are what limits this kernel) x the rows of one split; the byte form of a 64-row database tile (16 KB) and the rows' indices are
 //    built once per workgroup in LDS, thread = one word of two rows ((x * 0x08102040) & 0x40404040 spreads four bits over four bytes),
 //    double-buffered behind one barrier per tile.  Output = the split's partial result in the format of k_knn2, merged in split order by
 //    k_knn2_merge.
@@ -344,14 +344,16 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             pa[t] += __popc(Q[k]);
-            Bq[t][k] = bits16_to_bytes<0x10204080u, 0x80808080u>(Q[k], h);
+            Bq[t][k] = bits16_to_bytes<0x10204080u, 0x80808080u>(Q[k], h) | 0x40404040;   // 0xC0 = -64 per set bit, 0x40 = +64 per clear one
         }
         out[t].b1 = 256;
         out[t].idx = -1;
         out[t].b2 = 256;
     }
-    // staging role of this thread: word sw of the rows srow, srow + 32 of the staged tile
-    const int srow = tid >> 3, sw = tid & 7;
+    // staging role of this thread: word sw of the rows srow, srow + 32 of the staged tile (the 32 lanes of a half-wave write 32
+    // consecutive 16-byte slots: with the eight words of a row in adjacent lanes the writes were eight-way bank conflicts, 63 % of the
+    // LDS cycles of the kernel)
+    const int srow = tid & 31, sw = tid >> 5;
     constexpr int TR = 32 * KM_SUB;
     for (int c0 = j0; c0 < j1; c0 += KM_CHUNK) {   // (one trip unless the database has more rows than a key can index)
         const int c1 = min(j1, c0 + KM_CHUNK);
@@ -367,12 +369,8 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
             for (int u = 0; u < KM_SUB; u++) {
                 s_A[buf][u][sw][0][srow] = bits16_to_bytes<0x08102040u, 0x40404040u>(word[u], 0);
                 s_A[buf][u][sw][1][srow] = bits16_to_bytes<0x08102040u, 0x40404040u>(word[u], 1);
-                int pc = __popc(word[u]);   // |b| of the row: sum over the eight lanes that hold its words
-                pc += __builtin_amdgcn_update_dpp(0, pc, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-                pc += __builtin_amdgcn_update_dpp(0, pc, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-                pc += __builtin_amdgcn_update_dpp(0, pc, 0x141, 0xF, 0xF, true);   // row_half_mirror
                 const int j = jt + 32 * u + srow;
-                if (sw == 0) s_T[buf][32 * u + srow] = j < c1 ? ((pc << 12) | (j - c0)) : KM_NONE;
+                if (sw == 0) s_T[buf][32 * u + srow] = j < c1 ? j - c0 : KM_NONE;
             }
         };
         int m1[2] = {KM_NONE, KM_NONE}, m2[2] = {KM_NONE, KM_NONE};
