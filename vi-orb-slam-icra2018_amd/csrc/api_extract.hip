@@ -138,7 +138,7 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
     }
     orbhip_ctx *c = new orbhip_ctx();
     c->device = device;
-    if (const char *bp = getenv("ORBHIP_BLUR_PLACE")) c->blurPlace = std::min(2, std::max(0, atoi(bp)));
+    c->blurPlace = std::min(2, std::max(0, ORB_TUNE("BLUR_PLACE", 0)));
     c->max_w = max_w;
     c->max_h = max_h;
     c->max_batch = max_batch;
@@ -278,7 +278,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     const bool evFast = !c->capturing && c->stageTiming >= 1;
     if (ev) HIPCHK(c, hipEventRecord(c->ev[0], s));
     // E2 pyramid.  A frame or two: several levels per launch (k_pyramid_chain; ORBHIP_NO_CHAIN=1 keeps one launch per level)
-    static const bool noChain = getenv("ORBHIP_NO_CHAIN") && atoi(getenv("ORBHIP_NO_CHAIN")) != 0;
+    static const bool noChain = ORB_SWITCH("NO_CHAIN", 0) != 0;
     const bool chained = B < 8 && !noChain && !c->chainGroups.empty();
     if (chained)
         for (const ChainGroup &grp : c->chainGroups)
@@ -350,7 +350,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
     if (evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    static const bool noSplit = getenv("ORBHIP_NO_SPLIT") && atoi(getenv("ORBHIP_NO_SPLIT")) != 0;   // A/B: r02 schedule
+    static const bool noSplit = ORB_TUNE("NO_SPLIT", 0) != 0;   // A/B: r02 schedule
     if (B >= 16 && blurPlace == 0 && !noSplit) {
         const int nA = B / 2, nB = B - nA;
         if (!evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));   // (the hand-over event; the timing path has recorded it)
@@ -545,7 +545,7 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
             for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * s0, imgs[b] + (size_t)y * stride, (size_t)w);
     }
     uint8_t *blk = reinterpret_cast<uint8_t *>(c->d_kps);
-    static const bool directOut = !(getenv("ORBHIP_COPY_OUT") && atoi(getenv("ORBHIP_COPY_OUT")) != 0);   // A/B: 1 = result copy node
+    static const bool directOut = ORB_TUNE("COPY_OUT", 0) == 0;   // A/B: 1 = result copy node
     const void *key[5] = {c->d_lvl0, blk, c->h_in, c->h_stage, hpyr};
     const bool same = c->g_exec && c->g_w == w && c->g_h == h && c->g_B == B && c->g_gen == c->allocGen &&
                       memcmp(key, c->g_key, sizeof(key)) == 0;
@@ -612,7 +612,7 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
     const size_t kbytes = (size_t)B * dcap * sizeof(orbhip_keypoint), dbytes = (size_t)B * dcap * 32, cbytes = (size_t)B * 4;
     const size_t koff = 0, doff = align_up(kbytes, 256), coff = doff + align_up(dbytes, 256);
     uint8_t *blk = reinterpret_cast<uint8_t *>(c->d_kps);
-    static const bool noGraph = getenv("ORBHIP_NO_GRAPH") && atoi(getenv("ORBHIP_NO_GRAPH")) != 0;
+    static const bool noGraph = ORB_SWITCH("NO_GRAPH", 0) != 0;
     if (B < 8 && !noGraph) {
         if ((rc = extract_small_graph(c, imgs, B, w, h, stride, s0, kbytes, dbytes, cbytes, koff, doff, coff, dcap))) return rc;
     } else {

@@ -213,7 +213,7 @@ extern "C" int orbhip_search_by_bow_sets(orbhip_ctx *c, uint64_t key1, const uin
         if (s2->off[pairs[2 * p + 1] + 1] - s2->off[pairs[2 * p + 1]] > 128) hostOut = false;
     // the masks and the node pairs: read by the kernel straight from the page-locked block (no copy command) when the
     // matches go there too; a frame with a node of more than 128 features keeps everything on the device
-    static const bool zeroCopy = !(getenv("ORBHIP_SETS_COPY") && atoi(getenv("ORBHIP_SETS_COPY")) != 0);
+    static const bool zeroCopy = ORB_TUNE("SETS_COPY", 0) == 0;
     const bool hostIn = hostOut && zeroCopy;
     const uint8_t *dv1 = (const uint8_t *)(hostIn ? P.in_host(valid1, (size_t)n1) : P.in(valid1, (size_t)n1));
     const uint8_t *dv2 = !valid2 ? nullptr : (const uint8_t *)(hostIn ? P.in_host(valid2, (size_t)n2) : P.in(valid2, (size_t)n2));

@@ -27,7 +27,7 @@
 
 static int bs_threads()
 {
-    static const int n = getenv("ORBHIP_BOW_THREADS") ? atoi(getenv("ORBHIP_BOW_THREADS")) : 1024;
+    static const int n = ORB_TUNE("BOW_THREADS", 1024);
     return n;
 }
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
                                                  const uint8_t *__restrict__ valid, int cap, int NP, int lag, int th,
                                                  int th_mode, float nnratio, int check_ori,
                                                  int32_t *__restrict__ match12, int32_t *__restrict__ match21,
-                                                 int32_t *__restrict__ nmatches, int dbgPhases)
+                                                 int32_t *__restrict__ nmatches ORB_ABL_PARAM)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     unsigned long long *key1 = reinterpret_cast<unsigned long long *>(smem);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
         s_nm = 0;
     }
     __syncthreads();
-    if (dbgPhases < 1) return;
+    ORB_ABL_STOP(phases < 1);
     if (LDSD) {
         // both descriptor sets travel to LDS by LDS-DMA (16 bytes per lane, 1 KB per wave transfer) WHILE the keys are sorted: the
         // sort and the item list only touch the key arrays, the descriptors are first read by the greedy phase (waited for before
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
     int NS = 64;
     while (NS < max(n1, n2)) NS <<= 1;
     bs_sort2(key1, key2, NS, tid);
-    if (dbgPhases < 2) return;
+    ORB_ABL_STOP(phases < 2);
     // number of live entries per side
     for (int i = tid; i < NS; i += blockDim.x) {
         if (key1[i] != ~0ull && (i + 1 == NS || key1[i + 1] == ~0ull)) s_n1v = i + 1;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
     if (LDSD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's descriptor transfers have landed
     __syncthreads();
 
-    if (dbgPhases < 3) return;
+    ORB_ABL_STOP(phases < 3);
     // ---- 3. greedy matching ----
     // The greedy claiming of the reference is order dependent, so the side-1 features of a node form a serial
     // chain (key -> descriptor -> distances -> minima -> claim); the kernel's time is the longest chain plus
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
     }
     __syncthreads();
 
-    if (dbgPhases < 4) return;
+    ORB_ABL_STOP(phases < 4);
     // ---- 4. rotation consistency ----
     const orbhip_keypoint *k1 = kps + (size_t)b1 * cap, *k2 = kps + (size_t)b * cap;
     int mybin0 = -1;   // this thread handles features tid, tid+256, ...: remember bins in registers
@@ -541,16 +541,17 @@ void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *k
     while (NP < cap) NP <<= 1;
     const size_t base = (((size_t)NP * 36 + (size_t)NP / 32 * 12 + 15) & ~(size_t)15) + 64;
     const size_t full = base + (size_t)cap * 64;
-    static const int forceGlobal = getenv("ORBHIP_BOW_GLOBAL_DESC") ? atoi(getenv("ORBHIP_BOW_GLOBAL_DESC")) : 0;
+    static const int forceGlobal = ORB_TUNE("BOW_GLOBAL_DESC", 0);
     const bool ldsd = full <= 150 * 1024 && !forceGlobal;
-    static const int dbg = getenv("ORBHIP_BOW_PHASES") ? atoi(getenv("ORBHIP_BOW_PHASES")) : 9;
+    static const int dbg = ORB_TUNE("BOW_PHASES", 9);   // timing ablation only (liborbhip_ablation.so): results are then invalid
+    (void)dbg;
     const size_t lds = ldsd ? full : base;
     const void *fn = ldsd ? (const void *)k_bow_seq<true> : (const void *)k_bow_seq<false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ldsd)
         hipLaunchKernelGGL(k_bow_seq<true>, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid,
-                           cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches, dbg);
+                           cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches ORB_ABL_ARG(dbg));
     else
         hipLaunchKernelGGL(k_bow_seq<false>, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid,
-                           cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches, dbg);
+                           cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches ORB_ABL_ARG(dbg));
 }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
                                                   float *__restrict__ lvlAngle,
                                                   orbhip_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int32_t *__restrict__ counts,
-                                                  int cap, int xcdMap, int phases)
+                                                  int cap, int xcdMap ORB_ABL_PARAM)
 {
     __shared__ int s_pos[DS_KP];      // cx | cy << 12 | level << 24, -1 = empty slot
     __shared__ int s_out[DS_KP];      // output index
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
         s_bstride[tid] = l == 0 ? G.bstride0 : G.lv[l].stride;
     }
     __syncthreads();
-    if (phases < 1) return;   // timing ablation only (ORBHIP_DESCRIBE_PHASES): results are then invalid
+    ORB_ABL_STOP(phases < 1);   // timing ablation only (liborbhip_ablation.so, ORBHIP_DESCRIBE_PHASES): results are then invalid
 
     // ---- A. E5: IC_Angle moments on the un-blurred level ----
     if constexpr (AX4) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
     }
     }
     __syncthreads();
-    if (phases < 2) return;
+    ORB_ABL_STOP(phases < 2);
 
     // ---- B. angle, cos / sin, keypoint record: one thread per keypoint ----
     if (tid < DS_KP) {
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
         }
     }
     __syncthreads();
-    if (phases < 3) return;
+    ORB_ABL_STOP(phases < 3);
 
     // ---- C. E7: steered BRIEF on the blurred level ----
     // The 37 x 37 neighbourhood of the keypoint (the rotated pattern stays within 18 pixels) is staged per wave in
@@ -480,25 +480,26 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
 {
-    static const int kpwEnv = getenv("ORBHIP_DESCRIBE_KPW") ? atoi(getenv("ORBHIP_DESCRIBE_KPW")) : 0;
+    static const int kpwEnv = ORB_TUNE("DESCRIBE_KPW", 0);
     const int kpw = kpwEnv == 8 || kpwEnv == 16 || kpwEnv == 32 ? kpwEnv : (B >= 8 ? 16 : 8);
     // workgroup -> (slot block, frame): ORBHIP_DESCRIBE_MAP overrides this kernel's mapping alone (A/B runs)
-    static const int dmap = getenv("ORBHIP_DESCRIBE_MAP") ? atoi(getenv("ORBHIP_DESCRIBE_MAP")) : -1;
+    static const int dmap = ORB_TUNE("DESCRIBE_MAP", -1);
     const int mapArg = dmap >= 0 ? (dmap | (orb_xcd_chunk() << 8)) : orb_xcd_arg(DESCRIBE_DEFAULT_MAP);
-    static const int phases = getenv("ORBHIP_DESCRIBE_PHASES") ? atoi(getenv("ORBHIP_DESCRIBE_PHASES")) : 3;
+    static const int phases = ORB_TUNE("DESCRIBE_PHASES", 3);
+    (void)phases;
     // occupancy experiment only: unused dynamic LDS caps the workgroups per CU
-    static const int padLds = getenv("ORBHIP_DESCRIBE_PADLDS") ? atoi(getenv("ORBHIP_DESCRIBE_PADLDS")) : 0;
+    static const int padLds = ORB_TUNE("DESCRIBE_PADLDS", 0);
     const int nblk = (G.totalKps + kpw - 1) / kpw;
     dim3 grid((mapArg & 255) ? (nblk + 7) / 8 * 8 : nblk, B, 1), block(256, 1, 1);
     // the one-load form of the angle phase is written for the umax table of a 31-pixel patch (always what orb_init_tables computes)
-    static const int ax4Env = getenv("ORBHIP_DESCRIBE_AX4") ? atoi(getenv("ORBHIP_DESCRIBE_AX4")) : 1;
+    static const int ax4Env = ORB_TUNE("DESCRIBE_AX4", 1);
     static const int umaxWant[16] = {ANGLE_UMAX_VALUES};
     bool ax4 = ax4Env != 0 && kpw == 16;
     for (int v = 0; v < 16; v++) ax4 = ax4 && G.umax[v] == umaxWant[v];
 #define ORB_LAUNCH_DESCRIBE(KERN)                                                                                               \
     hipLaunchKernelGGL(KERN, grid, block, (size_t)padLds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc, \
-                       counts, cap, mapArg, phases)
+                       counts, cap, mapArg ORB_ABL_ARG(phases))
     if (kpw == 32)
         ORB_LAUNCH_DESCRIBE((k_describe<32, false>));
     else if (kpw == 16 && ax4)

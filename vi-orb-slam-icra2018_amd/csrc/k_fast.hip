@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
                                               unsigned long long pyrFrame, const FastTile *__restrict__ tiles,
                                               uint32_t *__restrict__ cand, uint16_t *__restrict__ cellCnt, int pixBytes,
                                               int scoreBytes, int listBytes, int cornerBytes, int bitsBytes, int listCap,
-                                              int cornerCap, int phases, int xcdMap, int ntiles)
+                                              int cornerCap, int xcdMap, int ntiles ORB_ABL_PARAM)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_cellAny[FAST_TILE_CELLS];
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
         s_nAct = 0;
     }
     __syncthreads();
-    if (phases < 2) return;   // timing ablation only (ORBHIP_FAST_PHASES), results are then invalid
+    ORB_ABL_STOP(phases < 2);   // timing ablation only (liborbhip_ablation.so, ORBHIP_FAST_PHASES): results are then invalid
 
     const int wCell = L.wCell;
     const unsigned cellMagic = 65536u / (unsigned)wCell + 1u;   // c / wCell for c < 65536 / wCell
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
                 // unit serialises the 64 adds instead, and it has the cycles to spare).  A thread whose entries do not all
                 // fit writes none: s_listCount then exceeds listCap and phase 3 takes the fallback.
                 const int n = __popc(acc);
-                if (phases == 12) {   // ablation only: the compass items without the list
+                ORB_ABL_IF(phases == 12) {   // ablation only: the compass items without the list
                     if (n == 77) s_list[0] = (uint16_t)n;
                     continue;
                 }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
             }
         }
         __syncthreads();
-        if (phases < 3 + 3 * pass || phases == 12) return;   // ablation stops: 2-4 = phases of pass 0, 5-7 = of pass 1
+        ORB_ABL_STOP(phases < 3 + 3 * pass || phases == 12);   // ablation stops: 2-4 = phases of pass 0, 5-7 = of pass 1
 
         // ---- 3. full score on the work list; corners (score >= t) -> score tile + corner list ----
         // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel of the
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
             }
         }
         __syncthreads();
-        if (phases < 4 + 3 * pass) return;
+        ORB_ABL_STOP(phases < 4 + 3 * pass);
 
         // ---- 4. NMS over the corners (cell-local neighbourhood); every survivor is final: set its bit ----
         const int ncorner = s_cornerCount;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
             }
         }
         __syncthreads();
-        if (phases < 5 + 3 * pass) return;
+        ORB_ABL_STOP(phases < 5 + 3 * pass);
     }
 
     // ---- 5. rank inside the cell (= raster order) from the bitmap, write the slots ----
@@ -656,6 +656,11 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
 //     (7-12 % of the entries are such pixels, so practically every wave paid for both polarities of all its 64 entries).
 // Tiles outside these bounds (other cell sizes, ORBHIP_FAST_PITCH=0) run k_fast<0>.
 // =====================================================================================================================
+// workgroup -> (run, frame) of the fixed-layout kernel: 4 = a whole frame's runs on one XCD (grid (8, runs, B / 8), see the kernel).
+// Measured (r04, gpurun_out/r04_fast2 -> profiles/r04): fabric reads 1.91 -> 0.92 GB per 1024 frames (1.13 x the algorithmic bytes)
+// at the same 1.02 ms -- the kernel is bound by vector and LDS issue, not by its loads; the r01 mappings paid an integer division
+// per thread for the same traffic and were slower.
+#define FAST_DEFAULT_XCD 4
 #define FF_RHM 40                      // staged rows (hCell + 6) the fixed layout holds
 #define FF_DHM (FF_RHM - 6)
 #define FF_NCM 5                       // cells per run
@@ -767,12 +772,89 @@ __device__ __forceinline__ uint32_t compass_items(const uint8_t *win, int nitems
     return (a01 >> 7) | (a23 << 1) | (a45 << 9) | (a67 << 17);
 }
 
+
+// ---- the ring gather of k_fast_fix: 17 byte loads at immediate offsets from one address, one wait ----
+// Ring pixel k comes by ds_read_u8, its opposite k + 8 by ds_read_u8_d16_hi: the byte lands in bits 16..23 and, on this target
+// (SRAM-ECC is always on: a d16 load rewrites the whole register), the other half is cleared -- so P[k] = lo | hi needs no
+// shift (v_lshlrev_b32 is a four-cycle instruction, profiles/r03/valu_rates.txt: eight of them per work-list entry), and the
+// OR folds into the v_bitop3 that applies the polarity constant.  Issued from one asm block because the compiler cannot be
+// told about d16 loads of separate registers; the offsets are spelled per pitch (an asm operand list holds 30 entries).
+#define ORB_RING_ASM(PS)                                                                                                          \
+    asm volatile("ds_read_u8 %0, %17 offset:6*" PS "+3\n\t"                                                                       \
+                 "ds_read_u8 %1, %17 offset:6*" PS "+4\n\t"                                                                       \
+                 "ds_read_u8 %2, %17 offset:5*" PS "+5\n\t"                                                                       \
+                 "ds_read_u8 %3, %17 offset:4*" PS "+6\n\t"                                                                       \
+                 "ds_read_u8 %4, %17 offset:3*" PS "+6\n\t"                                                                       \
+                 "ds_read_u8 %5, %17 offset:2*" PS "+6\n\t"                                                                       \
+                 "ds_read_u8 %6, %17 offset:" PS "+5\n\t"                                                                         \
+                 "ds_read_u8 %7, %17 offset:4\n\t"                                                                                \
+                 "ds_read_u8_d16_hi %8, %17 offset:3\n\t"                                                                         \
+                 "ds_read_u8_d16_hi %9, %17 offset:2\n\t"                                                                         \
+                 "ds_read_u8_d16_hi %10, %17 offset:" PS "+1\n\t"                                                                 \
+                 "ds_read_u8_d16_hi %11, %17 offset:2*" PS "\n\t"                                                                 \
+                 "ds_read_u8_d16_hi %12, %17 offset:3*" PS "\n\t"                                                                 \
+                 "ds_read_u8_d16_hi %13, %17 offset:4*" PS "\n\t"                                                                 \
+                 "ds_read_u8_d16_hi %14, %17 offset:5*" PS "+1\n\t"                                                               \
+                 "ds_read_u8_d16_hi %15, %17 offset:6*" PS "+2\n\t"                                                               \
+                 "ds_read_u8 %16, %17 offset:3*" PS "+3\n\t"                                                                      \
+                 "s_waitcnt lgkmcnt(0)"                                                                                           \
+                 : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(lo[6]), "=&v"(lo[7]), \
+                   "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7]), \
+                   "=&v"(v0)                                                                                                      \
+                 : "v"(a)                                                                                                         \
+                 : "memory")
+template <int PITCH>
+__device__ __forceinline__ void ring_gather(uint32_t a, uint32_t (&lo)[8], uint32_t (&hi)[8], uint32_t &v0)
+{
+    static_assert(PITCH == 160 || PITCH == 176 || PITCH == 192 || PITCH == 208, "ring_gather: pitch without an instance");
+    if constexpr (PITCH == 160) ORB_RING_ASM("160");
+    else if constexpr (PITCH == 176) ORB_RING_ASM("176");
+    else if constexpr (PITCH == 192) ORB_RING_ASM("192");
+    else ORB_RING_ASM("208");
+}
+#undef ORB_RING_ASM
+
+// fast_score_win / fast_score_dark on the gathered ring: a = LDS byte address of the top-left corner of the pixel's 7x7 window
+template <int PITCH, bool DEFER>
+__device__ __forceinline__ int fast_score_ring(uint32_t a, int t, bool *other)
+{
+    uint32_t lo[8], hi[8], v0u;
+    ring_gather<PITCH>(a, lo, hi, v0u);
+    const int v0 = (int)v0u;
+    const int q0 = (int)lo[0], q4 = (int)lo[4], q8 = (int)(hi[0] >> 16), q12 = (int)(hi[4] >> 16);
+    const bool pb = min(max(q0, q8), max(q4, q12)) > v0 + t;    // bright: q - v > t
+    const bool pd = max(min(q0, q8), min(q4, q12)) < v0 - t;    // dark:   v - q > t
+    if (!pb && !pd) return 0;
+    const bool dark = !pb;
+    const uint32_t C = dark ? 0x40FF40FFu : 0x40004000u;
+    uint32_t P[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) P[k] = lo[k] | hi[k];
+    int sc = arcs_score(P, C, v0 ^ (dark ? 0xFF : 0));
+    if (DEFER) {
+        *other = pb && pd && sc < t;
+    } else if (pb && pd)
+        sc = max(sc, arcs_score(P, 0x40FF40FFu, v0 ^ 0xFF));
+    return sc >= t ? sc : 0;
+}
+template <int PITCH>
+__device__ __forceinline__ int fast_score_ring_dark(uint32_t a, int t)
+{
+    uint32_t lo[8], hi[8], v0u;
+    ring_gather<PITCH>(a, lo, hi, v0u);
+    uint32_t P[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) P[k] = lo[k] | hi[k];
+    const int sc = arcs_score(P, 0x40FF40FFu, (int)v0u ^ 0xFF);
+    return sc >= t ? sc : 0;
+}
+
 template <int PITCH, bool DEFER>
 __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__ lvl0, int stride0, unsigned long long frame0,
                                                      const uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
                                                      const FastTile *__restrict__ tiles, uint32_t *__restrict__ cand,
                                                      uint16_t *__restrict__ cellCnt, int totalCells, int totalCands, int iniTh,
-                                                     int minTh, int listCap, int cornerCap, int phases, int xcdMap, int ntiles)
+                                                     int minTh, int listCap, int cornerCap, int xcdMap, int ntiles ORB_ABL_PARAM)
 {
     __shared__ __align__(16) uint8_t s_pix[PITCH * FF_RHM];
     __shared__ unsigned long long s_bits[FF_NCM * FF_DHM];   // [cell][row]: survivors of the row (wCell < 64)
@@ -784,7 +866,18 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
     __shared__ int s_wcnt[4][2];          // pass 1, per wave: work-list and corner-list counts
     extern __shared__ __align__(16) uint8_t s_score[];       // [DH][SP]
 
-    const int tileId = xcd_tile(xcdMap), frame = blockIdx.y;
+    int tileId, frame;
+    if ((xcdMap & 255) == 4) {
+        // grid (8, runs, ceil(B / 8)): workgroups are dealt to the XCDs round-robin by linear id = (z * runs + y) * 8 + x, so XCD x
+        // receives run y of frame x + 8 z, y = 0, 1, ... -- a whole frame's runs on one XCD, whose L2 then reads the frame's
+        // levels (1 MB of its 4 MB) once; the eight XCDs work on eight frames.  No division: the ids are the grid's own.
+        tileId = blockIdx.y;
+        frame = blockIdx.x + 8 * blockIdx.z;
+        if (frame >= (xcdMap >> 8)) return;
+    } else {
+        tileId = xcd_tile(xcdMap);
+        frame = blockIdx.y;
+    }
     if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
     const FastTile &T = tiles[tileId];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -795,6 +888,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
         return;
     }
     constexpr int pitch = PITCH;
+    const uint32_t pixAddr = (uint32_t)(uintptr_t)s_pix;   // LDS byte address of the pixel tile
     const int RH = T.RH, nchunk = T.nchunk, j0 = T.j0, jd0 = j0 & ~3, GPR = T.GPR;
     const int SP = (TW + 3) & ~3;
     const int nrowsAll = ncells * DH;
@@ -834,7 +928,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (phases < 2) return;   // timing ablation only (ORBHIP_FAST_PHASES), results are then invalid
+    ORB_ABL_STOP(phases < 2);   // timing ablation only (liborbhip_ablation.so, ORBHIP_FAST_PHASES): results are then invalid
 
     const int wCell = T.wCell;
     const unsigned cellMagic = (unsigned)T.cellMagic;
@@ -860,7 +954,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             const uint32_t dom = mine ? s_dom[slot] : 0u;   // domain mask of my four pixels (pixel k at bit 8k + 7)
             const uint32_t listCountAddr = (uint32_t)(uintptr_t)&s_listCount;   // LDS byte address (low half of the flat address)
             const uint8_t *win = s_pix + __mul24(mine ? rs : 0, pitch) + (jd - 4);
-            if (phases == 11) return;   // ablation only: the set-up of the compass phase
+            ORB_ABL_STOP(phases == 11);   // ablation only: the set-up of the compass phase
             for (int cb = 0; cb < seg; cb += 8) {
                 uint32_t acc = compass_items<PITCH>(win, seg - cb, dom, CK);
                 // rows of the last segment below the domain were computed on whatever lies there: drop them
@@ -871,7 +965,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 // claims its range.  A thread whose entries do not all fit writes none: s_listCount then exceeds listCap
                 // and phase 3 takes the fallback.
                 const int n = __popc(acc);
-                if (phases == 12) {   // ablation only: the compass items without the list
+                ORB_ABL_IF(phases == 12) {   // ablation only: the compass items without the list
                     if (n == 77) s_list[0] = (uint16_t)n;
                     continue;
                 }
@@ -885,7 +979,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             }
         }
         __syncthreads();
-        if (phases < 3 || phases == 12) return;   // ablation stops: 2-4 = phases of pass 0
+        ORB_ABL_STOP(phases < 3 || phases == 12);   // ablation stops: 2-4 = phases of pass 0
 
         // ---- 3. full score on the work list; corners (score >= t) -> score tile + corner list ----
         // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel is scored
@@ -908,7 +1002,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                     const int ent = s_list[e];
                     const int r = ENT_ROW(ent), j = ENT_COL(ent);
                     bool other;
-                    int s = fast_score_win<true>(s_pix, __mul24(r, pitch) + (j - 3), pitch, t, &other);
+                    int s = fast_score_ring<PITCH, true>(pixAddr + (uint32_t)(__mul24(r, pitch) + (j - 3)), t, &other);
                     if (other) {
                         // park the entry at the unused end of the work list (slots >= nlist are never read by this loop);
                         // if the list is full to that point, finish the pixel here
@@ -916,7 +1010,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                         asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(deferCountAddr), "v"(1) : "memory");
                         const int idx = listCap - 1 - d;
                         if (idx >= nlist) s_list[idx] = (uint16_t)ent;
-                        else s = fast_score_dark(s_pix, __mul24(r, pitch) + (j - 3), pitch, t);
+                        else s = fast_score_ring_dark<PITCH>(pixAddr + (uint32_t)(__mul24(r, pitch) + (j - 3)), t);
                     }
                     if (s > 0) put_corner(ent, r, j, s);
                 }
@@ -926,14 +1020,14 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 for (int e = tid; e < ndefer; e += 256) {
                     const int ent = s_list[listCap - 1 - e];
                     const int r = ENT_ROW(ent), j = ENT_COL(ent);
-                    const int s = fast_score_dark(s_pix, __mul24(r, pitch) + (j - 3), pitch, t);
+                    const int s = fast_score_ring_dark<PITCH>(pixAddr + (uint32_t)(__mul24(r, pitch) + (j - 3)), t);
                     if (s > 0) put_corner(ent, r, j, s);
                 }
             } else {
                 for (int e = tid; e < nlist; e += 256) {
                     const int ent = s_list[e];
                     const int r = ENT_ROW(ent), j = ENT_COL(ent);
-                    const int s = fast_score_win<false>(s_pix, __mul24(r, pitch) + (j - 3), pitch, t, nullptr);
+                    const int s = fast_score_ring<PITCH, false>(pixAddr + (uint32_t)(__mul24(r, pitch) + (j - 3)), t, nullptr);
                     if (s > 0) put_corner(ent, r, j, s);
                 }
             }
@@ -957,7 +1051,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             }
         }
         __syncthreads();
-        if (phases < 4) return;
+        ORB_ABL_STOP(phases < 4);
 
         // ---- 4. NMS over the corners (cell-local neighbourhood); every survivor is final: set its bit ----
         const int ncorner = s_cornerCount;
@@ -997,7 +1091,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
         }
     }
     __syncthreads();
-    if (phases < 5) return;
+    ORB_ABL_STOP(phases < 5);
 
     // ============ pass 1 and the output: ONE WAVE PER CELL, no workgroup barrier from here on ============
     // The cells without a survivor are searched again at minThFAST (:814-818).  A cell's second pass touches nothing outside the
@@ -1069,7 +1163,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 for (int e = lane; e < nl; e += 64) {
                     const int ent = wlist[e];
                     const int r = ENT_ROW(ent), j = ENT_COL(ent);
-                    const int s = fast_score_win<false>(s_pix, __mul24(r, pitch) + (j - 3), pitch, t, nullptr);
+                    const int s = fast_score_ring<PITCH, false>(pixAddr + (uint32_t)(__mul24(r, pitch) + (j - 3)), t, nullptr);
                     if (s > 0) put_corner1(ent, r, j, s);
                 }
             } else {
@@ -1106,7 +1200,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
                 }
             }
         }
-        if (phases < 8) continue;
+        ORB_ABL_IF(phases < 8) continue;
         // ---- 5. rank inside the cell (= raster order) from the bitmap, write the slots: lane = row (DH <= 34) ----
         // The rank of a survivor is the number of bits before it: a prefix over the rows of its cell plus a popcount inside its
         // row -- no survivor is ever compared with another one.
@@ -1134,7 +1228,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             slotp[rank++] = (posBase + (uint32_t)cl) | ((uint32_t)sc[cl] << 24);
         }
     }
-    if (phases < 8 && tid < ncells) cntRun[tid] = 0;
+    ORB_ABL_IF(phases < 8 && tid < ncells) cntRun[tid] = 0;
 #undef ENT_ROW
 #undef ENT_COL
 #undef ENT_MAKE
@@ -1166,8 +1260,10 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     }
     pixBytes = (pixBytes + 15) & ~15;
     scoreBytes = (scoreBytes + 15) & ~15;
-    static const int forced = getenv("ORBHIP_FAST_LISTCAP") ? atoi(getenv("ORBHIP_FAST_LISTCAP")) : 0;
-    static const int phases = getenv("ORBHIP_FAST_PHASES") ? atoi(getenv("ORBHIP_FAST_PHASES")) : 99;
+    static const int forced = ORB_TUNE("FAST_LISTCAP", 0);   // tests force every list to overflow
+    static const int phases = ORB_TUNE("FAST_PHASES", 99);
+    (void)phases;
+    static const int fastXcd = ORB_TUNE("FAST_XCD", FAST_DEFAULT_XCD);   // workgroup -> (run, frame) of the fixed-layout kernel
     dim3 grid(orb_xcd_grid(ntiles), B, 1), block(256, 1, 1);
     // r02 kernel: work list = a quarter of the tile's pixels (the first pass runs at iniThFAST), corner list = a sixteenth;
     // bitmap and row prefix per (cell, row).  Tiles that exceed the lists take the exact fallback paths.
@@ -1181,23 +1277,25 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     const int bitsBytes = (bitsRows * 8 + 15) & ~15, preBytes = (bitsRows * 4 + 15) & ~15;
     // the kernel with a compile-time pitch (176 / 192 / 208: five cells of 31..36 pixels + halo + alignment, i.e. every level of
     // the usual 30-pixel cell grid) when no level needs more, the run-time pitch otherwise (ORBHIP_FAST_PITCH=0 forces the latter)
-    static const int pitchEnv = getenv("ORBHIP_FAST_PITCH") ? atoi(getenv("ORBHIP_FAST_PITCH")) : 1;
+    static const int pitchEnv = ORB_TUNE("FAST_PITCH", 1);
     const int fixed = pitchEnv == 0 ? 0 : maxPitch <= 176 ? 176 : maxPitch <= 192 ? 192 : maxPitch <= 208 ? 208 : 0;
     const int fixedFix = fixed && maxPitch <= 160 ? 160 : fixed;   // the fixed-layout kernel also has a 160-byte instance
     if (fixed) pixBytes = (fixed * maxRh + 15) & ~15;
     const size_t lds = (size_t)(pixBytes + scoreBytes + lBytes + cBytes + bitsBytes + preBytes);
     // the fixed-layout kernel when every level fits its bounds (ORBHIP_FAST_FIX=0: the generic kernel)
-    static const int fixEnv = getenv("ORBHIP_FAST_FIX") ? atoi(getenv("ORBHIP_FAST_FIX")) : 1;
-    static const int deferEnv = getenv("ORBHIP_FAST_DEFER") ? atoi(getenv("ORBHIP_FAST_DEFER")) : 1;
+    static const int fixEnv = ORB_SWITCH("FAST_FIX", 1);
+    static const int deferEnv = ORB_TUNE("FAST_DEFER", 1);
     const int maxCells = fast_tile_cells();   // the configured run length bounds every tile's
     if (fixEnv && fixed && maxRh <= FF_RHM && maxCells <= FF_NCM) {
         const int lc = forced > 0 ? std::min(forced, FF_LISTCAP) : listCapFix, cc = forced > 0 ? std::min(forced, FF_CORNERCAP) : cornerCapFix;
-        static const int ldsPad = getenv("ORBHIP_FAST_LDS_PAD") ? atoi(getenv("ORBHIP_FAST_LDS_PAD")) : 0;   // occupancy experiments
+        static const int ldsPad = ORB_TUNE("FAST_LDS_PAD", 0);   // occupancy experiments (liborbhip_ablation.so)
         const size_t ldsScore = (size_t)scoreBytes + 16 + 256 + (size_t)ldsPad;   // + a row: nms_survives_fix reads one below the tile
+        const bool perXcd = fastXcd == 4 && B >= 8;   // (a frame or two: the runs over all XCDs)
+        if (perXcd) grid = dim3(8, ntiles, (B + 7) / 8);
 #define ORB_LAUNCH_FIX(P, D)                                                                                                 \
     hipLaunchKernelGGL((k_fast_fix<P, D>), grid, block, ldsScore, s, lvl0, stride0, (unsigned long long)frame0, pyr,         \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, G.totalCells, G.totalCands, G.iniTh, G.minTh, lc, \
-                       cc, phases, orb_xcd_arg(), ntiles)
+                       cc, perXcd ? (4 | (B << 8)) : orb_xcd_arg(), ntiles ORB_ABL_ARG(phases))
         if (deferEnv) {
             switch (fixedFix) {
             case 160: ORB_LAUNCH_FIX(160, true); break;
@@ -1219,7 +1317,7 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
 #define ORB_LAUNCH_FAST(P)                                                                                                   \
     hipLaunchKernelGGL(k_fast<P>, grid, block, lds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                    \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, pixBytes, scoreBytes, lBytes, cBytes, bitsBytes,  \
-                       listCap, cornerCap, phases, orb_xcd_arg(), ntiles)
+                       listCap, cornerCap, orb_xcd_arg(), ntiles ORB_ABL_ARG(phases))
     switch (fixed) {
     case 176: ORB_LAUNCH_FAST(176); break;
     case 192: ORB_LAUNCH_FAST(192); break;

@@ -1189,8 +1189,7 @@ static int init_keff()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("ORBHIP_INIT_K");   // tests force the rescan path with a small value
-        v = e ? atoi(e) : INIT_K;
+        v = ORB_TUNE("INIT_K", INIT_K);   // tests force the rescan path with a small value
         if (v < 1) v = 1;
         if (v > INIT_K) v = INIT_K;
     }
@@ -1234,8 +1233,7 @@ static int proj_keff()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("ORBHIP_PROJ_K");   // tests force the rescan path with a small value
-        v = e ? atoi(e) : PROJ_K;
+        v = ORB_TUNE("PROJ_K", PROJ_K);   // tests force the rescan path with a small value
         if (v < 1) v = 1;
         if (v > PROJ_K) v = PROJ_K;
     }
@@ -1276,7 +1274,7 @@ int launch_window_best(hipStream_t s, const orbhip_keypoint *kps, const uint8_t 
     for (int i = 0; i < 16; i++) gate.invSigma2[i] = (gate.on && i < nlevels) ? invLevelSigma2[i] : 0.f;
     float4 *rec = (float4 *)scratch;
     hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
-    static const bool seqOnly = getenv("ORBHIP_PROJ_SEQ") && atoi(getenv("ORBHIP_PROJ_SEQ")) != 0;
+    static const bool seqOnly = ORB_TUNE("PROJ_SEQ", 0) != 0;
     if (!seqOnly && cap < (1 << 20))   // a 16-lane row per point (written for one key frame per call; batches gain 3 % too)
         hipLaunchKernelGGL(k_window_best_row, dim3((capQ + 15) / 16, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gate, gp,
                            cellOff, rec, queries, qdesc, nq, capQ, bestIdx, bestDist);
@@ -1310,7 +1308,7 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
     int32_t *qfeat = tcount + (size_t)B * capQpad;
     const int keff = proj_keff();
     hipLaunchKernelGGL(k_proj_records, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cap, cellOff, cellIdx, rec);
-    static const bool seqOnly = getenv("ORBHIP_PROJ_SEQ") && atoi(getenv("ORBHIP_PROJ_SEQ")) != 0;
+    static const bool seqOnly = ORB_TUNE("PROJ_SEQ", 0) != 0;
     if (!seqOnly)   // a 16-lane row per point (written for the single-frame call; 512-frame batches gain 3-4 % from it too)
         hipLaunchKernelGGL(k_proj_cands_row, dim3((capQpad + 15) / 16, B, 1), dim3(256, 1, 1), 0, s, desc, cap, uRight, gp, cellOff, rec,
                            queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
@@ -1319,7 +1317,7 @@ int launch_search_by_projection(hipStream_t s, const orbhip_keypoint *kps, const
                            cellOff, rec, queries, qdesc, nq, capQ, capQpad, keff, tuples, tcount);
     // the parallel fixed-point kernel first; frames it cannot do (a point with more than 32
     // candidates, no fixed point yet) are left to the sequential one through fallback[] (ORBHIP_PROJ_SEQ=1: sequential only)
-    static const int maxRounds = getenv("ORBHIP_PROJ_ROUNDS") ? atoi(getenv("ORBHIP_PROJ_ROUNDS")) : PAR_ROUNDS;   // tests force the hand-over with 1
+    static const int maxRounds = ORB_TUNE("PROJ_ROUNDS", PAR_ROUNDS);   // tests force the hand-over with 1
     int32_t *fallback = nullptr;
     const size_t parLds = proj_assign_par_lds(cap, capQpad);
     if (!seqOnly && parLds <= 150 * 1024) {   // (batches: +2 % on the tracking front-end row of configs.md)

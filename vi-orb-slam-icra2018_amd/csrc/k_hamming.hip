@@ -265,7 +265,7 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
     }
     int qt, ns, rows;
     knn2_shape(nq, ndb, &qt, &ns, &rows);
-    static const int mfmaEnv = getenv("ORBHIP_KNN2_MFMA") ? atoi(getenv("ORBHIP_KNN2_MFMA")) : 1;
+    static const int mfmaEnv = ORB_SWITCH("KNN2_MFMA", 1);
     if (mfmaEnv)
         hipLaunchKernelGGL(k_knn2_mfma, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
     else
@@ -500,7 +500,7 @@ void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, 
                      int32_t *best_idx, int32_t *best_d, int32_t *second_d)
 {
     if (B <= 0) return;
-    static const int mfmaEnv = getenv("ORBHIP_KNN2_MFMA") ? atoi(getenv("ORBHIP_KNN2_MFMA")) : 1;
+    static const int mfmaEnv = ORB_SWITCH("KNN2_MFMA", 1);
     if (mfmaEnv)
         hipLaunchKernelGGL(k_knn2_seq_mfma, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag, best_idx,
                            best_d, second_d);

@@ -494,7 +494,7 @@ static void chain_need(const OrbLevels &G, const ChainLevels &CL, int base, int 
 bool chain_plan(const OrbLevels &G, const bool *levelOk, const ChainLevels &CL, std::vector<ChainTile> &tiles,
                 std::vector<ChainGroup> &groups)
 {
-    static const int depthEnv = getenv("ORBHIP_CHAIN_DEPTH") ? atoi(getenv("ORBHIP_CHAIN_DEPTH")) : 4;
+    static const int depthEnv = ORB_TUNE("CHAIN_DEPTH", 4);
     const int maxDepth = depthEnv < 1 ? 1 : depthEnv;
     const int ldsCap = 64 * 1024;
     tiles.clear();

@@ -237,7 +237,7 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     const int qtBytes = (int)((qt_shared_bytes(maxNodes) + 15) & ~(size_t)15);
     // more threads were measured not to shorten the level-0 workgroup (its passes are barrier / LDS-latency chains);
     // the switch accepts 64..256 (the kernel's launch bound)
-    static const int forced = getenv("ORBHIP_QT_THREADS") ? atoi(getenv("ORBHIP_QT_THREADS")) : 256;
+    static const int forced = ORB_TUNE("QT_THREADS", 256);
     const int nthreads = forced >= 64 && forced <= 256 && forced % 64 == 0 ? forced : 256;
     dim3 grid(B, G.nlevels, 1), block(nthreads, 1, 1);
     const size_t base = quadtree_lds_bytes(G);
@@ -250,12 +250,12 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     }
     if (B < 8) {
         // a frame or two: candidates and labels in LDS (8 bytes per candidate) for levels of up to 6144 candidates
-        static const int forcedPts = getenv("ORBHIP_QT_LDSPTS") ? atoi(getenv("ORBHIP_QT_LDSPTS")) : 6144;
+        static const int forcedPts = ORB_TUNE("QT_LDSPTS", 6144);
         int ldsPts = forcedPts;
         while (ldsPts > 0 && base + (size_t)ldsPts * 8 > 150 * 1024) ldsPts -= 256;
         if (ldsPts > 0) {
             // ... and 1024 threads: the steps are loops over a few thousand candidates between barriers
-            static const int smallThreads = getenv("ORBHIP_QT_THREADS_SMALL") ? atoi(getenv("ORBHIP_QT_THREADS_SMALL")) : 1024;
+            static const int smallThreads = ORB_TUNE("QT_THREADS_SMALL", 1024);
             block = dim3(smallThreads >= 64 && smallThreads <= 1024 && smallThreads % 64 == 0 ? smallThreads : 1024, 1, 1);
             hipLaunchKernelGGL((k_quadtree<true, false>), grid, block, base + (size_t)ldsPts * 8, s, G, cand, cellCnt, pts, pnode,
                                lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes, cellBytes, ldsPts, nullptr);

@@ -374,8 +374,7 @@ static int stereo_ent_per_kp()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("ORBHIP_STEREO_ENT_PER_KP");   // tests force the overflow path with 1
-        v = e ? atoi(e) : 8;
+        v = ORB_TUNE("STEREO_ENT_PER_KP", 8);   // tests force the overflow path with 1
         if (v < 1) v = 1;
     }
     return v;

@@ -16,10 +16,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 int fast_tile_cells()
 {
     static const int n = [] {
-        const char *e = getenv("ORBHIP_FAST_TILE_CELLS");
         // 4: the fixed-layout kernel finishes a run with one wave per cell (second pass, candidate order) -- four cells keep
         // its four waves equally busy to the end (5 cells: 1.08 ms per 1024 frames, 4: 1.04, 3: 1.18; r02's kernel preferred 5)
-        int v = e ? atoi(e) : 4;
+        int v = ORB_TUNE("FAST_TILE_CELLS", 4);
         return v < 1 ? 1 : (v > FAST_TILE_CELLS ? FAST_TILE_CELLS : v);
     }();
     return n;

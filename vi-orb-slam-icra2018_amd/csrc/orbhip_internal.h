@@ -10,6 +10,34 @@
 
 #include "../../include/orbhip.h"
 
+// ---- environment switches ----
+// The shipped liborbhip.so reads FOUR environment variables, each choosing between two equivalent paths that are both under
+// the parity tests (ORB_SWITCH): ORBHIP_KNN2_MFMA, ORBHIP_FAST_FIX, ORBHIP_NO_GRAPH, ORBHIP_NO_CHAIN.  Everything else -- tuning
+// knobs, the forced-overflow capacities with which the tests reach the fallback paths, occupancy dummies and the timing-ablation
+// stops that make a kernel return early with INVALID results -- is ORB_TUNE: its default, a compile-time constant, in the shipped
+// library, and an environment variable only in liborbhip_ablation.so (-DORBHIP_ABLATION; built for tests/ and tools/, never
+// loaded by the drop-in classes).  A stray variable in a SLAM process can therefore not change what the library computes.
+#include <stdlib.h>
+static inline int orb_env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#define ORB_SWITCH(name, dflt) orb_env_int("ORBHIP_" name, (dflt))
+#ifdef ORBHIP_ABLATION
+#define ORB_TUNE(name, dflt) orb_env_int("ORBHIP_" name, (dflt))
+#define ORB_ABL_PARAM , int phases
+#define ORB_ABL_ARG(p) , (p)
+#define ORB_ABL_STOP(cond) do { if (cond) return; } while (0)
+#define ORB_ABL_IF(cond) if (cond)
+#else
+#define ORB_TUNE(name, dflt) (dflt)
+#define ORB_ABL_PARAM
+#define ORB_ABL_ARG(p)
+#define ORB_ABL_STOP(cond) do { } while (0)
+#define ORB_ABL_IF(cond) if (false)
+#endif
+
 #define ORB_PATCH_SIZE 31      // ref: src/ORBextractor.cc:74
 #define ORB_HALF_PATCH 15      // :75
 #define ORB_EDGE_THRESHOLD 19  // :76
@@ -343,7 +371,7 @@ void launch_bow_match(hipStream_t s, const uint8_t *desc1, const uint8_t *valid1
 static inline int orb_xcd_map(int dflt = 0)
 {
     static int v = -2;
-    if (v == -2) v = getenv("ORBHIP_XCD_MAP") ? atoi(getenv("ORBHIP_XCD_MAP")) : -1;
+    if (v == -2) v = ORB_TUNE("XCD_MAP", -1);
     return v >= 0 ? v : dflt;   // per-kernel defaults: k_blur 2 (uniform tiles), k_describe / k_resize 1, k_fast 0
 }
 static inline int orb_xcd_chunk();
@@ -351,7 +379,7 @@ static inline int orb_xcd_arg(int dflt = 0);
 static inline int orb_xcd_chunk()
 {
     static int v = -1;
-    if (v < 0) v = getenv("ORBHIP_XCD_CHUNK") ? atoi(getenv("ORBHIP_XCD_CHUNK")) : 4;
+    if (v < 0) v = ORB_TUNE("XCD_CHUNK", 4);
     return v;
 }
 static inline int orb_xcd_grid(int ntiles, int dflt = 0)

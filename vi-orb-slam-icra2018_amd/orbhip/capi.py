@@ -10,7 +10,26 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC, "liborbhip.so")
+# liborbhip.so is the product: it reads four environment switches (equivalent, tested paths).  Every other ORBHIP_* knob
+# (tuning, forced-overflow capacities, timing-ablation stops; csrc/orbhip_internal.h, ORB_TUNE) exists only in
+# liborbhip_ablation.so, the same sources built with -DORBHIP_ABLATION.  This binding -- test and bench infrastructure, not
+# what the C++ drop-in classes link -- loads the ablation build when one of those knobs is set in the environment (or with
+# ORBHIP_ABLATION=1), so that tests/ and tools/ reach the fallback paths; otherwise the product library.
+TUNE_KNOBS = (
+    "BLUR_PLACE", "NO_SPLIT", "COPY_OUT", "BOW_THREADS", "BOW_GLOBAL_DESC", "BOW_PHASES", "CHAIN_DEPTH", "DESCRIBE_KPW",
+    "DESCRIBE_MAP", "DESCRIBE_PHASES", "DESCRIBE_PADLDS", "DESCRIBE_AX4", "PROJ_SEQ", "PROJ_ROUNDS", "PROJ_K", "INIT_K",
+    "QT_THREADS", "QT_LDSPTS", "QT_THREADS_SMALL", "SETS_COPY", "STEREO_ENT_PER_KP", "FAST_TILE_CELLS", "FAST_LISTCAP",
+    "FAST_PHASES", "FAST_PITCH", "FAST_DEFER", "FAST_LDS_PAD", "XCD_MAP", "XCD_CHUNK", "FAST_XCD", "FRAME_SPLIT",
+)
+
+
+def _wants_ablation():
+    if os.environ.get("ORBHIP_ABLATION", "0") not in ("", "0"):
+        return True
+    return any(("ORBHIP_" + k) in os.environ for k in TUNE_KNOBS)
+
+
+LIB_PATH = os.path.join(CSRC, "liborbhip_ablation.so" if _wants_ablation() else "liborbhip.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
