@@ -228,6 +228,10 @@ int orbhip_search_by_bow(orbhip_ctx *ctx, const uint8_t *desc1, int n1, const ui
  * orbhip_bcast_blob_device); it is copied back once for parsing. */
 int orbhip_vocab_load(orbhip_ctx *ctx, const void *blob, size_t nbytes);
 int orbhip_vocab_load_device(orbhip_ctx *ctx, const void *d_blob, size_t nbytes);
+/* The vocabulary tables of `src` serve `dst` too (contexts of one device; borrowed, not copied -- 58 MB for the stock tree;
+ * src must outlive dst's use of them).  What lets the extractor's context run the transform inside orbhip_frame_build on the
+ * vocabulary the ORBVocabulary drop-in loaded into its own context. */
+int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src);
 /* Replaces ORBVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1564-1647; chosen by
  * src/System.cc:335-336 for a ".txt" vocabulary such as the stock ORBvoc.txt): host-only conversion of the text (first
  * line "k L scoring weighting", then per node "parent is_leaf d0 .. d31 weight") to the binary layout above, which
@@ -461,6 +465,20 @@ int orbhip_set_put(orbhip_ctx *ctx, uint64_t key, const orbhip_keypoint *kps, co
                    const int32_t *off, const int32_t *idx, int ng, float min_x, float min_y, float inv_w, float inv_h);
 int orbhip_set_has(orbhip_ctx *ctx, uint64_t key, int n);
 int orbhip_set_drop(orbhip_ctx *ctx, uint64_t key);
+/* Is the set what the caller thinks it is?  Ids are not identities: Tracking::Reset restarts KeyFrame::nNextId and
+ * Frame::nNextId (ref: src/Tracking.cc:2758-2759), and a key frame met before KeyFrame::ComputeBoW (ref: src/KeyFrame.cc:392-400)
+ * has an empty FeatureVector.
+ *   orbhip_set_info         1 and the set's feature count, FeatureVector nodes and fingerprint when `key` is resident, else 0
+ *                           (any of the three pointers may be NULL).  The wrappers of the *_sets entry points size their
+ *                           buffers from it.
+ *   orbhip_set_fingerprint  the fingerprint orbhip_set_put / orbhip_set_put_from_frame store: a hash of n, the first
+ *                           keypoint's position and the first and last descriptor.  A caller compares the one of its own
+ *                           data with the resident one and puts the set again when they differ.
+ * The integration calls orbhip_set_drop(ctx, 0) from Tracking::Reset. */
+int orbhip_set_info(orbhip_ctx *ctx, uint64_t key, int *n, int *ng, uint64_t *fingerprint);
+uint64_t orbhip_set_fingerprint(const orbhip_keypoint *kps, const uint8_t *desc, int n);
+/* the same from the three things it hashes (descriptor rows that are not contiguous: a cv::Mat with a step) */
+uint64_t orbhip_set_fingerprint_rows(const orbhip_keypoint *first_kp, const uint8_t *first_desc, const uint8_t *last_desc, int n);
 /* orbhip_search_by_bow (above) between two resident sets: valid1[n1] (and valid2[n2] or NULL) are the only per-feature
  * inputs that travel.  Same results as orbhip_search_by_bow on the sets' data. */
 int orbhip_search_by_bow_sets(orbhip_ctx *ctx, uint64_t key1, const uint8_t *valid1, uint64_t key2, const uint8_t *valid2, int th,
@@ -468,6 +486,42 @@ int orbhip_search_by_bow_sets(orbhip_ctx *ctx, uint64_t key1, const uint8_t *val
 /* orbhip_window_best (above) into a resident set (with a grid): the projected points travel, the key frame does not. */
 int orbhip_window_best_set(orbhip_ctx *ctx, uint64_t key, const float *u_right, const float *inv_level_sigma2, int nlevels,
                            const orbhip_proj_query *queries, const uint8_t *qdesc, int nq, int32_t *best_idx, int32_t *best_dist);
+
+/* ---- the Frame constructor's device work as one launch (new) ----
+ * Frame::Frame (ref: src/Frame.cc:518-572) runs ExtractORB (:591-597), UndistortKeyPoints (:748-778) and AssignFeaturesToGrid
+ * (:574-589) one after the other, and Tracking asks for Frame::ComputeBoW (:739-746) before the frame's first SearchByBoW
+ * (ref: src/Tracking.cc, TrackReferenceKeyFrame).  As four entry points that is four launch + synchronise round trips for
+ * one dependency chain; orbhip_frame_build runs the chain as ONE captured graph with one synchronisation and one packed
+ * result block -- the kernels are those of orbhip_extract, orbhip_undistort_keypoints, orbhip_grid_build and
+ * orbhip_vocab_transform, the results are theirs.
+ *   fp->K, dist, ndist  mK / mDistCoef as for orbhip_undistort_keypoints (P = K); ndist == 0 or dist[0] == 0: kps_un = kps, the
+ *                       reference's shortcut (:750-754)
+ *   fp->min_x ... inv_h the grid of Frame::AssignFeaturesToGrid (mnMinX, mnMinY, mfGridElementWidthInv, ...HeightInv);
+ *                       inv_w <= 0: no grid (cell_off / cell_idx may be NULL) -- the first frame of a run, whose image
+ *                       bounds Frame::ComputeImageBounds derives after the extraction
+ *   fp->levelsup        >= 0: ORBVocabulary::transform of the descriptors with this levelsup (a vocabulary must be
+ *                       loaded); < 0: none (word_id / weight / node_id may be NULL)
+ * Outputs: kps, kps_un, desc (capacity `cap` features), n_out; cell_off[3073] / cell_idx[n] as orbhip_grid_build;
+ * word_id / weight / node_id [n] as orbhip_vocab_transform.  The result block stays on the device until the context's
+ * next orbhip_frame_build: orbhip_set_put_from_frame makes it a resident set of any context of the same device (the
+ * matcher's per-thread context in the drop-in classes) without the keypoints and descriptors travelling again;
+ * orbhip_frame_fingerprint is the orbhip_set_fingerprint of the frame it holds (0: none).  The graph is captured at the first
+ * call of an (image size, parameters) pair and replayed afterwards; ORBHIP_NO_GRAPH=1 keeps the eager sequence. */
+typedef struct orbhip_frame_params {
+    float K[9];
+    float dist[8];
+    int ndist;
+    float min_x, min_y, inv_w, inv_h;
+    int levelsup;
+} orbhip_frame_params;
+int orbhip_frame_build(orbhip_ctx *ctx, const uint8_t *img, int w, int h, int stride, const orbhip_frame_params *fp,
+                       orbhip_keypoint *kps, orbhip_keypoint *kps_un, uint8_t *desc, int cap, int *n_out, int32_t *cell_off,
+                       int32_t *cell_idx, int32_t *word_id, float *weight, int32_t *node_id);
+uint64_t orbhip_frame_fingerprint(const orbhip_ctx *ctx);
+/* orbhip_set_put with the frame that `src` built last: the FeatureVector (CSR as for orbhip_set_put; ng may be 0) is all
+ * that travels.  ctx and src must be contexts of the same device (they may be the same context). */
+int orbhip_set_put_from_frame(orbhip_ctx *ctx, uint64_t key, orbhip_ctx *src, const int32_t *node, const int32_t *off,
+                              const int32_t *idx, int ng);
 
 /* ---- multi-GPU (one process per GPU) ----
  * The reference is a single process (no distributed back end); these entry points are what a

@@ -51,6 +51,12 @@ public:
     void transform(const std::vector<cv::Mat> &features, DBoW2::BowVector &v, DBoW2::FeatureVector &fv,
                    int levelsup) const;
 
+    // the host half of transform (BowVector / FeatureVector from the per-feature word ids, weights and node ids of the
+    // descent): Frame::ComputeBoW uses it on the by-products of orbhip_frame_build (ORBextractor::BuiltBoW)
+    void assemble(const int *word, const float *weight, const int *node, int n, DBoW2::BowVector &v,
+                  DBoW2::FeatureVector &fv) const;
+    orbhip_ctx *Context() const { return mpCtx; }
+
     static void SetDevice(int device);
 
 private:

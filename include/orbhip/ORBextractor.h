@@ -16,6 +16,7 @@ struct orbhip_ctx;
 
 namespace ORB_SLAM2
 {
+class ORBVocabulary;
 
 class ORBextractor
 {
@@ -74,6 +75,28 @@ public:
     const char *LastError() const;
     orbhip_ctx *Context() { return mpCtx; }
 
+    // ---- the Frame constructor's device work in one launch (orbhip_frame_build, include/orbhip.h) ----
+    // Frame::Frame (ref: src/Frame.cc:518-572) calls operator(), UndistortKeyPoints, AssignFeaturesToGrid, and Tracking calls
+    // ComputeBoW before the frame's first SearchByBoW: one dependency chain.  After SetFrameBuild, operator() runs the whole
+    // chain as one graph launch and keeps the by-products; the Frame helpers of host/FrameGrid.cc (UndistortKeyPoints,
+    // AssignFeaturesToGrid, ComputeBoW) take them from here when they are asked about the frame this extractor built last, and
+    // fall back to their own device call otherwise -- the reference's call sequence stays as it is.
+    //   K, distCoef     Frame::mK / mDistCoef (CV_32F)
+    //   minX .. invH    Frame::mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv; invW <= 0: no grid (the first
+    //                   frame of a run, whose bounds ComputeImageBounds derives after the extraction)
+    //   voc, levelsup   the vocabulary ComputeBoW will use (NULL: no transform); levelsup 4 as in src/Frame.cc:744
+    void SetFrameBuild(const cv::Mat &K, const cv::Mat &distCoef, float minX, float minY, float invW, float invH,
+                       const ORBVocabulary *voc = 0, int levelsup = 4);
+    void ClearFrameBuild() { mbFrameBuild = false; mnBuiltN = -1; }
+    // Is (keys, descriptors) the frame the last operator() built?  (count, first and last keypoint, first descriptor)
+    bool BuiltFrame(const std::vector<cv::KeyPoint> &keys) const;
+    // by-products of that frame; false when there are none (frame build off, another frame, other parameters)
+    bool BuiltKeysUn(const std::vector<cv::KeyPoint> &keys, std::vector<cv::KeyPoint> &keysUn) const;
+    bool BuiltGrid(const std::vector<cv::KeyPoint> &keys, float minX, float minY, float invW, float invH, const int **cellOff,
+                   const int **cellIdx) const;
+    bool BuiltBoW(const std::vector<cv::KeyPoint> &keys, const ORBVocabulary *voc, int levelsup, const int **word, const float **weight,
+                  const int **node) const;
+
 protected:
     bool EnsureContext(int w, int h);
 
@@ -101,6 +124,18 @@ private:
     bool mbDownloadPyramid;
     bool mbBadParams;     // the constructor arguments are outside what liborbhip runs: operator() reports and returns nothing
     std::vector<cv::KeyPoint> mvKpStage;
+
+    // frame build (SetFrameBuild)
+    bool mbFrameBuild;
+    float mFbK[9], mFbDist[8], mFbGrid[4];
+    int mFbNDist, mFbLevelsup;
+    const ORBVocabulary *mpFbVoc;
+    bool mbFbVocShared;
+    int mnBuiltN;                               // features of the frame whose by-products are held; -1: none
+    bool mbBuiltGrid, mbBuiltBoW;
+    std::vector<cv::KeyPoint> mvBuiltKeysUn;
+    std::vector<int> mvBuiltCellOff, mvBuiltCellIdx, mvBuiltWord, mvBuiltNode;
+    std::vector<float> mvBuiltWeight;
 };
 
 } //namespace ORB_SLAM

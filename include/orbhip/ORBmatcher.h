@@ -52,6 +52,11 @@ public:
     // Computes the Hamming distance between two ORB descriptors (ref: src/ORBmatcher.cc:1675-1691)
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
 
+    // (addition) Empties the calling thread's table of device-resident key frames / frames (include/orbhip.h, orbhip_set_*).
+    // Stale sets are never used -- a set is checked against the object in hand -- so this only returns their memory early:
+    // call it from Tracking::Reset (ref: src/Tracking.cc:2724-2770), where the map and both id counters start over.
+    static void DropResidentSets();
+
     // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
     // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)
     // Used in Relocalisation and Loop Detection (ref: src/ORBmatcher.cc:159-288, 522-655)

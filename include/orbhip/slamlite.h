@@ -85,6 +85,7 @@ protected:
 };
 
 class ORBextractor;
+class ORBVocabulary;
 
 #define FRAME_GRID_ROWS 48                   // ref: include/Frame.h:41-42
 #define FRAME_GRID_COLS 64
@@ -92,8 +93,8 @@ class ORBextractor;
 class Frame
 {
 public:
-    Frame() : mnId(NextId()++), N(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0), mpORBextractorLeft(0),
-              mpORBextractorRight(0), mbf(0), mb(0) {}
+    Frame() : mnId(NextId()++), N(0), mpORBvocabulary(0), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0),
+              mpORBextractorLeft(0), mpORBextractorRight(0), mbf(0), mb(0) {}
     // ref: include/Frame.h "static long unsigned int nNextId; long unsigned int mnId;" (src/Frame.cc: mnId=nNextId++), the
     // key under which the drop-in matcher keeps a frame's descriptors resident on the device
     long unsigned int mnId;
@@ -103,6 +104,11 @@ public:
     cv::Mat mDescriptors;
     DBoW2::FeatureVector mFeatVec;
     std::vector<MapPoint *> mvpMapPoints;
+    // ref: include/Frame.h (mpORBvocabulary, mBowVec) and src/Frame.cc:739-746; body in host/FrameGrid.cc: the by-products of
+    // the extractor's frame build when it has them, ORBVocabulary::transform otherwise
+    ORBVocabulary *mpORBvocabulary;
+    DBoW2::BowVector mBowVec;
+    void ComputeBoW();
 
     // grid and guided-search members (ref: include/Frame.h:187-262) and the methods of src/Frame.cc:574-589,
     // :671-724; bodies in vi-orb-slam-icra2018_amd/host/FrameGrid.cc (device grid through liborbhip)

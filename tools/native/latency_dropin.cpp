@@ -43,6 +43,48 @@ int main(int argc, char **argv)
     for (int i = 0; i < iters; i++)
         if (orbhip_extract(c, pix.data(), w, h, w, kps.data(), desc.data(), cap, &n, t) != ORBHIP_OK) return 1;
     const double capi = ms_since(t0) / iters;
+    // (d) the Frame constructor's device work: four calls (extract, UndistortKeyPoints, AssignFeaturesToGrid, transform) against
+    //     ONE (orbhip_frame_build), EuRoC cam0 calibration, the vocabulary of argv[6]
+    double four = -1, one = -1, oneNoBow = -1;
+    if (argc > 6) {
+        std::vector<unsigned char> blob;
+        if (FILE *vf = fopen(argv[6], "rb")) {
+            fseek(vf, 0, SEEK_END);
+            blob.resize((size_t)ftell(vf));
+            fseek(vf, 0, SEEK_SET);
+            if (fread(blob.data(), 1, blob.size(), vf) != blob.size()) blob.clear();
+            fclose(vf);
+        }
+        if (!blob.empty() && orbhip_vocab_load(c, blob.data(), blob.size()) == ORBHIP_OK) {
+            orbhip_frame_params fp = {{458.654f, 0, 367.215f, 0, 457.296f, 248.375f, 0, 0, 1}, {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f},
+                                      4, 0.f, 0.f, 64.f / w, 48.f / h, 4};
+            std::vector<orbhip_keypoint> kun(cap);
+            std::vector<int32_t> off(ORBHIP_GRID_CELLS + 1), idx(cap), word(cap), node(cap);
+            std::vector<float> wt(cap);
+            auto sep = [&]() {
+                return orbhip_extract(c, pix.data(), w, h, w, kps.data(), desc.data(), cap, &n, nullptr) ||
+                       orbhip_undistort_keypoints(c, kps.data(), n, fp.K, fp.dist, fp.ndist, fp.K, kun.data()) ||
+                       orbhip_grid_build(c, kun.data(), n, fp.min_x, fp.min_y, fp.inv_w, fp.inv_h, off.data(), idx.data()) ||
+                       orbhip_vocab_transform(c, desc.data(), n, 4, word.data(), wt.data(), node.data());
+            };
+            auto fb = [&]() {
+                return orbhip_frame_build(c, pix.data(), w, h, w, &fp, kps.data(), kun.data(), desc.data(), cap, &n, off.data(), idx.data(),
+                                          word.data(), wt.data(), node.data());
+            };
+            for (int i = 0; i < 20; i++) if (sep() || fb()) { fprintf(stderr, "frame build: %s\n", orbhip_last_error(c)); return 1; }
+            t0 = Clock::now();
+            for (int i = 0; i < iters; i++) sep();
+            four = ms_since(t0) / iters;
+            t0 = Clock::now();
+            for (int i = 0; i < iters; i++) fb();
+            one = ms_since(t0) / iters;
+            fp.levelsup = -1;
+            for (int i = 0; i < 20; i++) fb();
+            t0 = Clock::now();
+            for (int i = 0; i < iters; i++) fb();
+            oneNoBow = ms_since(t0) / iters;
+        }
+    }
     orbhip_destroy(c);
 
     // (b) the drop-in class
@@ -63,6 +105,8 @@ int main(int argc, char **argv)
     printf("{\"w\": %d, \"h\": %d, \"nfeatures\": %d, \"keypoints\": %d, \"iterations\": %d, \"orbhip_extract_ms\": %.4f, "
            "\"dropin_operator_ms\": %.4f, \"dropin_operator_with_pyramid_ms\": %.4f",
            w, h, nf, nk, iters, capi, cls[0], cls[1]);
+    if (one >= 0)
+        printf(", \"frame_four_calls_ms\": %.4f, \"orbhip_frame_build_ms\": %.4f, \"orbhip_frame_build_no_transform_ms\": %.4f", four, one, oneNoBow);
     if (argc > 6 && two) {
         ORBVocabulary voc;
         if (!voc.loadFromBinaryFile(argv[6])) { fprintf(stderr, "cannot load %s\n", argv[6]); return 1; }

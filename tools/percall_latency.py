@@ -111,6 +111,34 @@ rows.append(("`Frame::UndistortKeyPoints` 1000 keypoints (EuRoC cam0 coefficient
 rows.append(("`Frame::AssignFeaturesToGrid` 1000 keypoints", bench(lambda: guided.AssignFeaturesToGrid(ex, k1, gp), 300),
              bench(lambda: O.grid_build(k1, gp), 50)))
 
+# the Frame constructor's device work in ONE launch (orbhip_frame_build): extraction + UndistortKeyPoints + AssignFeaturesToGrid +
+# the vocabulary transform; beside it the SUM of the four oracle calls, and the sum of the four separate device calls above
+def four_oracle_calls():
+    k, d = ref(fr[0])
+    xy = O.undistort_points(np.stack([k["x"], k["y"]], 1), Kc, Dc, Kc)
+    ku = k.copy()
+    ku["x"], ku["y"] = xy[:, 0], xy[:, 1]
+    O.grid_build(ku, gp)
+    ovoc.transform(d, 4)
+byname = {r[0]: r for r in rows}
+four = sum(byname[n][1] for n in ("`ORBextractor::operator()` 640x480, 1000 features",
+                                   "`ORBVocabulary::transform` descent, 1000 descriptors (k 10, L 6, levelsup 4)",
+                                   "`Frame::UndistortKeyPoints` 1000 keypoints (EuRoC cam0 coefficients)",
+                                   "`Frame::AssignFeaturesToGrid` 1000 keypoints"))
+rows.append(("`Frame::Frame` device work in one launch (`orbhip_frame_build`: extract + undistort + grid + transform; the four separate calls above: %.3f)" % four,
+             bench(lambda: ex.frame_build(fr[0], Kc, Dc, gp, 4), 500), bench(four_oracle_calls, 10)))
+rows.append(("`orbhip_frame_build` without the transform (extract + undistort + grid)",
+             bench(lambda: ex.frame_build(fr[0], Kc, Dc, gp, -1), 500), float("nan")))
+# SearchByBoW(KF, F) as the drop-in issues it since r04: the frame enters the matcher context's set table from the device
+# block of its frame_build (orbhip_set_put_from_frame, once per frame) -- registration + search, per frame
+r = ex.frame_build(fr[1], Kc, Dc, gp, 4)
+fvF = O.feature_vector(r["node_id"], r["weight"])
+def register_and_search():
+    M.put_set_from_frame(2, ex, fvF)
+    M.SearchByBoW_sets(1, v0, len(k0), 2, None, len(r["kps"]))
+rows.append(("`SearchByBoW(KF, F)` with the frame registered from its `orbhip_frame_build` block (registration + search)",
+             bench(register_and_search, 300), byname["`SearchByBoW(KF, F)` 1000 x 1000 features"][2]))
+
 print("| call (one per frame / key-frame pair) | liborbhip per call (ms) | oracle, one host core (ms) |")
 print("|---|---|---|")
 for name, g, c in rows:

@@ -44,6 +44,10 @@ int orb_configure(orbhip_ctx *c, int w, int h, int stride0, int B);
 int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t frame0, int B, orbhip_keypoint *d_kps,
                      uint8_t *d_desc, int32_t *d_counts, int cap, uint8_t *h_pyr_dst = nullptr);
 void orb_graph_release(orbhip_ctx *c);
+int orb_host_stage(orbhip_ctx *c, size_t bytes);                  // page-locked result block c->h_stage of at least `bytes`
+int orb_host_pyr_stage(orbhip_ctx *c, int B, uint8_t **dst);      // page-locked pyramid copy (or nullptr when not asked for)
+// api_frame.hip
+void orb_frame_release(orbhip_ctx *c);
 // api_pipe.hip / api_comm.hip: what orbhip_destroy releases
 void orb_pipe_release(orbhip_ctx *c);
 void orb_comm_release(orbhip_ctx *c);

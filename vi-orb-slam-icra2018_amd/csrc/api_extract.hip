@@ -195,6 +195,7 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     orb_pipe_release(c);
     orb_sets_release(c);
     orb_graph_release(c);
+    orb_frame_release(c);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
@@ -334,7 +335,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         launch_describe(st, G, lvl0 + (size_t)b0 * frame0, stride0, frame0, c->d_pyr + (size_t)b0 * c->pyrFrameBytes, c->pyrFrameBytes,
                         c->d_blur + (size_t)b0 * blurFrame, blurFrame, c->d_lvlKp + (size_t)b0 * G.totalKps,
                         c->d_lvlKpCnt + (size_t)b0 * ORBHIP_MAX_LEVELS, c->d_lvlAngle + (size_t)b0 * G.totalKps, d_kps + (size_t)b0 * cap,
-                        d_desc + (size_t)b0 * cap * 32, d_counts + b0, cap, nb);
+                        d_desc + (size_t)b0 * cap * 32, d_counts + b0, cap, nb, B < 8 ? c->describeMirror : 0);
     };
     if (B >= 8 && blurPlace == 1) {
         HIPCHK(c, hipEventRecord(c->evx[0], s));
@@ -471,7 +472,7 @@ extern "C" int orbhip_extract_batch_device(orbhip_ctx *c, const void *d_imgs, in
                         (int32_t *)d_counts, cap);
 }
 
-static int host_stage(orbhip_ctx *c, size_t bytes)
+int orb_host_stage(orbhip_ctx *c, size_t bytes)
 {
     if (bytes <= c->h_stage_bytes) return ORBHIP_OK;
     if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
@@ -485,7 +486,7 @@ static int host_stage(orbhip_ctx *c, size_t bytes)
 }
 
 // pinned block for the host copy of the pyramid (levels 1..) of B frames; nullptr when the copy is not asked for
-static int host_pyr_stage(orbhip_ctx *c, int B, uint8_t **dst)
+int orb_host_pyr_stage(orbhip_ctx *c, int B, uint8_t **dst)
 {
     *dst = nullptr;
     c->h_pyr_B = 0;
@@ -532,9 +533,9 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
         c->h_in_bytes = inBytes;
     }
     int rc;
-    if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
+    if ((rc = orb_host_stage(c, coff + align_up(cbytes, 256)))) return rc;
     uint8_t *hpyr = nullptr;
-    if ((rc = host_pyr_stage(c, B, &hpyr))) return rc;
+    if ((rc = orb_host_pyr_stage(c, B, &hpyr))) return rc;
     c->h_in_valid = false;
     for (int b = 0; b < B; b++) {
         if (!imgs[b]) return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: null image");
@@ -622,12 +623,12 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
                                        hipMemcpyHostToDevice, c->stream));
         }
         uint8_t *hpyr = nullptr;
-        if ((rc = host_pyr_stage(c, B, &hpyr))) return rc;
+        if ((rc = orb_host_pyr_stage(c, B, &hpyr))) return rc;
         c->h_in_valid = false;
         if ((rc = orb_run_pipeline(c, c->d_lvl0, s0, c->lvl0FrameBytes, B, (orbhip_keypoint *)(blk + koff), blk + doff,
                                (int32_t *)(blk + coff), dcap, hpyr)))
             return rc;
-        if ((rc = host_stage(c, coff + align_up(cbytes, 256)))) return rc;
+        if ((rc = orb_host_stage(c, coff + align_up(cbytes, 256)))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->h_stage, blk, coff + cbytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->h_pyr_B = hpyr ? B : 0;

@@ -294,6 +294,22 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
     return ORBHIP_OK;
 }
 
+// The tables of `src` serve `dst` as well (same device): what lets an extractor's context run the transform inside
+// orbhip_frame_build on the vocabulary that ORBVocabulary loaded into its own context.  Borrowed, not copied: 58 MB for the
+// stock tree.  `src` must outlive every use by `dst`; a vocabulary loaded into dst later replaces the borrowed one.
+extern "C" int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src)
+{
+    if (!dst || !src || !src->voc.desc) return fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: no vocabulary in the source context");
+    if (dst->device != src->device) return fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: the two contexts are on different devices");
+    if (dst == src) return ORBHIP_OK;
+    HIPCHK(dst, hipSetDevice(dst->device));
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    if (dst->d_vocBlock) HIPCHK(dst, hipFree(dst->d_vocBlock));
+    dst->d_vocBlock = nullptr;          // nothing of its own to free
+    dst->voc = src->voc;
+    return ORBHIP_OK;
+}
+
 extern "C" int orbhip_vocab_load_device(orbhip_ctx *c, const void *d_blob, size_t nbytes)
 {
     if (!c || !d_blob || nbytes < 24) return fail(c, ORBHIP_E_ARG, "orbhip_vocab_load_device: bad argument");

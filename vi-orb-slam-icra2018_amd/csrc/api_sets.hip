@@ -9,13 +9,22 @@
 
 #define ORB_MAX_SETS 96
 
+// A set's device block: keypoints | descriptors | count | grid offsets | grid entries | CSR offsets | CSR indices.  The first
+// five parts are laid out like the result block of orbhip_frame_build (api_frame.hip), so that a frame becomes a set with
+// one device-to-device copy.  Blocks and their page-locked CSR staging are pooled: a frame per camera image enters and
+// leaves the table, and a hipMalloc / hipHostMalloc pair per frame would cost more than the search it serves.
+struct OrbSetMem {
+    uint8_t *block = nullptr;          // device
+    uint8_t *h_csr = nullptr;          // page-locked: CSR offsets | CSR indices on their way to the device
+    int capN = 0;
+    size_t bytes = 0, oK = 0, oD = 0, oC = 0, oG = 0, oE = 0, oO = 0, oI = 0, csrBytes = 0;
+};
 struct OrbSet {
-    uint64_t key = 0;
+    uint64_t key = 0, fingerprint = 0;
     int n = 0, ng = 0;
     bool grid = false;
     float minX = 0, minY = 0, invW = 0, invH = 0;
-    uint8_t *block = nullptr;          // one device allocation
-    size_t bytes = 0;
+    OrbSetMem mem;
     orbhip_keypoint *d_kps = nullptr;
     uint8_t *d_desc = nullptr;
     int32_t *d_off = nullptr, *d_idx = nullptr, *d_cellOff = nullptr, *d_cellIdx = nullptr, *d_cnt = nullptr;
@@ -27,6 +36,7 @@ struct OrbSet {
 
 struct OrbSetTable {
     std::vector<OrbSet *> sets;
+    std::vector<OrbSetMem> pool;       // blocks of evicted / replaced sets
     unsigned long clock = 0;
 };
 
@@ -36,9 +46,38 @@ static OrbSetTable *table(orbhip_ctx *c)
     return static_cast<OrbSetTable *>(c->setTable);
 }
 
-static void set_free(OrbSet *s)
+static void mem_free(OrbSetMem &m)
 {
-    if (s->block) (void)hipFree(s->block);
+    if (m.block) (void)hipFree(m.block);
+    if (m.h_csr) (void)hipHostFree(m.h_csr);
+    m = OrbSetMem();
+}
+
+static void mem_layout(OrbSetMem &m, int capN)
+{
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
+    m.capN = capN;
+    m.oK = carve((size_t)capN * sizeof(orbhip_keypoint));
+    m.oD = carve((size_t)capN * 32 + 32);
+    m.oC = carve(16);
+    m.oG = carve((ORBHIP_GRID_CELLS + 1) * 4);
+    m.oE = carve((size_t)capN * 4);
+    m.oO = carve((size_t)(capN + 1) * 4);
+    m.oI = carve((size_t)capN * 4 + 4);
+    m.bytes = o;
+    m.csrBytes = m.bytes - m.oO;
+}
+
+// a set leaves the table: its memory goes to the pool (the caller has made sure no queued kernel reads it)
+static void set_retire(OrbSetTable *T, OrbSet *s)
+{
+    if (s->mem.block) {
+        if (T->pool.size() < 8)
+            T->pool.push_back(s->mem);
+        else
+            mem_free(s->mem);
+    }
     delete s;
 }
 
@@ -46,7 +85,11 @@ void orb_sets_release(orbhip_ctx *c)
 {
     if (!c->setTable) return;
     OrbSetTable *T = static_cast<OrbSetTable *>(c->setTable);
-    for (OrbSet *s : T->sets) set_free(s);
+    for (OrbSet *s : T->sets) {
+        mem_free(s->mem);
+        delete s;
+    }
+    for (OrbSetMem &m : T->pool) mem_free(m);
     delete T;
     c->setTable = nullptr;
 }
@@ -70,6 +113,17 @@ extern "C" int orbhip_set_has(orbhip_ctx *c, uint64_t key, int n)
     return s && s->n == n ? 1 : 0;
 }
 
+extern "C" int orbhip_set_info(orbhip_ctx *c, uint64_t key, int *n, int *ng, uint64_t *fingerprint)
+{
+    if (!c) return 0;
+    OrbSet *s = find_set(c, key);
+    if (!s) return 0;
+    if (n) *n = s->n;
+    if (ng) *ng = s->ng;
+    if (fingerprint) *fingerprint = s->fingerprint;
+    return 1;
+}
+
 extern "C" int orbhip_set_drop(orbhip_ctx *c, uint64_t key)
 {
     if (!c) return ORBHIP_E_ARG;
@@ -79,31 +133,29 @@ extern "C" int orbhip_set_drop(orbhip_ctx *c, uint64_t key)
     OrbSetTable *T = static_cast<OrbSetTable *>(c->setTable);
     for (size_t i = 0; i < T->sets.size();)
         if (key == 0 || T->sets[i]->key == key) {
-            set_free(T->sets[i]);
+            set_retire(T, T->sets[i]);
             T->sets.erase(T->sets.begin() + i);
         } else
             i++;
     return ORBHIP_OK;
 }
 
-extern "C" int orbhip_set_put(orbhip_ctx *c, uint64_t key, const orbhip_keypoint *kps, const uint8_t *desc, int n,
-                              const int32_t *node, const int32_t *off, const int32_t *idx, int ng, float min_x, float min_y,
-                              float inv_w, float inv_h)
+// Makes room for `key` with `n` features: a set of the same key and the least recently used one of a full table are retired
+// (after the stream has drained: a queued kernel may still read them), memory comes from the pool when a block there is
+// large enough.  Returns the new, empty set or nullptr (c->err set).
+static OrbSet *set_acquire(orbhip_ctx *c, uint64_t key, int n, int capWant = 0)
 {
-    if (!c || key == 0 || n <= 0 || !kps || !desc || ng < 0 || (ng > 0 && (!node || !off || !idx)))
-        return fail(c, ORBHIP_E_ARG, "orbhip_set_put: bad argument");
-    const int m = ng > 0 ? off[ng] : 0;
-    for (int g = 0; g < ng; g++)
-        if (off[g] > off[g + 1] || off[g] < 0 || (g > 0 && node[g] <= node[g - 1]))
-            return fail(c, ORBHIP_E_ARG, "orbhip_set_put: the FeatureVector must be a CSR over ascending node ids");
-    for (int t = 0; t < m; t++)
-        if (idx[t] < 0 || idx[t] >= n) return fail(c, ORBHIP_E_ARG, "orbhip_set_put: feature index out of range");
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));     // a set that is replaced or evicted may still be read by a queued kernel
     OrbSetTable *T = table(c);
+    bool drained = false;
+    auto drain = [&]() {
+        if (!drained && hipStreamSynchronize(c->stream) != hipSuccess) return false;
+        drained = true;
+        return true;
+    };
     for (size_t i = 0; i < T->sets.size(); i++)
         if (T->sets[i]->key == key) {
-            set_free(T->sets[i]);
+            if (!drain()) return fail(c, ORBHIP_E_HIP, "orbhip_set_put: stream synchronisation failed"), nullptr;
+            set_retire(T, T->sets[i]);
             T->sets.erase(T->sets.begin() + i);
             break;
         }
@@ -111,69 +163,181 @@ extern "C" int orbhip_set_put(orbhip_ctx *c, uint64_t key, const orbhip_keypoint
         size_t lru = 0;
         for (size_t i = 1; i < T->sets.size(); i++)
             if (T->sets[i]->stamp < T->sets[lru]->stamp) lru = i;
-        set_free(T->sets[lru]);
+        if (!drain()) return fail(c, ORBHIP_E_HIP, "orbhip_set_put: stream synchronisation failed"), nullptr;
+        set_retire(T, T->sets[lru]);
         T->sets.erase(T->sets.begin() + lru);
     }
     OrbSet *s = new OrbSet();
+    // (capWant: a block of exactly that capacity -- the layout of a frame's result block, one copy fills it)
+    int best = -1;
+    for (size_t i = 0; i < T->pool.size(); i++)
+        if (capWant > 0 ? T->pool[i].capN == capWant
+                        : (T->pool[i].capN >= n && (best < 0 || T->pool[i].capN < T->pool[best].capN)))
+            best = (int)i;
+    if (best >= 0) {
+        s->mem = T->pool[best];
+        T->pool.erase(T->pool.begin() + best);
+    } else {
+        // capacity in steps of 256 features, so that the frames of a sequence (whose counts differ by a few) share blocks
+        mem_layout(s->mem, capWant > 0 ? capWant : (int)align_up((size_t)n + 8, 256));
+        void *p = nullptr;
+        if (hipMalloc(&p, s->mem.bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            delete s;
+            return fail(c, ORBHIP_E_HIP, "orbhip_set_put: out of device memory"), nullptr;
+        }
+        s->mem.block = (uint8_t *)p;
+        if (hipHostMalloc(&p, s->mem.csrBytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            mem_free(s->mem);
+            delete s;
+            return fail(c, ORBHIP_E_HIP, "orbhip_set_put: out of page-locked memory"), nullptr;
+        }
+        s->mem.h_csr = (uint8_t *)p;
+    }
+    const OrbSetMem &m = s->mem;
     s->key = key;
     s->n = n;
+    s->d_kps = (orbhip_keypoint *)(m.block + m.oK);
+    s->d_desc = m.block + m.oD;
+    s->d_cnt = (int32_t *)(m.block + m.oC);
+    s->d_cellOff = (int32_t *)(m.block + m.oG);
+    s->d_cellIdx = (int32_t *)(m.block + m.oE);
+    s->d_off = (int32_t *)(m.block + m.oO);
+    s->d_idx = (int32_t *)(m.block + m.oI);
+    return s;
+}
+
+static int csr_check(orbhip_ctx *c, const char *who, const int32_t *node, const int32_t *off, const int32_t *idx, int ng, int n)
+{
+    const int m = ng > 0 ? off[ng] : 0;
+    if (ng > 0 && (off[0] != 0 || m > n)) return fail(c, ORBHIP_E_ARG, std::string(who) + ": the FeatureVector holds more entries than the set has features");
+    for (int g = 0; g < ng; g++)
+        if (off[g] > off[g + 1] || off[g] < 0 || (g > 0 && node[g] <= node[g - 1]))
+            return fail(c, ORBHIP_E_ARG, std::string(who) + ": the FeatureVector must be a CSR over ascending node ids");
+    for (int t = 0; t < m; t++)
+        if (idx[t] < 0 || idx[t] >= n) return fail(c, ORBHIP_E_ARG, std::string(who) + ": feature index out of range");
+    return ORBHIP_OK;
+}
+
+// the FeatureVector of a new set: host copies for the merge walk, device copy through the set's own page-locked staging
+// (asynchronous: every later use of the set is behind it on the context's stream)
+static hipError_t csr_upload(orbhip_ctx *c, OrbSet *s, const int32_t *node, const int32_t *off, const int32_t *idx, int ng)
+{
+    const OrbSetMem &m = s->mem;
+    const int cnt = ng > 0 ? off[ng] : 0;
     s->ng = ng;
+    if (ng > 0) {
+        s->node.assign(node, node + ng);
+        s->off.assign(off, off + ng + 1);
+        s->idx.assign(idx, idx + cnt);
+        memcpy(m.h_csr, off, (size_t)(ng + 1) * 4);
+        memcpy(m.h_csr + (m.oI - m.oO), idx, (size_t)cnt * 4);
+    } else {
+        memset(m.h_csr, 0, 4);
+    }
+    return hipMemcpyAsync(m.block + m.oO, m.h_csr, (m.oI - m.oO) + (size_t)cnt * 4 + 4, hipMemcpyHostToDevice, c->stream);
+}
+
+extern "C" int orbhip_set_put(orbhip_ctx *c, uint64_t key, const orbhip_keypoint *kps, const uint8_t *desc, int n,
+                              const int32_t *node, const int32_t *off, const int32_t *idx, int ng, float min_x, float min_y,
+                              float inv_w, float inv_h)
+{
+    if (!c || key == 0 || n <= 0 || !kps || !desc || ng < 0 || ng > n || (ng > 0 && (!node || !off || !idx)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_set_put: bad argument");
+    int rc;
+    if ((rc = csr_check(c, "orbhip_set_put", node, off, idx, ng, n))) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    OrbSet *s = set_acquire(c, key, n);
+    if (!s) return ORBHIP_E_HIP;
+    OrbSetTable *T = table(c);
+    s->fingerprint = orbhip_set_fingerprint(kps, desc, n);
     s->grid = inv_w > 0.f && inv_h > 0.f;
     s->minX = min_x; s->minY = min_y; s->invW = inv_w; s->invH = inv_h;
-    // device block: keypoints | descriptors | count | CSR offsets | CSR indices | grid offsets | grid entries
-    size_t o = 0;
-    auto carve = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
-    const size_t oK = carve((size_t)n * sizeof(orbhip_keypoint)), oD = carve((size_t)n * 32 + 32), oC = carve(16),
-                 oO = carve((size_t)(ng + 1) * 4), oI = carve((size_t)m * 4 + 4), oG = carve((ORBHIP_GRID_CELLS + 1) * 4),
-                 oE = carve((size_t)n * 4);
-    void *p = nullptr;
-    if (hipMalloc(&p, o) != hipSuccess) {
-        delete s;
-        return fail(c, ORBHIP_E_HIP, "orbhip_set_put: out of device memory");
-    }
-    s->block = (uint8_t *)p;
-    s->bytes = o;
-    s->d_kps = (orbhip_keypoint *)(s->block + oK);
-    s->d_desc = s->block + oD;
-    s->d_cnt = (int32_t *)(s->block + oC);
-    s->d_off = (int32_t *)(s->block + oO);
-    s->d_idx = (int32_t *)(s->block + oI);
-    s->d_cellOff = (int32_t *)(s->block + oG);
-    s->d_cellIdx = (int32_t *)(s->block + oE);
-    // one packed upload
+    const OrbSetMem &m = s->mem;
+    // keypoints | descriptors | count: one packed upload
     Packed P(c);
-    int rc;
-    if ((rc = P.begin(o + 4096))) {
-        set_free(s);
+    if ((rc = P.begin(m.oG + 4096))) {
+        set_retire(T, s);
         return rc;
     }
-    memcpy(P.h + oK, kps, (size_t)n * sizeof(orbhip_keypoint));
-    memcpy(P.h + oD, desc, (size_t)n * 32);
+    memcpy(P.h + m.oK, kps, (size_t)n * sizeof(orbhip_keypoint));
+    memcpy(P.h + m.oD, desc, (size_t)n * 32);
     const int32_t cnt[4] = {n, 0, 0, 0};
-    memcpy(P.h + oC, cnt, 16);
-    if (ng > 0) {
-        memcpy(P.h + oO, off, (size_t)(ng + 1) * 4);
-        memcpy(P.h + oI, idx, (size_t)m * 4);
-    } else {
-        memset(P.h + oO, 0, 4);
-    }
-    hipError_t e = hipMemcpyAsync(s->block, P.h, oG, hipMemcpyHostToDevice, c->stream);
+    memcpy(P.h + m.oC, cnt, 16);
+    hipError_t e = hipMemcpyAsync(m.block, P.h, m.oC + 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = csr_upload(c, s, node, off, idx, ng);
     if (e == hipSuccess && s->grid) {
-        launch_grid_build(c->stream, s->d_kps, s->d_cnt, n, 1, min_x, min_y, inv_w, inv_h, s->d_cellOff, s->d_cellIdx);
+        launch_grid_build(c->stream, s->d_kps, s->d_cnt, m.capN, 1, min_x, min_y, inv_w, inv_h, s->d_cellOff, s->d_cellIdx);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // (P's page-locked block is reused by the next call)
     if (e != hipSuccess) {
-        set_free(s);
+        (void)hipStreamSynchronize(c->stream);
+        set_retire(T, s);
         return fail(c, ORBHIP_E_HIP, std::string("orbhip_set_put: ") + hipGetErrorString(e));
     }
     s->angle.resize(n);
     for (int i = 0; i < n; i++) s->angle[i] = kps[i].angle;
-    if (ng > 0) {
-        s->node.assign(node, node + ng);
-        s->off.assign(off, off + ng + 1);
-        s->idx.assign(idx, idx + m);
+    s->stamp = ++T->clock;
+    T->sets.push_back(s);
+    return ORBHIP_OK;
+}
+
+// api_frame.hip
+int orb_frame_block(orbhip_ctx *src, const uint8_t **d_blk, size_t *setBytes, size_t off[5], int *n, int *dcap, bool *grid,
+                    float gp[4], const orbhip_keypoint **h_kps_un, const uint8_t **h_desc);
+int orb_frame_mark_busy(orbhip_ctx *src, hipStream_t copier);
+
+// The frame that `src` built last (orbhip_frame_build) becomes the resident set `key` of `c`: undistorted keypoints,
+// descriptors, count and grid go from device block to device block; only the FeatureVector (built on the host from the
+// transform's node ids: DBoW2::FeatureVector is an ordered map) travels.  No synchronisation: every later use of the set is
+// behind the copies on c's stream, and src's next orbhip_frame_build waits for them.
+extern "C" int orbhip_set_put_from_frame(orbhip_ctx *c, uint64_t key, orbhip_ctx *src, const int32_t *node, const int32_t *off,
+                                         const int32_t *idx, int ng)
+{
+    if (!c || !src || key == 0 || ng < 0 || (ng > 0 && (!node || !off || !idx)))
+        return fail(c, ORBHIP_E_ARG, "orbhip_set_put_from_frame: bad argument");
+    if (c->device != src->device) return fail(c, ORBHIP_E_ARG, "orbhip_set_put_from_frame: the two contexts are on different devices");
+    const uint8_t *blk = nullptr, *hdesc = nullptr;
+    const orbhip_keypoint *hkps = nullptr;
+    size_t setBytes = 0, so[5];
+    int n = 0, dcap = 0;
+    bool grid = false;
+    float gp[4];
+    if (orb_frame_block(src, &blk, &setBytes, so, &n, &dcap, &grid, gp, &hkps, &hdesc) != ORBHIP_OK)
+        return fail(c, ORBHIP_E_ARG, "orbhip_set_put_from_frame: the source context holds no frame (orbhip_frame_build)");
+    if (ng > n) return fail(c, ORBHIP_E_ARG, "orbhip_set_put_from_frame: bad argument");
+    int rc;
+    if ((rc = csr_check(c, "orbhip_set_put_from_frame", node, off, idx, ng, n))) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    OrbSet *s = set_acquire(c, key, n, dcap);
+    if (!s) return ORBHIP_E_HIP;
+    OrbSetTable *T = table(c);
+    const OrbSetMem &m = s->mem;
+    s->fingerprint = orbhip_set_fingerprint(hkps, hdesc, n);
+    s->grid = grid;
+    s->minX = gp[0]; s->minY = gp[1]; s->invW = gp[2]; s->invH = gp[3];
+    // the two blocks carve the same parts in the same order, each for its own capacity: part by part
+    const size_t part[5] = {(size_t)n * sizeof(orbhip_keypoint), (size_t)n * 32, 16, grid ? (size_t)(ORBHIP_GRID_CELLS + 1) * 4 : 0,
+                            grid ? (size_t)n * 4 : 0};
+    const size_t to[5] = {m.oK, m.oD, m.oC, m.oG, m.oE};
+    hipError_t e = hipSuccess;
+    if (m.capN == dcap) {
+        e = hipMemcpyAsync(m.block, blk, grid ? so[4] + part[4] : so[2] + 16, hipMemcpyDeviceToDevice, c->stream);   // identical layouts: one copy
+    } else {
+        for (int k = 0; k < 5 && e == hipSuccess; k++)
+            if (part[k]) e = hipMemcpyAsync(m.block + to[k], blk + so[k], part[k], hipMemcpyDeviceToDevice, c->stream);
     }
+    if (e == hipSuccess) e = csr_upload(c, s, node, off, idx, ng);
+    if (e == hipSuccess && orb_frame_mark_busy(src, c->stream) != ORBHIP_OK) e = hipErrorUnknown;
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        set_retire(T, s);
+        return fail(c, ORBHIP_E_HIP, std::string("orbhip_set_put_from_frame: ") + hipGetErrorString(e));
+    }
+    s->angle.resize(n);
+    for (int i = 0; i < n; i++) s->angle[i] = hkps[i].angle;
     s->stamp = ++T->clock;
     T->sets.push_back(s);
     return ORBHIP_OK;

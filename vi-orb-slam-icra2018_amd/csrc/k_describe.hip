@@ -122,7 +122,10 @@ struct __attribute__((packed, aligned(1))) UnalignedU4 {
     uint4 v;
 };
 
-template <int DS_KP, bool AX4>
+// MIRROR: every result (count, keypoint records, descriptors) is stored a second time `mirror` bytes further on -- the page-locked
+// twin of the device block the results go to (orbhip_frame_build: the kernels behind this one read the device copy, the host reads
+// the twin without a copy command in between).  Instantiated for the single-frame kernel only.
+template <int DS_KP, bool AX4, bool MIRROR = false>
 __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const uint8_t *__restrict__ lvl0,
                                                   int stride0, unsigned long long frame0,
                                                   const uint8_t *__restrict__ pyr,
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
                                                   float *__restrict__ lvlAngle,
                                                   orbhip_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int32_t *__restrict__ counts,
-                                                  int cap, int xcdMap ORB_ABL_PARAM)
+                                                  int cap, int xcdMap, long long mirror ORB_ABL_PARAM)
 {
     __shared__ int s_pos[DS_KP];      // cx | cy << 12 | level << 24, -1 = empty slot
     __shared__ int s_out[DS_KP];      // output index
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
                 }
                 total += cnts[k];
             }
-            if (g == 0) counts[frame] = total;
+            if (g == 0) {
+                counts[frame] = total;
+                if (MIRROR) *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(counts + frame) + mirror) = total;
+            }
             const int i = g - G.lv[l].kpBase;
             if (i < cnts[l]) {
                 const uint32_t pk = lvlKp[(size_t)frame * G.totalKps + g];
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
                 kp.octave = l;
                 kp.class_id = -1;
                 kps[(size_t)frame * cap + o] = kp;
+                if (MIRROR) *reinterpret_cast<orbhip_keypoint *>(reinterpret_cast<char *>(kps + ((size_t)frame * cap + o)) + mirror) = kp;
             }
         }
     }
@@ -467,6 +474,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
                 // bit (64j + lane) of the descriptor = test 64j+lane, LSB first inside each byte (:128-145)
                 const unsigned long long wsel = lane == 0 ? words[0] : (lane == 1 ? words[1] : (lane == 2 ? words[2] : words[3]));
                 reinterpret_cast<unsigned long long *>(desc + ((size_t)frame * cap + o) * 32)[lane] = wsel;
+                if (MIRROR) reinterpret_cast<unsigned long long *>(desc + ((size_t)frame * cap + o) * 32 + mirror)[lane] = wsel;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -478,10 +486,10 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                      const uint8_t *pyr, size_t pyrFrame, const uint8_t *blur, size_t blurFrame,
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
-                     orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B)
+                     orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B, long long mirror)
 {
     static const int kpwEnv = ORB_TUNE("DESCRIBE_KPW", 0);
-    const int kpw = kpwEnv == 8 || kpwEnv == 16 || kpwEnv == 32 ? kpwEnv : (B >= 8 ? 16 : 8);
+    const int kpw = mirror ? 8 : kpwEnv == 8 || kpwEnv == 16 || kpwEnv == 32 ? kpwEnv : (B >= 8 ? 16 : 8);   // (mirror: single frames only)
     // workgroup -> (slot block, frame): ORBHIP_DESCRIBE_MAP overrides this kernel's mapping alone (A/B runs)
     static const int dmap = ORB_TUNE("DESCRIBE_MAP", -1);
     const int mapArg = dmap >= 0 ? (dmap | (orb_xcd_chunk() << 8)) : orb_xcd_arg(DESCRIBE_DEFAULT_MAP);
@@ -499,13 +507,15 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
 #define ORB_LAUNCH_DESCRIBE(KERN)                                                                                               \
     hipLaunchKernelGGL(KERN, grid, block, (size_t)padLds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                     \
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, lvlKp, lvlKpCnt, lvlAngle, kps, desc, \
-                       counts, cap, mapArg ORB_ABL_ARG(phases))
+                       counts, cap, mapArg, mirror ORB_ABL_ARG(phases))
     if (kpw == 32)
         ORB_LAUNCH_DESCRIBE((k_describe<32, false>));
     else if (kpw == 16 && ax4)
         ORB_LAUNCH_DESCRIBE((k_describe<16, true>));
     else if (kpw == 16)
         ORB_LAUNCH_DESCRIBE((k_describe<16, false>));
+    else if (mirror)
+        ORB_LAUNCH_DESCRIBE((k_describe<8, false, true>));
     else
         ORB_LAUNCH_DESCRIBE((k_describe<8, false>));
 #undef ORB_LAUNCH_DESCRIBE

@@ -59,8 +59,10 @@ __device__ __forceinline__ int grid_wave_incl_scan(int v)
 template <bool LDSIDX>
 __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__restrict__ kps,
                                                     const int32_t *__restrict__ cnt, int cap, const GridParams gp,
-                                                    int32_t *__restrict__ cellOff, int32_t *__restrict__ cellIdx)
+                                                    int32_t *__restrict__ cellOff, int32_t *__restrict__ cellIdx,
+                                                    int32_t *__restrict__ cellOff2, int32_t *__restrict__ cellIdx2)
 {
+    // (cellOff2 / cellIdx2, frame 0 only: the page-locked twin of orbhip_frame_build's result block; LDSIDX form only)
     extern __shared__ int s_idx[];
     __shared__ int s_cnt[GCELLS];
     __shared__ int s_wtot[4];
@@ -88,11 +90,15 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
     __syncthreads();
     int run = incl - sum;
     for (int w = 0; w < (tid >> 6); w++) run += s_wtot[w];
-    if (tid == 255) O[GCELLS] = run + sum;
+    if (tid == 255) {
+        O[GCELLS] = run + sum;
+        if (cellOff2) cellOff2[GCELLS] = run + sum;
+    }
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         s_cnt[tid * PER + k] = run;   // fill cursor
         O[tid * PER + k] = run;
+        if (cellOff2) cellOff2[tid * PER + k] = run;
         run += c[k];
     }
     __syncthreads();
@@ -118,7 +124,10 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
     if (LDSIDX) {
         __syncthreads();
         const int total = s_cnt[GCELLS - 1];
-        for (int j = tid; j < total; j += 256) I[j] = s_idx[j];
+        for (int j = tid; j < total; j += 256) {
+            I[j] = s_idx[j];
+            if (cellIdx2) cellIdx2[j] = s_idx[j];
+        }
     }
 }
 
@@ -1241,13 +1250,17 @@ static int proj_keff()
 }
 
 int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, float minX,
-                      float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx)
+                      float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx, int32_t *cellOff2, int32_t *cellIdx2)
 {
     const GridParams gp = {minX, minY, invW, invH};
     if ((size_t)cap * 4 <= 48 * 1024)
-        hipLaunchKernelGGL(k_grid_build<true>, dim3(B, 1, 1), dim3(256, 1, 1), (size_t)cap * 4, s, kps, cnt, cap, gp, cellOff, cellIdx);
-    else
-        hipLaunchKernelGGL(k_grid_build<false>, dim3(B, 1, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, gp, cellOff, cellIdx);
+        hipLaunchKernelGGL(k_grid_build<true>, dim3(B, 1, 1), dim3(256, 1, 1), (size_t)cap * 4, s, kps, cnt, cap, gp, cellOff, cellIdx,
+                           cellOff2, cellIdx2);
+    else {
+        if (cellOff2 || cellIdx2) return ORBHIP_E_SIZE;   // (the twin is written by the LDS form)
+        hipLaunchKernelGGL(k_grid_build<false>, dim3(B, 1, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, gp, cellOff, cellIdx,
+                           (int32_t *)nullptr, (int32_t *)nullptr);
+    }
     return ORBHIP_OK;
 }
 

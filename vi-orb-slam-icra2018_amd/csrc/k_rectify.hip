@@ -27,7 +27,7 @@ struct UndistortParams {
 
 __global__ __launch_bounds__(256) void k_undistort(const orbhip_keypoint *__restrict__ kps,
                                                    const int32_t *__restrict__ cnt, int cap, const UndistortParams U,
-                                                   orbhip_keypoint *__restrict__ out)
+                                                   orbhip_keypoint *__restrict__ out, orbhip_keypoint *__restrict__ out2)
 {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int n = cnt ? min(cnt[b], cap) : cap;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void k_undistort(const orbhip_keypoint *__rest
     kp.x = (float)__dmul_rn(xx, ww);
     kp.y = (float)__dmul_rn(yy, ww);
     out[(size_t)b * cap + i] = kp;
+    if (out2) out2[(size_t)b * cap + i] = kp;   // (orbhip_frame_build: the page-locked twin of the device block)
 }
 
 __device__ __forceinline__ int remap_px(const uint8_t *__restrict__ S, int sw, int sh, int sstride, float mx, float my)
@@ -198,11 +199,11 @@ static void undistort_params(const float *K, const float *D, int nD, const float
 }
 
 int launch_undistort(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, const float *K,
-                     const float *D, int nD, const float *P, orbhip_keypoint *out)
+                     const float *D, int nD, const float *P, orbhip_keypoint *out, orbhip_keypoint *out2)
 {
     UndistortParams U;
     undistort_params(K, D, nD, P, U);
-    hipLaunchKernelGGL(k_undistort, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, U, out);
+    hipLaunchKernelGGL(k_undistort, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, U, out, out2);
     return ORBHIP_OK;
 }
 

@@ -187,6 +187,12 @@ extern "C" int orbhip_vocab_text_to_binary(const char *text, size_t nbytes, void
 
 #define VT_CHUNK 10   // children whose descriptors are in flight together (2 x 16 bytes each; the stock tree has k = 10)
 
+// EAGER_RANGES: the child ranges of ALL candidates travel with their descriptors, so that a level is ONE dependent round trip --
+// the chosen child's range is otherwise a second one.  For a frame's worth of descriptors (four workgroups) the descent is
+// nothing but its chain of round trips, 12 -> 6 for the stock k = 10, L = 6 tree (r04: orbhip_frame_build 0.163 -> 0.146 ms); a
+// batch is bound by the bytes it gathers, and 80 more per level and descriptor cost it 4 % of a step, so batches keep the
+// second trip.
+template <bool EAGER_RANGES>
 __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restrict__ desc, int n, int nidLevel,
                                                          int rootFirst, int rootLast,
                                                          const uint4 *__restrict__ edesc,
@@ -195,9 +201,10 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restri
                                                          const int32_t *__restrict__ eword,
                                                          const float *__restrict__ eweight,
                                                          int32_t *__restrict__ word_id, float *__restrict__ weight,
-                                                         int32_t *__restrict__ node_id)
+                                                         int32_t *__restrict__ node_id, const int32_t *__restrict__ cnt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (cnt) n = min(n, cnt[0]);   // (a captured graph: the number of descriptors is the extraction's count, on the device)
     if (i >= n) return;
     const uint4 a = reinterpret_cast<const uint4 *>(desc + (size_t)i * 32)[0];
     const uint4 b = reinterpret_cast<const uint4 *>(desc + (size_t)i * 32)[1];
@@ -207,27 +214,33 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restri
         // key = distance << 20 | position among the children: the minimum is the first child with the smallest
         // distance (strict '<' over the children in order, :1470)
         unsigned best = 0xFFFFFFFFu;
+        int2 br = make_int2(0, 0);
         for (int cb = c0; cb < c1; cb += VT_CHUNK) {
             uint4 p[VT_CHUNK], q[VT_CHUNK];
+            int2 rr[VT_CHUNK];
 #pragma unroll
             for (int j = 0; j < VT_CHUNK; j++) {          // unconditional loads from clamped edges, issued together
                 const int c = min(cb + j, c1 - 1);
                 p[j] = edesc[2 * (size_t)c];
                 q[j] = edesc[2 * (size_t)c + 1];
+                if (EAGER_RANGES) rr[j] = erange[c];
             }
 #pragma unroll
             for (int j = 0; j < VT_CHUNK; j++) {
                 const unsigned d = __popc(a.x ^ p[j].x) + __popc(a.y ^ p[j].y) + __popc(a.z ^ p[j].z) + __popc(a.w ^ p[j].w) +
                                    __popc(b.x ^ q[j].x) + __popc(b.y ^ q[j].y) + __popc(b.z ^ q[j].z) + __popc(b.w ^ q[j].w);
                 const unsigned key = (d << 20) | (unsigned)(cb + j - c0);
-                if (cb + j < c1) best = min(best, key);
+                if (cb + j < c1 && key < best) {
+                    best = key;
+                    if (EAGER_RANGES) br = rr[j];
+                }
             }
         }
         e = c0 + (int)(best & 0xFFFFFu);
         if (level == nidLevel) nidEdge = e;
-        const int2 r = erange[e];
-        c0 = r.x;
-        c1 = r.y;
+        if (!EAGER_RANGES) br = erange[e];
+        c0 = br.x;
+        c1 = br.y;
     } while (c0 < c1);
     word_id[i] = eword[e];
     weight[i] = eweight[e];
@@ -235,10 +248,16 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restri
 }
 
 void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *desc, int n, int levelsup,
-                            int32_t *word_id, float *weight, int32_t *node_id)
+                            int32_t *word_id, float *weight, int32_t *node_id, const int32_t *cnt)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_vocab_transform, dim3((n + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, desc, n, V.L - levelsup,
-                       V.rootFirst, V.rootLast, reinterpret_cast<const uint4 *>(V.desc), reinterpret_cast<const int2 *>(V.erange),
-                       V.eid, V.eword, V.eweight, word_id, weight, node_id);
+#define ORB_LAUNCH_VT(E)                                                                                                          \
+    hipLaunchKernelGGL(k_vocab_transform<E>, dim3((n + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, desc, n, V.L - levelsup,          \
+                       V.rootFirst, V.rootLast, reinterpret_cast<const uint4 *>(V.desc), reinterpret_cast<const int2 *>(V.erange), \
+                       V.eid, V.eword, V.eweight, word_id, weight, node_id, cnt)
+    if (n <= 16384)
+        ORB_LAUNCH_VT(true);
+    else
+        ORB_LAUNCH_VT(false);
+#undef ORB_LAUNCH_VT
 }

@@ -298,6 +298,9 @@ struct orbhip_ctx {
     OrbPipe *pipe = nullptr;
     // resident feature sets (api_sets.hip)
     void *setTable = nullptr;
+    // orbhip_frame_build (api_frame.hip): the Frame constructor's device work as one captured graph
+    void *frameBuild = nullptr;
+    long long describeMirror = 0;     // != 0 while orbhip_frame_build enqueues: k_describe<.., MIRROR> stores its results twice
 
     // RCCL
     void *comm = nullptr;
@@ -341,7 +344,7 @@ void blur_band_table(uint32_t out[6 * 64 * 4]);
 void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                      const uint8_t *pyr, size_t pyrFrame, const uint8_t *blur, size_t blurFrame,
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
-                     orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B);
+                     orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B, long long mirror = 0);
 size_t quadtree_lds_bytes(const OrbLevels &G);
 
 void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int ndb, int32_t *best_idx,
@@ -428,7 +431,8 @@ __device__ __forceinline__ int xcd_tile(int xcdMap)
 #endif
 
 int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, float minX,
-                      float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx);
+                      float minY, float invW, float invH, int32_t *cellOff, int32_t *cellIdx, int32_t *cellOff2 = nullptr,
+                      int32_t *cellIdx2 = nullptr);
 int launch_area_list(hipStream_t s, const orbhip_keypoint *kps, float minX, float minY, float invW, float invH,
                      const int32_t *cellOff, const int32_t *cellIdx, const orbhip_proj_query *queries, int nq, int slots,
                      int32_t *outCnt, int32_t *outIdx);
@@ -458,7 +462,7 @@ int launch_search_for_initialization(hipStream_t s, const orbhip_keypoint *kps1,
                                      const int32_t *cellIdx2, float *prev, int windowSize, float nnratio, int check_ori,
                                      int th_low, int32_t *matches12, int32_t *nmatches, void *scratch);
 int launch_undistort(hipStream_t s, const orbhip_keypoint *kps, const int32_t *cnt, int cap, int B, const float *K,
-                     const float *D, int nD, const float *P, orbhip_keypoint *out);
+                     const float *D, int nD, const float *P, orbhip_keypoint *out, orbhip_keypoint *out2 = nullptr);
 int launch_remap(hipStream_t s, const uint8_t *src, int B, int sw, int sh, int sstride, size_t sframe, const float *mapx,
                  const float *mapy, int dw, int dh, uint8_t *dst, int dstride, size_t dframe);
 void orb_init_undistort_rectify_map(const double *K, const double *D, int nD, const double *R, const double *P, int w,
@@ -469,7 +473,7 @@ int launch_stereo(orbhip_ctx *L, orbhip_ctx *R, const orbhip_keypoint *kpsL, con
                   float mbf, float *uRight, float *depth, int32_t *scratch, int32_t *nmatch);
 int orb_vocab_parse(const uint8_t *blob, size_t nbytes, OrbVocabHost &V, std::string &err);
 void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *desc, int n, int levelsup,
-                            int32_t *word_id, float *weight, int32_t *node_id);
+                            int32_t *word_id, float *weight, int32_t *node_id, const int32_t *cnt = nullptr);
 void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *kps, const int32_t *counts,
                     const int32_t *node, const float *weight, const uint8_t *valid, int cap, int B, int lag, int th,
                     int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21,

@@ -8,6 +8,7 @@
 
 #include "hiperror.h"
 #include "orbhip.h"
+#include "ORBVocabulary.h"
 #include "ORBextractor.h"
 #include "slamlite.h"
 
@@ -46,6 +47,8 @@ void Frame::UndistortKeyPoints()
     }
     mvKeysUn.resize(N);
     if (N == 0) return;
+    // the frame this extractor has just built (ORBextractor::SetFrameBuild): the undistorted keypoints came with the extraction
+    if (mpORBextractorLeft && mpORBextractorLeft->BuiltKeysUn(mvKeys, mvKeysUn)) return;
     orbhip_ctx *ctx = frame_ctx(this, "Frame::UndistortKeyPoints");
     float K[9];
     std::vector<float> D;
@@ -97,6 +100,17 @@ void Frame::AssignFeaturesToGrid()
     for (unsigned int i = 0; i < FRAME_GRID_COLS; i++)
         for (unsigned int j = 0; j < FRAME_GRID_ROWS; j++) mGrid[i][j].clear();
     if (N == 0) return;
+    const int *boff = 0, *bidx = 0;
+    if (mpORBextractorLeft && mpORBextractorLeft->BuiltGrid(mvKeys, mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv, &boff, &bidx))
+    {
+        // the grid of the frame build (same kernel, same parameters)
+        for (int i = 0; i < FRAME_GRID_COLS; i++)
+            for (int j = 0; j < FRAME_GRID_ROWS; j++) {
+                const int c = i * FRAME_GRID_ROWS + j;
+                mGrid[i][j].assign(bidx + boff[c], bidx + boff[c + 1]);
+            }
+        return;
+    }
     orbhip_ctx *ctx = frame_ctx(this, "Frame::AssignFeaturesToGrid");
     std::vector<int32_t> off(ORBHIP_GRID_CELLS + 1), idx(N);
     if (orbhip_grid_build(ctx, reinterpret_cast<const orbhip_keypoint *>(mvKeysUn.data()), N, mnMinX, mnMinY,
@@ -110,6 +124,25 @@ void Frame::AssignFeaturesToGrid()
             const int c = i * FRAME_GRID_ROWS + j;
             mGrid[i][j].assign(idx.begin() + off[c], idx.begin() + off[c + 1]);
         }
+}
+
+void Frame::ComputeBoW()
+{
+    if(mBowVec.empty())                                                   // ref: src/Frame.cc:741
+    {
+        if (!mpORBvocabulary) return;
+        const int *word = 0, *node = 0;
+        const float *weight = 0;
+        if (mpORBextractorLeft && mpORBextractorLeft->BuiltBoW(mvKeys, mpORBvocabulary, 4, &word, &weight, &node))
+        {
+            mpORBvocabulary->assemble(word, weight, node, N, mBowVec, mFeatVec);
+            return;
+        }
+        std::vector<cv::Mat> vCurrentDesc;                                // Converter::toDescriptorVector (src/Converter.cc:163-171)
+        vCurrentDesc.reserve(mDescriptors.rows);
+        for (int j = 0; j < mDescriptors.rows; j++) vCurrentDesc.push_back(mDescriptors.row(j));
+        mpORBvocabulary->transform(vCurrentDesc,mBowVec,mFeatVec,4);      // ref: :744
+    }
 }
 
 std::vector<size_t> Frame::GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel,

@@ -90,6 +90,14 @@ void ORBVocabulary::transform(const std::vector<cv::Mat> &features, DBoW2::BowVe
         hipdetail::Fail("ORBVocabulary::transform", orbhip_last_error(mpCtx));
         return;                   // empty BowVector / FeatureVector
     }
+    assemble(word.data(), weight.data(), node.data(), n, v, fv);
+}
+
+void ORBVocabulary::assemble(const int *word, const float *weight, const int *node, int n, DBoW2::BowVector &v,
+                             DBoW2::FeatureVector &fv) const
+{
+    v.clear();
+    fv.clear();
     // BowVector.h: WeightingType TF_IDF=0, TF=1, IDF=2, BINARY=3; ScoringType L1_NORM=0, L2_NORM=1,
     // CHI_SQUARE=2, KL=3, BHATTACHARYYA=4, DOT_PRODUCT=5
     const bool accumulate = (mWeighting == 0 || mWeighting == 1);

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 
+#include "ORBVocabulary.h"
 #include "hiperror.h"
 #include "orbhip.h"
 
@@ -26,7 +27,9 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels,
     nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels),
     iniThFAST(_iniThFAST), minThFAST(_minThFAST),
     mTimeOfComputePyramid(0), mTimeOfComputeKeyPointsOctTree(0), mTimeOfComputeDescriptor(0),
-    mpCtx(nullptr), mCtxW(0), mCtxH(0), mbDownloadPyramid(true), mbBadParams(false)
+    mpCtx(nullptr), mCtxW(0), mCtxH(0), mbDownloadPyramid(true), mbBadParams(false),
+    mbFrameBuild(false), mFbNDist(0), mFbLevelsup(-1), mpFbVoc(nullptr), mbFbVocShared(false), mnBuiltN(-1), mbBuiltGrid(false),
+    mbBuiltBoW(false)
 {
     // scale tables, per-level quotas and umax (ref: src/ORBextractor.cc:417-471) -- host arithmetic
     // inside liborbhip, no device needed yet
@@ -59,7 +62,58 @@ bool ORBextractor::EnsureContext(int w, int h)
     mCtxW = w > mCtxW ? w : mCtxW;
     mCtxH = h > mCtxH ? h : mCtxH;
     mpCtx = orbhip_create(g_device, nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, mCtxW, mCtxH, 1);
+    mbFbVocShared = false;
     return mpCtx != nullptr;
+}
+
+void ORBextractor::SetFrameBuild(const cv::Mat &K, const cv::Mat &distCoef, float minX, float minY, float invW, float invH,
+                                 const ORBVocabulary *voc, int levelsup)
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) mFbK[r * 3 + c] = K.at<float>(r, c);
+    const int nd = distCoef.rows * distCoef.cols;
+    mFbNDist = (nd == 4 || nd == 5 || nd == 8) ? nd : 0;
+    for (int i = 0; i < 8; i++) mFbDist[i] = 0.f;
+    for (int i = 0; i < mFbNDist; i++) mFbDist[i] = distCoef.rows == 1 ? distCoef.at<float>(0, i) : distCoef.at<float>(i, 0);
+    mFbGrid[0] = minX; mFbGrid[1] = minY; mFbGrid[2] = invW; mFbGrid[3] = invH;
+    if (voc != mpFbVoc) mbFbVocShared = false;
+    mpFbVoc = (voc && !voc->empty()) ? voc : nullptr;
+    mFbLevelsup = mpFbVoc ? levelsup : -1;
+    mbFrameBuild = true;
+    mnBuiltN = -1;
+}
+
+bool ORBextractor::BuiltFrame(const std::vector<cv::KeyPoint> &keys) const
+{
+    const int n = (int)keys.size();
+    if (mnBuiltN < 0 || n != mnBuiltN || n == 0) return false;
+    return memcmp(&keys[0], &mvKpStage[0], sizeof(cv::KeyPoint)) == 0 && memcmp(&keys[n - 1], &mvKpStage[n - 1], sizeof(cv::KeyPoint)) == 0;
+}
+
+bool ORBextractor::BuiltKeysUn(const std::vector<cv::KeyPoint> &keys, std::vector<cv::KeyPoint> &keysUn) const
+{
+    if (!BuiltFrame(keys)) return false;
+    keysUn.assign(mvBuiltKeysUn.begin(), mvBuiltKeysUn.begin() + mnBuiltN);
+    return true;
+}
+
+bool ORBextractor::BuiltGrid(const std::vector<cv::KeyPoint> &keys, float minX, float minY, float invW, float invH, const int **cellOff,
+                             const int **cellIdx) const
+{
+    if (!mbBuiltGrid || !BuiltFrame(keys) || minX != mFbGrid[0] || minY != mFbGrid[1] || invW != mFbGrid[2] || invH != mFbGrid[3]) return false;
+    *cellOff = mvBuiltCellOff.data();
+    *cellIdx = mvBuiltCellIdx.data();
+    return true;
+}
+
+bool ORBextractor::BuiltBoW(const std::vector<cv::KeyPoint> &keys, const ORBVocabulary *voc, int levelsup, const int **word,
+                            const float **weight, const int **node) const
+{
+    if (!mbBuiltBoW || !BuiltFrame(keys) || voc != mpFbVoc || levelsup != mFbLevelsup) return false;
+    *word = mvBuiltWord.data();
+    *weight = mvBuiltWeight.data();
+    *node = mvBuiltNode.data();
+    return true;
 }
 
 void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints,
@@ -88,8 +142,49 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
     cv::Mat descStage(cap, 32, CV_8U);
     int n = 0;
     float t[3] = {0, 0, 0};
-    const int rc = orbhip_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step,
-                                  reinterpret_cast<orbhip_keypoint *>(mvKpStage.data()), descStage.data, cap, &n, t);
+    int rc;
+    mnBuiltN = -1;
+    if (mbFrameBuild)
+    {
+        // extraction + UndistortKeyPoints + AssignFeaturesToGrid (+ the vocabulary transform) as one graph launch; the by-products
+        // wait here for the Frame helpers (host/FrameGrid.cc)
+        orbhip_frame_params fp;
+        memcpy(fp.K, mFbK, sizeof(fp.K));
+        memcpy(fp.dist, mFbDist, sizeof(fp.dist));
+        fp.ndist = mFbNDist;
+        fp.min_x = mFbGrid[0]; fp.min_y = mFbGrid[1]; fp.inv_w = mFbGrid[2]; fp.inv_h = mFbGrid[3];
+        fp.levelsup = mFbLevelsup;
+        if (mpFbVoc && !mbFbVocShared)
+        {
+            if (mpFbVoc->Context() && orbhip_vocab_share(mpCtx, mpFbVoc->Context()) == ORBHIP_OK)
+                mbFbVocShared = true;
+            else
+                fp.levelsup = -1;                            // (ComputeBoW then runs its own transform)
+        }
+        const bool grid = fp.inv_w > 0.f && fp.inv_h > 0.f, bow = fp.levelsup >= 0;
+        mvBuiltKeysUn.resize(cap);
+        mvBuiltCellOff.resize(ORBHIP_GRID_CELLS + 1);
+        mvBuiltCellIdx.resize(cap);
+        mvBuiltWord.resize(cap);
+        mvBuiltNode.resize(cap);
+        mvBuiltWeight.resize(cap);
+        rc = orbhip_frame_build(mpCtx, image.data, image.cols, image.rows, (int)image.step, &fp,
+                                reinterpret_cast<orbhip_keypoint *>(mvKpStage.data()),
+                                reinterpret_cast<orbhip_keypoint *>(mvBuiltKeysUn.data()), descStage.data, cap, &n,
+                                grid ? mvBuiltCellOff.data() : nullptr, grid ? mvBuiltCellIdx.data() : nullptr,
+                                bow ? mvBuiltWord.data() : nullptr, bow ? mvBuiltWeight.data() : nullptr, bow ? mvBuiltNode.data() : nullptr);
+        if (rc == ORBHIP_OK)
+        {
+            mnBuiltN = n;
+            mbBuiltGrid = grid;
+            mbBuiltBoW = bow;
+            float ms[6];
+            if (orbhip_get_stage_times(mpCtx, ms) == ORBHIP_OK) { t[0] = ms[0]; t[1] = ms[1] + ms[2]; t[2] = ms[3] + ms[4]; }
+        }
+    }
+    else
+        rc = orbhip_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step,
+                            reinterpret_cast<orbhip_keypoint *>(mvKpStage.data()), descStage.data, cap, &n, t);
     if (rc != ORBHIP_OK)
     {
         _descriptors.release();

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 
+#include "ORBextractor.h"
 #include "hiperror.h"
 #include "orbhip.h"
 
@@ -63,9 +64,14 @@ vector<uint8_t> contiguous(const cv::Mat &d)
 }
 
 // Resident feature sets (include/orbhip.h, orbhip_set_*): descriptors, undistorted keypoints, FeatureVector and feature grid of
-// a key frame or frame do not change once it exists, so they are uploaded the first time a matcher of this thread meets
-// it and stay on the device under its id (mnId is unique per run; a set nobody uses any more ages out of the 96 the
-// context keeps).  ORBHIP_NO_SETS=1 restores the upload-per-call entry points (A/B runs).
+// a key frame or frame stay on the device under its id once a matcher of this thread has met it (a set nobody uses any
+// more ages out of the 96 the context keeps).  An id is not an identity: Tracking::Reset restarts KeyFrame::nNextId and
+// Frame::nNextId (ref: src/Tracking.cc:2758-2759), and a key frame can be met before KeyFrame::ComputeBoW has filled its
+// FeatureVector (ref: src/KeyFrame.cc:392-400).  So a resident set is a hit only if its feature count, its FeatureVector
+// size and its fingerprint (first keypoint, first and last descriptor) are those of the object in hand; otherwise it is
+// put again.  A Frame that its extractor has just built (ORBextractor::SetFrameBuild) enters from the device block of that
+// build -- only its FeatureVector travels.  ORBmatcher::DropResidentSets() (for Tracking::Reset) empties the
+// calling thread's table.  ORBHIP_NO_SETS=1 restores the upload-per-call entry points (A/B runs).
 const uint64_t KF_KEY = 1ull << 62, FRAME_KEY = 1ull << 61;
 bool use_sets()
 {
@@ -73,13 +79,22 @@ bool use_sets()
     return !off;
 }
 template <class T>
-bool ensure_set(uint64_t key, const T &t, const vector<cv::KeyPoint> &keysUn, float minX, float minY, float invW, float invH)
+bool ensure_set(uint64_t key, const T &t, const vector<cv::KeyPoint> &keysUn, float minX, float minY, float invW, float invH,
+                orbhip_ctx *builder)
 {
     const int n = t.mDescriptors.rows;
     if (n <= 0 || (int)keysUn.size() != n) return false;
     orbhip_ctx *c = tls.get();
-    if (orbhip_set_has(c, key, n)) return true;
+    const uint64_t fp = orbhip_set_fingerprint_rows(reinterpret_cast<const orbhip_keypoint *>(keysUn.data()), t.mDescriptors.ptr(0),
+                                                    t.mDescriptors.ptr(n - 1), n);
+    int n0 = 0, ng0 = 0;
+    uint64_t fp0 = 0;
+    if (orbhip_set_info(c, key, &n0, &ng0, &fp0) && n0 == n && fp0 == fp && ng0 == (int)t.mFeatVec.size()) return true;
     const Csr fv = flatten(t.mFeatVec);
+    // the frame its extractor built last is still on the device: block to block, the FeatureVector alone travels
+    if (builder && orbhip_frame_fingerprint(builder) == fp &&
+        orbhip_set_put_from_frame(c, key, builder, fv.node.data(), fv.off.data(), fv.idx.data(), (int)fv.node.size()) == ORBHIP_OK)
+        return true;
     const vector<uint8_t> d = contiguous(t.mDescriptors);
     return orbhip_set_put(c, key, reinterpret_cast<const orbhip_keypoint *>(keysUn.data()), d.data(), n, fv.node.data(),
                           fv.off.data(), fv.idx.data(), (int)fv.node.size(), minX, minY, invW, invH) == ORBHIP_OK;
@@ -87,12 +102,12 @@ bool ensure_set(uint64_t key, const T &t, const vector<cv::KeyPoint> &keysUn, fl
 bool ensure_set(KeyFrame *pKF)
 {
     return ensure_set(KF_KEY | (uint64_t)(pKF->mnId + 1), *pKF, pKF->mvKeysUn, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
-                      pKF->mfGridElementHeightInv);
+                      pKF->mfGridElementHeightInv, NULL);
 }
 bool ensure_set(Frame &F)
 {
     return ensure_set(FRAME_KEY | (uint64_t)(F.mnId + 1), F, F.mvKeysUn, Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv,
-                      Frame::mfGridElementHeightInv);
+                      Frame::mfGridElementHeightInv, F.mpORBextractorLeft ? F.mpORBextractorLeft->Context() : NULL);
 }
 }  // namespace
 
@@ -101,6 +116,11 @@ ORBmatcher::ORBmatcher(float nnratio, bool checkOri): mfNNratio(nnratio), mbChec
 }
 
 ORBmatcher::~ORBmatcher() {}
+
+void ORBmatcher::DropResidentSets()
+{
+    if (tls.ctx) orbhip_set_drop(tls.ctx, 0);
+}
 
 int ORBmatcher::SearchByBoW(KeyFrame* pKF,Frame &F, vector<MapPoint*> &vpMapPointMatches)
 {

@@ -57,7 +57,13 @@ SYMBOLS = [
     "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
     "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
     "orbhip_set_put", "orbhip_set_has", "orbhip_set_drop", "orbhip_search_by_bow_sets", "orbhip_window_best_set",
+    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
 ]
+
+
+class FrameParams(C.Structure):   # orbhip_frame_params
+    _fields_ = [("K", C.c_float * 9), ("dist", C.c_float * 8), ("ndist", C.c_int), ("min_x", C.c_float), ("min_y", C.c_float),
+                ("inv_w", C.c_float), ("inv_h", C.c_float), ("levelsup", C.c_int)]
 
 
 QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("proj_xr", "<f4"), ("min_level", "<i4"),
@@ -167,6 +173,13 @@ def load():
     L.orbhip_set_drop.argtypes = [vp, C.c_uint64]
     L.orbhip_search_by_bow_sets.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, i32, i32, f32, i32, vp, vp, ip]
     L.orbhip_window_best_set.argtypes = [vp, C.c_uint64, vp, vp, i32, vp, vp, i32, vp, vp]
+    L.orbhip_set_info.argtypes = [vp, C.c_uint64, ip, ip, C.POINTER(C.c_uint64)]
+    L.orbhip_set_fingerprint.argtypes = [vp, vp, i32]
+    L.orbhip_set_fingerprint.restype = C.c_uint64
+    L.orbhip_frame_build.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, ip, vp, vp, vp, vp, vp]
+    L.orbhip_frame_fingerprint.argtypes = [vp]
+    L.orbhip_frame_fingerprint.restype = C.c_uint64
+    L.orbhip_set_put_from_frame.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, i32]
     L.orbhip_comm_unique_id.argtypes = [vp]
     L.orbhip_comm_init.argtypes = [vp, i32, i32, vp]
     L.orbhip_bcast_blob_device.argtypes = [vp, vp, C.c_size_t, i32]

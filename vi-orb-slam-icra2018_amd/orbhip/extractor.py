@@ -92,6 +92,47 @@ class ORBextractor:
         self._shape = img.shape
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def frame_build(self, image, K=None, dist_coef=None, gp=None, levelsup=-1):
+        """The Frame constructor's device work in one launch (orbhip_frame_build; ref: src/Frame.cc:518-572, 739-746):
+        extraction, UndistortKeyPoints with (K, dist_coef), AssignFeaturesToGrid with gp = (min_x, min_y, inv_w, inv_h) and,
+        for levelsup >= 0, the vocabulary transform.  Returns a dict: kps, kps_un, desc, cell_off, cell_idx (None without
+        gp), word_id, weight, node_id (None without levelsup)."""
+        img = np.ascontiguousarray(image, np.uint8)
+        assert img.ndim == 2
+        P = capi.FrameParams()
+        Kf = np.eye(3, dtype=np.float32).ravel() if K is None else np.ascontiguousarray(K, np.float32).ravel()
+        D = np.zeros(0, np.float32) if dist_coef is None else np.ascontiguousarray(dist_coef, np.float32).ravel()
+        for i in range(9):
+            P.K[i] = float(Kf[i])
+        for i in range(len(D)):
+            P.dist[i] = float(D[i])
+        P.ndist = len(D)
+        if gp is not None:
+            P.min_x, P.min_y, P.inv_w, P.inv_h = [float(v) for v in gp]
+        P.levelsup = int(levelsup)
+        cap = self.cap
+        kps, kun = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        off = np.zeros(capi.GRID_COLS * capi.GRID_ROWS + 1, np.int32) if gp is not None else None
+        idx = np.zeros(cap, np.int32) if gp is not None else None
+        word = np.zeros(cap, np.int32) if levelsup >= 0 else None
+        wt = np.zeros(cap, np.float32) if levelsup >= 0 else None
+        node = np.zeros(cap, np.int32) if levelsup >= 0 else None
+        n = C.c_int()
+        check(self._L.orbhip_frame_build(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], C.byref(P), _p(kps), _p(kun),
+                                         _p(desc), cap, C.byref(n), _p(off), _p(idx), _p(word), _p(wt), _p(node)),
+              self._h, "orbhip_frame_build")
+        self._shape = img.shape
+        m = n.value
+        cut = lambda a: None if a is None else a[:m].copy()
+        if idx is not None:
+            idx = idx[:off[-1]].copy()   # (features outside the image bounds are in no cell, :583-587)
+        return dict(kps=kps[:m].copy(), kps_un=kun[:m].copy(), desc=desc[:m].copy(), cell_off=off, cell_idx=idx,
+                    word_id=cut(word), weight=cut(wt), node_id=cut(node))
+
+    def frame_fingerprint(self):
+        return int(self._L.orbhip_frame_fingerprint(self._h))
+
     def extract_batch(self, images):
         """images: (B, H, W) uint8.  Returns lists of per-frame keypoints and descriptors."""
         imgs = np.ascontiguousarray(images, np.uint8)
@@ -318,8 +359,28 @@ class ORBmatcher:
         check(self._L.orbhip_set_put(self._ctx.handle, key, _p(kps), _p(desc), len(kps), _p(g[0]), _p(g[1]), _p(g[2]),
                                      0 if fv is None else len(g[0]), gp[0], gp[1], gp[2], gp[3]), self._ctx.handle, "orbhip_set_put")
 
+    def put_set_from_frame(self, key, src, fv=None):
+        """The frame that extractor `src` built last (frame_build) as resident set `key` of this matcher's context: only the
+        FeatureVector CSR travels."""
+        g = [None, None, None] if fv is None else [np.ascontiguousarray(a, np.int32) for a in fv]
+        check(self._L.orbhip_set_put_from_frame(self._ctx.handle, key, src.handle, _p(g[0]), _p(g[1]), _p(g[2]),
+                                                0 if fv is None else len(g[0])), self._ctx.handle, "orbhip_set_put_from_frame")
+
     def has_set(self, key, n):
         return bool(self._L.orbhip_set_has(self._ctx.handle, key, n))
+
+    def set_info(self, key):
+        """(n, ng, fingerprint) of a resident set, or None."""
+        n, ng, fp = C.c_int(), C.c_int(), C.c_uint64()
+        if not self._L.orbhip_set_info(self._ctx.handle, key, C.byref(n), C.byref(ng), C.byref(fp)):
+            return None
+        return n.value, ng.value, fp.value
+
+    @staticmethod
+    def fingerprint(kps, desc):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        return int(capi.load().orbhip_set_fingerprint(_p(kps), _p(desc), len(kps)))
 
     def drop_set(self, key=0):
         check(self._L.orbhip_set_drop(self._ctx.handle, key), self._ctx.handle, "orbhip_set_drop")
@@ -328,6 +389,11 @@ class ORBmatcher:
         """SearchByBoW between two resident sets; returns (nmatches, match12, match21) like SearchByBoW."""
         valid1 = np.ascontiguousarray(valid1, np.uint8)
         valid2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        # the entry point sizes everything from the resident sets: the caller's idea of them must agree (ORBHIP_E_ARG otherwise)
+        i1, i2 = self.set_info(key1), self.set_info(key2)
+        if i1 is None or i2 is None or i1[0] != n1 or i2[0] != n2 or len(valid1) != n1 or (valid2 is not None and len(valid2) != n2):
+            raise OrbHipError("SearchByBoW_sets: unknown set, or feature counts that differ from the resident sets' (%s, %s vs %d, %d)"
+                              % (i1, i2, n1, n2))
         m12 = np.empty(max(n1, 1), np.int32)
         m21 = np.empty(max(n2, 1), np.int32)
         nm = C.c_int()
