@@ -32,10 +32,8 @@ sys.path.insert(0, os.path.join(ROOT, "vi-orb-slam-icra2018_amd"))
 import numpy as np  # noqa: E402
 
 W, H, NFEAT = 640, 480, 1000          # the size BASELINE.json's metric is quoted on
-# share of the "4 cycles per vector instruction" count that k_fast_fix's instruction mix really occupies (tools/valu_mix.py on the
-# kernel's ISA with the issue rates of profiles/r03/valu_rates.txt: 556 two-cycle and 1132 four-cycle instructions)
-VALU_ISSUE_WEIGHT = 0.835
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+I8_MFMA_PEAK_OPS = 5.0e15             # MI355X_MICROARCH.md: dense I8 MFMA = 2 x BF16 per clock, BF16 ~2.5 PFLOP/s dense
 VOC_K, VOC_L, LEVELSUP = 10, 6, 4     # stock ORBvoc shape; Frame::ComputeBoW uses levelsup 4 (src/Frame.cc:744)
 NNRATIO = 0.7                         # TrackReferenceKeyFrame: ORBmatcher matcher(0.7,true) (src/Tracking.cc:1881)
 
@@ -47,6 +45,25 @@ def fast_algorithmic_bytes(w, h, nlevels, level_size):
         lw, lh = level_size(w, h, l)
         tot += (lw - 32) * (lh - 32)
     return tot
+
+
+def stage_algorithmic_bytes(w, h, nlevels, level_size, keypoints):
+    """SURVEY.md section 8d, per frame: pyramid = every level but the last read + every level but the first written; blur =
+    every level read and written; describe = 749 disc bytes + 512 test bytes read and 28 + 32 bytes written per keypoint."""
+    px = [level_size(w, h, l) for l in range(nlevels)]
+    px = [a * b for a, b in px]
+    return {"k_resize (7 launches)": sum(px[:-1]) + sum(px[1:]), "k_blur": 2 * sum(px),
+            "k_describe (2 launches)": int(round(keypoints * (749 + 512 + 60))),
+            "k_fast": fast_algorithmic_bytes(w, h, nlevels, level_size)}
+
+
+def file_sha16(path):
+    import hashlib
+    try:
+        with open(path, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def cpu_baseline(frames, nsample, match, blob, keep=0):
@@ -156,9 +173,12 @@ def cpu_baseline_all_cores(frames, nsample, match, blob):
 
 
 def committed_counters(batch, contexts):
-    """Per-launch figures of k_fast from the committed rocprofv3 PMC passes (profiles/traffic.json, written from the separate
-    --pmc passes of tools/r03_profile.sh for the default configuration): HBM-side bytes (FETCH_SIZE x2 + WRITE_SIZE as
-    MI355X_MICROARCH.md prescribes) and vector wave-instructions (SQ_INSTS_VALU).  {} when the file does not match."""
+    """Per-launch figures of k_fast from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/summarize_prof.py from the separate --pmc passes of the round's profile script, default configuration): HBM-side bytes
+    (FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), vector wave-instructions (SQ_INSTS_VALU), the issue weight
+    of the kernel's instruction mix (tools/valu_mix.py) and the sha256 of the kernel source they were taken from.  {} when the
+    file does not match the run's configuration.  The counters cannot be collected inside a timed bench run (a --pmc pass
+    serialises the kernels); main() marks them stale when the kernel source or the launch time has moved since."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh)
@@ -505,9 +525,87 @@ def config_relocalisation(device, B=256, steps=6, nq=4000, ndb=1000000, nver=32)
                         "previous frame; and one %d x %d Hamming relocalisation query" % (B, nq, ndb),
             "value": round(steps * B / dt, 1), "unit": "frames/s", "keypoints_per_frame": round(kp, 1),
             "query_ms": round(qdt * 1e3, 3), "query_pair_evals_per_s": round(nq * ndb / qdt, 0),
+            # k_knn2_mfma computes a pair's distance as a 256-term int8 dot product on the matrix pipe: 512 int8 operations per pair
+            "roofline_mfma": {"bound": "mfma", "kernel": "k_knn2_mfma", "achieved": round(nq * ndb / qdt * 512 / 1e12, 1),
+                              "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s (int8)", "frac": round(nq * ndb / qdt * 512 / I8_MFMA_PEAK_OPS, 4),
+                              "note": "pair evaluations/s x 512 int8 operations / the dense I8 MFMA rate (2 x BF16 per clock, "
+                                      "MI355X_MICROARCH.md); the query's wall time incl. the merge kernel"},
             "query_database_GBps": round(32.0 * ndb / qdt / 1e9, 1), "verified": verified + nver,
             "verified_what": "frames 0 and 1 (keypoints, descriptors, brute-force triples) and %d of the %d queries against the "
                              "full database vs oracle" % (nver, nq)}
+
+
+def content_classes(device, blob, B=256, steps=4):
+    """The headline step (extract + vocabulary transform + SearchByBoW) on each synthetic content class of orbhip/synth.py: FAST's
+    cost depends on what it looks at (the dense fallbacks of its lists, the second pass of empty cells), so the headline is a
+    property of its texture.  Per class: frames/s, the FAST launch time, and frames 0 and 1 verified against the oracle."""
+    import torch
+    from orbhip import synth
+    from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    oracle = _oracle()
+    out = {}
+    t_all = time.perf_counter()
+    dev = torch.device("cuda", device)
+    i32 = dict(dtype=torch.int32, device=dev)
+    ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B, device=device)
+    ORBVocabulary(ex).loadFromBinaryBlob(blob)
+    cap = ex.cap
+    L = ex._L
+    d_kps = torch.empty((B, cap, 7), **i32)
+    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt, d_nm = torch.zeros(B, **i32), torch.zeros(B, **i32)
+    d_word, d_node, d_m12, d_m21 = (torch.empty((B, cap), **i32) for _ in range(4))
+    d_wt = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    ref = oracle.Extractor(NFEAT, 1.2, 8, 20, 7)
+    voc = oracle.Vocabulary(blob)
+    for kind in synth.CONTENT_CLASSES:
+        uniq = synth.make_frames_class(kind, 2000, W, H, 8)
+        frames = np.concatenate([uniq] * (B // 8))
+        d_img = torch.from_numpy(np.ascontiguousarray(frames)).cuda(device)
+
+        def step():
+            ex.extract_batch_device(d_img.data_ptr(), B, W, H, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_cnt.data_ptr())
+            assert L.orbhip_vocab_transform_device(ex.handle, d_desc.data_ptr(), B * cap, LEVELSUP, d_word.data_ptr(), d_wt.data_ptr(),
+                                                   d_node.data_ptr()) == 0
+            assert L.orbhip_search_by_bow_seq_device(ex.handle, d_desc.data_ptr(), d_kps.data_ptr(), d_cnt.data_ptr(), d_node.data_ptr(),
+                                                     d_wt.data_ptr(), None, cap, B, 1, 0, C.c_float(NNRATIO), 1, d_m12.data_ptr(),
+                                                     d_m21.data_ptr(), d_nm.data_ptr()) == 0
+        step()
+        ex.sync()
+        t0 = time.perf_counter()
+        fast = 0.0
+        for _ in range(steps):
+            step()
+            ms = (C.c_float * 6)()
+            assert L.orbhip_get_stage_times(ex.handle, ms) == 0
+            fast += ms[1] / steps
+        ex.sync()
+        dt = time.perf_counter() - t0
+        cnt = d_cnt.cpu().numpy()
+        prev = None
+        for b in range(2):
+            k, d = ref(frames[b])
+            n = int(cnt[b])
+            if n != len(k) or d_kps[b, :n].cpu().numpy().tobytes() != k.tobytes() or not np.array_equal(d_desc[b, :n].cpu().numpy(), d):
+                raise SystemExit("bench.py: content class %s: frame %d differs from the oracle" % (kind, b))
+            _, wt, nid = voc.transform(d, LEVELSUP)
+            cur = (k, d, oracle.feature_vector(nid, wt))
+            if prev is not None:
+                nm, m12, m21 = oracle.search_by_bow(prev[1], np.ones(len(prev[1]), np.uint8), prev[0]["angle"], prev[2], d, None,
+                                                    k["angle"], cur[2], th=50, th_mode=0, nnratio=NNRATIO, check_ori=True)
+                if int(d_nm[b].item()) != nm or not np.array_equal(d_m21[b, :len(m21)].cpu().numpy(), m21):
+                    raise SystemExit("bench.py: content class %s: SearchByBoW of frame %d differs from the oracle" % (kind, b))
+            prev = cur
+        out[kind] = {"value": round(steps * B / dt, 1), "unit": "frames/s", "k_fast_ms_per_1024_frames": round(fast * 1024.0 / B, 4),
+                     "keypoints_per_frame": round(float(cnt.mean()), 1), "bow_matches_per_frame": round(float(d_nm.cpu().numpy()[1:].mean()), 1),
+                     "verified_frames": 2}
+        del d_img
+    ex.close()
+    out["frames_per_step"] = B
+    out["note"] = "batches of %d frames (8 distinct, tiled), %d timed steps each; the headline runs the textured class at 1024" % (B, steps)
+    out["seconds_total"] = round(time.perf_counter() - t_all, 1)
+    return out
 
 
 def secondary_configs(device, blob):
@@ -541,6 +639,8 @@ def main():
     ap.add_argument("--host-batch", type=int, default=256, help="frames per batch of the host-fed pipeline figure (0 = skip)")
     ap.add_argument("--configs", type=int, default=1, help="also time BASELINE.json's configs 2-5 (outside the headline's timed "
                     "region, each verified against the oracle); 0 = skip")
+    ap.add_argument("--content", type=int, default=1, help="also run the step on the synthetic content classes of orbhip/synth.py "
+                    "(textured, indoor_sparse, white_noise, low_contrast), each verified against the oracle; 0 = skip")
     ap.add_argument("--verify", type=int, default=8, help="frames of the timed batch whose GPU outputs are compared with "
                     "the oracle outside the timed region (0 = skip); a difference ends the run with exit code 3")
     args = ap.parse_args()
@@ -702,7 +802,7 @@ def main():
     dt = time.perf_counter() - t0
     for ex, _ in ctxs:
         assert L.orbhip_set_stage_timing(ex.handle, 2) == 0
-    stage_pass = min(5, args.steps)
+    stage_pass = max(1, min(5, args.steps))
     fast_instrumented = 0.0
     for _ in range(stage_pass):
         step()
@@ -710,7 +810,7 @@ def main():
             ms = (C.c_float * 6)()
             assert L.orbhip_get_stage_times(ex.handle, ms) == 0
             for i in (0, 2, 3, 4, 5):
-                stage[i] += ms[i] * args.steps / stage_pass
+                stage[i] += ms[i] * max(args.steps, 1) / stage_pass
             fast_instrumented += ms[1] / stage_pass
     barrier()
     per_rank_dt = [dt]
@@ -729,7 +829,7 @@ def main():
 
     out = None
     if rank == 0:
-        fps = world * B * args.steps / dt
+        fps = world * B * args.steps / dt if dt > 0 else 0.0
         alg = fast_algorithmic_bytes(W, H, 8, ex0.level_size) * Bc        # bytes per FAST launch (one per context)
         fast_ms = float(stage[1]) / NC                                    # average duration of one launch
         achieved = alg / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
@@ -739,6 +839,21 @@ def main():
         ctr = committed_counters(B, NC)
         traffic, traffic_src = ctr.get("traffic_bytes_per_launch"), ctr.get("source")
         valu = ctr.get("valu_wave_insts_per_launch")
+        # the committed counters describe THIS kernel only if its source has not changed since and the launch takes what it took then
+        src_now = file_sha16(os.path.join(ROOT, "vi-orb-slam-icra2018_amd", "csrc", "k_fast.hip"))
+        src_moved = bool(ctr) and ctr.get("kernel_source_sha16") != src_now
+        time_moved = bool(ctr) and fast_ms > 0 and abs(float(ctr.get("avg_launch_us", 0.0)) / 1e3 - fast_ms) > 0.05 * fast_ms
+        ctr_stale = src_moved or time_moved
+        VALU_ISSUE_WEIGHT = float(ctr.get("issue_weight", 0.835))
+        kp_mean = float(counts.mean())
+        alg_stage = stage_algorithmic_bytes(W, H, 8, ex0.level_size, kp_mean)
+        stage_of = {"k_resize (7 launches)": 0, "k_blur": 3, "k_describe (2 launches)": 4, "k_fast": 1}
+        rooflines = []
+        for kname, by in alg_stage.items():
+            ms_k = float(stage[stage_of[kname]]) / NC
+            rooflines.append({"kernel": kname, "algorithmic_bytes": int(by * Bc), "ms": round(ms_k, 4),
+                              "achieved_GBps": round(by * Bc / (ms_k * 1e-3) / 1e9, 1) if ms_k > 0 else 0.0,
+                              "frac": round(by * Bc / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_k > 0 else 0.0})
         # vector-issue roofline: 1024 SIMDs, one wave64 instruction per 4 cycles each, at the clock the counters saw
         issue_peak = 1024 / 4.0 * float(ctr.get("clock_ghz", 2.4)) * 1e9
         out = {
@@ -754,15 +869,21 @@ def main():
                        "parallelism": "frames sharded, 1 process per GPU, no per-frame collective"},
             # `bound` is what the counters say limits the kernel (vector-instruction issue); achieved / peak / frac are the HBM
             # figures the metric asks for, roofline_valu is the roofline of the resource that actually binds
-            "roofline": {"bound": "valu" if valu else "hbm", "kernel": "k_fast", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_stale": ctr_stale,
+                         "traffic_stale_why": None if not ctr_stale else ("k_fast.hip has changed since the counter pass" if src_moved
+                                                                            else "launch time differs by more than 5 % from the counter pass"),
+                         "limited_by": "vector and LDS instruction issue (roofline_valu), not bytes",
                          "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(fast_ms, 4),
                          "note": "achieved = algorithmic bytes / launch time (HIP events on the launch stream, k_fast alone on the "
                                  "device); the kernel is bound by vector-instruction issue, see roofline_valu"
                                  + ("; launch_ms is measured while the other contexts' kernels share the GPU" if NC > 1 else "")},
+            # one entry per streaming kernel of the step: SURVEY section 8d's algorithmic bytes per launch / the stage's HIP-event time of this
+            # run (the instrumented pass behind the timed region) / 8 TB/s
+            "rooflines": rooflines,
             "roofline_valu": None if not valu or fast_ms <= 0 else {
-                "kernel": "k_fast", "wave_insts": int(valu), "achieved": round(valu / (fast_ms * 1e-3) / 1e9, 1),
+                "kernel": "k_fast", "wave_insts": int(valu), "stale": ctr_stale, "achieved": round(valu / (fast_ms * 1e-3) / 1e9, 1),
                 "issue_peak": round(issue_peak / 1e9, 1), "unit": "G wave-instructions/s",
                 "frac": round(valu / (fast_ms * 1e-3) / issue_peak, 4),
                 "issue_weight": VALU_ISSUE_WEIGHT,
@@ -816,6 +937,12 @@ def main():
         if blob is None:
             blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L)
         out["configs"] = secondary_configs(local_rank, blob)
+        out["roofline_mfma"] = out["configs"]["5_tum_4000feat_1M_query"].get("roofline_mfma")
+    if out is not None and world == 1 and args.content:
+        torch.cuda.empty_cache()
+        if blob is None:
+            blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L)
+        out["content"] = content_classes(local_rank, blob)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

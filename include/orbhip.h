@@ -183,7 +183,9 @@ int orbhip_debug_get_level_keypoints(orbhip_ctx *ctx, int frame, int level, orbh
  * applied to a whole query set against a whole database with the best / second-best
  * bookkeeping of every search routine (src/ORBmatcher.cc:205-226 etc.): for each query the
  * lowest-index minimum (strict '<'), its distance and the second smallest distance; initial
- * values 256 / -1 / 256.  Descriptors are rows of 32 bytes. */
+ * values 256 / -1 / 256.  Descriptors are rows of 32 bytes.  Device pointers of any alignment are accepted; the matrix-pipe
+ * kernels want d_q 16-byte and d_db 4-byte aligned (what hipMalloc and rows of 32 bytes give) and hand other pointers to
+ * the scalar kernels (same results, about a third of the rate). */
 int orbhip_hamming_knn2(orbhip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *db, int ndb,
                         int32_t *best_idx, int32_t *best_d, int32_t *second_d);
 int orbhip_hamming_knn2_device(orbhip_ctx *ctx, const void *d_q, int nq, const void *d_db, int ndb,
@@ -522,6 +524,11 @@ uint64_t orbhip_frame_fingerprint(const orbhip_ctx *ctx);
  * that travels.  ctx and src must be contexts of the same device (they may be the same context). */
 int orbhip_set_put_from_frame(orbhip_ctx *ctx, uint64_t key, orbhip_ctx *src, const int32_t *node, const int32_t *off,
                               const int32_t *idx, int ng);
+
+/* The floor under a per-call entry point, in microseconds per call on this context's stream: mode 0 = an empty kernel and
+ * one synchronisation; 1 = 4 KB copied in, the kernel, 4 KB copied out, one synchronisation; 2 = the kernel stores its
+ * result to page-locked memory, one synchronisation.  (Measurement aid: tools/percall_latency.py.) */
+int orbhip_debug_roundtrip(orbhip_ctx *ctx, int mode, int iters, double *us_per_call);
 
 /* ---- multi-GPU (one process per GPU) ----
  * The reference is a single process (no distributed back end); these entry points are what a

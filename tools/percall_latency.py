@@ -143,3 +143,19 @@ print("| call (one per frame / key-frame pair) | liborbhip per call (ms) | oracl
 print("|---|---|---|")
 for name, g, c in rows:
     print("| %s | %.3f | %.3f |" % (name, g, c))
+# the floor under any of these calls on this box: what a launch and a synchronisation cost before anything is computed
+import ctypes
+from orbhip import capi
+L = capi.load()
+print()
+print("| floor (`orbhip_debug_roundtrip`, C side, no Python in the loop) | ms |")
+print("|---|---|")
+for mode, what in ((0, "empty kernel + one synchronisation"), (2, "... the kernel storing its result to page-locked memory"),
+                   (1, "4 KB in, empty kernel, 4 KB out, one synchronisation")):
+    us = ctypes.c_double()
+    capi.check(L.orbhip_debug_roundtrip(ex.handle, mode, 2000, ctypes.byref(us)), ex.handle, "orbhip_debug_roundtrip")
+    print("| %s | %.4f |" % (what, us.value / 1e3))
+t = time.perf_counter()
+for _ in range(2000):
+    L.orbhip_set_has(ex.handle, 12345, 1)
+print("| one ctypes call of the Python binding (no device work) | %.4f |" % ((time.perf_counter() - t) / 2000 * 1e3))

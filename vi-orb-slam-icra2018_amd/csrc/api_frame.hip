@@ -17,6 +17,8 @@
 // tests/test_frame_build.py.
 #include "api_common.h"
 
+#include <time.h>
+
 struct OrbFrameBuild {
     uint8_t *d_blk = nullptr;   // packed results, device
     uint8_t *h_blk = nullptr;   // page-locked twin
@@ -315,5 +317,43 @@ int orb_frame_mark_busy(orbhip_ctx *src, hipStream_t copier)
     if (!F) return ORBHIP_E_ARG;
     if (hipEventRecord(F->evBusy, copier) != hipSuccess) return ORBHIP_E_HIP;
     F->busy = true;
+    return ORBHIP_OK;
+}
+
+// ---- the floor under every per-call entry point ----
+// What a host-pointer call costs before it computes anything, measured on the context's own stream: mode 0 = one empty kernel
+// + one synchronisation; mode 1 = a 4 KB page-locked block copied in, the empty kernel, 4 KB copied out, one synchronisation
+// (the shape of struct Packed); mode 2 = as 0 with the kernel storing one word to page-locked memory (the zero-copy result
+// path).  tools/percall_latency.py prints them beside the per-call table: a row that sits at its floor cannot beat a host
+// core by arithmetic.
+__global__ void k_floor(int32_t *out)
+{
+    if (out && threadIdx.x == 0) out[0] = 1;
+}
+extern "C" int orbhip_debug_roundtrip(orbhip_ctx *c, int mode, int iters, double *us_per_call)
+{
+    if (!c || !us_per_call || iters <= 0 || mode < 0 || mode > 2) return fail(c, ORBHIP_E_ARG, "orbhip_debug_roundtrip: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    Packed P(c);
+    int rc;
+    if ((rc = P.begin(16384))) return rc;
+    uint8_t *din = (uint8_t *)P.in_fill(0, 4096);
+    int32_t *hout = (int32_t *)P.out_host(64);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto once = [&]() -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (mode == 1) e = hipMemcpyAsync(din, P.h, 4096, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_floor, dim3(1), dim3(64), 0, c->stream, mode == 2 ? hout : (int32_t *)nullptr);
+        if (mode == 1) e = hipMemcpyAsync(P.h + 8192, din, 4096, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(c->stream);
+    };
+    for (int i = 0; i < 20; i++) HIPCHK(c, once());
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < iters; i++) HIPCHK(c, once());
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *us_per_call = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / iters;
     return ORBHIP_OK;
 }

@@ -266,7 +266,10 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
     int qt, ns, rows;
     knn2_shape(nq, ndb, &qt, &ns, &rows);
     static const int mfmaEnv = ORB_SWITCH("KNN2_MFMA", 1);
-    if (mfmaEnv)
+    // (the matrix kernel reads queries as 16-byte words and database rows as dwords: a caller's device pointer that is not
+    // aligned like that takes the scalar kernel, whose accesses are dword / byte-safe scalar loads)
+    const bool aligned = (reinterpret_cast<uintptr_t>(q) & 15u) == 0 && (reinterpret_cast<uintptr_t>(db) & 3u) == 0;
+    if (mfmaEnv && aligned)
         hipLaunchKernelGGL(k_knn2_mfma, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
     else
         hipLaunchKernelGGL(k_knn2, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
@@ -501,7 +504,7 @@ void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, 
 {
     if (B <= 0) return;
     static const int mfmaEnv = ORB_SWITCH("KNN2_MFMA", 1);
-    if (mfmaEnv)
+    if (mfmaEnv && (reinterpret_cast<uintptr_t>(desc) & 15u) == 0)
         hipLaunchKernelGGL(k_knn2_seq_mfma, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag, best_idx,
                            best_d, second_d);
     else

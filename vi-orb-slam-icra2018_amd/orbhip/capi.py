@@ -57,7 +57,7 @@ SYMBOLS = [
     "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
     "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
     "orbhip_set_put", "orbhip_set_has", "orbhip_set_drop", "orbhip_search_by_bow_sets", "orbhip_window_best_set",
-    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
+    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_debug_roundtrip", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
 ]
 
 
@@ -177,6 +177,7 @@ def load():
     L.orbhip_set_fingerprint.argtypes = [vp, vp, i32]
     L.orbhip_set_fingerprint.restype = C.c_uint64
     L.orbhip_frame_build.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, ip, vp, vp, vp, vp, vp]
+    L.orbhip_debug_roundtrip.argtypes = [vp, i32, i32, C.POINTER(C.c_double)]
     L.orbhip_frame_fingerprint.argtypes = [vp]
     L.orbhip_frame_fingerprint.restype = C.c_uint64
     L.orbhip_set_put_from_frame.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, i32]

@@ -105,6 +105,48 @@ def make_frames(seed, width, height, count, start=0):
     return np.stack([warp_frame(scene, width, height, start + t) for t in range(count)])
 
 
+CONTENT_CLASSES = ("textured", "indoor_sparse", "white_noise", "low_contrast")
+
+
+def make_frames_class(kind, seed, width, height, count):
+    """`count` frames of one of the content classes bench.py reports (FAST's cost depends on what it looks at):
+      textured       make_frames: shapes of every contrast over band-limited noise (the headline's frames)
+      indoor_sparse  large flat regions (walls, floor) of slowly varying brightness with sensor noise of 1-2 levels, a dozen
+                     objects with hard edges and a few posters of fine texture: most cells find nothing at iniThFAST and many
+                     find nothing at minThFAST either
+      white_noise    independent uniform pixels: most pixels pass the compass test and many are corners (the dense fallbacks of
+                     the FAST kernel's lists)
+      low_contrast   the textured scene squeezed to a quarter of its range around mid-grey: the second FAST pass (minThFAST)
+                     does most of the work"""
+    if kind == "textured":
+        return make_frames(seed, width, height, count)
+    rng = np.random.default_rng(seed)
+    if kind == "white_noise":
+        return rng.integers(0, 256, (count, height, width), dtype=np.uint8)
+    if kind == "low_contrast":
+        f = make_frames(seed, width, height, count).astype(np.float32)
+        return np.clip(np.rint((f - 118.0) * 0.25 + 118.0), 0, 255).astype(np.uint8)
+    if kind == "indoor_sparse":
+        margin = 96
+        H, W = height + 2 * margin, width + 2 * margin
+        img = np.full((H, W), 135.0, np.float32) + _smooth_noise(rng, H, W, 200, 22.0)
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        img[yy > 0.62 * H + 0.05 * xx] -= 40.0                                     # the floor
+        for _ in range(14):                                                         # furniture: flat boxes with hard edges
+            cx, cy, hw, hh = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(20, 90), rng.uniform(20, 110)
+            th = rng.uniform(-0.2, 0.2)
+            u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+            v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+            img[(np.abs(u) <= hw) & (np.abs(v) <= hh)] = rng.uniform(40, 220)
+        for _ in range(4):                                                          # posters: fine texture
+            x0, y0 = int(rng.uniform(0, W - 120)), int(rng.uniform(0, H - 90))
+            img[y0:y0 + 90, x0:x0 + 120] = 128 + _smooth_noise(rng, 90, 120, 4, 60.0)
+        img += rng.standard_normal((H, W)).astype(np.float32) * 1.2
+        scene = np.clip(img, 0, 255)
+        return np.stack([warp_frame(scene, width, height, t) for t in range(count)])
+    raise ValueError("unknown content class %r" % (kind,))
+
+
 def make_descriptor_db(seed, n):
     """Random 256-bit descriptors (n, 32) uint8 -- SURVEY 8d config 5 database."""
     rng = np.random.default_rng(seed)
