@@ -278,7 +278,7 @@ int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoint
 
         const int &nPredictedLevel = pMP->mnTrackScaleLevel;
 
-        // The size of the window will depend on the viewing direction
+        // window radius: narrow when the point is seen almost head-on, wider otherwise (ref: :130-138), times th on request
         float r = RadiusByViewingCos(pMP->mTrackViewCos);
         if(bFactor)
             r*=th;
@@ -424,7 +424,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
         const float maxDistance = pMP->GetMaxDistanceInvariance();
         const float minDistance = pMP->GetMinDistanceInvariance();
 
-        // Depth must be inside the scale pyramid of the image
+        // a point nearer or farther than the range its scale invariance covers cannot be matched at any level (ref: :1394-1396)
         if(dist3D<minDistance || dist3D>maxDistance)
             continue;
 
@@ -626,37 +626,29 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const
     vector<int32_t> bestIdx, bestDist;
     run_window_best(pKF, q, qdesc, true, bestIdx, bestDist);
 
-    int nFused=0;
-    for(int i=0; i<nMPs; i++)
-    {
-        MapPoint* pMP = vpMapPoints[i];
-        if(!pMP)
-            continue;
-        if(pMP->isBad() || pMP->IsInKeyFrame(pKF))
-            continue;
-        // If there is already a MapPoint replace otherwise add new measurement
-        if(bestIdx[i]>=0 && bestDist[i]<=TH_LOW)
-        {
-            MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[i]);
-            if(pMPinKF)
-            {
-                if(!pMPinKF->isBad())
-                {
-                    if(pMPinKF->Observations()>pMP->Observations())
-                        pMP->Replace(pMPinKF);
-                    else
-                        pMPinKF->Replace(pMP);
-                }
+    // The device search is done; the map edits follow on the host, point by point in the caller's order, because an edit can
+    // change what a later point of the same call sees: a point replaced a moment ago is bad now, a feature claimed a moment
+    // ago holds a point now.  Both are therefore looked at here, not before the search (ref: :847-848 and :951-972).
+    int fused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint *cand = vpMapPoints[i];
+        const bool usable = cand && !cand->isBad() && !cand->IsInKeyFrame(pKF);
+        if (!usable || bestIdx[i] < 0 || bestDist[i] > TH_LOW) continue;
+        const int feat = bestIdx[i];
+        if (MapPoint *held = pKF->GetMapPoint(feat)) {
+            // the feature has a point already: the two are one landmark, the one seen from fewer key frames gives way
+            if (!held->isBad()) {
+                if (held->Observations() > cand->Observations()) cand->Replace(held);
+                else held->Replace(cand);
             }
-            else
-            {
-                pMP->AddObservation(pKF,bestIdx[i]);
-                pKF->AddMapPoint(pMP,bestIdx[i]);
-            }
-            nFused++;
+        } else {
+            // a free feature: the candidate gains an observation and the key frame a point
+            cand->AddObservation(pKF, feat);
+            pKF->AddMapPoint(cand, feat);
         }
+        fused++;      // (counted also when the held point was bad and nothing changed, as in the reference)
     }
-    return nFused;
+    return fused;
 }
 
 int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, float th, vector<MapPoint *> &vpReplacePoint)
@@ -666,7 +658,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     float tcw[3], Ow[3];
     decompose_sim3(Scw, Rcw, tcw, Ow);
 
-    // Set of MapPoints already found in the KeyFrame
+    // points the key frame observes already are left out of the search (:995-996)
     const set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
 
     const int nPoints = vpPoints.size();
@@ -687,40 +679,34 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     vector<int32_t> bestIdx, bestDist;
     run_window_best(pKF, q, qdesc, false, bestIdx, bestDist);
 
-    int nFused=0;
-    for(int iMP=0; iMP<nPoints; iMP++)
-    {
-        if(bestIdx[iMP]<0 || bestDist[iMP]>TH_LOW)
-            continue;
-        MapPoint* pMP = vpPoints[iMP];
-        MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[iMP]);
-        if(pMPinKF)
-        {
-            if(!pMPinKF->isBad())
-                vpReplacePoint[iMP] = pMPinKF;
+    // Loop closing does not replace points here (the caller does, under the map mutex): a feature that holds a good point is
+    // reported through vpReplacePoint, a free one takes the candidate at once (ref: :1079-1096).
+    int fused = 0;
+    for (int i = 0; i < nPoints; i++) {
+        const int feat = bestIdx[i];
+        if (feat < 0 || bestDist[i] > TH_LOW) continue;
+        MapPoint *held = pKF->GetMapPoint(feat);
+        if (!held) {
+            vpPoints[i]->AddObservation(pKF, feat);
+            pKF->AddMapPoint(vpPoints[i], feat);
+        } else if (!held->isBad()) {
+            vpReplacePoint[i] = held;
         }
-        else
-        {
-            pMP->AddObservation(pKF,bestIdx[iMP]);
-            pKF->AddMapPoint(pMP,bestIdx[iMP]);
-        }
-        nFused++;
+        fused++;
     }
-    return nFused;
+    return fused;
 }
 
 int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12,
                              const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)
 {
-    // ref: src/ORBmatcher.cc:1102-1326
-    //Camera 1 from world
+    // ref: src/ORBmatcher.cc:1102-1326.  Poses of the two key frames (world -> camera) and the similarity between the cameras in
+    // both directions; the two projection searches run on the device, the mutual-agreement pass on the host.
     const cv::Mat R1w = pKF1->GetRotation();
     const cv::Mat t1wM = pKF1->GetTranslation();
-    //Camera 2 from world
     const cv::Mat R2w = pKF2->GetRotation();
     const cv::Mat t2wM = pKF2->GetTranslation();
 
-    //Transformation between cameras
     cv::Mat sR12, sR21;
     scale3(R12, (double)s12, false, sR12);                     // s12*R12
     scale3(R12, 1.0/s12, true, sR21);                          // (1.0/s12)*R12.t()
@@ -734,22 +720,18 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
     const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
     const int N2 = vpMapPoints2.size();
 
+    // what the caller has matched already stays out of both searches (:1136-1151)
     vector<bool> vbAlreadyMatched1(N1,false);
     vector<bool> vbAlreadyMatched2(N2,false);
-
-    for(int i=0; i<N1; i++)
-    {
-        MapPoint* pMP = vpMatches12[i];
-        if(pMP)
-        {
-            vbAlreadyMatched1[i]=true;
-            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
-            if(idx2>=0 && idx2<N2)
-                vbAlreadyMatched2[idx2]=true;
-        }
+    for (int i = 0; i < N1; i++) {
+        MapPoint *known = vpMatches12[i];
+        if (!known) continue;
+        vbAlreadyMatched1[i] = true;
+        const int at2 = known->GetIndexInKeyFrame(pKF2);
+        if (at2 >= 0 && at2 < N2) vbAlreadyMatched2[at2] = true;
     }
 
-    // Transform from KF1 to KF2 and search; then from KF2 to KF1
+    // direction 0: the points of key frame 1 into key frame 2; direction 1: the other way round
     vector<int32_t> vnMatch1, vnMatch2, dist1, dist2;
     for (int dir = 0; dir < 2; dir++)
     {
@@ -783,25 +765,16 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
     for(int i1=0; i1<N1; i1++) if(dist1[i1]>TH_HIGH) vnMatch1[i1] = -1;
     for(int i2=0; i2<N2; i2++) if(dist2[i2]>TH_HIGH) vnMatch2[i2] = -1;
 
-    // Check agreement
-    int nFound = 0;
-
-    for(int i1=0; i1<N1; i1++)
-    {
-        int idx2 = vnMatch1[i1];
-
-        if(idx2>=0)
-        {
-            int idx1 = vnMatch2[idx2];
-            if(idx1==i1)
-            {
-                vpMatches12[i1] = vpMapPoints2[idx2];
-                nFound++;
-            }
+    // a match counts when the two directions name each other (:1306-1323)
+    int found = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        const int i2 = vnMatch1[i1];
+        if (i2 >= 0 && vnMatch2[i2] == i1) {
+            vpMatches12[i1] = vpMapPoints2[i2];
+            found++;
         }
     }
-
-    return nFound;
+    return found;
 }
 
 int ComputeDistinctiveDescriptors(const vector<MapPoint*> &vpMapPoints)
