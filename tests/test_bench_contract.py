@@ -31,6 +31,17 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 1 and c["unit"] == "frames/s" and c["sample"]
     assert d["cpu_baseline_all_cores"]["cores"] >= 1
     assert d["verified_frames"] == 8                             # GPU outputs of the first frames equal the oracle's
+    # r04: one roofline entry per streaming kernel of the step, measured in this run; the matrix-pipe roofline of the 1M query;
+    # the content classes, each verified; the committed counters flagged when they no longer describe the kernel
+    names = [e["kernel"] for e in d["rooflines"]]
+    assert any(n.startswith("k_resize") for n in names) and "k_blur" in names and "k_fast" in names and any(n.startswith("k_describe") for n in names)
+    for e in d["rooflines"]:
+        assert e["ms"] > 0 and e["algorithmic_bytes"] > 0 and abs(e["frac"] - e["achieved_GBps"] / 8000.0) < 1e-3
+    m = d["roofline_mfma"]
+    assert m["bound"] == "mfma" and 0 < m["frac"] < 1 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
+    for kind in ("textured", "indoor_sparse", "white_noise", "low_contrast"):
+        assert d["content"][kind]["verified_frames"] == 2 and d["content"][kind]["value"] > 1000
+    assert d["roofline"]["traffic_stale"] in (True, False)
 
 
 def _bench(args, env=None, timeout=600):

@@ -2,7 +2,7 @@
 # One GPU call: activity counters of k_fast for several prebuilt libraries (two passes).   tools/ab_fast_pmc2.sh lib1.so lib2.so ...
 LIB=vi-orb-slam-icra2018_amd/csrc/liborbhip.so
 cp $LIB /tmp/liborbhip_keep1.so
-A="--steps 2 --warmup 1 --batch 1024 --cpu-frames 0 --pipelined 0 --verify 0 --host-batch 0 --configs 0"
+A="--steps 2 --warmup 1 --batch 1024 --cpu-frames 0 --pipelined 0 --verify 0 --host-batch 0 --configs 0 --content 0"
 for v in "$@"; do
   cp $v $LIB
   echo "== $(basename $v)"

@@ -5,7 +5,7 @@
 OUT=gpurun_out/r04_fast1; mkdir -p $OUT
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_more.py tests/test_pipeline.py -m gpu -x -q 2>&1 | tail -4 > $OUT/parity.txt
 VERIFY=8 tools/ab_libs.sh 3 build_ab/base.so build_ab/d16.so > $OUT/ab.txt 2>&1
-BA="--cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --verify 8"
+BA="--cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --content 0 --verify 8"
 for i in 1 2 3; do
   for x in 0 4; do
     echo -n "FAST_XCD=$x " >> $OUT/xcd.txt
@@ -18,6 +18,6 @@ for x in 0 4; do
 done
 for p in 1 2 3 4 5 8 99; do
   echo -n "stop<=$p " >> $OUT/lds_conflict.txt
-  ORBHIP_FAST_PHASES=$p bash tools/pmc_gpu.sh ldsc_$p "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU" --steps 2 --warmup 1 --batch 1024 --cpu-frames 0 --pipelined 0 --verify 0 --host-batch 0 --configs 0 2>&1 | grep -E "^k_fast" >> $OUT/lds_conflict.txt
+  ORBHIP_FAST_PHASES=$p bash tools/pmc_gpu.sh ldsc_$p "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU" --steps 2 --warmup 1 --batch 1024 --cpu-frames 0 --pipelined 0 --verify 0 --host-batch 0 --configs 0 --content 0 2>&1 | grep -E "^k_fast" >> $OUT/lds_conflict.txt
 done
 cat $OUT/parity.txt $OUT/ab.txt $OUT/xcd.txt $OUT/xcd_traffic.txt $OUT/lds_conflict.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # r04: frame-per-XCD grid of k_fast_fix without the division (ablation library, ORBHIP_FAST_XCD=0 / 4), time and fabric traffic
 OUT=gpurun_out/r04_fast2; mkdir -p $OUT; rm -f $OUT/*.txt
-BA="--cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --verify 8"
+BA="--cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --content 0 --verify 8"
 for i in 1 2 3; do
   for x in 0 4; do
     echo -n "FAST_XCD=$x " >> $OUT/xcd.txt
