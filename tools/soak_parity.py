@@ -329,6 +329,49 @@ def main():
                 if not (np.array_equal(hw, wd) and np.array_equal(hwt, wt) and np.array_equal(hnid, nid)):
                     print("MISMATCH vocab", seed)
                     sys.exit(1)
+            # the Frame constructor in one launch (orbhip_frame_build) on random calibrations: extraction, undistortion, grid and
+            # transform against the oracle's four calls; every third time the frame then enters a matcher's resident sets from
+            # the device block and is searched against the other frame
+            Kc = np.array([[w * rng.uniform(0.5, 1.1), 0, w * rng.uniform(0.4, 0.6)], [0, w * rng.uniform(0.5, 1.1), h * rng.uniform(0.4, 0.6)],
+                           [0, 0, 1]], np.float32)
+            nd = int(rng.choice([0, 4, 4, 5, 8]))
+            Dc = (rng.normal(0, 1, nd) * np.array([0.25, 0.08, 0.001, 0.001, 0.02, 0.01, 0.01, 0.01][:nd])).astype(np.float32)
+            if nd and rng.random() < 0.15:
+                Dc[0] = 0.0                           # the reference's shortcut: mvKeysUn = mvKeys
+            lu = int(rng.choice([-1, 0, 2, 4]))
+            use_grid = rng.random() < 0.85
+            gpf = guided.grid_params(-0.05 * w, 1.04 * w, -0.03 * h, 1.05 * h)
+            fb = ex.frame_build(frames[1], Kc, Dc, gpf if use_grid else None, min(lu, 4))
+            kun = k1.copy()
+            if nd and Dc[0] != 0:
+                xy = oracle.undistort_points(np.stack([k1["x"], k1["y"]], 1), Kc, Dc, Kc)
+                kun["x"], kun["y"] = xy[:, 0], xy[:, 1]
+            okf = fb["kps"].tobytes() == k1.tobytes() and fb["kps_un"].tobytes() == kun.tobytes() and np.array_equal(fb["desc"], d1)
+            if okf and use_grid:
+                go, gi = oracle.grid_build(kun, gpf)
+                okf = np.array_equal(fb["cell_off"], go) and np.array_equal(fb["cell_idx"], gi)
+            if okf and lu >= 0:
+                wd, wt, nid = V.transform(d1, min(lu, 4))
+                okf = np.array_equal(fb["word_id"], wd) and np.array_equal(fb["weight"], wt) and np.array_equal(fb["node_id"], nid)
+            if not okf:
+                print("MISMATCH frame_build", w, h, nf, nlev, scale, ini, mn, seed, nd, lu, use_grid)
+                sys.exit(1)
+            stats["frame_build"] = stats.get("frame_build", 0) + 1
+            if n % 3 == 0 and lu >= 0:
+                from orbhip.extractor import ORBmatcher
+                Mf = ORBmatcher(0.7, True)
+                fvb = oracle.feature_vector(fb["node_id"], fb["weight"])
+                wd0, wt0, nid0 = V.transform(d0, min(lu, 4))
+                fva = oracle.feature_vector(nid0, wt0)
+                Mf.put_set_from_frame(21, ex, fvb)
+                Mf.put_set(22, k0, d0, fva)
+                v0 = (rng.random(len(k0)) < 0.8).astype(np.uint8)
+                a3 = Mf.SearchByBoW_sets(22, v0, len(k0), 21, None, len(k1))
+                b3 = oracle.search_by_bow(d0, v0, k0["angle"], fva, d1, None, k1["angle"], fvb, th=50, th_mode=0, nnratio=0.7, check_ori=True)
+                if a3[0] != b3[0] or not np.array_equal(a3[1], b3[1]) or not np.array_equal(a3[2], b3[2]):
+                    print("MISMATCH bow from frame block", w, h, nf, seed)
+                    sys.exit(1)
+                Mf.close()
             # guided search / initialisation / triangulation
             gp = guided.grid_params(0, w, 0, h)
             sf = np.array(list(ref.params.mvScaleFactor)[:nlev], np.float32)
