@@ -176,7 +176,7 @@ def committed_counters(batch, contexts):
     """Per-launch figures of k_fast from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
     tools/summarize_prof.py from the separate --pmc passes of the round's profile script, default configuration): HBM-side bytes
     (FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), vector wave-instructions (SQ_INSTS_VALU), the issue weight
-    of the kernel's instruction mix (tools/valu_mix.py) and the sha256 of the kernel source they were taken from.  {} when the
+    of the kernel's instruction mix (tools/update_traffic_meta.py) and the sha256 of the kernel source they were taken from.  {} when the
     file does not match the run's configuration.  The counters cannot be collected inside a timed bench run (a --pmc pass
     serialises the kernels); main() marks them stale when the kernel source or the launch time has moved since."""
     try:
@@ -894,7 +894,7 @@ def main():
                         "device (profiles/r03/valu_rates.txt) 16 simple opcodes (add / sub / and / or / xor / mov / right shifts, f32 "
                         "add / mul / fma, v_bitop3) issue in 2, everything else (v_lerp_u8, v_pk_minimum3_f16, v_perm, compares, "
                         "selects, left shifts ...) in 4: frac_weighted = frac x issue_weight, the static share of the two classes in "
-                        "the kernel's ISA (tools/valu_mix.py), is the fraction of the issue cycles really taken"
+                        "the kernel's ISA (tools/update_traffic_meta.py), is the fraction of the issue cycles really taken"
                         % float(ctr.get("clock_ghz", 2.4))},
             "stage_ms": {"pyramid": round(float(stage[0]), 4), "fast": round(float(stage[1]), 4),
                          "quadtree": round(float(stage[2]), 4), "blur": round(float(stage[3]), 4),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build container, after a tools/r04_profile.sh run: completes gpurun_out/prof_<tag>/traffic.json with what ties the counters
-to a kernel -- the sha256 of csrc/k_fast.hip and the issue weight of its instruction mix (tools/valu_mix.py on the ISA of the
+to a kernel -- the sha256 of csrc/k_fast.hip and the issue weight of its instruction mix (static count over the ISA of the
 launched instance) -- and copies the summaries into profiles/<tag>/ and profiles/traffic.json (what bench.py reads).
 usage: python tools/update_traffic_meta.py gpurun_out/prof_r04 [kernel-name-substring]"""
 import hashlib
