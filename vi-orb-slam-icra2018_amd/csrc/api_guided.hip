@@ -267,22 +267,26 @@ extern "C" int orbhip_search_for_initialization(orbhip_ctx *c, const orbhip_keyp
     const int32_t cnts[4] = {n1, n2, 0, 0};
     const orbhip_keypoint *dk1 = (const orbhip_keypoint *)P.in(kps1, (size_t)n1 * 28), *dk2 = (const orbhip_keypoint *)P.in(kps2, (size_t)n2 * 28);
     const uint8_t *dd1 = (const uint8_t *)P.in(desc1, (size_t)n1 * 32), *dd2 = (const uint8_t *)P.in(desc2, (size_t)n2 * 32);
-    // counts (incl. the number of matches) | vbPrevMatched (in and out) | matches: adjacent, one copy back
+    // the matches and their count are stored by the kernel straight into the page-locked block (no copy command behind it: that
+    // node started ~8 us after the kernel ended); vbPrevMatched is an input on the device and is brought up to date on the host
+    // from the matches -- the reference's last loop, vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt (:511-515)
     int32_t *dc = (int32_t *)P.in(cnts, 16);
     float *dpm = (float *)P.in(prev_matched, (size_t)n1 * 8);
-    int32_t *dm = (int32_t *)P.out((size_t)n1 * 4);
-    const size_t backEnd = (size_t)((uint8_t *)dm - P.d) + (size_t)n1 * 4;
     int32_t *doff = (int32_t *)P.out((ORBHIP_GRID_CELLS + 1) * 4), *didx = (int32_t *)P.out((size_t)n2 * 4);   // device scratch
+    int32_t *hm = (int32_t *)P.out_host((size_t)n1 * 4), *hn = (int32_t *)P.out_host(16);
     if ((rc = P.upload())) return rc;
     if ((rc = orbhip_grid_build_device(c, dk2, dc + 1, n2, 1, min_x, min_y, inv_w, inv_h, doff, didx))) return rc;
     if ((rc = orbhip_search_for_initialization_device(c, dk1, dd1, dc, n1, dk2, dd2, dc + 1, n2, 1, min_x, min_y, inv_w, inv_h, doff,
-                                                      didx, dpm, window_size, nnratio, check_ori, dm, dc + 2)))
+                                                      didx, dpm, window_size, nnratio, check_ori, hm, hn)))
         return rc;
-    P.off = backEnd;
-    if ((rc = P.download(dc))) return rc;
-    memcpy(matches12, P.host(dm), (size_t)n1 * 4);
-    memcpy(prev_matched, P.host(dpm), (size_t)n1 * 8);
-    if (nmatches) *nmatches = ((const int32_t *)P.host(dc))[2];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(matches12, hm, (size_t)n1 * 4);
+    for (int i = 0; i < n1; i++)
+        if (hm[i] >= 0 && hm[i] < n2) {
+            prev_matched[2 * i] = kps2[hm[i]].x;
+            prev_matched[2 * i + 1] = kps2[hm[i]].y;
+        }
+    if (nmatches) *nmatches = hn[0];
     return ORBHIP_OK;
 }
 
