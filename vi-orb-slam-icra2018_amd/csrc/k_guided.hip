@@ -490,12 +490,21 @@ __global__ __launch_bounds__(256) void k_window_best_row(const uint8_t *__restri
     }
 }
 
+// Minimum over the wave.  The four row steps as v_min_i32 with a DPP source operand (the builtin form compiles to v_mov_b32 +
+// s_nop + v_mov_b32_dpp + v_min_i32 per step: in the one-wave kernels of this file, whose time is their instruction count,
+// that was a quarter of a feature's instructions); the s_nop covers the VALU-write -> DPP-read hazard of each step.
 __device__ __forceinline__ int wave_min_i(int v)
 {
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    asm volatile("s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
     return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
@@ -1030,18 +1039,24 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
                                                     const int32_t *__restrict__ cellIdx2, int cap1pad, int keff,
                                                     const uint32_t *__restrict__ tuples, const int32_t *__restrict__ tcount,
                                                     float nnratio, int check_ori, int th_low,
-                                                    int32_t *__restrict__ matches12, int32_t *__restrict__ nmatches)
+                                                    int32_t *__restrict__ matches12, int32_t *__restrict__ nmatches, int stage)
 {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_tup[64 * INIT_K];
     __shared__ int s_hist[30];
     __shared__ int s_keep[3];
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int n1 = min(cnt1[b], cap1);   // (features of frame 2 beyond cnt2 are not in its grid)
+    int n1 = min(cnt1[b], cap1);   // (features of frame 2 beyond cnt2 are not in its grid)
     int *s_md = reinterpret_cast<int *>(s_dyn);   // vMatchedDistance [cap2]
     int *s_m21 = s_md + cap2;                     // vnMatches21 [cap2]
     int *s_m12 = s_m21 + cap2;                    // vnMatches12 [cap1]
     int *s_acc = s_m12 + cap1;                    // feature of frame 2 at the time i1 was accepted, or -1 [cap1]
+    // What the wave would otherwise fetch one dependent round trip at a time (r04 trace: 106 us per call, most of it ~60 such
+    // trips of ~1.5 us -- the list lengths per round of 64 features, the two angles per accepted feature in both passes of the
+    // rotation check, the matched keypoint's position in the last loop) is read once, coalesced, with the loads in flight together:
+    int *s_tc = s_acc + cap1;                                         // list lengths [cap1pad]
+    float *s_a1 = reinterpret_cast<float *>(s_tc + cap1pad);          // angles of frame 1 [cap1]
+    float *s_k2 = s_a1 + cap1;                                        // x, y, angle of frame 2 [3 * cap2]
     const orbhip_keypoint *K1 = kps1 + (size_t)b * cap1, *K2 = kps2 + (size_t)b * cap2;
     const uint4 *D2 = reinterpret_cast<const uint4 *>(desc2 + (size_t)b * cap2 * 32);
     const int32_t *O = cellOff2 + (size_t)b * (GCELLS + 1), *I = cellIdx2 + (size_t)b * cap2;
@@ -1055,26 +1070,185 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
         s_acc[i] = -1;
     }
     if (lane < 30) s_hist[lane] = 0;
+    if (stage) {   // (uniform: the tables fit the LDS beside the match tables -- frames of up to ~3000 features)
+        const int n2 = min(cnt2[b], cap2);
+        const int32_t *TC = tcount + (size_t)b * cap1pad;
+        constexpr int U = 8;   // loads in flight per lane
+        for (int i0 = 0; i0 < cap1pad; i0 += 64 * U) {
+            int v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + 64 * u + lane;
+                v[u] = i < n1 ? TC[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + 64 * u + lane;
+                if (i < cap1pad) s_tc[i] = v[u];
+            }
+        }
+        for (int i0 = 0; i0 < n1; i0 += 64 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + 64 * u + lane;
+                v[u] = i < n1 ? K1[i].angle : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + 64 * u + lane;
+                if (i < n1) s_a1[i] = v[u];
+            }
+        }
+        for (int i0 = 0; i0 < n2; i0 += 64 * (U / 2)) {
+            float x[U / 2], y[U / 2], a[U / 2];
+#pragma unroll
+            for (int u = 0; u < U / 2; u++) {
+                const int i = min(i0 + 64 * u + lane, n2 - 1);
+                x[u] = K2[i].x;
+                y[u] = K2[i].y;
+                a[u] = K2[i].angle;
+            }
+#pragma unroll
+            for (int u = 0; u < U / 2; u++) {
+                const int i = i0 + 64 * u + lane;
+                if (i < n2) {
+                    s_k2[3 * i] = x[u];
+                    s_k2[3 * i + 1] = y[u];
+                    s_k2[3 * i + 2] = a[u];
+                }
+            }
+        }
+    }
     WAVE_LDS_SYNC();
+    const int stop = stage >> 4;            (void)stop;   // timing ablation only (liborbhip_ablation.so, ORBHIP_INIT_STOP); 0 in the shipped library
+    stage &= 15;
+    ORB_ABL_IF(stop == 1) return;           // tables staged
+    ORB_ABL_IF(stop == 3) n1 = min(n1, 64); // one round of the feature loop
     int nm = 0;
     const uint4 *Tg = reinterpret_cast<const uint4 *>(tuples + (size_t)b * cap1pad * INIT_K);
     for (int base = 0; base < n1; base += 64) {
         const int myq = base + lane;
-        const int myc = myq < n1 ? tcount[(size_t)b * cap1pad + myq] : 0;
+        const int myc = myq < n1 ? (stage ? s_tc[myq] : tcount[(size_t)b * cap1pad + myq]) : 0;
         unsigned long long todo = __ballot(myc > 0);
         if (todo) {
+            // the 64 lists of this round: all INIT_K slots only if a list is longer than half of them (a window of 100 pixels
+            // holds ~30 level-0 features; the unused upper halves were half of the kernel's loads)
             uint4 *s4 = reinterpret_cast<uint4 *>(s_tup);
             const uint4 *src = Tg + (size_t)base * (INIT_K / 4);
+            if (__ballot(myc > INIT_K / 2)) {
 #pragma unroll 8
-            for (int k = 0; k < INIT_K / 4; k++) s4[k * 64 + lane] = src[k * 64 + lane];
+                for (int k = 0; k < INIT_K / 4; k++) s4[k * 64 + lane] = src[k * 64 + lane];
+            } else {
+                // lane -> (list, 16-byte piece of its lower half): INIT_K / 8 = 16 pieces per list, four lists per trip
+                const int piece = lane & (INIT_K / 8 - 1), lst = lane / (INIT_K / 8);
+#pragma unroll 8
+                for (int k = 0; k < 64 / (64 / (INIT_K / 8)); k++) {
+                    const int o = ((64 / (INIT_K / 8)) * k + lst) * (INIT_K / 4) + piece;
+                    s4[o] = src[o];
+                }
+            }
             WAVE_LDS_SYNC();
         }
+        // One wave walks the features in order, so the kernel's time is the instructions and LDS round trips of a feature (r04
+        // counters: ~88 vector + 37 scalar instructions and ~4 round trips each, 106 us for ~220 features with candidates) --
+        // not its global loads (staged above), not the first two round trips (requesting them a feature ahead changed
+        // nothing).  Lists of up to 32 candidates -- a window of 100 pixels holds ~30 level-0 features -- are therefore taken
+        // TWO AT A TIME, one per 32-lane half: the same instruction stream reduces both (the DPP steps stay inside 16-lane rows,
+        // the two rows of a half are joined by scalar minima), the features are then accepted in index order, and when the
+        // first one's match is a candidate of the second (whose vMatchedDistance was read before that match existed) the second
+        // half alone is reduced again.  Longer lists: one feature per trip over the whole wave, as before.
+        const int limP = min(32, keff);
+        auto accept = [&](int i1, int bestIdx, int bestDist, int bestDist2) -> bool {
+            if (!(bestIdx >= 0 && bestDist <= th_low && (float)bestDist < __fmul_rn((float)bestDist2, nnratio))) return false;   // :458-460
+            const int old = s_m21[bestIdx];
+            if (old >= 0) nm--;
+            if (lane == 0) {
+                if (old >= 0) s_m12[old] = -1;
+                s_m12[i1] = bestIdx;
+                s_m21[bestIdx] = i1;
+                s_md[bestIdx] = bestDist;
+                s_acc[i1] = bestIdx;
+            }
+            nm++;
+            WAVE_LDS_SYNC();
+            return true;
+        };
         while (todo) {
-            const int j = __builtin_ctzll(todo);
+            const int j = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const int i1 = base + j;
             const int c = __builtin_amdgcn_readlane(myc, j);
             int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx = -1;
+            if (c <= limP) {
+                // this feature in lanes 0..31 and, if its list is short too, the next one in lanes 32..63
+                int jB = -1, cB = 0;
+                if (todo) {
+                    const int jn = (int)__builtin_ctzll(todo);
+                    const int cn = __builtin_amdgcn_readlane(myc, jn);
+                    if (cn <= limP) {
+                        jB = jn;
+                        cB = cn;
+                        todo &= todo - 1;
+                    }
+                }
+                const int hi = lane >> 5, p = lane & 31;
+                const bool has = hi ? (jB >= 0 && p < cB) : p < c;
+                const uint32_t t = has ? s_tup[(hi ? jB : j) * INIT_K + p] : 0u;
+                const int d = (int)(t & 511u), idx = (int)(t >> 9);
+                int md = has ? s_md[idx] : 0;
+                int key = (has && !(md <= d)) ? ((d << 16) | p) : 0x7FFFFFFF;   // :443-444
+                auto row_min = [&](int v) {   // every lane: the minimum of its 16-lane row
+                    asm volatile("s_nop 1\n\t"
+                                 "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 1"
+                                 : "+v"(v));
+                    return v;
+                };
+                int r1 = row_min(key);
+                const int kA1 = min(__builtin_amdgcn_readlane(r1, 0), __builtin_amdgcn_readlane(r1, 16));
+                int kB1 = min(__builtin_amdgcn_readlane(r1, 32), __builtin_amdgcn_readlane(r1, 48));
+                // second minima: list positions are unique inside a half, one lane holds the first
+                int r2 = row_min(key == (hi ? kB1 : kA1) ? 0x7FFFFFFF : key);
+                const int kA2 = min(__builtin_amdgcn_readlane(r2, 0), __builtin_amdgcn_readlane(r2, 16));
+                int kB2 = min(__builtin_amdgcn_readlane(r2, 32), __builtin_amdgcn_readlane(r2, 48));
+                if (kA1 != 0x7FFFFFFF) {
+                    bestDist = kA1 >> 16;
+                    bestIdx = (int)((uint32_t)__builtin_amdgcn_readlane((int)t, kA1 & 31) >> 9);
+                    if (kA2 != 0x7FFFFFFF) bestDist2 = kA2 >> 16;
+                }
+                const bool tookA = accept(i1, bestIdx, bestDist, bestDist2);
+                if (jB >= 0) {
+                    if (tookA) {
+                        // feature A's match is a candidate of B: B saw vMatchedDistance of it before the match existed
+                        const bool stale = hi && has && idx == bestIdx;
+                        if (__ballot(stale)) {
+                            if (stale) {
+                                md = bestDist;
+                                key = !(md <= d) ? ((d << 16) | p) : 0x7FFFFFFF;
+                            }
+                            r1 = row_min(key);
+                            kB1 = min(__builtin_amdgcn_readlane(r1, 32), __builtin_amdgcn_readlane(r1, 48));
+                            r2 = row_min(key == kB1 ? 0x7FFFFFFF : key);
+                            kB2 = min(__builtin_amdgcn_readlane(r2, 32), __builtin_amdgcn_readlane(r2, 48));
+                        }
+                    }
+                    int bD = 0x7FFFFFFF, bD2 = 0x7FFFFFFF, bI = -1;
+                    if (kB1 != 0x7FFFFFFF) {
+                        bD = kB1 >> 16;
+                        bI = (int)((uint32_t)__builtin_amdgcn_readlane((int)t, 32 + (kB1 & 31)) >> 9);
+                        if (kB2 != 0x7FFFFFFF) bD2 = kB2 >> 16;
+                    }
+                    (void)accept(base + jB, bI, bD, bD2);
+                }
+                continue;
+            }
             if (c <= keff) {
                 int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
                 for (int p = lane; p < c; p += 64) {
@@ -1117,27 +1291,16 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
                     }
                 });
             }
-            if (bestIdx >= 0 && bestDist <= th_low && (float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {   // :458-460
-                const int old = s_m21[bestIdx];
-                if (old >= 0) nm--;
-                if (lane == 0) {
-                    if (old >= 0) s_m12[old] = -1;
-                    s_m12[i1] = bestIdx;
-                    s_m21[bestIdx] = i1;
-                    s_md[bestIdx] = bestDist;
-                    s_acc[i1] = bestIdx;
-                }
-                nm++;
-                WAVE_LDS_SYNC();
-            }
+            (void)accept(i1, bestIdx, bestDist, bestDist2);
         }
     }
     WAVE_LDS_SYNC();
+    ORB_ABL_IF(stop == 2) return;
     if (check_ori) {
         for (int i1 = lane; i1 < n1; i1 += 64) {
             const int f = s_acc[i1];
             if (f < 0) continue;
-            float rot = __fsub_rn(K1[i1].angle, K2[f].angle);
+            float rot = stage ? __fsub_rn(s_a1[i1], s_k2[3 * f + 2]) : __fsub_rn(K1[i1].angle, K2[f].angle);
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
             int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
             if (bin == 30) bin = 0;
@@ -1174,7 +1337,7 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
         for (int i1 = lane; i1 < n1; i1 += 64) {
             const int f = s_acc[i1];
             if (f < 0) continue;
-            float rot = __fsub_rn(K1[i1].angle, K2[f].angle);
+            float rot = stage ? __fsub_rn(s_a1[i1], s_k2[3 * f + 2]) : __fsub_rn(K1[i1].angle, K2[f].angle);
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
             int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
             if (bin == 30) bin = 0;
@@ -1189,7 +1352,7 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
     for (int i1 = lane; i1 < cap1; i1 += 64) {
         const int m = i1 < n1 ? s_m12[i1] : -1;
         matches12[(size_t)b * cap1 + i1] = m;
-        if (m >= 0) PM[i1] = make_float2(K2[m].x, K2[m].y);   // :512-515
+        if (m >= 0) PM[i1] = stage ? make_float2(s_k2[3 * m], s_k2[3 * m + 1]) : make_float2(K2[m].x, K2[m].y);   // :512-515
     }
     if (lane == 0) nmatches[b] = nm;
 }
@@ -1211,7 +1374,13 @@ size_t init_scratch_bytes(int B, int cap1, int cap2)
     return (size_t)B * cap2 * 16 + (size_t)B * cap1pad * (INIT_K * 4 + 4) + 256;
 }
 
-size_t init_assign_lds(int cap1, int cap2) { return ((size_t)cap1 * 2 + (size_t)cap2 * 2) * 4; }
+size_t init_assign_lds(int cap1, int cap2) { return ((size_t)cap1 * 2 + (size_t)cap2 * 2) * 4; }   // the match tables (required)
+// ... plus list lengths [cap1pad], angles of frame 1 [cap1] and x, y, angle of frame 2 [3 cap2], staged when they fit as well
+static size_t init_assign_lds_staged(int cap1, int cap2)
+{
+    const size_t cap1pad = ((size_t)cap1 + 63) / 64 * 64;
+    return init_assign_lds(cap1, cap2) + (cap1pad + (size_t)cap1 + 3 * (size_t)cap2) * 4;
+}
 
 int launch_search_for_initialization(hipStream_t s, const orbhip_keypoint *kps1, const uint8_t *desc1, const int32_t *cnt1,
                                      int cap1, const orbhip_keypoint *kps2, const uint8_t *desc2, const int32_t *cnt2, int cap2,
@@ -1229,12 +1398,13 @@ int launch_search_for_initialization(hipStream_t s, const orbhip_keypoint *kps1,
     hipLaunchKernelGGL(k_proj_records, dim3((cap2 + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps2, cap2, cellOff2, cellIdx2, rec);
     hipLaunchKernelGGL(k_init_cands, dim3(cap1pad / 4, B, 1), dim3(256, 1, 1), 0, s, kps1, desc1, cnt1, cap1, (const float2 *)prev,
                        radius, gp, cellOff2, rec, desc2, cap2, cap1pad, keff, tuples, tcount);
-    if (init_assign_lds(cap1, cap2) > 16 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_init_assign, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)init_assign_lds(cap1, cap2));
-    hipLaunchKernelGGL(k_init_assign, dim3(B, 1, 1), dim3(64, 1, 1), init_assign_lds(cap1, cap2), s, kps1, desc1, cnt1, cap1, kps2,
+    int stage = init_assign_lds_staged(cap1, cap2) <= 112 * 1024 ? 1 : 0;   // (+ 32 KB of static LDS for the lists)
+    stage |= ORB_TUNE("INIT_STOP", 0) << 4;
+    const size_t lds = stage ? init_assign_lds_staged(cap1, cap2) : init_assign_lds(cap1, cap2);
+    if (lds > 16 * 1024) (void)hipFuncSetAttribute((const void *)k_init_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_init_assign, dim3(B, 1, 1), dim3(64, 1, 1), lds, s, kps1, desc1, cnt1, cap1, kps2,
                        desc2, cnt2, cap2, (float2 *)prev, radius, gp, cellOff2, cellIdx2, cap1pad, keff, tuples, tcount, nnratio,
-                       check_ori, th_low, matches12, nmatches);
+                       check_ori, th_low, matches12, nmatches, stage);
     return ORBHIP_OK;
 }
 
