@@ -56,8 +56,11 @@ __device__ __forceinline__ int grid_wave_incl_scan(int v)
 // LDSIDX: the cell entries are sorted in LDS (cap * 4 bytes of dynamic LDS) and written out once -- the insertion sort on the
 // global array was a chain of dependent memory trips per cell (most of the 24 us a single frame's grid took); frames with
 // more features than fit keep the in-place form.
-template <bool LDSIDX>
-__global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__restrict__ kps,
+// NT threads: 256 for batches (one workgroup per frame, many frames), 1024 for a frame or two -- the single workgroup of a frame is
+// a chain of barrier-separated loops, and four times the threads make every loop a quarter as long (r04: 19.1 -> 16.0 us from keeping
+// the cells in registers, -> 9.2 us with 1024 threads).
+template <bool LDSIDX, int NT>
+__global__ __launch_bounds__(NT) void k_grid_build(const orbhip_keypoint *__restrict__ kps,
                                                     const int32_t *__restrict__ cnt, int cap, const GridParams gp,
                                                     int32_t *__restrict__ cellOff, int32_t *__restrict__ cellIdx,
                                                     int32_t *__restrict__ cellOff2, int32_t *__restrict__ cellIdx2)
@@ -65,20 +68,38 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
     // (cellOff2 / cellIdx2, frame 0 only: the page-locked twin of orbhip_frame_build's result block; LDSIDX form only)
     extern __shared__ int s_idx[];
     __shared__ int s_cnt[GCELLS];
-    __shared__ int s_wtot[4];
+    __shared__ int s_wtot[NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = min(cnt[b], cap);
     const orbhip_keypoint *K = kps + (size_t)b * cap;
     int32_t *O = cellOff + (size_t)b * (GCELLS + 1), *I = cellIdx + (size_t)b * cap;
     int *E = LDSIDX ? s_idx : I;
-    for (int c = tid; c < GCELLS; c += 256) s_cnt[c] = 0;
+    // a thread's first GB_KEEP features: position read and cell computed ONCE, kept for the fill pass (the single workgroup of a
+    // frame is a chain of latencies: the second read of the keypoints was one more global round trip of its ~19 us)
+    constexpr int GB_KEEP = 2048 / NT;
+    int myCell[GB_KEEP];
+    {
+        float kx[GB_KEEP], ky[GB_KEEP];
+#pragma unroll
+        for (int u = 0; u < GB_KEEP; u++) {
+            const int i = min(tid + NT * u, max(n - 1, 0));
+            kx[u] = K[i].x;
+            ky[u] = K[i].y;
+        }
+        for (int c = tid; c < GCELLS; c += NT) s_cnt[c] = 0;
+#pragma unroll
+        for (int u = 0; u < GB_KEEP; u++) myCell[u] = tid + NT * u < n ? grid_cell(gp, kx[u], ky[u]) : -1;
+    }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+#pragma unroll
+    for (int u = 0; u < GB_KEEP; u++)
+        if (myCell[u] >= 0) atomicAdd(&s_cnt[myCell[u]], 1);
+    for (int i = tid + NT * GB_KEEP; i < n; i += NT) {
         const int c = grid_cell(gp, K[i].x, K[i].y);
         if (c >= 0) atomicAdd(&s_cnt[c], 1);
     }
     __syncthreads();
-    constexpr int PER = GCELLS / 256;   // 12 cells per thread
+    constexpr int PER = GCELLS / NT;   // 12 (3) cells per thread
     int c[PER], sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -90,7 +111,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
     __syncthreads();
     int run = incl - sum;
     for (int w = 0; w < (tid >> 6); w++) run += s_wtot[w];
-    if (tid == 255) {
+    if (tid == NT - 1) {
         O[GCELLS] = run + sum;
         if (cellOff2) cellOff2[GCELLS] = run + sum;
     }
@@ -102,15 +123,24 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
         run += c[k];
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+#pragma unroll
+    for (int u = 0; u < GB_KEEP; u++)
+        if (myCell[u] >= 0) E[atomicAdd(&s_cnt[myCell[u]], 1)] = tid + NT * u;
+    for (int i = tid + NT * GB_KEEP; i < n; i += NT) {
         const int cc = grid_cell(gp, K[i].x, K[i].y);
         if (cc >= 0) E[atomicAdd(&s_cnt[cc], 1)] = i;
     }
     if (!LDSIDX) __threadfence_block();
     __syncthreads();
-    // ascending feature index inside each cell (cells hold a handful of features)
-    for (int cc = tid; cc < GCELLS; cc += 256) {
-        const int s = cc ? s_cnt[cc - 1] : 0, e = s_cnt[cc];   // cursors now sit at the cell ends
+    // ascending feature index inside each cell (cells hold a handful of features): the thread's PER cells are neighbours, their
+    // ends read together; only a cell of two or more entries has anything to sort
+    int ends[PER + 1];
+    ends[0] = tid ? s_cnt[tid * PER - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) ends[k + 1] = s_cnt[tid * PER + k];   // cursors now sit at the cell ends
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int s = ends[k], e = ends[k + 1];
         for (int a = s + 1; a < e; a++) {
             const int v = E[a];
             int p = a - 1;
@@ -124,7 +154,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbhip_keypoint *__res
     if (LDSIDX) {
         __syncthreads();
         const int total = s_cnt[GCELLS - 1];
-        for (int j = tid; j < total; j += 256) {
+        for (int j = tid; j < total; j += NT) {
             I[j] = s_idx[j];
             if (cellIdx2) cellIdx2[j] = s_idx[j];
         }
@@ -1424,11 +1454,15 @@ int launch_grid_build(hipStream_t s, const orbhip_keypoint *kps, const int32_t *
 {
     const GridParams gp = {minX, minY, invW, invH};
     if ((size_t)cap * 4 <= 48 * 1024)
-        hipLaunchKernelGGL(k_grid_build<true>, dim3(B, 1, 1), dim3(256, 1, 1), (size_t)cap * 4, s, kps, cnt, cap, gp, cellOff, cellIdx,
-                           cellOff2, cellIdx2);
+        if (B < 8)
+            hipLaunchKernelGGL((k_grid_build<true, 1024>), dim3(B, 1, 1), dim3(1024, 1, 1), (size_t)cap * 4, s, kps, cnt, cap, gp, cellOff,
+                               cellIdx, cellOff2, cellIdx2);
+        else
+            hipLaunchKernelGGL((k_grid_build<true, 256>), dim3(B, 1, 1), dim3(256, 1, 1), (size_t)cap * 4, s, kps, cnt, cap, gp, cellOff,
+                               cellIdx, cellOff2, cellIdx2);
     else {
         if (cellOff2 || cellIdx2) return ORBHIP_E_SIZE;   // (the twin is written by the LDS form)
-        hipLaunchKernelGGL(k_grid_build<false>, dim3(B, 1, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, gp, cellOff, cellIdx,
+        hipLaunchKernelGGL((k_grid_build<false, 256>), dim3(B, 1, 1), dim3(256, 1, 1), 0, s, kps, cnt, cap, gp, cellOff, cellIdx,
                            (int32_t *)nullptr, (int32_t *)nullptr);
     }
     return ORBHIP_OK;
