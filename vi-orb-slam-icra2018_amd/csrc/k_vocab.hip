@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restri
                                                          int32_t *__restrict__ word_id, float *__restrict__ weight,
                                                          int32_t *__restrict__ node_id, const int32_t *__restrict__ cnt)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (cnt) n = min(n, cnt[0]);   // (a captured graph: the number of descriptors is the extraction's count, on the device)
     if (i >= n) return;
     const uint4 a = reinterpret_cast<const uint4 *>(desc + (size_t)i * 32)[0];
@@ -251,13 +251,16 @@ void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *
                             int32_t *word_id, float *weight, int32_t *node_id, const int32_t *cnt)
 {
     if (n <= 0) return;
-#define ORB_LAUNCH_VT(E)                                                                                                          \
-    hipLaunchKernelGGL(k_vocab_transform<E>, dim3((n + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, desc, n, V.L - levelsup,          \
+    // A frame's worth of descriptors: workgroups of ONE wave, so that the descent spreads over 16 CUs instead of 4 -- every load of
+    // the descent touches 64 different lines, and four waves per CU queue 7 680 line requests per level at its texture unit
+    // (r04: the single-frame transform was ~25 us of which ~19 us this queue).  Batches fill the chip either way.
+#define ORB_LAUNCH_VT(E, T)                                                                                                       \
+    hipLaunchKernelGGL(k_vocab_transform<E>, dim3((n + (T) - 1) / (T), 1, 1), dim3((T), 1, 1), 0, s, desc, n, V.L - levelsup,       \
                        V.rootFirst, V.rootLast, reinterpret_cast<const uint4 *>(V.desc), reinterpret_cast<const int2 *>(V.erange), \
                        V.eid, V.eword, V.eweight, word_id, weight, node_id, cnt)
     if (n <= 16384)
-        ORB_LAUNCH_VT(true);
+        ORB_LAUNCH_VT(true, 64);
     else
-        ORB_LAUNCH_VT(false);
+        ORB_LAUNCH_VT(false, 256);
 #undef ORB_LAUNCH_VT
 }
