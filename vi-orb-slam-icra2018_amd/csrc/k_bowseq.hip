@@ -45,25 +45,9 @@ struct BsBest {
     int b1, pos, b2;
 };
 
-__device__ __forceinline__ int bs_wave_min(int v)
-{
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
+__device__ __forceinline__ int bs_wave_min(int v) { return orb_wave_min_i(v); }
 // minimum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ int bs_row_min(int v)
-{
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));   // row_mirror
-    return v;
-}
+__device__ __forceinline__ int bs_row_min(int v) { return orb_row_min_i(v); }
 
 // first position in sorted keys[0..n) whose node (high 32 bits) is >= / > node
 __device__ __forceinline__ int bs_bound(const unsigned long long *keys, int n, unsigned node, bool upper)

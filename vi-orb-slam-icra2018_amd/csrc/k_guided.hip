@@ -520,24 +520,7 @@ __global__ __launch_bounds__(256) void k_window_best_row(const uint8_t *__restri
     }
 }
 
-// Minimum over the wave.  The four row steps as v_min_i32 with a DPP source operand (the builtin form compiles to v_mov_b32 +
-// s_nop + v_mov_b32_dpp + v_min_i32 per step: in the one-wave kernels of this file, whose time is their instruction count,
-// that was a quarter of a feature's instructions); the s_nop covers the VALU-write -> DPP-read hazard of each step.
-__device__ __forceinline__ int wave_min_i(int v)
-{
-    asm volatile("s_nop 1\n\t"
-                 "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(v));
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
+__device__ __forceinline__ int wave_min_i(int v) { return orb_wave_min_i(v); }
 
 
 __device__ __forceinline__ int wave_sum_g(int v)
@@ -1228,19 +1211,7 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
                 const int d = (int)(t & 511u), idx = (int)(t >> 9);
                 int md = has ? s_md[idx] : 0;
                 int key = (has && !(md <= d)) ? ((d << 16) | p) : 0x7FFFFFFF;   // :443-444
-                auto row_min = [&](int v) {   // every lane: the minimum of its 16-lane row
-                    asm volatile("s_nop 1\n\t"
-                                 "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "s_nop 1\n\t"
-                                 "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                                 "s_nop 1\n\t"
-                                 "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                                 "s_nop 1\n\t"
-                                 "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                                 "s_nop 1"
-                                 : "+v"(v));
-                    return v;
-                };
+                auto row_min = [&](int v) { return orb_row_min_i(v); };   // every lane: the minimum of its 16-lane row
                 int r1 = row_min(key);
                 const int kA1 = min(__builtin_amdgcn_readlane(r1, 0), __builtin_amdgcn_readlane(r1, 16));
                 int kB1 = min(__builtin_amdgcn_readlane(r1, 32), __builtin_amdgcn_readlane(r1, 48));

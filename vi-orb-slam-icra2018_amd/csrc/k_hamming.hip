@@ -681,10 +681,17 @@ __global__ __launch_bounds__(256) void k_bow_match(const uint8_t *__restrict__ d
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const int ob1 = __shfl_xor(bd1, o), opos = __shfl_xor(bpos, o), ob2 = __shfl_xor(bd2, o);
-                    bow_merge(bd1, bpos, bd2, ob1, opos, ob2);
+                {
+                    // (best distance, lowest position) and the second smallest distance of the whole node: two wave minima --
+                    // the winner by (distance, position), then every lane's best, the winner lane's second (r04: the butterfly
+                    // of three shuffled values and six tie-aware merges was two thirds of a side-1 feature's instructions, and this
+                    // loop is the serial chain the call waits for)
+                    const int key = bpos != 0x7FFFFFFF ? ((bd1 << 8) | bpos) : 0x7FFFFFFF;
+                    const int k1 = orb_wave_min_i(key);
+                    const int k2 = orb_wave_min_i(key == k1 ? bd2 : bd1);
+                    bd1 = k1 != 0x7FFFFFFF ? k1 >> 8 : 256;
+                    bpos = k1 != 0x7FFFFFFF ? (k1 & 255) : 0x7FFFFFFF;
+                    bd2 = k2;
                 }
                 const bool pass = th_mode ? (bd1 < th) : (bd1 <= th);
                 if (pass && (float)bd1 < nnratio * (float)bd2) {  // ref: :228-230 / :598-600
@@ -739,10 +746,13 @@ __global__ __launch_bounds__(256) void k_bow_match(const uint8_t *__restrict__ d
                 bd2 = d;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int ob1 = __shfl_xor(bd1, o), opos = __shfl_xor(bpos, o), ob2 = __shfl_xor(bd2, o);
-            bow_merge(bd1, bpos, bd2, ob1, opos, ob2);
+        {
+            const int key = bpos != 0x7FFFFFFF ? ((bd1 << 20) | bpos) : 0x7FFFFFFF;   // (n2 < 2^20: orbhip_search_by_bow checks)
+            const int k1 = orb_wave_min_i(key);
+            const int k2 = orb_wave_min_i(key == k1 ? bd2 : bd1);
+            bd1 = k1 != 0x7FFFFFFF ? k1 >> 20 : 256;
+            bpos = k1 != 0x7FFFFFFF ? (k1 & 0xFFFFF) : 0x7FFFFFFF;
+            bd2 = k2;
         }
         const bool pass = th_mode ? (bd1 < th) : (bd1 <= th);
         if (pass && (float)bd1 < nnratio * (float)bd2) {  // ref: :228-230 / :598-600

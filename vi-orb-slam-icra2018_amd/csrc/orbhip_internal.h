@@ -394,6 +394,31 @@ static inline int orb_xcd_grid(int ntiles, int dflt = 0)
 }
 static inline int orb_xcd_arg(int dflt) { return orb_xcd_map(dflt) | (orb_xcd_chunk() << 8); }
 #ifdef __HIPCC__
+// Minimum over the 16 lanes of a DPP row (result in every lane of the row) / over the wave (a scalar).  The row steps are
+// v_min_i32 with a DPP source operand: the builtin form (min(v, update_dpp(v, v, ...))) compiles to v_mov_b32 + s_nop + v_mov_b32_dpp
+// + v_min_i32 per step, and in the one-wave kernels that use these (sequential matching semantics: their time is their instruction
+// count) that was a quarter of the instructions of a feature.  Every lane of the wave must be active.
+__device__ __forceinline__ int orb_row_min_i(int v)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int orb_wave_min_i(int v)
+{
+    v = orb_row_min_i(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // mode 4 (k_describe): a whole FRAME per XCD.  Workgroups are dealt round-robin over the XCDs by linear id
 // L = blockIdx.y * gridDim.x + blockIdx.x, so XCD k receives the ids L = k, k + 8, ...; the i-th of them (i = L / 8) works on
 // tile i % gridDim.x of frame k + 8 * (i / gridDim.x): every workgroup that touches a frame's raw and blurred pyramids
