@@ -660,9 +660,9 @@ __global__ __launch_bounds__(256) void k_bow_match(const uint8_t *__restrict__ d
             for (int k = 0; k < n1c; k++) {
                 const int i1 = i1n;
                 const uint32_t Q[8] = {q0n.x, q0n.y, q0n.z, q0n.w, q1n.x, q1n.y, q1n.z, q1n.w};
-                const int v1 = __shfl(myV1, k);
+                const int v1 = __builtin_amdgcn_readlane(myV1, k);   // (k is wave-uniform: v_readlane, not a trip through ds_bpermute)
                 if (k + 1 < n1c) {
-                    i1n = __shfl(myI1, k + 1);
+                    i1n = __builtin_amdgcn_readlane(myI1, k + 1);
                     q0n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[0];
                     q1n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[1];
                 }
@@ -853,11 +853,12 @@ __global__ __launch_bounds__(256) void k_tri_match(const orbhip_keypoint *__rest
             for (int k = 0; k < n1c; k++) {
                 const int i1 = i1n;
                 const uint32_t Q[8] = {q0n.x, q0n.y, q0n.z, q0n.w, q1n.x, q1n.y, q1n.z, q1n.w};
-                const int skip = __shfl(mySkip, k);
-                const bool stereo1 = __shfl(mySt1, k) != 0;
-                const float x1 = __shfl(myX1, k), y1 = __shfl(myY1, k);
+                const int skip = __builtin_amdgcn_readlane(mySkip, k);   // (k is wave-uniform: v_readlane, not ds_bpermute)
+                const bool stereo1 = __builtin_amdgcn_readlane(mySt1, k) != 0;
+                const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myX1), k));
+                const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myY1), k));
                 if (k + 1 < n1c) {
-                    i1n = __shfl(myI1, k + 1);
+                    i1n = __builtin_amdgcn_readlane(myI1, k + 1);
                     q0n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[0];
                     q1n = reinterpret_cast<const uint4 *>(desc1 + (size_t)i1n * 32)[1];
                 }
@@ -883,8 +884,7 @@ __global__ __launch_bounds__(256) void k_tri_match(const orbhip_keypoint *__rest
                     if (!((double)dsqr < lim2[c])) continue;
                     key = min(key, (d << 16) | (0xFFFF - (c * 64 + lane)));
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));
+                key = orb_wave_min_i(key);
                 if (key != 0x7FFFFFFF) {
                     const int pos = 0xFFFF - (key & 0xFFFF);
 #pragma unroll
@@ -934,8 +934,7 @@ __global__ __launch_bounds__(256) void k_tri_match(const orbhip_keypoint *__rest
             if (!((double)dsqr < __dmul_rn(3.84, (double)sigma2[k2.octave]))) continue;
             key = min(key, (d << 16) | (0xFFFF - min(p, 0xFFFF)));
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));
+        key = orb_wave_min_i(key);
         if (lane == 0 && key != 0x7FFFFFFF) match12[i1] = idx2[b0 + (0xFFFF - (key & 0xFFFF))];
     }
 }
