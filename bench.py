@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 W, H, NFEAT = 640, 480, 1000          # the size BASELINE.json's metric is quoted on
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 I8_MFMA_PEAK_OPS = 5.0e15             # MI355X_MICROARCH.md: dense I8 MFMA = 2 x BF16 per clock, BF16 ~2.5 PFLOP/s dense
+FP4_MFMA_PEAK_OPS = 10.0e15           # ... block-scaled FP4 (v_mfma_scale_f32_32x32x64_f8f6f4) = 4 x BF16 per clock
 VOC_K, VOC_L, LEVELSUP = 10, 6, 4     # stock ORBvoc shape; Frame::ComputeBoW uses levelsup 4 (src/Frame.cc:744)
 NNRATIO = 0.7                         # TrackReferenceKeyFrame: ORBmatcher matcher(0.7,true) (src/Tracking.cc:1881)
 
@@ -525,11 +526,15 @@ def config_relocalisation(device, B=256, steps=6, nq=4000, ndb=1000000, nver=32)
                         "previous frame; and one %d x %d Hamming relocalisation query" % (B, nq, ndb),
             "value": round(steps * B / dt, 1), "unit": "frames/s", "keypoints_per_frame": round(kp, 1),
             "query_ms": round(qdt * 1e3, 3), "query_pair_evals_per_s": round(nq * ndb / qdt, 0),
-            # k_knn2_mfma computes a pair's distance as a 256-term int8 dot product on the matrix pipe: 512 int8 operations per pair
+            # k_knn2_mfma computes a pair's distance as a 256-term FP4 dot product on the matrix pipe: 512 operations per pair
             "roofline_mfma": {"bound": "mfma", "kernel": "k_knn2_mfma", "achieved": round(nq * ndb / qdt * 512 / 1e12, 1),
-                              "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s (int8)", "frac": round(nq * ndb / qdt * 512 / I8_MFMA_PEAK_OPS, 4),
-                              "note": "pair evaluations/s x 512 int8 operations / the dense I8 MFMA rate (2 x BF16 per clock, "
-                                      "MI355X_MICROARCH.md); the query's wall time incl. the merge kernel"},
+                              "peak": FP4_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s (FP4, exact on 0 / 1 / -1 operands)",
+                              "frac": round(nq * ndb / qdt * 512 / FP4_MFMA_PEAK_OPS, 4),
+                              "frac_of_int8_rate": round(nq * ndb / qdt * 512 / I8_MFMA_PEAK_OPS, 4),
+                              "note": "pair evaluations/s x 512 operations / the dense FP4 MFMA rate (4 x BF16 per clock, "
+                                      "MI355X_MICROARCH.md) the kernel's v_mfma_scale_f32_32x32x64_f8f6f4 runs at; frac_of_int8_rate "
+                                      "prices the same work at the int8 rate of the r03 kernel (v_mfma_i32_32x32x32_i8); "
+                                      "the query's wall time incl. the merge kernel"},
             "query_database_GBps": round(32.0 * ndb / qdt / 1e9, 1), "verified": verified + nver,
             "verified_what": "frames 0 and 1 (keypoints, descriptors, brute-force triples) and %d of the %d queries against the "
                              "full database vs oracle" % (nver, nq)}

@@ -223,8 +223,8 @@ def test_alternative_batch_code_paths_give_the_same_results(env):
 def test_brute_force_matching_on_the_matrix_pipe_and_on_the_vector_pipe(mfma):
     """k_knn2_mfma / k_knn2_seq_mfma (default) and the scalar k_knn2 / k_knn2_seq (ORBHIP_KNN2_MFMA=0) against the oracle: low-entropy
     descriptors (few distinct distances: ties decide the index and the second-best), all-zero / all-one rows, duplicate rows, query and
-    database counts around the 128-query workgroup, the 32-row matrix tile and the 64-row staged tile, and the per-frame sequence
-    form with ragged counts."""
+    database counts around the 128-query workgroup, the 32-row matrix tile and the 64-row staged tile, the per-frame sequence
+    form with ragged counts, and second-best rows planted inside the winner's own group of the matrix tile (the rescan)."""
     import os
     import subprocess
     import sys
@@ -276,6 +276,25 @@ def test_brute_force_matching_on_the_matrix_pipe_and_on_the_vector_pipe(mfma):
         "wi, wd, ws = oracle.knn2(desc2[1, :4300], desc2[0, :5000])\n"
         "assert np.array_equal(d_bi.to_numpy(np.int32, (2, cap2))[1, :4300], wi) and np.array_equal(d_bd.to_numpy(np.int32, (2, cap2))[1, :4300], wd) and np.array_equal(d_sd.to_numpy(np.int32, (2, cap2))[1, :4300], ws)\n"
         "assert (wi >= 4096).sum() > 100, 'the second chunk must win for some queries'\n"
+        "# the second best inside the winner's own group of the matrix tile (a lane holds rows 8 g + 4 h + e of a 32-row tile and only its\n"
+        "# smallest key enters the running pair: the other 15 rows are looked at again after the chunk), both forms\n"
+        "ndb, nq = 5000, 600\n"
+        "db = rng.integers(0, 256, (ndb, 32), dtype=np.uint8)\n"
+        "rows = rng.permutation(ndb // 32 - 1)[:nq // 4].repeat(4) * 32 + rng.integers(0, 32, nq)\n"
+        "q = db[rows].copy()\n"
+        "for i, r in enumerate(rows):\n"
+        "    partner = (r & ~31) + ((r & 31) ^ (1, 2, 3, 8, 16, 24, 9)[i %% 7])   # same tile, same h (bit 2 of the row kept)\n"
+        "    db[partner] = q[i]; db[partner, i %% 32] ^= 1 << (i %% 8)\n"
+        "got = m.knn2(q, db); want = oracle.knn2(q, db)\n"
+        "for g, w in zip(got, want):\n"
+        "    assert np.array_equal(g, w), 'planted second best'\n"
+        "assert (want[2] <= 2).mean() > 0.5, 'most second-best distances are the planted ones'\n"
+        "desc3 = np.zeros((2, ndb, 32), np.uint8); desc3[0] = db; desc3[1, :nq] = q; counts3 = np.array([ndb, nq], np.int32)\n"
+        "d_desc = hiprt.DevBuf.from_numpy(desc3); d_cnt = hiprt.DevBuf.from_numpy(counts3)\n"
+        "d_bi, d_bd, d_sd = (hiprt.DevBuf(2 * ndb * 4) for _ in range(3))\n"
+        "check(ex._L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.ptr, d_cnt.ptr, ndb, 2, 1, d_bi.ptr, d_bd.ptr, d_sd.ptr), ex.handle)\n"
+        "ex.sync()\n"
+        "assert np.array_equal(d_bi.to_numpy(np.int32, (2, ndb))[1, :nq], want[0]) and np.array_equal(d_bd.to_numpy(np.int32, (2, ndb))[1, :nq], want[1]) and np.array_equal(d_sd.to_numpy(np.int32, (2, ndb))[1, :nq], want[2])\n"
         "ex.close()\n"
         "print('knn2 ok')\n"
     ) % (os.path.join(root, "vi-orb-slam-icra2018_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests"))

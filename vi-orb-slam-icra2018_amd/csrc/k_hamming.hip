@@ -3,7 +3,7 @@
 // :159-288 and :522-655 SearchByBoW).  Bitwise path (XOR + v_bcnt_u32_b32) everywhere except the brute force over many queries,
 // which runs on the matrix pipe.
 //
-//  k_knn2_mfma   brute force, many queries: |a & b| as an int8 matrix product of the bits written out as bytes (see the kernel);
+//  k_knn2_mfma   brute force, many queries: |a & b| as an FP4 matrix product of the bits written out as numbers (see the kernel);
 //                k_knn2_seq_mfma the same for the frame sequence form.  ORBHIP_KNN2_MFMA=0 selects the scalar kernels below.
 //  k_knn2        brute force, query tile x database split; a thread owns one query (8 VGPRs),
 //                the database row is wave-uniform and arrives through scalar loads; partial
@@ -117,16 +117,32 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
     if (qi < nq) partial[(size_t)split * nq + qi] = make_int4(B.b1, B.idx, B.b2, 0);
 }
 
+// 16 queries x 16 runs of consecutive splits per workgroup (thread per query alone: 16 workgroups walking 256 partial results
+// each took 73 us behind a 0.71 ms k_knn2_mfma); the runs are merged in split order, then the 16 run results in run order.
+#define KMERGE_Q 16
+#define KMERGE_P 16
 __global__ __launch_bounds__(256) void k_knn2_merge(const int4 *__restrict__ partial, int nq, int nsplit,
                                                     int32_t *__restrict__ best_idx,
                                                     int32_t *__restrict__ best_d,
                                                     int32_t *__restrict__ second_d)
 {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    if (qi >= nq) return;
+    __shared__ int4 s_run[KMERGE_P][KMERGE_Q];
+    const int ql = threadIdx.x & (KMERGE_Q - 1), run = threadIdx.x / KMERGE_Q;
+    const int qi = blockIdx.x * KMERGE_Q + ql;
+    const int per = (nsplit + KMERGE_P - 1) / KMERGE_P;
+    const int s0 = run * per, s1 = min(nsplit, s0 + per);
     Best A = {256, -1, 256};
-    for (int s = 0; s < nsplit; s++) {
-        const int4 p = partial[(size_t)s * nq + qi];
+    if (qi < nq)
+        for (int s = s0; s < s1; s++) {
+            const int4 p = partial[(size_t)s * nq + qi];
+            Best Bp = {p.x, p.y, p.z};
+            A = best_merge_ordered(A, Bp);
+        }
+    s_run[run][ql] = make_int4(A.b1, A.idx, A.b2, 0);
+    __syncthreads();
+    if (run != 0 || qi >= nq) return;
+    for (int r = 1; r < KMERGE_P; r++) {
+        const int4 p = s_run[r][ql];
         Best Bp = {p.x, p.y, p.z};
         A = best_merge_ordered(A, Bp);
     }
@@ -135,10 +151,13 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const int4 *__restrict__ par
     second_d[qi] = A.b2;
 }
 
+#ifndef KM_WANT
+#define KM_WANT 4096      // workgroups a query is cut into (query tiles x database splits)
+#endif
 static void knn2_shape(int nq, int ndb, int *qTiles, int *nsplit, int *rows)
 {
     *qTiles = (nq + 255) / 256;
-    int want = 4096 / (*qTiles > 0 ? *qTiles : 1);
+    int want = KM_WANT / (*qTiles > 0 ? *qTiles : 1);
     if (want < 1) want = 1;
     int maxSplit = (ndb + 63) / 64;
     if (maxSplit < 1) maxSplit = 1;
@@ -245,6 +264,13 @@ size_t knn2_scratch_bytes(int nq, int ndb)
     return (size_t)ns * (size_t)(nq > 0 ? nq : 1) * sizeof(int4);
 }
 
+#ifndef KM_SUB
+#define KM_SUB 2          // 32-row tiles of the matrix instruction per staged tile (one barrier per 64 rows)
+#endif
+#ifndef KM_QT
+#define KM_QT 2           // 32-query tiles per wave (each A fragment read from LDS feeds KM_QT matrix instructions)
+#endif
+#define KM_QPB (4 * 32 * KM_QT)   // queries per workgroup of four waves
 __global__ void k_knn2_mfma(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ db, int ndb, int rowsPerSplit,
                             int4 *__restrict__ partial);   // (below)
 
@@ -270,69 +296,93 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
     // aligned like that takes the scalar kernel, whose accesses are dword / byte-safe scalar loads)
     const bool aligned = (reinterpret_cast<uintptr_t>(q) & 15u) == 0 && (reinterpret_cast<uintptr_t>(db) & 3u) == 0;
     if (mfmaEnv && aligned)
-        hipLaunchKernelGGL(k_knn2_mfma, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
+        hipLaunchKernelGGL(k_knn2_mfma, dim3((nq + KM_QPB - 1) / KM_QPB, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
     else
         hipLaunchKernelGGL(k_knn2, dim3(qt, ns, 1), dim3(256, 1, 1), 0, s, q, nq, db, ndb, rows, partial);
-    hipLaunchKernelGGL(k_knn2_merge, dim3(qt, 1, 1), dim3(256, 1, 1), 0, s, partial, nq, ns, best_idx, best_d,
-                       second_d);
+    hipLaunchKernelGGL(k_knn2_merge, dim3((nq + KMERGE_Q - 1) / KMERGE_Q, 1, 1), dim3(256, 1, 1), 0, s, partial, nq, ns, best_idx,
+                       best_d, second_d);
 }
 
 // ---- brute force on the matrix pipe (many queries) ----
-// d(a, b) = |a| + |b| - 2 |a & b|, and |a & b| over 32 bits is a dot product of the bits written out as bytes: one
-// v_mfma_i32_32x32x32_i8 per descriptor word gives the 32 x 32 values |a & b| of 32 database rows (A operand) against 32 queries (B
-// operand), eight of them a tile of 1024 distances -- 8 matrix instructions instead of 1024 x (8 v_xor + 8 v_bcnt + 7 adds).
-//  * The instruction also builds the comparison key.  |b| - 2 |a & b| = sum over the set bits of b of (1 - 2 a_k): a row's set bits
-//    are written as 0x40 (64), a query's bits as +64 (clear) or -64 (set), so a set row bit contributes +-2^12, and with the
-//    accumulator started at the row's index inside a chunk of 4096 database rows the result is ((|b| - 2 |a & b|) << 12) + row:
-//    ordered by distance, then by index (|a| is the same for all keys of a query and added at the end).  Per value the vector pipe only keeps the two smallest keys, m2 = med3(m1, m2, key), m1 = min(m1, key) -- (best,
-//    lowest index) and the second smallest distance of the multiset, exactly what the strict '<' loop of the reference leaves (:205-226).
+// d(a, b) = |a| + |b| - 2 |a & b|, and |a & b| is a dot product of the bits written out as numbers: one
+// v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 (e2m1) operands takes 64 bits of 32 database rows (A operand) against 64 bits of 32
+// queries (B operand), four of them a tile of 1024 distances -- 4 matrix instructions instead of 1024 x (8 v_xor + 8 v_bcnt + 7
+// adds).  (r03: v_mfma_i32_32x32x32_i8 on the bits written out as bytes, 8 instructions per tile at the same 32 cycles each; the
+// FP4 form has twice the k per instruction, half the LDS image and half the operand registers.)
+//  * Exactness.  A row bit is the FP4 number 0.5 (0b0001) with block scale 2^7, a query bit +1 (clear, 0b0010) or -1 (set, 0b1010)
+//    with block scale 2^6: a set row bit contributes +-2^12, every partial sum is an integer below 2^23, the f32 accumulation is exact
+//    (tools/microbench/fp4_dot.hip checks the instruction against the integer formula; the parity tests check the kernel).
+//  * The instruction also builds the comparison key.  |b| - 2 |a & b| = sum over the set bits of b of (1 - 2 a_k), and the
+//    accumulator starts at the row's index inside a chunk of 4096 database rows plus 2^21, so the result is
+//    ((|b| - 2 |a & b|) << 12) + row + 2^21, a POSITIVE float: ordered by distance, then by index, and its bit pattern orders like
+//    its value, so the epilogue is integer min / med3 on the raw registers (|a| is the same for all keys of a query and added at the end).
+//    What must come out is the two smallest keys -- (best, lowest index) and the second smallest distance of the multiset, exactly
+//    what the strict '<' loop of the reference leaves (:205-226).  A lane takes the minimum of its 16 keys of a 32-row tile (8
+//    v_min3_i32) and updates the running pair with that one key: m1 is exact, m2 is the second smallest GROUP minimum, and the true
+//    second key is min(m2, second key of the winner's group) -- 15 rows per query and 4096-row chunk, recomputed by popcount after
+//    the chunk (the "rescan").  (r03 kept the pair per value: v_min + v_med3 per key, 136 of 238 vector instructions per 64 rows.)
+//  * Which bit goes to which k-slot is free as long as rows and queries agree: slot j of dword d of a word's 16-byte fragment holds
+//    bit 4 j + d, i.e. dword d = (word >> d) & 0x11111111 -- 7 vector instructions per 32 bits (the byte form took 24).
 //  * Result layout: column = lane & 31 = query, the 16 registers of a lane = 16 of the tile's rows (8 g + 4 h + e for register 4 g + e,
 //    h = lane >> 5): a lane folds its own values, no cross-lane work; the two lanes of a query merge once at the end.
-//  * A workgroup = 256 queries (two 32-query tiles per wave: each A fragment read from LDS feeds two matrix instructions, the LDS reads
-//    are what limits this kernel) x the rows of one split; the byte form of a 64-row database tile (16 KB) and the rows' indices are
-//    built once per workgroup in LDS, thread = one word of two rows ((x * 0x08102040) & 0x40404040 spreads four bits over four bytes),
-//    double-buffered behind one barrier per tile.  Output = the split's partial result in the format of k_knn2, merged in split order by
-//    k_knn2_merge.
+//  * A workgroup = 4 waves x KM_QT tiles of 32 queries x the rows of one split; the FP4 form of a 64-row database tile (8 KB) and
+//    the rows' start values are built once per workgroup in LDS, thread = one word of a row, double-buffered behind one barrier per
+//    tile.  Output = the split's partial result in the format of k_knn2, merged in split order by k_knn2_merge.
 typedef int v4i_h __attribute__((ext_vector_type(4)));
-typedef int v16i_h __attribute__((ext_vector_type(16)));
-#define KM_NONE 0x3FFFFFFF
-#define KM_SUB 2          // 32-row MFMA tiles per staged tile (one barrier per 64 rows)
-#define KM_CHUNK 4096     // database rows per key range (12 index bits)
+typedef int v8i_h __attribute__((ext_vector_type(8)));
+typedef float v16f_h __attribute__((ext_vector_type(16)));
+#define KM_BIAS (1 << 21)
+#define KM_NONE 0x4C000000   // the f32 2^25 as a bit pattern: above every key
+#define KM_SCALE_A 134       // E8M0 2^7: a row's set bit, 0.5, counts 64
+#define KM_SCALE_B 133       // E8M0 2^6: a query's bit, +-1, counts +-64
+#define KM_CHUNK 4096        // database rows per key range (12 index bits)
+#ifndef KM_WAVES
+#define KM_WAVES 4           // waves per SIMD the register budget is set for
+#endif
+#ifndef KM_PREFETCH
+#define KM_PREFETCH 1        // A fragments requested ahead of the matrix instructions that use them
+#endif
 
-// 16 bits of a descriptor word -> 16 bytes, `one` (0x40 / 0x80 in every byte of the mask, 0x08102040 / 0x10204080 as the multiplier) per set bit
-template <uint32_t MUL, uint32_t MASK>
-__device__ __forceinline__ v4i_h bits16_to_bytes(uint32_t word, int h)
+// 32 bits of a descriptor word -> 32 four-bit slots holding 0 or 1
+__device__ __forceinline__ v4i_h bits32_to_slots(uint32_t x)
 {
-    const uint32_t x = word >> (16 * h);
     v4i_h r;
-    r.x = (int)((((x >> 0) & 0xFu) * MUL) & MASK);
-    r.y = (int)((((x >> 4) & 0xFu) * MUL) & MASK);
-    r.z = (int)((((x >> 8) & 0xFu) * MUL) & MASK);
-    r.w = (int)((((x >> 12) & 0xFu) * MUL) & MASK);
+    r.x = (int)(x & 0x11111111u);
+    r.y = (int)((x >> 1) & 0x11111111u);
+    r.z = (int)((x >> 2) & 0x11111111u);
+    r.w = (int)((x >> 3) & 0x11111111u);
+    return r;
+}
+
+__device__ __forceinline__ int min3_after(int first, int b, int c)
+{
+    int r;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(first), "v"(b), "v"(c));
     return r;
 }
 
 __device__ __forceinline__ void top2_update(int &m1, int &m2, int key)
 {
-    // The min comes first and the inline instruction takes it as an (unused) operand: the compiler knows how long a matrix result
-    // must not be read after its instruction issued and waits before the v_min; it does not reason about what inline text reads.
-    const int lo = min(m1, key);
-    int med;
-    asm("v_med3_i32 %0, %1, %2, %3 ; after %4" : "=v"(med) : "v"(m1), "v"(m2), "v"(key), "v"(lo));   // second smallest of (m1 <= m2, key)
+    int med;   // (key is the result of a vector instruction here, never a matrix result: nothing to wait for)
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(med) : "v"(m1), "v"(m2), "v"(key));   // second smallest of (m1 <= m2, key)
+    m1 = min(m1, key);
     m2 = med;
-    m1 = lo;
 }
 
-// 256 queries q[qbase ..] against database rows j0 .. j1 - 1: query qbase + 64 wave + 32 t + (lane & 31) -> out[t] (valid in lanes < 32)
+// the key of (distance term s = |b| - 2 |a & b|, row r of the chunk) as the matrix instruction leaves it, and back
+__device__ __forceinline__ int km_key(int s, int r) { return __float_as_int((float)(s * KM_CHUNK + r + KM_BIAS)); }
+__device__ __forceinline__ int km_value(int key) { return (int)__int_as_float(key) - KM_BIAS; }
+
+// KM_QPB queries q[qbase ..] against database rows j0 .. j1 - 1: query qbase + 32 KM_QT wave + 32 t + (lane & 31) -> out[t] (valid in lanes < 32)
 __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, int nq, int qbase, const uint8_t *__restrict__ db,
-                                               int j0, int j1, v4i_h (*s_A)[KM_SUB][8][2][32], int (*s_T)[KM_SUB * 32], Best out[2])
+                                               int j0, int j1, v4i_h (*s_A)[KM_SUB][8][32], int (*s_T)[KM_SUB * 32], Best out[KM_QT])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    int pa[2];
-    v4i_h Bq[2][8];
+    int pa[KM_QT];
+    v4i_h Bq[KM_QT][4];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int qi = qbase + 64 * wave + 32 * t + c;
+    for (int t = 0; t < KM_QT; t++) {
+        const int qi = qbase + 32 * KM_QT * wave + 32 * t + c;
         uint32_t Q[8];
         if (qi < nq) {
             const uint4 a = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[0];
@@ -345,17 +395,16 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
         }
         pa[t] = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            pa[t] += __popc(Q[k]);
-            Bq[t][k] = bits16_to_bytes<0x10204080u, 0x80808080u>(Q[k], h) | 0x40404040;   // 0xC0 = -64 per set bit, 0x40 = +64 per clear one
-        }
+        for (int k = 0; k < 8; k++) pa[t] += __popc(Q[k]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)   // k-step ks of this lane: word 2 ks + h; -1 (0b1010) per set bit, +1 (0b0010) per clear one
+            Bq[t][ks] = (bits32_to_slots(h ? Q[2 * ks + 1] : Q[2 * ks]) << 3) | 0x22222222;
         out[t].b1 = 256;
         out[t].idx = -1;
         out[t].b2 = 256;
     }
-    // staging role of this thread: word sw of the rows srow, srow + 32 of the staged tile (the 32 lanes of a half-wave write 32
-    // consecutive 16-byte slots: with the eight words of a row in adjacent lanes the writes were eight-way bank conflicts, 63 % of the
-    // LDS cycles of the kernel)
+    // staging role of this thread: word sw of the rows srow, srow + 32, ... of the staged tile (the 32 lanes of a half-wave write 32
+    // consecutive 16-byte slots)
     const int srow = tid & 31, sw = tid >> 5;
     constexpr int TR = 32 * KM_SUB;
     for (int c0 = j0; c0 < j1; c0 += KM_CHUNK) {   // (one trip unless the database has more rows than a key can index)
@@ -370,13 +419,14 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
         auto stage = [&](int buf, int jt, const uint32_t word[KM_SUB]) {
 #pragma unroll
             for (int u = 0; u < KM_SUB; u++) {
-                s_A[buf][u][sw][0][srow] = bits16_to_bytes<0x08102040u, 0x40404040u>(word[u], 0);
-                s_A[buf][u][sw][1][srow] = bits16_to_bytes<0x08102040u, 0x40404040u>(word[u], 1);
+                s_A[buf][u][sw][srow] = bits32_to_slots(word[u]);
                 const int j = jt + 32 * u + srow;
-                if (sw == 0) s_T[buf][32 * u + srow] = j < c1 ? j - c0 : KM_NONE;
+                if (sw == 0) s_T[buf][32 * u + srow] = j < c1 ? km_key(0, j - c0) : KM_NONE;
             }
         };
-        int m1[2] = {KM_NONE, KM_NONE}, m2[2] = {KM_NONE, KM_NONE};
+        int m1[KM_QT], m2[KM_QT];
+#pragma unroll
+        for (int t = 0; t < KM_QT; t++) m1[t] = m2[t] = KM_NONE;
         const int ntiles = (c1 - c0 + TR - 1) / TR;
         uint32_t word[KM_SUB];
         __syncthreads();   // (a previous chunk's last tile may still be read)
@@ -389,79 +439,117 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
 #pragma unroll
             for (int u = 0; u < KM_SUB; u++) {
                 // the accumulators start at the rows' keys: register 4 g + e of this lane = row 8 g + 4 h + e of the 32-row tile
-                v16i_h acc0, acc1;
+                v16f_h acc[KM_QT];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const v4i_h T4 = reinterpret_cast<const v4i_h *>(s_T[buf] + 32 * u)[2 * g + h];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        acc0[4 * g + e] = T4[e];
-                        acc1[4 * g + e] = T4[e];
+                    for (int e = 0; e < 4; e++)
+#pragma unroll
+                        for (int t = 0; t < KM_QT; t++) acc[t][4 * g + e] = __int_as_float(T4[e]);
+                }
+                v4i_h ring[KM_PREFETCH + 1];
+#pragma unroll
+                for (int k = 0; k < KM_PREFETCH; k++) ring[k] = s_A[buf][u][2 * k + h][c];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k + KM_PREFETCH < 4) ring[(k + KM_PREFETCH) % (KM_PREFETCH + 1)] = s_A[buf][u][2 * (k + KM_PREFETCH) + h][c];
+                    const v4i_h a = ring[k % (KM_PREFETCH + 1)];
+                    const v8i_h A8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < KM_QT; t++) {
+                        const v8i_h B8 = {Bq[t][k].x, Bq[t][k].y, Bq[t][k].z, Bq[t][k].w, 0, 0, 0, 0};
+                        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8, B8, acc[t], 4, 4, 0, KM_SCALE_A, 0, KM_SCALE_B);
                     }
                 }
+                // the smallest of the lane's 16 keys, and only IT enters the running pair (see above).  Each chain starts with a
+                // v_min the compiler sees -- it knows how long a matrix result must not be read after its instruction issued and
+                // waits in front of it; the inline v_min3 that follow depend on its result.
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const v4i_h a = s_A[buf][u][k][h][c];
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[0][k], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[1][k], acc1, 0, 0, 0);
-                }
+                for (int t = 0; t < KM_QT; t++) {
+                    int tm = min(__float_as_int(acc[t][0]), __float_as_int(acc[t][15]));
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    top2_update(m1[0], m2[0], acc0[r]);
-                    top2_update(m1[1], m2[1], acc1[r]);
+                    for (int r = 1; r < 15; r += 2) tm = min3_after(tm, __float_as_int(acc[t][r]), __float_as_int(acc[t][r + 1]));
+                    top2_update(m1[t], m2[t], tm);
                 }
             }
             if (n + 1 < ntiles) stage(buf ^ 1, c0 + TR * (n + 1), word);
         }
+        // rescan: the other 15 rows of the group the smallest key came from, by popcount
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < KM_QT; t++) {
+            const int qi = qbase + 32 * KM_QT * wave + 32 * t + c;
+            if (m1[t] < KM_NONE && qi < nq) {
+                const uint4 qa = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[0];
+                const uint4 qb = reinterpret_cast<const uint4 *>(q + (size_t)qi * 32)[1];
+                const int win = km_value(m1[t]) & (KM_CHUNK - 1), base = (win & ~31) + 4 * h;
+                const uint8_t *rows = db + (size_t)(c0 + base) * 32;
+                int m2v = m2[t];
+#pragma unroll 4
+                for (int ge = 0; ge < 16; ge++) {
+                    const int ro = 8 * (ge >> 2) + (ge & 3), rr = base + ro;
+                    if (rr != win && c0 + rr < c1) {
+                        const uint4 ra = reinterpret_cast<const uint4 *>(rows + ro * 32)[0];
+                        const uint4 rb = reinterpret_cast<const uint4 *>(rows + ro * 32)[1];
+                        const int nb = __popc(ra.x) + __popc(ra.y) + __popc(ra.z) + __popc(ra.w) + __popc(rb.x) + __popc(rb.y) +
+                                       __popc(rb.z) + __popc(rb.w);
+                        const int nab = __popc(ra.x & qa.x) + __popc(ra.y & qa.y) + __popc(ra.z & qa.z) + __popc(ra.w & qa.w) +
+                                        __popc(rb.x & qb.x) + __popc(rb.y & qb.y) + __popc(rb.z & qb.z) + __popc(rb.w & qb.w);
+                        m2v = min(m2v, km_key(nb - 2 * nab, rr));
+                    }
+                }
+                m2[t] = m2v;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KM_QT; t++) {
             // the other half of this query's rows, then this chunk behind the earlier ones
             const int o1 = __shfl_xor(m1[t], 32), o2 = __shfl_xor(m2[t], 32);
             const int k1 = min(m1[t], o1), k2 = min(max(m1[t], o1), min(m2[t], o2));
             const int add = pa[t] << 12;
             Best C;
-            C.b1 = k1 >= KM_NONE ? 256 : (k1 + add) >> 12;
-            C.idx = k1 >= KM_NONE ? -1 : c0 + (k1 & (KM_CHUNK - 1));
-            C.b2 = k2 >= KM_NONE ? 256 : (k2 + add) >> 12;
+            C.b1 = k1 >= KM_NONE ? 256 : (km_value(k1) + add) >> 12;
+            C.idx = k1 >= KM_NONE ? -1 : c0 + (km_value(k1) & (KM_CHUNK - 1));
+            C.b2 = k2 >= KM_NONE ? 256 : (km_value(k2) + add) >> 12;
             out[t] = best_merge_ordered(out[t], C);
         }
     }
 }
 
-__global__ __launch_bounds__(256, 4) void k_knn2_mfma(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ db, int ndb,
-                                                   int rowsPerSplit, int4 *__restrict__ partial)
+__global__ __launch_bounds__(256, KM_WAVES) void k_knn2_mfma(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ db, int ndb,
+                                                          int rowsPerSplit, int4 *__restrict__ partial)
 {
-    __shared__ v4i_h s_A[2][KM_SUB][8][2][32];
+    __shared__ v4i_h s_A[2][KM_SUB][8][32];
     __shared__ __align__(16) int s_T[2][KM_SUB * 32];
     const int split = blockIdx.y;
     const int j0 = split * rowsPerSplit, j1 = min(ndb, j0 + rowsPerSplit);
-    Best B[2];
-    knn2_mfma_core(q, nq, blockIdx.x * 256, db, j0, j1, s_A, s_T, B);
+    Best B[KM_QT];
+    knn2_mfma_core(q, nq, blockIdx.x * KM_QPB, db, j0, j1, s_A, s_T, B);
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int qi = blockIdx.x * 256 + 64 * (threadIdx.x >> 6) + 32 * t + (lane & 31);
+    for (int t = 0; t < KM_QT; t++) {
+        const int qi = blockIdx.x * KM_QPB + 32 * KM_QT * (threadIdx.x >> 6) + 32 * t + (lane & 31);
         if (lane < 32 && qi < nq) partial[(size_t)split * nq + qi] = make_int4(B[t].b1, B[t].idx, B[t].b2, 0);
     }
 }
 
-__global__ __launch_bounds__(256, 4) void k_knn2_seq_mfma(const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap,
-                                                       int lag, int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
-                                                       int32_t *__restrict__ second_d)
+__global__ __launch_bounds__(256, KM_WAVES) void k_knn2_seq_mfma(const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap,
+                                                              int lag, int32_t *__restrict__ best_idx, int32_t *__restrict__ best_d,
+                                                              int32_t *__restrict__ second_d)
 {
-    __shared__ v4i_h s_A[2][KM_SUB][8][2][32];
+    __shared__ v4i_h s_A[2][KM_SUB][8][32];
     __shared__ __align__(16) int s_T[2][KM_SUB * 32];
     const int b = blockIdx.y;
     const int nq = min(counts[b], cap);
-    if (blockIdx.x * 256 >= nq) return;   // whole block idle (uniform)
+    if (blockIdx.x * KM_QPB >= nq) return;   // whole block idle (uniform)
     const int ndb = b >= lag ? min(counts[b - lag], cap) : 0;
-    Best B[2];
-    knn2_mfma_core(desc + (size_t)b * cap * 32, nq, blockIdx.x * 256, desc + (size_t)(b >= lag ? b - lag : 0) * cap * 32, 0, ndb,
+    Best B[KM_QT];
+    knn2_mfma_core(desc + (size_t)b * cap * 32, nq, blockIdx.x * KM_QPB, desc + (size_t)(b >= lag ? b - lag : 0) * cap * 32, 0, ndb,
                    s_A, s_T, B);
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int qi = blockIdx.x * 256 + 64 * (threadIdx.x >> 6) + 32 * t + (lane & 31);
+    for (int t = 0; t < KM_QT; t++) {
+        const int qi = blockIdx.x * KM_QPB + 32 * KM_QT * (threadIdx.x >> 6) + 32 * t + (lane & 31);
         if (lane < 32 && qi < nq) {
             const size_t o = (size_t)b * cap + qi;
             best_idx[o] = B[t].idx;
@@ -505,7 +593,7 @@ void launch_knn2_seq(hipStream_t s, const uint8_t *desc, const int32_t *counts, 
     if (B <= 0) return;
     static const int mfmaEnv = ORB_SWITCH("KNN2_MFMA", 1);
     if (mfmaEnv && (reinterpret_cast<uintptr_t>(desc) & 15u) == 0)
-        hipLaunchKernelGGL(k_knn2_seq_mfma, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag, best_idx,
+        hipLaunchKernelGGL(k_knn2_seq_mfma, dim3((cap + KM_QPB - 1) / KM_QPB, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag, best_idx,
                            best_d, second_d);
     else
         hipLaunchKernelGGL(k_knn2_seq, dim3((cap + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, desc, counts, cap, lag,
