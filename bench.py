@@ -564,8 +564,12 @@ def content_classes(device, blob, B=256, steps=4):
     d_wt = torch.empty((B, cap), dtype=torch.float32, device=dev)
     ref = oracle.Extractor(NFEAT, 1.2, 8, 20, 7)
     voc = oracle.Vocabulary(blob)
-    for kind in synth.CONTENT_CLASSES:
-        uniq = synth.make_frames_class(kind, 2000, W, H, 8)
+    for kind in synth.CONTENT_CLASSES + ("photographs",):
+        # (photographs: the sample pictures scikit-learn / matplotlib install in this image, read where they lie -- the one class
+        # that is not orbhip/synth.py's own drawing; left out when they are absent)
+        uniq = synth.photograph_frames(W, H, 8) if kind == "photographs" else synth.make_frames_class(kind, 2000, W, H, 8)
+        if uniq is None:
+            continue
         frames = np.concatenate([uniq] * (B // 8))
         d_img = torch.from_numpy(np.ascontiguousarray(frames)).cuda(device)
 

@@ -39,7 +39,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
         assert e["ms"] > 0 and e["algorithmic_bytes"] > 0 and abs(e["frac"] - e["achieved_GBps"] / 8000.0) < 1e-3
     m = d["roofline_mfma"]
     assert m["bound"] == "mfma" and 0 < m["frac"] < 1 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
-    for kind in ("textured", "indoor_sparse", "white_noise", "low_contrast"):
+    from orbhip import synth
+    for kind in ("textured", "indoor_sparse", "white_noise", "low_contrast") + (("photographs",) if synth.load_photographs() else ()):
         assert d["content"][kind]["verified_frames"] == 2 and d["content"][kind]["value"] > 1000
     assert d["roofline"]["traffic_stale"] in (True, False)
 

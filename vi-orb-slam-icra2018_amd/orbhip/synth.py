@@ -108,6 +108,59 @@ def make_frames(seed, width, height, count, start=0):
 CONTENT_CLASSES = ("textured", "indoor_sparse", "white_noise", "low_contrast")
 
 
+def load_photographs():
+    """The camera photographs this image's Python packages install as sample data (scikit-learn: china.jpg, flower.jpg, 427 x 640;
+    matplotlib: grace_hopper.jpg, 600 x 512), as grey uint8 arrays at their own sizes -- the only real pictures available here
+    (no network, no dataset).  Read where they lie at run time, never copied; [] when the packages or PIL are absent.
+    Grey = (4899 R + 9617 G + 1868 B + 8192) >> 14, the fixed-point RGB -> grey of cv::cvtColor (ref: the grey conversion every
+    frame goes through before the extractor sees it, src/Tracking.cc GrabImageMonocular)."""
+    import os
+    out = []
+    try:
+        from PIL import Image
+    except Exception:
+        return out
+    paths = []
+    try:
+        import sklearn.datasets as skd
+        paths += [os.path.join(os.path.dirname(skd.__file__), "images", n) for n in ("china.jpg", "flower.jpg")]
+    except Exception:
+        pass
+    try:
+        import matplotlib
+        paths.append(os.path.join(os.path.dirname(matplotlib.__file__), "mpl-data", "sample_data", "grace_hopper.jpg"))
+    except Exception:
+        pass
+    for p in paths:
+        if not os.path.exists(p):
+            continue
+        rgb = np.asarray(Image.open(p).convert("RGB")).astype(np.int32)
+        out.append(((4899 * rgb[:, :, 0] + 9617 * rgb[:, :, 1] + 1868 * rgb[:, :, 2] + 8192) >> 14).astype(np.uint8))
+    return out
+
+
+def photograph_frames(width, height, count):
+    """`count` frames of width x height cut from the photographs: each photograph mirrored out to cover the frame, then windows of
+    it moved by a few pixels per frame (and flipped every other round) so that the frames differ.  None without photographs."""
+    photos = load_photographs()
+    if not photos:
+        return None
+    big = []
+    for g in photos:
+        ry = -(-(height + 64) // g.shape[0]) + 1
+        rx = -(-(width + 64) // g.shape[1]) + 1
+        row = np.concatenate([g if i % 2 == 0 else g[:, ::-1] for i in range(rx)], axis=1)
+        big.append(np.concatenate([row if i % 2 == 0 else row[::-1] for i in range(ry)], axis=0))
+    frames = []
+    for i in range(count):
+        b = big[i % len(big)]
+        r = i // len(big)
+        y0, x0 = (7 * r) % 64, (11 * r) % 64
+        f = b[y0:y0 + height, x0:x0 + width]
+        frames.append(f[:, ::-1] if (r & 1) else f)
+    return np.ascontiguousarray(np.stack(frames))
+
+
 def make_frames_class(kind, seed, width, height, count):
     """`count` frames of one of the content classes bench.py reports (FAST's cost depends on what it looks at):
       textured       make_frames: shapes of every contrast over band-limited noise (the headline's frames)
