@@ -266,16 +266,16 @@ def test_brute_force_matching_on_the_matrix_pipe_and_on_the_vector_pipe(mfma):
         "    if n == 0: continue\n"
         "    wi, wd, ws = oracle.knn2(desc[b, :n], desc[b - 1, :counts[b - 1]]) if b >= 1 else (np.full(n, -1), np.full(n, 256), np.full(n, 256))\n"
         "    assert np.array_equal(bi[b, :n], wi) and np.array_equal(bd[b, :n], wd) and np.array_equal(sd[b, :n], ws), b\n"
-        "# a database longer than one key range (4096 rows): the matrix kernel walks it in chunks\n"
-        "cap2 = 5000; counts2 = np.array([5000, 4300], np.int32)\n"
-        "desc2 = np.stack([lowent(cap2), lowent(cap2)]); desc2[0, 4500] = desc2[0, 17]; desc2[1, :600] = desc2[0, rng.integers(4000, 5000, 600)]\n"
+        "# a database longer than one key range (16384 rows): the matrix kernel walks it in chunks\n"
+        "cap2 = 17000; counts2 = np.array([17000, 4300], np.int32)\n"
+        "desc2 = np.stack([lowent(cap2), lowent(cap2)]); desc2[0, 16500] = desc2[0, 17]; desc2[1, :600] = desc2[0, rng.integers(16384, 17000, 600)]\n"
         "d_desc = hiprt.DevBuf.from_numpy(desc2); d_cnt = hiprt.DevBuf.from_numpy(counts2)\n"
         "d_bi, d_bd, d_sd = (hiprt.DevBuf(2 * cap2 * 4) for _ in range(3))\n"
         "check(ex._L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.ptr, d_cnt.ptr, cap2, 2, 1, d_bi.ptr, d_bd.ptr, d_sd.ptr), ex.handle)\n"
         "ex.sync()\n"
-        "wi, wd, ws = oracle.knn2(desc2[1, :4300], desc2[0, :5000])\n"
+        "wi, wd, ws = oracle.knn2(desc2[1, :4300], desc2[0, :17000])\n"
         "assert np.array_equal(d_bi.to_numpy(np.int32, (2, cap2))[1, :4300], wi) and np.array_equal(d_bd.to_numpy(np.int32, (2, cap2))[1, :4300], wd) and np.array_equal(d_sd.to_numpy(np.int32, (2, cap2))[1, :4300], ws)\n"
-        "assert (wi >= 4096).sum() > 100, 'the second chunk must win for some queries'\n"
+        "assert (wi >= 16384).sum() > 100, 'the second chunk must win for some queries'\n"
         "# the second best inside the winner's own group of the matrix tile (a lane holds rows 8 g + 4 h + e of a 32-row tile and only its\n"
         "# smallest key enters the running pair: the other 15 rows are looked at again after the chunk), both forms\n"
         "ndb, nq = 5000, 600\n"

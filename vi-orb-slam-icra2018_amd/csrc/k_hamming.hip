@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const int4 *__restrict__ par
 }
 
 #ifndef KM_WANT
-#define KM_WANT 4096      // workgroups a query is cut into (query tiles x database splits)
+#define KM_WANT 1024      // workgroups a query is cut into (query tiles x database splits): one round of four per CU -- a workgroup's
+                          // set-up and its rescan (below) are ~15 us in which its waves issue no matrix instruction, and the
+                          // workgroups of a round reach them together (4096 workgroups of 4096-row key ranges: 0.51 ms for 4000 x 1 M; 1024 of 16384: 0.47)
 #endif
 static void knn2_shape(int nq, int ndb, int *qTiles, int *nsplit, int *rows)
 {
@@ -309,17 +311,17 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
 // queries (B operand), four of them a tile of 1024 distances -- 4 matrix instructions instead of 1024 x (8 v_xor + 8 v_bcnt + 7
 // adds).  (r03: v_mfma_i32_32x32x32_i8 on the bits written out as bytes, 8 instructions per tile at the same 32 cycles each; the
 // FP4 form has twice the k per instruction, half the LDS image and half the operand registers.)
-//  * Exactness.  A row bit is the FP4 number 0.5 (0b0001) with block scale 2^7, a query bit +1 (clear, 0b0010) or -1 (set, 0b1010)
-//    with block scale 2^6: a set row bit contributes +-2^12, every partial sum is an integer below 2^23, the f32 accumulation is exact
+//  * Exactness.  A row bit is the FP4 number 0.5 (0b0001) with block scale 2^9, a query bit +1 (clear, 0b0010) or -1 (set, 0b1010)
+//    with block scale 2^6: a set row bit contributes +-2^14, every partial sum is an integer below 2^24, the f32 accumulation is exact
 //    (tools/microbench/fp4_dot.hip checks the instruction against the integer formula; the parity tests check the kernel).
 //  * The instruction also builds the comparison key.  |b| - 2 |a & b| = sum over the set bits of b of (1 - 2 a_k), and the
-//    accumulator starts at the row's index inside a chunk of 4096 database rows plus 2^21, so the result is
-//    ((|b| - 2 |a & b|) << 12) + row + 2^21, a POSITIVE float: ordered by distance, then by index, and its bit pattern orders like
+//    accumulator starts at the row's index inside a chunk of 16384 database rows plus a bias, so the result is
+//    ((|b| - 2 |a & b|) << 14) + row + bias, a POSITIVE float: ordered by distance, then by index, and its bit pattern orders like
 //    its value, so the epilogue is integer min / med3 on the raw registers (|a| is the same for all keys of a query and added at the end).
 //    What must come out is the two smallest keys -- (best, lowest index) and the second smallest distance of the multiset, exactly
 //    what the strict '<' loop of the reference leaves (:205-226).  A lane takes the minimum of its 16 keys of a 32-row tile (8
 //    v_min3_i32) and updates the running pair with that one key: m1 is exact, m2 is the second smallest GROUP minimum, and the true
-//    second key is min(m2, second key of the winner's group) -- 15 rows per query and 4096-row chunk, recomputed by popcount after
+//    second key is min(m2, second key of the winner's group) -- 15 rows per query and 16384-row chunk, recomputed by popcount after
 //    the chunk (the "rescan").  (r03 kept the pair per value: v_min + v_med3 per key, 136 of 238 vector instructions per 64 rows.)
 //  * Which bit goes to which k-slot is free as long as rows and queries agree: slot j of dword d of a word's 16-byte fragment holds
 //    bit 4 j + d, i.e. dword d = (word >> d) & 0x11111111 -- 7 vector instructions per 32 bits (the byte form took 24).
@@ -331,16 +333,16 @@ void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int
 typedef int v4i_h __attribute__((ext_vector_type(4)));
 typedef int v8i_h __attribute__((ext_vector_type(8)));
 typedef float v16f_h __attribute__((ext_vector_type(16)));
-#define KM_BIAS (1 << 21)
+#ifndef KM_SHIFT
+#define KM_SHIFT 14          // index bits of a key = log2 of the database rows per key range (14 is the most an exact f32 key holds)
+#endif
+#define KM_BIAS ((1 << (KM_SHIFT + 8)) + (1 << (KM_SHIFT + 2)))   // > 256 << KM_SHIFT, a multiple of the chunk: every key is positive
 #define KM_NONE 0x4C000000   // the f32 2^25 as a bit pattern: above every key
-#define KM_SCALE_A 134       // E8M0 2^7: a row's set bit, 0.5, counts 64
+#define KM_SCALE_A (127 + KM_SHIFT - 5)   // E8M0: a row's set bit, 0.5, counts 2^(KM_SHIFT - 6) (2^7 x 0.5 = 64 for 12 index bits)
 #define KM_SCALE_B 133       // E8M0 2^6: a query's bit, +-1, counts +-64
-#define KM_CHUNK 4096        // database rows per key range (12 index bits)
+#define KM_CHUNK (1 << KM_SHIFT)   // database rows per key range
 #ifndef KM_WAVES
 #define KM_WAVES 4           // waves per SIMD the register budget is set for
-#endif
-#ifndef KM_PREFETCH
-#define KM_PREFETCH 1        // A fragments requested ahead of the matrix instructions that use them
 #endif
 
 // 32 bits of a descriptor word -> 32 four-bit slots holding 0 or 1
@@ -370,6 +372,7 @@ __device__ __forceinline__ void top2_update(int &m1, int &m2, int key)
 }
 
 // the key of (distance term s = |b| - 2 |a & b|, row r of the chunk) as the matrix instruction leaves it, and back
+static_assert(KM_SHIFT >= 6 && 2 * (256 << KM_SHIFT) + (1 << (KM_SHIFT + 2)) + KM_CHUNK < (1 << 24), "keys must be integers an f32 holds exactly");
 __device__ __forceinline__ int km_key(int s, int r) { return __float_as_int((float)(s * KM_CHUNK + r + KM_BIAS)); }
 __device__ __forceinline__ int km_value(int key) { return (int)__int_as_float(key) - KM_BIAS; }
 
@@ -436,25 +439,32 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
             const int buf = n & 1;
             __syncthreads();   // tile n is staged; every wave is done with tile n - 1 (whose buffer the staging below overwrites)
             if (n + 1 < ntiles) fetch(c0 + TR * (n + 1), word);
+            // the accumulators start at the rows' keys: register 4 g + e of this lane = row 8 g + 4 h + e of the 32-row tile.  The
+            // start values and the first A fragment of a 32-row tile are requested BEFORE the keys of the tile in front of it
+            // are folded (into registers of their own): the LDS round trip runs beside the fold instead of behind it.
+            struct Start {
+                v4i_h T[4], a0;
+            };
+            auto request = [&](int u) {
+                Start S;
 #pragma unroll
-            for (int u = 0; u < KM_SUB; u++) {
-                // the accumulators start at the rows' keys: register 4 g + e of this lane = row 8 g + 4 h + e of the 32-row tile
-                v16f_h acc[KM_QT];
+                for (int g = 0; g < 4; g++) S.T[g] = reinterpret_cast<const v4i_h *>(s_T[buf] + 32 * u)[2 * g + h];
+                S.a0 = s_A[buf][u][h][c];
+                return S;
+            };
+            auto issue = [&](int u, const Start &S, v16f_h (&acc)[KM_QT]) {
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const v4i_h T4 = reinterpret_cast<const v4i_h *>(s_T[buf] + 32 * u)[2 * g + h];
+                for (int g = 0; g < 4; g++)
 #pragma unroll
                     for (int e = 0; e < 4; e++)
 #pragma unroll
-                        for (int t = 0; t < KM_QT; t++) acc[t][4 * g + e] = __int_as_float(T4[e]);
-                }
-                v4i_h ring[KM_PREFETCH + 1];
-#pragma unroll
-                for (int k = 0; k < KM_PREFETCH; k++) ring[k] = s_A[buf][u][2 * k + h][c];
+                        for (int t = 0; t < KM_QT; t++) acc[t][4 * g + e] = __int_as_float(S.T[g][e]);
+                v4i_h ring[2];
+                ring[0] = S.a0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (k + KM_PREFETCH < 4) ring[(k + KM_PREFETCH) % (KM_PREFETCH + 1)] = s_A[buf][u][2 * (k + KM_PREFETCH) + h][c];
-                    const v4i_h a = ring[k % (KM_PREFETCH + 1)];
+                    if (k + 1 < 4) ring[(k + 1) & 1] = s_A[buf][u][2 * (k + 1) + h][c];
+                    const v4i_h a = ring[k & 1];
                     const v8i_h A8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
 #pragma unroll
                     for (int t = 0; t < KM_QT; t++) {
@@ -462,16 +472,30 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
                         acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8, B8, acc[t], 4, 4, 0, KM_SCALE_A, 0, KM_SCALE_B);
                     }
                 }
-                // the smallest of the lane's 16 keys, and only IT enters the running pair (see above).  Each chain starts with a
-                // v_min the compiler sees -- it knows how long a matrix result must not be read after its instruction issued and
-                // waits in front of it; the inline v_min3 that follow depend on its result.
+            };
+            // the smallest of the lane's 16 keys, and only IT enters the running pair (see above).  Each chain starts with a
+            // v_min the compiler sees -- it knows how long a matrix result must not be read after its instruction issued and
+            // waits in front of it; the inline v_min3 that follow depend on its result.
+            auto fold = [&](const v16f_h (&acc)[KM_QT]) {
 #pragma unroll
                 for (int t = 0; t < KM_QT; t++) {
-                    int tm = min(__float_as_int(acc[t][0]), __float_as_int(acc[t][15]));
+                    // a tree, not a chain: five independent minima of three, two of those, one of two (depth 3 + the update)
+                    int x[16];
 #pragma unroll
-                    for (int r = 1; r < 15; r += 2) tm = min3_after(tm, __float_as_int(acc[t][r]), __float_as_int(acc[t][r + 1]));
-                    top2_update(m1[t], m2[t], tm);
+                    for (int r = 0; r < 16; r++) x[r] = __float_as_int(acc[t][r]);
+                    const int a0 = min(min(x[0], x[1]), x[2]), a1 = min(min(x[3], x[4]), x[5]), a2 = min(min(x[6], x[7]), x[8]);
+                    const int a3 = min(min(x[9], x[10]), x[11]), a4 = min(min(x[12], x[13]), x[14]);
+                    const int b0 = min(min(a0, a1), a2), b1 = min(min(a3, a4), x[15]);
+                    top2_update(m1[t], m2[t], min(b0, b1));
                 }
+            };
+            Start S = request(0);
+#pragma unroll
+            for (int u = 0; u < KM_SUB; u++) {
+                v16f_h acc[KM_QT];
+                issue(u, S, acc);
+                if (u + 1 < KM_SUB) S = request(u + 1);
+                fold(acc);
             }
             if (n + 1 < ntiles) stage(buf ^ 1, c0 + TR * (n + 1), word);
         }
@@ -506,11 +530,11 @@ __device__ __forceinline__ void knn2_mfma_core(const uint8_t *__restrict__ q, in
             // the other half of this query's rows, then this chunk behind the earlier ones
             const int o1 = __shfl_xor(m1[t], 32), o2 = __shfl_xor(m2[t], 32);
             const int k1 = min(m1[t], o1), k2 = min(max(m1[t], o1), min(m2[t], o2));
-            const int add = pa[t] << 12;
+            const int add = pa[t] << KM_SHIFT;
             Best C;
-            C.b1 = k1 >= KM_NONE ? 256 : (km_value(k1) + add) >> 12;
+            C.b1 = k1 >= KM_NONE ? 256 : (km_value(k1) + add) >> KM_SHIFT;
             C.idx = k1 >= KM_NONE ? -1 : c0 + (km_value(k1) & (KM_CHUNK - 1));
-            C.b2 = k2 >= KM_NONE ? 256 : (km_value(k2) + add) >> 12;
+            C.b2 = k2 >= KM_NONE ? 256 : (km_value(k2) + add) >> KM_SHIFT;
             out[t] = best_merge_ordered(out[t], C);
         }
     }
