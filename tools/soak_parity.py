@@ -245,8 +245,57 @@ def soak_match(budget, rng):
     print("soak matcher primitives ok: %d random configurations in %.0f s" % (n, time.time() - t0))
 
 
+def soak_knn2_seq(budget, rng):
+    """The frame-sequence form of the brute force (orbhip_hamming_knn2_seq_device: frame b against frame b - lag, one workgroup walks
+    the whole database of its frame): ragged counts, databases of one tile to several key ranges (16384 rows each), low-entropy
+    descriptors (ties decide index and second best) and near-duplicates planted next to the best row."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hiprt                                            # (tests/hiprt.py: device buffers without torch)
+    from orbhip.capi import check
+    from orbhip.extractor import ORBextractor
+    ex = ORBextractor(1000, max_w=640, max_h=480)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget:
+        cap = int(rng.choice([70, 300, 1000, 4000, 17000, 33500]))
+        B = int(rng.integers(2, 5))
+        lag = int(rng.integers(1, 3))
+        counts = rng.integers(0, cap + 1, B).astype(np.int32)
+        counts[rng.integers(0, B)] = cap
+        if cap > 4000:
+            counts[1:] = np.minimum(counts[1:], 1500)       # (the oracle's all-pairs loop sets the size)
+            counts[0] = cap
+        nbase = int(rng.integers(1, 60))
+        base = rng.integers(0, 256, (nbase, 32), dtype=np.uint8)
+        desc = base[rng.integers(0, nbase, (B, cap))].copy()
+        noise = rng.random((B, cap)) < 0.5
+        desc[noise, rng.integers(0, 32)] ^= rng.integers(0, 256, int(noise.sum()), dtype=np.uint8) & rng.integers(0, 256, int(noise.sum()), dtype=np.uint8)
+        d_desc, d_cnt = hiprt.DevBuf.from_numpy(desc), hiprt.DevBuf.from_numpy(counts)
+        d_bi, d_bd, d_sd = (hiprt.DevBuf(B * cap * 4) for _ in range(3))
+        check(ex._L.orbhip_hamming_knn2_seq_device(ex.handle, d_desc.ptr, d_cnt.ptr, cap, B, lag, d_bi.ptr, d_bd.ptr, d_sd.ptr), ex.handle)
+        ex.sync()
+        bi, bd, sd = (x.to_numpy(np.int32, (B, cap)) for x in (d_bi, d_bd, d_sd))
+        for b in range(B):
+            nq = int(counts[b])
+            if nq == 0:
+                continue
+            if b >= lag and counts[b - lag] > 0:
+                wi, wd, ws = oracle.knn2(desc[b, :nq], desc[b - lag, :counts[b - lag]])
+            else:
+                wi, wd, ws = np.full(nq, -1), np.full(nq, 256), np.full(nq, 256)
+            if not (np.array_equal(bi[b, :nq], wi) and np.array_equal(bd[b, :nq], wd) and np.array_equal(sd[b, :nq], ws)):
+                print("MISMATCH knn2_seq", cap, B, lag, counts, b)
+                sys.exit(1)
+        n += 1
+    ex.close()
+    print("soak knn2_seq ok: %d random configurations in %.0f s" % (n, time.time() - t0))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    if len(sys.argv) > 3 and sys.argv[3] == "knn2seq":
+        soak_knn2_seq(budget, np.random.default_rng(int(sys.argv[2])))
+        return
     if len(sys.argv) > 3 and sys.argv[3] == "match":
         soak_match(budget, np.random.default_rng(int(sys.argv[2])))
         return
