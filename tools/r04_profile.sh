@@ -46,6 +46,7 @@ done > $OUT/fast_ablate_pmc.txt 2>&1
 timeout 300 bash tools/pmc_gpu.sh l2 "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" 2>&1 | grep -E "^k_" > $OUT/counters_l2.txt
 python tools/percall_latency.py > $OUT/percall_table.md 2> $OUT/percall_stderr.txt
 bash tools/latency_native.sh 3000 > $OUT/latency_native.json 2>&1
+bash tools/knn_pmc.sh $TAG > $OUT/knn2_counters.txt 2>&1      # the 4000 x 1M query alone: kernel trace + two counter passes
 { nproc; lscpu | grep 'Model name'; rocm-smi --showclocks 2>/dev/null | head -12; } > $OUT/gpu_box_env.txt 2>&1
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 find $OUT -name '*.csv' -size +2M -delete
