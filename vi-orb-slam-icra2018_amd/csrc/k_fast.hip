@@ -664,7 +664,11 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
 #define FF_RHM 40                      // staged rows (hCell + 6) the fixed layout holds
 #define FF_DHM (FF_RHM - 6)
 #define FF_NCM 5                       // cells per run
-#define FF_LISTCAP 1664                // work list entries  (a third of the largest tile's pixels: 156 x 32 / 3)
+#define FF_LISTCAP 2176                // work list entries: what the eighth workgroup per CU leaves (8 x 20 KB of LDS): 44 % of the largest
+                                       // tile's pixels.  (r04: a third, 1664 -- on the photographs 15 % of the runs exceeded it and took the
+                                       // every-pixel path, 9 % exceed 2176: k_fast 1.55 -> 1.46 ms per 1024 frames there, the textured class
+                                       // 1.25 -> 1.22; taking the space from the corner list instead (2496 / 320) costs more in suppression
+                                       // scans than it saves: 1.60 / 1.26)
 #define FF_CORNERCAP 640               // corner list entries (an eighth)
 #define FF_GRPM 64                     // dword groups per row
 
@@ -1269,9 +1273,9 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     // bitmap and row prefix per (cell, row).  Tiles that exceed the lists take the exact fallback paths.
     const int px = listBytes / 2;                      // sp * hCell of the largest tile
     int listCap = px / 4, cornerCap = px / 16;
-    // (the fixed-layout kernel: a third and an eighth -- on densely textured frames 5 % of the runs exceeded a quarter /
-    // a sixteenth, and their fallbacks (every pixel scored; score tile scanned) were a third of the kernel's score work)
-    const int listCapFix = std::min(px / 3, FF_LISTCAP), cornerCapFix = std::min(px / 8, FF_CORNERCAP);
+    // (the fixed-layout kernel: up to a half (FF_LISTCAP) and an eighth -- on densely textured frames 5 % of the runs exceeded a
+    // quarter / a sixteenth, and their fallbacks (every pixel scored; score tile scanned) were a third of the kernel's score work)
+    const int listCapFix = std::min(px / 2, FF_LISTCAP), cornerCapFix = std::min(px / 8, FF_CORNERCAP);
     if (forced > 0) listCap = cornerCap = forced;
     const int lBytes = (listCap * 2 + 15) & ~15, cBytes = (cornerCap * 2 + 15) & ~15;
     const int bitsBytes = (bitsRows * 8 + 15) & ~15, preBytes = (bitsRows * 4 + 15) & ~15;
