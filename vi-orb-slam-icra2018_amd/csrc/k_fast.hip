@@ -661,8 +661,9 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
 // at the same 1.02 ms -- the kernel is bound by vector and LDS issue, not by its loads; the r01 mappings paid an integer division
 // per thread for the same traffic and were slower.
 #define FAST_DEFAULT_XCD 4
-#define FF_RHM 40                      // staged rows (hCell + 6) the fixed layout holds
-#define FF_DHM (FF_RHM - 6)
+#define FF_RHM 40                      // staged rows (hCell + 6) the fixed layout holds: cells of up to 34 rows, every level of 640 x 480 / 752 x 480 ...
+#define FF_RHM_TALL 48                 // ... and the instance for taller cells (a level of two or three cell rows rounds its cell height up:
+                                       // 1241 x 376 has cells of 40 rows at its smallest level); 1.7 KB more LDS: seven workgroups per CU
 #define FF_NCM 5                       // cells per run
 #define FF_LISTCAP 2176                // work list entries: what the eighth workgroup per CU leaves (8 x 20 KB of LDS): 44 % of the largest
                                        // tile's pixels.  (r04: a third, 1664 -- on the photographs 15 % of the runs exceeded it and took the
@@ -853,15 +854,15 @@ __device__ __forceinline__ int fast_score_ring_dark(uint32_t a, int t)
     return sc >= t ? sc : 0;
 }
 
-template <int PITCH, bool DEFER>
+template <int PITCH, bool DEFER, int RHM>
 __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__ lvl0, int stride0, unsigned long long frame0,
                                                      const uint8_t *__restrict__ pyr, unsigned long long pyrFrame,
                                                      const FastTile *__restrict__ tiles, uint32_t *__restrict__ cand,
                                                      uint16_t *__restrict__ cellCnt, int totalCells, int totalCands, int iniTh,
                                                      int minTh, int listCap, int cornerCap, int xcdMap, int ntiles ORB_ABL_PARAM)
 {
-    __shared__ __align__(16) uint8_t s_pix[PITCH * FF_RHM];
-    __shared__ unsigned long long s_bits[FF_NCM * FF_DHM];   // [cell][row]: survivors of the row (wCell < 64)
+    __shared__ __align__(16) uint8_t s_pix[PITCH * RHM];
+    __shared__ unsigned long long s_bits[FF_NCM * (RHM - 6)];   // [cell][row]: survivors of the row (wCell < 64)
     __shared__ uint16_t s_list[FF_LISTCAP];
     __shared__ uint16_t s_corner[FF_CORNERCAP];
     __shared__ uint32_t s_dom[FF_GRPM];   // per dword group: which of its 4 pixels lie in the domain (bit 8k + 7)
@@ -1290,31 +1291,38 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     static const int fixEnv = ORB_SWITCH("FAST_FIX", 1);
     static const int deferEnv = ORB_TUNE("FAST_DEFER", 1);
     const int maxCells = fast_tile_cells();   // the configured run length bounds every tile's
-    if (fixEnv && fixed && maxRh <= FF_RHM && maxCells <= FF_NCM) {
+    if (fixEnv && fixed && maxRh <= FF_RHM_TALL && maxCells <= FF_NCM) {
+        const bool tall = maxRh > FF_RHM;
         const int lc = forced > 0 ? std::min(forced, FF_LISTCAP) : listCapFix, cc = forced > 0 ? std::min(forced, FF_CORNERCAP) : cornerCapFix;
         static const int ldsPad = ORB_TUNE("FAST_LDS_PAD", 0);   // occupancy experiments (liborbhip_ablation.so)
         const size_t ldsScore = (size_t)scoreBytes + 16 + 256 + (size_t)ldsPad;   // + a row: nms_survives_fix reads one below the tile
         const bool perXcd = fastXcd == 4 && B >= 8;   // (a frame or two: the runs over all XCDs)
         if (perXcd) grid = dim3(8, ntiles, (B + 7) / 8);
-#define ORB_LAUNCH_FIX(P, D)                                                                                                 \
-    hipLaunchKernelGGL((k_fast_fix<P, D>), grid, block, ldsScore, s, lvl0, stride0, (unsigned long long)frame0, pyr,         \
+#define ORB_LAUNCH_FIX(P, D, R)                                                                                              \
+    hipLaunchKernelGGL((k_fast_fix<P, D, R>), grid, block, ldsScore, s, lvl0, stride0, (unsigned long long)frame0, pyr,      \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, G.totalCells, G.totalCands, G.iniTh, G.minTh, lc, \
                        cc, perXcd ? (4 | (B << 8)) : orb_xcd_arg(), ntiles ORB_ABL_ARG(phases))
+#define ORB_LAUNCH_FIX_P(D, R)                             \
+    switch (fixedFix) {                                    \
+    case 160: ORB_LAUNCH_FIX(160, D, R); break;            \
+    case 176: ORB_LAUNCH_FIX(176, D, R); break;            \
+    case 192: ORB_LAUNCH_FIX(192, D, R); break;            \
+    default: ORB_LAUNCH_FIX(208, D, R); break;             \
+    }
         if (deferEnv) {
-            switch (fixedFix) {
-            case 160: ORB_LAUNCH_FIX(160, true); break;
-            case 176: ORB_LAUNCH_FIX(176, true); break;
-            case 192: ORB_LAUNCH_FIX(192, true); break;
-            default: ORB_LAUNCH_FIX(208, true); break;
+            if (tall) {
+                ORB_LAUNCH_FIX_P(true, FF_RHM_TALL)
+            } else {
+                ORB_LAUNCH_FIX_P(true, FF_RHM)
             }
         } else {
-            switch (fixedFix) {
-            case 160: ORB_LAUNCH_FIX(160, false); break;
-            case 176: ORB_LAUNCH_FIX(176, false); break;
-            case 192: ORB_LAUNCH_FIX(192, false); break;
-            default: ORB_LAUNCH_FIX(208, false); break;
+            if (tall) {
+                ORB_LAUNCH_FIX_P(false, FF_RHM_TALL)
+            } else {
+                ORB_LAUNCH_FIX_P(false, FF_RHM)
             }
         }
+#undef ORB_LAUNCH_FIX_P
 #undef ORB_LAUNCH_FIX
         return;
     }
