@@ -247,6 +247,67 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restri
     node_id[i] = nidEdge >= 0 ? eid[nidEdge] : 0;
 }
 
+// Batches: FOUR LANES PER DESCRIPTOR.  The thread-per-descriptor form above requests 20 separate lines per lane and level (two
+// 16-byte halves of ten children: every load instruction touches 64 different lines) and is bound by the rate its texture unit
+// takes line requests (~1.1 per cycle and CU: 0.18 ms per 1024 frames at 17 % vector issue).  Here a quad takes two children per
+// trip -- lane q holds half (q & 1) of child (q >> 1): the quad's four 16-byte loads are 64 consecutive bytes, one request --,
+// the halves' popcounts meet by a quad permute, and the smallest key (distance << 20 | position: the first child with the
+// smallest distance, the strict '<' over the children in order, :1470) by a second one.  A quarter of the requests for 1.5 x the
+// vector instructions.
+__device__ __forceinline__ unsigned vq_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned vq_swap2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+
+#ifndef VT_LPD
+#define VT_LPD 4   // lanes per descriptor: 4 (two children per trip), 8 (four) or 16 (eight)
+#endif
+__global__ __launch_bounds__(256) void k_vocab_transform_quad(const uint8_t *__restrict__ desc, int n, int nidLevel, int rootFirst,
+                                                              int rootLast, const uint4 *__restrict__ edesc,
+                                                              const int2 *__restrict__ erange, const int32_t *__restrict__ eid,
+                                                              const int32_t *__restrict__ eword, const float *__restrict__ eweight,
+                                                              int32_t *__restrict__ word_id, float *__restrict__ weight,
+                                                              int32_t *__restrict__ node_id)
+{
+    constexpr int CPT = VT_LPD / 2;                          // children per trip
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = min(t / VT_LPD, n - 1), q = t & (VT_LPD - 1), half = q & 1, sub = q >> 1;   // (a tail group repeats the last descriptor and stores nothing)
+    const uint4 a = reinterpret_cast<const uint4 *>(desc + (size_t)i * 32)[half];   // this lane's half of the descriptor
+    int c0 = rootFirst, c1 = rootLast, level = 0, nidEdge = -1, e = 0;
+    constexpr int TRIPS = (VT_CHUNK + CPT - 1) / CPT;
+    do {
+        ++level;
+        unsigned best = 0xFFFFFFFFu;
+        for (int cb = c0; cb < c1; cb += TRIPS * CPT) {
+            uint4 p[TRIPS];
+#pragma unroll
+            for (int j = 0; j < TRIPS; j++) {             // unconditional loads from clamped edges, issued together
+                const int c = min(cb + CPT * j + sub, c1 - 1);
+                p[j] = edesc[2 * (size_t)c + half];
+            }
+#pragma unroll
+            for (int j = 0; j < TRIPS; j++) {
+                unsigned d = __popc(a.x ^ p[j].x) + __popc(a.y ^ p[j].y) + __popc(a.z ^ p[j].z) + __popc(a.w ^ p[j].w);
+                d += vq_swap1(d);                          // both halves of the child
+                const int c = cb + CPT * j + sub;
+                const unsigned key = (d << 20) | (unsigned)(c - c0);
+                if (c < c1) best = min(best, key);
+            }
+        }
+        best = min(best, vq_swap2(best));                  // the children columns of a quad, ...
+        if (VT_LPD >= 8) best = min(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x141, 0xF, 0xF, true));    // ... of two quads (row_half_mirror), ...
+        if (VT_LPD >= 16) best = min(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x140, 0xF, 0xF, true));   // ... of a row (row_mirror)
+        e = c0 + (int)(best & 0xFFFFFu);
+        if (level == nidLevel) nidEdge = e;
+        const int2 br = erange[e];
+        c0 = br.x;
+        c1 = br.y;
+    } while (c0 < c1);
+    if (q == 0 && (t / VT_LPD) < n) {
+        word_id[i] = eword[e];
+        weight[i] = eweight[e];
+        node_id[i] = nidEdge >= 0 ? eid[nidEdge] : 0;
+    }
+}
+
 void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *desc, int n, int levelsup,
                             int32_t *word_id, float *weight, int32_t *node_id, const int32_t *cnt)
 {
@@ -258,8 +319,13 @@ void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *
     hipLaunchKernelGGL(k_vocab_transform<E>, dim3((n + (T) - 1) / (T), 1, 1), dim3((T), 1, 1), 0, s, desc, n, V.L - levelsup,       \
                        V.rootFirst, V.rootLast, reinterpret_cast<const uint4 *>(V.desc), reinterpret_cast<const int2 *>(V.erange), \
                        V.eid, V.eword, V.eweight, word_id, weight, node_id, cnt)
+    static const int quad = ORB_TUNE("VOCAB_QUAD", 1);   // (A/B: 0 = thread per descriptor for batches too)
     if (n <= 16384)
         ORB_LAUNCH_VT(true, 64);
+    else if (quad && !cnt)
+        hipLaunchKernelGGL(k_vocab_transform_quad, dim3((int)(((size_t)n * VT_LPD + 255) / 256), 1, 1), dim3(256, 1, 1), 0, s, desc, n,
+                           V.L - levelsup, V.rootFirst, V.rootLast, reinterpret_cast<const uint4 *>(V.desc),
+                           reinterpret_cast<const int2 *>(V.erange), V.eid, V.eword, V.eweight, word_id, weight, node_id);
     else
         ORB_LAUNCH_VT(false, 256);
 #undef ORB_LAUNCH_VT
