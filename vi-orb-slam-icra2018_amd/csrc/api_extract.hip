@@ -346,7 +346,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     }
     if (B >= 8)
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles, c->nFastTilesBatch, c->d_cand,
-                    c->d_cellCnt, B);
+                    c->d_cellCnt, B, c->nFastTilesTall);
     else
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);

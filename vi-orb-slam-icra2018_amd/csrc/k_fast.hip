@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
 // at the same 1.02 ms -- the kernel is bound by vector and LDS issue, not by its loads; the r01 mappings paid an integer division
 // per thread for the same traffic and were slower.
 #define FAST_DEFAULT_XCD 4
-#define FF_RHM 40                      // staged rows (hCell + 6) the fixed layout holds: cells of up to 34 rows, every level of 640 x 480 / 752 x 480 ...
+#define FF_RHM FAST_FIX_ROWS            // staged rows (hCell + 6) the fixed layout holds: cells of up to 34 rows, every level of 640 x 480 / 752 x 480 ...
 #define FF_RHM_TALL 48                 // ... and the instance for taller cells (a level of two or three cell rows rounds its cell height up:
                                        // 1241 x 376 has cells of 40 rows at its smallest level); 1.7 KB more LDS: seven workgroups per CU
 #define FF_NCM 5                       // cells per run
@@ -1239,13 +1239,15 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
 #undef ENT_MAKE
 }
 
-void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
-                 const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
-                 uint32_t *cand, uint16_t *cellCnt, int B)
+// the runs tiles[0 .. ntiles) of the levels in levelMask, one launch
+static void launch_fast_levels(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
+                               const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
+                               uint32_t *cand, uint16_t *cellCnt, int B, unsigned levelMask)
 {
-    // LDS: pixel tile + score tile + work list of the largest run over all levels
+    // LDS: pixel tile + score tile + work list of the largest run over the levels of this launch
     int pixBytes = 0, scoreBytes = 0, listBytes = 0, survBytes = 0, bitsRows = 0, maxPitch = 0, maxRh = 0;
     for (int l = 0; l < G.nlevels; l++) {
+        if (!((levelMask >> l) & 1u)) continue;
         const OrbLevel &L = G.lv[l];
         int tileCells = fast_tile_cells();
         while (tileCells > 1 && tileCells * L.wCell + 6 + 16 > FAST_MAX_TILE_W) tileCells--;
@@ -1337,4 +1339,23 @@ void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
     default: ORB_LAUNCH_FAST(0); break;
     }
 #undef ORB_LAUNCH_FAST
+}
+
+// Batches: the run list is ordered [levels whose cells fit the 34-row instance | levels with taller cells] (orb_geometry.hip), ntall =
+// length of the second part.  When both parts exist they are two launches, so that the taller cells of one or two small levels
+// (1241 x 376, 1280 x 720, 960 x 540 ... end in them) do not put every level on the instance with seven workgroups per CU.
+void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
+                 const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
+                 uint32_t *cand, uint16_t *cellCnt, int B, int ntall)
+{
+    unsigned all = 0, tallMask = 0;
+    for (int l = 0; l < G.nlevels; l++) {
+        all |= 1u << l;
+        if (G.lv[l].hCell + 6 > FAST_FIX_ROWS) tallMask |= 1u << l;
+    }
+    if (ntall > 0 && ntall < ntiles && B >= 8) {
+        launch_fast_levels(s, G, lvl0, stride0, frame0, pyr, pyrFrame, tiles, ntiles - ntall, cand, cellCnt, B, all & ~tallMask);
+        launch_fast_levels(s, G, lvl0, stride0, frame0, pyr, pyrFrame, tiles + (ntiles - ntall), ntall, cand, cellCnt, B, tallMask);
+    } else
+        launch_fast_levels(s, G, lvl0, stride0, frame0, pyr, pyrFrame, tiles, ntiles, cand, cellCnt, B, all);
 }

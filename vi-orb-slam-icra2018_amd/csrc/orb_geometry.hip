@@ -4,6 +4,8 @@
 // (OpenCV 2.4 imgwarp.cpp, restated in DESIGN.md "pyramid").
 #include "orbhip_internal.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -282,6 +284,12 @@ int orb_build_geometry(orbhip_ctx *c, int w, int h, int stride0)
             }
     }
     c->blurLevelFirst[G.nlevels] = (int)c->blurTiles.size();
+    // levels with cells taller than the fixed-layout kernel's first instance holds go to the end of the batch list (launch_fast)
+    std::stable_partition(c->fastTiles.begin(), c->fastTiles.end(),
+                          [&](const FastTile &t) { return G.lv[t.level].hCell + 6 <= FAST_FIX_ROWS; });
+    c->nFastTilesTall = 0;
+    for (const FastTile &t : c->fastTiles)
+        if (G.lv[t.level].hCell + 6 > FAST_FIX_ROWS) c->nFastTilesTall++;
     c->nFastTilesBatch = (int)c->fastTiles.size();
     c->fastTiles.insert(c->fastTiles.end(), single.begin(), single.end());   // [batch list | single-frame list]
     for (FastTile &t : c->fastTiles) fast_tile_geometry(G, t);

@@ -48,6 +48,7 @@ static inline int orb_env_int(const char *name, int dflt)
 int fast_tile_cells();        // cells per workgroup actually used (<= FAST_TILE_CELLS; env ORBHIP_FAST_TILE_CELLS)
 #define FAST_MAX_TILE_W 320    // LDS tile width bound (pixels incl. halo, before 16-B rounding)
 #define FAST_MAX_TILE_H 72     // LDS tile height bound (hCell + 6)
+#define FAST_FIX_ROWS 40       // staged rows of the fixed-layout FAST kernel's first instance (k_fast.hip); levels with taller cells come last in the batch run list
 
 // Geometry of one pyramid level, shared by host and device code (passed by value in kernel args).
 struct OrbLevel {
@@ -203,6 +204,7 @@ struct orbhip_ctx {
     OrbLevels G;
     std::vector<FastTile> fastTiles;              // runs of up to 5 cells (batches), then runs of 1 cell (a frame or two)
     int nFastTilesBatch = 0;
+    int nFastTilesTall = 0;                       // ... of which the last nFastTilesTall belong to levels with cells taller than 34 rows
     std::vector<BlurTile> blurTiles;              // level by level
     int blurLevelFirst[ORBHIP_MAX_LEVELS + 1] = {};   // first tile of every level (and the end)
     std::vector<ChainTile> chainTiles;            // chained pyramid of the single-frame path (empty = not available)
@@ -332,7 +334,7 @@ void launch_pyramid_chain(hipStream_t s, const OrbLevels &G, const ChainLevels &
                           uint8_t *hostPyr);
 void launch_fast(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, const FastTile *tiles, int ntiles,
-                 uint32_t *cand, uint16_t *cellCnt, int B);
+                 uint32_t *cand, uint16_t *cellCnt, int B, int ntall = 0);
 void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, const uint16_t *cellCnt,
                      uint32_t *pts, uint32_t *pnode, int32_t *lvlCandCnt, uint32_t *lvlKp,
                      int32_t *lvlKpCnt, int B, uint8_t *tableScratch);
