@@ -230,10 +230,15 @@ int orbhip_search_by_bow(orbhip_ctx *ctx, const uint8_t *desc1, int n1, const ui
  * orbhip_bcast_blob_device); it is copied back once for parsing. */
 int orbhip_vocab_load(orbhip_ctx *ctx, const void *blob, size_t nbytes);
 int orbhip_vocab_load_device(orbhip_ctx *ctx, const void *d_blob, size_t nbytes);
-/* The vocabulary tables of `src` serve `dst` too (contexts of one device; borrowed, not copied -- 58 MB for the stock tree;
- * src must outlive dst's use of them).  What lets the extractor's context run the transform inside orbhip_frame_build on the
- * vocabulary the ORBVocabulary drop-in loaded into its own context. */
+/* The vocabulary tables of `src` serve `dst` too (contexts of one device; borrowed, not copied -- 58 MB for the stock tree).
+ * What lets the extractor's context run the transform inside orbhip_frame_build on the vocabulary the ORBVocabulary drop-in
+ * loaded into its own context.  The device block is reference-counted: src may load another vocabulary or be destroyed while
+ * dst still uses what it borrowed -- dst then keeps running on the OLD tables until it shares again.
+ * orbhip_vocab_generation: a process-wide counter of orbhip_vocab_load calls as seen by this context's tables (0 = no
+ * vocabulary); a borrower compares it with the lender's to learn that it should share again (no counterpart in the reference:
+ * System.cc:336-339 loads the vocabulary once). */
 int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src);
+unsigned long long orbhip_vocab_generation(const orbhip_ctx *ctx);
 /* Replaces ORBVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1564-1647; chosen by
  * src/System.cc:335-336 for a ".txt" vocabulary such as the stock ORBvoc.txt): host-only conversion of the text (first
  * line "k L scoring weighting", then per node "parent is_leaf d0 .. d31 weight") to the binary layout above, which
@@ -521,7 +526,11 @@ int orbhip_frame_build(orbhip_ctx *ctx, const uint8_t *img, int w, int h, int st
                        int32_t *cell_idx, int32_t *word_id, float *weight, int32_t *node_id);
 uint64_t orbhip_frame_fingerprint(const orbhip_ctx *ctx);
 /* orbhip_set_put with the frame that `src` built last: the FeatureVector (CSR as for orbhip_set_put; ng may be 0) is all
- * that travels.  ctx and src must be contexts of the same device (they may be the same context). */
+ * that travels.  ctx and src must be contexts of the same device (they may be the same context).  Several contexts may copy
+ * the same frame, each from its own thread: src's next orbhip_frame_build waits for every one of the copies.  What the caller
+ * orders itself, as with any two calls on one context: a copy of src's frame must not START (this call) while another thread
+ * is inside orbhip_frame_build on src -- in the reference the thread that builds a Frame is the one that makes it a KeyFrame
+ * (src/Tracking.cc, CreateNewKeyFrame). */
 int orbhip_set_put_from_frame(orbhip_ctx *ctx, uint64_t key, orbhip_ctx *src, const int32_t *node, const int32_t *off,
                               const int32_t *idx, int ng);
 

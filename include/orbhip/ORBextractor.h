@@ -91,7 +91,9 @@ public:
     // Is (keys, descriptors) the frame the last operator() built?  (count, first and last keypoint, first descriptor)
     bool BuiltFrame(const std::vector<cv::KeyPoint> &keys) const;
     // by-products of that frame; false when there are none (frame build off, another frame, other parameters)
-    bool BuiltKeysUn(const std::vector<cv::KeyPoint> &keys, std::vector<cv::KeyPoint> &keysUn) const;
+    // (K, distCoef: the asking Frame's calibration -- compared bit for bit with what SetFrameBuild was given, like the grid's bounds)
+    bool BuiltKeysUn(const std::vector<cv::KeyPoint> &keys, const cv::Mat &K, const cv::Mat &distCoef,
+                     std::vector<cv::KeyPoint> &keysUn) const;
     bool BuiltGrid(const std::vector<cv::KeyPoint> &keys, float minX, float minY, float invW, float invH, const int **cellOff,
                    const int **cellIdx) const;
     bool BuiltBoW(const std::vector<cv::KeyPoint> &keys, const ORBVocabulary *voc, int levelsup, const int **word, const float **weight,
@@ -131,6 +133,7 @@ private:
     int mFbNDist, mFbLevelsup;
     const ORBVocabulary *mpFbVoc;
     bool mbFbVocShared;
+    unsigned long long mnFbVocGen;              // orbhip_vocab_generation of the lender when its tables were borrowed
     int mnBuiltN;                               // features of the frame whose by-products are held; -1: none
     bool mbBuiltGrid, mbBuiltBoW;
     std::vector<cv::KeyPoint> mvBuiltKeysUn;

@@ -178,3 +178,47 @@ def test_cpp_frame_constructor_in_one_launch(tmp_path):
                          capture_output=True, text=True)
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert out.returncode == 0 and len(lines) >= 12 and all(l.endswith(" ok") for l in lines), out.stdout + out.stderr
+
+
+def test_borrowed_vocabulary_outlives_reload_and_destroy(oracle):
+    """orbhip_vocab_share lends the lender's device block.  The lender loading another vocabulary, or being destroyed,
+    must leave the borrower on valid (old) tables -- the block is reference-counted -- and orbhip_vocab_generation must tell the
+    borrower to share again, after which its frame build runs on the new tables."""
+    from orbhip import distributed as Dist, synth
+    from orbhip.extractor import ORBextractor
+    from orbhip.vocabulary import ORBVocabulary
+    img = synth.make_frames(43, 640, 480, 1)[0]
+    lender = ORBextractor(1000, max_w=640, max_h=480)
+    ex = ORBextractor(1000, max_w=640, max_h=480)
+    blobA = Dist.make_synthetic_vocabulary(61, k=10, L=4)
+    blobB = Dist.make_synthetic_vocabulary(62, k=9, L=4)
+    VA, VB = oracle.Vocabulary(blobA), oracle.Vocabulary(blobB)
+    voc = ORBVocabulary(lender)
+    voc.loadFromBinaryBlob(blobA)
+    assert voc.generation(ex) == 0
+    voc.shareWith(ex)
+    genA = voc.generation()
+    assert genA > 0 and voc.generation(ex) == genA
+    r = ex.frame_build(img, levelsup=4)
+    wantA = VA.transform(r["desc"], 4)
+    assert np.array_equal(r["word_id"], wantA[0]) and np.array_equal(r["node_id"], wantA[2])
+    r = ex.frame_build(img, levelsup=4)      # (the replayed graph)
+    assert np.array_equal(r["word_id"], wantA[0])
+    # the lender loads another vocabulary: the borrower still holds vocabulary A, and can see that it is behind
+    voc.loadFromBinaryBlob(blobB)
+    assert voc.generation() > genA and voc.generation(ex) == genA
+    junk = [ORBextractor(500, max_w=640, max_h=480) for _ in range(2)]   # (allocations that would reuse a freed block)
+    r = ex.frame_build(img, levelsup=4)
+    assert np.array_equal(r["word_id"], wantA[0]) and np.array_equal(r["node_id"], wantA[2]), "borrowed tables were freed"
+    voc.shareWith(ex)
+    assert voc.generation(ex) == voc.generation()
+    r = ex.frame_build(img, levelsup=4)
+    wantB = VB.transform(r["desc"], 4)
+    assert np.array_equal(r["word_id"], wantB[0]) and np.array_equal(r["node_id"], wantB[2]), "stale graph after sharing again"
+    # the lender goes away altogether
+    lender.close()
+    for j in junk:
+        j.close()
+    r = ex.frame_build(img, levelsup=4)
+    assert np.array_equal(r["word_id"], wantB[0]) and np.array_equal(r["node_id"], wantB[2])
+    ex.close()

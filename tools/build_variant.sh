@@ -6,7 +6,7 @@ NAME=$1; shift
 CS=vi-orb-slam-icra2018_amd/csrc
 OBJ=/tmp/orbhip_variant_$NAME
 mkdir -p $OBJ build_ab
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950:sramecc+ -ffp-contract=off -Wall -Wno-unused-function"
 pids=()
 for f in $CS/*.hip; do
   b=$(basename $f .hip)
@@ -19,5 +19,5 @@ for f in $CS/*.hip; do
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_ab/$NAME.so $OBJ/*.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950:sramecc+ -shared -fPIC -o build_ab/$NAME.so $OBJ/*.o -ldl
 echo built build_ab/$NAME.so

@@ -200,9 +200,10 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
                     c->d_lvlCandCnt, c->d_lvlKp, c->d_lvlKpCnt, c->d_lvlAngle, c->d_kps, c->d_desc,
-                    c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_blurBands, c->d_chainTiles, c->d_resizeTab, c->d_match, c->d_vocBlock, c->d_maps, c->d_tmp};
+                    c->d_counts, c->d_qtTables, c->d_fastTiles, c->d_blurTiles, c->d_blurBands, c->d_chainTiles, c->d_resizeTab, c->d_match, c->d_maps, c->d_tmp};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    c->vocHold.reset();   // (the block itself lives on while another context borrows it)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_pack) (void)hipHostFree(c->h_pack);
     for (int i = 0; i < 8; i++)

@@ -18,6 +18,8 @@
 #include "api_common.h"
 
 #include <time.h>
+#include <mutex>
+#include <vector>
 
 struct OrbFrameBuild {
     uint8_t *d_blk = nullptr;   // packed results, device
@@ -27,14 +29,17 @@ struct OrbFrameBuild {
     // offsets inside the block; [oU, setEnd) has the layout of a resident set's block (api_sets.hip)
     size_t oU = 0, oD = 0, oC = 0, oG = 0, oE = 0, setEnd = 0, oK = 0, oW = 0, oT = 0, oN = 0;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
-    hipEvent_t evBusy = nullptr;           // recorded by a context that copies the block (orbhip_set_put_from_frame)
-    bool busy = false;
+    // Contexts that are copying the block (orbhip_set_put_from_frame) each leave an event of their own here, on any thread; the
+    // owner's next orbhip_frame_build waits for all of them and hands the events back.  (One shared event was overwritten by a
+    // second copier: the build then waited for the last copy only.)
+    std::mutex busyMu;
+    std::vector<hipEvent_t> busyEvents, freeEvents;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     // replay key
     int w = 0, h = 0;
     orbhip_frame_params fp;
-    const void *key[6] = {};
+    const void *key[7] = {};
     unsigned long gen = 0;
     unsigned calls = 0;
     // the frame whose results the block holds
@@ -60,7 +65,10 @@ void orb_frame_release(orbhip_ctx *c)
     fb_graph_release(F);
     if (F->d_blk) (void)hipFree(F->d_blk);
     if (F->h_blk) (void)hipHostFree(F->h_blk);
-    for (hipEvent_t e : {F->evFork, F->evJoin, F->evBusy})
+    for (hipEvent_t e : F->busyEvents) (void)hipEventSynchronize(e);
+    for (hipEvent_t e : F->busyEvents) (void)hipEventDestroy(e);
+    for (hipEvent_t e : F->freeEvents) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {F->evFork, F->evJoin})
         if (e) (void)hipEventDestroy(e);
     delete F;
     c->frameBuild = nullptr;
@@ -160,7 +168,6 @@ extern "C" int orbhip_frame_build(orbhip_ctx *c, const uint8_t *img, int w, int 
         c->frameBuild = F;
         HIPCHK(c, hipEventCreateWithFlags(&F->evFork, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&F->evJoin, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&F->evBusy, hipEventDisableTiming));
     }
     const int dcap = (int)c->cap_out;
     if (F->dcap != dcap || !F->d_blk) {
@@ -211,11 +218,23 @@ extern "C" int orbhip_frame_build(orbhip_ctx *c, const uint8_t *img, int w, int 
     else
         for (int y = 0; y < h; y++) memcpy(c->h_in + (size_t)y * s0, img + (size_t)y * stride, (size_t)w);
     // a context that is still copying the last frame's block into a resident set (orbhip_set_put_from_frame) goes first
-    if (F->busy) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, F->evBusy, 0));
-        F->busy = false;
+    {
+        std::vector<hipEvent_t> pending;
+        {
+            std::lock_guard<std::mutex> g(F->busyMu);
+            pending.swap(F->busyEvents);
+        }
+        hipError_t e = hipSuccess;
+        for (hipEvent_t ev : pending)
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+        {
+            // (an enqueued wait refers to the record it saw: the event may be recorded again by the next copier)
+            std::lock_guard<std::mutex> g(F->busyMu);
+            F->freeEvents.insert(F->freeEvents.end(), pending.begin(), pending.end());
+        }
+        HIPCHK(c, e);
     }
-    const void *key[6] = {c->d_lvl0, F->d_blk, c->h_in, F->h_blk, hpyr, c->voc.desc};
+    const void *key[7] = {c->d_lvl0, F->d_blk, c->h_in, F->h_blk, hpyr, c->voc.desc, (const void *)(uintptr_t)c->voc.gen};
     const bool same = F->exec && F->w == w && F->h == h && F->gen == c->allocGen && memcmp(key, F->key, sizeof(key)) == 0 &&
                       memcmp(&F->fp, fp, sizeof(*fp)) == 0;
     static const bool noGraph = ORB_SWITCH("NO_GRAPH", 0) != 0;
@@ -233,7 +252,8 @@ extern "C" int orbhip_frame_build(orbhip_ctx *c, const uint8_t *img, int w, int 
         if (rc != ORBHIP_OK || e != hipSuccess || e2 != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
-            return fail(c, ORBHIP_E_HIP, std::string("orbhip_frame_build: graph capture failed: ") +
+            // (a refusal of fb_enqueue itself -- ORBHIP_E_SIZE from the grid kernel's limit -- keeps its own code)
+            return fail(c, rc != ORBHIP_OK ? rc : ORBHIP_E_HIP, std::string("orbhip_frame_build: graph capture failed: ") +
                                              (rc != ORBHIP_OK ? c->err : std::string(hipGetErrorString(e != hipSuccess ? e : e2))));
         }
         F->graph = g;
@@ -315,8 +335,18 @@ int orb_frame_mark_busy(orbhip_ctx *src, hipStream_t copier)
 {
     OrbFrameBuild *F = fb_of(src);
     if (!F) return ORBHIP_E_ARG;
-    if (hipEventRecord(F->evBusy, copier) != hipSuccess) return ORBHIP_E_HIP;
-    F->busy = true;
+    std::lock_guard<std::mutex> g(F->busyMu);
+    hipEvent_t ev = nullptr;
+    if (!F->freeEvents.empty()) {
+        ev = F->freeEvents.back();
+        F->freeEvents.pop_back();
+    } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+        return ORBHIP_E_HIP;
+    if (hipEventRecord(ev, copier) != hipSuccess) {
+        F->freeEvents.push_back(ev);
+        return ORBHIP_E_HIP;
+    }
+    F->busyEvents.push_back(ev);
     return ORBHIP_OK;
 }
 

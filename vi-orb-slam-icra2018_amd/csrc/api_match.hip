@@ -1,6 +1,7 @@
 // api_match.hip -- C ABI, part 3: Hamming best/second search, SearchByBoW (merge walk over the two FeatureVectors and the
 // rotation histogram on the host), the vocabulary, the distinctive-descriptor choice and SearchForTriangulation.
 #include "api_common.h"
+#include <atomic>
 
 // ------------------------------------------------------------------------------------------------
 // matching
@@ -169,6 +170,8 @@ extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1,
     const int npairs = (int)pairs.size() / 2;
     if (npairs == 0) return ORBHIP_OK;
     const int m1 = off1[ng1], m2 = off2[ng2];
+    // k_bow_match reduces (distance << 20 | position in the node's side-2 list) over the wave: the position needs 20 bits
+    if (m2 >= (1 << 20)) return fail(c, ORBHIP_E_SIZE, "orbhip_search_by_bow: more than 2^20 - 1 entries in the second FeatureVector");
     for (int t = 0; t < m1; t++)
         if (idx1[t] < 0 || idx1[t] >= n1) return fail(c, ORBHIP_E_ARG, "idx1 out of range");
     for (int t = 0; t < m2; t++)
@@ -274,11 +277,15 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
         off[i] = total;
         total += align_up(sizes[i], 256);
     }
-    if (c->d_vocBlock) HIPCHK(c, hipFree(c->d_vocBlock));
-    c->d_vocBlock = nullptr;
+    // The block is reference-counted: a context that borrowed the previous tables (orbhip_vocab_share) keeps them alive and
+    // keeps reading the OLD vocabulary until it shares again -- orbhip_vocab_generation tells it to.
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->vocHold.reset();
     c->voc = OrbVocabDev();
-    HIPCHK(c, hipMalloc(&c->d_vocBlock, total));
-    uint8_t *base = (uint8_t *)c->d_vocBlock;
+    void *blk = nullptr;
+    HIPCHK(c, hipMalloc(&blk, total));
+    c->vocHold = std::shared_ptr<void>(blk, [](void *p) { (void)hipFree(p); });
+    uint8_t *base = (uint8_t *)blk;
     const void *src[5] = {H.edesc.data(), H.erange.data(), H.child.data(), H.eword.data(), H.eweight.data()};
     for (int i = 0; i < 5; i++) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -291,12 +298,22 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
     V.eid = (int32_t *)(base + off[2]);
     V.eword = (int32_t *)(base + off[3]);
     V.eweight = (float *)(base + off[4]);
+    static std::atomic<unsigned long long> loads{0};
+    V.gen = ++loads;
     return ORBHIP_OK;
+}
+
+// Which load the context's tables come from: a process-wide counter, 0 without a vocabulary.  A borrower compares it with the value
+// it saw when it shared and shares again when the lender has loaded since (host/ORBextractor.cc).
+extern "C" unsigned long long orbhip_vocab_generation(const orbhip_ctx *c)
+{
+    return c && c->voc.desc ? c->voc.gen : 0ull;
 }
 
 // The tables of `src` serve `dst` as well (same device): what lets an extractor's context run the transform inside
 // orbhip_frame_build on the vocabulary that ORBVocabulary loaded into its own context.  Borrowed, not copied: 58 MB for the
-// stock tree.  `src` must outlive every use by `dst`; a vocabulary loaded into dst later replaces the borrowed one.
+// stock tree.  The block is reference-counted (OrbCtx::vocHold): `src` may load another vocabulary or be destroyed while `dst` still
+// runs on the tables it borrowed; a vocabulary loaded into dst later replaces the borrowed one.
 extern "C" int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src)
 {
     if (!dst || !src || !src->voc.desc) return fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: no vocabulary in the source context");
@@ -304,8 +321,7 @@ extern "C" int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src)
     if (dst == src) return ORBHIP_OK;
     HIPCHK(dst, hipSetDevice(dst->device));
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
-    if (dst->d_vocBlock) HIPCHK(dst, hipFree(dst->d_vocBlock));
-    dst->d_vocBlock = nullptr;          // nothing of its own to free
+    dst->vocHold = src->vocHold;
     dst->voc = src->voc;
     return ORBHIP_OK;
 }

@@ -368,6 +368,9 @@ extern "C" int orbhip_search_by_bow_sets(orbhip_ctx *c, uint64_t key1, const uin
     }
     const int npairs = (int)pairs.size() / 2;
     if (npairs == 0) return ORBHIP_OK;
+    // (k_bow_match keeps the position inside a node's side-2 list in 20 bits, as in orbhip_search_by_bow)
+    if (s2->ng > 0 && s2->off[s2->ng] >= (1 << 20))
+        return fail(c, ORBHIP_E_SIZE, "orbhip_search_by_bow_sets: more than 2^20 - 1 entries in the second FeatureVector");
     HIPCHK(c, hipSetDevice(c->device));
     Packed P(c);
     int rc;

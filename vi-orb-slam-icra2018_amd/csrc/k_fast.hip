@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
 #define FF_RHM_TALL 48                 // ... and the instance for taller cells (a level of two or three cell rows rounds its cell height up:
                                        // 1241 x 376 has cells of 40 rows at its smallest level); 1.7 KB more LDS: seven workgroups per CU
 #define FF_NCM 5                       // cells per run
-#define FF_LISTCAP 2176                // work list entries: what the eighth workgroup per CU leaves (8 x 20 KB of LDS): 44 % of the largest
+#define FF_LISTCAP 2176                // work list entries: what the eighth workgroup per CU leaves at the 176-byte pitch (8 x 20 KB of LDS; ff_max_lds below): 44 % of the largest
                                        // tile's pixels.  (r04: a third, 1664 -- on the photographs 15 % of the runs exceeded it and took the
                                        // every-pixel path, 9 % exceed 2176: k_fast 1.55 -> 1.46 ms per 1024 frames there, the textured class
                                        // 1.25 -> 1.22; taking the space from the corner list instead (2496 / 320) costs more in suppression
@@ -780,7 +780,8 @@ __device__ __forceinline__ uint32_t compass_items(const uint8_t *win, int nitems
 
 // ---- the ring gather of k_fast_fix: 17 byte loads at immediate offsets from one address, one wait ----
 // Ring pixel k comes by ds_read_u8, its opposite k + 8 by ds_read_u8_d16_hi: the byte lands in bits 16..23 and, on this target
-// (SRAM-ECC is always on: a d16 load rewrites the whole register), the other half is cleared -- so P[k] = lo | hi needs no
+// (SRAM-ECC on: a d16 load rewrites the whole register -- the library is built for gfx950:sramecc+, csrc/Makefile, so a device
+// that preserved the other half would refuse the code object instead of scoring garbage), the other half is cleared -- so P[k] = lo | hi needs no
 // shift (v_lshlrev_b32 is a four-cycle instruction, profiles/r03/valu_rates.txt: eight of them per work-list entry), and the
 // OR folds into the v_bitop3 that applies the polarity constant.  Issued from one asm block because the compiler cannot be
 // told about d16 loads of separate registers; the offsets are spelled per pitch (an asm operand list holds 30 entries).
@@ -853,6 +854,16 @@ __device__ __forceinline__ int fast_score_ring_dark(uint32_t a, int t)
     const int sc = arcs_score(P, 0x40FF40FFu, (int)v0u ^ 0xFF);
     return sc >= t ? sc : 0;
 }
+
+// LDS of a workgroup of the fixed-layout kernel: the static arrays below + the score tile (largest: SP x DH with SP <= PITCH - 20,
+// DH <= RHM - 6, + a padding row and the launcher's 16 + 256 bytes).  Eight workgroups per CU (8 x 20 KB of the 160 KB) hold
+// for the 160- and 176-byte pitches at 40 staged rows -- every level of 640 x 480 and 752 x 480; the wider pitches and the tall
+// instance run seven.
+constexpr int ff_static_lds(int pitch, int rhm) { return pitch * rhm + FF_NCM * (rhm - 6) * 8 + FF_LISTCAP * 2 + FF_CORNERCAP * 2 + FF_GRPM * 4 + 8 * 4 + 3 * 4 + 4 * 2 * 4; }
+constexpr int ff_max_lds(int pitch, int rhm) { return ff_static_lds(pitch, rhm) + (pitch - 20) * (rhm - 6) + 16 + 256; }
+static_assert(ff_max_lds(176, FAST_FIX_ROWS) <= 160 * 1024 / 8, "k_fast_fix<176>: the eighth workgroup per CU no longer fits (FF_LISTCAP / FF_CORNERCAP)");
+static_assert(ff_max_lds(160, FAST_FIX_ROWS) <= 160 * 1024 / 8, "k_fast_fix<160>: the eighth workgroup per CU no longer fits");
+static_assert(ff_max_lds(208, FF_RHM_TALL) <= 160 * 1024 / 6, "k_fast_fix<208, tall>: fewer than six workgroups per CU");
 
 template <int PITCH, bool DEFER, int RHM>
 __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__ lvl0, int stride0, unsigned long long frame0,

@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const uint8_t *__restrict__ d
             }
         }
         {
-            const int key = bpos != 0x7FFFFFFF ? ((bd1 << 20) | bpos) : 0x7FFFFFFF;   // (n2 < 2^20: orbhip_search_by_bow checks)
+            const int key = bpos != 0x7FFFFFFF ? ((bd1 << 20) | bpos) : 0x7FFFFFFF;   // (a FeatureVector of < 2^20 entries: orbhip_search_by_bow / _sets check)
             const int k1 = orb_wave_min_i(key);
             const int k2 = orb_wave_min_i(key == k1 ? bd2 : bd1);
             bd1 = k1 != 0x7FFFFFFF ? k1 >> 20 : 256;

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -158,6 +159,7 @@ struct OrbVocabDev {
     int32_t *eid = nullptr;                   // [nnodes - 1] node id
     int32_t *eword = nullptr;
     float *eweight = nullptr;
+    unsigned long long gen = 0;               // process-wide load counter (orbhip_vocab_generation): which load these tables are
 };
 
 // Host-fed pipeline (orbhip_pipe_*): a ring of `depth` device input slots and device / pinned-host output slots, a
@@ -294,7 +296,8 @@ struct orbhip_ctx {
 
     // vocabulary
     OrbVocabDev voc;
-    void *d_vocBlock = nullptr;
+    std::shared_ptr<void> vocHold;            // the device block behind `voc`, shared by every context that borrowed it
+                                              // (orbhip_vocab_share): freed when the last of them lets go
 
     // host-fed pipeline
     OrbPipe *pipe = nullptr;

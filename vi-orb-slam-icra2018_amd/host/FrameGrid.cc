@@ -48,7 +48,7 @@ void Frame::UndistortKeyPoints()
     mvKeysUn.resize(N);
     if (N == 0) return;
     // the frame this extractor has just built (ORBextractor::SetFrameBuild): the undistorted keypoints came with the extraction
-    if (mpORBextractorLeft && mpORBextractorLeft->BuiltKeysUn(mvKeys, mvKeysUn)) return;
+    if (mpORBextractorLeft && mpORBextractorLeft->BuiltKeysUn(mvKeys, mK, mDistCoef, mvKeysUn)) return;
     orbhip_ctx *ctx = frame_ctx(this, "Frame::UndistortKeyPoints");
     float K[9];
     std::vector<float> D;

@@ -28,7 +28,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels,
     iniThFAST(_iniThFAST), minThFAST(_minThFAST),
     mTimeOfComputePyramid(0), mTimeOfComputeKeyPointsOctTree(0), mTimeOfComputeDescriptor(0),
     mpCtx(nullptr), mCtxW(0), mCtxH(0), mbDownloadPyramid(true), mbBadParams(false),
-    mbFrameBuild(false), mFbNDist(0), mFbLevelsup(-1), mpFbVoc(nullptr), mbFbVocShared(false), mnBuiltN(-1), mbBuiltGrid(false),
+    mbFrameBuild(false), mFbNDist(0), mFbLevelsup(-1), mpFbVoc(nullptr), mbFbVocShared(false), mnFbVocGen(0), mnBuiltN(-1), mbBuiltGrid(false),
     mbBuiltBoW(false)
 {
     // scale tables, per-level quotas and umax (ref: src/ORBextractor.cc:417-471) -- host arithmetic
@@ -90,9 +90,23 @@ bool ORBextractor::BuiltFrame(const std::vector<cv::KeyPoint> &keys) const
     return memcmp(&keys[0], &mvKpStage[0], sizeof(cv::KeyPoint)) == 0 && memcmp(&keys[n - 1], &mvKpStage[n - 1], sizeof(cv::KeyPoint)) == 0;
 }
 
-bool ORBextractor::BuiltKeysUn(const std::vector<cv::KeyPoint> &keys, std::vector<cv::KeyPoint> &keysUn) const
+bool ORBextractor::BuiltKeysUn(const std::vector<cv::KeyPoint> &keys, const cv::Mat &K, const cv::Mat &distCoef,
+                               std::vector<cv::KeyPoint> &keysUn) const
 {
     if (!BuiltFrame(keys)) return false;
+    // the frame's own calibration, bit for bit what the build ran with -- otherwise Frame::UndistortKeyPoints makes its own call
+    if (K.rows != 3 || K.cols != 3) return false;
+    float k[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) k[r * 3 + c] = K.at<float>(r, c);
+    if (memcmp(k, mFbK, sizeof(k)) != 0) return false;
+    const int nd = distCoef.rows * distCoef.cols;
+    if (nd != mFbNDist) return false;
+    for (int i = 0; i < nd; i++)
+    {
+        const float d = distCoef.rows == 1 ? distCoef.at<float>(0, i) : distCoef.at<float>(i, 0);
+        if (memcmp(&d, &mFbDist[i], sizeof(float)) != 0) return false;
+    }
     keysUn.assign(mvBuiltKeysUn.begin(), mvBuiltKeysUn.begin() + mnBuiltN);
     return true;
 }
@@ -154,10 +168,15 @@ void ORBextractor::operator()( cv::InputArray _image, cv::InputArray _mask, std:
         fp.ndist = mFbNDist;
         fp.min_x = mFbGrid[0]; fp.min_y = mFbGrid[1]; fp.inv_w = mFbGrid[2]; fp.inv_h = mFbGrid[3];
         fp.levelsup = mFbLevelsup;
+        // (the vocabulary object may have loaded again since its tables were borrowed: its generation says so)
+        if (mpFbVoc && mbFbVocShared && orbhip_vocab_generation(mpFbVoc->Context()) != mnFbVocGen) mbFbVocShared = false;
         if (mpFbVoc && !mbFbVocShared)
         {
             if (mpFbVoc->Context() && orbhip_vocab_share(mpCtx, mpFbVoc->Context()) == ORBHIP_OK)
+            {
                 mbFbVocShared = true;
+                mnFbVocGen = orbhip_vocab_generation(mpFbVoc->Context());
+            }
             else
                 fp.levelsup = -1;                            // (ComputeBoW then runs its own transform)
         }

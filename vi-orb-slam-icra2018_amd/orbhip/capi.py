@@ -58,7 +58,7 @@ SYMBOLS = [
     "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
     "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
     "orbhip_set_put", "orbhip_set_has", "orbhip_set_drop", "orbhip_search_by_bow_sets", "orbhip_window_best_set",
-    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_debug_roundtrip", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
+    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_vocab_generation", "orbhip_debug_roundtrip", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
 ]
 
 
@@ -138,6 +138,9 @@ def load():
     L.orbhip_vocab_load.argtypes = [vp, vp, C.c_size_t]
     L.orbhip_vocab_load_device.argtypes = [vp, vp, C.c_size_t]
     L.orbhip_vocab_info.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    L.orbhip_vocab_share.argtypes = [vp, vp]
+    L.orbhip_vocab_generation.argtypes = [vp]
+    L.orbhip_vocab_generation.restype = C.c_ulonglong
     L.orbhip_vocab_text_to_binary.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t]
     L.orbhip_vocab_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_vocab_transform_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]

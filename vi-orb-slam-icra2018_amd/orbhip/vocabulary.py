@@ -53,6 +53,15 @@ class ORBVocabulary:
         self._info()
         return True
 
+    def shareWith(self, other_ctx):
+        """orbhip_vocab_share: another context of the same device (an ORBextractor) runs on these tables too -- what the C++
+        ORBextractor does before orbhip_frame_build.  The block is reference-counted; generation() tells a borrower to share
+        again after this object has loaded another vocabulary."""
+        check(self._L.orbhip_vocab_share(other_ctx.handle, self._ctx.handle), other_ctx.handle, "orbhip_vocab_share")
+
+    def generation(self, ctx=None):
+        return int(self._L.orbhip_vocab_generation((ctx or self._ctx).handle))
+
     def transform_raw(self, desc, levelsup=4):
         """(word_id, weight, node_id) per descriptor -- TemplatedVocabulary.h:1443-1485."""
         desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
