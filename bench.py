@@ -142,6 +142,67 @@ def verify_against_oracle(kept, bufs, cap, match):
     return n
 
 
+def verify_tiled_copies(bufs, U, B, cap, match):
+    """Every frame of the batch beyond the first U + 1 is a copy of one of them (frame b = distinct frame b % U, its predecessor
+    = distinct frame (b - 1) % U): its keypoint count, keypoints, descriptors and match results must equal, bit for bit, those of
+    its ORIGINAL -- frame b % U for what belongs to the frame, row ((b - 1) % U) + 1 for what belongs to the pair (b - 1, b).  The
+    originals are rows 0 .. U, which verify_against_oracle has compared with the oracle.  Runs on the device (a few gathers and
+    compares of ~100 MB); returns the number of copies checked, raises SystemExit(3) at the first difference.  Also proves that
+    the batch path is deterministic across the batch: U outputs repeated B / U times by different workgroups at different times."""
+    import torch
+    if B <= U + 1:
+        return 0
+    cnt = bufs["cnt"][:B]
+    dev = cnt.device
+    b = torch.arange(B, device=dev)
+    orig = b % U
+    porig = torch.where(b >= 1, (b - 1) % U + 1, b)
+    prev = (b - 1).clamp(min=0)
+
+    def bad(what, mask_rows):
+        row = int(torch.nonzero(mask_rows)[0].item())
+        print("bench.py: frame %d of the timed batch differs from its original (frame %d): %s" % (row, row % U, what), file=sys.stderr)
+        raise SystemExit(3)
+    d = cnt != cnt[orig]
+    if bool(d.any()):
+        bad("keypoint count", d)
+    col = torch.arange(cap, device=dev)[None, :]
+    live = col < cnt[:, None]                                  # (B, cap): features of frame b
+    live_prev = col < cnt[prev][:, None]                       # features of frame b - 1
+    d = ((bufs["kps"][:B] != bufs["kps"][:B][orig]).any(-1) & live).any(-1)
+    if bool(d.any()):
+        bad("keypoints", d)
+    d = ((bufs["desc"][:B] != bufs["desc"][:B][orig]).any(-1) & live).any(-1)
+    if bool(d.any()):
+        bad("descriptors", d)
+    pair = b >= 1
+    if match in ("bow", "both"):
+        d = (bufs["nm"][:B] != bufs["nm"][:B][porig]) & pair
+        if bool(d.any()):
+            bad("SearchByBoW match count", d)
+        d = ((bufs["m21"][:B] != bufs["m21"][:B][porig]) & live).any(-1) & pair
+        if bool(d.any()):
+            bad("SearchByBoW match21", d)
+        d = ((bufs["m12"][:B] != bufs["m12"][:B][porig]) & live_prev).any(-1) & pair
+        if bool(d.any()):
+            bad("SearchByBoW match12", d)
+    if match in ("brute", "both"):
+        for name in ("bi", "bd", "sd"):
+            d = ((bufs[name][:B] != bufs[name][:B][porig]) & live).any(-1) & pair
+            if bool(d.any()):
+                bad("brute-force " + name, d)
+    return B - (U + 1)
+
+
+def gather_objects(dist, obj, world):
+    """One Python object per rank on every rank (any backend); [obj] without a process group."""
+    if dist is None or world == 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def cpu_worker(path, nsample, match):
     """Child process of cpu_baseline_all_cores: never touches the GPU; prints its own frame count and seconds."""
     z = np.load(path, allow_pickle=False)
@@ -278,7 +339,7 @@ def host_fed_throughput(args, uniq, blob, device):
     ex.close()
     fps = nb * Bp / dt
     return {"value": round(fps, 1), "unit": "frames/s", "pinned": True, "frames_per_batch": Bp, "ring_depth": depth,
-            "batches": nb, "h2d_GBps": round(fps * W * H / 1e9, 2),
+            "batches": nb, "seconds": round(dt, 4), "h2d_GBps": round(fps * W * H / 1e9, 2),
             "d2h_GBps": round(fps * (ex.cap * (28 + 32 + (8 if blob is not None else 0)) + 8) / 1e9, 2),
             "keypoints_per_frame": round(nkp / (nb * Bp), 1),
             "note": "orbhip_pipe_submit / orbhip_pipe_wait: frames in pinned host memory, copy-in, kernels (extract"
@@ -617,6 +678,68 @@ def content_classes(device, blob, B=256, steps=4):
     return out
 
 
+def config_streams_ranks(device, blob, rank, world, dist, barrier, B=512, uniq=16):
+    """BASELINE config 4 proper under N ranks: the four EuRoC sequences (V1_01 / V1_02 / V2_01 / MH_02; twice for eight ranks), whole
+    streams assigned to ranks longest first (orbhip.distributed.assign_streams: one stream per rank from N = 4 on), every rank runs
+    its streams through orbhip.streams.StreamRunner on its own GPU -- no exchange per frame; the vocabulary has already travelled.
+    value = all frames / the slowest rank's time.  Every rank checks the sampled frames of its first stream against the oracle."""
+    from orbhip import distributed as D
+    from orbhip import streams, synth
+    oracle = _oracle()
+    lengths = [n for _, n in streams.EUROC_STREAMS] * max(1, (world + 3) // 4)
+    lengths = lengths[:max(4, world)]
+    plan = D.assign_streams(lengths, world)
+    mine = plan[rank]
+    runners = [(si, streams.StreamRunner(device, B, synth.make_frames(2000 + si, streams.W, streams.H, uniq), blob=blob)) for si in mine]
+    for si, r in runners:
+        r.run(min(lengths[si], B))                              # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    for si, r in runners:
+        r.run(lengths[si])
+    barrier()
+    dt = time.perf_counter() - t0
+    verified = 0
+    if runners:
+        si, r = runners[0]
+        n = lengths[si]
+        got = r.run(n, streams.default_samples(n, B))
+        ref, V = oracle.Extractor(streams.NFEAT, 1.2, 8, 20, 7), oracle.Vocabulary(blob)
+        cache = {}
+
+        def rf(t):
+            if t not in cache:
+                k, d = ref(r.frame(t))
+                _, wt, nid = V.transform(d, streams.LEVELSUP)
+                cache[t] = (k, d, oracle.feature_vector(nid, wt))
+            return cache[t]
+        for t, rec in sorted(got.items()):
+            k, d, fv = rf(t)
+            if rec["n"] != len(k) or rec["kps"] != k.tobytes() or not np.array_equal(rec["desc"], d):
+                raise SystemExit("bench.py: config 4, rank %d: frame %d of stream %d differs from the oracle" % (rank, t, si))
+            if t >= 1:
+                pk, pd, pfv = rf(t - 1)
+                nm, m12, m21 = oracle.search_by_bow(pd, np.ones(len(pd), np.uint8), pk["angle"], pfv, d, None, k["angle"], fv,
+                                                    th=50, th_mode=0, nnratio=NNRATIO, check_ori=True)
+                if rec["nm"] != nm or not np.array_equal(rec["m12"], m12) or not np.array_equal(rec["m21"], m21):
+                    raise SystemExit("bench.py: config 4, rank %d: SearchByBoW of frame %d differs from the oracle" % (rank, t))
+            verified += 1
+    for _, r in runners:
+        r.close()
+    allr = gather_objects(dist, (dt, sum(lengths[si] for si in mine), verified, len(mine)), world)
+    tmax = max(a[0] for a in allr)
+    total = sum(a[1] for a in allr)
+    return {"workload": "EuRoC %s: %s frames %dx%d, %d features, one stream per rank from 4 ranks on (assignment %s), extract + "
+                        "vocabulary transform + SearchByBoW vs previous frame, batches of %d overlapping by one frame" % (
+                            " / ".join(nm for nm, _ in streams.EUROC_STREAMS), "+".join(str(n) for n in lengths), streams.W, streams.H,
+                            streams.NFEAT, plan, B),
+            "value": round(total / tmax, 1), "unit": "frames/s", "frames": int(total), "seconds": round(tmax, 4), "ranks": world,
+            "per_rank": [{"rank": i, "streams": a[3], "frames": a[1], "seconds": round(a[0], 4),
+                          "frames_per_s": round(a[1] / a[0], 1) if a[0] > 0 else None, "verified": a[2]} for i, a in enumerate(allr)],
+            "verified": sum(a[2] for a in allr),
+            "verified_what": "sampled frames of every rank's first stream (keypoints, descriptors, SearchByBoW) vs oracle"}
+
+
 def secondary_configs(device, blob):
     """BASELINE.json configs 2-5 on this GPU, each with its own check against the oracle; ~40 s in total."""
     from orbhip.streams import EUROC_STREAMS
@@ -650,8 +773,18 @@ def main():
                     "region, each verified against the oracle); 0 = skip")
     ap.add_argument("--content", type=int, default=1, help="also run the step on the synthetic content classes of orbhip/synth.py "
                     "(textured, indoor_sparse, white_noise, low_contrast), each verified against the oracle; 0 = skip")
-    ap.add_argument("--verify", type=int, default=8, help="frames of the timed batch whose GPU outputs are compared with "
-                    "the oracle outside the timed region (0 = skip); a difference ends the run with exit code 3")
+    ap.add_argument("--verify", type=int, default=-1, help="frames of the timed batch whose GPU outputs are compared with "
+                    "the oracle outside the timed region (0 = skip; -1 = every distinct frame and the pair across the first tile "
+                    "boundary, i.e. unique + 1); a difference ends the run with exit code 3.  With one context every tiled copy is "
+                    "then compared ON THE DEVICE with its original, so that the whole timed batch is verified")
+    ap.add_argument("--no-tiling", type=int, default=1, help="also time a few steps on a batch of `batch` DISTINCT frames (the "
+                    "distinct frames shifted cyclically, a different shift per copy) -- shows that tiling 32 frames to the batch "
+                    "neither costs nor gains; 0 = skip")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("ORBHIP_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend of an N > 1 run; gloo only for ranks that share one device (tests): RCCL "
+                    "refuses duplicate devices, the vocabulary then travels through host memory")
+    ap.add_argument("--streams-config", type=int, default=-1, help="N > 1: also run BASELINE config 4 proper, one EuRoC stream per "
+                    "rank (-1 = when N >= 4; 1 = always; 0 = never)")
     args = ap.parse_args()
     if args.cpu_worker:
         cpu_worker(args.cpu_worker, args.cpu_frames, args.match)
@@ -699,7 +832,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    # N > 1: every rank next to its GPU (CPUs of the GPU's NUMA node), before anything page-locked is allocated
+    numa = D.numa_bind(local_rank, bind=os.environ.get("ORBHIP_BENCH_NUMA_BIND", "1") != "0") if dist is not None else None
 
     from orbhip import synth
     from orbhip.extractor import ORBextractor
@@ -738,7 +876,10 @@ def main():
     rccl_ranks, bcast_ms = None, None
     if use_bow or dist is not None:
         blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L) if rank == 0 else b""
-        if dist is not None:
+        if dist is not None and args.backend != "nccl":
+            buf = D.broadcast_blob(blob, src=0, device="cpu")
+            blob = bytes(buf.numpy().tobytes())
+        elif dist is not None:
             from orbhip import streams
 
             def exchange(u):
@@ -757,16 +898,17 @@ def main():
                 ORBVocabulary(ex).loadFromDeviceBlob(d_blob.data_ptr(), d_blob.numel())
             else:
                 ORBVocabulary(ex).loadFromBinaryBlob(blob)
-    if d_blob is not None and rank != 0 and use_bow:
-        blob = None
+    if d_blob is not None and rank != 0:
+        blob = bytes(d_blob.cpu().numpy().tobytes())      # (every rank checks its own outputs against the oracle)
     del d_blob
     ex0 = ctxs[0][0]
     cap = ex0.cap
     L = ex0._L
 
-    def step():
-        for ex, b in ctxs:
-            ex.extract_batch_device(b["img"].data_ptr(), Bc, W, H, W, H * W, b["kps"].data_ptr(), b["desc"].data_ptr(), cap,
+    def step(img=None):
+        for ci, (ex, b) in enumerate(ctxs):
+            src = b["img"] if img is None else img[ci * Bc:(ci + 1) * Bc]
+            ex.extract_batch_device(src.data_ptr(), Bc, W, H, W, H * W, b["kps"].data_ptr(), b["desc"].data_ptr(), cap,
                                     b["cnt"].data_ptr())
             if use_bow:
                 rc = L.orbhip_vocab_transform_device(ex.handle, b["desc"].data_ptr(), Bc * cap, LEVELSUP, b["word"].data_ptr(),
@@ -822,13 +964,8 @@ def main():
                 stage[i] += ms[i] * max(args.steps, 1) / stage_pass
             fast_instrumented += ms[1] / stage_pass
     barrier()
-    per_rank_dt = [dt]
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        allt = torch.empty(world, dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(allt, t)
-        per_rank_dt = [float(x) for x in allt.cpu().numpy()]
-        dt = max(per_rank_dt)                                  # the MAX over ranks is the job's time
+    per_rank_dt = [float(x) for x in gather_objects(dist, dt, world)]
+    dt = max(per_rank_dt)                                      # the MAX over ranks is the job's time
     stage /= max(args.steps, 1)
 
     counts = np.concatenate([b["cnt"].cpu().numpy() for _, b in ctxs])
@@ -863,6 +1000,10 @@ def main():
             rooflines.append({"kernel": kname, "algorithmic_bytes": int(by * Bc), "ms": round(ms_k, 4),
                               "achieved_GBps": round(by * Bc / (ms_k * 1e-3) / 1e9, 1) if ms_k > 0 else 0.0,
                               "frac": round(by * Bc / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_k > 0 else 0.0})
+        # the whole step against the HBM roofline: the streaming kernels' algorithmic bytes + what the matching stage reads and writes
+        # per keypoint (descriptor 32 B read by the transform and twice by SearchByBoW -- as side 1 and as side 2 -- word / weight /
+        # node 12 B written and read, match12 / match21 8 B written)
+        step_bytes = (sum(alg_stage.values()) + (kp_mean * (3 * 32 + 2 * 12 + 8) if use_bow else 0.0)) * B
         # vector-issue roofline: 1024 SIMDs, one wave64 instruction per 4 cycles each, at the clock the counters saw
         issue_peak = 1024 / 4.0 * float(ctr.get("clock_ghz", 2.4)) * 1e9
         out = {
@@ -891,6 +1032,8 @@ def main():
             # one entry per streaming kernel of the step: SURVEY section 8d's algorithmic bytes per launch / the stage's HIP-event time of this
             # run (the instrumented pass behind the timed region) / 8 TB/s
             "rooflines": rooflines,
+            "step_hbm_frac": round(step_bytes / (dt / max(args.steps, 1)) / 1e9 / HBM_PEAK_GBS, 4) if dt > 0 else None,
+            "step_algorithmic_bytes": int(step_bytes),
             "roofline_valu": None if not valu or fast_ms <= 0 else {
                 "kernel": "k_fast", "wave_insts": int(valu), "stale": ctr_stale, "achieved": round(valu / (fast_ms * 1e-3) / 1e9, 1),
                 "issue_peak": round(issue_peak / 1e9, 1), "unit": "G wave-instructions/s",
@@ -923,21 +1066,93 @@ def main():
             out["pipelined"] = pipelined_throughput(args, d_img, blob if use_bow else None, local_rank, cap)
         if world == 1 and args.host_batch > 0:
             out["host_fed"] = host_fed_throughput(args, uniq, blob if use_bow else None, local_rank)
-        # the GPU's outputs for the first frames of the timed batch against the oracle, outside the timed region
-        nver = max(0, min(args.verify, Bc))
-        kept = []
-        if world == 1 and args.cpu_frames > 0:
-            nver = min(nver, args.cpu_frames)
-            res = cpu_baseline(uniq, args.cpu_frames, args.match, blob, keep=nver)
-            out["cpu_baseline"], kept = res if nver else (res, [])
-            out["speedup_vs_cpu_1core"] = round(fps / out["cpu_baseline"]["value"], 1)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(uniq, args.cpu_frames, args.match, blob)
-        elif nver:
-            kept = cpu_baseline(uniq, nver, args.match, blob, keep=nver)[1]
-        out["verified_frames"] = verify_against_oracle(kept, ctxs[0][1], cap, args.match) if kept else 0
+    # ---- the GPU's outputs for the timed batch against the oracle, outside the timed region; every rank checks its own ----
+    # Rows 0 .. U (every distinct frame, and the pair across the first tile boundary) against the oracle; with one context every
+    # further row -- a tiled copy -- against its original on the device.
+    U = int(len(uniq))
+    nver = min(U + 1, Bc) if args.verify < 0 else max(0, min(args.verify, Bc))
+    kept = []
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        nver = min(nver, args.cpu_frames)
+        res = cpu_baseline(uniq, args.cpu_frames, args.match, blob, keep=nver)
+        out["cpu_baseline"], kept = res if nver else (res, [])
+        out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(uniq, args.cpu_frames, args.match, blob)
+    elif nver:
+        kept = cpu_baseline(uniq, nver, args.match, blob, keep=nver)[1]
+    v_oracle = verify_against_oracle(kept, ctxs[0][1], cap, args.match) if kept else 0
+    v_copies = verify_tiled_copies(ctxs[0][1], U, Bc, cap, args.match) if (NC == 1 and v_oracle >= min(U + 1, Bc)) else 0
+    v_all = gather_objects(dist, (v_oracle, v_copies), world)
+    if out is not None:
+        out["verified_frames"] = v_oracle + v_copies
+        out["verified_vs_oracle"] = v_oracle
+        out["verified_copies_vs_original"] = v_copies
+        if world > 1:
+            out["verified_frames_per_rank"] = [a + c for a, c in v_all]
         out["verified_against"] = "oracle/liborb_oracle.so: keypoints (28-byte records), descriptors, " + \
             {"bow": "SearchByBoW match12/match21/count", "brute": "brute-force best/second",
-             "both": "SearchByBoW and brute-force results"}[args.match] + " of frames 0..n-1 of the timed batch, bit for bit"
+             "both": "SearchByBoW and brute-force results"}[args.match] + " of frames 0..%d of the timed batch, bit for bit" % max(v_oracle - 1, 0) + \
+            ("; frames %d..%d are tiled copies, each compared on the device with its original among those (count, keypoints, "
+             "descriptors, match results of its pair)" % (v_oracle, v_oracle + v_copies - 1) if v_copies else "")
+    # ---- the same step on a batch of B DISTINCT frames: does tiling U frames to the batch cost or gain anything? ----
+    if args.no_tiling and NC == 1 and world == 1 and B > U:
+        d_uniq = d_img[:U]
+        d_img2 = torch.empty_like(d_img)
+        shifts = [((5 * r) % H, (9 * r) % W) for r in range(reps)]
+        for r in range(reps):
+            nfr = min(U, B - r * U)
+            d_img2[r * U:r * U + nfr] = torch.roll(d_uniq[:nfr], shifts=shifts[r], dims=(1, 2))
+        step(d_img2)
+        barrier()
+        nt_steps = max(1, min(5, args.steps))
+        t0 = time.perf_counter()
+        for _ in range(nt_steps):
+            step(d_img2)
+        barrier()
+        nt = (time.perf_counter() - t0) / nt_steps
+        ms = (C.c_float * 6)()                                  # (stage events are on again since the pass behind the timed region)
+        assert L.orbhip_get_stage_times(ex0.handle, ms) == 0
+        nt_stage = {k: round(float(ms[i]), 4) for i, k in enumerate(("pyramid", "fast", "quadtree", "blur", "describe", "last_match_kernel"))}
+        # two of the shifted frames (the first copy's frames 0 and 1, and their match) against the oracle on the same shifted pixels
+        chk = [np.roll(uniq[i], shifts[1], axis=(0, 1)) for i in (0, 1)] if reps > 1 else []
+        nt_ver = 0
+        if chk and args.cpu_frames >= 0 and nver:
+            rec = cpu_baseline(np.stack(chk), 2, args.match, blob, keep=2)[1]
+            sub = {k: v[U:U + 2] for k, v in ctxs[0][1].items() if k != "img"}
+            # (row U of the batch is matched against row U - 1, a different predecessor than the oracle's: only frame U + 1's pair)
+            rec[0] = {"k": rec[0]["k"], "d": rec[0]["d"]}
+            nt_ver = verify_against_oracle(rec, sub, cap, args.match)
+        out["no_tiling_check"] = {"unique_frames": B, "value": round(B / nt, 1), "unit": "frames/s", "ms_per_step": round(nt * 1e3, 3),
+                                  "steps": nt_steps, "ratio_to_headline": round((B / nt) / out["value"], 4), "verified_frames": nt_ver, "stage_ms": nt_stage,
+                                  "note": "the %d distinct frames shifted cyclically by (5 r, 9 r) pixels for copy r: %d different "
+                                          "frames of the same content class in the batch; same context, same buffers" % (U, B)}
+        del d_img2
+    # ---- N > 1: the mode that can fail to scale -- every rank fed from host memory at once ----
+    if dist is not None and args.host_batch > 0:
+        barrier()
+        hf = host_fed_throughput(args, uniq, blob if use_bow else None, local_rank)
+        hf_all = gather_objects(dist, (hf, numa), world)
+        if out is not None:
+            topo = D.host_topology()
+            topo.pop("_cpus", None)
+            secs = [h["seconds"] for h, _ in hf_all]
+            frames_all = sum(h["batches"] * h["frames_per_batch"] for h, _ in hf_all)
+            out["host_fed"] = {
+                "value": round(frames_all / max(secs), 1), "unit": "frames/s", "ranks": world,
+                "h2d_GBps_total": round(frames_all / max(secs) * W * H / 1e9, 2),
+                "per_rank": [{"rank": i, "frames_per_s": h["value"], "h2d_GBps": h["h2d_GBps"], "d2h_GBps": h["d2h_GBps"],
+                              "seconds": h["seconds"], "numa": n} for i, (h, n) in enumerate(hf_all)],
+                "frames_per_batch": hf["frames_per_batch"], "ring_depth": hf["ring_depth"], "pinned": True, "host": topo,
+                "note": "every rank runs its own orbhip_pipe_* ring at the same time (barrier in front): pinned frame buffers "
+                        "allocated after the rank was bound to the CPUs of its GPU's NUMA node, copy-in / kernels / copy-out "
+                        "overlapped; value = all ranks' frames / the slowest rank's time.  This, not the device-resident "
+                        "headline, is what can bend a 1 -> N curve: N x ~50 GB/s out of one host's memory"}
+    # ---- N >= 4: BASELINE config 4 proper, one EuRoC stream per rank ----
+    want_streams = args.streams_config == 1 or (args.streams_config < 0 and world >= 4)
+    if dist is not None and want_streams and use_bow:
+        cfg4 = config_streams_ranks(local_rank, blob, rank, world, dist, barrier)
+        if out is not None:
+            out.setdefault("configs", {})["4_euroc_streams_one_per_rank"] = cfg4
     for ex, _ in ctxs:
         ex.close()
     del ctxs, d_img
@@ -945,7 +1160,7 @@ def main():
         torch.cuda.empty_cache()
         if blob is None:
             blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L)
-        out["configs"] = secondary_configs(local_rank, blob)
+        out.setdefault("configs", {}).update(secondary_configs(local_rank, blob))
         out["roofline_mfma"] = out["configs"]["5_tum_4000feat_1M_query"].get("roofline_mfma")
     if out is not None and world == 1 and args.content:
         torch.cuda.empty_cache()

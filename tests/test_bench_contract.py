@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
-                          "--cpu-frames", "24", "--pipelined", "0"], capture_output=True, text=True, timeout=600)
+                          "--cpu-frames", "40", "--pipelined", "0"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     d = json.loads(lines[-1])                                   # the JSON line is the LAST thing on stdout
@@ -30,7 +30,12 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 1 and c["unit"] == "frames/s" and c["sample"]
     assert d["cpu_baseline_all_cores"]["cores"] >= 1
-    assert d["verified_frames"] == 8                             # GPU outputs of the first frames equal the oracle's
+    # r05: the WHOLE timed batch is verified -- the 32 distinct frames and the pair across the first tile boundary against the
+    # oracle, every tiled copy against its original on the device; the whole step against the HBM roofline; a batch of distinct frames
+    assert d["verified_frames"] == 64 and d["verified_vs_oracle"] == 33 and d["verified_copies_vs_original"] == 31
+    assert 0 < d["step_hbm_frac"] < 1 and d["step_algorithmic_bytes"] > 64 * 5e6
+    nt = d["no_tiling_check"]
+    assert nt["unique_frames"] == 64 and nt["value"] > 1000 and nt["verified_frames"] == 2 and 0.5 < nt["ratio_to_headline"] < 2.0
     # r04: one roofline entry per streaming kernel of the step, measured in this run; the matrix-pipe roofline of the 1M query;
     # the content classes, each verified; the committed counters flagged when they no longer describe the kernel
     names = [e["kernel"] for e in d["rooflines"]]
@@ -83,11 +88,46 @@ def test_launch_ranks_reports_a_failing_rank():
 def test_bench_distributed_code_path_on_one_gpu():
     """ORBHIP_BENCH_FORCE_DIST=1: process group (nccl = RCCL, world 1), vocabulary broadcast into a device buffer and
     the vocabulary load from that buffer -- the N > 1 code path of bench.py on the one GPU the box has."""
-    out = _bench(["--steps", "2", "--warmup", "1", "--batch", "64", "--cpu-frames", "0", "--pipelined", "0"],
-                 env={"ORBHIP_BENCH_FORCE_DIST": "1"})
+    out = _bench(["--steps", "2", "--warmup", "1", "--batch", "64", "--cpu-frames", "0", "--pipelined", "0", "--configs", "0",
+                  "--content", "0", "--streams-config", "1"], env={"ORBHIP_BENCH_FORCE_DIST": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
-    assert d["n_gpus"] == 1 and d["value"] > 1000 and d["verified_frames"] == 8 and d["bow_matches_per_frame"] > 50
+    assert d["n_gpus"] == 1 and d["value"] > 1000 and d["verified_frames"] == 64 and d["bow_matches_per_frame"] > 50
+    assert d["rccl_ranks"] == 1 and d["vocabulary_broadcast"]["bytes"] > 40e6
+    _check_multi_rank_fields(d, 1)
+
+
+def _check_multi_rank_fields(d, world):
+    """r05: what an N > 1 run reports beyond the device-resident step -- every rank fed from host memory at the same time (the
+    mode that can fail to scale), with where each rank sits on the host; and config 4 proper, whole streams per rank."""
+    hf = d["host_fed"]
+    assert hf["ranks"] == world and len(hf["per_rank"]) == world and hf["value"] > 1000 and hf["h2d_GBps_total"] > 0.3
+    assert hf["host"]["nproc"] >= 1 and hf["host"]["numa_nodes"] >= 0 and "numa_node_cpus" in hf["host"]
+    for i, r in enumerate(hf["per_rank"]):
+        assert r["rank"] == i and r["frames_per_s"] > 500 and r["h2d_GBps"] > 0.1 and r["seconds"] > 0
+        assert "gpu_numa_node" in r["numa"] and r["numa"]["bound"] in (True, False) and r["numa"]["cpus"] >= 1
+    assert hf["value"] <= sum(r["frames_per_s"] for r in hf["per_rank"]) * 1.02         # all frames / the SLOWEST rank's time
+    c4 = d["configs"]["4_euroc_streams_one_per_rank"]
+    assert c4["ranks"] == world and c4["frames"] == 2912 + 1710 + 2280 + 3040 and c4["value"] > 1000
+    assert len(c4["per_rank"]) == world and sum(r["frames"] for r in c4["per_rank"]) == c4["frames"]
+    assert all(r["verified"] >= 4 for r in c4["per_rank"]) and c4["verified"] == sum(r["verified"] for r in c4["per_rank"])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_device_0():
+    """The N > 1 path of bench.py with two real rank processes on the one GPU a box has (gloo: RCCL refuses duplicate devices,
+    the vocabulary travels through host memory): sharded frames, max-over-ranks time, every rank's whole batch verified, the
+    host-fed mode on both ranks at once, config 4's streams split over the ranks."""
+    from orbhip import distributed as D
+    rc, out = D.launch_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                              "--warmup", "1", "--batch", "64", "--pipelined", "0", "--streams-config", "1"], 2, timeout=900,
+                             local_ranks=[0, 0])
+    assert rc == 0, out[-3000:]
+    d = json.loads([l for l in out.splitlines() if l.strip().startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["rccl_ranks"] is None and len(d["per_rank_frames_per_s"]) == 2
+    assert d["verified_frames_per_rank"] == [64, 64] and d["verified_frames"] == 64
+    assert "cpu_baseline" not in d and "content" not in d            # rank 0 at N = 1 only
+    _check_multi_rank_fields(d, 2)
 
 
 @pytest.mark.gpu
