@@ -1102,15 +1102,21 @@ def main():
         for r in range(reps):
             nfr = min(U, B - r * U)
             d_img2[r * U:r * U + nfr] = torch.roll(d_uniq[:nfr], shifts=shifts[r], dims=(1, 2))
+        assert L.orbhip_set_stage_timing(ex0.handle, 1) == 0    # as in the timed region: the FAST launch's two events only
         step(d_img2)
         barrier()
         nt_steps = max(1, min(5, args.steps))
         t0 = time.perf_counter()
         for _ in range(nt_steps):
             step(d_img2)
+            ms = (C.c_float * 6)()
+            assert L.orbhip_get_stage_times(ex0.handle, ms) == 0     # (reading them waits for the step, as the timed loop does)
         barrier()
         nt = (time.perf_counter() - t0) / nt_steps
-        ms = (C.c_float * 6)()                                  # (stage events are on again since the pass behind the timed region)
+        assert L.orbhip_set_stage_timing(ex0.handle, 2) == 0
+        step(d_img2)
+        barrier()
+        ms = (C.c_float * 6)()
         assert L.orbhip_get_stage_times(ex0.handle, ms) == 0
         nt_stage = {k: round(float(ms[i]), 4) for i, k in enumerate(("pyramid", "fast", "quadtree", "blur", "describe", "last_match_kernel"))}
         # two of the shifted frames (the first copy's frames 0 and 1, and their match) against the oracle on the same shifted pixels

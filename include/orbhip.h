@@ -472,6 +472,10 @@ int orbhip_set_put(orbhip_ctx *ctx, uint64_t key, const orbhip_keypoint *kps, co
                    const int32_t *off, const int32_t *idx, int ng, float min_x, float min_y, float inv_w, float inv_h);
 int orbhip_set_has(orbhip_ctx *ctx, uint64_t key, int n);
 int orbhip_set_drop(orbhip_ctx *ctx, uint64_t key);
+/* Bounds the table: at most max_sets sets (clamped to 4 .. 96, the default) stay resident in this context, least recently used
+ * out -- ~90 KB of device memory per set of 1000 features.  Returns the limit in force.  (The reference keeps every KeyFrame's
+ * descriptors in host memory for the life of the map, src/KeyFrame.cc:55-89; this is the device-side counterpart's budget.) */
+int orbhip_set_limit(orbhip_ctx *ctx, int max_sets);
 /* Is the set what the caller thinks it is?  Ids are not identities: Tracking::Reset restarts KeyFrame::nNextId and
  * Frame::nNextId (ref: src/Tracking.cc:2758-2759), and a key frame met before KeyFrame::ComputeBoW (ref: src/KeyFrame.cc:392-400)
  * has an empty FeatureVector.

@@ -56,6 +56,9 @@ public:
     // Stale sets are never used -- a set is checked against the object in hand -- so this only returns their memory early:
     // call it from Tracking::Reset (ref: src/Tracking.cc:2724-2770), where the map and both id counters start over.
     static void DropResidentSets();
+    // (addition) At most n key frames / frames stay resident per matcher thread from now on (4 .. 96, the default; orbhip_set_limit):
+    // the device-memory budget of a thread's table, least recently used out.  Takes effect in every thread at its next search.
+    static void SetResidentSetLimit(int n);
 
     // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
     // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)

@@ -4,28 +4,7 @@
 // Two identical worlds are built; one runs the drop-in (HIP), the other the loops below, which restate the routines on
 // the host with KeyFrame::GetFeaturesInArea and ORBmatcher::DescriptorDistance; the resulting map states must be equal.
 // Self-checking: exit code 0 and one "ok" line per routine.
-#include <algorithm>
-#include <climits>
-#include <map>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <set>
-#include <vector>
-
-#include "ORBextractor.h"
-#include "ORBmatcher.h"
-
-using namespace ORB_SLAM2;
-using std::vector;
-
-static unsigned long long g_rng = 88172645463325252ull;
-static double urand()   // xorshift64*, [0, 1)
-{
-    g_rng ^= g_rng >> 12; g_rng ^= g_rng << 25; g_rng ^= g_rng >> 27;
-    return (double)((g_rng * 2685821657736338717ull) >> 11) / 9007199254740992.0;
-}
+#include "host_restate.h"
 
 struct Shared {                    // one extraction, shared by every key frame of both worlds
     vector<cv::KeyPoint> keys;
@@ -40,26 +19,6 @@ struct World {
     vector<MapPoint> pts;
     vector<MapPoint *> cand;       // fuse candidates (points of kf[0] and of kf[2])
 };
-
-static cv::Mat pose(float ax, float ay, float tx, float ty, float tz)
-{
-    cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
-    const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay);
-    const float R[9] = {cy, 0, sy, sx * sy, cx, -sx * cy, -cx * sy, sx, cx * cy};   // Rx(ax) * Ry(ay)
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) T.at<float>(r, c) = R[r * 3 + c];
-    T.at<float>(0, 3) = tx; T.at<float>(1, 3) = ty; T.at<float>(2, 3) = tz; T.at<float>(3, 3) = 1.f;
-    return T;
-}
-
-static void mul3(const cv::Mat &R, const float x[3], const float *t, float out[3], bool transpose = false, double alpha = 1.0)
-{
-    for (int r = 0; r < 3; r++) {
-        double s = 0;
-        for (int k = 0; k < 3; k++) s += (double)(transpose ? R.at<float>(k, r) : R.at<float>(r, k)) * (double)x[k];
-        out[r] = (float)(alpha * s + (t ? (double)t[r] : 0.0));
-    }
-}
 
 static void setupKF(KeyFrame &K, const Shared &S, const cv::Mat &Tcw, float stereoShare)
 {
@@ -126,219 +85,6 @@ static void buildWorld(World &W, const Shared &S, unsigned long long seed)
         }
     W.cand.push_back(static_cast<MapPoint *>(NULL));
     if (W.kf[1].mvpMapPoints[7]) W.cand.push_back(W.kf[1].mvpMapPoints[7]);   // already in the key frame -> skipped
-}
-
-// ---------------- the routines restated on the host ----------------
-static bool window(KeyFrame *pKF, MapPoint *pMP, const float p3Dc[3], const float *PO, float dist3D, float th, float &u, float &v,
-                   float &ur, int &level, float &radius)
-{
-    if (p3Dc[2] < 0.0f) return false;
-    const float invz = 1.0 / p3Dc[2];
-    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
-    u = pKF->fx * x + pKF->cx;
-    v = pKF->fy * y + pKF->cy;
-    if (!pKF->IsInImage(u, v)) return false;
-    ur = u - pKF->mbf * invz;
-    if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) return false;
-    if (PO) {
-        cv::Mat Pn = pMP->GetNormal();
-        double dot = 0;
-        for (int k = 0; k < 3; k++) dot += (double)PO[k] * (double)Pn.at<float>(k, 0);
-        if (dot < 0.5 * dist3D) return false;
-    }
-    level = pMP->PredictScale(dist3D, pKF);
-    radius = th * pKF->mvScaleFactors[level];
-    return true;
-}
-
-static float norm3(const float a[3])
-{
-    double s = 0;
-    for (int k = 0; k < 3; k++) s += (double)a[k] * (double)a[k];
-    return std::sqrt(s);
-}
-
-// best feature of the window (gate: Fuse's chi-square test); vpClosed != NULL: features holding a match are skipped
-static int bestInWindow(KeyFrame *pKF, MapPoint *pMP, float u, float v, float ur, int level, float radius, bool gate,
-                        const vector<MapPoint *> *vpClosed, int &bestDist)
-{
-    const vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);
-    const cv::Mat dMP = pMP->GetDescriptor();
-    bestDist = 256;
-    int bestIdx = -1;
-    for (size_t c = 0; c < vIndices.size(); c++) {
-        const size_t idx = vIndices[c];
-        if (vpClosed && (*vpClosed)[idx]) continue;
-        const cv::KeyPoint &kp = pKF->mvKeysUn[idx];
-        const int kpLevel = kp.octave;
-        if (kpLevel < level - 1 || kpLevel > level) continue;
-        if (gate) {
-            const float ex = u - kp.pt.x, ey = v - kp.pt.y;
-            if (pKF->mvuRight[idx] >= 0) {
-                const float er = ur - pKF->mvuRight[idx];
-                const float e2 = ex * ex + ey * ey + er * er;
-                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
-            } else {
-                const float e2 = ex * ex + ey * ey;
-                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
-            }
-        }
-        const int dist = ORBmatcher::DescriptorDistance(dMP, pKF->mDescriptors.row((int)idx));
-        if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
-    }
-    return bestIdx;
-}
-
-static void worldPos(MapPoint *p, float xw[3])
-{
-    cv::Mat m = p->GetWorldPos();
-    for (int k = 0; k < 3; k++) xw[k] = m.at<float>(k, 0);
-}
-
-static void kfPose(KeyFrame *K, cv::Mat &R, float t[3], float o[3])
-{
-    R = K->GetRotation();
-    cv::Mat tm = K->GetTranslation(), om = K->GetCameraCenter();
-    for (int k = 0; k < 3; k++) { t[k] = tm.at<float>(k, 0); o[k] = om.at<float>(k, 0); }
-}
-
-static void sim3Pose(const cv::Mat &Scw, cv::Mat &Rcw, float tcw[3], float Ow[3])
-{
-    double dot = 0;
-    for (int k = 0; k < 3; k++) dot += (double)Scw.at<float>(0, k) * (double)Scw.at<float>(0, k);
-    const float scw = sqrt(dot);
-    Rcw = cv::Mat(3, 3, CV_32F);
-    for (int r = 0; r < 3; r++) {
-        for (int k = 0; k < 3; k++) Rcw.at<float>(r, k) = (float)((double)Scw.at<float>(r, k) * (1.0 / scw));
-        tcw[r] = (float)((double)Scw.at<float>(r, 3) * (1.0 / scw));
-    }
-    mul3(Rcw, tcw, NULL, Ow, true, -1.0);
-}
-
-static int refFuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, float th)
-{
-    cv::Mat Rcw; float tcw[3], Ow[3];
-    kfPose(pKF, Rcw, tcw, Ow);
-    int nFused = 0;
-    for (size_t i = 0; i < vpMapPoints.size(); i++) {
-        MapPoint *pMP = vpMapPoints[i];
-        if (!pMP) continue;
-        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
-        float xw[3], pc[3], PO[3], u, v, ur, radius; int level, bestDist;
-        worldPos(pMP, xw);
-        mul3(Rcw, xw, tcw, pc);
-        for (int k = 0; k < 3; k++) PO[k] = xw[k] - Ow[k];
-        if (!window(pKF, pMP, pc, PO, norm3(PO), th, u, v, ur, level, radius)) continue;
-        const int bestIdx = bestInWindow(pKF, pMP, u, v, ur, level, radius, true, NULL, bestDist);
-        if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_LOW) {
-            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);
-            if (pMPinKF) {
-                if (!pMPinKF->isBad()) {
-                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
-                    else pMPinKF->Replace(pMP);
-                }
-            } else {
-                pMP->AddObservation(pKF, bestIdx);
-                pKF->AddMapPoint(pMP, bestIdx);
-            }
-            nFused++;
-        }
-    }
-    return nFused;
-}
-
-static int refFuseScw(KeyFrame *pKF, const cv::Mat &Scw, const vector<MapPoint *> &vpPoints, float th, vector<MapPoint *> &vpReplacePoint)
-{
-    cv::Mat Rcw; float tcw[3], Ow[3];
-    sim3Pose(Scw, Rcw, tcw, Ow);
-    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();
-    int nFused = 0;
-    for (size_t i = 0; i < vpPoints.size(); i++) {
-        MapPoint *pMP = vpPoints[i];
-        if (!pMP || pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-        float xw[3], pc[3], PO[3], u, v, ur, radius; int level, bestDist;
-        worldPos(pMP, xw);
-        mul3(Rcw, xw, tcw, pc);
-        for (int k = 0; k < 3; k++) PO[k] = xw[k] - Ow[k];
-        if (!window(pKF, pMP, pc, PO, norm3(PO), th, u, v, ur, level, radius)) continue;
-        const int bestIdx = bestInWindow(pKF, pMP, u, v, ur, level, radius, false, NULL, bestDist);
-        if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_LOW) {
-            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);
-            if (pMPinKF) {
-                if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
-            } else {
-                pMP->AddObservation(pKF, bestIdx);
-                pKF->AddMapPoint(pMP, bestIdx);
-            }
-            nFused++;
-        }
-    }
-    return nFused;
-}
-
-static int refProjScw(KeyFrame *pKF, const cv::Mat &Scw, const vector<MapPoint *> &vpPoints, vector<MapPoint *> &vpMatched, int th)
-{
-    cv::Mat Rcw; float tcw[3], Ow[3];
-    sim3Pose(Scw, Rcw, tcw, Ow);
-    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
-    spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
-    int nmatches = 0;
-    for (size_t i = 0; i < vpPoints.size(); i++) {
-        MapPoint *pMP = vpPoints[i];
-        if (!pMP || pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-        float xw[3], pc[3], PO[3], u, v, ur, radius; int level, bestDist;
-        worldPos(pMP, xw);
-        mul3(Rcw, xw, tcw, pc);
-        for (int k = 0; k < 3; k++) PO[k] = xw[k] - Ow[k];
-        if (!window(pKF, pMP, pc, PO, norm3(PO), (float)th, u, v, ur, level, radius)) continue;
-        const int bestIdx = bestInWindow(pKF, pMP, u, v, ur, level, radius, false, &vpMatched, bestDist);
-        if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_LOW) { vpMatched[bestIdx] = pMP; nmatches++; }
-    }
-    return nmatches;
-}
-
-static int refSim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12, float s12, const cv::Mat &R12, const cv::Mat &t12, float th)
-{
-    cv::Mat R1w, R2w; float t1w[3], t2w[3], o[3];
-    kfPose(pKF1, R1w, t1w, o);
-    kfPose(pKF2, R2w, t2w, o);
-    cv::Mat sR12(3, 3, CV_32F), sR21(3, 3, CV_32F);
-    for (int r = 0; r < 3; r++)
-        for (int k = 0; k < 3; k++) {
-            sR12.at<float>(r, k) = (float)((double)s12 * (double)R12.at<float>(r, k));
-            sR21.at<float>(r, k) = (float)((1.0 / s12) * (double)R12.at<float>(k, r));
-        }
-    float t12v[3] = {t12.at<float>(0, 0), t12.at<float>(1, 0), t12.at<float>(2, 0)}, t21[3];
-    mul3(sR21, t12v, NULL, t21, false, -1.0);
-    const vector<MapPoint *> vp1 = pKF1->GetMapPointMatches(), vp2 = pKF2->GetMapPointMatches();
-    const int N1 = (int)vp1.size(), N2 = (int)vp2.size();
-    vector<bool> done1(N1, false), done2(N2, false);
-    for (int i = 0; i < N1; i++)
-        if (vpMatches12[i]) {
-            done1[i] = true;
-            const int idx2 = vpMatches12[i]->GetIndexInKeyFrame(pKF2);
-            if (idx2 >= 0 && idx2 < N2) done2[idx2] = true;
-        }
-    vector<int> m1(N1, -1), m2(N2, -1);
-    for (int dir = 0; dir < 2; dir++) {
-        const vector<MapPoint *> &vp = dir ? vp2 : vp1;
-        for (int i = 0; i < (int)vp.size(); i++) {
-            MapPoint *pMP = vp[i];
-            if (!pMP || (dir ? done2[i] : done1[i]) || pMP->isBad()) continue;
-            float xw[3], pa[3], pb[3], u, v, ur, radius; int level, bestDist;
-            worldPos(pMP, xw);
-            if (!dir) { mul3(R1w, xw, t1w, pa); mul3(sR21, pa, t21, pb); }
-            else { mul3(R2w, xw, t2w, pa); mul3(sR12, pa, t12v, pb); }
-            KeyFrame *dst = dir ? pKF1 : pKF2;
-            if (!window(dst, pMP, pb, NULL, norm3(pb), th, u, v, ur, level, radius)) continue;
-            const int bestIdx = bestInWindow(dst, pMP, u, v, ur, level, radius, false, NULL, bestDist);
-            if (bestIdx >= 0 && bestDist <= ORBmatcher::TH_HIGH) (dir ? m2 : m1)[i] = bestIdx;
-        }
-    }
-    int nFound = 0;
-    for (int i1 = 0; i1 < N1; i1++)
-        if (m1[i1] >= 0 && m2[m1[i1]] == i1) { vpMatches12[i1] = vp2[m1[i1]]; nFound++; }
-    return nFound;
 }
 
 // ---------------- state comparison ----------------

@@ -41,3 +41,7 @@ def test_skimage_rows(oracle):
     # the exact rows really ran
     assert out.count("FAST-9/16 corner set") == 6 and "0 differing (pixel, t) pairs" in out
     assert "rBRIEF pattern table T0 (256 pairs) | scikit-image" in out and "| equal | ok |" in out
+    # round 5: the steering arithmetic of rBRIEF (src/ORBextractor.cc:110-149) against scikit-image's own rotated-pattern loop on the
+    # oracle's keypoints, angles and blurred levels: every differing bit (if any) is a rounding tie of a rotated coordinate
+    steer = [l for l in out.splitlines() if l.startswith("| rBRIEF steering")]
+    assert len(steer) == 1 and " 0 non-tie differences" in steer[0] and steer[0].rstrip().endswith("| ok |")

@@ -408,3 +408,24 @@ def test_cpp_dropins_do_not_throw_and_load_text_vocabularies(oracle, tmp_path):
     for i, nid in enumerate(ofv[0]):
         assert fv[int(nid)] == ofv[2][ofv[1][i]:ofv[1][i + 1]].tolist()
     assert int(kv["errors_total"]) >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_sets", ["0", "1"])
+def test_cpp_matcher_from_three_threads_over_the_same_keyframes(tmp_path, no_sets):
+    """The reference runs ORBmatcher from Tracking, LocalMapping and LoopClosing at once on shared KeyFrames (src/System.cc:365-375;
+    include/ORBmatcher.h:100-101 are plain stack objects).  tests/native/test_threads_dropin.cpp: thread T (SearchByBoW(KF, F) +
+    SearchByProjection(F, F)), M (SearchForTriangulation + Fuse) and L (SearchByBoW(KF, KF) + SearchBySim3) over the same 30 key
+    frames for 500 rounds, eight resident sets per thread (every round evicts), ORBmatcher::DropResidentSets() from T mid-run;
+    every result equal to the single-threaded host restatement (tests/native/host_restate.h).  Once more with ORBHIP_NO_SETS=1."""
+    from orbhip import distributed as D, synth
+    exe = os.path.join(ROOT, "tests", "native", "test_threads_dropin")
+    assert os.path.exists(exe), "tests/native/test_threads_dropin is not built (run __graft_entry__.build())"
+    W, H, NF = 640, 480, 3
+    frames = synth.make_frames(91, W, H, NF)
+    (tmp_path / "frames.raw").write_bytes(np.ascontiguousarray(frames).tobytes())
+    (tmp_path / "voc.bin").write_bytes(D.make_synthetic_vocabulary(17, k=10, L=5))
+    r = subprocess.run([exe, str(W), str(H), "1200", str(tmp_path / "frames.raw"), str(NF), str(tmp_path / "voc.bin"), "500"],
+                       capture_output=True, text=True, env=dict(os.environ, ORBHIP_NO_SETS=no_sets), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count(": ok") == 6 and "all ok" in r.stdout, r.stdout

@@ -169,6 +169,53 @@ def check_skimage():
             % (d, np.abs(mine - ideal).max()), d <= 0.5 + 1e-9)
 
 
+def check_skimage_steering():
+    """rBRIEF steering (src/ORBextractor.cc:110-149): for the oracle's own keypoints and angles on its own blurred levels, the
+    descriptor recomputed by scikit-image's rotated-pattern loop (feature/orb_cy.pyx _orb_loop: float64 sin / cos, C round(), the same
+    256 pairs, "first < second" sets the bit).  The two loops index the same pixels unless a rotated coordinate lies within
+    rounding error of k + 0.5 -- the reference multiplies in float and rounds half to even (cvRound), skimage in double and
+    rounds half away from zero -- so every differing bit must be such a tie (|frac - 0.5| < 1e-4 for one of the pair's four
+    rotated coordinates); a difference that is not a tie would be a different indexing formula."""
+    import skimage
+    from skimage.feature.orb_cy import _orb_loop
+    ver = "scikit-image %s" % skimage.__version__
+    pat = oracle_pattern().astype(np.float64)
+    img = synth.make_frames(13, 640, 480, 1)[0]
+    ex = oracle.Extractor(1000)
+    kps, desc = ex(img)
+    off = nbits = ndiff = nties = nkp = 0
+    worst = None
+    for level in range(8):
+        lk = ex.level_keypoints(level)
+        n = len(lk)
+        if n == 0:
+            continue
+        blurred = np.ascontiguousarray(ex.blurred(level), np.float64)
+        rc = np.ascontiguousarray(np.stack([np.rint(lk["y"]), np.rint(lk["x"])], 1).astype(np.intp))
+        ang = np.deg2rad(lk["angle"].astype(np.float64))
+        theirs = np.asarray(_orb_loop(blurred, rc, ang)).astype(np.uint8)
+        mine = np.unpackbits(desc[off:off + n], axis=1, bitorder="little")
+        d = np.argwhere(theirs != mine)
+        for i, j in d:
+            a, b = np.cos(ang[i]), np.sin(ang[i])
+            x0, y0, x1, y1 = pat[j]
+            coords = np.array([x0 * b + y0 * a, x0 * a - y0 * b, x1 * b + y1 * a, x1 * a - y1 * b])
+            dist = np.abs(np.abs(coords - np.floor(coords)) - 0.5).min()
+            if dist < 1e-4:
+                nties += 1
+            elif worst is None or dist > worst[0]:
+                worst = (float(dist), level, int(i), int(j))
+        ndiff += len(d)
+        nbits += n * 256
+        nkp += n
+        off += n
+    nontie = ndiff - nties
+    row("rBRIEF steering: %d keypoints x 256 tests on the oracle's blurred levels" % nkp, ver + " feature.orb_cy._orb_loop (float64, round())",
+        "exact up to rounding ties of a rotated coordinate", "%d of %d bits equal (%.5f %%), %d differ, all %d of them ties, %d non-tie differences%s"
+        % (nbits - ndiff, nbits, 100.0 * (nbits - ndiff) / max(nbits, 1), ndiff, nties, nontie,
+           "" if worst is None else " (worst: %.4f from a tie, level %d keypoint %d bit %d)" % worst), nontie == 0 and nkp > 800 and off == len(kps))
+
+
 def oracle_pattern():
     """The 256 x (x0, y0, x1, y1) test pairs the oracle uses (oracle/orb_pattern_data.h)."""
     import re
@@ -352,6 +399,7 @@ def main():
         import skimage  # noqa: F401
         have.append("skimage")
         check_skimage()
+        check_skimage_steering()
     except ImportError:
         row("scikit-image", "-", "-", "not importable under %s (try /opt/conda/bin/python3.9)" % sys.executable, True)
     lines = ["# Oracle cross-check against independent implementations", "",

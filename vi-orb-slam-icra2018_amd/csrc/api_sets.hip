@@ -35,6 +35,7 @@ struct OrbSet {
 };
 
 struct OrbSetTable {
+    int limit = ORB_MAX_SETS;          // orbhip_set_limit
     std::vector<OrbSet *> sets;
     std::vector<OrbSetMem> pool;       // blocks of evicted / replaced sets
     unsigned long clock = 0;
@@ -124,6 +125,16 @@ extern "C" int orbhip_set_info(orbhip_ctx *c, uint64_t key, int *n, int *ng, uin
     return 1;
 }
 
+// At most `max_sets` resident sets in this context from now on (clamped to [4, ORB_MAX_SETS]; a search holds two at a time); the
+// least recently used ones beyond it leave at the next orbhip_set_put.  Returns the limit in force.
+extern "C" int orbhip_set_limit(orbhip_ctx *c, int max_sets)
+{
+    if (!c) return 0;
+    OrbSetTable *T = table(c);
+    T->limit = max_sets < 4 ? 4 : max_sets > ORB_MAX_SETS ? ORB_MAX_SETS : max_sets;
+    return T->limit;
+}
+
 extern "C" int orbhip_set_drop(orbhip_ctx *c, uint64_t key)
 {
     if (!c) return ORBHIP_E_ARG;
@@ -159,7 +170,7 @@ static OrbSet *set_acquire(orbhip_ctx *c, uint64_t key, int n, int capWant = 0)
             T->sets.erase(T->sets.begin() + i);
             break;
         }
-    if (T->sets.size() >= ORB_MAX_SETS) {
+    while (T->sets.size() >= (size_t)T->limit) {
         size_t lru = 0;
         for (size_t i = 1; i < T->sets.size(); i++)
             if (T->sets[i]->stamp < T->sets[lru]->stamp) lru = i;

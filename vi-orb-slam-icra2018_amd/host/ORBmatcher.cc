@@ -5,6 +5,7 @@
 // in liborbhip.so (orbhip_search_by_bow).
 #include "ORBmatcher.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -24,12 +25,15 @@ const int ORBmatcher::HISTO_LENGTH = 30;
 
 static int g_match_device = 0;
 void ORBmatcher::SetDevice(int device) { g_match_device = device; }
+static std::atomic<int> g_set_limit(0);                  // 0: the library's default
+void ORBmatcher::SetResidentSetLimit(int n) { g_set_limit.store(n < 4 ? 4 : n); }
 
 namespace {
 // one small device context per host thread (matchers are used concurrently from Tracking,
 // LocalMapping and LoopClosing; a context is not re-entrant)
 struct ThreadCtx {
     orbhip_ctx *ctx = nullptr;
+    int limit = 0;                                       // the value of g_set_limit this thread's table runs with
     ~ThreadCtx() { if (ctx) orbhip_destroy(ctx); }
     orbhip_ctx *get()
     {
@@ -85,6 +89,11 @@ bool ensure_set(uint64_t key, const T &t, const vector<cv::KeyPoint> &keysUn, fl
     const int n = t.mDescriptors.rows;
     if (n <= 0 || (int)keysUn.size() != n) return false;
     orbhip_ctx *c = tls.get();
+    const int lim = g_set_limit.load();
+    if (lim != tls.limit && c) {
+        orbhip_set_limit(c, lim);
+        tls.limit = lim;
+    }
     const uint64_t fp = orbhip_set_fingerprint_rows(reinterpret_cast<const orbhip_keypoint *>(keysUn.data()), t.mDescriptors.ptr(0),
                                                     t.mDescriptors.ptr(n - 1), n);
     int n0 = 0, ng0 = 0;

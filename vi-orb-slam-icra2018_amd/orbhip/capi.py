@@ -58,7 +58,7 @@ SYMBOLS = [
     "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
     "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
     "orbhip_set_put", "orbhip_set_has", "orbhip_set_drop", "orbhip_search_by_bow_sets", "orbhip_window_best_set",
-    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_vocab_generation", "orbhip_debug_roundtrip", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
+    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_vocab_generation", "orbhip_set_limit", "orbhip_debug_roundtrip", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
 ]
 
 
