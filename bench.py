@@ -601,7 +601,7 @@ def config_relocalisation(device, B=256, steps=6, nq=4000, ndb=1000000, nver=32)
                              "full database vs oracle" % (nver, nq)}
 
 
-def content_classes(device, blob, B=256, steps=4):
+def content_classes(device, blob, B=256, steps=4, verify=True):
     """The headline step (extract + vocabulary transform + SearchByBoW) on each synthetic content class of orbhip/synth.py: FAST's
     cost depends on what it looks at (the dense fallbacks of its lists, the second pass of empty cells), so the headline is a
     property of its texture.  Per class: frames/s, the FAST launch time, and frames 0 and 1 verified against the oracle."""
@@ -654,7 +654,7 @@ def content_classes(device, blob, B=256, steps=4):
         dt = time.perf_counter() - t0
         cnt = d_cnt.cpu().numpy()
         prev = None
-        for b in range(2):
+        for b in range(2 if verify else 0):        # (--verify 0: timing ablations, whose results are invalid by design)
             k, d = ref(frames[b])
             n = int(cnt[b])
             if n != len(k) or d_kps[b, :n].cpu().numpy().tobytes() != k.tobytes() or not np.array_equal(d_desc[b, :n].cpu().numpy(), d):
@@ -669,7 +669,7 @@ def content_classes(device, blob, B=256, steps=4):
             prev = cur
         out[kind] = {"value": round(steps * B / dt, 1), "unit": "frames/s", "k_fast_ms_per_1024_frames": round(fast * 1024.0 / B, 4),
                      "keypoints_per_frame": round(float(cnt.mean()), 1), "bow_matches_per_frame": round(float(d_nm.cpu().numpy()[1:].mean()), 1),
-                     "verified_frames": 2}
+                     "verified_frames": 2 if verify else 0}
         del d_img
     ex.close()
     out["frames_per_step"] = B
@@ -1119,6 +1119,20 @@ def main():
         ms = (C.c_float * 6)()
         assert L.orbhip_get_stage_times(ex0.handle, ms) == 0
         nt_stage = {k: round(float(ms[i]), 4) for i, k in enumerate(("pyramid", "fast", "quadtree", "blur", "describe", "last_match_kernel"))}
+        # where a difference comes from: the vocabulary transform descends the same branches for a frame and its copies (its 58 MB of
+        # tables are read through the 4 MB L2s), so it is timed alone on the distinct batch's descriptors and on the tiled batch's
+        def time_transform():
+            b0 = ctxs[0][1]
+            ex0.sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                L.orbhip_vocab_transform_device(ex0.handle, b0["desc"].data_ptr(), Bc * cap, LEVELSUP, b0["word"].data_ptr(),
+                                                b0["wt"].data_ptr(), b0["node"].data_ptr())
+            ex0.sync()
+            return round((time.perf_counter() - t1) / 5 * 1e3, 4)
+        voc_ms = None
+        if use_bow:
+            voc_ms = {"distinct": time_transform()}
         # two of the shifted frames (the first copy's frames 0 and 1, and their match) against the oracle on the same shifted pixels
         chk = [np.roll(uniq[i], shifts[1], axis=(0, 1)) for i in (0, 1)] if reps > 1 else []
         nt_ver = 0
@@ -1128,8 +1142,12 @@ def main():
             # (row U of the batch is matched against row U - 1, a different predecessor than the oracle's: only frame U + 1's pair)
             rec[0] = {"k": rec[0]["k"], "d": rec[0]["d"]}
             nt_ver = verify_against_oracle(rec, sub, cap, args.match)
+        if voc_ms is not None:
+            step()
+            barrier()
+            voc_ms["tiled"] = time_transform()
         out["no_tiling_check"] = {"unique_frames": B, "value": round(B / nt, 1), "unit": "frames/s", "ms_per_step": round(nt * 1e3, 3),
-                                  "steps": nt_steps, "ratio_to_headline": round((B / nt) / out["value"], 4), "verified_frames": nt_ver, "stage_ms": nt_stage,
+                                  "steps": nt_steps, "ratio_to_headline": round((B / nt) / out["value"], 4), "verified_frames": nt_ver, "stage_ms": nt_stage, "vocab_transform_ms": voc_ms,
                                   "note": "the %d distinct frames shifted cyclically by (5 r, 9 r) pixels for copy r: %d different "
                                           "frames of the same content class in the batch; same context, same buffers" % (U, B)}
         del d_img2
@@ -1172,7 +1190,7 @@ def main():
         torch.cuda.empty_cache()
         if blob is None:
             blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L)
-        out["content"] = content_classes(local_rank, blob)
+        out["content"] = content_classes(local_rank, blob, verify=args.verify != 0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
