@@ -515,6 +515,560 @@ __global__ __launch_bounds__(1024) void k_bow_seq(const uint8_t *__restrict__ de
     if (tid == 0) nmatches[b] = s_nm;
 }
 
+
+// =====================================================================================================================
+// k_bow_lane (r05): the same search with ONE LANE PER VOCABULARY NODE.
+//
+// What k_bow_seq above spends its time on is not distances: a frame pair holds ~10^4 (side-1, side-2) pairs inside shared nodes
+// (1000 features over ~100 nodes), but every side-1 feature costs a wave two cross-lane minima, a claim and a hand-over to the
+// next feature -- ~150 instructions for ~10 useful distances, 16 waves of one 144 KB workgroup per CU, 0.25 ms per 1024 frames
+// (profiles/r04: greedy phase 0.142 of it).  The greedy claiming is serial only INSIDE a node (a side-2 feature belongs to one
+// node: ref :180-264, the claims of two nodes never meet), so here
+//   a. the distances of all pairs of a node are computed up front, densely (16-lane groups, side-2 descriptor in registers,
+//      side-1 descriptors streamed), into a byte matrix in LDS -- rows = the node's side-1 features in FeatureVector order,
+//      16-byte chunks of side-2 candidates, 255 = "no candidate here" (padding) or a distance >= 255;
+//   b. a lane then walks ITS node alone: per side-1 feature the row's chunks (one 16-byte LDS read each), claimed candidates OR-ed
+//      to 255, best / second as min / med3 over keys (distance << 8 | position: the lowest position wins a tie, as the reference's
+//      strict '<' scan does), the acceptance test, the claim -- no cross-lane traffic at all; 64 nodes per wave side by side,
+//      nodes dealt in cost order so that a wave's lanes finish together.
+// Nodes with more than 64 side-2 features, and what does not fit the byte matrix, take the wave-cooperative path (descriptors
+// from global memory) after it: degenerate vocabularies (levelsup above the tree's depth puts every feature under one node) and
+// nothing else.  Exactness of the 255 clamp: a clamped or claimed candidate can only be the SECOND best, and the ratio test then
+// reads b1 < nnratio * 255 instead of * 256; with b1 <= th both hold whenever th < nnratio * 255, which the launcher checks
+// (th 50 / 100, nnratio 0.6 .. 0.9 in the reference) -- otherwise k_bow_seq runs.
+// LDS per workgroup (512 threads): keys 2 x NS x 8 bytes (dead after the item list: the byte matrix takes their place) + ~20 KB
+// of index arrays: three workgroups per CU at 1000 features.
+// =====================================================================================================================
+#define BL_THREADS 512
+#define BL_TILES 640     // 16 x 16 tiles of the byte matrices per frame pair (~200 at 1000 features)
+#define BL_MAXN2 128   // side-2 features of a node the matrix paths take (8 candidates per lane of a 16-lane group)
+
+__device__ __forceinline__ int bl_dist(const uint4 &q0, const uint4 &q1, const uint4 &r0, const uint4 &r1)
+{
+    return __popc(q0.x ^ r0.x) + __popc(q0.y ^ r0.y) + __popc(q0.z ^ r0.z) + __popc(q0.w ^ r0.w) + __popc(q1.x ^ r1.x) +
+           __popc(q1.y ^ r1.y) + __popc(q1.z ^ r1.z) + __popc(q1.w ^ r1.w);
+}
+
+__global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__restrict__ desc, const orbhip_keypoint *__restrict__ kps,
+                                                        const int32_t *__restrict__ counts, const int32_t *__restrict__ node,
+                                                        const float *__restrict__ weight, const uint8_t *__restrict__ valid, int cap,
+                                                        int NP, int lag, int th, int th_mode, float nnratio, int check_ori,
+                                                        int32_t *__restrict__ match12, int32_t *__restrict__ match21,
+                                                        int32_t *__restrict__ nmatches ORB_ABL_PARAM)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    // [keys | byte matrix] [idx1 idx2 m12 : u16 x capP] [items : uint2 x capP] [ioff : u16 x capP] [order : u16 x capP] [claim vbit1 vbit2]
+    const int capP = (cap + 63) & ~63;
+    unsigned long long *key1 = reinterpret_cast<unsigned long long *>(smem);
+    unsigned long long *key2 = key1 + NP;
+    uint8_t *dist = smem;                                             // takes the keys' place once the items exist
+    const int dcap = NP * 16 - BL_TILES * 4;                          // bytes (offsets count 4-byte units); behind them the tile list:
+    uint32_t *tiles = reinterpret_cast<uint32_t *>(smem + dcap);      // rank | tile row << 11 | tile column << 15 (written once the keys are dead)
+    uint16_t *idx1 = reinterpret_cast<uint16_t *>(smem + (size_t)NP * 16);
+    uint16_t *idx2 = idx1 + capP;
+    uint16_t *m12 = idx2 + capP;                                      // side-1 feature -> side-2 feature, 0xFFFF = none
+    uint2 *items = reinterpret_cast<uint2 *>(m12 + capP);             // (s1 | e1 << 16, s2 | e2 << 16)
+    uint16_t *ioff = reinterpret_cast<uint16_t *>(items + capP);      // byte-matrix offset of the item / 16; 0xFFFF: cooperative path
+    uint16_t *order = ioff + capP;                                    // item slots: lane items by cost, then the others
+    unsigned *claim = reinterpret_cast<unsigned *>(order + capP);
+    unsigned *vbit1 = claim + NP / 32, *vbit2 = vbit1 + NP / 32;
+    __shared__ int s_n1v, s_n2v, s_nitems, s_nlane, s_ngroup, s_next, s_nm, s_over, s_ntiles;
+    __shared__ int s_hist[BS_HISTO];
+    __shared__ int s_keep[3];
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n2 = min(counts[b], cap);
+    int32_t *o12 = match12 + (size_t)b * cap;
+    int32_t *o21 = match21 + (size_t)b * cap;
+    if (b < lag) {
+        for (int i = tid; i < cap; i += BL_THREADS) {
+            o12[i] = -1;
+            o21[i] = -1;
+        }
+        if (tid == 0) nmatches[b] = 0;
+        return;
+    }
+    const int b1 = b - lag;
+    const int n1 = min(counts[b1], cap);
+    const uint8_t *d1 = desc + (size_t)b1 * cap * 32, *d2 = desc + (size_t)b * cap * 32;
+    const int32_t *nd1 = node + (size_t)b1 * cap, *nd2 = node + (size_t)b * cap;
+    const float *w1 = weight + (size_t)b1 * cap, *w2 = weight + (size_t)b * cap;
+    int NS = 64;
+    while (NS < max(n1, n2)) NS <<= 1;
+
+    // ---- 1. keys (node << 32 | index); absent / stopped features sort last ----
+    for (int i = tid; i < NS; i += BL_THREADS) {
+        key1[i] = (i < n1 && w1[i] > 0.f) ? (((unsigned long long)(unsigned)nd1[i] << 32) | (unsigned)i) : ~0ull;
+        key2[i] = (i < n2 && w2[i] > 0.f) ? (((unsigned long long)(unsigned)nd2[i] << 32) | (unsigned)i) : ~0ull;
+    }
+    for (int i = tid; i < capP; i += BL_THREADS) m12[i] = 0xFFFFu;
+    for (int i = tid; i < NP / 32; i += BL_THREADS) {
+        claim[i] = 0;
+        unsigned v1 = 0xFFFFFFFFu, v2 = 0xFFFFFFFFu;
+        if (valid) {
+            v1 = v2 = 0;
+            for (int k = 0; k < 32; k++) {
+                const int f = i * 32 + k;
+                if (f < n1 && valid[(size_t)b1 * cap + f]) v1 |= 1u << k;
+                if (f < n2 && valid[(size_t)b * cap + f]) v2 |= 1u << k;
+            }
+        }
+        vbit1[i] = v1;
+        vbit2[i] = v2;
+    }
+    if (tid < BS_HISTO) s_hist[tid] = 0;
+    if (tid == 0) {
+        s_n1v = 0;
+        s_n2v = 0;
+        s_nitems = 0;
+        s_nlane = 0;
+        s_ngroup = 0;
+        s_next = 0;
+        s_nm = 0;
+        s_over = 0;
+        s_ntiles = 0;
+    }
+    __syncthreads();
+    ORB_ABL_STOP(phases < 1);
+    bs_sort2(key1, key2, NS, tid);
+    ORB_ABL_STOP(phases < 2);
+    for (int i = tid; i < NS; i += BL_THREADS) {
+        if (key1[i] != ~0ull && (i + 1 == NS || key1[i + 1] == ~0ull)) s_n1v = i + 1;
+        if (key2[i] != ~0ull && (i + 1 == NS || key2[i + 1] == ~0ull)) s_n2v = i + 1;
+    }
+    __syncthreads();
+    const int n1v = s_n1v, n2v = s_n2v;
+
+    // ---- 2. the FeatureVectors as index lists; work items = nodes present on both sides ----
+    for (int p = tid; p < n1v; p += BL_THREADS) {
+        idx1[p] = (uint16_t)(unsigned)key1[p];
+        const unsigned nodeId = (unsigned)(key1[p] >> 32);
+        if (p == 0 || (unsigned)(key1[p - 1] >> 32) != nodeId) {
+            const int s2 = bs_bound(key2, n2v, nodeId, false), e2 = bs_bound(key2, n2v, nodeId, true);
+            if (e2 > s2) {
+                const int e1 = bs_bound(key1, n1v, nodeId, true);
+                const int slot = atomicAdd(&s_nitems, 1);
+                items[slot] = make_uint2((unsigned)p | ((unsigned)e1 << 16), (unsigned)s2 | ((unsigned)e2 << 16));
+            }
+        }
+    }
+    for (int p = tid; p < n2v; p += BL_THREADS) idx2[p] = (uint16_t)(unsigned)key2[p];
+    __syncthreads();
+    ORB_ABL_STOP(phases < 3);
+    const int nitems = s_nitems;
+
+    // ---- 3. classes and order: [group items, 17 .. 128 side-2 features][lane items, <= 16][the rest], each by cost, largest first;
+    //         offsets of the byte matrices (rows of ceil4(n2) bytes) in rank order ----
+    auto rank_key = [&](const uint2 it) {
+        const int c1 = (int)((it.x >> 16) - (it.x & 0xFFFF)), c2 = (int)((it.y >> 16) - (it.y & 0xFFFF));
+        const int cls = c2 > BL_MAXN2 ? 0 : c2 > 16 ? 2 : 1;       // ranks descend: group items first, then lane items, then the rest
+        return (cls << 24) + min(c1 * c2, (1 << 24) - 1);
+    };
+    for (int i = tid; i < nitems; i += BL_THREADS) {
+        const int c = rank_key(items[i]);
+        int rank = 0;
+        for (int o = 0; o < nitems; o++) {
+            const int oc = rank_key(items[o]);
+            rank += (oc > c) || (oc == c && o < i);
+        }
+        order[rank] = (uint16_t)i;
+        if ((c >> 24) == 2) atomicAdd(&s_ngroup, 1);
+        if ((c >> 24) != 0) atomicAdd(&s_nlane, 1);
+    }
+    __syncthreads();
+    const int ngroup = s_ngroup, nmat = s_nlane;   // ranks [0, ngroup): group items; [ngroup, nmat): lane items; [nmat, nitems): cooperative
+    if (tid < 64) {
+        // offsets (4-byte units) in rank order by one wave; what no longer fits the matrix space goes to the cooperative path
+        int base = 0, tbase = 0;
+        for (int r0 = 0; r0 < nmat; r0 += 64) {
+            const int r = r0 + lane;
+            int units = 0;
+            if (r < nmat) {
+                const uint2 it = items[order[r]];
+                units = (int)((it.x >> 16) - (it.x & 0xFFFF)) * (int)((((it.y >> 16) - (it.y & 0xFFFF)) + 3) >> 2);
+            }
+            int incl = units;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const int start = base + incl - units;
+            // the item's 16 x 16 tiles, appended to the tile list
+            int ntl = 0, tR = 0, tC = 0;
+            if (r < nmat) {
+                const uint2 it = items[order[r]];
+                tR = ((int)((it.x >> 16) - (it.x & 0xFFFF)) + 15) >> 4;
+                tC = ((int)((it.y >> 16) - (it.y & 0xFFFF)) + 15) >> 4;
+                ntl = tR * tC;
+            }
+            int tincl = ntl;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(tincl, d);
+                if (lane >= d) tincl += o;
+            }
+            const int tstart = tbase + tincl - ntl;
+            const bool fits = (start + units) * 4 <= dcap && start + units < 0xFFFF && tR <= 16 && tstart + ntl <= BL_TILES;
+            if (r < nmat) ioff[order[r]] = fits ? (uint16_t)start : (uint16_t)0xFFFFu;
+            // (an item that does not fit leaves empty tiles in its part of the list: the prefix counted them before that was known)
+            if (r < nmat)
+                for (int k = 0; k < ntl && tstart + k < BL_TILES; k++)
+                    tiles[tstart + k] = fits ? ((uint32_t)r | ((uint32_t)(k / tC) << 11) | ((uint32_t)(k % tC) << 15)) : 0xFFFFFFFFu;
+            if (__ballot(r < nmat && !fits) && lane == 0) s_over = 1;
+            base += __shfl(incl, 63);
+            tbase += __shfl(tincl, 63);
+        }
+        if (lane == 0) s_ntiles = min(tbase, BL_TILES);
+    }
+    for (int r = nmat + tid; r < nitems; r += BL_THREADS) ioff[order[r]] = 0xFFFFu;
+    __syncthreads();
+    ORB_ABL_STOP(phases < 4);
+    const int ntiles = s_ntiles;
+    // (the keys are dead from here on: `dist` overwrites them)
+
+    // ---- 4. byte matrices, by 16 x 16 tiles (rows x candidates) dealt over the 16-lane groups: lane gl fetches the descriptor of ITS row
+    //         and of ITS candidate -- four independent loads, the next tile's in flight while this one is computed -- and the
+    //         rows' descriptors then ROTATE through the group (DPP row_ror on the XOR's operand: no LDS, no exchange): in step u
+    //         lane gl holds row (gl - u) mod 16 and scores it against its own candidate ----
+    {
+        const int gl = lane & 15, grp = tid >> 4, ngrp = BL_THREADS >> 4;
+        const uint4 *D1 = reinterpret_cast<const uint4 *>(d1), *D2 = reinterpret_cast<const uint4 *>(d2);
+        struct Tile {
+            int off, stride, nrow, c, row0;
+            bool hasC;
+        };
+        uint4 q0, q1, r0, r1, nq0, nq1, nr0, nr1;
+        Tile T, NT;
+        auto fetch = [&](int t, Tile &X, uint4 &a0, uint4 &a1, uint4 &b0, uint4 &b1) {
+            const uint32_t e0 = tiles[t];
+            const bool empty = e0 == 0xFFFFFFFFu;
+            const uint32_t e = empty ? 0u : e0;
+            const int slot = order[e & 0x7FF], tr = (e >> 11) & 15, tc = (e >> 15) & 15;
+            const uint2 it = items[slot];
+            const int s1 = it.x & 0xFFFF, n1i = (int)(it.x >> 16) - s1, s2 = it.y & 0xFFFF, n2i = (int)(it.y >> 16) - s2;
+            X.off = ioff[slot];
+            X.stride = (n2i + 3) & ~3;
+            X.nrow = empty || X.off == 0xFFFF ? 0 : n1i;          // (no row: nothing is stored)
+            X.row0 = tr * 16;
+            X.c = tc * 16 + gl;
+            X.hasC = X.c < n2i;
+            const int i1 = idx1[s1 + min(tr * 16 + gl, n1i - 1)];
+            const int i2 = idx2[s2 + min(X.c, n2i - 1)];
+            a0 = D1[2 * i1];
+            a1 = D1[2 * i1 + 1];
+            b0 = D2[2 * i2];
+            b1 = D2[2 * i2 + 1];
+        };
+        int t = grp;
+        if (t < ntiles) fetch(t, NT, nq0, nq1, nr0, nr1);
+        for (; t < ntiles; t += ngrp) {
+            T = NT;
+            q0 = nq0; q1 = nq1; r0 = nr0; r1 = nr1;
+            if (t + ngrp < ntiles) fetch(t + ngrp, NT, nq0, nq1, nr0, nr1);
+            uint8_t *dst = dist + (size_t)T.off * 4 + T.c;
+            const bool inPad = T.c < T.stride;
+            // (a vector write of a register needs two wait states before a DPP read of it: the copies above, if the compiler kept any)
+            asm volatile("s_nop 1" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+#define BL_STEP(U)                                                                                                              \
+    {                                                                                                                           \
+        const int row = T.row0 + ((gl - (U)) & 15);                                                                            \
+        const uint32_t QQ[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, RR[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}; \
+        int d = 0;                                                                                                              \
+        _Pragma("unroll") for (int k = 0; k < 8; k++)                                                                          \
+        {                                                                                                                       \
+            uint32_t x;                                                                                                         \
+            if ((U) == 0) x = QQ[k] ^ RR[k];                                                                                    \
+            else asm volatile("v_xor_b32_dpp %0, %1, %2 row_ror:" #U " row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(QQ[k]), "v"(RR[k])); \
+            d += __popc(x);                                                                                                     \
+        }                                                                                                                       \
+        if (inPad && row < T.nrow) dst[(size_t)row * T.stride] = (uint8_t)(T.hasC ? min(d, 255) : 255);                         \
+    }
+            BL_STEP(0) BL_STEP(1) BL_STEP(2) BL_STEP(3) BL_STEP(4) BL_STEP(5) BL_STEP(6) BL_STEP(7)
+            BL_STEP(8) BL_STEP(9) BL_STEP(10) BL_STEP(11) BL_STEP(12) BL_STEP(13) BL_STEP(14) BL_STEP(15)
+#undef BL_STEP
+        }
+    }
+    __syncthreads();
+    ORB_ABL_STOP(phases < 5);
+
+    // ---- 5. greedy matching ----
+    // 5a. group items: a 16-lane DPP row per node, four nodes per wave; lane gl owns the candidates gl, gl + 16, ... (up to 8), reads
+    //     their bytes of the row, folds them into (best, second) keys, two row minima give the node's best / second
+    {
+        const int gl = lane & 15, grp = tid >> 4, ngrp = BL_THREADS >> 4;
+        for (int r = grp; r < ngroup; r += ngrp) {
+            const int slot = order[r];
+            const int off = ioff[slot];
+            if (off == 0xFFFF) continue;
+            const uint2 it = items[slot];
+            const int s1 = it.x & 0xFFFF, nrow = (int)(it.x >> 16) - s1, s2 = it.y & 0xFFFF, n2i = (int)(it.y >> 16) - s2;
+            const int stride = (n2i + 3) & ~3;
+            unsigned gone = 0;                               // bit j: my candidate gl + 16 j is claimed, invalid or absent
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = gl + 16 * j;
+                bool out = c >= n2i;
+                if (!out && th_mode) {
+                    const int i2 = idx2[s2 + c];
+                    out = !((vbit2[i2 >> 5] >> (i2 & 31)) & 1u);   // :572-578
+                }
+                if (out) gone |= 1u << j;
+            }
+            // The next row's bytes and feature index are requested before this row is reduced (a row is then two DPP minima and a
+            // chain of eight med3 / min, no LDS round trip).  In assembly: the compiler waits lgkmcnt(0) right behind a load whose
+            // value it wants to zero-extend, which is exactly the round trip to be hidden; the wait is ours, at the loop top.
+            // A lane reads all eight of its bytes whether the node has that many candidates or not (what lies there is masked by
+            // `gm`, and the addresses stay inside the workgroup's LDS).
+            uint32_t rowAddr = (uint32_t)(uintptr_t)(dist + (size_t)off * 4 + gl);
+            uint32_t idxAddr = (uint32_t)(uintptr_t)(idx1 + s1);
+            const bool checkValid = valid != nullptr;
+            uint32_t gm[8];                                  // 0xFF: my candidate gl + 16 j is claimed, invalid or absent
+#pragma unroll
+            for (int j = 0; j < 8; j++) gm[j] = ((gone >> j) & 1u) ? 0xFFu : 0u;
+            uint32_t dn[8], i1n;
+#define BL_ROW_LOADS()                                                                                                                    \
+    asm volatile("ds_read_u8 %0, %9\n\tds_read_u8 %1, %9 offset:16\n\tds_read_u8 %2, %9 offset:32\n\tds_read_u8 %3, %9 offset:48\n\t"          \
+                 "ds_read_u8 %4, %9 offset:64\n\tds_read_u8 %5, %9 offset:80\n\tds_read_u8 %6, %9 offset:96\n\tds_read_u8 %7, %9 offset:112\n\t" \
+                 "ds_read_u16 %8, %10"                                                                                                    \
+                 : "=&v"(dn[0]), "=&v"(dn[1]), "=&v"(dn[2]), "=&v"(dn[3]), "=&v"(dn[4]), "=&v"(dn[5]), "=&v"(dn[6]), "=&v"(dn[7]), "=&v"(i1n)    \
+                 : "v"(rowAddr), "v"(idxAddr)                                                                                             \
+                 : "memory")
+            BL_ROW_LOADS();
+            for (int a = 0; a < nrow; a++) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]), "+v"(dn[4]), "+v"(dn[5]), "+v"(dn[6]), "+v"(dn[7]), "+v"(i1n)
+                             :
+                             : "memory");
+                const int i1 = (int)i1n;
+                uint32_t dj[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) dj[j] = dn[j] | gm[j];
+                rowAddr += (uint32_t)stride;
+                idxAddr += 2u;
+                if (a + 1 < nrow) BL_ROW_LOADS();
+                if (checkValid && !((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;   // (uniform over the row) no good MapPoint: :193-199
+                unsigned k1 = 0xFFFFFFu, k2 = (256u << 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const unsigned key = (dj[j] << 8) | (unsigned)(gl + 16 * j);
+                    unsigned nk2;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(nk2) : "v"(k1), "v"(k2), "v"(key));
+                    k1 = min(k1, key);
+                    k2 = nk2;
+                }
+                const int K1 = bs_row_min((int)k1);
+                const int K2 = bs_row_min((int)(k1 == (unsigned)K1 ? k2 : k1));
+                const int bd1 = K1 >> 8, bd2 = K2 >> 8, pos = K1 & 0xFF;
+                const bool pass = th_mode ? (bd1 < th) : (bd1 <= th);
+                if (pass && (float)bd1 < nnratio * (float)bd2) {        // ref: :228-230 / :598-600
+                    if ((pos & 15) == gl) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if ((pos >> 4) == j) gm[j] = 0xFFu;
+                        m12[i1] = idx2[s2 + pos];
+                    }
+                }
+            }
+#undef BL_ROW_LOADS
+        }
+    }
+    // 5b. lane items: a lane walks its node alone (at most 16 candidates: up to four dwords per row); dealt from the last thread down,
+    //     so that they start on the waves the group items left idle
+    for (int r = ngroup + (BL_THREADS - 1 - tid); r < nmat; r += BL_THREADS) {
+        const int slot = order[r];
+        const int off = ioff[slot];
+        if (off == 0xFFFF) continue;
+        const uint2 it = items[slot];
+        const int s1 = it.x & 0xFFFF, nrow = (int)(it.x >> 16) - s1, s2 = it.y & 0xFFFF, n2i = (int)(it.y >> 16) - s2;
+        const int nw = (n2i + 3) >> 2;                      // dwords per row
+        uint32_t cm[4] = {0u, 0u, 0u, 0u};                    // claimed / invalid candidates as bytes of 255
+        if (th_mode) {
+            for (int c = 0; c < n2i; c++) {
+                const int i2 = idx2[s2 + c];
+                if (!((vbit2[i2 >> 5] >> (i2 & 31)) & 1u)) {
+                    const uint32_t m = 0xFFu << (8 * (c & 3));
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((c >> 2) == k) cm[k] |= m;
+                }
+            }
+        }
+        uint32_t rowAddr = (uint32_t)(uintptr_t)(dist + (size_t)off * 4);
+        uint32_t idxAddr = (uint32_t)(uintptr_t)(idx1 + s1);
+        const bool checkValid = valid != nullptr;
+        // (four dwords of every row are read whatever the node's width: the dwords beyond it belong to the next row and are masked)
+        const uint32_t padm[4] = {0u, nw > 1 ? 0u : 0xFFFFFFFFu, nw > 2 ? 0u : 0xFFFFFFFFu, nw > 3 ? 0u : 0xFFFFFFFFu};
+        uint32_t wn[4], i1n;
+#define BL_LANE_LOADS()                                                                                                          \
+    asm volatile("ds_read_b32 %0, %5\n\tds_read_b32 %1, %5 offset:4\n\tds_read_b32 %2, %5 offset:8\n\tds_read_b32 %3, %5 offset:12\n\t" \
+                 "ds_read_u16 %4, %6"                                                                                            \
+                 : "=&v"(wn[0]), "=&v"(wn[1]), "=&v"(wn[2]), "=&v"(wn[3]), "=&v"(i1n)                                            \
+                 : "v"(rowAddr), "v"(idxAddr)                                                                                    \
+                 : "memory")
+        BL_LANE_LOADS();
+        for (int a = 0; a < nrow; a++) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(i1n) : : "memory");
+            const int i1 = (int)i1n;
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = wn[k] | cm[k] | padm[k];
+            rowAddr += 4u * (uint32_t)nw;
+            idxAddr += 2u;
+            if (a + 1 < nrow) BL_LANE_LOADS();                   // the next row is requested before this one is reduced
+            if (checkValid && !((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;   // no (good) MapPoint: :193-199
+            unsigned k1 = 0xFFFFFFu, k2 = (256u << 8);          // best / second keys (distance << 8 | position)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k < nw) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned key = (((w[k] >> (8 * q)) & 0xFFu) << 8) | (unsigned)(4 * k + q);
+                        unsigned nk2;                            // second smallest of the three (k1 <= k2 after the first key)
+                        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(nk2) : "v"(k1), "v"(k2), "v"(key));
+                        k1 = min(k1, key);
+                        k2 = nk2;
+                    }
+                }
+            }
+            const int bd1 = (int)(k1 >> 8), bd2 = (int)(k2 >> 8), pos = (int)(k1 & 0xFFu);
+            const bool pass = th_mode ? (bd1 < th) : (bd1 <= th);
+            if (pass && (float)bd1 < nnratio * (float)bd2) {        // ref: :228-230 / :598-600
+                m12[i1] = idx2[s2 + pos];
+                const uint32_t m = 0xFFu << (8 * (pos & 3));
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((pos >> 2) == k) cm[k] |= m;
+            }
+        }
+#undef BL_LANE_LOADS
+    }
+    __syncthreads();
+    ORB_ABL_STOP(phases < 6);
+
+    // ---- 6. what is left: nodes of more than 64 side-2 features or beyond the byte matrix -- a wave per node, lanes scan the node's
+    //         unclaimed side-2 features, descriptors from global memory (k_bow_seq's general form) ----
+    // (the ranks from nlane on; the lane items too only if one of them did not fit the byte matrix)
+    const int firstCoop = s_over ? 0 : nmat;
+    if (firstCoop >= nitems) goto rotation;
+    if (tid == 0) s_next = firstCoop;
+    __syncthreads();
+    for (;;) {
+        int rr = 0;
+        if (lane == 0) rr = atomicAdd(&s_next, 1);
+        rr = __builtin_amdgcn_readfirstlane(rr);
+        if (rr >= nitems) break;
+        const int slot = order[rr];
+        if (ioff[slot] != 0xFFFF) continue;
+        const uint2 it = items[slot];
+        const int e1 = it.x >> 16, s2 = it.y & 0xFFFF, e2 = it.y >> 16;
+        for (int a = it.x & 0xFFFF; a < e1; a++) {
+            const int i1 = __builtin_amdgcn_readfirstlane((int)idx1[a]);
+            if (!((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;
+            const uint4 q0 = reinterpret_cast<const uint4 *>(d1)[2 * i1], q1 = reinterpret_cast<const uint4 *>(d1)[2 * i1 + 1];
+            BsBest B = {256, 0x7FFFFFFF, 256};
+            for (int p = s2 + lane; p < e2; p += 64) {
+                const int i2 = idx2[p];
+                if ((claim[i2 >> 5] >> (i2 & 31)) & 1u) continue;
+                if (th_mode && !((vbit2[i2 >> 5] >> (i2 & 31)) & 1u)) continue;
+                const uint4 r0 = reinterpret_cast<const uint4 *>(d2)[2 * i2], r1 = reinterpret_cast<const uint4 *>(d2)[2 * i2 + 1];
+                const int d = bl_dist(q0, q1, r0, r1);
+                if (d < B.b1) {
+                    B.b2 = B.b1;
+                    B.b1 = d;
+                    B.pos = p;
+                } else if (d < B.b2) {
+                    B.b2 = d;
+                }
+            }
+            const int key = B.b1 < 256 ? ((B.b1 << 16) | B.pos) : 0x7FFFFFFF;
+            const int k1 = bs_wave_min(key);
+            const int k2 = bs_wave_min(key == k1 ? B.b2 : B.b1);
+            const int bd1 = k1 == 0x7FFFFFFF ? 256 : (k1 >> 16), bd2 = k2;
+            const bool pass = th_mode ? (bd1 < th) : (bd1 <= th);
+            if (pass && (float)bd1 < nnratio * (float)bd2) {
+                const int i2 = idx2[k1 & 0xFFFF];
+                if (lane == 0) {
+                    m12[i1] = (uint16_t)i2;
+                    atomicOr(&claim[i2 >> 5], 1u << (i2 & 31));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+    __syncthreads();
+rotation:
+    ORB_ABL_STOP(phases < 7);
+
+    // ---- 7. rotation consistency (:267-285) and outputs ----
+    const orbhip_keypoint *k1p = kps + (size_t)b1 * cap, *k2p = kps + (size_t)b * cap;
+    auto bin_of = [&](int i1, int i2) {
+        float rot = k1p[i1].angle - k2p[i2].angle;
+        if (rot < 0.0f) rot += 360.0f;
+        int bin = (int)roundf(rot * (1.0f / BS_HISTO));
+        if (bin == BS_HISTO) bin = 0;
+        return bin;
+    };
+    if (check_ori) {
+        for (int i1 = tid; i1 < n1; i1 += BL_THREADS) {
+            const int i2 = m12[i1];
+            if (i2 != 0xFFFF) {
+                const int bin = bin_of(i1, i2);
+                if (bin >= 0 && bin < BS_HISTO) atomicAdd(&s_hist[bin], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < BS_HISTO; i++) {
+                const int sz = s_hist[i];
+                if (sz > max1) {
+                    max3 = max2; max2 = max1; max1 = sz;
+                    i3 = i2; i2 = i1; i1 = i;
+                } else if (sz > max2) {
+                    max3 = max2; max2 = sz;
+                    i3 = i2; i2 = i;
+                } else if (sz > max3) {
+                    max3 = sz;
+                    i3 = i;
+                }
+            }
+            if ((float)max2 < 0.1f * (float)max1) {
+                i2 = -1;
+                i3 = -1;
+            } else if ((float)max3 < 0.1f * (float)max1) {
+                i3 = -1;
+            }
+            s_keep[0] = i1;
+            s_keep[1] = i2;
+            s_keep[2] = i3;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < cap; i += BL_THREADS) o21[i] = -1;
+    __syncthreads();
+    int local = 0;
+    for (int i1 = tid; i1 < cap; i1 += BL_THREADS) {
+        int i2 = i1 < n1 ? (int)m12[i1] : 0xFFFF;
+        if (i2 == 0xFFFF) i2 = -1;
+        if (i2 >= 0 && check_ori) {
+            const int bin = bin_of(i1, i2);
+            if (bin >= 0 && bin < BS_HISTO && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) i2 = -1;
+        }
+        o12[i1] = i2;
+        if (i2 >= 0) {
+            o21[i2] = i1;
+            local++;
+        }
+    }
+    atomicAdd(&s_nm, local);
+    __syncthreads();
+    if (tid == 0) nmatches[b] = s_nm;
+}
+
 void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *kps, const int32_t *counts,
                     const int32_t *node, const float *weight, const uint8_t *valid, int cap, int B, int lag, int th,
                     int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21,
@@ -523,6 +1077,21 @@ void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *k
     if (B <= 0) return;
     int NP = 512;
     while (NP < cap) NP <<= 1;
+    // the lane-per-node kernel (above) when its byte clamp is exact for these thresholds, the features fit its 16-bit indices and
+    // its LDS fits; ORBHIP_BOW_LANE=0 (liborbhip_ablation.so): the wave-per-node kernel
+    static const int laneEnv = ORB_TUNE("BOW_LANE", 1);
+    {
+        const int capP = (cap + 63) & ~63;
+        const size_t ldsLane = (size_t)NP * 16 + (size_t)capP * (3 * 2 + 8 + 2 + 2) + (size_t)NP / 32 * 12 + 64;
+        if (laneEnv && cap < 65535 && NP <= 4096 && ldsLane <= 150 * 1024 && (float)th < nnratio * 255.0f && th < 255) {
+            static const int dbgL = ORB_TUNE("BOW_PHASES", 9);
+            (void)dbgL;
+            if (ldsLane > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_bow_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLane);
+            hipLaunchKernelGGL(k_bow_lane, dim3(B, 1, 1), dim3(BL_THREADS, 1, 1), ldsLane, s, desc, kps, counts, node, weight, valid, cap, NP,
+                               lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches ORB_ABL_ARG(dbgL));
+            return;
+        }
+    }
     const size_t base = (((size_t)NP * 36 + (size_t)NP / 32 * 12 + 15) & ~(size_t)15) + 64;
     const size_t full = base + (size_t)cap * 64;
     static const int forceGlobal = ORB_TUNE("BOW_GLOBAL_DESC", 0);

@@ -661,6 +661,9 @@ __global__ __launch_bounds__(256, 8) void k_fast(const OrbLevels G, const uint8_
 // at the same 1.02 ms -- the kernel is bound by vector and LDS issue, not by its loads; the r01 mappings paid an integer division
 // per thread for the same traffic and were slower.
 #define FAST_DEFAULT_XCD 4
+#ifndef ORB_FAST_TILE_BY_VALUE
+#define ORB_FAST_TILE_BY_VALUE 1
+#endif
 #define FF_RHM FAST_FIX_ROWS            // staged rows (hCell + 6) the fixed layout holds: cells of up to 34 rows, every level of 640 x 480 / 752 x 480 ...
 #define FF_RHM_TALL 48                 // ... and the instance for taller cells (a level of two or three cell rows rounds its cell height up:
                                        // 1241 x 376 has cells of 40 rows at its smallest level); 1.7 KB more LDS: seven workgroups per CU
@@ -882,6 +885,12 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
     __shared__ int s_wcnt[4][2];          // pass 1, per wave: work-list and corner-list counts
     extern __shared__ __align__(16) uint8_t s_score[];       // [DH][SP]
 
+#if ORB_FAST_TILE_BY_VALUE
+    // (every kernel argument fetched together, in front of the descriptor: the compiler otherwise fetches each where it is first used)
+    asm volatile("" ::"s"(stride0), "s"(frame0), "s"(pyrFrame), "s"(totalCells), "s"(totalCands), "s"(iniTh), "s"(minTh), "s"(listCap),
+                 "s"(cornerCap), "s"(xcdMap), "s"(ntiles), "s"((unsigned long long)(uintptr_t)lvl0), "s"((unsigned long long)(uintptr_t)pyr),
+                 "s"((unsigned long long)(uintptr_t)cand), "s"((unsigned long long)(uintptr_t)cellCnt));
+#endif
     int tileId, frame;
     if ((xcdMap & 255) == 4) {
         // grid (8, runs, ceil(B / 8)): workgroups are dealt to the XCDs round-robin by linear id = (z * runs + y) * 8 + x, so XCD x
@@ -895,7 +904,22 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
         frame = blockIdx.y;
     }
     if (tileId >= ntiles) return;   // grid padded to a multiple of 8 (orbhip_internal.h, xcd_tile)
+#if ORB_FAST_TILE_BY_VALUE
+    // The run's descriptor in ONE scalar round trip: read field by field where it is first used (the reference below) the
+    // prologue is a chain of seven dependent scalar loads in front of the first LDS-DMA -- ~1 us of a workgroup's ~8 us.
+    FastTile T;
+    {
+        const uint4 *tp = reinterpret_cast<const uint4 *>(tiles + tileId);
+        uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3], q4 = tp[4], q5 = tp[5];
+        asm volatile("" : "+s"(q0.x), "+s"(q0.y), "+s"(q0.z), "+s"(q0.w), "+s"(q1.x), "+s"(q1.y), "+s"(q1.z), "+s"(q1.w), "+s"(q2.x), "+s"(q2.y),
+                          "+s"(q2.z), "+s"(q2.w), "+s"(q3.x), "+s"(q3.y), "+s"(q3.z), "+s"(q3.w), "+s"(q4.x), "+s"(q4.y), "+s"(q4.z), "+s"(q4.w),
+                          "+s"(q5.x), "+s"(q5.y), "+s"(q5.z), "+s"(q5.w));
+        const uint4 q[6] = {q0, q1, q2, q3, q4, q5};
+        __builtin_memcpy(&T, q, sizeof(T));
+    }
+#else
     const FastTile &T = tiles[tileId];
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int DH = T.DH, TW = T.TW, ncells = T.nc;
@@ -996,6 +1020,39 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
         }
         __syncthreads();
         ORB_ABL_STOP(phases < 3 || phases == 12);   // ablation stops: 2-4 = phases of pass 0
+        // Ablation only (liborbhip_ablation.so, ORBHIP_FAST_PHASES=13 / 14; r05 review item 1a): the work list regrouped BY ROW in front
+        // of the score phase -- a counting sort over the entries' rows through the (still empty) score tile -- so that a wave's 64
+        // entries come from two or three rows.  Stop 13 ends after the sort, stop 14 after the score phase on the sorted list: the
+        // difference of their LDS counters is the ring gather's cost with a row-grouped list, to set beside (stop 3 - stop 2).
+        ORB_ABL_IF(phases == 13 || phases == 14) {
+            const int nl = s_listCount;
+            if (nl <= listCap && nl * 2 <= DH * SP) {
+                uint32_t *hist = reinterpret_cast<uint32_t *>(s_corner);   // [64] rows' counts, [64] rows' cursors
+                uint16_t *tmp = reinterpret_cast<uint16_t *>(s_score);
+                if (tid < 128) hist[tid] = 0;
+                __syncthreads();
+                for (int e = tid; e < nl; e += 256) atomicAdd(&hist[ENT_ROW(s_list[e])], 1u);
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t a = 0;
+                    for (int r = 0; r < 64; r++) {
+                        hist[64 + r] = a;
+                        a += hist[r];
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < nl; e += 256) {
+                    const int ent = s_list[e];
+                    tmp[atomicAdd(&hist[64 + ENT_ROW(ent)], 1u)] = (uint16_t)ent;
+                }
+                __syncthreads();
+                for (int e = tid; e < nl; e += 256) s_list[e] = tmp[e];
+                __syncthreads();
+                for (int i = tid; i < (DH * SP + 15) >> 4; i += 256) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
+                __syncthreads();
+            }
+        }
+        ORB_ABL_STOP(phases == 13);
 
         // ---- 3. full score on the work list; corners (score >= t) -> score tile + corner list ----
         // If a tile has more compass survivors than the work list holds (noise-like images), every domain pixel is scored
@@ -1067,7 +1124,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_fix(const uint8_t *__restrict__
             }
         }
         __syncthreads();
-        ORB_ABL_STOP(phases < 4);
+        ORB_ABL_STOP(phases < 4 || phases == 14);
 
         // ---- 4. NMS over the corners (cell-local neighbourhood); every survivor is final: set its bit ----
         const int ncorner = s_cornerCount;
