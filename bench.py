@@ -1146,8 +1146,22 @@ def main():
             step()
             barrier()
             voc_ms["tiled"] = time_transform()
+        # control: the TILED frames copied into the second buffer -- is a difference the frames' or the buffer's (where the allocator put it)?
+        d_img2.copy_(d_img)
+        assert L.orbhip_set_stage_timing(ex0.handle, 1) == 0
+        step(d_img2)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nt_steps):
+            step(d_img2)
+            ms = (C.c_float * 6)()
+            assert L.orbhip_get_stage_times(ex0.handle, ms) == 0
+        barrier()
+        nt_control = (time.perf_counter() - t0) / nt_steps
+        assert L.orbhip_set_stage_timing(ex0.handle, 2) == 0
         out["no_tiling_check"] = {"unique_frames": B, "value": round(B / nt, 1), "unit": "frames/s", "ms_per_step": round(nt * 1e3, 3),
                                   "steps": nt_steps, "ratio_to_headline": round((B / nt) / out["value"], 4), "verified_frames": nt_ver, "stage_ms": nt_stage, "vocab_transform_ms": voc_ms,
+                                  "control_tiled_frames_in_the_second_buffer": {"value": round(B / nt_control, 1), "ms_per_step": round(nt_control * 1e3, 3)},
                                   "note": "the %d distinct frames shifted cyclically by (5 r, 9 r) pixels for copy r: %d different "
                                           "frames of the same content class in the batch; same context, same buffers" % (U, B)}
         del d_img2

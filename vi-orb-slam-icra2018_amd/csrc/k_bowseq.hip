@@ -572,7 +572,8 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
     uint16_t *order = ioff + capP;                                    // item slots: lane items by cost, then the others
     unsigned *claim = reinterpret_cast<unsigned *>(order + capP);
     unsigned *vbit1 = claim + NP / 32, *vbit2 = vbit1 + NP / 32;
-    __shared__ int s_n1v, s_n2v, s_nitems, s_nlane, s_ngroup, s_next, s_nm, s_over, s_ntiles;
+    __shared__ int s_n1v, s_n2v, s_nitems, s_next, s_nm, s_over, s_ntiles;
+    __shared__ int s_cls[4], s_cur[4];
     __shared__ int s_hist[BS_HISTO];
     __shared__ int s_keep[3];
 
@@ -622,8 +623,8 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
         s_n1v = 0;
         s_n2v = 0;
         s_nitems = 0;
-        s_nlane = 0;
-        s_ngroup = 0;
+        s_cls[0] = s_cls[1] = s_cls[2] = s_cls[3] = 0;
+        s_cur[0] = s_cur[1] = s_cur[2] = s_cur[3] = 0;
         s_next = 0;
         s_nm = 0;
         s_over = 0;
@@ -658,26 +659,23 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
     ORB_ABL_STOP(phases < 3);
     const int nitems = s_nitems;
 
-    // ---- 3. classes and order: [group items, 17 .. 128 side-2 features][lane items, <= 16][the rest], each by cost, largest first;
-    //         offsets of the byte matrices (rows of ceil4(n2) bytes) in rank order ----
-    auto rank_key = [&](const uint2 it) {
-        const int c1 = (int)((it.x >> 16) - (it.x & 0xFFFF)), c2 = (int)((it.y >> 16) - (it.y & 0xFFFF));
-        const int cls = c2 > BL_MAXN2 ? 0 : c2 > 16 ? 2 : 1;       // ranks descend: group items first, then lane items, then the rest
-        return (cls << 24) + min(c1 * c2, (1 << 24) - 1);
+    // ---- 3. classes and order: [group items, 17 .. 128 side-2 features][lane items, <= 16][the rest]; inside a class the order is
+    //         whatever the counters give (every group item gets a 16-lane row of its own, every lane item a lane: nothing to
+    //         balance); offsets of the byte matrices (rows of ceil4(n2) bytes) in that order ----
+    auto class_of = [&](const uint2 it) {
+        const int c2 = (int)((it.y >> 16) - (it.y & 0xFFFF));
+        return c2 > BL_MAXN2 ? 3 : c2 > 64 ? 0 : c2 > 16 ? 1 : 2;
     };
+    for (int i = tid; i < nitems; i += BL_THREADS) atomicAdd(&s_cls[class_of(items[i])], 1);
+    __syncthreads();
+    // ranks [0, ngroup8): group items of 65 .. 128 side-2 features; [ngroup8, ngroup): of 17 .. 64; [ngroup, nmat): lane items; then the rest
+    const int ngroup8 = s_cls[0], ngroup = ngroup8 + s_cls[1], nmat = ngroup + s_cls[2];
     for (int i = tid; i < nitems; i += BL_THREADS) {
-        const int c = rank_key(items[i]);
-        int rank = 0;
-        for (int o = 0; o < nitems; o++) {
-            const int oc = rank_key(items[o]);
-            rank += (oc > c) || (oc == c && o < i);
-        }
-        order[rank] = (uint16_t)i;
-        if ((c >> 24) == 2) atomicAdd(&s_ngroup, 1);
-        if ((c >> 24) != 0) atomicAdd(&s_nlane, 1);
+        const int cls = class_of(items[i]);
+        const int r = (cls == 0 ? 0 : cls == 1 ? ngroup8 : cls == 2 ? ngroup : nmat) + atomicAdd(&s_cur[cls], 1);
+        order[r] = (uint16_t)i;
     }
     __syncthreads();
-    const int ngroup = s_ngroup, nmat = s_nlane;   // ranks [0, ngroup): group items; [ngroup, nmat): lane items; [nmat, nitems): cooperative
     if (tid < 64) {
         // offsets (4-byte units) in rank order by one wave; what no longer fits the matrix space goes to the cooperative path
         int base = 0, tbase = 0;
@@ -794,64 +792,74 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
     ORB_ABL_STOP(phases < 5);
 
     // ---- 5. greedy matching ----
-    // 5a. group items: a 16-lane DPP row per node, four nodes per wave; lane gl owns the candidates gl, gl + 16, ... (up to 8), reads
-    //     their bytes of the row, folds them into (best, second) keys, two row minima give the node's best / second
+    // 5a. group items: a 16-lane DPP row per node, four nodes per wave; lane gl owns the candidates gl, gl + 16, ... (J = 4 of them for
+    //     nodes of up to 64 side-2 features, 8 up to 128), reads their bytes of the row, folds them into (best, second) keys, two row
+    //     minima give the node's best / second
     {
         const int gl = lane & 15, grp = tid >> 4, ngrp = BL_THREADS >> 4;
-        for (int r = grp; r < ngroup; r += ngrp) {
+        auto group_item = [&](auto jtag, int r) {
+            constexpr int J = decltype(jtag)::value;
             const int slot = order[r];
             const int off = ioff[slot];
-            if (off == 0xFFFF) continue;
+            if (off == 0xFFFF) return;
             const uint2 it = items[slot];
             const int s1 = it.x & 0xFFFF, nrow = (int)(it.x >> 16) - s1, s2 = it.y & 0xFFFF, n2i = (int)(it.y >> 16) - s2;
             const int stride = (n2i + 3) & ~3;
-            unsigned gone = 0;                               // bit j: my candidate gl + 16 j is claimed, invalid or absent
+            uint32_t gm[J];                                  // 0xFF: my candidate gl + 16 j is claimed, invalid or absent
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < J; j++) {
                 const int c = gl + 16 * j;
                 bool out = c >= n2i;
                 if (!out && th_mode) {
                     const int i2 = idx2[s2 + c];
                     out = !((vbit2[i2 >> 5] >> (i2 & 31)) & 1u);   // :572-578
                 }
-                if (out) gone |= 1u << j;
+                gm[j] = out ? 0xFFu : 0u;
             }
             // The next row's bytes and feature index are requested before this row is reduced (a row is then two DPP minima and a
-            // chain of eight med3 / min, no LDS round trip).  In assembly: the compiler waits lgkmcnt(0) right behind a load whose
+            // chain of J med3 / min, no LDS round trip).  In assembly: the compiler waits lgkmcnt(0) right behind a load whose
             // value it wants to zero-extend, which is exactly the round trip to be hidden; the wait is ours, at the loop top.
-            // A lane reads all eight of its bytes whether the node has that many candidates or not (what lies there is masked by
+            // A lane reads all J of its bytes whether the node has that many candidates or not (what lies there is masked by
             // `gm`, and the addresses stay inside the workgroup's LDS).
             uint32_t rowAddr = (uint32_t)(uintptr_t)(dist + (size_t)off * 4 + gl);
             uint32_t idxAddr = (uint32_t)(uintptr_t)(idx1 + s1);
             const bool checkValid = valid != nullptr;
-            uint32_t gm[8];                                  // 0xFF: my candidate gl + 16 j is claimed, invalid or absent
-#pragma unroll
-            for (int j = 0; j < 8; j++) gm[j] = ((gone >> j) & 1u) ? 0xFFu : 0u;
             uint32_t dn[8], i1n;
-#define BL_ROW_LOADS()                                                                                                                    \
-    asm volatile("ds_read_u8 %0, %9\n\tds_read_u8 %1, %9 offset:16\n\tds_read_u8 %2, %9 offset:32\n\tds_read_u8 %3, %9 offset:48\n\t"          \
-                 "ds_read_u8 %4, %9 offset:64\n\tds_read_u8 %5, %9 offset:80\n\tds_read_u8 %6, %9 offset:96\n\tds_read_u8 %7, %9 offset:112\n\t" \
-                 "ds_read_u16 %8, %10"                                                                                                    \
-                 : "=&v"(dn[0]), "=&v"(dn[1]), "=&v"(dn[2]), "=&v"(dn[3]), "=&v"(dn[4]), "=&v"(dn[5]), "=&v"(dn[6]), "=&v"(dn[7]), "=&v"(i1n)    \
-                 : "v"(rowAddr), "v"(idxAddr)                                                                                             \
-                 : "memory")
-            BL_ROW_LOADS();
+            auto row_loads = [&]() {
+                if constexpr (J == 4)
+                    asm volatile("ds_read_u8 %0, %5\n\tds_read_u8 %1, %5 offset:16\n\tds_read_u8 %2, %5 offset:32\n\tds_read_u8 %3, %5 offset:48\n\t"
+                                 "ds_read_u16 %4, %6"
+                                 : "=&v"(dn[0]), "=&v"(dn[1]), "=&v"(dn[2]), "=&v"(dn[3]), "=&v"(i1n)
+                                 : "v"(rowAddr), "v"(idxAddr)
+                                 : "memory");
+                else
+                    asm volatile("ds_read_u8 %0, %9\n\tds_read_u8 %1, %9 offset:16\n\tds_read_u8 %2, %9 offset:32\n\tds_read_u8 %3, %9 offset:48\n\t"
+                                 "ds_read_u8 %4, %9 offset:64\n\tds_read_u8 %5, %9 offset:80\n\tds_read_u8 %6, %9 offset:96\n\tds_read_u8 %7, %9 offset:112\n\t"
+                                 "ds_read_u16 %8, %10"
+                                 : "=&v"(dn[0]), "=&v"(dn[1]), "=&v"(dn[2]), "=&v"(dn[3]), "=&v"(dn[4]), "=&v"(dn[5]), "=&v"(dn[6]), "=&v"(dn[7]), "=&v"(i1n)
+                                 : "v"(rowAddr), "v"(idxAddr)
+                                 : "memory");
+            };
+            row_loads();
             for (int a = 0; a < nrow; a++) {
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]), "+v"(dn[4]), "+v"(dn[5]), "+v"(dn[6]), "+v"(dn[7]), "+v"(i1n)
-                             :
-                             : "memory");
+                if constexpr (J == 4)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]), "+v"(i1n) : : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]), "+v"(dn[4]), "+v"(dn[5]), "+v"(dn[6]), "+v"(dn[7]), "+v"(i1n)
+                                 :
+                                 : "memory");
                 const int i1 = (int)i1n;
-                uint32_t dj[8];
+                uint32_t dj[J];
 #pragma unroll
-                for (int j = 0; j < 8; j++) dj[j] = dn[j] | gm[j];
+                for (int j = 0; j < J; j++) dj[j] = dn[j] | gm[j];
                 rowAddr += (uint32_t)stride;
                 idxAddr += 2u;
-                if (a + 1 < nrow) BL_ROW_LOADS();
+                if (a + 1 < nrow) row_loads();
                 if (checkValid && !((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;   // (uniform over the row) no good MapPoint: :193-199
                 unsigned k1 = 0xFFFFFFu, k2 = (256u << 8);
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < J; j++) {
                     const unsigned key = (dj[j] << 8) | (unsigned)(gl + 16 * j);
                     unsigned nk2;
                     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(nk2) : "v"(k1), "v"(k2), "v"(key));
@@ -865,13 +873,21 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
                 if (pass && (float)bd1 < nnratio * (float)bd2) {        // ref: :228-230 / :598-600
                     if ((pos & 15) == gl) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
+                        for (int j = 0; j < J; j++)
                             if ((pos >> 4) == j) gm[j] = 0xFFu;
                         m12[i1] = idx2[s2 + pos];
                     }
                 }
             }
-#undef BL_ROW_LOADS
+        };
+        // (the two kinds never share a wave -- a wave would run them one after the other: the items of up to 64 candidates start at the
+        // next multiple of four groups)
+        const int g8pad = (ngroup8 + 3) & ~3, n4 = ngroup - ngroup8;
+        for (int g = grp; g < g8pad + n4; g += ngrp) {
+            if (g < ngroup8)
+                group_item(std::integral_constant<int, 8>{}, g);
+            else if (g >= g8pad)
+                group_item(std::integral_constant<int, 4>{}, ngroup8 + (g - g8pad));
         }
     }
     // 5b. lane items: a lane walks its node alone (at most 16 candidates: up to four dwords per row); dealt from the last thread down,
