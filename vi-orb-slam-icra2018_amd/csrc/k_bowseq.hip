@@ -767,20 +767,32 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
             if (t + ngrp < ntiles) fetch(t + ngrp, NT, nq0, nq1, nr0, nr1);
             uint8_t *dst = dist + (size_t)T.off * 4 + T.c;
             const bool inPad = T.c < T.stride;
-            // (a vector write of a register needs two wait states before a DPP read of it: the copies above, if the compiler kept any)
-            asm volatile("s_nop 1" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+            // One assembly block per step: a vector write of a register needs two wait states before a DPP read of it, and the
+            // compiler neither sees the DPP reads inside inline assembly nor is kept from placing a register copy right in front of
+            // one (the whole-batch check of bench.py caught exactly that: a copy of a descriptor dword ahead of its rotated read,
+            // one frame pair in a thousand off by a match).  The s_nop at the top covers every operand; nothing can be scheduled
+            // into the block.
 #define BL_STEP(U)                                                                                                              \
     {                                                                                                                           \
         const int row = T.row0 + ((gl - (U)) & 15);                                                                            \
-        const uint32_t QQ[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, RR[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}; \
-        int d = 0;                                                                                                              \
-        _Pragma("unroll") for (int k = 0; k < 8; k++)                                                                          \
-        {                                                                                                                       \
-            uint32_t x;                                                                                                         \
-            if ((U) == 0) x = QQ[k] ^ RR[k];                                                                                    \
-            else asm volatile("v_xor_b32_dpp %0, %1, %2 row_ror:" #U " row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(QQ[k]), "v"(RR[k])); \
-            d += __popc(x);                                                                                                     \
-        }                                                                                                                       \
+        uint32_t x0, x1, x2, x3, x4, x5, x6, x7;                                                                                \
+        if ((U) == 0) {                                                                                                         \
+            x0 = q0.x ^ r0.x; x1 = q0.y ^ r0.y; x2 = q0.z ^ r0.z; x3 = q0.w ^ r0.w;                                             \
+            x4 = q1.x ^ r1.x; x5 = q1.y ^ r1.y; x6 = q1.z ^ r1.z; x7 = q1.w ^ r1.w;                                             \
+        } else                                                                                                                  \
+            asm volatile("s_nop 1\n\t"                                                                                          \
+                         "v_xor_b32_dpp %0, %8, %16 row_ror:" #U " row_mask:0xf bank_mask:0xf\n\t"                              \
+                         "v_xor_b32_dpp %1, %9, %17 row_ror:" #U " row_mask:0xf bank_mask:0xf\n\t"                              \
+                         "v_xor_b32_dpp %2, %10, %18 row_ror:" #U " row_mask:0xf bank_mask:0xf\n\t"                             \
+                         "v_xor_b32_dpp %3, %11, %19 row_ror:" #U " row_mask:0xf bank_mask:0xf\n\t"                             \
+                         "v_xor_b32_dpp %4, %12, %20 row_ror:" #U " row_mask:0xf bank_mask:0xf\n\t"                             \
+                         "v_xor_b32_dpp %5, %13, %21 row_ror:" #U " row_mask:0xf bank_mask:0xf\n\t"                             \
+                         "v_xor_b32_dpp %6, %14, %22 row_ror:" #U " row_mask:0xf bank_mask:0xf\n\t"                             \
+                         "v_xor_b32_dpp %7, %15, %23 row_ror:" #U " row_mask:0xf bank_mask:0xf"                                 \
+                         : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)               \
+                         : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(r0.x),   \
+                           "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w));                        \
+        const int d = __popc(x0) + __popc(x1) + __popc(x2) + __popc(x3) + __popc(x4) + __popc(x5) + __popc(x6) + __popc(x7);    \
         if (inPad && row < T.nrow) dst[(size_t)row * T.stride] = (uint8_t)(T.hasC ? min(d, 255) : 255);                         \
     }
             BL_STEP(0) BL_STEP(1) BL_STEP(2) BL_STEP(3) BL_STEP(4) BL_STEP(5) BL_STEP(6) BL_STEP(7)
@@ -817,45 +829,30 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
                 gm[j] = out ? 0xFFu : 0u;
             }
             // The next row's bytes and feature index are requested before this row is reduced (a row is then two DPP minima and a
-            // chain of J med3 / min, no LDS round trip).  In assembly: the compiler waits lgkmcnt(0) right behind a load whose
-            // value it wants to zero-extend, which is exactly the round trip to be hidden; the wait is ours, at the loop top.
-            // A lane reads all J of its bytes whether the node has that many candidates or not (what lies there is masked by
-            // `gm`, and the addresses stay inside the workgroup's LDS).
-            uint32_t rowAddr = (uint32_t)(uintptr_t)(dist + (size_t)off * 4 + gl);
-            uint32_t idxAddr = (uint32_t)(uintptr_t)(idx1 + s1);
+            // chain of J med3 / min, no LDS round trip).  The index is fetched as the 32-bit word that holds it and taken apart
+            // only where it is used, one row later: behind a 16-bit load the compiler zero-extends at once and puts its wait there
+            // -- the round trip that was to be hidden.  (A first form issued the loads from inline assembly and waited at the loop
+            // top; the compiler is free to copy such a register before the wait, and bench.py's whole-batch check found one frame
+            // pair in a few thousand off by a match.)  A lane reads all J of its bytes whether the node has that many candidates or
+            // not (what lies there is masked by `gm`, and the addresses stay inside the workgroup's LDS).
+            const uint8_t *rowp = dist + (size_t)off * 4 + gl;
+            const uint32_t *idx1w = reinterpret_cast<const uint32_t *>(idx1);
             const bool checkValid = valid != nullptr;
-            uint32_t dn[8], i1n;
-            auto row_loads = [&]() {
-                if constexpr (J == 4)
-                    asm volatile("ds_read_u8 %0, %5\n\tds_read_u8 %1, %5 offset:16\n\tds_read_u8 %2, %5 offset:32\n\tds_read_u8 %3, %5 offset:48\n\t"
-                                 "ds_read_u16 %4, %6"
-                                 : "=&v"(dn[0]), "=&v"(dn[1]), "=&v"(dn[2]), "=&v"(dn[3]), "=&v"(i1n)
-                                 : "v"(rowAddr), "v"(idxAddr)
-                                 : "memory");
-                else
-                    asm volatile("ds_read_u8 %0, %9\n\tds_read_u8 %1, %9 offset:16\n\tds_read_u8 %2, %9 offset:32\n\tds_read_u8 %3, %9 offset:48\n\t"
-                                 "ds_read_u8 %4, %9 offset:64\n\tds_read_u8 %5, %9 offset:80\n\tds_read_u8 %6, %9 offset:96\n\tds_read_u8 %7, %9 offset:112\n\t"
-                                 "ds_read_u16 %8, %10"
-                                 : "=&v"(dn[0]), "=&v"(dn[1]), "=&v"(dn[2]), "=&v"(dn[3]), "=&v"(dn[4]), "=&v"(dn[5]), "=&v"(dn[6]), "=&v"(dn[7]), "=&v"(i1n)
-                                 : "v"(rowAddr), "v"(idxAddr)
-                                 : "memory");
-            };
-            row_loads();
+            uint32_t dn[J], iwn;
+#pragma unroll
+            for (int j = 0; j < J; j++) dn[j] = rowp[16 * j];
+            iwn = idx1w[s1 >> 1];
             for (int a = 0; a < nrow; a++) {
-                if constexpr (J == 4)
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]), "+v"(i1n) : : "memory");
-                else
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]), "+v"(dn[4]), "+v"(dn[5]), "+v"(dn[6]), "+v"(dn[7]), "+v"(i1n)
-                                 :
-                                 : "memory");
-                const int i1 = (int)i1n;
+                const int i1 = (int)((iwn >> (16 * ((s1 + a) & 1))) & 0xFFFFu);
                 uint32_t dj[J];
 #pragma unroll
                 for (int j = 0; j < J; j++) dj[j] = dn[j] | gm[j];
-                rowAddr += (uint32_t)stride;
-                idxAddr += 2u;
-                if (a + 1 < nrow) row_loads();
+                rowp += stride;
+                if (a + 1 < nrow) {
+#pragma unroll
+                    for (int j = 0; j < J; j++) dn[j] = rowp[16 * j];
+                    iwn = idx1w[(s1 + a + 1) >> 1];
+                }
                 if (checkValid && !((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;   // (uniform over the row) no good MapPoint: :193-199
                 unsigned k1 = 0xFFFFFFu, k2 = (256u << 8);
 #pragma unroll
@@ -911,28 +908,27 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
                 }
             }
         }
-        uint32_t rowAddr = (uint32_t)(uintptr_t)(dist + (size_t)off * 4);
-        uint32_t idxAddr = (uint32_t)(uintptr_t)(idx1 + s1);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(dist + (size_t)off * 4);
+        const uint32_t *idx1w = reinterpret_cast<const uint32_t *>(idx1);
         const bool checkValid = valid != nullptr;
-        // (four dwords of every row are read whatever the node's width: the dwords beyond it belong to the next row and are masked)
+        // (four dwords of every row are read whatever the node's width: the dwords beyond it belong to the next row and are masked;
+        // the next row and its feature index -- as the 32-bit word that holds it, see 5a -- are requested before this row is reduced)
         const uint32_t padm[4] = {0u, nw > 1 ? 0u : 0xFFFFFFFFu, nw > 2 ? 0u : 0xFFFFFFFFu, nw > 3 ? 0u : 0xFFFFFFFFu};
-        uint32_t wn[4], i1n;
-#define BL_LANE_LOADS()                                                                                                          \
-    asm volatile("ds_read_b32 %0, %5\n\tds_read_b32 %1, %5 offset:4\n\tds_read_b32 %2, %5 offset:8\n\tds_read_b32 %3, %5 offset:12\n\t" \
-                 "ds_read_u16 %4, %6"                                                                                            \
-                 : "=&v"(wn[0]), "=&v"(wn[1]), "=&v"(wn[2]), "=&v"(wn[3]), "=&v"(i1n)                                            \
-                 : "v"(rowAddr), "v"(idxAddr)                                                                                    \
-                 : "memory")
-        BL_LANE_LOADS();
+        uint32_t wn[4], iwn;
+#pragma unroll
+        for (int k = 0; k < 4; k++) wn[k] = row[k];
+        iwn = idx1w[s1 >> 1];
         for (int a = 0; a < nrow; a++) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(i1n) : : "memory");
-            const int i1 = (int)i1n;
+            const int i1 = (int)((iwn >> (16 * ((s1 + a) & 1))) & 0xFFFFu);
             uint32_t w[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) w[k] = wn[k] | cm[k] | padm[k];
-            rowAddr += 4u * (uint32_t)nw;
-            idxAddr += 2u;
-            if (a + 1 < nrow) BL_LANE_LOADS();                   // the next row is requested before this one is reduced
+            row += nw;
+            if (a + 1 < nrow) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) wn[k] = row[k];
+                iwn = idx1w[(s1 + a + 1) >> 1];
+            }
             if (checkValid && !((vbit1[i1 >> 5] >> (i1 & 31)) & 1u)) continue;   // no (good) MapPoint: :193-199
             unsigned k1 = 0xFFFFFFu, k2 = (256u << 8);          // best / second keys (distance << 8 | position)
 #pragma unroll
@@ -958,7 +954,6 @@ __global__ __launch_bounds__(BL_THREADS, 3) void k_bow_lane(const uint8_t *__res
                     if ((pos >> 2) == k) cm[k] |= m;
             }
         }
-#undef BL_LANE_LOADS
     }
     __syncthreads();
     ORB_ABL_STOP(phases < 6);

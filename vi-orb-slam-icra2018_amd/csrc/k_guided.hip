@@ -968,7 +968,7 @@ __global__ __launch_bounds__(1024) void k_proj_assign_par(const orbhip_keypoint 
 // ---- ORBmatcher::SearchForInitialization (ref: src/ORBmatcher.cc:405-520) ----------------------------------
 //   k_init_cands   one wave per level-0 feature of frame 1: the window of GetFeaturesInArea(prev_matched[i1], windowSize,
 //                  0, 0) over frame 2's records, 64 at a time; the features that pass keep the reference's order through
-//                  a ballot prefix count; tuple = distance | index << 9.
+//                  a ballot prefix count; tuple = distance << 23 | position << 16 | index; lists of up to 64 leave sorted (r05).
 //   k_init_assign  one wave per frame pair, features of frame 1 in index order: a candidate is skipped when frame 2's
 //                  feature is already matched at a distance <= this one (vMatchedDistance, LDS), best / second are two
 //                  minima over (distance, list position), an accepted match displaces the earlier owner.  Then the rotation
@@ -985,6 +985,7 @@ __global__ __launch_bounds__(256) void k_init_cands(const orbhip_keypoint *__res
 {
     __shared__ int s_pre[4][65];
     __shared__ int s_beg[4][64];
+    __shared__ uint32_t s_lst[4][INIT_K];   // the feature's tuples in visiting order, before they are (sorted and) stored
     const int b = blockIdx.y, i1 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i1 >= cap1pad) return;
     int count = 0;
@@ -1034,9 +1035,29 @@ __global__ __launch_bounds__(256) void k_init_cands(const orbhip_keypoint *__res
                 const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
                 if (pass && pos < keff) {
                     const int idx = w >> 8;
-                    T[pos] = (uint32_t)hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]) | ((uint32_t)idx << 9);
+                    // tuple = distance << 23 | position in visiting order << 16 | feature of frame 2 (< 2^16): as an integer it
+                    // orders by distance, then by position -- the reference's strict '<' scan takes the first of equal distances
+                    s_lst[wv][pos] = ((uint32_t)hamming256g(a0, a1, D[2 * idx], D[2 * idx + 1]) << 23) | ((uint32_t)pos << 16) | (uint32_t)idx;
                 }
                 count += __popcll(m);
+            }
+            WAVE_LDS_SYNC();
+            const int stored = min(count, keff);
+            if (count <= 64 && count <= keff) {
+                // r05: a list of up to 64 candidates leaves SORTED (bitonic network over the wave): k_init_assign then finds best and
+                // second as the first two entries that the state of vMatchedDistance does not skip -- one ballot, no reduction
+                uint32_t v = lane < count ? s_lst[wv][lane] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        const uint32_t o = (uint32_t)__shfl_xor((int)v, j);
+                        const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                        v = (lower == up) ? min(v, o) : max(v, o);
+                    }
+                if (lane < count) T[lane] = v;
+            } else {
+                for (int p = lane; p < stored; p += 64) T[p] = s_lst[wv][p];
             }
         }
     }
@@ -1163,15 +1184,14 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
             }
             WAVE_LDS_SYNC();
         }
-        // One wave walks the features in order, so the kernel's time is the instructions and LDS round trips of a feature (r04
-        // counters: ~88 vector + 37 scalar instructions and ~4 round trips each, 106 us for ~220 features with candidates) --
-        // not its global loads (staged above), not the first two round trips (requesting them a feature ahead changed
-        // nothing).  Lists of up to 32 candidates -- a window of 100 pixels holds ~30 level-0 features -- are therefore taken
-        // TWO AT A TIME, one per 32-lane half: the same instruction stream reduces both (the DPP steps stay inside 16-lane rows,
-        // the two rows of a half are joined by scalar minima), the features are then accepted in index order, and when the
-        // first one's match is a candidate of the second (whose vMatchedDistance was read before that match existed) the second
-        // half alone is reduced again.  Longer lists: one feature per trip over the whole wave, as before.
-        const int limP = min(32, keff);
+        // One wave walks the features in order (the reference's vMatchedDistance makes a feature depend on every earlier one that touched
+        // one of its candidates), so the kernel's time is the instructions and LDS round trips of a feature.  r04 reduced every list
+        // over the wave (two short lists per trip, DPP minima: ~88 vector + 37 scalar instructions and ~4 round trips per feature,
+        // 82 us for ~220 features with candidates).  r05: lists of up to 64 candidates arrive SORTED by (distance, position) from
+        // k_init_cands, where the sort is parallel over the features; best and second are then the first two entries the current
+        // state does not skip: one dependent read (vMatchedDistance of the lane's entry), one ballot, two find-first-bits.
+        // Longer lists: one feature per trip over the whole wave, minima over (distance, position) keys, as before.
+        const int limS = min(64, keff);
         auto accept = [&](int i1, int bestIdx, int bestDist, int bestDist2) -> bool {
             if (!(bestIdx >= 0 && bestDist <= th_low && (float)bestDist < __fmul_rn((float)bestDist2, nnratio))) return false;   // :458-460
             const int old = s_m21[bestIdx];
@@ -1193,69 +1213,33 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
             const int i1 = base + j;
             const int c = __builtin_amdgcn_readlane(myc, j);
             int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx = -1;
-            if (c <= limP) {
-                // this feature in lanes 0..31 and, if its list is short too, the next one in lanes 32..63
-                int jB = -1, cB = 0;
-                if (todo) {
-                    const int jn = (int)__builtin_ctzll(todo);
-                    const int cn = __builtin_amdgcn_readlane(myc, jn);
-                    if (cn <= limP) {
-                        jB = jn;
-                        cB = cn;
-                        todo &= todo - 1;
-                    }
+            if (c <= limS) {
+                // a sorted list (k_init_cands): lane p holds entry p; the entries vMatchedDistance does not skip (:443-444) as a ballot,
+                // its two lowest bits are the best and the second.  (Requesting the next feature's entry a feature ahead and carrying
+                // vnMatches21 of the lane's entry along with vMatchedDistance -- one v_readlane instead of one more LDS read in the
+                // accept -- were measured: 88.7 -> 96.3 us; the walk is ~100 instructions and ten branches per feature on one wave,
+                // not its round trips.)
+                const bool has = lane < c;
+                const uint32_t t = has ? s_tup[j * INIT_K + lane] : 0u;
+                const int d = (int)(t >> 23), idx = (int)(t & 0xFFFFu);
+                const int md = has ? s_md[idx] : 0;
+                const unsigned long long m = __ballot(has && !(md <= d));
+                if (m) {
+                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)__builtin_ctzll(m));
+                    bestDist = (int)(t1 >> 23);
+                    bestIdx = (int)(t1 & 0xFFFFu);
+                    const unsigned long long m2 = m & (m - 1ull);
+                    if (m2) bestDist2 = (int)((uint32_t)__builtin_amdgcn_readlane((int)t, (int)__builtin_ctzll(m2)) >> 23);
                 }
-                const int hi = lane >> 5, p = lane & 31;
-                const bool has = hi ? (jB >= 0 && p < cB) : p < c;
-                const uint32_t t = has ? s_tup[(hi ? jB : j) * INIT_K + p] : 0u;
-                const int d = (int)(t & 511u), idx = (int)(t >> 9);
-                int md = has ? s_md[idx] : 0;
-                int key = (has && !(md <= d)) ? ((d << 16) | p) : 0x7FFFFFFF;   // :443-444
-                auto row_min = [&](int v) { return orb_row_min_i(v); };   // every lane: the minimum of its 16-lane row
-                int r1 = row_min(key);
-                const int kA1 = min(__builtin_amdgcn_readlane(r1, 0), __builtin_amdgcn_readlane(r1, 16));
-                int kB1 = min(__builtin_amdgcn_readlane(r1, 32), __builtin_amdgcn_readlane(r1, 48));
-                // second minima: list positions are unique inside a half, one lane holds the first
-                int r2 = row_min(key == (hi ? kB1 : kA1) ? 0x7FFFFFFF : key);
-                const int kA2 = min(__builtin_amdgcn_readlane(r2, 0), __builtin_amdgcn_readlane(r2, 16));
-                int kB2 = min(__builtin_amdgcn_readlane(r2, 32), __builtin_amdgcn_readlane(r2, 48));
-                if (kA1 != 0x7FFFFFFF) {
-                    bestDist = kA1 >> 16;
-                    bestIdx = (int)((uint32_t)__builtin_amdgcn_readlane((int)t, kA1 & 31) >> 9);
-                    if (kA2 != 0x7FFFFFFF) bestDist2 = kA2 >> 16;
-                }
-                const bool tookA = accept(i1, bestIdx, bestDist, bestDist2);
-                if (jB >= 0) {
-                    if (tookA) {
-                        // feature A's match is a candidate of B: B saw vMatchedDistance of it before the match existed
-                        const bool stale = hi && has && idx == bestIdx;
-                        if (__ballot(stale)) {
-                            if (stale) {
-                                md = bestDist;
-                                key = !(md <= d) ? ((d << 16) | p) : 0x7FFFFFFF;
-                            }
-                            r1 = row_min(key);
-                            kB1 = min(__builtin_amdgcn_readlane(r1, 32), __builtin_amdgcn_readlane(r1, 48));
-                            r2 = row_min(key == kB1 ? 0x7FFFFFFF : key);
-                            kB2 = min(__builtin_amdgcn_readlane(r2, 32), __builtin_amdgcn_readlane(r2, 48));
-                        }
-                    }
-                    int bD = 0x7FFFFFFF, bD2 = 0x7FFFFFFF, bI = -1;
-                    if (kB1 != 0x7FFFFFFF) {
-                        bD = kB1 >> 16;
-                        bI = (int)((uint32_t)__builtin_amdgcn_readlane((int)t, 32 + (kB1 & 31)) >> 9);
-                        if (kB2 != 0x7FFFFFFF) bD2 = kB2 >> 16;
-                    }
-                    (void)accept(base + jB, bI, bD, bD2);
-                }
+                (void)accept(i1, bestIdx, bestDist, bestDist2);
                 continue;
             }
             if (c <= keff) {
                 int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
                 for (int p = lane; p < c; p += 64) {
-                    const uint32_t t = s_tup[j * INIT_K + p];
-                    const int d = (int)(t & 511u), idx = (int)(t >> 9);
-                    const int key = s_md[idx] <= d ? 0x7FFFFFFF : ((d << 16) | p);   // :443-444
+                    const uint32_t t = s_tup[j * INIT_K + p];      // (longer than 64: in visiting order, position = slot)
+                    const int d = (int)(t >> 23), idx = (int)(t & 0xFFFFu);
+                    const int key = s_md[idx] <= d ? 0x7FFFFFFF : (int)(t >> 16);   // :443-444; distance << 7 | position
                     if (key < m1) {
                         m2 = m1;
                         m1 = key;
@@ -1266,9 +1250,9 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
                 const int k1 = wave_min_i(m1);
                 if (k1 != 0x7FFFFFFF) {
                     const int k2 = wave_min_i(m1 == k1 ? m2 : m1);   // list positions are unique: one lane holds k1
-                    bestDist = k1 >> 16;
-                    bestIdx = (int)(s_tup[j * INIT_K + (k1 & 0xFFFF)] >> 9);
-                    if (k2 != 0x7FFFFFFF) bestDist2 = k2 >> 16;
+                    bestDist = k1 >> 7;
+                    bestIdx = (int)(s_tup[j * INIT_K + (k1 & 127)] & 0xFFFFu);
+                    if (k2 != 0x7FFFFFFF) bestDist2 = k2 >> 7;
                 }
             } else {
                 // more candidates than the list holds: the reference's scan, identically in every lane
