@@ -654,7 +654,8 @@ def content_classes(device, blob, B=256, steps=4, verify=True):
         dt = time.perf_counter() - t0
         cnt = d_cnt.cpu().numpy()
         prev = None
-        for b in range(2 if verify else 0):        # (--verify 0: timing ablations, whose results are invalid by design)
+        nv = min(len(uniq) + 1, B) if verify else 0   # every distinct frame and the pair across the first tile boundary
+        for b in range(nv):                           # (--verify 0: timing ablations, whose results are invalid by design)
             k, d = ref(frames[b])
             n = int(cnt[b])
             if n != len(k) or d_kps[b, :n].cpu().numpy().tobytes() != k.tobytes() or not np.array_equal(d_desc[b, :n].cpu().numpy(), d):
@@ -667,13 +668,17 @@ def content_classes(device, blob, B=256, steps=4, verify=True):
                 if int(d_nm[b].item()) != nm or not np.array_equal(d_m21[b, :len(m21)].cpu().numpy(), m21):
                     raise SystemExit("bench.py: content class %s: SearchByBoW of frame %d differs from the oracle" % (kind, b))
             prev = cur
+        # ... and every tiled copy against its original, on the device
+        ncopies = verify_tiled_copies({"cnt": d_cnt, "kps": d_kps, "desc": d_desc, "nm": d_nm, "m12": d_m12, "m21": d_m21}, len(uniq), B, cap,
+                                      "bow") if verify else 0
         out[kind] = {"value": round(steps * B / dt, 1), "unit": "frames/s", "k_fast_ms_per_1024_frames": round(fast * 1024.0 / B, 4),
                      "keypoints_per_frame": round(float(cnt.mean()), 1), "bow_matches_per_frame": round(float(d_nm.cpu().numpy()[1:].mean()), 1),
-                     "verified_frames": 2 if verify else 0}
+                     "verified_frames": nv + ncopies}
         del d_img
     ex.close()
     out["frames_per_step"] = B
-    out["note"] = "batches of %d frames (8 distinct, tiled), %d timed steps each; the headline runs the textured class at 1024" % (B, steps)
+    out["note"] = ("batches of %d frames (8 distinct, tiled), %d timed steps each; every distinct frame and the pair across the first tile boundary "
+                   "against the oracle, every copy against its original on the device; the headline runs the textured class at 1024" % (B, steps))
     out["seconds_total"] = round(time.perf_counter() - t_all, 1)
     return out
 
