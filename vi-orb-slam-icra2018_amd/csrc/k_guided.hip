@@ -1000,7 +1000,9 @@ __global__ __launch_bounds__(256) void k_init_cands(const orbhip_keypoint *__res
             const uint4 *D = reinterpret_cast<const uint4 *>(desc2 + (size_t)b * cap2 * 32);
             const float4 *R = rec2 + (size_t)b * cap2;
             const int32_t *O = cellOff2 + (size_t)b * (GCELLS + 1);
-            uint32_t *T = tuples + ((size_t)b * cap1pad + i1) * INIT_K;
+            // a round's 64 lists (features i1 & ~63 ...) are stored TRANSPOSED: entry p of list l at [p * 64 + l] -- in k_init_assign a
+            // lane walks its own list, and the round's rows [0, longest list) are one contiguous piece
+            uint32_t *T = tuples + ((size_t)b * cap1pad + (i1 & ~63)) * INIT_K + (i1 & 63);
             // The window's cell columns are contiguous record ranges; the wave walks their concatenation 64 records at
             // a time (lane c holds column c's range, a prefix sum over the lengths maps a flat position back to its
             // column), which is the visiting order of GetFeaturesInArea.
@@ -1055,9 +1057,9 @@ __global__ __launch_bounds__(256) void k_init_cands(const orbhip_keypoint *__res
                         const bool up = (lane & k) == 0, lower = (lane & j) == 0;
                         v = (lower == up) ? min(v, o) : max(v, o);
                     }
-                if (lane < count) T[lane] = v;
+                if (lane < count) T[lane * 64] = v;
             } else {
-                for (int p = lane; p < stored; p += 64) T[p] = s_lst[wv][p];
+                for (int p = lane; p < stored; p += 64) T[p * 64] = s_lst[wv][p];
             }
         }
     }
@@ -1088,7 +1090,8 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
     // What the wave would otherwise fetch one dependent round trip at a time (r04 trace: 106 us per call, most of it ~60 such
     // trips of ~1.5 us -- the list lengths per round of 64 features, the two angles per accepted feature in both passes of the
     // rotation check, the matched keypoint's position in the last loop) is read once, coalesced, with the loads in flight together:
-    int *s_tc = s_acc + cap1;                                         // list lengths [cap1pad]
+    int *s_stamp = s_acc + cap1;                  // who accepted a feature of frame 2 in the current trip of the walk [cap2]
+    int *s_tc = s_stamp + cap2;                                       // list lengths [cap1pad]
     float *s_a1 = reinterpret_cast<float *>(s_tc + cap1pad);          // angles of frame 1 [cap1]
     float *s_k2 = s_a1 + cap1;                                        // x, y, angle of frame 2 [3 * cap2]
     const orbhip_keypoint *K1 = kps1 + (size_t)b * cap1, *K2 = kps2 + (size_t)b * cap2;
@@ -1098,6 +1101,7 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
     for (int i = lane; i < cap2; i += 64) {
         s_md[i] = 0x7FFFFFFF;
         s_m21[i] = -1;
+        s_stamp[i] = 0;
     }
     for (int i = lane; i < cap1; i += 64) {
         s_m12[i] = -1;
@@ -1159,39 +1163,32 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
     stage &= 15;
     ORB_ABL_IF(stop == 1) return;           // tables staged
     ORB_ABL_IF(stop == 3) n1 = min(n1, 64); // one round of the feature loop
-    int nm = 0;
+    int nm = 0, trip = 0;
     const uint4 *Tg = reinterpret_cast<const uint4 *>(tuples + (size_t)b * cap1pad * INIT_K);
+    const int limS = min(64, keff);   // lists of up to limS candidates arrive sorted by (distance, position)
     for (int base = 0; base < n1; base += 64) {
         const int myq = base + lane;
         const int myc = myq < n1 ? (stage ? s_tc[myq] : tcount[(size_t)b * cap1pad + myq]) : 0;
-        unsigned long long todo = __ballot(myc > 0);
-        if (todo) {
-            // the 64 lists of this round: all INIT_K slots only if a list is longer than half of them (a window of 100 pixels
-            // holds ~30 level-0 features; the unused upper halves were half of the kernel's loads)
+        const unsigned long long todo = __ballot(myc > 0);
+        if (!todo) continue;
+        {
+            // the round's 64 lists, transposed (entry p of list l at [p * 64 + l]): rows [0, longest stored list) are contiguous
+            // (a window of 100 pixels holds ~30 level-0 features: ~10 of the 32 KB)
+            const int rows = -wave_min_i(-min(myc, keff));
             uint4 *s4 = reinterpret_cast<uint4 *>(s_tup);
             const uint4 *src = Tg + (size_t)base * (INIT_K / 4);
-            if (__ballot(myc > INIT_K / 2)) {
-#pragma unroll 8
-                for (int k = 0; k < INIT_K / 4; k++) s4[k * 64 + lane] = src[k * 64 + lane];
-            } else {
-                // lane -> (list, 16-byte piece of its lower half): INIT_K / 8 = 16 pieces per list, four lists per trip
-                const int piece = lane & (INIT_K / 8 - 1), lst = lane / (INIT_K / 8);
-#pragma unroll 8
-                for (int k = 0; k < 64 / (64 / (INIT_K / 8)); k++) {
-                    const int o = ((64 / (INIT_K / 8)) * k + lst) * (INIT_K / 4) + piece;
-                    s4[o] = src[o];
-                }
+            const int nq = rows * 16;
+            for (int k0 = 0; k0 < nq; k0 += 64 * 8) {
+                // eight loads in flight and no branch around any of them (a guarded load is compiled as load, wait, next load):
+                // what lies beyond the last piece reads and writes the last piece again
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = src[min(k0 + 64 * u + lane, nq - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s4[min(k0 + 64 * u + lane, nq - 1)] = v[u];
             }
             WAVE_LDS_SYNC();
         }
-        // One wave walks the features in order (the reference's vMatchedDistance makes a feature depend on every earlier one that touched
-        // one of its candidates), so the kernel's time is the instructions and LDS round trips of a feature.  r04 reduced every list
-        // over the wave (two short lists per trip, DPP minima: ~88 vector + 37 scalar instructions and ~4 round trips per feature,
-        // 82 us for ~220 features with candidates).  r05: lists of up to 64 candidates arrive SORTED by (distance, position) from
-        // k_init_cands, where the sort is parallel over the features; best and second are then the first two entries the current
-        // state does not skip: one dependent read (vMatchedDistance of the lane's entry), one ballot, two find-first-bits.
-        // Longer lists: one feature per trip over the whole wave, minima over (distance, position) keys, as before.
-        const int limS = min(64, keff);
         auto accept = [&](int i1, int bestIdx, int bestDist, int bestDist2) -> bool {
             if (!(bestIdx >= 0 && bestDist <= th_low && (float)bestDist < __fmul_rn((float)bestDist2, nnratio))) return false;   // :458-460
             const int old = s_m21[bestIdx];
@@ -1207,76 +1204,134 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
             WAVE_LDS_SYNC();
             return true;
         };
-        while (todo) {
-            const int j = (int)__builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int i1 = base + j;
+        // The reference walks the features of frame 1 in index order, and vMatchedDistance makes a feature depend on every earlier
+        // one that was accepted with one of its candidates.  Through r05's first half one wave walked them one at a time: ~100
+        // instructions and three dependent LDS round trips per feature (0.4 us; written without a single branch it took the same
+        // time).  Now a LANE walks its own feature and the wave keeps the order: in one trip every undecided feature of the round
+        // takes best / second as the first two entries of its sorted list that the state BEFORE the trip does not skip, and a
+        // feature that would be accepted stamps its best candidate (trip, lowest such lane: one atomicMax).  vMatchedDistance only
+        // ever decreases, so a feature's decision stands unless an earlier feature of the same trip stamped one of the entries
+        // it looked at: the features before the first such one (the first undecided one never is) are committed together -- their
+        // best candidates are distinct, their displaced owners were accepted before the trip -- and the rest decide again in the
+        // next trip.  Features with a longer list (unsorted, or longer than the table: the rescan) take a trip of their own over the
+        // whole wave, as before.
+        const bool mine = myc > 0 && myc <= limS;
+        uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = mine && k < myc ? s_tup[k * 64 + lane] : 0u;
+        unsigned long long rem = todo;
+        while (rem) {
+            const int j = (int)__builtin_ctzll(rem);
             const int c = __builtin_amdgcn_readlane(myc, j);
-            int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx = -1;
-            if (c <= limS) {
-                // a sorted list (k_init_cands): lane p holds entry p; the entries vMatchedDistance does not skip (:443-444) as a ballot,
-                // its two lowest bits are the best and the second.  (Requesting the next feature's entry a feature ahead and carrying
-                // vnMatches21 of the lane's entry along with vMatchedDistance -- one v_readlane instead of one more LDS read in the
-                // accept -- were measured: 88.7 -> 96.3 us; the walk is ~100 instructions and ten branches per feature on one wave,
-                // not its round trips.)
-                const bool has = lane < c;
-                const uint32_t t = has ? s_tup[j * INIT_K + lane] : 0u;
-                const int d = (int)(t >> 23), idx = (int)(t & 0xFFFFu);
-                const int md = has ? s_md[idx] : 0;
-                const unsigned long long m = __ballot(has && !(md <= d));
-                if (m) {
-                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)__builtin_ctzll(m));
-                    bestDist = (int)(t1 >> 23);
-                    bestIdx = (int)(t1 & 0xFFFFu);
-                    const unsigned long long m2 = m & (m - 1ull);
-                    if (m2) bestDist2 = (int)((uint32_t)__builtin_amdgcn_readlane((int)t, (int)__builtin_ctzll(m2)) >> 23);
+            if (c > limS) {
+                const int i1 = base + j;
+                int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx = -1;
+                if (c <= keff) {
+                    int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
+                    for (int p = lane; p < c; p += 64) {
+                        const uint32_t t = s_tup[p * 64 + j];         // (in visiting order, position = slot)
+                        const int d = (int)(t >> 23), idx = (int)(t & 0xFFFFu);
+                        const int key = s_md[idx] <= d ? 0x7FFFFFFF : (int)(t >> 16);   // :443-444; distance << 7 | position
+                        if (key < m1) {
+                            m2 = m1;
+                            m1 = key;
+                        } else if (key < m2) {
+                            m2 = key;
+                        }
+                    }
+                    const int k1 = wave_min_i(m1);
+                    if (k1 != 0x7FFFFFFF) {
+                        const int k2 = wave_min_i(m1 == k1 ? m2 : m1);   // list positions are unique: one lane holds k1
+                        bestDist = k1 >> 7;
+                        bestIdx = (int)(s_tup[(k1 & 127) * 64 + j] & 0xFFFFu);
+                        if (k2 != 0x7FFFFFFF) bestDist2 = k2 >> 7;
+                    }
+                } else {
+                    // more candidates than the list holds: the reference's scan, identically in every lane
+                    orbhip_proj_query q;
+                    const float2 pm = PM[i1];
+                    q.u = pm.x;
+                    q.v = pm.y;
+                    q.radius = radius;
+                    q.min_level = q.max_level = K1[i1].octave;
+                    const uint4 *qd = reinterpret_cast<const uint4 *>(desc1 + ((size_t)b * cap1 + i1) * 32);
+                    const uint4 a0 = qd[0], a1 = qd[1];
+                    walk_window(gp, q, K2, O, I, [&](int idx, int) {
+                        const int d = hamming256g(a0, a1, D2[2 * idx], D2[2 * idx + 1]);
+                        if (s_md[idx] <= d) return;
+                        if (d < bestDist) {
+                            bestDist2 = bestDist;
+                            bestDist = d;
+                            bestIdx = idx;
+                        } else if (d < bestDist2) {
+                            bestDist2 = d;
+                        }
+                    });
                 }
                 (void)accept(i1, bestIdx, bestDist, bestDist2);
+                rem &= rem - 1ull;
                 continue;
             }
-            if (c <= keff) {
-                int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
-                for (int p = lane; p < c; p += 64) {
-                    const uint32_t t = s_tup[j * INIT_K + p];      // (longer than 64: in visiting order, position = slot)
-                    const int d = (int)(t >> 23), idx = (int)(t & 0xFFFFu);
-                    const int key = s_md[idx] <= d ? 0x7FFFFFFF : (int)(t >> 16);   // :443-444; distance << 7 | position
-                    if (key < m1) {
-                        m2 = m1;
-                        m1 = key;
-                    } else if (key < m2) {
-                        m2 = key;
-                    }
+            trip++;
+            const bool undecided = (rem >> lane) & 1ull;
+            const bool act = mine && undecided;
+            int found = 0, pend = 0;
+            uint32_t b1 = 0, b2 = 0;
+            {
+                // (no branch around the reads: an absent entry, or a lane without a feature, reads feature 0 and does not use it)
+                int md[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) md[k] = s_md[e[k] & 0xFFFFu];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool there = act && k < myc;
+                    const bool take = there && found < 2 && !(md[k] <= (int)(e[k] >> 23));   // :443-444
+                    pend = there && found < 2 ? k + 1 : pend;
+                    b2 = take && found == 1 ? e[k] : b2;
+                    b1 = take && found == 0 ? e[k] : b1;
+                    found += take ? 1 : 0;
                 }
-                const int k1 = wave_min_i(m1);
-                if (k1 != 0x7FFFFFFF) {
-                    const int k2 = wave_min_i(m1 == k1 ? m2 : m1);   // list positions are unique: one lane holds k1
-                    bestDist = k1 >> 7;
-                    bestIdx = (int)(s_tup[j * INIT_K + (k1 & 127)] & 0xFFFFu);
-                    if (k2 != 0x7FFFFFFF) bestDist2 = k2 >> 7;
-                }
-            } else {
-                // more candidates than the list holds: the reference's scan, identically in every lane
-                orbhip_proj_query q;
-                const float2 pm = PM[i1];
-                q.u = pm.x;
-                q.v = pm.y;
-                q.radius = radius;
-                q.min_level = q.max_level = K1[i1].octave;
-                const uint4 *qd = reinterpret_cast<const uint4 *>(desc1 + ((size_t)b * cap1 + i1) * 32);
-                const uint4 a0 = qd[0], a1 = qd[1];
-                walk_window(gp, q, K2, O, I, [&](int idx, int) {
-                    const int d = hamming256g(a0, a1, D2[2 * idx], D2[2 * idx + 1]);
-                    if (s_md[idx] <= d) return;
-                    if (d < bestDist) {
-                        bestDist2 = bestDist;
-                        bestDist = d;
-                        bestIdx = idx;
-                    } else if (d < bestDist2) {
-                        bestDist2 = d;
+                if (__ballot(act && found < 2 && myc > 4))   // (rare: both of the first four skipped)
+                    for (int p = 4; act && p < myc && found < 2; p++) {
+                        const uint32_t t = s_tup[p * 64 + lane];
+                        pend = p + 1;
+                        if (!(s_md[t & 0xFFFFu] <= (int)(t >> 23))) {
+                            if (found == 0) b1 = t;
+                            else b2 = t;
+                            found++;
+                        }
                     }
-                });
             }
-            (void)accept(i1, bestIdx, bestDist, bestDist2);
+            const int bD = found >= 1 ? (int)(b1 >> 23) : 0x7FFFFFFF, bI = (int)(b1 & 0xFFFFu);
+            const int bD2 = found >= 2 ? (int)(b2 >> 23) : 0x7FFFFFFF;
+            const bool ok = act && found >= 1 && bD <= th_low && (float)bD < __fmul_rn((float)bD2, nnratio);   // :458-460
+            if (ok) atomicMax(&s_stamp[bI], trip * 64 + 63 - lane);
+            WAVE_LDS_SYNC();
+            bool dirty = undecided && !mine;   // a long list: decided in a trip of its own, when it is the first undecided one
+            int st[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) st[k] = s_stamp[e[k] & 0xFFFFu];
+            const int old = s_m21[bI];
+#pragma unroll
+            for (int k = 0; k < 4; k++) dirty |= (k < pend) & ((st[k] >> 6) == trip) & (63 - (st[k] & 63) < lane);
+            if (__ballot(pend > 4))
+                for (int p = 4; p < pend; p++) {
+                    const int s5 = s_stamp[s_tup[p * 64 + lane] & 0xFFFFu];
+                    dirty |= (s5 >> 6) == trip && 63 - (s5 & 63) < lane;
+                }
+            const unsigned long long dm = __ballot(dirty);
+            const unsigned long long commit = dm ? rem & ((1ull << __builtin_ctzll(dm)) - 1ull) : rem;
+            const bool w = ok && ((commit >> lane) & 1ull);
+            if (w) {
+                if (old >= 0) s_m12[old] = -1;   // the feature's previous owner loses it (:462-466)
+                s_m12[myq] = bI;
+                s_m21[bI] = myq;
+                s_md[bI] = bD;
+                s_acc[myq] = bI;
+            }
+            nm += __popcll(__ballot(w)) - __popcll(__ballot(w && old >= 0));
+            rem &= ~commit;
+            WAVE_LDS_SYNC();
         }
     }
     WAVE_LDS_SYNC();
@@ -1339,6 +1394,7 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
         matches12[(size_t)b * cap1 + i1] = m;
         if (m >= 0) PM[i1] = stage ? make_float2(s_k2[3 * m], s_k2[3 * m + 1]) : make_float2(K2[m].x, K2[m].y);   // :512-515
     }
+    ORB_ABL_IF(stop == 4) nm = trip;   // (ablation only: the walk's trips instead of the match count)
     if (lane == 0) nmatches[b] = nm;
 }
 
@@ -1359,7 +1415,7 @@ size_t init_scratch_bytes(int B, int cap1, int cap2)
     return (size_t)B * cap2 * 16 + (size_t)B * cap1pad * (INIT_K * 4 + 4) + 256;
 }
 
-size_t init_assign_lds(int cap1, int cap2) { return ((size_t)cap1 * 2 + (size_t)cap2 * 2) * 4; }   // the match tables (required)
+size_t init_assign_lds(int cap1, int cap2) { return ((size_t)cap1 * 2 + (size_t)cap2 * 3) * 4; }   // the match tables (required)
 // ... plus list lengths [cap1pad], angles of frame 1 [cap1] and x, y, angle of frame 2 [3 cap2], staged when they fit as well
 static size_t init_assign_lds_staged(int cap1, int cap2)
 {
