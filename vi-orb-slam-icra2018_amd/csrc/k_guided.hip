@@ -1066,31 +1066,37 @@ __global__ __launch_bounds__(256) void k_init_cands(const orbhip_keypoint *__res
     if (lane == 0) tcount[(size_t)b * cap1pad + i1] = count;
 }
 
-__global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__restrict__ kps1,
-                                                    const uint8_t *__restrict__ desc1, const int32_t *__restrict__ cnt1,
-                                                    int cap1, const orbhip_keypoint *__restrict__ kps2,
-                                                    const uint8_t *__restrict__ desc2, const int32_t *__restrict__ cnt2,
-                                                    int cap2, float2 *__restrict__ prev, float radius, const GridParams gp,
-                                                    const int32_t *__restrict__ cellOff2,
-                                                    const int32_t *__restrict__ cellIdx2, int cap1pad, int keff,
-                                                    const uint32_t *__restrict__ tuples, const int32_t *__restrict__ tcount,
-                                                    float nnratio, int check_ori, int th_low,
-                                                    int32_t *__restrict__ matches12, int32_t *__restrict__ nmatches, int stage)
+#define INIT_NT 256   // k_init_assign: wave 0 walks the features, all four waves stage, prefetch the lists, check the rotation, write
+#define INIT_ROUND (64 * INIT_K)   // words of one round's 64 lists
+
+__global__ __launch_bounds__(INIT_NT) void k_init_assign(const orbhip_keypoint *__restrict__ kps1,
+                                                         const uint8_t *__restrict__ desc1, const int32_t *__restrict__ cnt1,
+                                                         int cap1, const orbhip_keypoint *__restrict__ kps2,
+                                                         const uint8_t *__restrict__ desc2, const int32_t *__restrict__ cnt2,
+                                                         int cap2, float2 *__restrict__ prev, float radius, const GridParams gp,
+                                                         const int32_t *__restrict__ cellOff2,
+                                                         const int32_t *__restrict__ cellIdx2, int cap1pad, int keff,
+                                                         const uint32_t *__restrict__ tuples, const int32_t *__restrict__ tcount,
+                                                         float nnratio, int check_ori, int th_low,
+                                                         int32_t *__restrict__ matches12, int32_t *__restrict__ nmatches, int mode)
 {
     extern __shared__ uint32_t s_dyn[];
-    __shared__ uint32_t s_tup[64 * INIT_K];
     __shared__ int s_hist[30];
     __shared__ int s_keep[3];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_rm;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool staged = mode & 1;   // the tables below fit the LDS beside the match tables (frames of up to ~3000 features)
+    const bool dbl = mode & 2;      // ... and so does a second buffer for the lists: the next round's arrive while this one is walked
     int n1 = min(cnt1[b], cap1);   // (features of frame 2 beyond cnt2 are not in its grid)
-    int *s_md = reinterpret_cast<int *>(s_dyn);   // vMatchedDistance [cap2]
+    uint32_t *s_tup = s_dyn;                                       // the lists of a round, one or two buffers
+    int *s_md = reinterpret_cast<int *>(s_dyn + (dbl ? 2 : 1) * INIT_ROUND);   // vMatchedDistance [cap2]
     int *s_m21 = s_md + cap2;                     // vnMatches21 [cap2]
     int *s_m12 = s_m21 + cap2;                    // vnMatches12 [cap1]
     int *s_acc = s_m12 + cap1;                    // feature of frame 2 at the time i1 was accepted, or -1 [cap1]
-    // What the wave would otherwise fetch one dependent round trip at a time (r04 trace: 106 us per call, most of it ~60 such
+    int *s_stamp = s_acc + cap1;                  // who accepted a feature of frame 2 in the current trip of the walk [cap2]
+    // What the walk would otherwise fetch one dependent round trip at a time (r04 trace: 106 us per call, most of it ~60 such
     // trips of ~1.5 us -- the list lengths per round of 64 features, the two angles per accepted feature in both passes of the
     // rotation check, the matched keypoint's position in the last loop) is read once, coalesced, with the loads in flight together:
-    int *s_stamp = s_acc + cap1;                  // who accepted a feature of frame 2 in the current trip of the walk [cap2]
     int *s_tc = s_stamp + cap2;                                       // list lengths [cap1pad]
     float *s_a1 = reinterpret_cast<float *>(s_tc + cap1pad);          // angles of frame 1 [cap1]
     float *s_k2 = s_a1 + cap1;                                        // x, y, angle of frame 2 [3 * cap2]
@@ -1098,58 +1104,50 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
     const uint4 *D2 = reinterpret_cast<const uint4 *>(desc2 + (size_t)b * cap2 * 32);
     const int32_t *O = cellOff2 + (size_t)b * (GCELLS + 1), *I = cellIdx2 + (size_t)b * cap2;
     float2 *PM = prev + (size_t)b * cap1;
-    for (int i = lane; i < cap2; i += 64) {
-        s_md[i] = 0x7FFFFFFF;
-        s_m21[i] = -1;
-        s_stamp[i] = 0;
-    }
-    for (int i = lane; i < cap1; i += 64) {
-        s_m12[i] = -1;
-        s_acc[i] = -1;
-    }
-    if (lane < 30) s_hist[lane] = 0;
-    if (stage) {   // (uniform: the tables fit the LDS beside the match tables -- frames of up to ~3000 features)
-        const int n2 = min(cnt2[b], cap2);
-        const int32_t *TC = tcount + (size_t)b * cap1pad;
-        constexpr int U = 8;   // loads in flight per lane
-        for (int i0 = 0; i0 < cap1pad; i0 += 64 * U) {
+    const int32_t *TC = tcount + (size_t)b * cap1pad;
+    const uint4 *Tg = reinterpret_cast<const uint4 *>(tuples + (size_t)b * cap1pad * INIT_K);
+    // rows of a round that hold entries: the longest stored list of its 64 features (every wave computes the same number)
+    auto round_rows = [&](int base) -> int {
+        const int q = base + lane;
+        const int c = q < n1 ? (staged ? s_tc[q] : TC[q]) : 0;
+        return -wave_min_i(-min(c, keff));
+    };
+    // a round's 64 lists, transposed (entry p of list l at [p * 64 + l]): rows [0, rows) are contiguous (a window of 100 pixels
+    // holds ~30 level-0 features: ~10 of the 32 KB).  Thread t of nt; eight loads in flight and no branch around any of them
+    // (a guarded load is compiled as load, wait, next load): what lies beyond the last piece reads and writes the last piece again
+    auto load_round = [&](int base, uint32_t *buf, int rows, int t, int nt) {
+        uint4 *s4 = reinterpret_cast<uint4 *>(buf);
+        const uint4 *src = Tg + (size_t)base * (INIT_K / 4);
+        const int nq = rows * 16;
+        for (int k0 = 0; k0 < nq; k0 += nt * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[min(k0 + nt * u + t, nq - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s4[min(k0 + nt * u + t, nq - 1)] = v[u];
+        }
+    };
+    if (staged) {
+        // one trip for frames of up to 1024 features: the five loads of a thread's four positions are issued before the first store
+        const int n2 = min(cnt2[b], cap2), n2c = max(n2 - 1, 0);
+        constexpr int U = 4;
+        for (int i0 = 0; i0 < max(cap1pad, n2); i0 += INIT_NT * U) {
             int v[U];
+            float w[U], x[U], y[U], a[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = i0 + 64 * u + lane;
+                const int i = i0 + INIT_NT * u + tid, i2 = min(i, n2c);
                 v[u] = i < n1 ? TC[i] : 0;
+                w[u] = i < n1 ? K1[i].angle : 0.f;
+                x[u] = K2[i2].x;
+                y[u] = K2[i2].y;
+                a[u] = K2[i2].angle;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int i = i0 + 64 * u + lane;
+                const int i = i0 + INIT_NT * u + tid;
                 if (i < cap1pad) s_tc[i] = v[u];
-            }
-        }
-        for (int i0 = 0; i0 < n1; i0 += 64 * U) {
-            float v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = i0 + 64 * u + lane;
-                v[u] = i < n1 ? K1[i].angle : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = i0 + 64 * u + lane;
-                if (i < n1) s_a1[i] = v[u];
-            }
-        }
-        for (int i0 = 0; i0 < n2; i0 += 64 * (U / 2)) {
-            float x[U / 2], y[U / 2], a[U / 2];
-#pragma unroll
-            for (int u = 0; u < U / 2; u++) {
-                const int i = min(i0 + 64 * u + lane, n2 - 1);
-                x[u] = K2[i].x;
-                y[u] = K2[i].y;
-                a[u] = K2[i].angle;
-            }
-#pragma unroll
-            for (int u = 0; u < U / 2; u++) {
-                const int i = i0 + 64 * u + lane;
+                if (i < n1) s_a1[i] = w[u];
                 if (i < n2) {
                     s_k2[3 * i] = x[u];
                     s_k2[3 * i + 1] = y[u];
@@ -1158,196 +1156,201 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
             }
         }
     }
-    WAVE_LDS_SYNC();
-    const int stop = stage >> 4;            (void)stop;   // timing ablation only (liborbhip_ablation.so, ORBHIP_INIT_STOP); 0 in the shipped library
-    stage &= 15;
+    for (int i = tid; i < cap2; i += INIT_NT) {
+        s_md[i] = 0x7FFFFFFF;
+        s_m21[i] = -1;
+        s_stamp[i] = 0;
+    }
+    for (int i = tid; i < cap1; i += INIT_NT) {
+        s_m12[i] = -1;
+        s_acc[i] = -1;
+    }
+    if (tid < 30) s_hist[tid] = 0;
+    if (tid == 0) s_rm = 0;
+    __syncthreads();
+    const int rows0 = n1 > 0 ? round_rows(0) : 0;
+    load_round(0, s_tup, rows0, tid, INIT_NT);
+    __syncthreads();
+    const int stop = mode >> 4;            (void)stop;   // timing ablation only (liborbhip_ablation.so, ORBHIP_INIT_STOP); 0 in the shipped library
     ORB_ABL_IF(stop == 1) return;           // tables staged
     ORB_ABL_IF(stop == 3) n1 = min(n1, 64); // one round of the feature loop
     int nm = 0, trip = 0;
-    const uint4 *Tg = reinterpret_cast<const uint4 *>(tuples + (size_t)b * cap1pad * INIT_K);
     const int limS = min(64, keff);   // lists of up to limS candidates arrive sorted by (distance, position)
-    for (int base = 0; base < n1; base += 64) {
-        const int myq = base + lane;
-        const int myc = myq < n1 ? (stage ? s_tc[myq] : tcount[(size_t)b * cap1pad + myq]) : 0;
-        const unsigned long long todo = __ballot(myc > 0);
-        if (!todo) continue;
-        {
-            // the round's 64 lists, transposed (entry p of list l at [p * 64 + l]): rows [0, longest stored list) are contiguous
-            // (a window of 100 pixels holds ~30 level-0 features: ~10 of the 32 KB)
-            const int rows = -wave_min_i(-min(myc, keff));
-            uint4 *s4 = reinterpret_cast<uint4 *>(s_tup);
-            const uint4 *src = Tg + (size_t)base * (INIT_K / 4);
-            const int nq = rows * 16;
-            for (int k0 = 0; k0 < nq; k0 += 64 * 8) {
-                // eight loads in flight and no branch around any of them (a guarded load is compiled as load, wait, next load):
-                // what lies beyond the last piece reads and writes the last piece again
-                uint4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = src[min(k0 + 64 * u + lane, nq - 1)];
-#pragma unroll
-                for (int u = 0; u < 8; u++) s4[min(k0 + 64 * u + lane, nq - 1)] = v[u];
+    int rows = rows0;
+    for (int base = 0, r = 0; base < n1; base += 64, r++) {
+        const uint32_t *tupb = s_tup + (dbl ? (r & 1) * INIT_ROUND : 0);
+        const int rowsNext = base + 64 < n1 ? round_rows(base + 64) : 0;
+        if (wv != 0) {
+            if (dbl) load_round(base + 64, s_tup + ((r + 1) & 1) * INIT_ROUND, rowsNext, tid - 64, INIT_NT - 64);
+        } else if (rows > 0) {
+            const int myq = base + lane;
+            const int myc = myq < n1 ? (staged ? s_tc[myq] : TC[myq]) : 0;
+            const unsigned long long todo = __ballot(myc > 0);
+            auto accept = [&](int i1, int bestIdx, int bestDist, int bestDist2) -> bool {
+                if (!(bestIdx >= 0 && bestDist <= th_low && (float)bestDist < __fmul_rn((float)bestDist2, nnratio))) return false;   // :458-460
+                const int old = s_m21[bestIdx];
+                if (old >= 0) nm--;
+                if (lane == 0) {
+                    if (old >= 0) s_m12[old] = -1;
+                    s_m12[i1] = bestIdx;
+                    s_m21[bestIdx] = i1;
+                    s_md[bestIdx] = bestDist;
+                    s_acc[i1] = bestIdx;
+                }
+                nm++;
+                WAVE_LDS_SYNC();
+                return true;
+            };
+            // The reference walks the features of frame 1 in index order, and vMatchedDistance makes a feature depend on every earlier
+            // one that was accepted with one of its candidates.  Through r05's first half one wave walked them one at a time: ~100
+            // instructions and three dependent LDS round trips per feature (0.4 us; written without a single branch it took the same
+            // time).  Now a LANE walks its own feature and the wave keeps the order: in one trip every undecided feature of the round
+            // takes best / second as the first two entries of its sorted list that the state BEFORE the trip does not skip, and a
+            // feature that would be accepted stamps its best candidate (trip, lowest such lane: one atomicMax).  vMatchedDistance only
+            // ever decreases, so a feature's decision stands unless an earlier feature of the same trip stamped one of the entries
+            // it looked at: the features before the first such one (the first undecided one never is) are committed together -- their
+            // best candidates are distinct, their displaced owners were accepted before the trip -- and the rest decide again in the
+            // next trip.  Features with a longer list (unsorted, or longer than the table: the rescan) take a trip of their own over the
+            // whole wave, as before.
+            const bool mine = myc > 0 && myc <= limS;
+            uint32_t e[4];
+    #pragma unroll
+            for (int k = 0; k < 4; k++) e[k] = mine && k < myc ? tupb[k * 64 + lane] : 0u;
+            unsigned long long rem = todo;
+            while (rem) {
+                const int j = (int)__builtin_ctzll(rem);
+                const int c = __builtin_amdgcn_readlane(myc, j);
+                if (c > limS) {
+                    const int i1 = base + j;
+                    int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx = -1;
+                    if (c <= keff) {
+                        int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
+                        for (int p = lane; p < c; p += 64) {
+                            const uint32_t t = tupb[p * 64 + j];         // (in visiting order, position = slot)
+                            const int d = (int)(t >> 23), idx = (int)(t & 0xFFFFu);
+                            const int key = s_md[idx] <= d ? 0x7FFFFFFF : (int)(t >> 16);   // :443-444; distance << 7 | position
+                            if (key < m1) {
+                                m2 = m1;
+                                m1 = key;
+                            } else if (key < m2) {
+                                m2 = key;
+                            }
+                        }
+                        const int k1 = wave_min_i(m1);
+                        if (k1 != 0x7FFFFFFF) {
+                            const int k2 = wave_min_i(m1 == k1 ? m2 : m1);   // list positions are unique: one lane holds k1
+                            bestDist = k1 >> 7;
+                            bestIdx = (int)(tupb[(k1 & 127) * 64 + j] & 0xFFFFu);
+                            if (k2 != 0x7FFFFFFF) bestDist2 = k2 >> 7;
+                        }
+                    } else {
+                        // more candidates than the list holds: the reference's scan, identically in every lane
+                        orbhip_proj_query q;
+                        const float2 pm = PM[i1];
+                        q.u = pm.x;
+                        q.v = pm.y;
+                        q.radius = radius;
+                        q.min_level = q.max_level = K1[i1].octave;
+                        const uint4 *qd = reinterpret_cast<const uint4 *>(desc1 + ((size_t)b * cap1 + i1) * 32);
+                        const uint4 a0 = qd[0], a1 = qd[1];
+                        walk_window(gp, q, K2, O, I, [&](int idx, int) {
+                            const int d = hamming256g(a0, a1, D2[2 * idx], D2[2 * idx + 1]);
+                            if (s_md[idx] <= d) return;
+                            if (d < bestDist) {
+                                bestDist2 = bestDist;
+                                bestDist = d;
+                                bestIdx = idx;
+                            } else if (d < bestDist2) {
+                                bestDist2 = d;
+                            }
+                        });
+                    }
+                    (void)accept(i1, bestIdx, bestDist, bestDist2);
+                    rem &= rem - 1ull;
+                    continue;
+                }
+                trip++;
+                const bool undecided = (rem >> lane) & 1ull;
+                const bool act = mine && undecided;
+                int found = 0, pend = 0;
+                uint32_t b1 = 0, b2 = 0;
+                {
+                    // (no branch around the reads: an absent entry, or a lane without a feature, reads feature 0 and does not use it)
+                    int md[4];
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) md[k] = s_md[e[k] & 0xFFFFu];
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool there = act && k < myc;
+                        const bool take = there && found < 2 && !(md[k] <= (int)(e[k] >> 23));   // :443-444
+                        pend = there && found < 2 ? k + 1 : pend;
+                        b2 = take && found == 1 ? e[k] : b2;
+                        b1 = take && found == 0 ? e[k] : b1;
+                        found += take ? 1 : 0;
+                    }
+                    if (__ballot(act && found < 2 && myc > 4))   // (rare: both of the first four skipped)
+                        for (int p = 4; act && p < myc && found < 2; p++) {
+                            const uint32_t t = tupb[p * 64 + lane];
+                            pend = p + 1;
+                            if (!(s_md[t & 0xFFFFu] <= (int)(t >> 23))) {
+                                if (found == 0) b1 = t;
+                                else b2 = t;
+                                found++;
+                            }
+                        }
+                }
+                const int bD = found >= 1 ? (int)(b1 >> 23) : 0x7FFFFFFF, bI = (int)(b1 & 0xFFFFu);
+                const int bD2 = found >= 2 ? (int)(b2 >> 23) : 0x7FFFFFFF;
+                const bool ok = act && found >= 1 && bD <= th_low && (float)bD < __fmul_rn((float)bD2, nnratio);   // :458-460
+                if (ok) atomicMax(&s_stamp[bI], trip * 64 + 63 - lane);
+                WAVE_LDS_SYNC();
+                bool dirty = undecided && !mine;   // a long list: decided in a trip of its own, when it is the first undecided one
+                int st[4];
+    #pragma unroll
+                for (int k = 0; k < 4; k++) st[k] = s_stamp[e[k] & 0xFFFFu];
+                const int old = s_m21[bI];
+    #pragma unroll
+                for (int k = 0; k < 4; k++) dirty |= (k < pend) & ((st[k] >> 6) == trip) & (63 - (st[k] & 63) < lane);
+                if (__ballot(pend > 4))
+                    for (int p = 4; p < pend; p++) {
+                        const int s5 = s_stamp[tupb[p * 64 + lane] & 0xFFFFu];
+                        dirty |= (s5 >> 6) == trip && 63 - (s5 & 63) < lane;
+                    }
+                const unsigned long long dm = __ballot(dirty);
+                const unsigned long long commit = dm ? rem & ((1ull << __builtin_ctzll(dm)) - 1ull) : rem;
+                const bool w = ok && ((commit >> lane) & 1ull);
+                if (w) {
+                    if (old >= 0) s_m12[old] = -1;   // the feature's previous owner loses it (:462-466)
+                    s_m12[myq] = bI;
+                    s_m21[bI] = myq;
+                    s_md[bI] = bD;
+                    s_acc[myq] = bI;
+                }
+                nm += __popcll(__ballot(w)) - __popcll(__ballot(w && old >= 0));
+                rem &= ~commit;
+                WAVE_LDS_SYNC();
             }
-            WAVE_LDS_SYNC();
         }
-        auto accept = [&](int i1, int bestIdx, int bestDist, int bestDist2) -> bool {
-            if (!(bestIdx >= 0 && bestDist <= th_low && (float)bestDist < __fmul_rn((float)bestDist2, nnratio))) return false;   // :458-460
-            const int old = s_m21[bestIdx];
-            if (old >= 0) nm--;
-            if (lane == 0) {
-                if (old >= 0) s_m12[old] = -1;
-                s_m12[i1] = bestIdx;
-                s_m21[bestIdx] = i1;
-                s_md[bestIdx] = bestDist;
-                s_acc[i1] = bestIdx;
-            }
-            nm++;
-            WAVE_LDS_SYNC();
-            return true;
-        };
-        // The reference walks the features of frame 1 in index order, and vMatchedDistance makes a feature depend on every earlier
-        // one that was accepted with one of its candidates.  Through r05's first half one wave walked them one at a time: ~100
-        // instructions and three dependent LDS round trips per feature (0.4 us; written without a single branch it took the same
-        // time).  Now a LANE walks its own feature and the wave keeps the order: in one trip every undecided feature of the round
-        // takes best / second as the first two entries of its sorted list that the state BEFORE the trip does not skip, and a
-        // feature that would be accepted stamps its best candidate (trip, lowest such lane: one atomicMax).  vMatchedDistance only
-        // ever decreases, so a feature's decision stands unless an earlier feature of the same trip stamped one of the entries
-        // it looked at: the features before the first such one (the first undecided one never is) are committed together -- their
-        // best candidates are distinct, their displaced owners were accepted before the trip -- and the rest decide again in the
-        // next trip.  Features with a longer list (unsorted, or longer than the table: the rescan) take a trip of their own over the
-        // whole wave, as before.
-        const bool mine = myc > 0 && myc <= limS;
-        uint32_t e[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) e[k] = mine && k < myc ? s_tup[k * 64 + lane] : 0u;
-        unsigned long long rem = todo;
-        while (rem) {
-            const int j = (int)__builtin_ctzll(rem);
-            const int c = __builtin_amdgcn_readlane(myc, j);
-            if (c > limS) {
-                const int i1 = base + j;
-                int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx = -1;
-                if (c <= keff) {
-                    int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
-                    for (int p = lane; p < c; p += 64) {
-                        const uint32_t t = s_tup[p * 64 + j];         // (in visiting order, position = slot)
-                        const int d = (int)(t >> 23), idx = (int)(t & 0xFFFFu);
-                        const int key = s_md[idx] <= d ? 0x7FFFFFFF : (int)(t >> 16);   // :443-444; distance << 7 | position
-                        if (key < m1) {
-                            m2 = m1;
-                            m1 = key;
-                        } else if (key < m2) {
-                            m2 = key;
-                        }
-                    }
-                    const int k1 = wave_min_i(m1);
-                    if (k1 != 0x7FFFFFFF) {
-                        const int k2 = wave_min_i(m1 == k1 ? m2 : m1);   // list positions are unique: one lane holds k1
-                        bestDist = k1 >> 7;
-                        bestIdx = (int)(s_tup[(k1 & 127) * 64 + j] & 0xFFFFu);
-                        if (k2 != 0x7FFFFFFF) bestDist2 = k2 >> 7;
-                    }
-                } else {
-                    // more candidates than the list holds: the reference's scan, identically in every lane
-                    orbhip_proj_query q;
-                    const float2 pm = PM[i1];
-                    q.u = pm.x;
-                    q.v = pm.y;
-                    q.radius = radius;
-                    q.min_level = q.max_level = K1[i1].octave;
-                    const uint4 *qd = reinterpret_cast<const uint4 *>(desc1 + ((size_t)b * cap1 + i1) * 32);
-                    const uint4 a0 = qd[0], a1 = qd[1];
-                    walk_window(gp, q, K2, O, I, [&](int idx, int) {
-                        const int d = hamming256g(a0, a1, D2[2 * idx], D2[2 * idx + 1]);
-                        if (s_md[idx] <= d) return;
-                        if (d < bestDist) {
-                            bestDist2 = bestDist;
-                            bestDist = d;
-                            bestIdx = idx;
-                        } else if (d < bestDist2) {
-                            bestDist2 = d;
-                        }
-                    });
-                }
-                (void)accept(i1, bestIdx, bestDist, bestDist2);
-                rem &= rem - 1ull;
-                continue;
-            }
-            trip++;
-            const bool undecided = (rem >> lane) & 1ull;
-            const bool act = mine && undecided;
-            int found = 0, pend = 0;
-            uint32_t b1 = 0, b2 = 0;
-            {
-                // (no branch around the reads: an absent entry, or a lane without a feature, reads feature 0 and does not use it)
-                int md[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) md[k] = s_md[e[k] & 0xFFFFu];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool there = act && k < myc;
-                    const bool take = there && found < 2 && !(md[k] <= (int)(e[k] >> 23));   // :443-444
-                    pend = there && found < 2 ? k + 1 : pend;
-                    b2 = take && found == 1 ? e[k] : b2;
-                    b1 = take && found == 0 ? e[k] : b1;
-                    found += take ? 1 : 0;
-                }
-                if (__ballot(act && found < 2 && myc > 4))   // (rare: both of the first four skipped)
-                    for (int p = 4; act && p < myc && found < 2; p++) {
-                        const uint32_t t = s_tup[p * 64 + lane];
-                        pend = p + 1;
-                        if (!(s_md[t & 0xFFFFu] <= (int)(t >> 23))) {
-                            if (found == 0) b1 = t;
-                            else b2 = t;
-                            found++;
-                        }
-                    }
-            }
-            const int bD = found >= 1 ? (int)(b1 >> 23) : 0x7FFFFFFF, bI = (int)(b1 & 0xFFFFu);
-            const int bD2 = found >= 2 ? (int)(b2 >> 23) : 0x7FFFFFFF;
-            const bool ok = act && found >= 1 && bD <= th_low && (float)bD < __fmul_rn((float)bD2, nnratio);   // :458-460
-            if (ok) atomicMax(&s_stamp[bI], trip * 64 + 63 - lane);
-            WAVE_LDS_SYNC();
-            bool dirty = undecided && !mine;   // a long list: decided in a trip of its own, when it is the first undecided one
-            int st[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) st[k] = s_stamp[e[k] & 0xFFFFu];
-            const int old = s_m21[bI];
-#pragma unroll
-            for (int k = 0; k < 4; k++) dirty |= (k < pend) & ((st[k] >> 6) == trip) & (63 - (st[k] & 63) < lane);
-            if (__ballot(pend > 4))
-                for (int p = 4; p < pend; p++) {
-                    const int s5 = s_stamp[s_tup[p * 64 + lane] & 0xFFFFu];
-                    dirty |= (s5 >> 6) == trip && 63 - (s5 & 63) < lane;
-                }
-            const unsigned long long dm = __ballot(dirty);
-            const unsigned long long commit = dm ? rem & ((1ull << __builtin_ctzll(dm)) - 1ull) : rem;
-            const bool w = ok && ((commit >> lane) & 1ull);
-            if (w) {
-                if (old >= 0) s_m12[old] = -1;   // the feature's previous owner loses it (:462-466)
-                s_m12[myq] = bI;
-                s_m21[bI] = myq;
-                s_md[bI] = bD;
-                s_acc[myq] = bI;
-            }
-            nm += __popcll(__ballot(w)) - __popcll(__ballot(w && old >= 0));
-            rem &= ~commit;
-            WAVE_LDS_SYNC();
+        __syncthreads();
+        if (!dbl) {
+            load_round(base + 64, s_tup, rowsNext, tid, INIT_NT);
+            __syncthreads();
         }
+        rows = rowsNext;
     }
-    WAVE_LDS_SYNC();
     ORB_ABL_IF(stop == 2) return;
     if (check_ori) {
-        for (int i1 = lane; i1 < n1; i1 += 64) {
+        for (int i1 = tid; i1 < n1; i1 += INIT_NT) {
             const int f = s_acc[i1];
             if (f < 0) continue;
-            float rot = stage ? __fsub_rn(s_a1[i1], s_k2[3 * f + 2]) : __fsub_rn(K1[i1].angle, K2[f].angle);
+            float rot = staged ? __fsub_rn(s_a1[i1], s_k2[3 * f + 2]) : __fsub_rn(K1[i1].angle, K2[f].angle);
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
             int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
             if (bin == 30) bin = 0;
             if (bin >= 0 && bin < 30) atomicAdd(&s_hist[bin], 1);
         }
-        WAVE_LDS_SYNC();
-        if (lane == 0) {
+        __syncthreads();
+        if (tid == 0) {
             int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
             for (int i = 0; i < 30; i++) {
                 const int s = s_hist[i];
@@ -1372,12 +1375,12 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
             s_keep[1] = i2;
             s_keep[2] = i3;
         }
-        WAVE_LDS_SYNC();
+        __syncthreads();
         int removed = 0;
-        for (int i1 = lane; i1 < n1; i1 += 64) {
+        for (int i1 = tid; i1 < n1; i1 += INIT_NT) {
             const int f = s_acc[i1];
             if (f < 0) continue;
-            float rot = stage ? __fsub_rn(s_a1[i1], s_k2[3 * f + 2]) : __fsub_rn(K1[i1].angle, K2[f].angle);
+            float rot = staged ? __fsub_rn(s_a1[i1], s_k2[3 * f + 2]) : __fsub_rn(K1[i1].angle, K2[f].angle);
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
             int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
             if (bin == 30) bin = 0;
@@ -1386,16 +1389,16 @@ __global__ __launch_bounds__(64) void k_init_assign(const orbhip_keypoint *__res
                 removed++;
             }
         }
-        nm -= wave_sum_g(removed);
-        WAVE_LDS_SYNC();
+        if (removed) atomicAdd(&s_rm, removed);
+        __syncthreads();
     }
-    for (int i1 = lane; i1 < cap1; i1 += 64) {
+    for (int i1 = tid; i1 < cap1; i1 += INIT_NT) {
         const int m = i1 < n1 ? s_m12[i1] : -1;
         matches12[(size_t)b * cap1 + i1] = m;
-        if (m >= 0) PM[i1] = stage ? make_float2(s_k2[3 * m], s_k2[3 * m + 1]) : make_float2(K2[m].x, K2[m].y);   // :512-515
+        if (m >= 0) PM[i1] = staged ? make_float2(s_k2[3 * m], s_k2[3 * m + 1]) : make_float2(K2[m].x, K2[m].y);   // :512-515
     }
-    ORB_ABL_IF(stop == 4) nm = trip;   // (ablation only: the walk's trips instead of the match count)
-    if (lane == 0) nmatches[b] = nm;
+    ORB_ABL_IF(stop == 4) nm = trip + s_rm;   // (ablation only: the walk's trips instead of the match count)
+    if (tid == 0) nmatches[b] = nm - s_rm;
 }
 
 static int init_keff()
@@ -1439,13 +1442,18 @@ int launch_search_for_initialization(hipStream_t s, const orbhip_keypoint *kps1,
     hipLaunchKernelGGL(k_proj_records, dim3((cap2 + 255) / 256, B, 1), dim3(256, 1, 1), 0, s, kps2, cap2, cellOff2, cellIdx2, rec);
     hipLaunchKernelGGL(k_init_cands, dim3(cap1pad / 4, B, 1), dim3(256, 1, 1), 0, s, kps1, desc1, cnt1, cap1, (const float2 *)prev,
                        radius, gp, cellOff2, rec, desc2, cap2, cap1pad, keff, tuples, tcount);
-    int stage = init_assign_lds_staged(cap1, cap2) <= 112 * 1024 ? 1 : 0;   // (+ 32 KB of static LDS for the lists)
-    stage |= ORB_TUNE("INIT_STOP", 0) << 4;
-    const size_t lds = stage ? init_assign_lds_staged(cap1, cap2) : init_assign_lds(cap1, cap2);
+    // LDS: one buffer for a round's lists (32 KB) + the match tables are required (the API checks); the staged tables and a second
+    // list buffer when they fit as well
+    const size_t kLds = 144 * 1024, round = (size_t)INIT_ROUND * 4;
+    int mode = round + init_assign_lds_staged(cap1, cap2) <= kLds ? 1 : 0;
+    const size_t tables = mode ? init_assign_lds_staged(cap1, cap2) : init_assign_lds(cap1, cap2);
+    if (2 * round + tables <= kLds) mode |= 2;
+    mode |= ORB_TUNE("INIT_STOP", 0) << 4;
+    const size_t lds = ((mode & 2) ? 2 : 1) * round + tables;
     if (lds > 16 * 1024) (void)hipFuncSetAttribute((const void *)k_init_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_init_assign, dim3(B, 1, 1), dim3(64, 1, 1), lds, s, kps1, desc1, cnt1, cap1, kps2,
+    hipLaunchKernelGGL(k_init_assign, dim3(B, 1, 1), dim3(INIT_NT, 1, 1), lds, s, kps1, desc1, cnt1, cap1, kps2,
                        desc2, cnt2, cap2, (float2 *)prev, radius, gp, cellOff2, cellIdx2, cap1pad, keff, tuples, tcount, nnratio,
-                       check_ori, th_low, matches12, nmatches, stage);
+                       check_ori, th_low, matches12, nmatches, mode);
     return ORBHIP_OK;
 }
 
