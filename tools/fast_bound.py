@@ -159,6 +159,12 @@ def analyse(frames, want_lds=True):
                     T["surv_hist"].append(n / float(DH * TW))
                     T["both"] += int(both[y0:y1, x0:x1].sum())
                     T["overflow"] += n > 2176
+                    if n > 2176:
+                        # the same run in two rounds (lower / upper half of the row segments, k_fast_fix r05): survivors of each half,
+                        # corners of the run (corner list: 640)
+                        half_rows = ((((DH + seg - 1) // seg) + 1) >> 1) * seg
+                        lo = int(cm[:half_rows].sum())
+                        T.setdefault("over_runs", []).append((n, lo, n - lo, int(((sc[y0:y1, x0:x1] >= INI) & cm).sum())))
                     # the divergent append: per wave of 64 threads (tid = sidx * GPR + slot) the largest survivor count of a lane
                     jd0 = j0 & ~3
                     grp = (np.arange(TW) + j0 - jd0) >> 2                       # dword group of a domain column
@@ -273,6 +279,10 @@ def main():
                   "| compass survivors at %d | %.0f = %.1f %% of the pixels (median run %.1f %%, 90th percentile %.1f %%); both polarities %.1f %% of them |"
                   % (INI, per("surv"), 100.0 * T["surv"] / T["px"], 100 * np.median(sh), 100 * np.percentile(sh, 90), 100.0 * T["both"] / max(T["surv"], 1)),
                   "| runs over the 2176-entry list | %.1f %% |" % (100.0 * T["overflow"] / T["runs"]),
+                  "| ... of these: survivors <= 7/4 of the list / both halves fit a list / survivors (median, max) / corners (median) | %s |" % (
+                      (lambda o: "%d of %d / %d / %d, %d / %d" % (sum(x[0] <= 3808 for x in o), len(o), sum(x[0] <= 3808 and x[1] <= 2176 and x[2] <= 2176 for x in o),
+                                                               sorted(x[0] for x in o)[len(o) // 2], max(x[0] for x in o), sorted(x[3] for x in o)[len(o) // 2]))(T["over_runs"])
+                      if T.get("over_runs") else "-"),
                   "| corners (score >= %d) / after suppression | %.0f (%.1f %% of the survivors) / %.0f |" % (INI, per("corners"), 100.0 * T["corners"] / max(T["surv"], 1), per("nms")),
                   "| cells without a survivor | %.0f = %.1f %% (pixels %.0f = %.1f %%) |" % (per("empty"), 100.0 * T["empty"] / T["cells"], per("px2"), 100.0 * T["px2"] / T["px"]),
                   "| second pass at %d: items / survivors / corners / after suppression | %.0f / %.0f (%.1f %% of its pixels) / %.0f / %.0f |"

@@ -48,6 +48,7 @@ int orb_configure(orbhip_ctx *c, int w, int h, int stride0, int B)
         // resize tables
         std::vector<int32_t> all;
         bool chainOk[ORBHIP_MAX_LEVELS] = {};
+        c->fuseBlurOk = c->nlevels > 1;
         for (int l = 1; l < c->nlevels; l++) {
             std::vector<int32_t> xt, yt;
             orb_build_resize_tables(c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, xt, yt);
@@ -61,6 +62,8 @@ int orb_configure(orbhip_ctx *c, int w, int h, int stride0, int B)
             c->resizeGroups[l] = orb_build_resize_groups(xt, yt, c->G.lv[l].w, gt);
             c->resizeHint[l][0] = resize_hint_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, 32);
             c->resizeHint[l][1] = resize_hint_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, 8);
+            c->fuseBlurOk = c->fuseBlurOk && c->resizeGroups[l] &&
+                            resize_blur_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h);
             while (all.size() % 4) all.push_back(0);
             c->resizeTabOff[l][2] = all.size();
             if (c->resizeGroups[l]) all.insert(all.end(), gt.begin(), gt.end());
@@ -287,11 +290,20 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
             launch_pyramid_chain(s, G, c->chainLevels, grp, c->d_chainTiles, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes,
                                  c->d_resizeTab, B, h_pyr_dst);   // (the host copy of the pyramid is written by the kernel itself)
     // batches: level l from level l-1 (sequential dependency), all frames per launch
+    // ORBHIP_FUSE_BLUR=1 (r05 experiment): levels 1.. and their blurred twins from one kernel per level; k_blur keeps level 0
+    static const bool fuseSwitch = ORB_TUNE("FUSE_BLUR", 0) != 0;   // (liborbhip_ablation.so only: measured slower)
+    const bool fuseBlur = fuseSwitch && B >= 8 && !chained && c->fuseBlurOk;
     for (int l = 1; l < G.nlevels && !chained; l++) {
         const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
         const uint8_t *src = (l == 1) ? lvl0 : c->d_pyr + S.imgOff;
         const int sstride = (l == 1) ? stride0 : S.stride;
         const size_t sframe = (l == 1) ? frame0 : c->pyrFrameBytes;
+        if (fuseBlur) {
+            launch_resize_blur(s, src, S.w, S.h, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride, c->pyrFrameBytes,
+                               c->d_blur + G.boff1 + D.imgOff, D.stride, c->lvl0FrameBytes + c->pyrFrameBytes,
+                               c->d_resizeTab + c->resizeTabOff[l][1], c->d_resizeTab + c->resizeTabOff[l][2], c->d_blurBands, B);
+            continue;
+        }
         launch_resize(s, src, S.w, S.h, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride,
                       c->pyrFrameBytes, c->d_resizeTab + c->resizeTabOff[l][0],
                       c->d_resizeTab + c->resizeTabOff[l][1],
@@ -322,7 +334,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     const size_t blurFrame = c->lvl0FrameBytes + c->pyrFrameBytes;
     auto blur_all = [&](hipStream_t st) {
         launch_blur(st, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur, blurFrame, c->d_blurTiles,
-                    (int)c->blurTiles.size(), c->d_blurBands, B);
+                    fuseBlur ? c->blurLevelFirst[1] : (int)c->blurTiles.size(), c->d_blurBands, B);
     };
     // quadtree / describe of the frames [b0, b0 + nb)
     const size_t qtPerFrame = B > 0 ? quadtree_table_scratch_bytes(G, 1) : 0;

@@ -38,6 +38,7 @@
 // workgroup (load latency + matrix chain + store) at four workgroups per CU.
 #include "orbhip_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -315,6 +316,266 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevels G, const uint8_t *
     BM_RAW_BARRIER();
     store(g1);
 #undef S_RAW
+}
+
+// =====================================================================================================================
+// r05 review item 5: the blurred twin of a level from the kernel that BUILDS the level.  One workgroup per 128 x 58 tile of
+// level l (the blur's tile): the source window of level l - 1 travels to LDS (as in k_resize), the 64 x 136 pixels of level l
+// that the tile's blur reads (3 halo rows above and below, a 4-pixel group left and right) are interpolated from it into the raw
+// image k_blur stages -- k_resize's arithmetic, item by item -- the tile's own 128 x 58 of them are stored as level l, and the
+// row / column passes of k_blur run on the raw image.  Level l is then written once and read only by the next level's
+// launch, FAST and the orientation; its blur costs no read at all.  One launch per level (the chain of k_resize); level 0 keeps
+// k_blur.  ORBHIP_FUSE_BLUR=1 (experiment: see DESIGN section 7 for the measurement).
+// =====================================================================================================================
+#define RB_SROWS 82                // staged source rows (64 output rows x 1.2 + margin: 81 at level 4 of 640 x 480)
+#define RB_SPITCH (13 * 16)        // 13 chunks: 136 output columns x 1.2 + margin + alignment
+#define RB_NG 34                   // output column groups of 4 pixels: 4 halo + 128 + 4 halo
+typedef unsigned short rb_us2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_resize_blur(const uint8_t *__restrict__ src, int sstride, unsigned long long sframe, int sw,
+                                                     int sh, uint8_t *__restrict__ dst, int dw, int dh, int dstride,
+                                                     unsigned long long dframe, uint8_t *__restrict__ bdst, int bstride,
+                                                     unsigned long long bframe, const int4 *__restrict__ ytab,
+                                                     const int4 *__restrict__ gtab, float winx, float winy,
+                                                     const uint4 *__restrict__ bands, int xcdMap, int ntiles)
+{
+    // [raw image of the blur 64 x 208][source window 81 x 208, later the blur's output image 64 x 144][row taps 64][group taps 34 x 3]
+    __shared__ __align__(16) uint8_t smem[BM_IN * BM_PITCH + (RB_SROWS + 1) * RB_SPITCH + 64 * 16 + RB_NG * 3 * 16];
+    uint8_t *const raw = smem;
+    uint8_t *const s_src = smem + BM_IN * BM_PITCH;
+    uint8_t *const s_out0 = s_src;
+    const int4 *const s_ytab = reinterpret_cast<const int4 *>(smem + BM_IN * BM_PITCH + (RB_SROWS + 1) * RB_SPITCH);
+    const int4 *const s_gtab = s_ytab + 64;
+    const int t = xcd_tile(xcdMap), frame = blockIdx.y;
+    if (t >= ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesX = (dw + BM_W - 1) / BM_W;
+    const int ty = t / tilesX, tx = t - ty * tilesX;
+    const int x0 = tx * BM_W, y0 = ty * BM_H;
+    const uint8_t *S = src + (size_t)frame * sframe;
+    uint8_t *D = dst + (size_t)frame * dframe;
+
+    uint4 bq[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) bq[q] = bands[q * 64 + lane];
+    asm volatile("" ::: "memory");
+
+    // the pixels of level l to interpolate: rows [ryA, ryB], column groups from gxA on (inside the image)
+    const int ryA = max(y0 - 3, 0), ryB = min(y0 + BM_IN - 4, dh - 1);
+    const int gxA = max(x0 - 4, 0), gxB = min(x0 + BM_W + 4, (dw + 3) & ~3);
+    const int ngrp = (gxB - gxA) >> 2, nrowsOut = ryB - ryA + 1;
+    // their source window (k_resize's window hint; launch_resize_blur checks it against the tap tables)
+    const int sxmin = max((int)((float)gxA * winx) - 1, 0), sxmax = min((int)((float)min(gxB, dw) * winx) + 1, sw - 1);
+    const int symin = max((int)((float)ryA * winy) - 1, 0), symax = min((int)((float)(ryB + 1) * winy) + 1, sh - 1);
+    const int XA = sxmin & ~15;
+    const int nch = ((sxmax - XA) >> 4) + 1, nrows = symax - symin + 1;
+    {
+        // LDS-DMA, four whole rows of 13 chunks per wave transfer (blur_dma)
+        const int rl = (lane * 5) >> 6, ch = lane - 13 * rl;
+        const uint8_t *sp = S + (size_t)(symin + rl) * sstride + XA + (ch << 4);
+        const uint32_t ldsBase = (uint32_t)(uintptr_t)s_src;
+        for (int rb = wv * 4; rb < nrows; rb += 16)
+            if (lane < 52 && ch < nch && rb + rl < nrows)
+                glds16(sp + (size_t)rb * sstride, __builtin_amdgcn_readfirstlane(ldsBase + (uint32_t)(rb * RB_SPITCH)));
+        if (wv == 1) {
+            glds16(ytab + min(ryA + lane, dh - 1), (uint32_t)(uintptr_t)s_ytab);
+        } else if (wv >= 2) {
+            const int q = 64 * (wv - 2) + lane, grp = q / 3, part = q - 3 * grp;
+            if (q < RB_NG * 3) glds16(gtab + 3 * (min(gxA + 4 * grp, dw - 1) >> 2) + part, (uint32_t)(uintptr_t)(s_gtab + 64 * (wv - 2)));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BM_RAW_BARRIER();
+
+#define S_RAW(r, c) raw[(r) * BM_PITCH + (c)]
+    // ---- level l: k_resize's grouped path, item = (row, group of 4 columns) ----
+    for (int i = tid; i < 64 * RB_NG; i += 256) {
+        const int row = (int)(((unsigned)i * 1928u) >> 16), g = i - row * RB_NG;   // i / 34 for i < 2176
+        if (row >= nrowsOut || g >= ngrp) continue;
+        const int y = ryA + row, gx = gxA + 4 * g;
+        const int4 yt = s_ytab[row];
+        const int4 g0 = s_gtab[3 * g], gsel = s_gtab[3 * g + 1], gw = s_gtab[3 * g + 2];
+        const int bcol = g0.x - XA, wb = bcol & ~3, shf = bcol & 3;
+        const uint32_t sel[4] = {(uint32_t)gsel.x, (uint32_t)gsel.y, (uint32_t)gsel.z, (uint32_t)gsel.w};
+        const uint32_t wt[4] = {(uint32_t)gw.x, (uint32_t)gw.y, (uint32_t)gw.z, (uint32_t)gw.w};
+        const uint32_t b0s = ((uint32_t)yt.z & 0xFFFu) << 12, b1s = ((uint32_t)yt.w & 0xFFFu) << 12;
+        const uint32_t *q0 = reinterpret_cast<const uint32_t *>(s_src + (yt.x - symin) * RB_SPITCH + wb);
+        const uint32_t *q1 = reinterpret_cast<const uint32_t *>(s_src + (yt.y - symin) * RB_SPITCH + wb);
+        const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], c0 = q1[0], c1 = q1[1], c2 = q1[2];
+        const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, shf), hi0 = __builtin_amdgcn_alignbyte(a2, a1, shf);
+        const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, shf), hi1 = __builtin_amdgcn_alignbyte(c2, c1, shf);
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const rb_us2 p0 = __builtin_bit_cast(rb_us2, __builtin_amdgcn_perm(hi0, lo0, sel[k]));
+            const rb_us2 p1 = __builtin_bit_cast(rb_us2, __builtin_amdgcn_perm(hi1, lo1, sel[k]));
+            const rb_us2 w2 = __builtin_bit_cast(rb_us2, wt[k]);
+            const uint32_t r0 = __builtin_amdgcn_udot2(p0, w2, 0u, false);
+            const uint32_t r1 = __builtin_amdgcn_udot2(p1, w2, 0u, false);
+            v[k] = (__umulhi(b0s, r0 & 0x7FFFF0u) + __umulhi(b1s, r1 & 0x7FFFF0u) + 2u) >> 2;   // <= 255
+        }
+        const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        *reinterpret_cast<uint32_t *>(&S_RAW(y - (y0 - 3), 16 + gx - x0)) = packed;
+        if (y >= y0 && y < y0 + BM_H && gx >= x0 && gx < x0 + BM_W) {   // the tile's own pixels: level l
+            uint8_t *o = D + (size_t)y * dstride + gx;
+            if (gx + 3 < dw) {
+                *reinterpret_cast<uint32_t *>(o) = packed;
+            } else {
+                for (int k = 0; k < 4 && gx + k < dw; k++) o[k] = (uint8_t)(packed >> (8 * k));
+            }
+        }
+    }
+    BM_RAW_BARRIER();
+    // reflected rows above the image (y = -1, -2, -3 <- 1, 2, 3) and below it (y = h + k <- h - 2 - k): block-uniform
+    if (y0 == 0 || y0 + BM_IN - 4 >= dh) {
+        if (y0 == 0)
+            for (int i = tid; i < 3 * BM_CW; i += 256) {
+                const int r = i / BM_CW, c = i - r * BM_CW;
+                reinterpret_cast<uint4 *>(raw + r * BM_PITCH)[c] = reinterpret_cast<const uint4 *>(raw + (6 - r) * BM_PITCH)[c];
+            }
+        if (y0 + BM_IN - 4 >= dh)
+            for (int i = tid; i < 3 * BM_CW; i += 256) {
+                const int k = i / BM_CW, c = i - k * BM_CW;
+                const int r = dh + k - (y0 - 3), rs = dh - 2 - k - (y0 - 3);
+                if (r < BM_IN && rs >= 0) reinterpret_cast<uint4 *>(raw + r * BM_PITCH)[c] = reinterpret_cast<const uint4 *>(raw + rs * BM_PITCH)[c];
+            }
+        BM_RAW_BARRIER();
+    }
+    {
+        // reflected halo columns at the image edges (k_blur's edge_patch)
+        const bool edgeL = x0 == 0, edgeR = x0 + BM_W + 3 > dw;
+        if (edgeL || edgeR) {
+            if (edgeL)
+                for (int i = tid; i < BM_IN * 3; i += 256) {
+                    const int r = i / 3, k = i - r * 3 + 1;
+                    S_RAW(r, 16 - k) = S_RAW(r, 16 + k);
+                }
+            if (edgeR)
+                for (int i = tid; i < BM_IN * 3; i += 256) {
+                    const int r = i / 3, k = i - r * 3;
+                    S_RAW(r, 16 + (dw + k - x0)) = S_RAW(r, 16 + (dw - 2 - k - x0));
+                }
+            BM_RAW_BARRIER();
+        }
+    }
+    // ---- k_blur's row and column pass on the raw image (stages 2 and 3 of k_blur, same operands) ----
+    {
+        const int w = dw;
+        const int c0 = x0 + 32 * wv;
+        if (c0 < w) {
+            v16i hinit;
+            v16f zinit;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                hinit[i] = 128 * 257 + 0x04000000;
+                zinit[i] = -(float)(257 * 1024) / 65536.0f;
+            }
+            v16i H[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+                uint4 a0 = *reinterpret_cast<const uint4 *>(&S_RAW(32 * tt + n, 32 * wv + 16 * hh));
+                uint4 a1 = *reinterpret_cast<const uint4 *>(&S_RAW(32 * tt + n, 32 * wv + 32 + 16 * hh));
+                a0.x ^= 0x80808080u; a0.y ^= 0x80808080u; a0.z ^= 0x80808080u; a0.w ^= 0x80808080u;
+                a1.x ^= 0x80808080u; a1.y ^= 0x80808080u; a1.z ^= 0x80808080u; a1.w ^= 0x80808080u;
+                H[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a0), __builtin_bit_cast(v4i, bq[0]), hinit, 0, 0, 0);
+                H[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, a1), __builtin_bit_cast(v4i, bq[1]), H[tt], 0, 0, 0);
+            }
+            uint4 lo[2][2], hi[2][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    uint32_t pl[4], ph[4];
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t a = (uint32_t)H[tt][8 * s2 + 2 * d], b = (uint32_t)H[tt][8 * s2 + 2 * d + 1];
+                        pl[d] = __builtin_amdgcn_perm(b, a, 0x07040300u);
+                        ph[d] = __builtin_amdgcn_perm(b, a, 0x07050301u);
+                    }
+                    lo[tt][s2] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                    hi[tt][s2] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                }
+            const int wvec = w - (w & 3);
+            const bool tail = wvec < w && c0 <= wvec && wvec < c0 + 32;
+            const int gT = (wvec - c0) >> 3, hT = ((wvec - c0) >> 2) & 1;
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+                v16f zl = zinit, zh = zinit;
+#pragma unroll
+                for (int q = 0; q < (tt == 0 ? 4 : 2); q++) {
+                    const int rt = tt == 0 ? (q >> 1) : 1, s2 = q & 1;
+                    const v8h bw = __builtin_bit_cast(v8h, bq[2 + q]);
+                    zl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, lo[rt][s2]), bw, zl, 0, 0, 0);
+                    zh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, hi[rt][s2]), bw, zh, 0, 0, 0);
+                }
+#pragma unroll
+                for (int gg = 0; gg < 4; gg++) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        packed = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]), e, packed);
+                    // (the output image lies over the source window, which no wave reads after the barrier behind the interpolation)
+                    *reinterpret_cast<uint32_t *>(&s_out0[(32 * tt + n) * BM_OP + 32 * wv + 8 * gg + 4 * hh]) = packed;
+                }
+                if (tail) {
+#pragma unroll
+                    for (int gg = 0; gg < 4; gg++)
+                        if (gg == gT) {
+                            asm volatile("" ::: "memory");
+                            uint32_t packed = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                packed = __builtin_amdgcn_cvt_pk_u8_f32(floorf(fmaf(zh[4 * gg + e], 256.0f, zl[4 * gg + e]) + 0.5f), e, packed);
+                            if (hh == hT) *reinterpret_cast<uint32_t *>(&s_out0[(32 * tt + n) * BM_OP + 32 * wv + 8 * gg + 4 * hh]) = packed;
+                        }
+                }
+            }
+        }
+    }
+    BM_RAW_BARRIER();
+    {
+        uint8_t *BD = bdst + (size_t)frame * bframe;
+        for (int i = tid; i < BM_H * (BM_W / 16); i += 256) {
+            const int r = i >> 3, c = i & 7;
+            const int y = y0 + r, x = x0 + (c << 4);
+            if (y < dh && x < dw)
+                *reinterpret_cast<uint4 *>(BD + (size_t)y * bstride + x) = *reinterpret_cast<const uint4 *>(&s_out0[r * BM_OP + (c << 4)]);
+        }
+    }
+#undef S_RAW
+}
+
+// Does every tile's computed source window hold the taps of the pixels it interpolates, and fit the staging area?
+bool resize_blur_fits(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh)
+{
+    const float winx = (float)sw / (float)dw, winy = (float)sh / (float)dh;
+    for (int x0 = 0; x0 < dw; x0 += BM_W) {
+        const int gxA = std::max(x0 - 4, 0), gxB = std::min(x0 + BM_W + 4, (dw + 3) & ~3);
+        const int c1 = std::min(gxB, dw) - 1;
+        const int lo = std::max((int)((float)gxA * winx) - 1, 0), hi = std::min((int)((float)std::min(gxB, dw) * winx) + 1, sw - 1);
+        if (lo > (xt[2 * gxA] & 0xFFFF) || hi < (int)((uint32_t)xt[2 * c1] >> 16)) return false;
+        if (((hi - (lo & ~15)) >> 4) + 1 > 13) return false;
+        for (int y0 = 0; y0 < dh; y0 += BM_H) {
+            const int ryA = std::max(y0 - 3, 0), ryB = std::min(y0 + BM_IN - 4, dh - 1);
+            const int rlo = std::max((int)((float)ryA * winy) - 1, 0), rhi = std::min((int)((float)(ryB + 1) * winy) + 1, sh - 1);
+            if (rlo > yt[4 * ryA] || rhi < yt[4 * ryB + 1]) return false;
+            if (rhi - rlo + 1 > RB_SROWS) return false;
+        }
+    }
+    return true;
+}
+
+void launch_resize_blur(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw, int dh,
+                        int dstride, size_t dframe, uint8_t *bdst, int bstride, size_t bframe, const int32_t *ytab, const int32_t *gtab,
+                        const uint32_t *bands, int B)
+{
+    const int ntiles = ((dw + BM_W - 1) / BM_W) * ((dh + BM_H - 1) / BM_H);
+    dim3 grid(orb_xcd_grid(ntiles, 1), B, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(k_resize_blur, grid, block, 0, s, src, sstride, (unsigned long long)sframe, sw, sh, dst, dw, dh, dstride,
+                       (unsigned long long)dframe, bdst, bstride, (unsigned long long)bframe, reinterpret_cast<const int4 *>(ytab),
+                       reinterpret_cast<const int4 *>(gtab), (float)sw / (float)dw, (float)sh / (float)dh,
+                       reinterpret_cast<const uint4 *>(bands), orb_xcd_arg(1), ntiles);
 }
 
 // cv::getGaussianKernel(7, 2, CV_32F) converted to CV_32S with scale 256 (filter.cpp

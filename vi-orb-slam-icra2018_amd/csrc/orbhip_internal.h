@@ -208,6 +208,7 @@ struct orbhip_ctx {
     int nFastTilesBatch = 0;
     int nFastTilesTall = 0;                       // ... of which the last nFastTilesTall belong to levels with cells taller than 34 rows
     std::vector<BlurTile> blurTiles;              // level by level
+    bool fuseBlurOk = false;                      // every level's k_resize_blur window fits (ORBHIP_FUSE_BLUR)
     int blurLevelFirst[ORBHIP_MAX_LEVELS + 1] = {};   // first tile of every level (and the end)
     std::vector<ChainTile> chainTiles;            // chained pyramid of the single-frame path (empty = not available)
     std::vector<ChainGroup> chainGroups;
@@ -342,6 +343,10 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
                      uint32_t *pts, uint32_t *pnode, int32_t *lvlCandCnt, uint32_t *lvlKp,
                      int32_t *lvlKpCnt, int B, uint8_t *tableScratch);
 size_t quadtree_table_scratch_bytes(const OrbLevels &G, int B);   // 0 when the node tables fit in LDS
+bool resize_blur_fits(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh);
+void launch_resize_blur(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw, int dh,
+                        int dstride, size_t dframe, uint8_t *bdst, int bstride, size_t bframe, const int32_t *ytab, const int32_t *gtab,
+                        const uint32_t *bands, int B);
 void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                  const uint8_t *pyr, size_t pyrFrame, uint8_t *blur, size_t blurFrame,
                  const BlurTile *tiles, int ntiles, const uint32_t *bands, int B);
