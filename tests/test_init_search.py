@@ -140,7 +140,7 @@ def _check_gpu(oracle, ex, k1, d1, k2, d2, gp, prev, window, nnratio, check_ori,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nf,window,check_ori", [(2000, 100, True), (2000, 100, False), (1000, 10, True), (4000, 60, True)])
+@pytest.mark.parametrize("nf,window,check_ori", [(2000, 100, True), (2000, 100, False), (1000, 10, True), (4000, 60, True), (5000, 60, True)])   # (4000: tables not staged; 5000: one list buffer)
 def test_hip_search_for_initialization_matches_oracle(oracle, nf, window, check_ori):
     from orbhip import guided
     from orbhip.extractor import ORBextractor

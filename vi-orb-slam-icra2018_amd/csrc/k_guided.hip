@@ -1176,10 +1176,16 @@ __global__ __launch_bounds__(INIT_NT) void k_init_assign(const orbhip_keypoint *
     ORB_ABL_IF(stop == 3) n1 = min(n1, 64); // one round of the feature loop
     int nm = 0, trip = 0;
     const int limS = min(64, keff);   // lists of up to limS candidates arrive sorted by (distance, position)
+    // the last feature with a candidate (every wave computes it): only level-0 features have any, and the extractor puts them
+    // first -- three quarters of the rounds would be a barrier and nothing else
+    int lastq = -1;
+    for (int i = lane; i < n1; i += 64) lastq = (staged ? s_tc[i] : TC[i]) > 0 ? i : lastq;
+    lastq = -wave_min_i(-lastq);
+    const int nWalk = min(n1, lastq + 1);
     int rows = rows0;
-    for (int base = 0, r = 0; base < n1; base += 64, r++) {
+    for (int base = 0, r = 0; base < nWalk; base += 64, r++) {
         const uint32_t *tupb = s_tup + (dbl ? (r & 1) * INIT_ROUND : 0);
-        const int rowsNext = base + 64 < n1 ? round_rows(base + 64) : 0;
+        const int rowsNext = base + 64 < nWalk ? round_rows(base + 64) : 0;
         if (wv != 0) {
             if (dbl) load_round(base + 64, s_tup + ((r + 1) & 1) * INIT_ROUND, rowsNext, tid - 64, INIT_NT - 64);
         } else if (rows > 0) {
@@ -1205,7 +1211,8 @@ __global__ __launch_bounds__(INIT_NT) void k_init_assign(const orbhip_keypoint *
             // one that was accepted with one of its candidates.  Through r05's first half one wave walked them one at a time: ~100
             // instructions and three dependent LDS round trips per feature (0.4 us; written without a single branch it took the same
             // time).  Now a LANE walks its own feature and the wave keeps the order: in one trip every undecided feature of the round
-            // takes best / second as the first two entries of its sorted list that the state BEFORE the trip does not skip, and a
+            // takes best / second as the first two entries of its sorted list that the state BEFORE the trip does not skip (held from
+            // trip to trip, below), and a
             // feature that would be accepted stamps its best candidate (trip, lowest such lane: one atomicMax).  vMatchedDistance only
             // ever decreases, so a feature's decision stands unless an earlier feature of the same trip stamped one of the entries
             // it looked at: the features before the first such one (the first undecided one never is) are committed together -- their
@@ -1213,9 +1220,11 @@ __global__ __launch_bounds__(INIT_NT) void k_init_assign(const orbhip_keypoint *
             // next trip.  Features with a longer list (unsorted, or longer than the table: the rescan) take a trip of their own over the
             // whole wave, as before.
             const bool mine = myc > 0 && myc <= limS;
-            uint32_t e[4];
-    #pragma unroll
-            for (int k = 0; k < 4; k++) e[k] = mine && k < myc ? tupb[k * 64 + lane] : 0u;
+            // what a lane knows of its list: the first two entries not skipped so far (h1, h2; held = how many), and where its scan
+            // stands (next).  An entry once skipped stays skipped -- vMatchedDistance only decreases -- so a trip only looks at
+            // h1 and h2 again and scans on from `next` when one of them has gone: every entry is read once per round, not once per trip
+            uint32_t h1 = 0, h2 = 0;
+            int held = 0, next = 0;
             unsigned long long rem = todo;
             while (rem) {
                 const int j = (int)__builtin_ctzll(rem);
@@ -1272,50 +1281,44 @@ __global__ __launch_bounds__(INIT_NT) void k_init_assign(const orbhip_keypoint *
                 trip++;
                 const bool undecided = (rem >> lane) & 1ull;
                 const bool act = mine && undecided;
-                int found = 0, pend = 0;
-                uint32_t b1 = 0, b2 = 0;
                 {
-                    // (no branch around the reads: an absent entry, or a lane without a feature, reads feature 0 and does not use it)
-                    int md[4];
+                    // (no branch around the reads: a lane without an entry reads feature 0 and does not use it)
+                    const int m1 = s_md[h1 & 0xFFFFu], m2 = s_md[h2 & 0xFFFFu];
+                    const bool k1 = held >= 1 && !(m1 <= (int)(h1 >> 23)), k2 = held >= 2 && !(m2 <= (int)(h2 >> 23));   // :443-444
+                    h1 = k1 ? h1 : h2;
+                    held = (k1 ? 1 : 0) + (k2 ? 1 : 0);
+                    // scan on, four entries at a time (their reads in flight together); a lane stops behind its second entry
+                    while (__ballot(act && held < 2 && next < myc)) {
+                        uint32_t t4[4];
+                        int md[4];
     #pragma unroll
-                    for (int k = 0; k < 4; k++) md[k] = s_md[e[k] & 0xFFFFu];
+                        for (int k = 0; k < 4; k++) t4[k] = next + k < myc ? tupb[(next + k) * 64 + lane] : 0u;
     #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool there = act && k < myc;
-                        const bool take = there && found < 2 && !(md[k] <= (int)(e[k] >> 23));   // :443-444
-                        pend = there && found < 2 ? k + 1 : pend;
-                        b2 = take && found == 1 ? e[k] : b2;
-                        b1 = take && found == 0 ? e[k] : b1;
-                        found += take ? 1 : 0;
-                    }
-                    if (__ballot(act && found < 2 && myc > 4))   // (rare: both of the first four skipped)
-                        for (int p = 4; act && p < myc && found < 2; p++) {
-                            const uint32_t t = tupb[p * 64 + lane];
-                            pend = p + 1;
-                            if (!(s_md[t & 0xFFFFu] <= (int)(t >> 23))) {
-                                if (found == 0) b1 = t;
-                                else b2 = t;
-                                found++;
-                            }
+                        for (int k = 0; k < 4; k++) md[k] = s_md[t4[k] & 0xFFFFu];
+                        const int from = next;
+    #pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool there = act && held < 2 && from + k < myc;
+                            const bool take = there && !(md[k] <= (int)(t4[k] >> 23));
+                            next = there ? from + k + 1 : next;
+                            h2 = take && held == 1 ? t4[k] : h2;
+                            h1 = take && held == 0 ? t4[k] : h1;
+                            held += take ? 1 : 0;
                         }
+                    }
                 }
-                const int bD = found >= 1 ? (int)(b1 >> 23) : 0x7FFFFFFF, bI = (int)(b1 & 0xFFFFu);
-                const int bD2 = found >= 2 ? (int)(b2 >> 23) : 0x7FFFFFFF;
-                const bool ok = act && found >= 1 && bD <= th_low && (float)bD < __fmul_rn((float)bD2, nnratio);   // :458-460
+                const int bD = held >= 1 ? (int)(h1 >> 23) : 0x7FFFFFFF, bI = (int)(h1 & 0xFFFFu);
+                const int bD2 = held >= 2 ? (int)(h2 >> 23) : 0x7FFFFFFF;
+                const bool ok = act && held >= 1 && bD <= th_low && (float)bD < __fmul_rn((float)bD2, nnratio);   // :458-460
                 if (ok) atomicMax(&s_stamp[bI], trip * 64 + 63 - lane);
                 WAVE_LDS_SYNC();
-                bool dirty = undecided && !mine;   // a long list: decided in a trip of its own, when it is the first undecided one
-                int st[4];
-    #pragma unroll
-                for (int k = 0; k < 4; k++) st[k] = s_stamp[e[k] & 0xFFFFu];
+                // the decision rests on h1 and h2 alone: what lies before them is skipped for good, what lies behind them only
+                // counts once one of them goes
+                const int st1 = s_stamp[h1 & 0xFFFFu], st2 = s_stamp[h2 & 0xFFFFu];
                 const int old = s_m21[bI];
-    #pragma unroll
-                for (int k = 0; k < 4; k++) dirty |= (k < pend) & ((st[k] >> 6) == trip) & (63 - (st[k] & 63) < lane);
-                if (__ballot(pend > 4))
-                    for (int p = 4; p < pend; p++) {
-                        const int s5 = s_stamp[tupb[p * 64 + lane] & 0xFFFFu];
-                        dirty |= (s5 >> 6) == trip && 63 - (s5 & 63) < lane;
-                    }
+                bool dirty = undecided && !mine;   // a long list: decided in a trip of its own, when it is the first undecided one
+                dirty |= act & (held >= 1) & ((st1 >> 6) == trip) & (63 - (st1 & 63) < lane);
+                dirty |= act & (held >= 2) & ((st2 >> 6) == trip) & (63 - (st2 & 63) < lane);
                 const unsigned long long dm = __ballot(dirty);
                 const unsigned long long commit = dm ? rem & ((1ull << __builtin_ctzll(dm)) - 1ull) : rem;
                 const bool w = ok && ((commit >> lane) & 1ull);
