@@ -251,6 +251,27 @@ def committed_counters(batch, contexts):
     return {}
 
 
+def batch_sweep(args):
+    """The same step at larger batches, each in a child process of its own (fresh contexts and buffers): launch gaps and the last,
+    partly filled round of workgroups of every kernel weigh less.  Supplementary: the headline, the profiles and every per-launch
+    figure stay at --batch."""
+    import subprocess
+    res = {}
+    for mult in (2, 3):
+        b = args.batch * mult
+        cmd = [sys.executable, os.path.abspath(__file__), "--batch", str(b), "--steps", "8", "--warmup", "2", "--match", args.match,
+               "--cpu-frames", "0", "--pipelined", "0", "--host-batch", "0", "--configs", "0", "--content", "0", "--no-tiling", "0",
+               "--verify", "-1", "--batch-sweep", "0"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d = json.loads(p.stdout.strip().splitlines()[-1])
+            res[str(b)] = {"value": d["value"], "unit": "frames/s", "ms_per_step": d["ms_per_step"], "verified_frames": d["verified_frames"]}
+        except Exception as e:   # a supplementary figure must not take the line with it
+            res[str(b)] = {"error": repr(e)[:200]}
+    res["note"] = "same step, frames_per_step_per_gpu as the key; every frame of each batch verified as in the headline"
+    return res
+
+
 def pipelined_throughput(args, d_img, blob, device, cap):
     """Free-running multi-context throughput of the same step (no per-step readout): supplementary figure."""
     import torch
@@ -788,6 +809,8 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("ORBHIP_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend of an N > 1 run; gloo only for ranks that share one device (tests): RCCL "
                     "refuses duplicate devices, the vocabulary then travels through host memory")
+    ap.add_argument("--batch-sweep", type=int, default=1, help="also time the same step at 2 and 3 times the batch in child processes "
+                    "(the headline stays at --batch: the profiles and every per-launch figure refer to it)")
     ap.add_argument("--streams-config", type=int, default=-1, help="N > 1: also run BASELINE config 4 proper, one EuRoC stream per "
                     "rank (-1 = when N >= 4; 1 = always; 0 = never)")
     args = ap.parse_args()
@@ -1210,6 +1233,8 @@ def main():
         if blob is None:
             blob = D.make_synthetic_vocabulary(4242, VOC_K, VOC_L)
         out["content"] = content_classes(local_rank, blob, verify=args.verify != 0)
+    if out is not None and world == 1 and args.batch_sweep:
+        out["batch_sweep"] = batch_sweep(args)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -48,6 +48,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     for kind in ("textured", "indoor_sparse", "white_noise", "low_contrast") + (("photographs",) if synth.load_photographs() else ()):
         assert d["content"][kind]["verified_frames"] == 256 and d["content"][kind]["value"] > 1000     # 9 vs the oracle + 247 copies
     assert d["roofline"]["traffic_stale"] in (True, False)
+    # r05: the same step at two and three times the batch (child processes), every frame verified there too
+    for b in ("128", "192"):
+        assert d["batch_sweep"][b]["value"] > 1000 and d["batch_sweep"][b]["verified_frames"] == int(b), d["batch_sweep"]
 
 
 def _bench(args, env=None, timeout=600):
