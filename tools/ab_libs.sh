@@ -7,7 +7,7 @@ cp $LIB /tmp/liborbhip_keep.so
 for i in $(seq $N); do
   for v in "$@"; do
     cp $v $LIB
-    python bench.py --cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --content 0 --verify ${VERIFY:-0} 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$(basename $v)', d['value'], d['stage_ms'], d['verified_frames'])"
+    python bench.py --cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --content 0 --batch-sweep 0 --verify ${VERIFY:-0} 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$(basename $v)', d['value'], d['stage_ms'], d['verified_frames'])"
   done
 done
 cp /tmp/liborbhip_keep.so $LIB

@@ -4,7 +4,7 @@
 # other trace domains).  Usage: tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 5 --warmup 2 --batch 1024 --cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --content 0 --verify 0}
+ARGS=${@:---steps 5 --warmup 2 --batch 1024 --cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --content 0 --batch-sweep 0 --verify 0}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -41,7 +41,7 @@ json.dump(t, open(d + "/traffic.json", "w"), indent=1)
 PY
 bash tools/fast_ablate.sh > $OUT/fast_ablate_time.txt 2>&1
 for p in 1 2 3 4 5 8; do
-  echo -n "stop<=$p "; ORBHIP_FAST_PHASES=$p bash tools/pmc_gpu.sh ab$p "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" --steps 2 --warmup 1 --batch 1024 --cpu-frames 0 --pipelined 0 --verify 0 --host-batch 0 --configs 0 --content 0 2>&1 | grep -E "^k_fast"
+  echo -n "stop<=$p "; ORBHIP_FAST_PHASES=$p bash tools/pmc_gpu.sh ab$p "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" --steps 2 --warmup 1 --batch 1024 --cpu-frames 0 --pipelined 0 --verify 0 --host-batch 0 --configs 0 --content 0 --batch-sweep 0 2>&1 | grep -E "^k_fast"
 done > $OUT/fast_ablate_pmc.txt 2>&1
 timeout 300 bash tools/pmc_gpu.sh l2 "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" 2>&1 | grep -E "^k_" > $OUT/counters_l2.txt
 python tools/percall_latency.py > $OUT/percall_table.md 2> $OUT/percall_stderr.txt
