@@ -247,8 +247,9 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
     const int th = B >= 8 ? 32 : 8;
     const float winx = hint ? (float)sw / (float)dw : 0.f, winy = hint ? (float)sh / (float)dh : 0.f;
     dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + th - 1) / th), 1), B, 1);
+    static const int ldsPad = ORB_TUNE("RESIZE_LDS_PAD", 0);   // occupancy experiment (ablation build): unused dynamic LDS per workgroup
     if (th == 32)
-        hipLaunchKernelGGL(k_resize<32>, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
+        hipLaunchKernelGGL(k_resize<32>, grid, block, (size_t)ldsPad, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
                            (unsigned long long)dframe, reinterpret_cast<const int2 *>(xtab),
                            reinterpret_cast<const int4 *>(ytab), reinterpret_cast<const int4 *>(gtab), sw, sh, winx, winy,
                            orb_xcd_arg(1));
