@@ -62,6 +62,9 @@ int orb_configure(orbhip_ctx *c, int w, int h, int stride0, int B)
             c->resizeGroups[l] = orb_build_resize_groups(xt, yt, c->G.lv[l].w, gt);
             c->resizeHint[l][0] = resize_hint_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, 32);
             c->resizeHint[l][1] = resize_hint_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, 8);
+            c->resizeFit[l] = ResizeFit();
+            if (c->resizeGroups[l] && !resize_fit_plan(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h, c->resizeFit[l]))
+                c->resizeFit[l] = ResizeFit();
             c->fuseBlurOk = c->fuseBlurOk && c->resizeGroups[l] &&
                             resize_blur_fits(xt.data(), yt.data(), c->G.lv[l - 1].w, c->G.lv[l - 1].h, c->G.lv[l].w, c->G.lv[l].h);
             while (all.size() % 4) all.push_back(0);
@@ -293,6 +296,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     // ORBHIP_FUSE_BLUR=1 (r05 experiment): levels 1.. and their blurred twins from one kernel per level; k_blur keeps level 0
     static const bool fuseSwitch = ORB_TUNE("FUSE_BLUR", 0) != 0;   // (liborbhip_ablation.so only: measured slower)
     const bool fuseBlur = fuseSwitch && B >= 8 && !chained && c->fuseBlurOk;
+    static const bool fitTiles = ORB_TUNE("RESIZE_FIT", 1) != 0;   // batches: tiles fitted to the level (k_resize_fit)
     for (int l = 1; l < G.nlevels && !chained; l++) {
         const OrbLevel &S = G.lv[l - 1], &D = G.lv[l];
         const uint8_t *src = (l == 1) ? lvl0 : c->d_pyr + S.imgOff;
@@ -302,6 +306,11 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
             launch_resize_blur(s, src, S.w, S.h, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride, c->pyrFrameBytes,
                                c->d_blur + G.boff1 + D.imgOff, D.stride, c->lvl0FrameBytes + c->pyrFrameBytes,
                                c->d_resizeTab + c->resizeTabOff[l][1], c->d_resizeTab + c->resizeTabOff[l][2], c->d_blurBands, B);
+            continue;
+        }
+        if (fitTiles && B >= 8 && c->resizeFit[l].ntx > 0) {
+            launch_resize_fit(s, src, S.w, S.h, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride, c->pyrFrameBytes,
+                              c->d_resizeTab + c->resizeTabOff[l][1], c->d_resizeTab + c->resizeTabOff[l][2], c->resizeFit[l], B);
             continue;
         }
         launch_resize(s, src, S.w, S.h, sstride, sframe, c->d_pyr + D.imgOff, D.w, D.h, D.stride,

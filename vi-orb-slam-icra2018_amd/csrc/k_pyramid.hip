@@ -212,6 +212,146 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// r05: tiles FITTED to the level.  k_resize<32> lays 128 x 32 tiles over every level: 533 columns are five tiles of which the last
+// holds 21, 257 columns three tiles of which the last holds ONE -- and a wave (two rows of 32 column groups) issues its
+// instructions whether 32 or 5 of its groups exist: 17 % of the lanes of the batch's pyramid are such groups (33 % at level 5).
+// Here the host picks, per level, the number of tile columns, the groups per tile (<= 32), from them the rows per pass
+// (256 / groups) and the passes (3..6): a thread is (row of the pass, group) by one multiplication, everything else as in the
+// grouped path of k_resize.  RF_* bound the staged window and the tables.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RF_MAXROWS 62   // staged source rows: tiles of up to 48 rows
+#define RF_MAXTH 48
+
+__global__ __launch_bounds__(256) void k_resize_fit(const uint8_t *__restrict__ src, int sstride, unsigned long long sframe,
+                                                    uint8_t *__restrict__ dst, int dw, int dh, int dstride,
+                                                    unsigned long long dframe, const int4 *__restrict__ ytab,
+                                                    const int4 *__restrict__ gtab, int sw, int sh, float winx, float winy,
+                                                    int xcdMap, int ntx, int nty, int twg, int rpp, int npass, int rmagic)
+{
+    __shared__ __align__(16) uint8_t s_src[RF_MAXROWS + 1][RZ_MAXCH * 16];
+    __shared__ __align__(16) int4 s_ytab[64];
+    __shared__ __align__(16) int4 s_gtab[96];
+    const int tid = threadIdx.x;
+    const int t = xcd_tile(xcdMap), frame = blockIdx.y;
+    if (t >= ntx * nty) return;
+    const int by = t / ntx, bx = t - by * ntx;
+    const int TH = rpp * npass;
+    const int ox0 = bx * (twg << 2), oy0 = by * TH;
+    const int ox1 = min(ox0 + (twg << 2), dw) - 1, oy1 = min(oy0 + TH, dh) - 1;   // inclusive
+    const uint8_t *S = src + (size_t)frame * sframe;
+    uint8_t *D = dst + (size_t)frame * dframe;
+    const int sxmin = max((int)((float)ox0 * winx) - 1, 0), sxmax = min((int)((float)(ox1 + 1) * winx) + 1, sw - 1);
+    const int symin = max((int)((float)oy0 * winy) - 1, 0), symax = min((int)((float)(oy1 + 1) * winy) + 1, sh - 1);
+    const int XA = sxmin & ~15;
+    const int nch = ((sxmax - XA) >> 4) + 1, nrows = symax - symin + 1;
+    {
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int rl = lane >> 4, ch = lane & 15;
+        const uint8_t *sp = S + (size_t)(symin + rl) * sstride + XA + (ch << 4);
+        const uint32_t ldsBase = (uint32_t)(uintptr_t)&s_src[0][0];
+        for (int rb = wv * 4; rb < nrows; rb += 16)
+            if (ch < nch && rb + rl < nrows) rz_glds16(sp + (size_t)rb * sstride, ldsBase + (uint32_t)(rb * (RZ_MAXCH * 16)));
+        if (wv == 1) {
+            if (lane < TH) rz_glds16(ytab + min(oy0 + lane, dh - 1), (uint32_t)(uintptr_t)&s_ytab[0]);
+        } else if (wv >= 2) {
+            const int q = 64 * (wv - 2) + lane;                 // 16-byte chunk of the twg x 3 group entries
+            const int grp = q / 3, part = q - 3 * grp;
+            if (q < 3 * twg) rz_glds16(gtab + 3 * (min(ox0 + 4 * grp, dw - 1) >> 2) + part, (uint32_t)(uintptr_t)&s_gtab[64 * (wv - 2)]);
+        }
+    }
+    const int r = (int)(((unsigned)tid * (unsigned)rmagic) >> 16), g = tid - r * twg;   // tid / twg, tid % twg
+    const int gx = ox0 + (g << 2);
+    const bool live = r < rpp && gx < dw;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!live) return;
+    const int4 *gp = s_gtab + 3 * g;
+    const int4 g0 = gp[0], gsel = gp[1], gw = gp[2];
+    const int bcol = g0.x - XA, wb = bcol & ~3, shf = bcol & 3;
+    const uint32_t sel[4] = {(uint32_t)gsel.x, (uint32_t)gsel.y, (uint32_t)gsel.z, (uint32_t)gsel.w};
+    const uint32_t wt[4] = {(uint32_t)gw.x, (uint32_t)gw.y, (uint32_t)gw.z, (uint32_t)gw.w};
+    for (int j = 0; j < npass; j++) {
+        const int ry = r + rpp * j, dy = oy0 + ry;
+        if (dy >= dh) break;
+        const int4 ytj = s_ytab[ry];
+        const uint32_t b0s = ((uint32_t)ytj.z & 0xFFFu) << 12, b1s = ((uint32_t)ytj.w & 0xFFFu) << 12;   // (k_resize: v_mul_hi_u32_u24)
+        const uint32_t *q0 = reinterpret_cast<const uint32_t *>(&s_src[ytj.x - symin][wb]);
+        const uint32_t *q1 = reinterpret_cast<const uint32_t *>(&s_src[ytj.y - symin][wb]);
+        const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], c0 = q1[0], c1 = q1[1], c2 = q1[2];
+        const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, shf), hi0 = __builtin_amdgcn_alignbyte(a2, a1, shf);
+        const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, shf), hi1 = __builtin_amdgcn_alignbyte(c2, c1, shf);
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const us2 p0 = __builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, sel[k]));
+            const us2 p1 = __builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, sel[k]));
+            const us2 w2 = __builtin_bit_cast(us2, wt[k]);
+            const uint32_t r0 = __builtin_amdgcn_udot2(p0, w2, 0u, false);
+            const uint32_t r1 = __builtin_amdgcn_udot2(p1, w2, 0u, false);
+            v[k] = (__umulhi(b0s, r0 & 0x7FFFF0u) + __umulhi(b1s, r1 & 0x7FFFF0u) + 2u) >> 2;   // <= 255
+        }
+        const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        uint8_t *o = D + (size_t)dy * dstride + gx;
+        if (gx + 3 < dw) {
+            *reinterpret_cast<uint32_t *>(o) = packed;
+        } else {
+            for (int k = 0; k < 4 && gx + k < dw; k++) o[k] = (uint8_t)(packed >> (8 * k));
+        }
+    }
+}
+
+// The fitted tile geometry of a level (cost = workgroups x (prologue + passes x row), in thread-instructions), or false when no
+// geometry passes the window check.
+bool resize_fit_plan(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, ResizeFit &out)
+{
+    const int ng = (dw + 3) / 4;
+    const float winx = (float)sw / (float)dw, winy = (float)sh / (float)dh;
+    long best = -1;
+    for (int ntx = (ng + 31) / 32; ntx <= (ng + 31) / 32 + 3; ntx++) {
+        const int twg = (ng + ntx - 1) / ntx;
+        if (twg < 8 || twg > 32) continue;
+        const int rpp = 256 / twg, rmagic = (65536 + twg - 1) / twg;
+        bool okMagic = true;
+        for (int tid = 0; tid < 256; tid++) okMagic = okMagic && (int)(((unsigned)tid * (unsigned)rmagic) >> 16) == tid / twg;
+        if (!okMagic) continue;
+        for (int npass = 3; npass <= 6; npass++) {
+            const int TH = rpp * npass;
+            if (TH > RF_MAXTH) continue;
+            const int nty = (dh + TH - 1) / TH;
+            const long cost = (long)ntx * nty * (100 + 70 * npass);
+            if (best >= 0 && cost >= best) continue;
+            // the computed windows hold the taps and fit the staging area
+            bool ok = true;
+            for (int bx = 0; bx < ntx && ok; bx++) {
+                const int ox0 = bx * 4 * twg, ox1 = std::min(ox0 + 4 * twg, dw) - 1;
+                if (ox0 >= dw) { ok = false; break; }
+                const int lo = std::max((int)((float)ox0 * winx) - 1, 0), hi = std::min((int)((float)(ox1 + 1) * winx) + 1, sw - 1);
+                if (lo > (xt[2 * ox0] & 0xFFFF) || hi < (int)((uint32_t)xt[2 * ox1] >> 16)) ok = false;
+                if (((hi - (lo & ~15)) >> 4) + 1 > RZ_MAXCH) ok = false;
+            }
+            for (int by = 0; by < nty && ok; by++) {
+                const int oy0 = by * TH, oy1 = std::min(oy0 + TH, dh) - 1;
+                const int rlo = std::max((int)((float)oy0 * winy) - 1, 0), rhi = std::min((int)((float)(oy1 + 1) * winy) + 1, sh - 1);
+                if (rlo > yt[4 * oy0] || rhi < yt[4 * oy1 + 1] || rhi - rlo + 1 > RF_MAXROWS) ok = false;
+            }
+            if (!ok) continue;
+            best = cost;
+            out.ntx = ntx; out.nty = nty; out.twg = twg; out.rpp = rpp; out.npass = npass; out.rmagic = rmagic;
+        }
+    }
+    return best >= 0;
+}
+
+void launch_resize_fit(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw, int dh,
+                       int dstride, size_t dframe, const int32_t *ytab, const int32_t *gtab, const ResizeFit &f, int B)
+{
+    dim3 grid(orb_xcd_grid(f.ntx * f.nty, 1), B, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(k_resize_fit, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
+                       (unsigned long long)dframe, reinterpret_cast<const int4 *>(ytab), reinterpret_cast<const int4 *>(gtab), sw, sh,
+                       (float)sw / (float)dw, (float)sh / (float)dh, orb_xcd_arg(1), f.ntx, f.nty, f.twg, f.rpp, f.npass, f.rmagic);
+}
+
 // Can every tile of the level stage the window that the kernel derives from the scale factors, and does that window
 // contain the taps of the tile?  (Checked on the host against the tables; otherwise the kernel reads the bounds.)
 static bool resize_window_hint_ok(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, int th, float winx,

@@ -117,6 +117,11 @@ void fast_tile_geometry(const OrbLevels &G, FastTile &t);
 // output rows; four waves of 32 columns).
 #define BLUR_TILE_W 128
 #define BLUR_TILE_H 58
+// k_resize_fit: tiles fitted to the level (tile columns / rows, column groups per tile, rows per pass, passes, tid / twg by multiplication)
+struct ResizeFit {
+    int ntx = 0, nty = 0, twg = 0, rpp = 0, npass = 0, rmagic = 0;
+};
+
 struct BlurTile {
     short level, tx, ty, pad;
 };
@@ -241,6 +246,7 @@ struct orbhip_ctx {
     int32_t *d_resizeTab = nullptr; // per level: x table [dw] int2, y table [dh] int4
     size_t resizeTabOff[ORBHIP_MAX_LEVELS][3];   // column taps, row taps, 4-pixel groups (k_pyramid.hip)
     bool resizeGroups[ORBHIP_MAX_LEVELS] = {};
+    ResizeFit resizeFit[ORBHIP_MAX_LEVELS];       // .ntx == 0: the level keeps k_resize<32>
     bool resizeHint[ORBHIP_MAX_LEVELS][2] = {};  // the computed source window is valid for 32-row / 8-row tiles    // the level has a group table (fast path of k_resize)
     size_t cap_lvl0 = 0, cap_pyr = 0, cap_blur = 0, cap_cand = 0, cap_cells = 0, cap_pts = 0,
            cap_kps = 0, cap_out = 0, cap_resize = 0, cap_fastTiles = 0, cap_blurTiles = 0,
@@ -329,6 +335,9 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
                    uint8_t *dst, int dw, int dh, int dstride, size_t dframe, const int32_t *xtab,
                    const int32_t *ytab, const int32_t *gtab, bool hint, int B);
 bool resize_hint_fits(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, int th);
+bool resize_fit_plan(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh, ResizeFit &out);
+void launch_resize_fit(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw, int dh,
+                       int dstride, size_t dframe, const int32_t *ytab, const int32_t *gtab, const ResizeFit &f, int B);
 bool resize_hint_pointwise(const int32_t *xt, const int32_t *yt, int sw, int sh, int dw, int dh);
 // plans the chained pyramid (groups of levels per launch, their tiles and LDS sizes); false = some level cannot be chained
 bool chain_plan(const OrbLevels &G, const bool *levelOk, const ChainLevels &CL, std::vector<ChainTile> &tiles,
