@@ -319,7 +319,8 @@ bool resize_fit_plan(const int32_t *xt, const int32_t *yt, int sw, int sh, int d
             const int TH = rpp * npass;
             if (TH > RF_MAXTH) continue;
             const int nty = (dh + TH - 1) / TH;
-            const long cost = (long)ntx * nty * (100 + 70 * npass);
+            static const int prologue = ORB_TUNE("RESIZE_FIT_P", 100);   // thread-instructions of a workgroup's fixed part / of a pass (70)
+            const long cost = (long)ntx * nty * (prologue + 70 * npass);
             if (best >= 0 && cost >= best) continue;
             // the computed windows hold the taps and fit the staging area
             bool ok = true;
