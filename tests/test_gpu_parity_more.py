@@ -187,6 +187,7 @@ def test_alternative_code_paths_give_the_same_results(env):
     {"ORBHIP_DESCRIBE_KPW": "32"},            # ... 32 slots per workgroup (always the dword form)
     {"ORBHIP_NO_SPLIT": "1"},                 # batch schedules: no half-batch split; blur beside FAST
     {"ORBHIP_BLUR_PLACE": "1"},
+    {"ORBHIP_RESIZE_FIT": "0"},               # k_resize<32> (128 x 32 tiles), what a level keeps when no fitted geometry passes the window check
     {"ORBHIP_FUSE_BLUR": "1"},                # levels 1.. and their blurred twins from one kernel per level (k_resize_blur)
 ])
 def test_alternative_batch_code_paths_give_the_same_results(env):
