@@ -236,7 +236,10 @@ int orbhip_vocab_load_device(orbhip_ctx *ctx, const void *d_blob, size_t nbytes)
  * dst still uses what it borrowed -- dst then keeps running on the OLD tables until it shares again.
  * orbhip_vocab_generation: a process-wide counter of orbhip_vocab_load calls as seen by this context's tables (0 = no
  * vocabulary); a borrower compares it with the lender's to learn that it should share again (no counterpart in the reference:
- * System.cc:336-339 loads the vocabulary once). */
+ * System.cc:336-339 loads the vocabulary once).  orbhip_vocab_share / orbhip_vocab_generation on `src` may run on another
+ * thread than an orbhip_vocab_load on it: the (block, tables) pair is swapped under a lock, the borrower sees the old pair or
+ * the new one.  Work already queued on src's OWN stream against the old tables is the caller's to order, as with any two
+ * calls on one context. */
 int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src);
 unsigned long long orbhip_vocab_generation(const orbhip_ctx *ctx);
 /* Replaces ORBVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1564-1647; chosen by
@@ -542,6 +545,13 @@ int orbhip_set_put_from_frame(orbhip_ctx *ctx, uint64_t key, orbhip_ctx *src, co
  * one synchronisation; 1 = 4 KB copied in, the kernel, 4 KB copied out, one synchronisation; 2 = the kernel stores its
  * result to page-locked memory, one synchronisation.  (Measurement aid: tools/percall_latency.py.) */
 int orbhip_debug_roundtrip(orbhip_ctx *ctx, int mode, int iters, double *us_per_call);
+
+/* Which kernel variants this PROCESS has launched since the last reset (test aid: a test that claims to reach a fallback path
+ * checks the bit).  Bits: 0 k_fast_fix, 1 k_fast (generic grid), 2 k_resize_fit, 3 k_resize<32> / <8>, 4 k_pyramid_chain,
+ * 5 k_quadtree (tables in LDS), 6 k_quadtree (tables and candidates in LDS, a frame or two), 7 k_quadtree (tables in global
+ * memory), 8 k_bow_lane, 9 k_bow_seq (descriptors in LDS), 10 k_bow_seq (descriptors in global memory), 11 k_fast_fix on the
+ * tall-cell instance.  Returns the mask; reset != 0 clears it. */
+unsigned orbhip_debug_path_mask(int reset);
 
 /* ---- multi-GPU (one process per GPU) ----
  * The reference is a single process (no distributed back end); these entry points are what a

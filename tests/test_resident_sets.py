@@ -90,3 +90,19 @@ def test_window_best_into_a_resident_key_frame(oracle):
     with pytest.raises(OrbHipError, match="without a grid"):
         guided.WindowBestSet(M._ctx, 8, q, d0)
     M.close()
+
+
+def test_set_limit_evicts_least_recently_used(oracle):
+    """orbhip_set_limit: the limit is clamped to 4..96 and the oldest sets leave first."""
+    from orbhip.extractor import ORBmatcher
+    k, d, fv = _frames_with_fv(oracle, n=1, nf=300)[0]
+    M = ORBmatcher(0.7, True)
+    assert M.set_limit(1) == 4 and M.set_limit(1000) == 96 and M.set_limit(4) == 4
+    for j in range(6):
+        M.put_set(500 + j, k[:40], d[:40])
+    assert [M.has_set(500 + j, 40) for j in range(6)] == [False, False, True, True, True, True]
+    assert M.has_set(502, 40)                       # (has_set is a use: 502 is now the most recent)
+    M.put_set(510, k[:40], d[:40])
+    assert M.has_set(502, 40) and not M.has_set(503, 40) and M.has_set(510, 40)
+    M.drop_set()
+    M.close()

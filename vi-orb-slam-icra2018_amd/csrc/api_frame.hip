@@ -356,6 +356,12 @@ int orb_frame_mark_busy(orbhip_ctx *src, hipStream_t copier)
 // (the shape of struct Packed); mode 2 = as 0 with the kernel storing one word to page-locked memory (the zero-copy result
 // path).  tools/percall_latency.py prints them beside the per-call table: a row that sits at its floor cannot beat a host
 // core by arithmetic.
+std::atomic<unsigned> g_orbPathMask{0};
+extern "C" unsigned orbhip_debug_path_mask(int reset)
+{
+    return reset ? g_orbPathMask.exchange(0u, std::memory_order_relaxed) : g_orbPathMask.load(std::memory_order_relaxed);
+}
+
 __global__ void k_floor(int32_t *out)
 {
     if (out && threadIdx.x == 0) out[0] = 1;

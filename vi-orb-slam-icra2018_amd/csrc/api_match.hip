@@ -279,17 +279,17 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
     }
     // The block is reference-counted: a context that borrowed the previous tables (orbhip_vocab_share) keeps them alive and
     // keeps reading the OLD vocabulary until it shares again -- orbhip_vocab_generation tells it to.
+    // The new tables are complete before the context sees them; the swap happens under vocMutex, so that a borrower's
+    // orbhip_vocab_share / orbhip_vocab_generation on another thread reads either the old pair or the new one.
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->vocHold.reset();
-    c->voc = OrbVocabDev();
     void *blk = nullptr;
     HIPCHK(c, hipMalloc(&blk, total));
-    c->vocHold = std::shared_ptr<void>(blk, [](void *p) { (void)hipFree(p); });
+    std::shared_ptr<void> hold(blk, [](void *p) { (void)hipFree(p); });
     uint8_t *base = (uint8_t *)blk;
     const void *src[5] = {H.edesc.data(), H.erange.data(), H.child.data(), H.eword.data(), H.eweight.data()};
     for (int i = 0; i < 5; i++) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    OrbVocabDev &V = c->voc;
+    OrbVocabDev V;
     V.k = H.k; V.L = H.L; V.scoring = H.scoring; V.weighting = H.weighting; V.nnodes = H.nnodes; V.nwords = H.nwords;
     V.rootFirst = H.childOff[0];
     V.rootLast = H.childOff[1];
@@ -300,6 +300,11 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
     V.eweight = (float *)(base + off[4]);
     static std::atomic<unsigned long long> loads{0};
     V.gen = ++loads;
+    {
+        std::lock_guard<std::mutex> g(c->vocMutex);
+        c->vocHold = std::move(hold);   // (the old block lives on while another context borrows it)
+        c->voc = V;
+    }
     return ORBHIP_OK;
 }
 
@@ -307,7 +312,9 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
 // it saw when it shared and shares again when the lender has loaded since (host/ORBextractor.cc).
 extern "C" unsigned long long orbhip_vocab_generation(const orbhip_ctx *c)
 {
-    return c && c->voc.desc ? c->voc.gen : 0ull;
+    if (!c) return 0ull;
+    std::lock_guard<std::mutex> g(c->vocMutex);
+    return c->voc.desc ? c->voc.gen : 0ull;
 }
 
 // The tables of `src` serve `dst` as well (same device): what lets an extractor's context run the transform inside
@@ -316,13 +323,22 @@ extern "C" unsigned long long orbhip_vocab_generation(const orbhip_ctx *c)
 // runs on the tables it borrowed; a vocabulary loaded into dst later replaces the borrowed one.
 extern "C" int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src)
 {
-    if (!dst || !src || !src->voc.desc) return fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: no vocabulary in the source context");
+    if (!dst || !src) return fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: no vocabulary in the source context");
+    if (dst == src) return src->voc.desc ? ORBHIP_OK : fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: no vocabulary in the source context");
+    std::shared_ptr<void> hold;
+    OrbVocabDev V;
+    {
+        std::lock_guard<std::mutex> g(src->vocMutex);   // a consistent (block, tables) pair while the lender may be loading
+        hold = src->vocHold;
+        V = src->voc;
+    }
+    if (!V.desc) return fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: no vocabulary in the source context");
     if (dst->device != src->device) return fail(dst, ORBHIP_E_ARG, "orbhip_vocab_share: the two contexts are on different devices");
-    if (dst == src) return ORBHIP_OK;
     HIPCHK(dst, hipSetDevice(dst->device));
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
-    dst->vocHold = src->vocHold;
-    dst->voc = src->voc;
+    std::lock_guard<std::mutex> g(dst->vocMutex);
+    dst->vocHold = std::move(hold);
+    dst->voc = V;
     return ORBHIP_OK;
 }
 
@@ -397,11 +413,10 @@ extern "C" int orbhip_search_by_bow_seq_device(orbhip_ctx *c, const void *d_desc
                                       "tables exceed the 160 KB of LDS); use orbhip_search_by_bow per pair");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    launch_bow_seq(c->stream, (const uint8_t *)d_desc, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts,
-                   (const int32_t *)d_node, (const float *)d_weight, (const uint8_t *)d_valid, cap, B, lag, 50, th_mode,
-                   nnratio, check_ori, (int32_t *)d_match12, (int32_t *)d_match21, (int32_t *)d_nmatches);
+    HIPCHK(c, launch_bow_seq(c->stream, (const uint8_t *)d_desc, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts,
+                             (const int32_t *)d_node, (const float *)d_weight, (const uint8_t *)d_valid, cap, B, lag, 50, th_mode,
+                             nnratio, check_ori, (int32_t *)d_match12, (int32_t *)d_match21, (int32_t *)d_nmatches));
     if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-    HIPCHK(c, hipGetLastError());
     c->haveMatchEvents = c->stageTiming >= 2;
     return ORBHIP_OK;
 }

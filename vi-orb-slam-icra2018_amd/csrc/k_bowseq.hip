@@ -1080,12 +1080,14 @@ rotation:
     if (tid == 0) nmatches[b] = s_nm;
 }
 
-void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *kps, const int32_t *counts,
-                    const int32_t *node, const float *weight, const uint8_t *valid, int cap, int B, int lag, int th,
-                    int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21,
-                    int32_t *nmatches)
+// Returns the launch's error (hipSuccess when a kernel is in the stream).  A lane kernel that the runtime refuses (dynamic LDS
+// attribute or launch) is not an error yet: the wave-per-node kernel takes the call.
+hipError_t launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *kps, const int32_t *counts,
+                          const int32_t *node, const float *weight, const uint8_t *valid, int cap, int B, int lag, int th,
+                          int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21,
+                          int32_t *nmatches)
 {
-    if (B <= 0) return;
+    if (B <= 0) return hipSuccess;
     int NP = 512;
     while (NP < cap) NP <<= 1;
     // the lane-per-node kernel (above) when its byte clamp is exact for these thresholds, the features fit its 16-bit indices and
@@ -1097,10 +1099,19 @@ void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *k
         if (laneEnv && cap < 65535 && NP <= 4096 && ldsLane <= 150 * 1024 && (float)th < nnratio * 255.0f && th < 255) {
             static const int dbgL = ORB_TUNE("BOW_PHASES", 9);
             (void)dbgL;
-            if (ldsLane > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_bow_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLane);
-            hipLaunchKernelGGL(k_bow_lane, dim3(B, 1, 1), dim3(BL_THREADS, 1, 1), ldsLane, s, desc, kps, counts, node, weight, valid, cap, NP,
-                               lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches ORB_ABL_ARG(dbgL));
-            return;
+            hipError_t e = hipSuccess;
+            if (ldsLane > 48 * 1024) e = hipFuncSetAttribute((const void *)k_bow_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLane);
+            if (e == hipSuccess) {
+                (void)hipGetLastError();
+                hipLaunchKernelGGL(k_bow_lane, dim3(B, 1, 1), dim3(BL_THREADS, 1, 1), ldsLane, s, desc, kps, counts, node, weight, valid, cap,
+                                   NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches ORB_ABL_ARG(dbgL));
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) {
+                orb_path(ORB_PATH_BOW_LANE);
+                return hipSuccess;
+            }
+            (void)hipGetLastError();   // refused: fall through to k_bow_seq
         }
     }
     const size_t base = (((size_t)NP * 36 + (size_t)NP / 32 * 12 + 15) & ~(size_t)15) + 64;
@@ -1111,11 +1122,16 @@ void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *k
     (void)dbg;
     const size_t lds = ldsd ? full : base;
     const void *fn = ldsd ? (const void *)k_bow_seq<true> : (const void *)k_bow_seq<false>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    orb_path(ldsd ? ORB_PATH_BOW_SEQ_LDS : ORB_PATH_BOW_SEQ_GLOBAL);
     if (ldsd)
         hipLaunchKernelGGL(k_bow_seq<true>, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid,
                            cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches ORB_ABL_ARG(dbg));
     else
         hipLaunchKernelGGL(k_bow_seq<false>, dim3(B, 1, 1), dim3(bs_threads(), 1, 1), lds, s, desc, kps, counts, node, weight, valid,
                            cap, NP, lag, th, th_mode, nnratio, check_ori, match12, match21, nmatches ORB_ABL_ARG(dbg));
+    return hipGetLastError();
 }

@@ -1368,6 +1368,7 @@ static void launch_fast_levels(hipStream_t s, const OrbLevels &G, const uint8_t 
         const size_t ldsScore = (size_t)scoreBytes + 16 + 256 + (size_t)ldsPad;   // + a row: nms_survives_fix reads one below the tile
         const bool perXcd = fastXcd == 4 && B >= 8;   // (a frame or two: the runs over all XCDs)
         if (perXcd) grid = dim3(8, ntiles, (B + 7) / 8);
+        orb_path(ORB_PATH_FAST_FIX | (tall ? ORB_PATH_FAST_TALL : 0u));
 #define ORB_LAUNCH_FIX(P, D, R)                                                                                              \
     hipLaunchKernelGGL((k_fast_fix<P, D, R>), grid, block, ldsScore, s, lvl0, stride0, (unsigned long long)frame0, pyr,      \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, G.totalCells, G.totalCands, G.iniTh, G.minTh, lc, \
@@ -1400,6 +1401,7 @@ static void launch_fast_levels(hipStream_t s, const OrbLevels &G, const uint8_t 
     hipLaunchKernelGGL(k_fast<P>, grid, block, lds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,                    \
                        (unsigned long long)pyrFrame, tiles, cand, cellCnt, pixBytes, scoreBytes, lBytes, cBytes, bitsBytes,  \
                        listCap, cornerCap, orb_xcd_arg(), ntiles ORB_ABL_ARG(phases))
+    orb_path(ORB_PATH_FAST_GENERIC);
     switch (fixed) {
     case 176: ORB_LAUNCH_FAST(176); break;
     case 192: ORB_LAUNCH_FAST(192); break;

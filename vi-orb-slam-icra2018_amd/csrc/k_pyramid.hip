@@ -348,6 +348,7 @@ void launch_resize_fit(hipStream_t s, const uint8_t *src, int sw, int sh, int ss
                        int dstride, size_t dframe, const int32_t *ytab, const int32_t *gtab, const ResizeFit &f, int B)
 {
     dim3 grid(orb_xcd_grid(f.ntx * f.nty, 1), B, 1), block(256, 1, 1);
+    orb_path(ORB_PATH_RESIZE_FIT);
     hipLaunchKernelGGL(k_resize_fit, grid, block, 0, s, src, sstride, (unsigned long long)sframe, dst, dw, dh, dstride,
                        (unsigned long long)dframe, reinterpret_cast<const int4 *>(ytab), reinterpret_cast<const int4 *>(gtab), sw, sh,
                        (float)sw / (float)dw, (float)sh / (float)dh, orb_xcd_arg(1), f.ntx, f.nty, f.twg, f.rpp, f.npass, f.rmagic);
@@ -386,6 +387,7 @@ void launch_resize(hipStream_t s, const uint8_t *src, int sw, int sh, int sstrid
 {
     dim3 block(256, 1, 1);
     const int th = B >= 8 ? 32 : 8;
+    orb_path(ORB_PATH_RESIZE_TILES);
     const float winx = hint ? (float)sw / (float)dw : 0.f, winy = hint ? (float)sh / (float)dh : 0.f;
     dim3 grid(orb_xcd_grid(((dw + RZ_TW - 1) / RZ_TW) * ((dh + th - 1) / th), 1), B, 1);
     static const int ldsPad = ORB_TUNE("RESIZE_LDS_PAD", 0);   // occupancy experiment (ablation build): unused dynamic LDS per workgroup
@@ -686,6 +688,7 @@ void launch_pyramid_chain(hipStream_t s, const OrbLevels &G, const ChainLevels &
                           uint8_t *hostPyr)
 {
     dim3 grid(grp.ntiles, B, 1), block(CH_NT, 1, 1);
+    orb_path(ORB_PATH_PYRAMID_CHAIN);
     hipLaunchKernelGGL(k_pyramid_chain, grid, block, (size_t)(grp.bufA + grp.bufB + grp.xtabBytes + grp.ytabBytes), s, G, CL,
                        tiles + grp.firstTile, lvl0, stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame, tab,
                        grp.bufA, grp.bufB, grp.xtabBytes, hostPyr);

@@ -244,6 +244,7 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     const int cellBytes = (int)(base - (size_t)qtBytes);
     if (base > QT_LDS_LIMIT) {
         // tables in global memory (tableScratch sized by quadtree_table_scratch_bytes); LDS holds the cell offsets only
+        orb_path(ORB_PATH_QT_GLOBAL);
         hipLaunchKernelGGL((k_quadtree<false, true>), grid, block, (size_t)cellBytes, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp,
                            lvlKpCnt, maxNodes, qtBytes, cellBytes, 0, tableScratch);
         return;
@@ -257,11 +258,13 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
             // ... and 1024 threads: the steps are loops over a few thousand candidates between barriers
             static const int smallThreads = ORB_TUNE("QT_THREADS_SMALL", 1024);
             block = dim3(smallThreads >= 64 && smallThreads <= 1024 && smallThreads % 64 == 0 ? smallThreads : 1024, 1, 1);
+            orb_path(ORB_PATH_QT_LDSPTS);
             hipLaunchKernelGGL((k_quadtree<true, false>), grid, block, base + (size_t)ldsPts * 8, s, G, cand, cellCnt, pts, pnode,
                                lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes, cellBytes, ldsPts, nullptr);
             return;
         }
     }
+    orb_path(ORB_PATH_QT_LDS);
     hipLaunchKernelGGL((k_quadtree<false, false>), grid, block, base, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp, lvlKpCnt,
                        maxNodes, qtBytes, cellBytes, 0, nullptr);
 }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,17 @@ static inline int orb_env_int(const char *name, int dflt)
 #define ORB_ABL_STOP(cond) do { } while (0)
 #define ORB_ABL_IF(cond) if (false)
 #endif
+
+// Which kernel variants have been launched in this process (orbhip_debug_path_mask, include/orbhip.h): the tests that claim to reach
+// a fallback path check the bit instead of trusting the geometry they picked.
+#include <atomic>
+enum OrbPath : unsigned {
+    ORB_PATH_FAST_FIX = 1u << 0, ORB_PATH_FAST_GENERIC = 1u << 1, ORB_PATH_RESIZE_FIT = 1u << 2, ORB_PATH_RESIZE_TILES = 1u << 3,
+    ORB_PATH_PYRAMID_CHAIN = 1u << 4, ORB_PATH_QT_LDS = 1u << 5, ORB_PATH_QT_LDSPTS = 1u << 6, ORB_PATH_QT_GLOBAL = 1u << 7,
+    ORB_PATH_BOW_LANE = 1u << 8, ORB_PATH_BOW_SEQ_LDS = 1u << 9, ORB_PATH_BOW_SEQ_GLOBAL = 1u << 10, ORB_PATH_FAST_TALL = 1u << 11
+};
+extern std::atomic<unsigned> g_orbPathMask;
+static inline void orb_path(unsigned bit) { g_orbPathMask.fetch_or(bit, std::memory_order_relaxed); }
 
 #define ORB_PATCH_SIZE 31      // ref: src/ORBextractor.cc:74
 #define ORB_HALF_PATCH 15      // :75
@@ -303,6 +315,7 @@ struct orbhip_ctx {
 
     // vocabulary
     OrbVocabDev voc;
+    mutable std::mutex vocMutex;              // orders a load on this context against another thread's share / generation of it
     std::shared_ptr<void> vocHold;            // the device block behind `voc`, shared by every context that borrowed it
                                               // (orbhip_vocab_share): freed when the last of them lets go
 
@@ -518,9 +531,9 @@ int launch_stereo(orbhip_ctx *L, orbhip_ctx *R, const orbhip_keypoint *kpsL, con
 int orb_vocab_parse(const uint8_t *blob, size_t nbytes, OrbVocabHost &V, std::string &err);
 void launch_vocab_transform(hipStream_t s, const OrbVocabDev &V, const uint8_t *desc, int n, int levelsup,
                             int32_t *word_id, float *weight, int32_t *node_id, const int32_t *cnt = nullptr);
-void launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *kps, const int32_t *counts,
-                    const int32_t *node, const float *weight, const uint8_t *valid, int cap, int B, int lag, int th,
-                    int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21,
-                    int32_t *nmatches);
+hipError_t launch_bow_seq(hipStream_t s, const uint8_t *desc, const orbhip_keypoint *kps, const int32_t *counts,
+                          const int32_t *node, const float *weight, const uint8_t *valid, int cap, int B, int lag, int th,
+                          int th_mode, float nnratio, int check_ori, int32_t *match12, int32_t *match21,
+                          int32_t *nmatches);
 
 #endif

@@ -133,31 +133,31 @@ void ORBmatcher::DropResidentSets()
 
 int ORBmatcher::SearchByBoW(KeyFrame* pKF,Frame &F, vector<MapPoint*> &vpMapPointMatches)
 {
-    const vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
-    vpMapPointMatches = vector<MapPoint*>(F.N,static_cast<MapPoint*>(NULL));
+    const vector<MapPoint*> kfPoints(pKF->GetMapPointMatches());
+    vpMapPointMatches.assign(F.N, (MapPoint *)0);
 
     const int n1 = pKF->mDescriptors.rows, n2 = F.mDescriptors.rows;
     if (n1 == 0 || n2 == 0) return 0;
     vector<uint8_t> valid1(n1, 0);
     vector<float> a1(n1, 0.f), a2(n2, 0.f);
     for (int i = 0; i < n1; i++) {
-        MapPoint *pMP = i < (int)vpMapPointsKF.size() ? vpMapPointsKF[i] : NULL;
+        MapPoint *pMP = i < (int)kfPoints.size() ? kfPoints[i] : NULL;
         valid1[i] = (pMP && !pMP->isBad()) ? 1 : 0;          // ref: :193-199
         a1[i] = pKF->mvKeysUn[i].angle;                        // ref: :234
     }
     for (int i = 0; i < n2; i++) a2[i] = F.mvKeys[i].angle;   // ref: :238
     vector<int32_t> m12(n1), m21(n2);
-    int nmatches = 0;
+    int found = 0;
     // (the rotation check reads pKF->mvKeysUn[i].angle and F.mvKeys[i].angle: undistortion leaves the angle alone, so the
     // resident sets -- built from the undistorted keypoints -- hold the same values)
     if (use_sets() && (int)F.mvKeysUn.size() == n2 && ensure_set(pKF) && ensure_set(F)) {
         const int rc = orbhip_search_by_bow_sets(tls.get(), KF_KEY | (uint64_t)(pKF->mnId + 1), valid1.data(),
                                                  FRAME_KEY | (uint64_t)(F.mnId + 1), NULL, TH_LOW, 0, mfNNratio,
-                                                 mbCheckOrientation ? 1 : 0, m12.data(), m21.data(), &nmatches);
+                                                 mbCheckOrientation ? 1 : 0, m12.data(), m21.data(), &found);
         if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
         for (int i2 = 0; i2 < n2 && i2 < F.N; i2++)
-            if (m21[i2] >= 0) vpMapPointMatches[i2] = vpMapPointsKF[m21[i2]];   // ref: :232
-        return nmatches;
+            if (m21[i2] >= 0) vpMapPointMatches[i2] = kfPoints[m21[i2]];   // ref: :232
+        return found;
     }
     const Csr c1 = flatten(pKF->mFeatVec), c2 = flatten(F.mFeatVec);
     const vector<uint8_t> d1 = contiguous(pKF->mDescriptors), d2 = contiguous(F.mDescriptors);
@@ -165,18 +165,17 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF,Frame &F, vector<MapPoint*> &vpMapPoin
                                         c1.off.data(), c1.idx.data(), (int)c1.node.size(), d2.data(), n2, NULL,
                                         a2.data(), c2.node.data(), c2.off.data(), c2.idx.data(), (int)c2.node.size(),
                                         TH_LOW, 0, mfNNratio, mbCheckOrientation ? 1 : 0, m12.data(), m21.data(),
-                                        &nmatches);
+                                        &found);
     if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
     for (int i2 = 0; i2 < n2 && i2 < F.N; i2++)
-        if (m21[i2] >= 0) vpMapPointMatches[i2] = vpMapPointsKF[m21[i2]];   // ref: :232
-    return nmatches;
+        if (m21[i2] >= 0) vpMapPointMatches[i2] = kfPoints[m21[i2]];   // ref: :232
+    return found;
 }
 
 int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12)
 {
-    const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
-    const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
-    vpMatches12 = vector<MapPoint*>(vpMapPoints1.size(),static_cast<MapPoint*>(NULL));
+    const vector<MapPoint*> points1(pKF1->GetMapPointMatches()), points2(pKF2->GetMapPointMatches());
+    vpMatches12.assign(points1.size(), (MapPoint *)0);
 
     const int n1 = pKF1->mDescriptors.rows, n2 = pKF2->mDescriptors.rows;
     if (n1 == 0 || n2 == 0) return 0;
@@ -193,15 +192,15 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
         a2[i] = pKF2->mvKeysUn[i].angle;
     }
     vector<int32_t> m12(n1), m21(n2);
-    int nmatches = 0;
+    int found = 0;
     if (use_sets() && pKF1 != pKF2 && ensure_set(pKF1) && ensure_set(pKF2)) {
         const int rc = orbhip_search_by_bow_sets(tls.get(), KF_KEY | (uint64_t)(pKF1->mnId + 1), valid1.data(),
                                                  KF_KEY | (uint64_t)(pKF2->mnId + 1), valid2.data(), TH_LOW, 1, mfNNratio,
-                                                 mbCheckOrientation ? 1 : 0, m12.data(), m21.data(), &nmatches);
+                                                 mbCheckOrientation ? 1 : 0, m12.data(), m21.data(), &found);
         if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
         for (int i1 = 0; i1 < n1 && i1 < (int)vpMatches12.size(); i1++)
             if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];           // ref: :602
-        return nmatches;
+        return found;
     }
     const Csr c1 = flatten(pKF1->mFeatVec), c2 = flatten(pKF2->mFeatVec);
     const vector<uint8_t> d1 = contiguous(pKF1->mDescriptors), d2 = contiguous(pKF2->mDescriptors);
@@ -209,11 +208,11 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
                                         c1.off.data(), c1.idx.data(), (int)c1.node.size(), d2.data(), n2,
                                         valid2.data(), a2.data(), c2.node.data(), c2.off.data(), c2.idx.data(),
                                         (int)c2.node.size(), TH_LOW, 1, mfNNratio, mbCheckOrientation ? 1 : 0,
-                                        m12.data(), m21.data(), &nmatches);
+                                        m12.data(), m21.data(), &found);
     if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
     for (int i1 = 0; i1 < n1 && i1 < (int)vpMatches12.size(); i1++)
         if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];           // ref: :602
-    return nmatches;
+    return found;
 }
 
 float ORBmatcher::RadiusByViewingCos(const float &viewCos)
@@ -240,12 +239,12 @@ int run_projection_search(Frame &F, const vector<orbhip_proj_query> &q, const ve
             occupied[i] = 1;   // ref: :88-90, :1413-1415 (observed points only); :1565-1566 (any point)
     const vector<uint8_t> d = contiguous(F.mDescriptors);
     vector<int32_t> match(n);
-    int nmatches = 0;
+    int found = 0;
     const int rc = orbhip_search_by_projection(
         tls.get(), reinterpret_cast<const orbhip_keypoint *>(F.mvKeysUn.data()), d.data(), n,
         (useRight && (int)F.mvuRight.size() == n) ? F.mvuRight.data() : NULL, occupied.data(), Frame::mnMinX, Frame::mnMinY,
         Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv, q.data(), qdesc.data(), nq, use_ratio ? 1 : 0, nnratio,
-        check_ori ? 1 : 0, th_high, match.data(), &nmatches);
+        check_ori ? 1 : 0, th_high, match.data(), &found);
     if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByProjection", orbhip_last_error(tls.get())), 0;
     for (int i = 0; i < n; i++) {
         if (match[i] >= 0)
@@ -253,7 +252,7 @@ int run_projection_search(Frame &F, const vector<orbhip_proj_query> &q, const ve
         else if (match[i] == -2)
             F.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);
     }
-    return nmatches;
+    return found;
 }
 
 // d = R * x + t for 3x3 / 3x1 float matrices.  OpenCV evaluates the MatExpr Rcw*x3Dw+tcw as one gemm whose
@@ -270,185 +269,154 @@ void affine3(const cv::Mat &R, const float x[3], const float t[3], float out[3],
 
 int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
 {
-    const bool bFactor = th!=1.0;
-
+    // Tracking::SearchLocalPoints (ref: src/ORBmatcher.cc:41-128): the points Frame::isInFrustum marked, each with the
+    // projection and the octave it stored in the point.
+    const bool widen = th!=1.0;
     const int nq = (int)vpMapPoints.size();
     vector<orbhip_proj_query> q(nq);
     vector<uint8_t> qdesc((size_t)nq * 32, 0);
-    for(int iMP=0; iMP<nq; iMP++)
-    {
-        MapPoint* pMP = vpMapPoints[iMP];
-        orbhip_proj_query &e = q[iMP];
-        memset(&e, 0, sizeof(e));
-        if(!pMP->mbTrackInView)                                // ref: :55-59
-            continue;
-        if(pMP->isBad())
-            continue;
-
-        const int &nPredictedLevel = pMP->mnTrackScaleLevel;
-
+    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)nq);
+    for (int k = 0; k < nq; k++) {
+        MapPoint *pt = vpMapPoints[k];
+        if (!pt->mbTrackInView || pt->isBad()) continue;       // ref: :55-59
+        const int level = pt->mnTrackScaleLevel;
         // window radius: narrow when the point is seen almost head-on, wider otherwise (ref: :130-138), times th on request
-        float r = RadiusByViewingCos(pMP->mTrackViewCos);
-        if(bFactor)
-            r*=th;
-
-        e.u = pMP->mTrackProjX;                                // ref: :68-69
-        e.v = pMP->mTrackProjY;
-        e.radius = r*F.mvScaleFactors[nPredictedLevel];
-        e.min_level = nPredictedLevel-1;
-        e.max_level = nPredictedLevel;
-        e.proj_xr = pMP->mTrackProjXR;                         // ref: :94
-        e.flags = ORBHIP_Q_ACTIVE | (pMP->Observations()>0 ? ORBHIP_Q_OBSERVED : 0);
-        const cv::Mat MPdescriptor = pMP->GetDescriptor();
-        memcpy(&qdesc[(size_t)iMP * 32], MPdescriptor.ptr(0), 32);
+        float radius = RadiusByViewingCos(pt->mTrackViewCos);
+        if (widen) radius*=th;
+        orbhip_proj_query &e = q[k];
+        e.u = pt->mTrackProjX;                                 // ref: :68-69
+        e.v = pt->mTrackProjY;
+        e.radius = radius*F.mvScaleFactors[level];
+        e.min_level = level-1;
+        e.max_level = level;
+        e.proj_xr = pt->mTrackProjXR;                          // ref: :94
+        e.flags = ORBHIP_Q_ACTIVE | (pt->Observations()>0 ? ORBHIP_Q_OBSERVED : 0);
+        query_descriptor(pt, qdesc, k);
     }
     return run_projection_search(F, q, qdesc, vpMapPoints, true, mfNNratio, false, TH_HIGH);
 }
 
+namespace {
+// A frame's camera as the guided searches of Tracking use it: world -> camera -> pixel, and the bounds of the undistorted
+// image.  The float operations are those of the reference's loops in their order (the native guided test pins them): the
+// camera coordinates come out of one gemm (affine3), the reciprocal depth is a double division rounded to float, a pixel
+// coordinate is ((f * coordinate) * reciprocal depth) + principal point in float.
+struct FrameCamera {
+    cv::Mat R;                 // rotation block of mTcw
+    float t[3];                // translation column of mTcw
+    const Frame *F;
+
+    explicit FrameCamera(const Frame &frame): R(frame.mTcw.rowRange(0,3).colRange(0,3)), F(&frame)
+    {
+        for (int r = 0; r < 3; r++) t[r] = frame.mTcw.at<float>(r, 3);
+    }
+    void centre(float out[3]) const { affine3(R, t, NULL, out, true, -1.0); }   // -R' t
+    // false where the point lies outside the undistorted image; *invz is set either way (its sign is the caller's test)
+    bool project(const float xw[3], float *u, float *v, float *invz) const
+    {
+        float pc[3];
+        affine3(R, xw, t, pc);
+        const float iz = 1.0/pc[2];
+        *invz = iz;
+        *u = F->fx*pc[0]*iz+F->cx;
+        *v = F->fy*pc[1]*iz+F->cy;
+        return !(*u<Frame::mnMinX || *u>Frame::mnMaxX || *v<Frame::mnMinY || *v>Frame::mnMaxY);
+    }
+};
+
+inline void world_point(MapPoint *pMP, float xw[3])
+{
+    const cv::Mat p = pMP->GetWorldPos();
+    for (int k = 0; k < 3; k++) xw[k] = p.at<float>(k, 0);
+}
+
+inline void query_descriptor(MapPoint *pMP, vector<uint8_t> &qdesc, int slot)
+{
+    const cv::Mat d = pMP->GetDescriptor();
+    memcpy(&qdesc[(size_t)slot * 32], d.ptr(0), 32);
+}
+}  // namespace
+
+// Tracking::TrackWithMotionModel (ref: src/ORBmatcher.cc:1340-1498): every point the last frame holds is projected with the
+// current frame's predicted pose and searched in a window around the projection, on the octaves the camera's motion along its
+// axis allows.
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
 {
-    // ref: :1351-1365 -- camera pose pieces
-    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0,3).colRange(0,3);
-    const cv::Mat Rlw = LastFrame.mTcw.rowRange(0,3).colRange(0,3);
-    float tcw[3], tlw[3], twc[3], tlc[3];
-    for (int r = 0; r < 3; r++) {
-        tcw[r] = CurrentFrame.mTcw.at<float>(r, 3);
-        tlw[r] = LastFrame.mTcw.at<float>(r, 3);
-    }
-    affine3(Rcw, tcw, NULL, twc, true, -1.0);                  // twc = -Rcw.t()*tcw
-    affine3(Rlw, twc, tlw, tlc);                               // tlc = Rlw*twc+tlw
-
-    const bool bForward = tlc[2]>CurrentFrame.mb && !bMono;
-    const bool bBackward = -tlc[2]>CurrentFrame.mb && !bMono;
+    const FrameCamera cam(CurrentFrame), last(LastFrame);
+    // the current camera's centre in the last camera's frame: its z says whether the camera moved forward or backward by more
+    // than the stereo baseline (ref: :1351-1365; never for monocular input)
+    float centreW[3], centreL[3];
+    cam.centre(centreW);
+    affine3(last.R, centreW, last.t, centreL);
+    enum { SAME, FORWARD, BACKWARD } motion = SAME;
+    if (!bMono && centreL[2]>CurrentFrame.mb) motion = FORWARD;
+    else if (!bMono && -centreL[2]>CurrentFrame.mb) motion = BACKWARD;
 
     const int nq = LastFrame.N;
     vector<orbhip_proj_query> q(nq);
     vector<uint8_t> qdesc((size_t)nq * 32, 0);
-    for(int i=0; i<nq; i++)
-    {
+    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)nq);
+    for (int i = 0; i < nq; i++) {
+        MapPoint *pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP || LastFrame.mvbOutlier[i]) continue;
+        float xw[3], u, v, invz;
+        world_point(pMP, xw);
+        const bool inside = cam.project(xw, &u, &v, &invz);    // ref: :1376-1398
+        if (invz<0 || !inside) continue;
+        const int octave = LastFrame.mvKeys[i].octave;
         orbhip_proj_query &e = q[i];
-        memset(&e, 0, sizeof(e));
-        MapPoint* pMP = LastFrame.mvpMapPoints[i];
-        if(!pMP)
-            continue;
-        if(LastFrame.mvbOutlier[i])
-            continue;
-
-        // Project (ref: :1376-1398)
-        const cv::Mat x3Dw = pMP->GetWorldPos();
-        const float xw[3] = {x3Dw.at<float>(0, 0), x3Dw.at<float>(1, 0), x3Dw.at<float>(2, 0)};
-        float x3Dc[3];
-        affine3(Rcw, xw, tcw, x3Dc);
-
-        const float xc = x3Dc[0];
-        const float yc = x3Dc[1];
-        const float invzc = 1.0/x3Dc[2];
-
-        if(invzc<0)
-            continue;
-
-        float u = CurrentFrame.fx*xc*invzc+CurrentFrame.cx;
-        float v = CurrentFrame.fy*yc*invzc+CurrentFrame.cy;
-
-        if(u<CurrentFrame.mnMinX || u>CurrentFrame.mnMaxX)
-            continue;
-        if(v<CurrentFrame.mnMinY || v>CurrentFrame.mnMaxY)
-            continue;
-
-        int nLastOctave = LastFrame.mvKeys[i].octave;
-
-        // Search in a window. Size depends on scale (ref: :1403-1416)
         e.u = u;
         e.v = v;
-        e.radius = th*CurrentFrame.mvScaleFactors[nLastOctave];
-        if(bForward) {
-            e.min_level = nLastOctave;
-            e.max_level = -1;
-        } else if(bBackward) {
-            e.min_level = 0;
-            e.max_level = nLastOctave;
-        } else {
-            e.min_level = nLastOctave-1;
-            e.max_level = nLastOctave+1;
-        }
-        e.proj_xr = u - CurrentFrame.mbf*invzc;                // ref: :1435
+        e.radius = th*CurrentFrame.mvScaleFactors[octave];     // ref: :1403-1416
+        e.min_level = motion == FORWARD ? octave : motion == BACKWARD ? 0 : octave-1;
+        e.max_level = motion == FORWARD ? -1 : motion == BACKWARD ? octave : octave+1;
+        e.proj_xr = u - CurrentFrame.mbf*invz;                 // ref: :1435
         e.angle = LastFrame.mvKeysUn[i].angle;                 // ref: :1461
         e.flags = ORBHIP_Q_ACTIVE | (pMP->Observations()>0 ? ORBHIP_Q_OBSERVED : 0);
-        const cv::Mat dMP = pMP->GetDescriptor();
-        memcpy(&qdesc[(size_t)i * 32], dMP.ptr(0), 32);
+        query_descriptor(pMP, qdesc, i);
     }
     return run_projection_search(CurrentFrame, q, qdesc, LastFrame.mvpMapPoints, false, mfNNratio, mbCheckOrientation,
                                  TH_HIGH);
 }
 
+// Tracking::Relocalization (ref: src/ORBmatcher.cc:1500-1627): the key frame's points that PnP has not matched yet, projected
+// with the pose PnP found.  Best only, no right-coordinate test, every feature that holds a point is closed (:1565-1566),
+// threshold ORBdist, rotation histogram.
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th , const int ORBdist)
 {
-    // ref: src/ORBmatcher.cc:1500-1627 (relocalisation).  Best only, no right-coordinate test, every assigned
-    // feature is closed to the points after it (:1565-1566), threshold ORBdist, rotation histogram.
-    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0,3).colRange(0,3);
-    float tcw[3], Ow[3];
-    for (int r = 0; r < 3; r++) tcw[r] = CurrentFrame.mTcw.at<float>(r, 3);
-    affine3(Rcw, tcw, NULL, Ow, true, -1.0);                   // Ow = -Rcw.t()*tcw
+    const FrameCamera cam(CurrentFrame);
+    float Ow[3];
+    cam.centre(Ow);
 
     const vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
     const int nq = (int)vpMPs.size();
     vector<orbhip_proj_query> q(nq);
     vector<uint8_t> qdesc((size_t)nq * 32, 0);
-    for(int i=0; i<nq; i++)
-    {
-        orbhip_proj_query &e = q[i];
-        memset(&e, 0, sizeof(e));
-        MapPoint* pMP = vpMPs[i];
-        if(!pMP)
-            continue;
-        if(pMP->isBad() || sAlreadyFound.count(pMP))
-            continue;
-
-        //Project (ref: :1524-1539)
-        const cv::Mat x3Dw = pMP->GetWorldPos();
-        const float xw[3] = {x3Dw.at<float>(0, 0), x3Dw.at<float>(1, 0), x3Dw.at<float>(2, 0)};
-        float x3Dc[3];
-        affine3(Rcw, xw, tcw, x3Dc);
-
-        const float xc = x3Dc[0];
-        const float yc = x3Dc[1];
-        const float invzc = 1.0/x3Dc[2];
-
-        const float u = CurrentFrame.fx*xc*invzc+CurrentFrame.cx;
-        const float v = CurrentFrame.fy*yc*invzc+CurrentFrame.cy;
-
-        if(u<CurrentFrame.mnMinX || u>CurrentFrame.mnMaxX)
-            continue;
-        if(v<CurrentFrame.mnMinY || v>CurrentFrame.mnMaxY)
-            continue;
-
-        // Compute predicted scale level (ref: :1541-1553); cv::norm of a float vector sums the squares in double
+    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)nq);
+    for (int i = 0; i < nq; i++) {
+        MapPoint *pMP = vpMPs[i];
+        if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        float xw[3], u, v, invz;
+        world_point(pMP, xw);
+        if (!cam.project(xw, &u, &v, &invz)) continue;         // ref: :1524-1539 (no depth-sign test here)
+        // the octave the point should appear on at this distance (ref: :1541-1553); cv::norm sums the squares in double
         double sq = 0;
         for (int k = 0; k < 3; k++) {
             const float po = xw[k]-Ow[k];
             sq += (double)po*(double)po;
         }
-        float dist3D = std::sqrt(sq);
-
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-
-        // a point nearer or farther than the range its scale invariance covers cannot be matched at any level (ref: :1394-1396)
-        if(dist3D<minDistance || dist3D>maxDistance)
-            continue;
-
-        int nPredictedLevel = pMP->PredictScale(dist3D,&CurrentFrame);
-
-        // Search in a window (ref: :1555-1558)
+        const float dist3D = std::sqrt(sq);
+        if (dist3D<pMP->GetMinDistanceInvariance() || dist3D>pMP->GetMaxDistanceInvariance()) continue;
+        const int level = pMP->PredictScale(dist3D,&CurrentFrame);
+        orbhip_proj_query &e = q[i];
         e.u = u;
         e.v = v;
-        e.radius = th*CurrentFrame.mvScaleFactors[nPredictedLevel];
-        e.min_level = nPredictedLevel-1;
-        e.max_level = nPredictedLevel+1;
+        e.radius = th*CurrentFrame.mvScaleFactors[level];      // ref: :1555-1558
+        e.min_level = level-1;
+        e.max_level = level+1;
         e.angle = pKF->mvKeysUn[i].angle;                      // ref: :1587
         e.flags = ORBHIP_Q_ACTIVE | ORBHIP_Q_OBSERVED;
-        const cv::Mat dMP = pMP->GetDescriptor();
-        memcpy(&qdesc[(size_t)i * 32], dMP.ptr(0), 32);
+        query_descriptor(pMP, qdesc, i);
     }
     return run_projection_search(CurrentFrame, q, qdesc, vpMPs, false, mfNNratio, mbCheckOrientation, ORBdist, true, false);
 }
@@ -477,12 +445,6 @@ void decompose_sim3(const cv::Mat &Scw, cv::Mat &Rcw, float tcw[3], float Ow[3])
     scale3(sRcw, 1.0 / scw, false, Rcw);
     for (int r = 0; r < 3; r++) tcw[r] = (float)((double)Scw.at<float>(r, 3) * (1.0 / scw));
     affine3(Rcw, tcw, NULL, Ow, true, -1.0);                   // Ow = -Rcw.t()*tcw
-}
-
-inline void world_pos(MapPoint *pMP, float xw[3])
-{
-    const cv::Mat p = pMP->GetWorldPos();
-    xw[0] = p.at<float>(0, 0); xw[1] = p.at<float>(1, 0); xw[2] = p.at<float>(2, 0);
 }
 
 inline float norm3(const float a[3])                           // cv::norm of a float vector sums the squares in double
@@ -585,7 +547,7 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapP
         if(!pMP || pMP->isBad() || spAlreadyFound.count(pMP))
             continue;
         float xw[3], p3Dc[3], PO[3];
-        world_pos(pMP, xw);
+        world_point(pMP, xw);
         affine3(Rcw, xw, tcw, p3Dc);
         for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
         kf_window(pKF, pMP, p3Dc, PO, norm3(PO), (float)th, false, q[iMP], &qdesc[(size_t)iMP * 32]);
@@ -595,15 +557,15 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapP
     for (int i = 0; i < n && i < (int)vpMatched.size(); i++) occupied[i] = vpMatched[i] ? 1 : 0;
     const vector<uint8_t> d = contiguous(pKF->mDescriptors);
     vector<int32_t> match(n);
-    int nmatches = 0;
+    int found = 0;
     const int rc = orbhip_search_by_projection(
         tls.get(), reinterpret_cast<const orbhip_keypoint *>(pKF->mvKeysUn.data()), d.data(), n, NULL, occupied.data(),
         pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, q.data(), qdesc.data(), nq, 0,
-        mfNNratio, 0, TH_LOW, match.data(), &nmatches);
+        mfNNratio, 0, TH_LOW, match.data(), &found);
     if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByProjection", orbhip_last_error(tls.get())), 0;
     for (int i = 0; i < n; i++)
         if (match[i] >= 0) vpMatched[i] = vpPoints[match[i]];
-    return nmatches;
+    return found;
 }
 
 int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th)
@@ -627,7 +589,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const
         if(!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF))
             continue;
         float xw[3], p3Dc[3], PO[3];
-        world_pos(pMP, xw);
+        world_point(pMP, xw);
         affine3(Rcw, xw, tcw, p3Dc);
         for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
         kf_window(pKF, pMP, p3Dc, PO, norm3(PO), th, true, q[i], &qdesc[(size_t)i * 32]);
@@ -680,7 +642,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
         if(!pMP || pMP->isBad() || spAlreadyFound.count(pMP))
             continue;
         float xw[3], p3Dc[3], PO[3];
-        world_pos(pMP, xw);
+        world_point(pMP, xw);
         affine3(Rcw, xw, tcw, p3Dc);
         for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
         kf_window(pKF, pMP, p3Dc, PO, norm3(PO), th, false, q[iMP], &qdesc[(size_t)iMP * 32]);
@@ -759,7 +721,7 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
             if(pMP->isBad())
                 continue;
             float xw[3], pa[3], pb[3];
-            world_pos(pMP, xw);
+            world_point(pMP, xw);
             if (dir == 0) {
                 affine3(R1w, xw, t1w, pa);                     // p3Dc1 = R1w*p3Dw + t1w
                 affine3(sR21, pa, t21, pb);                    // p3Dc2 = sR21*p3Dc1 + t21
@@ -859,25 +821,25 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
             F[3*r+c] = F12.at<float>(r,c);
     const vector<uint8_t> d1 = contiguous(pKF1->mDescriptors), d2 = contiguous(pKF2->mDescriptors);
     vector<int> vMatches12(n1,-1);
-    int nmatches=0;
+    int found=0;
     const int rc = orbhip_search_for_triangulation(
         tls.get(), reinterpret_cast<const orbhip_keypoint *>(pKF1->mvKeysUn.data()), d1.data(), n1, skip1.data(),
         (int)pKF1->mvuRight.size()==n1 ? pKF1->mvuRight.data() : NULL, f1.node.data(), f1.off.data(), f1.idx.data(), (int)f1.node.size(),
         reinterpret_cast<const orbhip_keypoint *>(pKF2->mvKeysUn.data()), d2.data(), n2, skip2.data(),
         (int)pKF2->mvuRight.size()==n2 ? pKF2->mvuRight.data() : NULL, f2.node.data(), f2.off.data(), f2.idx.data(), (int)f2.node.size(),
         F, ex, ey, pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(), (int)pKF2->mvScaleFactors.size(),
-        bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, vMatches12.data(), &nmatches);
+        bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, vMatches12.data(), &found);
     if(rc != ORBHIP_OK)
         return hipdetail::Fail("ORBmatcher::SearchForTriangulation", orbhip_last_error(tls.get())), 0;
 
-    vMatchedPairs.reserve(nmatches);
+    vMatchedPairs.reserve(found);
     for(size_t i=0, iend=vMatches12.size(); i<iend; i++)
     {
         if(vMatches12[i]<0)
             continue;
         vMatchedPairs.push_back(make_pair(i,vMatches12[i]));
     }
-    return nmatches;
+    return found;
 }
 
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)
@@ -889,18 +851,18 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f
         return 0;
     if((int)vbPrevMatched.size()<n1)
         return hipdetail::Fail("ORBmatcher::SearchForInitialization", "vbPrevMatched is shorter than F1.mvKeysUn"), 0;
-    int nmatches=0;
+    int found=0;
     const int rc = orbhip_search_for_initialization(tls.get(), (const orbhip_keypoint *)F1.mvKeysUn.data(), F1.mDescriptors.ptr(0), n1,
                                                     (const orbhip_keypoint *)F2.mvKeysUn.data(), F2.mDescriptors.ptr(0), n2,
                                                     Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv,
                                                     Frame::mfGridElementHeightInv, (float *)vbPrevMatched.data(), windowSize,
-                                                    mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches);
+                                                    mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &found);
     if(rc != ORBHIP_OK)
     {
         vnMatches12.assign(n1,-1);
         return hipdetail::Fail("ORBmatcher::SearchForInitialization", orbhip_last_error(tls.get())), 0;
     }
-    return nmatches;
+    return found;
 }
 
 // ---- KeyFrame grid twin (ref: src/KeyFrame.cc:55-89, :1138-1177) ----

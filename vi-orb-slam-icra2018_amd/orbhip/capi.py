@@ -58,7 +58,7 @@ SYMBOLS = [
     "orbhip_undistort_keypoints", "orbhip_undistort_keypoints_device", "orbhip_init_undistort_rectify_map",
     "orbhip_remap_set_maps", "orbhip_remap", "orbhip_remap_device",
     "orbhip_set_put", "orbhip_set_has", "orbhip_set_drop", "orbhip_search_by_bow_sets", "orbhip_window_best_set",
-    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_vocab_generation", "orbhip_set_limit", "orbhip_debug_roundtrip", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
+    "orbhip_set_info", "orbhip_set_fingerprint", "orbhip_set_fingerprint_rows", "orbhip_vocab_share", "orbhip_vocab_generation", "orbhip_set_limit", "orbhip_debug_roundtrip", "orbhip_debug_path_mask", "orbhip_frame_build", "orbhip_frame_fingerprint", "orbhip_set_put_from_frame",
 ]
 
 
@@ -175,6 +175,10 @@ def load():
     L.orbhip_set_put.argtypes = [vp, C.c_uint64, vp, vp, i32, vp, vp, vp, i32, f32, f32, f32, f32]
     L.orbhip_set_has.argtypes = [vp, C.c_uint64, i32]
     L.orbhip_set_drop.argtypes = [vp, C.c_uint64]
+    L.orbhip_set_limit.argtypes = [vp, i32]
+    L.orbhip_set_limit.restype = i32
+    L.orbhip_debug_path_mask.argtypes = [i32]
+    L.orbhip_debug_path_mask.restype = C.c_uint32
     L.orbhip_search_by_bow_sets.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, i32, i32, f32, i32, vp, vp, ip]
     L.orbhip_window_best_set.argtypes = [vp, C.c_uint64, vp, vp, i32, vp, vp, i32, vp, vp]
     L.orbhip_set_info.argtypes = [vp, C.c_uint64, ip, ip, C.POINTER(C.c_uint64)]

@@ -382,6 +382,10 @@ class ORBmatcher:
         desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
         return int(capi.load().orbhip_set_fingerprint(_p(kps), _p(desc), len(kps)))
 
+    def set_limit(self, max_sets):
+        """At most `max_sets` resident sets (clamped to 4..96), least recently used out; returns the limit in force."""
+        return int(self._L.orbhip_set_limit(self._ctx.handle, int(max_sets)))
+
     def drop_set(self, key=0):
         check(self._L.orbhip_set_drop(self._ctx.handle, key), self._ctx.handle, "orbhip_set_drop")
 
