@@ -182,12 +182,12 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
     vector<uint8_t> valid1(n1, 0), valid2(n2, 0);
     vector<float> a1(n1, 0.f), a2(n2, 0.f);
     for (int i = 0; i < n1; i++) {
-        MapPoint *p = i < (int)vpMapPoints1.size() ? vpMapPoints1[i] : NULL;
+        MapPoint *p = i < (int)points1.size() ? points1[i] : NULL;
         valid1[i] = (p && !p->isBad()) ? 1 : 0;               // ref: :556-560
         a1[i] = pKF1->mvKeysUn[i].angle;
     }
     for (int i = 0; i < n2; i++) {
-        MapPoint *p = i < (int)vpMapPoints2.size() ? vpMapPoints2[i] : NULL;
+        MapPoint *p = i < (int)points2.size() ? points2[i] : NULL;
         valid2[i] = (p && !p->isBad()) ? 1 : 0;               // ref: :572-578
         a2[i] = pKF2->mvKeysUn[i].angle;
     }
@@ -199,7 +199,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
                                                  mbCheckOrientation ? 1 : 0, m12.data(), m21.data(), &found);
         if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
         for (int i1 = 0; i1 < n1 && i1 < (int)vpMatches12.size(); i1++)
-            if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];           // ref: :602
+            if (m12[i1] >= 0) vpMatches12[i1] = points2[m12[i1]];           // ref: :602
         return found;
     }
     const Csr c1 = flatten(pKF1->mFeatVec), c2 = flatten(pKF2->mFeatVec);
@@ -211,7 +211,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
                                         m12.data(), m21.data(), &found);
     if (rc != ORBHIP_OK) return hipdetail::Fail("ORBmatcher::SearchByBoW", orbhip_last_error(tls.get())), 0;
     for (int i1 = 0; i1 < n1 && i1 < (int)vpMatches12.size(); i1++)
-        if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];           // ref: :602
+        if (m12[i1] >= 0) vpMatches12[i1] = points2[m12[i1]];           // ref: :602
     return found;
 }
 
@@ -267,35 +267,6 @@ void affine3(const cv::Mat &R, const float x[3], const float t[3], float out[3],
 }
 }  // namespace
 
-int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
-{
-    // Tracking::SearchLocalPoints (ref: src/ORBmatcher.cc:41-128): the points Frame::isInFrustum marked, each with the
-    // projection and the octave it stored in the point.
-    const bool widen = th!=1.0;
-    const int nq = (int)vpMapPoints.size();
-    vector<orbhip_proj_query> q(nq);
-    vector<uint8_t> qdesc((size_t)nq * 32, 0);
-    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)nq);
-    for (int k = 0; k < nq; k++) {
-        MapPoint *pt = vpMapPoints[k];
-        if (!pt->mbTrackInView || pt->isBad()) continue;       // ref: :55-59
-        const int level = pt->mnTrackScaleLevel;
-        // window radius: narrow when the point is seen almost head-on, wider otherwise (ref: :130-138), times th on request
-        float radius = RadiusByViewingCos(pt->mTrackViewCos);
-        if (widen) radius*=th;
-        orbhip_proj_query &e = q[k];
-        e.u = pt->mTrackProjX;                                 // ref: :68-69
-        e.v = pt->mTrackProjY;
-        e.radius = radius*F.mvScaleFactors[level];
-        e.min_level = level-1;
-        e.max_level = level;
-        e.proj_xr = pt->mTrackProjXR;                          // ref: :94
-        e.flags = ORBHIP_Q_ACTIVE | (pt->Observations()>0 ? ORBHIP_Q_OBSERVED : 0);
-        query_descriptor(pt, qdesc, k);
-    }
-    return run_projection_search(F, q, qdesc, vpMapPoints, true, mfNNratio, false, TH_HIGH);
-}
-
 namespace {
 // A frame's camera as the guided searches of Tracking use it: world -> camera -> pixel, and the bounds of the undistorted
 // image.  The float operations are those of the reference's loops in their order (the native guided test pins them): the
@@ -336,6 +307,35 @@ inline void query_descriptor(MapPoint *pMP, vector<uint8_t> &qdesc, int slot)
     memcpy(&qdesc[(size_t)slot * 32], d.ptr(0), 32);
 }
 }  // namespace
+
+int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+{
+    // Tracking::SearchLocalPoints (ref: src/ORBmatcher.cc:41-128): the points Frame::isInFrustum marked, each with the
+    // projection and the octave it stored in the point.
+    const bool widen = th!=1.0;
+    const int nq = (int)vpMapPoints.size();
+    vector<orbhip_proj_query> q(nq);
+    vector<uint8_t> qdesc((size_t)nq * 32, 0);
+    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)nq);
+    for (int k = 0; k < nq; k++) {
+        MapPoint *pt = vpMapPoints[k];
+        if (!pt->mbTrackInView || pt->isBad()) continue;       // ref: :55-59
+        const int level = pt->mnTrackScaleLevel;
+        // window radius: narrow when the point is seen almost head-on, wider otherwise (ref: :130-138), times th on request
+        float radius = RadiusByViewingCos(pt->mTrackViewCos);
+        if (widen) radius*=th;
+        orbhip_proj_query &e = q[k];
+        e.u = pt->mTrackProjX;                                 // ref: :68-69
+        e.v = pt->mTrackProjY;
+        e.radius = radius*F.mvScaleFactors[level];
+        e.min_level = level-1;
+        e.max_level = level;
+        e.proj_xr = pt->mTrackProjXR;                          // ref: :94
+        e.flags = ORBHIP_Q_ACTIVE | (pt->Observations()>0 ? ORBHIP_Q_OBSERVED : 0);
+        query_descriptor(pt, qdesc, k);
+    }
+    return run_projection_search(F, q, qdesc, vpMapPoints, true, mfNNratio, false, TH_HIGH);
+}
 
 // Tracking::TrackWithMotionModel (ref: src/ORBmatcher.cc:1340-1498): every point the last frame holds is projected with the
 // current frame's predicted pose and searched in a window around the projection, on the octaves the camera's motion along its
@@ -468,9 +468,7 @@ bool kf_window(KeyFrame *pKF, MapPoint *pMP, const float p3Dc[3], const float *P
     const float v = pKF->fy*y+pKF->cy;
     if(!pKF->IsInImage(u,v))
         return false;
-    const float maxDistance = pMP->GetMaxDistanceInvariance();
-    const float minDistance = pMP->GetMinDistanceInvariance();
-    if(dist3D<minDistance || dist3D>maxDistance)
+    if (dist3D<pMP->GetMinDistanceInvariance() || dist3D>pMP->GetMaxDistanceInvariance())
         return false;
     if(PO)
     {
@@ -480,16 +478,16 @@ bool kf_window(KeyFrame *pKF, MapPoint *pMP, const float p3Dc[3], const float *P
         if(dot<0.5*dist3D)
             return false;
     }
-    const int nPredictedLevel = pMP->PredictScale(dist3D,pKF);
+    const int level = pMP->PredictScale(dist3D, pKF);
     e.u = u;
     e.v = v;
-    e.radius = th*pKF->mvScaleFactors[nPredictedLevel];
+    e.radius = th*pKF->mvScaleFactors[level];
     e.proj_xr = bf ? u-pKF->mbf*invz : 0.f;
-    e.min_level = nPredictedLevel-1;
-    e.max_level = nPredictedLevel;
+    e.min_level = level-1;
+    e.max_level = level;
     e.flags = ORBHIP_Q_ACTIVE | ORBHIP_Q_OBSERVED;
-    const cv::Mat dMP = pMP->GetDescriptor();
-    memcpy(qdesc, dMP.ptr(0), 32);
+    const cv::Mat dsc(pMP->GetDescriptor());
+    memcpy(qdesc, dsc.ptr(0), 32);
     return true;
 }
 
@@ -534,23 +532,22 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapP
     float tcw[3], Ow[3];
     decompose_sim3(Scw, Rcw, tcw, Ow);
 
-    set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
-    spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+    set<MapPoint*> known;
+    for (size_t i = 0; i < vpMatched.size(); i++)
+        if (vpMatched[i]) known.insert(vpMatched[i]);
 
     const int nq = (int)vpPoints.size(), n = (int)pKF->mvKeysUn.size();
     vector<orbhip_proj_query> q(nq);
     vector<uint8_t> qdesc((size_t)nq * 32, 0);
-    for(int iMP=0; iMP<nq; iMP++)
-    {
-        memset(&q[iMP], 0, sizeof(q[iMP]));
-        MapPoint* pMP = vpPoints[iMP];
-        if(!pMP || pMP->isBad() || spAlreadyFound.count(pMP))
-            continue;
+    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)nq);
+    for (int k = 0; k < nq; k++) {
+        MapPoint *pMP = vpPoints[k];
+        if (!pMP || pMP->isBad() || known.count(pMP)) continue;
         float xw[3], p3Dc[3], PO[3];
         world_point(pMP, xw);
         affine3(Rcw, xw, tcw, p3Dc);
         for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
-        kf_window(pKF, pMP, p3Dc, PO, norm3(PO), (float)th, false, q[iMP], &qdesc[(size_t)iMP * 32]);
+        kf_window(pKF, pMP, p3Dc, PO, norm3(PO), (float)th, false, q[k], &qdesc[(size_t)k * 32]);
     }
     if (n == 0 || nq == 0) return 0;
     vector<uint8_t> occupied(n, 0);
@@ -579,15 +576,13 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const
     float tcw[3], Ow[3];
     for (int r = 0; r < 3; r++) { tcw[r] = tcwM.at<float>(r, 0); Ow[r] = OwM.at<float>(r, 0); }
 
-    const int nMPs = vpMapPoints.size();
-    vector<orbhip_proj_query> q(nMPs);
-    vector<uint8_t> qdesc((size_t)nMPs * 32, 0);
-    for(int i=0; i<nMPs; i++)
-    {
-        memset(&q[i], 0, sizeof(q[i]));
-        MapPoint* pMP = vpMapPoints[i];
-        if(!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF))
-            continue;
+    const int npts = (int)vpMapPoints.size();
+    vector<orbhip_proj_query> q(npts);
+    vector<uint8_t> qdesc((size_t)npts * 32, 0);
+    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)npts);
+    for (int i = 0; i < npts; i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         float xw[3], p3Dc[3], PO[3];
         world_point(pMP, xw);
         affine3(Rcw, xw, tcw, p3Dc);
@@ -601,7 +596,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const
     // change what a later point of the same call sees: a point replaced a moment ago is bad now, a feature claimed a moment
     // ago holds a point now.  Both are therefore looked at here, not before the search (ref: :847-848 and :951-972).
     int fused = 0;
-    for (int i = 0; i < nMPs; i++) {
+    for (int i = 0; i < npts; i++) {
         MapPoint *cand = vpMapPoints[i];
         const bool usable = cand && !cand->isBad() && !cand->IsInKeyFrame(pKF);
         if (!usable || bestIdx[i] < 0 || bestDist[i] > TH_LOW) continue;
@@ -630,22 +625,20 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     decompose_sim3(Scw, Rcw, tcw, Ow);
 
     // points the key frame observes already are left out of the search (:995-996)
-    const set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+    const set<MapPoint*> held(pKF->GetMapPoints());
 
-    const int nPoints = vpPoints.size();
-    vector<orbhip_proj_query> q(nPoints);
-    vector<uint8_t> qdesc((size_t)nPoints * 32, 0);
-    for(int iMP=0; iMP<nPoints; iMP++)
-    {
-        memset(&q[iMP], 0, sizeof(q[iMP]));
-        MapPoint* pMP = vpPoints[iMP];
-        if(!pMP || pMP->isBad() || spAlreadyFound.count(pMP))
-            continue;
+    const int ncand = (int)vpPoints.size();
+    vector<orbhip_proj_query> q(ncand);
+    vector<uint8_t> qdesc((size_t)ncand * 32, 0);
+    memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)ncand);
+    for (int k = 0; k < ncand; k++) {
+        MapPoint *pMP = vpPoints[k];
+        if (!pMP || pMP->isBad() || held.count(pMP)) continue;
         float xw[3], p3Dc[3], PO[3];
         world_point(pMP, xw);
         affine3(Rcw, xw, tcw, p3Dc);
         for (int k = 0; k < 3; k++) PO[k] = xw[k]-Ow[k];
-        kf_window(pKF, pMP, p3Dc, PO, norm3(PO), th, false, q[iMP], &qdesc[(size_t)iMP * 32]);
+        kf_window(pKF, pMP, p3Dc, PO, norm3(PO), th, false, q[k], &qdesc[(size_t)k * 32]);
     }
     vector<int32_t> bestIdx, bestDist;
     run_window_best(pKF, q, qdesc, false, bestIdx, bestDist);
@@ -653,7 +646,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     // Loop closing does not replace points here (the caller does, under the map mutex): a feature that holds a good point is
     // reported through vpReplacePoint, a free one takes the candidate at once (ref: :1079-1096).
     int fused = 0;
-    for (int i = 0; i < nPoints; i++) {
+    for (int i = 0; i < ncand; i++) {
         const int feat = bestIdx[i];
         if (feat < 0 || bestDist[i] > TH_LOW) continue;
         MapPoint *held = pKF->GetMapPoint(feat);
@@ -673,10 +666,8 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
 {
     // ref: src/ORBmatcher.cc:1102-1326.  Poses of the two key frames (world -> camera) and the similarity between the cameras in
     // both directions; the two projection searches run on the device, the mutual-agreement pass on the host.
-    const cv::Mat R1w = pKF1->GetRotation();
-    const cv::Mat t1wM = pKF1->GetTranslation();
-    const cv::Mat R2w = pKF2->GetRotation();
-    const cv::Mat t2wM = pKF2->GetTranslation();
+    const cv::Mat R1w(pKF1->GetRotation()), t1wM(pKF1->GetTranslation());
+    const cv::Mat R2w(pKF2->GetRotation()), t2wM(pKF2->GetTranslation());
 
     cv::Mat sR12, sR21;
     scale3(R12, (double)s12, false, sR12);                     // s12*R12
@@ -685,41 +676,33 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
     for (int r = 0; r < 3; r++) { t1w[r] = t1wM.at<float>(r, 0); t2w[r] = t2wM.at<float>(r, 0); t12v[r] = t12.at<float>(r, 0); }
     affine3(sR21, t12v, NULL, t21, false, -1.0);               // t21 = -sR21*t12
 
-    const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
-    const int N1 = vpMapPoints1.size();
-
-    const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
-    const int N2 = vpMapPoints2.size();
+    const vector<MapPoint*> points1(pKF1->GetMapPointMatches()), points2(pKF2->GetMapPointMatches());
+    const int N1 = (int)points1.size(), N2 = (int)points2.size();
 
     // what the caller has matched already stays out of both searches (:1136-1151)
-    vector<bool> vbAlreadyMatched1(N1,false);
-    vector<bool> vbAlreadyMatched2(N2,false);
+    vector<bool> taken1(N1), taken2(N2);
     for (int i = 0; i < N1; i++) {
         MapPoint *known = vpMatches12[i];
         if (!known) continue;
-        vbAlreadyMatched1[i] = true;
+        taken1[i] = true;
         const int at2 = known->GetIndexInKeyFrame(pKF2);
-        if (at2 >= 0 && at2 < N2) vbAlreadyMatched2[at2] = true;
+        if (at2 >= 0 && at2 < N2) taken2[at2] = true;
     }
 
     // direction 0: the points of key frame 1 into key frame 2; direction 1: the other way round
     vector<int32_t> vnMatch1, vnMatch2, dist1, dist2;
     for (int dir = 0; dir < 2; dir++)
     {
-        const vector<MapPoint*> &vpMPs = dir == 0 ? vpMapPoints1 : vpMapPoints2;
-        const vector<bool> &vbAlready = dir == 0 ? vbAlreadyMatched1 : vbAlreadyMatched2;
+        const vector<MapPoint*> &src = dir == 0 ? points1 : points2;
+        const vector<bool> &taken = dir == 0 ? taken1 : taken2;
         KeyFrame *pKFdst = dir == 0 ? pKF2 : pKF1;
-        const int N = vpMPs.size();
+        const int N = (int)src.size();
         vector<orbhip_proj_query> q(N);
         vector<uint8_t> qdesc((size_t)N * 32, 0);
-        for(int i=0; i<N; i++)
-        {
-            memset(&q[i], 0, sizeof(q[i]));
-            MapPoint* pMP = vpMPs[i];
-            if(!pMP || vbAlready[i])
-                continue;
-            if(pMP->isBad())
-                continue;
+        memset(q.data(), 0, sizeof(orbhip_proj_query) * (size_t)N);
+        for (int i = 0; i < N; i++) {
+            MapPoint *pMP = src[i];
+            if (!pMP || taken[i] || pMP->isBad()) continue;
             float xw[3], pa[3], pb[3];
             world_point(pMP, xw);
             if (dir == 0) {
@@ -741,7 +724,7 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
     for (int i1 = 0; i1 < N1; i1++) {
         const int i2 = vnMatch1[i1];
         if (i2 >= 0 && vnMatch2[i2] == i1) {
-            vpMatches12[i1] = vpMapPoints2[i2];
+            vpMatches12[i1] = points2[i2];
             found++;
         }
     }
@@ -754,28 +737,20 @@ int ComputeDistinctiveDescriptors(const vector<MapPoint*> &vpMapPoints)
     vector<uint8_t> desc;
     vector<int32_t> off(1, 0);
     vector<MapPoint*> pts;
-    for(size_t i=0; i<vpMapPoints.size(); i++)
-    {
-        MapPoint* pMP = vpMapPoints[i];
-        if(!pMP || pMP->isBad())
-            continue;
-        const map<KeyFrame*,size_t> observations = pMP->GetObservations();
-        if(observations.empty())
-            continue;
+    typedef map<KeyFrame*,size_t> Seen;
+    for (size_t i = 0; i < vpMapPoints.size(); i++) {
+        MapPoint *pt = vpMapPoints[i];
+        if (!pt || pt->isBad()) continue;
+        const Seen seen(pt->GetObservations());
         const size_t before = desc.size();
-        for(map<KeyFrame*,size_t>::const_iterator mit=observations.begin(), mend=observations.end(); mit!=mend; mit++)
-        {
-            KeyFrame* pKF = mit->first;
-            if(!pKF->isBad())
-            {
-                const uint8_t *row = pKF->mDescriptors.ptr((int)mit->second);
-                desc.insert(desc.end(), row, row+32);
-            }
+        for (Seen::const_iterator it = seen.begin(); it != seen.end(); ++it) {
+            if (it->first->isBad()) continue;                  // ref: :299-300
+            const uint8_t *row = it->first->mDescriptors.ptr((int)it->second);
+            desc.insert(desc.end(), row, row+32);
         }
-        if(desc.size()==before)
-            continue;
+        if (desc.size() == before) continue;                   // no observation in a good key frame (:290, :305)
         off.push_back((int32_t)(desc.size()/32));
-        pts.push_back(pMP);
+        pts.push_back(pt);
     }
     const int P = (int)pts.size();
     if (P == 0) return 0;
@@ -796,9 +771,7 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
 {
     // ref: src/ORBmatcher.cc:657-827.  Epipole in the second image (:664-671) on the host; the node-grouped search with
     // the epipolar tests and the rotation histogram in one call.
-    cv::Mat Cw = pKF1->GetCameraCenter();
-    cv::Mat R2w = pKF2->GetRotation();
-    cv::Mat t2w = pKF2->GetTranslation();
+    const cv::Mat Cw(pKF1->GetCameraCenter()), R2w(pKF2->GetRotation()), t2w(pKF2->GetTranslation());
     const float cw[3] = {Cw.at<float>(0, 0), Cw.at<float>(1, 0), Cw.at<float>(2, 0)};
     const float t2[3] = {t2w.at<float>(0, 0), t2w.at<float>(1, 0), t2w.at<float>(2, 0)};
     float C2[3];
@@ -833,12 +806,8 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
         return hipdetail::Fail("ORBmatcher::SearchForTriangulation", orbhip_last_error(tls.get())), 0;
 
     vMatchedPairs.reserve(found);
-    for(size_t i=0, iend=vMatches12.size(); i<iend; i++)
-    {
-        if(vMatches12[i]<0)
-            continue;
-        vMatchedPairs.push_back(make_pair(i,vMatches12[i]));
-    }
+    for (int i = 0; i < n1; i++)
+        if (vMatches12[i] >= 0) vMatchedPairs.push_back(pair<size_t, size_t>(i, vMatches12[i]));
     return found;
 }
 
@@ -873,30 +842,25 @@ void KeyFrame::CopyGridFrom(const Frame &F)
     mfGridElementWidthInv = Frame::mfGridElementWidthInv;
     mfGridElementHeightInv = Frame::mfGridElementHeightInv;
     mnMinX = Frame::mnMinX; mnMinY = Frame::mnMinY; mnMaxX = Frame::mnMaxX; mnMaxY = Frame::mnMaxY;
-    mGrid.resize(mnGridCols);
-    for(int i=0; i<mnGridCols;i++)
-    {
-        mGrid[i].resize(mnGridRows);
-        for(int j=0; j<mnGridRows; j++)
-            mGrid[i][j] = F.mGrid[i][j];
-    }
+    mGrid.assign(mnGridCols, vector<vector<size_t> >(mnGridRows));
+    for (int c = 0; c < mnGridCols; c++)
+        for (int r = 0; r < mnGridRows; r++) mGrid[c][r] = F.mGrid[c][r];
 }
 
 vector<size_t> KeyFrame::GetFeaturesInArea(const float &x, const float &y, const float &r) const
 {
     // the window query of liborbhip on mvKeysUn (the grid it builds from them is the one mGrid holds)
-    vector<size_t> vIndices;
+    vector<size_t> inside;
     const int n = (int)mvKeysUn.size();
-    if(n==0)
-        return vIndices;
+    if (n == 0) return inside;
     orbhip_proj_query q = {x, y, r, 0.f, -1, -1, 0.f, ORBHIP_Q_ACTIVE};
     vector<int32_t> idx(n);
     int32_t off[2] = {0, 0};
     if(orbhip_features_in_area(tls.get(), reinterpret_cast<const orbhip_keypoint *>(mvKeysUn.data()), n, mnMinX, mnMinY,
                                mfGridElementWidthInv, mfGridElementHeightInv, &q, 1, off, idx.data(), n) != ORBHIP_OK)
-        return hipdetail::Fail("KeyFrame::GetFeaturesInArea", orbhip_last_error(tls.get())), vIndices;
-    vIndices.assign(idx.begin(), idx.begin() + off[1]);
-    return vIndices;
+        return hipdetail::Fail("KeyFrame::GetFeaturesInArea", orbhip_last_error(tls.get())), inside;
+    inside.assign(idx.begin(), idx.begin() + off[1]);
+    return inside;
 }
 
 void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3)
