@@ -51,12 +51,14 @@ def fast_algorithmic_bytes(w, h, nlevels, level_size):
 
 
 def stage_algorithmic_bytes(w, h, nlevels, level_size, keypoints):
-    """SURVEY.md section 8d, per frame: pyramid = every level but the last read + every level but the first written; blur =
-    every level read and written; describe = 749 disc bytes + 512 test bytes read and 28 + 32 bytes written per keypoint."""
+    """SURVEY.md section 8d, per frame: pyramid = every level but the last read + every level but the first written; describe
+    (round 6: k_describe_blur, the 7 x 7 blur inside the describe kernel -- no blurred pyramid is written or read) = the 43 x 43 raw
+    pixels a keypoint's blurred 37 x 37 patch and its orientation disc depend on, read once, and 28 + 32 bytes written per
+    keypoint.  (Rounds 1-5: k_blur read and wrote every level, k_describe read 749 disc bytes + 512 test bytes per keypoint.)"""
     px = [level_size(w, h, l) for l in range(nlevels)]
     px = [a * b for a, b in px]
-    return {"k_resize (7 launches)": sum(px[:-1]) + sum(px[1:]), "k_blur": 2 * sum(px),
-            "k_describe (2 launches)": int(round(keypoints * (749 + 512 + 60))),
+    return {"k_resize (7 launches)": sum(px[:-1]) + sum(px[1:]),
+            "k_describe_blur (2 launches)": int(round(keypoints * (43 * 43 + 60))),
             "k_fast": fast_algorithmic_bytes(w, h, nlevels, level_size)}
 
 
@@ -1111,7 +1113,7 @@ def main():
         VALU_ISSUE_WEIGHT = float(ctr.get("issue_weight", 0.835))
         kp_mean = float(counts.mean())
         alg_stage = stage_algorithmic_bytes(W, H, 8, ex0.level_size, kp_mean)
-        stage_of = {"k_resize (7 launches)": 0, "k_blur": 3, "k_describe (2 launches)": 4, "k_fast": 1}
+        stage_of = {"k_resize (7 launches)": 0, "k_describe_blur (2 launches)": 4, "k_fast": 1}
         rooflines = []
         for kname, by in alg_stage.items():
             ms_k = float(stage[stage_of[kname]]) / NC

@@ -162,7 +162,8 @@ def test_stage_timing_modes_change_no_result():
     ex = ORBextractor(600, 1.2, 6, 20, 7, max_w=W, max_h=H, max_batch=B)
     L = ex._L
     want = None
-    for mode, nonzero in ((2, {0, 1, 2, 3, 4}), (1, {1}), (0, set())):
+    # (stage 3 -- k_blur -- reads 0 since round 6: a batch blurs inside the describe kernel and never launches it)
+    for mode, nonzero in ((2, {0, 1, 2, 4}), (1, {1}), (0, set())):
         assert L.orbhip_set_stage_timing(ex.handle, mode) == 0
         ks, ds = ex.extract_batch(frames)
         ms = (C.c_float * 6)()

@@ -65,7 +65,7 @@ def path_mask(reset=False):
 
 PATH_BITS = {"k_fast_fix": 0, "k_fast": 1, "k_resize_fit": 2, "k_resize<32>/<8>": 3, "k_pyramid_chain": 4, "k_quadtree(lds)": 5,
              "k_quadtree(lds points)": 6, "k_quadtree(global)": 7, "k_bow_lane": 8, "k_bow_seq(lds)": 9, "k_bow_seq(global)": 10,
-             "k_fast_fix(tall)": 11}
+             "k_fast_fix(tall)": 11, "k_describe": 12, "k_describe_blur": 13, "k_blur": 14}
 
 
 def paths_of(mask):
@@ -386,17 +386,21 @@ def test_random_extraction_configurations_match_oracle(oracle, tally):
     # quadtree tables in global memory
     assert s["reached"]["k_fast"] >= 20 and s["reached"]["k_quadtree(global)"] >= 10 and s["reached"]["k_resize<32>/<8>"] >= 4, s
     assert "k_fast_fix" in s["paths"] and "k_resize_fit" in s["paths"] and "k_pyramid_chain" in s["paths"], s
+    # batches blur inside the describe kernel (r06); a frame or two keep k_blur + k_describe
+    assert "k_describe_blur" in s["paths"] and "k_describe" in s["paths"] and "k_blur" in s["paths"], s
     tally("extraction configs (shipped switches default)", s["configs"])
     tally("extraction keypoints compared", s["keypoints"])
     for k, v in s["reached"].items():
         tally("extraction configs that ran " + k, v)
 
 
-@pytest.mark.parametrize("env", [{"ORBHIP_FAST_FIX": "0", "ORBHIP_NO_CHAIN": "1"}, {"ORBHIP_NO_GRAPH": "1", "ORBHIP_RESIZE_FIT": "0"}],
-                         ids=["fast_generic+no_chain", "no_graph+resize_tiles"])
+@pytest.mark.parametrize("env", [{"ORBHIP_FAST_FIX": "0", "ORBHIP_NO_CHAIN": "1"}, {"ORBHIP_NO_GRAPH": "1", "ORBHIP_RESIZE_FIT": "0"},
+                                 {"ORBHIP_DESCRIBE_FUSED": "0"}],
+                         ids=["fast_generic+no_chain", "no_graph+resize_tiles", "blur_and_describe_as_two_kernels"])
 def test_random_extraction_configurations_other_switches(env, tally):
     """The same generator in a child process under the shipped switches' other positions (k_fast for every grid, one launch per
-    pyramid level, no hipGraph) and with the fitted resize tiles off (k_resize<32> for every batch; ablation build)."""
+    pyramid level, no hipGraph) and with the fitted resize tiles off (k_resize<32> for every batch; ablation build), and with the blur as a kernel of its own for batches
+    too (k_blur + k_describe, the path of rounds 1-5; ablation build)."""
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "100", "777"], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -404,6 +408,8 @@ def test_random_extraction_configurations_other_switches(env, tally):
     assert s["configs"] == 100
     if "ORBHIP_FAST_FIX" in env:
         assert "k_fast" in s["paths"] and "k_fast_fix" not in s["paths"] and "k_pyramid_chain" not in s["paths"], s
+    elif "ORBHIP_DESCRIBE_FUSED" in env:
+        assert "k_describe_blur" not in s["paths"] and "k_describe" in s["paths"] and "k_blur" in s["paths"], s
     else:
         assert "k_resize_fit" not in s["paths"] and "k_resize<32>/<8>" in s["paths"], s
     tally("extraction configs (other switch positions)", s["configs"])

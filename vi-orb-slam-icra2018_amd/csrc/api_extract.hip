@@ -341,6 +341,11 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     // time is one workgroup's latency), everything on one stream (a cross-stream hand-over costs more than it hides).
     const int blurPlace = c->blurPlace;
     const size_t blurFrame = c->lvl0FrameBytes + c->pyrFrameBytes;
+    // r06, batches: the blur inside the describe kernel (k_describe_blur) -- no blurred pyramid, no k_blur.  Schedule:
+    //     main stream  : FAST(all) | quadtree(A) | describe+blur(A)       | describe+blur(B)
+    //     second stream:                         | quadtree(B)            |
+    // (orbhip_set_blur_placement 1 / 2 are measurements of k_blur: they keep the two-kernel path)
+    const bool fusedDescribe = blurPlace == 0 && !fuseBlur && describe_blur_available(G, B);
     auto blur_all = [&](hipStream_t st) {
         launch_blur(st, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur, blurFrame, c->d_blurTiles,
                     fuseBlur ? c->blurLevelFirst[1] : (int)c->blurTiles.size(), c->d_blurBands, B);
@@ -354,6 +359,13 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
                         c->d_lvlKpCnt + (size_t)b0 * ORBHIP_MAX_LEVELS, nb, c->d_qtTables ? c->d_qtTables + (size_t)b0 * qtPerFrame : nullptr);
     };
     auto describe_part = [&](hipStream_t st, int b0, int nb) {
+        if (fusedDescribe) {
+            launch_describe_blur(st, G, lvl0 + (size_t)b0 * frame0, stride0, frame0, c->d_pyr + (size_t)b0 * c->pyrFrameBytes,
+                                 c->pyrFrameBytes, c->d_lvlKp + (size_t)b0 * G.totalKps, c->d_lvlKpCnt + (size_t)b0 * ORBHIP_MAX_LEVELS,
+                                 c->d_lvlAngle + (size_t)b0 * G.totalKps, d_kps + (size_t)b0 * cap, d_desc + (size_t)b0 * cap * 32,
+                                 d_counts + b0, cap, nb);
+            return;
+        }
         launch_describe(st, G, lvl0 + (size_t)b0 * frame0, stride0, frame0, c->d_pyr + (size_t)b0 * c->pyrFrameBytes, c->pyrFrameBytes,
                         c->d_blur + (size_t)b0 * blurFrame, blurFrame, c->d_lvlKp + (size_t)b0 * G.totalKps,
                         c->d_lvlKpCnt + (size_t)b0 * ORBHIP_MAX_LEVELS, c->d_lvlAngle + (size_t)b0 * G.totalKps, d_kps + (size_t)b0 * cap,
@@ -373,8 +385,28 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
         launch_fast(s, G, lvl0, stride0, frame0, c->d_pyr, c->pyrFrameBytes, c->d_fastTiles + c->nFastTilesBatch,
                     (int)c->fastTiles.size() - c->nFastTilesBatch, c->d_cand, c->d_cellCnt, B);
     if (evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));
+#ifndef DF_SCHED
+#define DF_SCHED 1
+#endif
     static const bool noSplit = ORB_TUNE("NO_SPLIT", 0) != 0;   // A/B: r02 schedule
-    if (B >= 16 && blurPlace == 0 && !noSplit) {
+    static const int fusedSched = ORB_TUNE("DESCRIBE_FUSED_SCHED", DF_SCHED);   // 1: quadtree(B) beside describe(A); 0: one quadtree launch
+    if (fusedDescribe && B >= 16 && fusedSched == 1) {
+        const int nA = B / 2, nB = B - nA;
+        quadtree_part(s, 0, nA);
+        HIPCHK(c, hipEventRecord(c->ev[3], s));                 // quadtree(A) is done: the second stream may start quadtree(B)
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[3], 0));
+        quadtree_part(c->stream2, nA, nB);
+        HIPCHK(c, hipEventRecord(c->evx[0], c->stream2));
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
+        describe_part(s, 0, nA);
+        HIPCHK(c, hipStreamWaitEvent(s, c->evx[0], 0));
+        describe_part(s, nA, nB);
+    } else if (fusedDescribe) {
+        quadtree_part(s, 0, B);
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[3], s));
+        if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
+        describe_part(s, 0, B);
+    } else if (B >= 16 && blurPlace == 0 && !noSplit) {
         const int nA = B / 2, nB = B - nA;
         if (!evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));   // (the hand-over event; the timing path has recorded it)
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
@@ -431,6 +463,7 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
     c->last_stride0 = stride0;
     c->last_frame0 = frame0;
     c->last_B = B;
+    c->blurValid = !fusedDescribe;   // (orbhip_debug_get_blurred_level builds the blurred pyramid on request)
     return ORBHIP_OK;
 }
 
@@ -460,7 +493,7 @@ extern "C" int orbhip_get_stage_times(orbhip_ctx *c, float ms[6])
         HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));    // pyramid
         HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));    // FAST
         HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]));    // quadtree (overlaps the blur)
-        HIPCHK(c, hipEventElapsedTime(&ms[3], c->evx[1], c->evx[2]));  // blur (second stream)
+        if (c->blurValid) HIPCHK(c, hipEventElapsedTime(&ms[3], c->evx[1], c->evx[2]));  // blur (second stream; none with k_describe_blur)
         HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[4], c->ev[5]));    // describe
     }
     if (c->haveMatchEvents) HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[6], c->ev[7]));
@@ -746,6 +779,13 @@ extern "C" int orbhip_debug_get_blurred_level(orbhip_ctx *c, int frame, int leve
     if (!dst) return ORBHIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bf = c->lvl0FrameBytes + c->pyrFrameBytes;
+    if (!c->blurValid) {
+        // the last batch ran k_describe_blur and never built the blurred pyramid: k_blur on the same levels, now
+        launch_blur(c->stream, c->G, c->last_lvl0, c->last_stride0, c->last_frame0, c->d_pyr, c->pyrFrameBytes, c->d_blur, bf,
+                    c->d_blurTiles, (int)c->blurTiles.size(), c->d_blurBands, c->last_B);
+        HIPCHK(c, hipGetLastError());
+        c->blurValid = true;
+    }
     const uint8_t *src = c->d_blur + (size_t)frame * bf + (level == 0 ? 0 : c->G.boff1 + L.imgOff);
     return copy_level(c, src, level == 0 ? c->G.bstride0 : L.stride, L.w, L.h, dst, dst_stride);
 }

@@ -641,6 +641,7 @@ void launch_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int str
                  const BlurTile *tiles, int ntiles, const uint32_t *bands, int B)
 {
     if (ntiles <= 0) return;
+    orb_path(ORB_PATH_BLUR);
     dim3 grid(orb_xcd_grid((ntiles + BM_TPW - 1) / BM_TPW, 2), B, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_blur, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr,
                        (unsigned long long)pyrFrame, blur, (unsigned long long)blurFrame, tiles,

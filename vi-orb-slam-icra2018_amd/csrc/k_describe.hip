@@ -483,11 +483,451 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
     }
 }
 
+// =====================================================================================================================
+// r06: the blur INSIDE the describe kernel.  The only consumer of the blurred pyramid is the 37 x 37 patch
+// around a retained keypoint (ref: src/ORBextractor.cc:1103-1107 blurs the whole level, :109-149 reads 512 pixels of it), so a
+// batch never builds that pyramid: a wave stages the 43 x 43 RAW neighbourhood of its keypoint (rows cy - 21 .. cy + 21, 48 bytes
+// from column cx - 23, by three byte-unaligned global_load_lds_dwordx4 -- the next keypoint's travel while this one is computed),
+// runs k_blur's two passes on it -- the same arithmetic on the 16 x 16 MFMA shapes, a keypoint being 3 x 3 tiles of them:
+//   row pass     v_mfma_i32_16x16x64_i8: H[row][col] = sum_c (p[row][c] - 128) Kx[c][col] + 128 * 257; A = 16 rows x 64 bytes
+//                straight from LDS (ds_read_b128; the lanes of the upper half of K multiply zeros of the band), B = the taps'
+//                band, a per-lane constant; the result tile has its column on the lane and four rows in the lane's registers;
+//   column pass  v_mfma_f32_16x16x32_f16 with two row-pass tiles (rows 0-15 and 16-31 of a block) as the B operand IN PLACE:
+//                the contraction runs over the tiles' row index, which lives in the registers; k-slot j of lane quarter q is
+//                row 4q + j (j < 4) or 16 + 4q + j - 4, and the band operand A is laid out for exactly that order; byte planes
+//                as binary16 0x0400 | byte, weights tap * 2^8, accumulator started at minus the constant part: exact (k_blur.hip);
+//   rounding     v_cvt_pk_u8_f32 = round half to even + saturation (the SSE2 column filter of OpenCV 2.4 for x < w - w % 4);
+//                keypoints whose patch reaches the scalar tail's columns take floor(v + 0.5) there (wave-uniform branch);
+// -- writes the blurred 37 x 37 patch over the raw one (transposed, [column][row], pitch 40) and runs the 256 tests on it.
+// Image borders (BORDER_REFLECT_101 in LEVEL coordinates): rows by reflecting the row index of the transfer; the two columns
+// a keypoint 19-20 pixels from the left / right edge reaches beyond it are patched into the staged rows (rare, wave-uniform).
+// Phases 0, A (IC angle from the raw level, one 16-byte load per lane) and B are those of k_describe<16, true>.
+// k_blur stays for a frame or two and for orbhip_debug_get_blurred_level.
+// =====================================================================================================================
+#define DF_ROWS 48                    // staged raw rows: 43 needed, the rest complete the three 16-row tiles
+#define DF_PITCH 48                   // bytes per staged row: columns cx - 23 .. cx + 24 (12 dwords: the A operand's 16 rows fall on distinct banks)
+#define DF_A 2                        // byte of column cx - 21 (the first one the blur reads) in a staged row
+#define DF_RAW (DF_ROWS * DF_PITCH)   // 2304
+#define DF_BUF 2368                   // + 64: the upper-K lanes of the last rows' A operand read (and ignore) bytes beyond the image
+#ifndef DF_WG_PER_CU
+#define DF_WG_PER_CU 5                // 96 registers per lane: the nine row-pass tiles and their planes are live together
+#endif
+#ifndef DF_SKIP_CORNER
+#define DF_SKIP_CORNER 1
+#endif
+#define DF_OP 40                      // pitch of the blurred patch, [column 0..36][row 0..36 (+3)]
+typedef int dfv4i __attribute__((ext_vector_type(4)));
+typedef float dfv4f __attribute__((ext_vector_type(4)));
+typedef float dfv2f __attribute__((ext_vector_type(2)));
+typedef _Float16 dfv8h __attribute__((ext_vector_type(8)));
+
+struct DfBands {
+    unsigned row[64][4];   // B operand of the row pass: lane (n = l & 15, q = l >> 4), byte j: tap[16 q + j - n - DF_A]
+    unsigned col[64][4];   // A operand of the column pass: lane (m = l & 15, q), half j: tap[row(q, j) - m] * 256 as binary16
+};
+constexpr unsigned df_half_bits(int v)   // binary16 pattern of a small positive integer (exact below 2048 * 2^k)
+{
+    if (v == 0) return 0;
+    int e = 0, m = v;
+    while (m >= 2048) { m >>= 1; e++; }
+    while (m < 1024) { m <<= 1; e--; }
+    return (unsigned)(((e + 25) << 10) | (m & 1023));   // m in [1024, 2048): value m * 2^e = 1.f * 2^(e + 10)
+}
+constexpr DfBands make_df_bands()
+{
+    constexpr int tap[7] = {18, 34, 49, 55, 49, 34, 18};
+    DfBands b{};
+    for (int l = 0; l < 64; l++) {
+        const int n = l & 15, q = l >> 4;
+        for (int j = 0; j < 16; j++) {
+            const int i = 16 * q + j - n - DF_A;
+            const unsigned v = (i >= 0 && i <= 6) ? (unsigned)tap[i] : 0u;
+            b.row[l][j >> 2] |= v << (8 * (j & 3));
+        }
+        for (int j = 0; j < 8; j++) {
+            const int r = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4), i = r - n;
+            const unsigned v = (i >= 0 && i <= 6) ? df_half_bits(tap[i] * 256) : 0u;
+            b.col[l][j >> 1] |= v << (16 * (j & 1));
+        }
+    }
+    return b;
+}
+__constant__ __attribute__((aligned(16))) DfBands c_df_bands = make_df_bands();
+static_assert(df_half_bits(18 * 256) == 0x6C80 && df_half_bits(55 * 256) == 0x72E0, "binary16 of tap * 256");
+
+__device__ __forceinline__ void df_glds16(const void *gsrc, uint32_t ldsAddr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(ldsAddr)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLevels G, const uint8_t *__restrict__ lvl0, int stride0,
+                                                          unsigned long long frame0, const uint8_t *__restrict__ pyr,
+                                                          unsigned long long pyrFrame, const uint32_t *__restrict__ lvlKp,
+                                                          const int32_t *__restrict__ lvlKpCnt, float *__restrict__ lvlAngle,
+                                                          orbhip_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                          int32_t *__restrict__ counts, int cap, int xcdMap ORB_ABL_PARAM)
+{
+    constexpr int DS_KP = 16;
+    __shared__ int s_pos[DS_KP], s_out[DS_KP], s_m10[DS_KP], s_m01[DS_KP];
+    __shared__ float s_a[DS_KP], s_b[DS_KP];
+    __shared__ unsigned s_ioff[DS_KP];
+    __shared__ int s_istride[DS_KP], s_wh[DS_KP];      // level width | height << 16
+    __shared__ __align__(16) uint8_t s_raw[4][2][DF_BUF];
+    int blk = xcd_tile(xcdMap), frame = blockIdx.y;
+    if ((xcdMap & 255) == 4) xcd_frame_tile((int)gridDim.y, blk, frame);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g0 = blk * DS_KP;
+    if (g0 >= G.totalKps) return;
+    const int32_t *cnts = lvlKpCnt + frame * ORBHIP_MAX_LEVELS;
+
+    // ---- 0. slot -> (level, position, output index): as k_describe ----
+    int my_score = 0;
+    if (tid < DS_KP) {
+        const int g = g0 + tid;
+        int pos = -1, o = 0;
+        if (g < G.totalKps) {
+            int l = 0, off = 0, total = 0;
+            for (int k = 0; k < G.nlevels; k++) {
+                if (g >= G.lv[k].kpBase) {
+                    l = k;
+                    off = total;
+                }
+                total += cnts[k];
+            }
+            if (g == 0) counts[frame] = total;
+            const int i = g - G.lv[l].kpBase;
+            if (i < cnts[l]) {
+                const uint32_t pk = lvlKp[(size_t)frame * G.totalKps + g];
+                const int cx = (int)(pk & 0xFFFu) + ORB_MIN_BORDER;
+                const int cy = (int)((pk >> 12) & 0xFFFu) + ORB_MIN_BORDER;
+                my_score = (int)(pk >> 24);
+                pos = cx | (cy << 12) | (l << 24);
+                o = off + i;
+            }
+        }
+        s_pos[tid] = pos;
+        s_out[tid] = o;
+        const int l = pos >= 0 ? pos >> 24 : 0;
+        s_ioff[tid] = l == 0 ? 0u : (unsigned)G.lv[l].imgOff;
+        s_istride[tid] = l == 0 ? stride0 : G.lv[l].stride;
+        s_wh[tid] = G.lv[l].w | (G.lv[l].h << 16);
+    }
+    __syncthreads();
+    ORB_ABL_STOP(phases < 1);
+
+    // the raw neighbourhood of slot kp -> buf: lane (row of 21, chunk of 3); rows 43.. repeat row 42
+    const int drow = (lane * 43) >> 7, dchunk = lane - 3 * drow;   // lane / 3, lane % 3 (lane 63: row 21, not sent)
+    auto stage = [&](int kp, uint8_t *buf) -> bool {
+        const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+        if (pos < 0 || __builtin_amdgcn_readfirstlane(s_out[kp]) >= cap) return false;
+        const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+        const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0
+                                    : pyr + (size_t)frame * pyrFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_ioff[kp]);
+        const int stride = __builtin_amdgcn_readfirstlane(s_istride[kp]);
+        const int wh = __builtin_amdgcn_readfirstlane(s_wh[kp]), w = wh & 0xFFFF, h = wh >> 16;
+        // columns: chunk c starts at cx - 23 + 16 c, kept inside [0, wAl - 16] (what may be read; a chunk that was moved is put right
+        // by fix_columns below)
+        const int wAl = (w + 15) & ~15;
+        const int xc = min(max(cx - 23 + 16 * dchunk, 0), wAl - 16);
+        const uint32_t ldsBase = (uint32_t)(uintptr_t)buf;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            int y = cy - 21 + min(21 * t + drow, 42);
+            y = y < 0 ? -y : y;                      // BORDER_REFLECT_101 of the level's rows (|excursion| <= 2)
+            y = y >= h ? 2 * h - 2 - y : y;
+            const uint8_t *src = img + (size_t)(unsigned)(__mul24(y, stride) + xc);
+            if (lane < (t < 2 ? 63 : 18)) df_glds16(src, __builtin_amdgcn_readfirstlane((int)(ldsBase + 1008u * (uint32_t)t)));
+        }
+        return true;
+    };
+    // A keypoint closer than 23 pixels to the left edge or 25 to the (16-byte padded) right edge, or one whose blur reaches beyond
+    // column w - 1: every byte the blur reads (DF_A .. DF_A + 42) is fetched again from where its (reflected) column landed.
+    auto fix_columns = [&](int kp, uint8_t *buf) {
+        const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+        const int cx = pos & 0xFFF;
+        const int w = __builtin_amdgcn_readfirstlane(s_wh[kp]) & 0xFFFF, wAl = (w + 15) & ~15;
+        if (cx - 23 >= 0 && cx + 25 <= wAl && cx + 21 < w) return;   // wave-uniform
+        uint8_t *row = buf + lane * DF_PITCH;
+        if (lane < DF_ROWS) {
+            uint32_t nw[12];   // the row's new dwords (fully unrolled: registers, no scratch); in-order LDS: every read precedes the writes
+#pragma unroll
+            for (int d = 0; d < 12; d++) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = 4 * d + k - DF_A;   // 0 .. 42: column cx - 21 + j
+                    int at = 4 * d + k;
+                    if (j >= 0 && j < 43) {
+                        int col = cx - 21 + j;
+                        col = col < 0 ? -col : col;
+                        col = col >= w ? 2 * w - 2 - col : col;
+                        // the chunk that holds it: the last one whose (moved) first column is not beyond it
+                        int c = 2, first = min(max(cx - 23 + 32, 0), wAl - 16);
+                        if (col < first) { c = 1; first = min(max(cx - 23 + 16, 0), wAl - 16); }
+                        if (col < first) { c = 0; first = min(max(cx - 23, 0), wAl - 16); }
+                        at = 16 * c + (col - first);
+                    }
+                    x |= (uint32_t)row[at] << (8 * k);
+                }
+                nw[d] = x;
+            }
+#pragma unroll
+            for (int d = 0; d < 12; d++) reinterpret_cast<uint32_t *>(row)[d] = nw[d];
+        }
+    };
+
+    const int kp0 = wave;
+    bool sent0 = stage(kp0, s_raw[wave][0]);   // (in flight during phases A and B)
+
+    // ---- A. IC_Angle moments on the un-blurred level: k_describe<16, true> ----
+    {
+        const uint4 wu = *reinterpret_cast<const uint4 *>(&c_angle_wt.wu[lane][0]);
+        const uint4 wm = *reinterpret_cast<const uint4 *>(&c_angle_wt.wm[lane][0]);
+        const int rowc = min(lane >> 1, 2 * ORB_HALF_PATCH), half16 = 16 * (lane & 1), vrow = (lane >> 1) - ORB_HALF_PATCH;
+        uint4 ring[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kp = kp0 + 4 * q;
+            const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+            if (pos >= 0) {
+                const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+                const uint8_t *img = l == 0 ? lvl0 + (size_t)frame * frame0
+                                            : pyr + (size_t)frame * pyrFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_ioff[kp]);
+                const int stride = __builtin_amdgcn_readfirstlane(s_istride[kp]);
+                const uint8_t *p = img + (size_t)(cy - ORB_HALF_PATCH) * stride + (cx - ORB_HALF_PATCH);
+                ring[q] = reinterpret_cast<const UnalignedU4 *>(p + (unsigned)(__mul24(rowc, stride) + half16))->v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kp = kp0 + 4 * q;
+            const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+            if (pos >= 0) {
+                const uint4 c = ring[q];
+                unsigned S = __builtin_amdgcn_udot4(c.x, wm.x, 0u, false);
+                S = __builtin_amdgcn_udot4(c.y, wm.y, S, false);
+                S = __builtin_amdgcn_udot4(c.z, wm.z, S, false);
+                S = __builtin_amdgcn_udot4(c.w, wm.w, S, false);
+                unsigned U = __builtin_amdgcn_udot4(c.x, wu.x, 0u, false);
+                U = __builtin_amdgcn_udot4(c.y, wu.y, U, false);
+                U = __builtin_amdgcn_udot4(c.z, wu.z, U, false);
+                U = __builtin_amdgcn_udot4(c.w, wu.w, U, false);
+                const int m10 = wave_sum((int)U - 16 * (int)S);
+                const int m01 = wave_sum(__mul24(vrow, (int)S));
+                if (lane == 0) {
+                    s_m10[kp] = m10;
+                    s_m01[kp] = m01;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    ORB_ABL_STOP(phases < 2);
+
+    // ---- B. angle, cos / sin, keypoint record: one thread per keypoint (k_describe) ----
+    if (tid < DS_KP) {
+        const int pos = s_pos[tid];
+        if (pos >= 0) {
+            const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
+            const OrbLevel &L = G.lv[l];
+            const float angle = fast_atan2_dev((float)s_m01[tid], (float)s_m10[tid]);
+            const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+            const float rad = __fmul_rn(angle, factorPI);
+            float a, b;
+            orb_sincosf(rad, &b, &a);
+            s_a[tid] = a;
+            s_b[tid] = b;
+            lvlAngle[(size_t)frame * G.totalKps + g0 + tid] = angle;
+            const int o = s_out[tid];
+            if (o < cap) {
+                orbhip_keypoint kp;
+                kp.x = __fmul_rn((float)cx, L.scale);
+                kp.y = __fmul_rn((float)cy, L.scale);
+                kp.size = L.kpSize;
+                kp.angle = angle;
+                kp.response = (float)my_score;
+                kp.octave = l;
+                kp.class_id = -1;
+                kps[(size_t)frame * cap + o] = kp;
+            }
+        }
+    }
+    __syncthreads();
+    ORB_ABL_STOP(phases < 3);
+
+    // ---- C. per keypoint: blur of the staged neighbourhood, then the 256 tests on it ----
+    float px0[4], py0[4], px1[4], py1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int pw = reinterpret_cast<const int *>(c_pattern)[64 * j + lane];
+        px0[j] = (float)(signed char)(pw & 0xFF);
+        py0[j] = (float)(signed char)((pw >> 8) & 0xFF);
+        px1[j] = (float)(signed char)((pw >> 16) & 0xFF);
+        py1[j] = (float)(signed char)((pw >> 24) & 0xFF);
+    }
+    const uint4 bandRow = *reinterpret_cast<const uint4 *>(&c_df_bands.row[lane][0]);
+    const uint4 bandCol = *reinterpret_cast<const uint4 *>(&c_df_bands.col[lane][0]);
+    const int n16 = lane & 15, q4 = lane >> 4;
+    dfv4i hinit;
+    dfv4f zinit;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        hinit[i] = 128 * 257 + 0x04000000;
+        zinit[i] = -(float)(257 * 1024) / 65536.0f;
+    }
+    bool sentCur = sent0;
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+        const int kp = kp0 + 4 * q;
+        uint8_t *buf = s_raw[wave][q & 1];
+        // this keypoint's rows have landed; the next one's start now, into the buffer whose tests ended an iteration ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool sentNext = q + 1 < 4 ? stage(kp + 4, s_raw[wave][(q + 1) & 1]) : false;
+        if (sentCur) {   // wave-uniform
+            const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
+            const int o = __builtin_amdgcn_readfirstlane(s_out[kp]);
+            const int cx = pos & 0xFFF;
+            const int w = __builtin_amdgcn_readfirstlane(s_wh[kp]) & 0xFFFF;
+            fix_columns(kp, buf);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // row pass: tile (rt, cs) = rows 16 rt .., blurred columns 16 cs ..; lanes of K's upper half re-read the lower half's bytes
+            dfv4i H[3][3];
+            const uint8_t *arow = buf + n16 * DF_PITCH + 16 * (q4 & 1);
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+                for (int cs = 0; cs < 3; cs++) {
+                    uint4 a = *reinterpret_cast<const uint4 *>(arow + rt * 16 * DF_PITCH + 16 * cs);
+                    a.x ^= 0x80808080u; a.y ^= 0x80808080u; a.z ^= 0x80808080u; a.w ^= 0x80808080u;
+                    H[rt][cs] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(dfv4i, a), __builtin_bit_cast(dfv4i, bandRow), hinit, 0, 0, 0);
+                }
+            // byte planes as binary16 pairs
+            uint32_t lo[3][3][2], hi[3][3][2];
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+                for (int cs = 0; cs < 3; cs++)
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        const uint32_t x = (uint32_t)H[rt][cs][2 * d], y = (uint32_t)H[rt][cs][2 * d + 1];
+                        lo[rt][cs][d] = __builtin_amdgcn_perm(y, x, 0x07040300u);
+                        hi[rt][cs][d] = __builtin_amdgcn_perm(y, x, 0x07050301u);
+                    }
+            // column pass + rounding: block (mb, cs) = blurred rows 16 mb .., columns 16 cs ..; the result replaces the raw rows
+            const int wvec = w - (w & 3);
+            const bool tail = cx + 18 >= wvec;   // wave-uniform: some of the patch's columns belong to the reference's scalar tail
+            uint8_t *obase = buf + n16 * DF_OP + 4 * q4;
+#pragma unroll
+            for (int cs = 0; cs < 3; cs++) {
+                // the strip's matrix products first (six, independent), then their roundings: no result is waited for
+                dfv4f zl[3], zh[3];
+#pragma unroll
+                for (int mb = 0; mb < 3; mb++) {
+                    // rows 32 .. 36 x columns 32 .. 36: 14 or more pixels from the centre both ways -- beyond the pattern's radius
+                    // (18.4 after rotation, each coordinate rounded): never read
+                    if (DF_SKIP_CORNER && mb == 2 && cs == 2) continue;
+                    const int m2 = mb < 2 ? mb + 1 : 2;
+                    const uint4 bl = make_uint4(lo[mb][cs][0], lo[mb][cs][1], lo[m2][cs][0], lo[m2][cs][1]);
+                    const uint4 bh = make_uint4(hi[mb][cs][0], hi[mb][cs][1], hi[m2][cs][0], hi[m2][cs][1]);
+                    zl[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandCol), __builtin_bit_cast(dfv8h, bl), zinit, 0, 0, 0);
+                    zh[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandCol), __builtin_bit_cast(dfv8h, bh), zinit, 0, 0, 0);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 3; mb++) {
+                    if (DF_SKIP_CORNER && mb == 2 && cs == 2) continue;
+                    float v[4];   // S * 2^-16 = high plane * 256 + low plane, exact
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaf(zh[mb][e], 256.0f, zl[mb][e]);
+                    if (tail) {
+                        const bool up = cx - 18 + 16 * cs + n16 >= wvec;   // this lane's column: (S + 32768) >> 16
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = up ? floorf(v[e] + 0.5f) : v[e];
+                    }
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) packed = __builtin_amdgcn_cvt_pk_u8_f32(v[e], e, packed);
+                    if (16 * cs + n16 < 37 && 16 * mb + 4 * q4 < 37)
+                        *reinterpret_cast<uint32_t *>(obase + 16 * cs * DF_OP + 16 * mb) = packed;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            bool tests = true;
+            ORB_ABL_IF(phases < 4) tests = false;
+            if (tests) {
+            // the 256 tests: pixel (row r, column c) of the patch at buf + (18 + c) * DF_OP + 18 + r; r, c = the rotated coordinates
+            // rounded to nearest-even through the 1.5 * 2^23 trick of k_describe
+            const float RMAGIC = 12582912.f;   // 0x4B400000
+            const uint32_t bcAddr = (uint32_t)(uintptr_t)buf + (uint32_t)(DS_R * DF_OP + DS_R) - (0x400000u * DF_OP + 0x4B400000u);
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[kp])));
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[kp])));
+            unsigned long long words[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(px0[j], b), __fmul_rn(py0[j], a)), RMAGIC));
+                const int c0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(px0[j], a), __fmul_rn(py0[j], b)), RMAGIC));
+                const int r1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(px1[j], b), __fmul_rn(py1[j], a)), RMAGIC));
+                const int c1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(px1[j], a), __fmul_rn(py1[j], b)), RMAGIC));
+                const int t0 = *(lds_u8p)(bcAddr + (uint32_t)(__mul24(c0, DF_OP) + r0));
+                const int t1 = *(lds_u8p)(bcAddr + (uint32_t)(__mul24(c1, DF_OP) + r1));
+                words[j] = __ballot(t0 < t1);
+            }
+            if (lane < 4) {
+                const unsigned long long wsel = lane == 0 ? words[0] : (lane == 1 ? words[1] : (lane == 2 ? words[2] : words[3]));
+                reinterpret_cast<unsigned long long *>(desc + ((size_t)frame * cap + o) * 32)[lane] = wsel;
+            }
+            }
+        }
+        sentCur = sentNext;
+    }
+}
+
+// Can a batch of this geometry take k_describe_blur (the blurred pyramid is then never built)?  The kernel is written for the umax
+// table of a 31-pixel patch (always what orb_init_tables computes) and for 16 slots per workgroup.  ORBHIP_DESCRIBE_FUSED=0
+// (liborbhip_ablation.so): k_blur + k_describe for batches too.
+bool describe_blur_available(const OrbLevels &G, int B)
+{
+    static const int fusedEnv = ORB_TUNE("DESCRIBE_FUSED", 1);
+    static const int kpwEnv = ORB_TUNE("DESCRIBE_KPW", 0);
+    static const int ax4Env = ORB_TUNE("DESCRIBE_AX4", 1);
+    static const int umaxWant[16] = {ANGLE_UMAX_VALUES};
+    bool ok = fusedEnv != 0 && B >= 8 && ax4Env != 0 && (kpwEnv == 0 || kpwEnv == 16);
+    for (int v = 0; v < 16; v++) ok = ok && G.umax[v] == umaxWant[v];
+    for (int l = 0; l < G.nlevels; l++) ok = ok && G.lv[l].w >= 48 && G.lv[l].h >= 40 && G.lv[l].w < 65536 && G.lv[l].h < 32768;
+    return ok;
+}
+
+void launch_describe_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0, const uint8_t *pyr,
+                          size_t pyrFrame, const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle, orbhip_keypoint *kps,
+                          uint8_t *desc, int32_t *counts, int cap, int B)
+{
+    static const int dmap = ORB_TUNE("DESCRIBE_MAP", -1);
+    const int mapArg = dmap >= 0 ? (dmap | (orb_xcd_chunk() << 8)) : orb_xcd_arg(DESCRIBE_DEFAULT_MAP);
+    static const int phases = ORB_TUNE("DESCRIBE_PHASES", 4);
+    (void)phases;
+    const int nblk = (G.totalKps + 15) / 16;
+    dim3 grid((mapArg & 255) ? (nblk + 7) / 8 * 8 : nblk, B, 1), block(256, 1, 1);
+    orb_path(ORB_PATH_DESCRIBE_BLUR);
+    hipLaunchKernelGGL(k_describe_blur, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame,
+                       lvlKp, lvlKpCnt, lvlAngle, kps, desc, counts, cap, mapArg ORB_ABL_ARG(phases));
+}
+
 void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0,
                      const uint8_t *pyr, size_t pyrFrame, const uint8_t *blur, size_t blurFrame,
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B, long long mirror)
 {
+    orb_path(ORB_PATH_DESCRIBE);
     static const int kpwEnv = ORB_TUNE("DESCRIBE_KPW", 0);
     const int kpw = mirror ? 8 : kpwEnv == 8 || kpwEnv == 16 || kpwEnv == 32 ? kpwEnv : (B >= 8 ? 16 : 8);   // (mirror: single frames only)
     // workgroup -> (slot block, frame): ORBHIP_DESCRIBE_MAP overrides this kernel's mapping alone (A/B runs)

@@ -46,7 +46,7 @@ static inline int orb_env_int(const char *name, int dflt)
 enum OrbPath : unsigned {
     ORB_PATH_FAST_FIX = 1u << 0, ORB_PATH_FAST_GENERIC = 1u << 1, ORB_PATH_RESIZE_FIT = 1u << 2, ORB_PATH_RESIZE_TILES = 1u << 3,
     ORB_PATH_PYRAMID_CHAIN = 1u << 4, ORB_PATH_QT_LDS = 1u << 5, ORB_PATH_QT_LDSPTS = 1u << 6, ORB_PATH_QT_GLOBAL = 1u << 7,
-    ORB_PATH_BOW_LANE = 1u << 8, ORB_PATH_BOW_SEQ_LDS = 1u << 9, ORB_PATH_BOW_SEQ_GLOBAL = 1u << 10, ORB_PATH_FAST_TALL = 1u << 11
+    ORB_PATH_BOW_LANE = 1u << 8, ORB_PATH_BOW_SEQ_LDS = 1u << 9, ORB_PATH_BOW_SEQ_GLOBAL = 1u << 10, ORB_PATH_FAST_TALL = 1u << 11, ORB_PATH_DESCRIBE = 1u << 12, ORB_PATH_DESCRIBE_BLUR = 1u << 13, ORB_PATH_BLUR = 1u << 14
 };
 extern std::atomic<unsigned> g_orbPathMask;
 static inline void orb_path(unsigned bit) { g_orbPathMask.fetch_or(bit, std::memory_order_relaxed); }
@@ -265,6 +265,7 @@ struct orbhip_ctx {
            cap_pnode = 0, cap_angle = 0, cap_cnt1 = 0, cap_cnt2 = 0, cap_cnt3 = 0;
 
     // state of the last extract call
+    bool blurValid = false;        // d_blur holds the blurred pyramid of the last call (false after a batch through k_describe_blur)
     const uint8_t *last_lvl0 = nullptr;  // device pointer to level 0 of frame 0
     int last_stride0 = 0;
     size_t last_frame0 = 0;
@@ -377,6 +378,10 @@ void launch_describe(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int
                      const uint8_t *pyr, size_t pyrFrame, const uint8_t *blur, size_t blurFrame,
                      const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle,
                      orbhip_keypoint *kps, uint8_t *desc, int32_t *counts, int cap, int B, long long mirror = 0);
+bool describe_blur_available(const OrbLevels &G, int B);
+void launch_describe_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0, int stride0, size_t frame0, const uint8_t *pyr,
+                          size_t pyrFrame, const uint32_t *lvlKp, const int32_t *lvlKpCnt, float *lvlAngle, orbhip_keypoint *kps,
+                          uint8_t *desc, int32_t *counts, int cap, int B);
 size_t quadtree_lds_bytes(const OrbLevels &G);
 
 void launch_knn2(hipStream_t s, const uint8_t *q, int nq, const uint8_t *db, int ndb, int32_t *best_idx,
