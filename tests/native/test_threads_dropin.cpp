@@ -12,6 +12,13 @@
 // (Fuse edits the map; slamlite's MapPoint / KeyFrame twins have no mutexes, so M fuses in a map no other thread reads --
 // the matcher's own state is what is shared: the device, the library's statics, the HIP runtime.)
 // Usage: test_threads_dropin w h nfeatures frames.raw nframes vocabulary.bin [rounds]      exit code 0 and "all ok".
+//
+// -DORBHIP_TSAN_MOCK (tests/native/Makefile: test_threads_tsan, built with -fsanitize=thread against tests/native/mock_orbhip.cc
+// instead of liborbhip.so): the same three threads and the same schedule -- eight resident sets per thread,
+// DropResidentSets() mid-run -- over synthetic features, no GPU.  The mock answers every search with a deterministic function
+// of the data it was handed, so "expected" is the same call made single-threaded before the threads start; ThreadSanitizer
+// watches the host side (thread_local contexts, the shared limit, the statics of host/*.cc) while they run.
+// Usage there: test_threads_tsan [rounds]
 #include <thread>
 
 #include "ORBVocabulary.h"
@@ -270,10 +277,79 @@ static void roundL(const Plan &P, int r, bool hip, Res out[2])
     out[1].h = hashVec(S, m12);
 }
 
+#ifdef ORBHIP_TSAN_MOCK
+extern "C" long mock_orbhip_calls();
+extern "C" long mock_orbhip_evictions();
+// three "extractions" of random features: positions inside the image, octaves 0..7, descriptors from 300 base rows with a few bits
+// flipped, FeatureVectors over 90 nodes, the 64 x 48 grid by the drop-in's own AssignFeaturesToGrid (host arithmetic)
+static void syntheticExtractions(Common &C, int nframes, int nf)
+{
+    g_rng = 0xC0FFEEull;
+    vector<vector<unsigned char> > base(300, vector<unsigned char>(32));
+    for (size_t b = 0; b < base.size(); b++)
+        for (int k = 0; k < 32; k++) base[b][k] = (unsigned char)(256 * urand());
+    C.ex.resize(nframes);
+    for (int e = 0; e < nframes; e++) {
+        Extraction &X = C.ex[e];
+        const int n = nf - 7 * e;
+        X.keys.resize(n);
+        X.desc = cv::Mat(n, 32, CV_8U);
+        for (int i = 0; i < n; i++) {
+            cv::KeyPoint &kp = X.keys[i];
+            kp.pt.x = (float)(20 + (C.w - 40) * urand()); kp.pt.y = (float)(20 + (C.h - 40) * urand());
+            kp.octave = (int)(8 * urand()) & 7; kp.angle = (float)(360 * urand()); kp.size = 31.f; kp.response = 20.f; kp.class_id = -1;
+            const int b = (int)(base.size() * urand()) % (int)base.size();
+            memcpy(X.desc.ptr(i), base[b].data(), 32);
+            for (int f = (int)(4 * urand()); f > 0; f--) { const int bit = (int)(256 * urand()) & 255; X.desc.ptr(i)[bit >> 3] ^= 1 << (bit & 7); }
+            X.fv[(unsigned)(1000 + b % 90)].push_back((unsigned)i);
+        }
+        X.grid.mvKeys = X.keys; X.grid.mvKeysUn = X.keys; X.grid.N = n;
+        X.grid.mpORBextractorLeft = NULL;
+        X.grid.AssignFeaturesToGrid();
+    }
+    C.scale.resize(8); C.sigma2.resize(8); C.invSigma2.resize(8);
+    for (int l = 0; l < 8; l++) { C.scale[l] = l ? C.scale[l - 1] * 1.2f : 1.f; C.sigma2[l] = C.scale[l] * C.scale[l]; C.invSigma2[l] = 1.f / C.sigma2[l]; }
+}
+#endif
+
 int main(int argc, char **argv)
 {
-    if (argc < 7) { fprintf(stderr, "usage: %s w h nfeatures frames.raw nframes vocabulary.bin [rounds]\n", argv[0]); return 2; }
     Common C;
+#ifdef ORBHIP_TSAN_MOCK
+    const int rounds = argc > 1 ? atoi(argv[1]) : 300;
+    C.w = 640; C.h = 480;
+    Frame::fx = 517.3f; Frame::fy = 516.5f; Frame::cx = 318.6f; Frame::cy = 255.3f;
+    Frame::mnMinX = 0; Frame::mnMaxX = (float)C.w; Frame::mnMinY = 0; Frame::mnMaxY = (float)C.h;
+    Frame::mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / (Frame::mnMaxX - Frame::mnMinX);
+    Frame::mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / (Frame::mnMaxY - Frame::mnMinY);
+    syntheticExtractions(C, 3, 600);
+    SharedMap S;
+    buildShared(S, C, 30);
+    Plan P = {rounds, 30, &C, &S};
+    ORBmatcher::SetResidentSetLimit(8);
+    // ---- expected: the same calls, single-threaded (this thread has a context and a table of its own) ----
+    vector<Res> wantT(2 * rounds), wantM(2 * rounds), wantL(2 * rounds);
+    {
+        FuseMap W;
+        for (int r = 0; r < rounds; r++) {
+            roundT(P, r, true, &wantT[2 * r]);
+            roundM(P, r, true, W, &wantM[2 * r]);
+            roundL(P, r, true, &wantL[2 * r]);
+        }
+    }
+    long sum[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < rounds; r++) {
+        sum[0] += wantT[2 * r].n; sum[1] += wantT[2 * r + 1].n; sum[2] += wantM[2 * r].n; sum[3] += wantM[2 * r + 1].n;
+        sum[4] += wantL[2 * r].n; sum[5] += wantL[2 * r + 1].n;
+    }
+    printf("single-threaded against the mock, %d rounds: %ld / %ld / %ld / %ld / %ld / %ld results; %ld library calls, %ld evictions\n", rounds,
+           sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], mock_orbhip_calls(), mock_orbhip_evictions());
+    int fails = 0;
+    for (int k = 0; k < 6; k++)
+        if (sum[k] <= 0) { printf("FAILED: search %d returns nothing\n", k); fails++; }
+    if (mock_orbhip_evictions() < rounds) { printf("FAILED: the schedule does not evict\n"); fails++; }
+#else
+    if (argc < 7) { fprintf(stderr, "usage: %s w h nfeatures frames.raw nframes vocabulary.bin [rounds]\n", argv[0]); return 2; }
     C.w = atoi(argv[1]); C.h = atoi(argv[2]);
     const int nf = atoi(argv[3]), nframes = atoi(argv[5]);
     const int rounds = argc > 7 ? atoi(argv[7]) : 500;
@@ -330,6 +406,7 @@ int main(int argc, char **argv)
     const long floor_[6] = {50, 100, 20, 20, 20, 5};       // per round on average: the searches have something to find
     for (int k = 0; k < 6; k++)
         if (sum[k] < floor_[k] * (long)rounds) { printf("FAILED: search %d finds too little to be a test (%ld)\n", k, sum[k]); fails++; }
+#endif
 
     // ---- the drop-in from three threads at once ----
     ORBmatcher::SetResidentSetLimit(8);

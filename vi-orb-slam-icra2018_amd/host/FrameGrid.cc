@@ -1,9 +1,11 @@
 // FrameGrid.cc -- Frame::UndistortKeyPoints / ComputeImageBounds (ref: src/Frame.cc:748-808) through
 // orbhip_undistort_keypoints, and Frame::AssignFeaturesToGrid / GetFeaturesInArea (:574-589, :671-724) on the
-// device grid of liborbhip (orbhip_grid_build, orbhip_features_in_area).  mGrid keeps the
-// reference's public layout (a vector of feature indices per cell).  No CPU path and no exceptions (hiperror.h):
-// a failed device call is reported and leaves the "nothing there" result.
+// device grid of liborbhip (orbhip_frame_build's by-product, orbhip_features_in_area).  mGrid keeps the
+// reference's public layout (a vector of feature indices per cell).  No exceptions (hiperror.h): a failed device call is
+// reported and leaves the "nothing there" result.  The one piece of arithmetic done on the host is the cell number of a
+// keypoint when AssignFeaturesToGrid is called outside a frame build (r06).
 #include <algorithm>
+#include <cmath>
 #include <string>
 
 #include "hiperror.h"
@@ -111,19 +113,20 @@ void Frame::AssignFeaturesToGrid()
             }
         return;
     }
-    orbhip_ctx *ctx = frame_ctx(this, "Frame::AssignFeaturesToGrid");
-    std::vector<int32_t> off(ORBHIP_GRID_CELLS + 1), idx(N);
-    if (orbhip_grid_build(ctx, reinterpret_cast<const orbhip_keypoint *>(mvKeysUn.data()), N, mnMinX, mnMinY,
-                          mfGridElementWidthInv, mfGridElementHeightInv, off.data(), idx.data()) != ORBHIP_OK)
+    // Called on its own (a frame that did not come out of orbhip_frame_build): 64 x 48 counters and N cell numbers -- a
+    // device round trip costs four times what the binning does on the host (profiles/r05/percall_table.md: 0.038 vs 0.010 ms),
+    // so it is done here, with the float operations of k_grid_build's grid_cell (ref: src/Frame.cc:726-736 PosInGrid: the
+    // difference, then the product, each rounded to float, then round()), features in index order = the reference's push_back
+    // order.  The device grid (orbhip_frame_build, orbhip_set_put) is the same function of the same keypoints.
+    for (int i = 0; i < N; i++)
     {
-        hipdetail::Fail("Frame::AssignFeaturesToGrid", orbhip_last_error(ctx));
-        return;                   // empty grid
+        const cv::KeyPoint &kp = mvKeysUn[i];
+        const float gx = (kp.pt.x - mnMinX) * mfGridElementWidthInv;
+        const float gy = (kp.pt.y - mnMinY) * mfGridElementHeightInv;
+        const int cellX = (int)roundf(gx), cellY = (int)roundf(gy);
+        if (cellX < 0 || cellX >= FRAME_GRID_COLS || cellY < 0 || cellY >= FRAME_GRID_ROWS) continue;   // outside the undistorted image
+        mGrid[cellX][cellY].push_back((std::size_t)i);
     }
-    for (int i = 0; i < FRAME_GRID_COLS; i++)
-        for (int j = 0; j < FRAME_GRID_ROWS; j++) {
-            const int c = i * FRAME_GRID_ROWS + j;
-            mGrid[i][j].assign(idx.begin() + off[c], idx.begin() + off[c + 1]);
-        }
 }
 
 void Frame::ComputeBoW()
