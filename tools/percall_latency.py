@@ -139,10 +139,18 @@ def register_and_search():
 rows.append(("`SearchByBoW(KF, F)` with the frame registered from its `orbhip_frame_build` block (registration + search)",
              bench(register_and_search, 300), byname["`SearchByBoW(KF, F)` 1000 x 1000 features"][2]))
 
-print("| call (one per frame / key-frame pair) | liborbhip per call (ms) | oracle, one host core (ms) |")
-print("|---|---|---|")
+# how the C++ drop-in (host/*.cc) reaches a row whose stand-alone C-ABI call does not beat a host core
+HOW = {
+    "`SearchByBoW(KF, F)` 1000 x 1000 features": "only with ORBHIP_NO_SETS=1; the drop-in's default is the resident-set row below",
+    "`Fuse` window search (1000 points into one key frame)": "only with ORBHIP_NO_SETS=1; default: the resident key frame row below",
+    "`SearchForTriangulation` key-frame pair, 1000 x 1000 features": "per call (LocalMapping: once per new key frame and neighbour)",
+    "`Frame::UndistortKeyPoints` 1000 keypoints (EuRoC cam0 coefficients)": "frame-build only: the Frame constructor takes orbhip_frame_build's by-product; a stand-alone call is this row",
+    "`Frame::AssignFeaturesToGrid` 1000 keypoints": "frame-build only: the by-product of orbhip_frame_build; called alone the drop-in bins on the host (r06: the host column), this entry point serves batches and resident sets",
+}
+print("| call (one per frame / key-frame pair) | liborbhip per call (ms) | oracle, one host core (ms) | how the drop-in reaches it |")
+print("|---|---|---|---|")
 for name, g, c in rows:
-    print("| %s | %.3f | %.3f |" % (name, g, c))
+    print("| %s | %.3f | %.3f | %s |" % (name, g, c, HOW.get(name, "")))
 # the floor under any of these calls on this box: what a launch and a synchronisation cost before anything is computed
 import ctypes
 from orbhip import capi

@@ -512,13 +512,18 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 #ifndef DF_WG_PER_CU
 #define DF_WG_PER_CU 5                // 96 registers per lane: the nine row-pass tiles and their planes are live together
 #endif
+#ifndef DF_KP
+#define DF_KP 32                      // keypoint slots per workgroup (a multiple of 16)
+#endif
 #ifndef DF_SKIP_CORNER
 #define DF_SKIP_CORNER 1
 #endif
+#define DF_OBUF 1536                  // 37 columns x DF_OP
 #define DF_OP 40                      // pitch of the blurred patch, [column 0..36][row 0..36 (+3)]
 typedef int dfv4i __attribute__((ext_vector_type(4)));
 typedef float dfv4f __attribute__((ext_vector_type(4)));
-typedef float dfv2f __attribute__((ext_vector_type(2)));
+typedef uint32_t dfv8u __attribute__((ext_vector_type(8)));
+typedef uint32_t dfv4u __attribute__((ext_vector_type(4)));
 typedef _Float16 dfv8h __attribute__((ext_vector_type(8)));
 
 struct DfBands {
@@ -571,12 +576,13 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
                                                           orbhip_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                           int32_t *__restrict__ counts, int cap, int xcdMap ORB_ABL_PARAM)
 {
-    constexpr int DS_KP = 16;
+    constexpr int DS_KP = DF_KP, NQ = DS_KP / 4;   // slots per workgroup, keypoints per wave
     __shared__ int s_pos[DS_KP], s_out[DS_KP], s_m10[DS_KP], s_m01[DS_KP];
     __shared__ float s_a[DS_KP], s_b[DS_KP];
     __shared__ unsigned s_ioff[DS_KP];
     __shared__ int s_istride[DS_KP], s_wh[DS_KP];      // level width | height << 16
     __shared__ __align__(16) uint8_t s_raw[4][2][DF_BUF];
+    __shared__ __align__(16) uint8_t s_blurred[4][DF_OBUF];   // the keypoint's blurred 37 x 37 patch, [column][row]
     int blk = xcd_tile(xcdMap), frame = blockIdx.y;
     if ((xcdMap & 255) == 4) xcd_frame_tile((int)gridDim.y, blk, frame);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -621,6 +627,7 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
 
     // the raw neighbourhood of slot kp -> buf: lane (row of 21, chunk of 3); rows 43.. repeat row 42
     const int drow = (lane * 43) >> 7, dchunk = lane - 3 * drow;   // lane / 3, lane % 3 (lane 63: row 21, not sent)
+    const int stageRow[3] = {drow, min(21 + drow, 42), 42};         // the staged row of this lane in each of the three transfers
     auto stage = [&](int kp, uint8_t *buf) -> bool {
         const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
         if (pos < 0 || __builtin_amdgcn_readfirstlane(s_out[kp]) >= cap) return false;
@@ -634,9 +641,17 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
         const int wAl = (w + 15) & ~15;
         const int xc = min(max(cx - 23 + 16 * dchunk, 0), wAl - 16);
         const uint32_t ldsBase = (uint32_t)(uintptr_t)buf;
+        if (cy >= 21 && cy + 21 < h) {   // wave-uniform: no row to reflect -- a lane's three rows are fixed distances below the first one
+            const uint8_t *src = img + (size_t)(unsigned)(__mul24(cy - 21, stride) + xc);
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (lane < (t < 2 ? 63 : 18))
+                    df_glds16(src + (unsigned)__mul24(stageRow[t], stride), __builtin_amdgcn_readfirstlane((int)(ldsBase + 1008u * (uint32_t)t)));
+            return true;
+        }
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            int y = cy - 21 + min(21 * t + drow, 42);
+            int y = cy - 21 + stageRow[t];
             y = y < 0 ? -y : y;                      // BORDER_REFLECT_101 of the level's rows (|excursion| <= 2)
             y = y >= h ? 2 * h - 2 - y : y;
             const uint8_t *src = img + (size_t)(unsigned)(__mul24(y, stride) + xc);
@@ -681,17 +696,19 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
     };
 
     const int kp0 = wave;
-    bool sent0 = stage(kp0, s_raw[wave][0]);   // (in flight during phases A and B)
 
     // ---- A. IC_Angle moments on the un-blurred level: k_describe<16, true> ----
+    bool sent0 = false;
     {
         const uint4 wu = *reinterpret_cast<const uint4 *>(&c_angle_wt.wu[lane][0]);
         const uint4 wm = *reinterpret_cast<const uint4 *>(&c_angle_wt.wm[lane][0]);
         const int rowc = min(lane >> 1, 2 * ORB_HALF_PATCH), half16 = 16 * (lane & 1), vrow = (lane >> 1) - ORB_HALF_PATCH;
+#pragma unroll
+        for (int qb = 0; qb < NQ; qb += 4) {
         uint4 ring[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int kp = kp0 + 4 * q;
+            const int kp = kp0 + 4 * (qb + q);
             const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
             if (pos >= 0) {
                 const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
@@ -702,9 +719,12 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
                 ring[q] = reinterpret_cast<const UnalignedU4 *>(p + (unsigned)(__mul24(rowc, stride) + half16))->v;
             }
         }
+        // the first keypoint's neighbourhood: requested BEHIND the disc loads (loads return in order: the moments do not wait for it),
+        // in flight during the rest of phase A and phase B
+        if (qb == 0) sent0 = stage(kp0, s_raw[wave][0]);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int kp = kp0 + 4 * q;
+            const int kp = kp0 + 4 * (qb + q);
             const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
             if (pos >= 0) {
                 const uint4 c = ring[q];
@@ -723,6 +743,7 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
                     s_m01[kp] = m01;
                 }
             }
+        }
         }
     }
     __syncthreads();
@@ -781,15 +802,15 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
     }
     bool sentCur = sent0;
 #pragma unroll 1
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NQ; q++) {
         const int kp = kp0 + 4 * q;
-        uint8_t *buf = s_raw[wave][q & 1];
+        uint8_t *buf = s_raw[wave][q & 1], *obuf = s_blurred[wave];
         // this keypoint's rows have landed; the next one's start now, into the buffer whose tests ended an iteration ago
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool sentNext = q + 1 < 4 ? stage(kp + 4, s_raw[wave][(q + 1) & 1]) : false;
+        const bool sentNext = q + 1 < NQ ? stage(kp + 4, s_raw[wave][(q + 1) & 1]) : false;
         if (sentCur) {   // wave-uniform
             const int pos = __builtin_amdgcn_readfirstlane(s_pos[kp]);
             const int o = __builtin_amdgcn_readfirstlane(s_out[kp]);
@@ -799,45 +820,41 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // row pass: tile (rt, cs) = rows 16 rt .., blurred columns 16 cs ..; lanes of K's upper half re-read the lower half's bytes
-            dfv4i H[3][3];
-            const uint8_t *arow = buf + n16 * DF_PITCH + 16 * (q4 & 1);
-#pragma unroll
-            for (int rt = 0; rt < 3; rt++)
-#pragma unroll
-                for (int cs = 0; cs < 3; cs++) {
-                    uint4 a = *reinterpret_cast<const uint4 *>(arow + rt * 16 * DF_PITCH + 16 * cs);
-                    a.x ^= 0x80808080u; a.y ^= 0x80808080u; a.z ^= 0x80808080u; a.w ^= 0x80808080u;
-                    H[rt][cs] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(dfv4i, a), __builtin_bit_cast(dfv4i, bandRow), hinit, 0, 0, 0);
-                }
-            // byte planes as binary16 pairs
-            uint32_t lo[3][3][2], hi[3][3][2];
-#pragma unroll
-            for (int rt = 0; rt < 3; rt++)
-#pragma unroll
-                for (int cs = 0; cs < 3; cs++)
-#pragma unroll
-                    for (int d = 0; d < 2; d++) {
-                        const uint32_t x = (uint32_t)H[rt][cs][2 * d], y = (uint32_t)H[rt][cs][2 * d + 1];
-                        lo[rt][cs][d] = __builtin_amdgcn_perm(y, x, 0x07040300u);
-                        hi[rt][cs][d] = __builtin_amdgcn_perm(y, x, 0x07050301u);
-                    }
-            // column pass + rounding: block (mb, cs) = blurred rows 16 mb .., columns 16 cs ..; the result replaces the raw rows
+            // One strip of 16 blurred columns at a time (three row-pass tiles, their planes, three column blocks: 12 + 12 registers live
+            // instead of 36 + 36): row pass -- tile rt = rows 16 rt .., lanes of K's upper half re-read the lower half's bytes --,
+            // byte planes as binary16 pairs, column pass + rounding -- block mb = blurred rows 16 mb .. -- into the wave's patch buffer
+            // ([column][row], pitch DF_OP).
             const int wvec = w - (w & 3);
             const bool tail = cx + 18 >= wvec;   // wave-uniform: some of the patch's columns belong to the reference's scalar tail
-            uint8_t *obase = buf + n16 * DF_OP + 4 * q4;
+            const uint8_t *arow = buf + n16 * DF_PITCH + 16 * (q4 & 1);
+            uint8_t *obase = obuf + n16 * DF_OP + 4 * q4;
 #pragma unroll
             for (int cs = 0; cs < 3; cs++) {
-                // the strip's matrix products first (six, independent), then their roundings: no result is waited for
+                dfv4i H[3];
+#pragma unroll
+                for (int rt = 0; rt < 3; rt++) {
+                    uint4 a = *reinterpret_cast<const uint4 *>(arow + rt * 16 * DF_PITCH + 16 * cs);
+                    a.x ^= 0x80808080u; a.y ^= 0x80808080u; a.z ^= 0x80808080u; a.w ^= 0x80808080u;
+                    H[rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(dfv4i, a), __builtin_bit_cast(dfv4i, bandRow), hinit, 0, 0, 0);
+                }
+                uint32_t lo[3][2], hi[3][2];
+#pragma unroll
+                for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        const uint32_t x = (uint32_t)H[rt][2 * d], y = (uint32_t)H[rt][2 * d + 1];
+                        lo[rt][d] = __builtin_amdgcn_perm(y, x, 0x07040300u);
+                        hi[rt][d] = __builtin_amdgcn_perm(y, x, 0x07050301u);
+                    }
                 dfv4f zl[3], zh[3];
 #pragma unroll
                 for (int mb = 0; mb < 3; mb++) {
                     // rows 32 .. 36 x columns 32 .. 36: 14 or more pixels from the centre both ways -- beyond the pattern's radius
                     // (18.4 after rotation, each coordinate rounded): never read
                     if (DF_SKIP_CORNER && mb == 2 && cs == 2) continue;
-                    const int m2 = mb < 2 ? mb + 1 : 2;
-                    const uint4 bl = make_uint4(lo[mb][cs][0], lo[mb][cs][1], lo[m2][cs][0], lo[m2][cs][1]);
-                    const uint4 bh = make_uint4(hi[mb][cs][0], hi[mb][cs][1], hi[m2][cs][0], hi[m2][cs][1]);
+                    const int m2 = mb < 2 ? mb + 1 : 2;   // (what follows tile 2 is multiplied by zeros of the band)
+                    const uint4 bl = make_uint4(lo[mb][0], lo[mb][1], lo[m2][0], lo[m2][1]);
+                    const uint4 bh = make_uint4(hi[mb][0], hi[mb][1], hi[m2][0], hi[m2][1]);
                     zl[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandCol), __builtin_bit_cast(dfv8h, bl), zinit, 0, 0, 0);
                     zh[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandCol), __builtin_bit_cast(dfv8h, bh), zinit, 0, 0, 0);
                 }
@@ -868,7 +885,7 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
             // the 256 tests: pixel (row r, column c) of the patch at buf + (18 + c) * DF_OP + 18 + r; r, c = the rotated coordinates
             // rounded to nearest-even through the 1.5 * 2^23 trick of k_describe
             const float RMAGIC = 12582912.f;   // 0x4B400000
-            const uint32_t bcAddr = (uint32_t)(uintptr_t)buf + (uint32_t)(DS_R * DF_OP + DS_R) - (0x400000u * DF_OP + 0x4B400000u);
+            const uint32_t bcAddr = (uint32_t)(uintptr_t)obuf + (uint32_t)(DS_R * DF_OP + DS_R) - (0x400000u * DF_OP + 0x4B400000u);
             const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[kp])));
             const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[kp])));
             unsigned long long words[4];
@@ -915,10 +932,11 @@ void launch_describe_blur(hipStream_t s, const OrbLevels &G, const uint8_t *lvl0
     const int mapArg = dmap >= 0 ? (dmap | (orb_xcd_chunk() << 8)) : orb_xcd_arg(DESCRIBE_DEFAULT_MAP);
     static const int phases = ORB_TUNE("DESCRIBE_PHASES", 4);
     (void)phases;
-    const int nblk = (G.totalKps + 15) / 16;
+    const int nblk = (G.totalKps + DF_KP - 1) / DF_KP;
     dim3 grid((mapArg & 255) ? (nblk + 7) / 8 * 8 : nblk, B, 1), block(256, 1, 1);
     orb_path(ORB_PATH_DESCRIBE_BLUR);
-    hipLaunchKernelGGL(k_describe_blur, grid, block, 0, s, G, lvl0, stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame,
+    static const int padLds = ORB_TUNE("DESCRIBE_PADLDS", 0);   // occupancy experiment only: unused dynamic LDS caps the workgroups per CU
+    hipLaunchKernelGGL(k_describe_blur, grid, block, (size_t)padLds, s, G, lvl0, stride0, (unsigned long long)frame0, pyr, (unsigned long long)pyrFrame,
                        lvlKp, lvlKpCnt, lvlAngle, kps, desc, counts, cap, mapArg ORB_ABL_ARG(phases));
 }
 
