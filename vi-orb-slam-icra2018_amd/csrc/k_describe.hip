@@ -498,11 +498,24 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 //                as binary16 0x0400 | byte, weights tap * 2^8, accumulator started at minus the constant part: exact (k_blur.hip);
 //   rounding     v_cvt_pk_u8_f32 = round half to even + saturation (the SSE2 column filter of OpenCV 2.4 for x < w - w % 4);
 //                keypoints whose patch reaches the scalar tail's columns take floor(v + 0.5) there (wave-uniform branch);
-// -- writes the blurred 37 x 37 patch over the raw one (transposed, [column][row], pitch 40) and runs the 256 tests on it.
+// -- one strip of 16 blurred columns at a time (12 + 12 registers of tiles and planes live) into the wave's patch buffer (37 x 37,
+// transposed: [column][row], pitch 40), and runs the 256 tests on it.  32 keypoint slots per workgroup, eight per wave.
 // Image borders (BORDER_REFLECT_101 in LEVEL coordinates): rows by reflecting the row index of the transfer; the two columns
 // a keypoint 19-20 pixels from the left / right edge reaches beyond it are patched into the staged rows (rare, wave-uniform).
 // Phases 0, A (IC angle from the raw level, one 16-byte load per lane) and B are those of k_describe<16, true>.
 // k_blur stays for a frame or two and for orbhip_debug_get_blurred_level.
+// Measured on the way (profiles/r06/describe_blur.md; 1024 frames, the kernel's two launches incl. the quadtree half beside them):
+//   first form (16 slots, all nine tiles live, patch over the raw rows, 96 registers)              1.09 ms  (k_blur 0.63 + k_describe 0.74 before)
+//   + the corner block skipped                                                                      1.08
+//   + the strip's six column products issued before their roundings                                 1.07
+//   + 32 slots per workgroup, first neighbourhood requested behind the disc loads                   1.01
+//   + one strip at a time into a patch buffer of its own (74 registers)                             0.97
+// and not kept: v_pk_mul / add / fma_f32 for the tests and the roundings (they issue at half the rate of the scalar forms: the
+// same time, 16 more registers: 1.17 at four workgroups per CU); five / six / four workgroups per CU by register bound (1.08 /
+// 1.15 with spills / 1.08); the moments from the staged rows instead of loads of their own, in rounds of two keypoints per wave
+// with the angles of a round computed between two workgroup barriers (removes ~40 cache lines per keypoint, worth 0.09 ms
+// by ablation; the barriers and the lost overlap cost 0.17: 1.05); unused LDS capping the workgroups per CU at 4 / 3 / 2:
+// 0.99 / 1.16 / 1.52 for the kernel alone (0.85 at 5).
 // =====================================================================================================================
 #define DF_ROWS 48                    // staged raw rows: 43 needed, the rest complete the three 16-row tiles
 #define DF_PITCH 48                   // bytes per staged row: columns cx - 23 .. cx + 24 (12 dwords: the A operand's 16 rows fall on distinct banks)
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 #define DF_RAW (DF_ROWS * DF_PITCH)   // 2304
 #define DF_BUF 2368                   // + 64: the upper-K lanes of the last rows' A operand read (and ignore) bytes beyond the image
 #ifndef DF_WG_PER_CU
-#define DF_WG_PER_CU 5                // 96 registers per lane: the nine row-pass tiles and their planes are live together
+#define DF_WG_PER_CU 6                // 74 registers per lane, 25 KB of LDS per workgroup (measured: 4 -> 5 workgroups per CU -13 %, 5 -> 6 none)
 #endif
 #ifndef DF_KP
 #define DF_KP 32                      // keypoint slots per workgroup (a multiple of 16)
@@ -716,7 +729,10 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
                                             : pyr + (size_t)frame * pyrFrame + (unsigned)__builtin_amdgcn_readfirstlane((int)s_ioff[kp]);
                 const int stride = __builtin_amdgcn_readfirstlane(s_istride[kp]);
                 const uint8_t *p = img + (size_t)(cy - ORB_HALF_PATCH) * stride + (cx - ORB_HALF_PATCH);
-                ring[q] = reinterpret_cast<const UnalignedU4 *>(p + (unsigned)(__mul24(rowc, stride) + half16))->v;
+                bool ld = true;
+                ORB_ABL_IF(phases == 5) ld = false;   // timing ablation only: what do the disc loads cost?
+                if (ld) ring[q] = reinterpret_cast<const UnalignedU4 *>(p + (unsigned)(__mul24(rowc, stride) + half16))->v;
+                else ring[q] = make_uint4(cx, cy, lane, q);
             }
         }
         // the first keypoint's neighbourhood: requested BEHIND the disc loads (loads return in order: the moments do not wait for it),
@@ -920,7 +936,15 @@ bool describe_blur_available(const OrbLevels &G, int B)
     static const int umaxWant[16] = {ANGLE_UMAX_VALUES};
     bool ok = fusedEnv != 0 && B >= 8 && ax4Env != 0 && (kpwEnv == 0 || kpwEnv == 16);
     for (int v = 0; v < 16; v++) ok = ok && G.umax[v] == umaxWant[v];
-    for (int l = 0; l < G.nlevels; l++) ok = ok && G.lv[l].w >= 48 && G.lv[l].h >= 40 && G.lv[l].w < 65536 && G.lv[l].h < 32768;
+    long long px = 0;
+    for (int l = 0; l < G.nlevels; l++) {
+        ok = ok && G.lv[l].w >= 48 && G.lv[l].h >= 40 && G.lv[l].w < 65536 && G.lv[l].h < 32768;
+        px += (long long)G.lv[l].w * G.lv[l].h;
+    }
+    // Blurring 37 x 37 pixels per keypoint beats blurring the pyramid while the keypoints are few for the pixels: measured
+    // (profiles/r06/describe_blur.md) +10 % of the whole step at 640 x 480 / 1000 features (1.1 keypoints per 1000 pyramid pixels),
+    // +6 % at 1241 x 376 / 2000 (1.4), -10 % at 640 x 480 / 4000 (4.2).  The switch sits at 2.5 (ORBHIP_DESCRIBE_FUSED=2: always).
+    if (fusedEnv != 2) ok = ok && (long long)G.totalKps * 400 <= px;
     return ok;
 }
 
