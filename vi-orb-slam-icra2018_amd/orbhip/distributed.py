@@ -218,7 +218,8 @@ def gpu_numa_node(pci_domain, pci_bus, pci_device):
 
 
 def numa_bind(local_rank, bind=True):
-    """Run this rank on the CPUs of its GPU's NUMA node (sched_setaffinity, before any page-locked ring is allocated: pages
+    """Run this rank -- every thread it has at this point, and through inheritance every later one -- on the CPUs of its GPU's NUMA
+    node (sched_setaffinity per thread id of /proc/self/task, before any page-locked ring is allocated: pages
     are placed on the node of the thread that first touches them, and the threads that fill the rings then run next to
     them).  Eight ranks each pull ~50 GB/s out of host memory over their own PCIe link; a ring on the other socket crosses
     the inter-socket fabric twice per frame.  Best effort: returns what it found and what it did, never raises."""
@@ -233,9 +234,25 @@ def numa_bind(local_rank, bind=True):
         if bind and node is not None and topo["numa_nodes"] > 1:
             allowed = sorted(set(topo["_cpus"].get(node, [])) & os.sched_getaffinity(0))
             if allowed:
+                # every thread the process has by now (the HIP runtime's, RCCL's and OpenMP's were started by the set_device /
+                # init_process_group calls in front of this one and would keep the old mask; threads created later inherit the
+                # caller's) -- ADVICE r05
+                tids = [0]
+                try:
+                    tids = [int(t) for t in os.listdir("/proc/self/task")]
+                except OSError:
+                    pass
+                done = 0
+                for t in tids:
+                    try:
+                        os.sched_setaffinity(t, allowed)
+                        done += 1
+                    except OSError:                  # a thread that ended meanwhile
+                        pass
                 os.sched_setaffinity(0, allowed)
                 info["bound"] = True
                 info["cpus"] = len(allowed)
+                info["threads_bound"] = done
     except Exception as exc:                      # noqa: BLE001 -- placement is an optimisation, never a reason to fail
         info["error"] = str(exc)[:200]
     return info
