@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 I8_MFMA_PEAK_OPS = 5.0e15             # MI355X_MICROARCH.md: dense I8 MFMA = 2 x BF16 per clock, BF16 ~2.5 PFLOP/s dense
 FP4_MFMA_PEAK_OPS = 10.0e15           # ... block-scaled FP4 (v_mfma_scale_f32_32x32x64_f8f6f4) = 4 x BF16 per clock
 VOC_K, VOC_L, LEVELSUP = 10, 6, 4     # stock ORBvoc shape; Frame::ComputeBoW uses levelsup 4 (src/Frame.cc:744)
+FAST_CEILING_FRAC = 0.276             # floor of the k_fast_fix formulation (242 M wave-instructions at full issue) as a fraction of HBM
 NNRATIO = 0.7                         # TrackReferenceKeyFrame: ORBmatcher matcher(0.7,true) (src/Tracking.cc:1881)
 
 
@@ -1150,7 +1151,12 @@ def main():
                          "traffic_source": traffic_src, "traffic_stale": ctr_stale,
                          "traffic_stale_why": None if not ctr_stale else ("k_fast.hip has changed since the counter pass" if src_moved
                                                                             else "launch time differs by more than 5 % from the counter pass"),
-                         "limited_by": "vector and LDS instruction issue (roofline_valu), not bytes",
+                         "limited_by": "vector and LDS instruction issue (roofline_valu), not bytes: exact cv::FAST in this formulation "
+                                       "takes at least 242 M vector wave-instructions per 1024 frames (tools/fast_bound.py, DESIGN "
+                                       "section 4) = %.3f of the HBM roofline at full issue -- the ceiling; this run reaches %.2f of "
+                                       "that ceiling (frozen in round 6: the remaining structural ideas cost more instructions than "
+                                       "they remove, tools/fast_append_model.py)" % (FAST_CEILING_FRAC, achieved / HBM_PEAK_GBS / FAST_CEILING_FRAC),
+                         "ceiling_frac": FAST_CEILING_FRAC, "frac_of_ceiling": round(achieved / HBM_PEAK_GBS / FAST_CEILING_FRAC, 3),
                          "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(fast_ms, 4),
                          "note": "achieved = algorithmic bytes / launch time (HIP events on the launch stream, k_fast alone on the "
                                  "device); the kernel is bound by vector-instruction issue, see roofline_valu"
