@@ -420,3 +420,61 @@ if __name__ == "__main__":          # child process of test_random_extraction_co
     for p_ in (os.path.join(ROOT, "vi-orb-slam-icra2018_amd"), os.path.join(ROOT, "oracle"), HERE):
         sys.path.insert(0, p_)
     print(json.dumps(run_extraction_configs(int(sys.argv[1]), int(sys.argv[2]))))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# (d) k_describe_blur at the image borders (r06): the reflected columns / rows of the blur and the scalar tail of its rounding
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(640, 480), (641, 363), (642, 301), (643, 480), (527, 241)])
+def test_describe_blur_border_keypoints_match_oracle(oracle, w, h, tally):
+    """Frames with strong corners planted along all four borders of every level -- keypoints 19 to 24 pixels from an edge, whose 43 x 43
+    blur neighbourhood leaves the image (BORDER_REFLECT_101, ref src/ORBextractor.cc:1104), on widths with w % 4 = 0 .. 3 (the columns
+    from w - w % 4 on take the scalar tail's rounding of OpenCV's column filter) -- through the batch path (k_describe_blur) and as
+    single frames (k_blur + k_describe), against the oracle; the test counts how many keypoints exercised each border path."""
+    from orbhip.extractor import ORBextractor
+    rng = np.random.default_rng(w * 1000 + h)
+    frames = []
+    for f in range(2):
+        img = rng.integers(90, 110, (h, w)).astype(np.int32)
+        # bright / dark squares whose corners fall 19 .. 24 pixels from the borders at several scales (so that higher levels see them too)
+        for s in (1.0, 1.2, 1.44, 1.728, 2.0736, 2.488, 2.986, 3.583):
+            d = int(round(21 * s)) + f
+            size = max(3, int(round(5 * s)))
+            for t in range(d, max(w, h), int(26 * s) + 3):
+                for (y, x) in ((d, t), (h - 1 - d, t), (t, d), (t, w - 1 - d)):
+                    if 0 <= y - size and y + size < h and 0 <= x - size and x + size < w:
+                        img[y - size:y, x - size:x] += 70 if (t // 7) % 2 else -70
+        frames.append(np.clip(img + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8))
+    frames = np.stack(frames)
+    # as many features as the batch path still describes with k_describe_blur (up to 2.5 keypoints per 1000 pyramid pixels)
+    P0 = oracle.params(1000)
+    NF = min(1500, sum(a * b for a, b in (oracle.level_size(P0, w, h, l) for l in range(8))) // 450)
+    ref = oracle.Extractor(NF)
+    want = [ref(f) for f in frames]
+    path_mask(reset=True)
+    ex = ORBextractor(NF, max_w=w, max_h=h, max_batch=8)
+    ks, ds = ex.extract_batch(np.concatenate([frames] * 4))
+    assert path_mask() >> PATH_BITS["k_describe_blur"] & 1
+    for b in range(8):
+        assert ks[b].tobytes() == want[b % 2][0].tobytes() and np.array_equal(ds[b], want[b % 2][1]), "batch frame %d (%d x %d)" % (b, w, h)
+    for b in range(2):                               # a frame at a time: k_blur + k_describe
+        k1, d1 = ex(frames[b])
+        assert k1.tobytes() == want[b][0].tobytes() and np.array_equal(d1, want[b][1])
+    ex.close()
+    # how many keypoints took which border path of k_describe_blur (level coordinates)
+    left = right = tail = rows = 0
+    for k, _ in want:
+        for l in range(8):
+            lw, lh = oracle.level_size(ref.params, w, h, l)
+            sel = k[k["octave"] == l]
+            sc = float(ref.params.mvScaleFactor[l])
+            cx = np.rint(sel["x"] / np.float32(sc)).astype(np.int64)
+            cy = np.rint(sel["y"] / np.float32(sc)).astype(np.int64)
+            left += int((cx < 23).sum())
+            right += int((cx + 21 >= lw).sum())
+            tail += int((cx + 18 >= lw - lw % 4).sum()) if lw % 4 else 0
+            rows += int(((cy < 21) | (cy + 21 >= lh)).sum())
+    assert left > 3 and right > 3 and rows > 6, (left, right, tail, rows)
+    tally("describe_blur border keypoints: columns reflected", left + right)
+    tally("describe_blur border keypoints: rows reflected", rows)
+    tally("describe_blur border keypoints: scalar-tail columns", tail)
