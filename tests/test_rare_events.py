@@ -160,7 +160,7 @@ def test_bow_seq_synthetic_batches_match_oracle(oracle, recipe, rep, tally):
     path_mask(reset=True)
     got = _bow_seq_device(ex, bufs, cap, B, lag, th_mode, ratio, check_ori, valid)
     mask = path_mask()
-    want_lane = 50.0 < ratio * 255.0
+    want_lane = 50.0 < ratio * 255.0 and os.environ.get("ORBHIP_BOW_LANE", "1") != "0"   # (ablation build: k_bow_seq for every pair)
     assert bool(mask >> 8 & 1) == want_lane and bool(mask >> 9 & 3) == (not want_lane), paths_of(mask)
     pairs, matches = _check_pairs(oracle, "synthetic %r" % (recipe,), desc, kps["angle"], counts, node, wt, valid, lag, th_mode, ratio,
                                   check_ori, got)
@@ -170,6 +170,18 @@ def test_bow_seq_synthetic_batches_match_oracle(oracle, recipe, rep, tally):
     for x in bufs.values():
         x.free()
     ex.close()
+
+
+def test_bow_seq_wave_per_node_kernel_on_the_same_batches():
+    """k_bow_seq, the fallback of k_bow_lane: the synthetic recipes with the lane kernel switched off (ORBHIP_BOW_LANE=0,
+    ablation build, child process) -- among them 2500 slots per frame (NP 4096: descriptors in global memory), one node holding
+    everything, five nodes beyond 128 candidates and a thousand small ones."""
+    ids = ["%s::test_bow_seq_synthetic_batches_match_oracle[seed%d-B%d-cap%d-0]" % ((os.path.abspath(__file__),) + r[:3])
+           for r in SYNTH_RECIPES if r[0] in (9001, 9003, 9005, 9006, 9010)]
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x"] + ids,
+                       env=dict(os.environ, ORBHIP_BOW_LANE="0"), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "5 passed" in p.stdout, p.stdout[-1500:]
 
 
 @pytest.mark.parametrize("seed,B,levelsup,k,Lv,th_mode", [(9101, 1024, 4, 10, 6, 0), (9102, 1024, 2, 10, 4, 1), (9103, 512, 1, 6, 3, 0)])

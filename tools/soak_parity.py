@@ -291,6 +291,24 @@ def soak_knn2_seq(budget, rng):
     print("soak knn2_seq ok: %d random configurations in %.0f s" % (n, time.time() - t0))
 
 
+_hip = None
+
+
+def probe(step, cfg):
+    """SOAK_PROBE=1: the HIP runtime's sticky last error after every step of the loop -- which call leaves one behind without reporting it?"""
+    global _hip
+    if not os.environ.get("SOAK_PROBE"):
+        return
+    if _hip is None:
+        import ctypes
+        _hip = ctypes.CDLL("libamdhip64.so.7")
+        _hip.hipGetErrorString.restype = ctypes.c_char_p
+    e = _hip.hipGetLastError()
+    if e:
+        print("PROBE: sticky HIP error %d (%s) after step '%s' of configuration %r" % (e, _hip.hipGetErrorString(e).decode(), step, cfg))
+        sys.exit(2)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     if len(sys.argv) > 3 and sys.argv[3] == "knn2seq":
@@ -349,6 +367,7 @@ def main():
         try:
             ex = ORBextractor(nf, scale, nlev, ini, mn, max_w=w, max_h=h, max_batch=2 * reps)
             ks, ds = ex.extract_batch(np.concatenate([frames] * reps))
+            probe("extract_batch", (w, h, nf, nlev, scale, seed, reps))
             for b in range(2, 2 * reps):
                 if ks[b].tobytes() != ks[b % 2].tobytes() or not np.array_equal(ds[b], ds[b % 2]):
                     print("MISMATCH batch copy", w, h, nf, nlev, scale, ini, mn, seed, b)
@@ -391,6 +410,7 @@ def main():
             use_grid = rng.random() < 0.85
             gpf = guided.grid_params(-0.05 * w, 1.04 * w, -0.03 * h, 1.05 * h)
             fb = ex.frame_build(frames[1], Kc, Dc, gpf if use_grid else None, min(lu, 4))
+            probe("frame_build", (w, h, nf, nlev, scale, seed, reps))
             kun = k1.copy()
             if nd and Dc[0] != 0:
                 xy = oracle.undistort_points(np.stack([k1["x"], k1["y"]], 1), Kc, Dc, Kc)
@@ -421,6 +441,7 @@ def main():
                     print("MISMATCH bow from frame block", w, h, nf, seed)
                     sys.exit(1)
                 Mf.close()
+                probe("bow from frame block", (w, h, nf, nlev, scale, seed, reps))
             # guided search / initialisation / triangulation
             gp = guided.grid_params(0, w, 0, h)
             sf = np.array(list(ref.params.mvScaleFactor)[:nlev], np.float32)
@@ -429,6 +450,7 @@ def main():
                                               k0["octave"], k0["angle"], rng.random(len(k0)) < 0.9, rng.random(len(k0)) < 0.7,
                                               float(rng.choice([7, 15, 30])), sf)
             a = guided.SearchByProjection(ex, k1, d1, gp, q, d0, use_ratio=False, nnratio=0.9, check_ori=True)
+            probe("SearchByProjection", (w, h, nf, nlev, scale, seed, reps))
             b_ = oracle.search_by_projection(k1, d1, gp, q, d0, use_ratio=False, nnratio=0.9, check_ori=True)
             if a[0] != b_[0] or not np.array_equal(a[1], b_[1]):
                 print("MISMATCH proj", w, h, nf, seed)
@@ -437,6 +459,7 @@ def main():
             prev = np.stack([k0["x"], k0["y"]], 1).astype(np.float32)
             win = int(rng.choice([10, 40, 100]))
             a = guided.SearchForInitialization(ex, k0, d0, k1, d1, gp, prev, win, 0.9, True)
+            probe("SearchForInitialization", (w, h, nf, nlev, scale, seed, reps))
             b_ = oracle.search_for_initialization(k0, d0, k1, d1, gp, prev, win, 0.9, True)
             if a[0] != b_[0] or not np.array_equal(a[1], b_[1]) or not np.array_equal(a[2], b_[2]):
                 print("MISMATCH init", w, h, nf, seed, win)
@@ -445,6 +468,7 @@ def main():
             F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-5, (3, 3)).astype(np.float32)
             sk0, sk1 = (rng.random(len(k0)) < 0.3).astype(np.uint8), (rng.random(len(k1)) < 0.3).astype(np.uint8)
             a = guided.SearchForTriangulation(ex, k0, d0, sk0, g[0], k1, d1, sk1, g[1], F, w / 2, h / 2, sf, s2)
+            probe("SearchForTriangulation", (w, h, nf, nlev, scale, seed, reps))
             b_ = oracle.search_for_triangulation(k0, d0, sk0, g[0], k1, d1, sk1, g[1], F, w / 2, h / 2, sf, s2)
             if a[0] != b_[0] or not np.array_equal(a[1], b_[1]):
                 print("MISMATCH tri", w, h, nf, seed)
@@ -465,6 +489,7 @@ def main():
                 if rng.random() < 0.5 else None
             isg = (np.float32(1) / s2).astype(np.float32) if gate else None
             a = guided.WindowBest(ex, k1, d1, gp, qw, d0, ur, isg)
+            probe("WindowBest", (w, h, nf, nlev, scale, seed, reps))
             b_ = oracle.window_best(k1, d1, gp, qw, d0, ur, isg)
             if not np.array_equal(a[0], b_[0]) or not np.array_equal(a[1], b_[1]):
                 print("MISMATCH window_best", w, h, nf, seed, gate, ur is not None)
@@ -486,7 +511,9 @@ def main():
                 print("MISMATCH bow_sets", w, h, nf, seed)
                 sys.exit(1)
             M.drop_set()
+            probe("sets", (w, h, nf, nlev, scale, seed, reps))
         ex.close()
+        probe("close", (w, h, nf, nlev, scale, seed, reps))
         n += 1
     print("soak ok: %d random configurations in %.0f s, %s" % (n, time.time() - t0, stats))
 

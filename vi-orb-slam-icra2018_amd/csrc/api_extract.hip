@@ -195,13 +195,25 @@ extern "C" orbhip_ctx *orbhip_create(int device, int nfeatures, float scaleFacto
 extern "C" void orbhip_destroy(orbhip_ctx *c)
 {
     if (!c) return;
+    static const int dbg = ORB_TUNE("DEBUG_DESTROY", 0);   // (ablation build: which step leaves a sticky HIP error behind?)
+    auto step = [&](const char *what) {
+        if (!dbg) return;
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) fprintf(stderr, "orbhip_destroy: sticky HIP error after %s: %s\n", what, hipGetErrorString(e));
+    };
+    step("entry");
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    step("sync");
     orb_comm_release(c);
     orb_pipe_release(c);
+    step("comm/pipe");
     orb_sets_release(c);
+    step("sets");
     orb_graph_release(c);
+    step("graph");
     orb_frame_release(c);
+    step("frame");
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
     void *bufs[] = {c->d_lvl0, c->d_pyr, c->d_blur, c->d_cand, c->d_cellCnt, c->d_pts, c->d_pnode,
@@ -218,8 +230,15 @@ extern "C" void orbhip_destroy(orbhip_ctx *c)
         if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     for (int i = 0; i < 2; i++)
         if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
+    step("events");
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    step("streams");
+    // Best-effort clean-up must not leave the runtime's sticky last error behind for whatever the thread calls next: e.g.
+    // hipEventSynchronize on a busy event whose recording stream -- another context's, destroyed before this one -- is gone can
+    // report "operation not permitted on an event last recorded in a capturing stream" (seen twice in 4440 soak configurations, r06;
+    // the next context's graph capture then failed on it).
+    (void)hipGetLastError();
     delete c;
 }
 
@@ -279,6 +298,9 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
 {
     const OrbLevels &G = c->G;
     hipStream_t s = c->stream;
+    // The chain ends with hipGetLastError() (a launch reports its failure there): start from a clean slate, so that a sticky error
+    // some EARLIER call of this thread left behind -- the caller's own HIP code, a best-effort clean-up -- is not taken for ours.
+    (void)hipGetLastError();
     // (timing events are not recorded into a graph capture: events recorded by a graph node cannot be read back with
     // hipEventElapsedTime on this runtime; the graph path refreshes the stage times with an eager run now and then)
     // (an event record between two kernels of a stream costs ~4 us of device time: orbhip_set_stage_timing narrows the set)
@@ -623,8 +645,9 @@ static int extract_small_graph(orbhip_ctx *c, const uint8_t *const *imgs, int B,
         c->capturing = false;
         if (rc != ORBHIP_OK || e != hipSuccess || e2 != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
+            const std::string inner = rc != ORBHIP_OK ? c->err : std::string();   // (what a call inside the captured chain reported)
             return fail(c, ORBHIP_E_HIP, std::string("graph capture of the single-frame chain failed: ") +
-                                             hipGetErrorString(e != hipSuccess ? e : e2));
+                                             hipGetErrorString(e != hipSuccess ? e : e2) + (inner.empty() ? "" : " [" + inner + "]"));
         }
         c->g_graph = g;
         HIPCHK(c, hipGraphInstantiate(&c->g_exec, g, nullptr, nullptr, 0));
