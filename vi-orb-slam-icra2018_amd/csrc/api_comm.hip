@@ -78,7 +78,7 @@ extern "C" int orbhip_comm_init(orbhip_ctx *c, int rank, int nranks, const uint8
 {
     if (!c || !uid || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, ORBHIP_E_ARG, "orbhip_comm_init: bad argument");
     if (!rccl_load()) return fail(c, ORBHIP_E_COMM, "cannot load librccl (or it lacks a required symbol)");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     orb_comm_release(c);
     rccl_uid_t u;
     memcpy(u.internal, uid, 128);
@@ -95,7 +95,7 @@ extern "C" int orbhip_comm_init(orbhip_ctx *c, int rank, int nranks, const uint8
 extern "C" int orbhip_comm_destroy(orbhip_ctx *c)
 {
     if (!c) return ORBHIP_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     orb_comm_release(c);
     return ORBHIP_OK;
@@ -124,7 +124,7 @@ extern "C" int orbhip_bcast_blob_device(orbhip_ctx *c, void *d_buf, size_t nbyte
         return fail(c, ORBHIP_E_COMM, "orbhip_comm_init was not called");
     }
     if (root < 0 || root >= c->nranks) return fail(c, ORBHIP_E_ARG, "orbhip_bcast_blob_device: bad root");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     // ncclChar = 0; with a communicator the collective runs also for one rank (an in-place no-op that exercises the RCCL path)
     int rc = g_rccl.bcast(d_buf, d_buf, nbytes, 0, root, c->comm, c->stream);
     if (rc != 0) return fail(c, ORBHIP_E_COMM, rccl_err("ncclBroadcast", rc));
@@ -137,7 +137,7 @@ extern "C" int orbhip_knn2_merge_device(orbhip_ctx *c, const void *d_parts, int 
     if (!c || nshards < 1 || nq < 0 || (nq > 0 && (!d_parts || !d_best_idx || !d_best_d || !d_second_d)))
         return fail(c, ORBHIP_E_ARG, "orbhip_knn2_merge_device: bad argument");
     if (nq == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     launch_knn2_merge(c->stream, (const int32_t *)d_parts, nshards, nq, (int32_t *)d_best_idx, (int32_t *)d_best_d,
                       (int32_t *)d_second_d);
     HIPCHK(c, hipGetLastError());
@@ -153,7 +153,7 @@ extern "C" int orbhip_knn2_allgather_merge_device(orbhip_ctx *c, const void *d_b
         return fail(c, ORBHIP_E_ARG, "orbhip_knn2_allgather_merge_device: bad argument");
     if (nq == 0) return ORBHIP_OK;
     if (c->nranks > 1 && !c->comm) return fail(c, ORBHIP_E_COMM, "orbhip_comm_init was not called");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     // scratch: my part [3 * nq + 1] then the gathered parts [nranks][3 * nq + 1]; part = best_idx | best_d | second_d | offset
     const size_t part = (size_t)3 * nq + 1;
     int rc;

@@ -22,6 +22,16 @@ static inline int fail(orbhip_ctx *c, int code, const std::string &msg) { return
             return fail((c), ORBHIP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
     } while (0)
 
+// Entry of a C-ABI call that launches kernels: the context's device becomes current, and the runtime's sticky last error -- whatever
+// an earlier call of this thread left behind without reading it: the caller's own HIP code, a best-effort clean-up -- is cleared,
+// so that the hipGetLastError() behind the launches reports THESE launches (r06: a stale error once failed a graph capture).
+static inline hipError_t orb_enter(const orbhip_ctx *c)
+{
+    const hipError_t e = hipSetDevice(c->device);
+    (void)hipGetLastError();
+    return e;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <class T>

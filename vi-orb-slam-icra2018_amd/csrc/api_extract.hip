@@ -412,11 +412,15 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
 #endif
     static const bool noSplit = ORB_TUNE("NO_SPLIT", 0) != 0;   // A/B: r02 schedule
     static const int fusedSched = ORB_TUNE("DESCRIBE_FUSED_SCHED", DF_SCHED);   // 1: quadtree(B) beside describe(A); 0: one quadtree launch
-    if (fusedDescribe && B >= 16 && fusedSched == 1) {
+    if (fusedDescribe && B >= 16 && fusedSched >= 1) {
         const int nA = B / 2, nB = B - nA;
+        if (fusedSched == 2) {                                  // (A/B: both quadtree halves from the end of FAST, side by side)
+            if (!evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
+        }
         quadtree_part(s, 0, nA);
         HIPCHK(c, hipEventRecord(c->ev[3], s));                 // quadtree(A) is done: the second stream may start quadtree(B)
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[3], 0));
+        if (fusedSched == 1) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[3], 0));
         quadtree_part(c->stream2, nA, nB);
         HIPCHK(c, hipEventRecord(c->evx[0], c->stream2));
         if (ev) HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -506,7 +510,7 @@ extern "C" int orbhip_set_stage_timing(orbhip_ctx *c, int mode)
 extern "C" int orbhip_get_stage_times(orbhip_ctx *c, float ms[6])
 {
     if (!c || !ms) return fail(c, ORBHIP_E_ARG, "orbhip_get_stage_times: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 6; i++) ms[i] = 0.f;
     if (c->haveFastEvents && !c->haveStageEvents) HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));    // FAST
@@ -528,7 +532,7 @@ extern "C" int orbhip_extract_batch_device(orbhip_ctx *c, const void *d_imgs, in
 {
     if (!c || !d_imgs || !d_kps || !d_desc || !d_counts || cap <= 0 || stride < w)
         return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch_device: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     c->h_pyr_B = 0;          // no host copy of this call's pyramid / level 0 (orbhip_host_pyramid_level reports that)
     c->h_in_valid = false;
     const bool aliasOk = (stride % 16 == 0) && (((uintptr_t)d_imgs) % 16 == 0) && (frame_stride % 16 == 0);
@@ -680,7 +684,7 @@ extern "C" int orbhip_extract_batch(orbhip_ctx *c, const uint8_t *const *imgs, i
 {
     if (!c || !imgs || !kps || !desc || !n_out || cap <= 0 || stride < w)
         return fail(c, ORBHIP_E_ARG, "orbhip_extract_batch: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const int s0 = (int)align_up((size_t)w, 64);
     int rc;
     if ((rc = orb_configure(c, w, h, s0, B))) return rc;
@@ -755,7 +759,7 @@ extern "C" int orbhip_get_pyramid_level(orbhip_ctx *c, int frame, int level, uin
     if (h) *h = L.h;
     if (!dst) return ORBHIP_OK;
     if (dst_stride < L.w) return fail(c, ORBHIP_E_ARG, "dst_stride too small");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     if (level == 0)
         return copy_level(c, c->last_lvl0 + (size_t)frame * c->last_frame0, c->last_stride0, L.w, L.h, dst, dst_stride);
     return copy_level(c, c->d_pyr + (size_t)frame * c->pyrFrameBytes + L.imgOff, L.stride, L.w, L.h, dst, dst_stride);
@@ -800,7 +804,7 @@ extern "C" int orbhip_debug_get_blurred_level(orbhip_ctx *c, int frame, int leve
     if (w) *w = L.w;
     if (h) *h = L.h;
     if (!dst) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const size_t bf = c->lvl0FrameBytes + c->pyrFrameBytes;
     if (!c->blurValid) {
         // the last batch ran k_describe_blur and never built the blurred pyramid: k_blur on the same levels, now
@@ -818,7 +822,7 @@ extern "C" int orbhip_debug_get_candidates(orbhip_ctx *c, int frame, int level, 
 {
     if (!c || !c->last_lvl0 || frame < 0 || frame >= c->last_B || level < 0 || level >= c->nlevels || !n_out)
         return fail(c, ORBHIP_E_ARG, "orbhip_debug_get_candidates: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const OrbLevels &G = c->G;
     const OrbLevel &L = G.lv[level];
     const int ncells = L.nCols * L.nRows;
@@ -850,7 +854,7 @@ extern "C" int orbhip_debug_get_level_keypoints(orbhip_ctx *c, int frame, int le
 {
     if (!c || !c->last_lvl0 || frame < 0 || frame >= c->last_B || level < 0 || level >= c->nlevels || !n_out)
         return fail(c, ORBHIP_E_ARG, "orbhip_debug_get_level_keypoints: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const OrbLevels &G = c->G;
     const OrbLevel &L = G.lv[level];
     int32_t cnts[ORBHIP_MAX_LEVELS];

@@ -158,7 +158,7 @@ extern "C" int orbhip_frame_build(orbhip_ctx *c, const uint8_t *img, int w, int 
     if (grid && (!cell_off || !cell_idx)) return fail(c, ORBHIP_E_ARG, "orbhip_frame_build: grid parameters without grid outputs");
     if (bow && (!word_id || !weight || !node_id)) return fail(c, ORBHIP_E_ARG, "orbhip_frame_build: levelsup >= 0 without transform outputs");
     if (bow && !c->voc.desc) return fail(c, ORBHIP_E_ARG, "orbhip_frame_build: no vocabulary loaded (orbhip_vocab_load)");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const int s0 = (int)align_up((size_t)w, 64);
     int rc;
     if ((rc = orb_configure(c, w, h, s0, 1))) return rc;
@@ -369,7 +369,7 @@ __global__ void k_floor(int32_t *out)
 extern "C" int orbhip_debug_roundtrip(orbhip_ctx *c, int mode, int iters, double *us_per_call)
 {
     if (!c || !us_per_call || iters <= 0 || mode < 0 || mode > 2) return fail(c, ORBHIP_E_ARG, "orbhip_debug_roundtrip: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     if ((rc = P.begin(16384))) return rc;

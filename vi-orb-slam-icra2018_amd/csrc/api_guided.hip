@@ -11,7 +11,7 @@ extern "C" int orbhip_grid_build_device(orbhip_ctx *c, const void *d_kps, const 
 {
     if (!c || !d_kps || !d_counts || cap <= 0 || B <= 0 || !d_cell_off || !d_cell_idx || !grid_params_ok(inv_w, inv_h))
         return fail(c, ORBHIP_E_ARG, "orbhip_grid_build_device: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     launch_grid_build(c->stream, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts, cap, B, min_x, min_y, inv_w,
                       inv_h, (int32_t *)d_cell_off, (int32_t *)d_cell_idx);
     HIPCHK(c, hipGetLastError());
@@ -23,7 +23,7 @@ extern "C" int orbhip_grid_build(orbhip_ctx *c, const orbhip_keypoint *kps, int 
 {
     if (!c || n < 0 || (n > 0 && (!kps || !cell_idx)) || !cell_off || !grid_params_ok(inv_w, inv_h))
         return fail(c, ORBHIP_E_ARG, "orbhip_grid_build: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const int cap = std::max(n, 1);
     Packed P(c);
     int rc;
@@ -51,7 +51,7 @@ extern "C" int orbhip_features_in_area(orbhip_ctx *c, const orbhip_keypoint *kps
         return fail(c, ORBHIP_E_ARG, "orbhip_features_in_area: bad argument");
     out_off[0] = 0;
     if (nq == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const int cap = std::max(n, 1);
     hipStream_t s = c->stream;
     int slots = 64;
@@ -104,7 +104,7 @@ extern "C" int orbhip_search_by_projection_device(orbhip_ctx *c, const void *d_k
         return fail(c, ORBHIP_E_ARG, "orbhip_search_by_projection_device: bad argument");
     if (proj_assign_lds(cap) > 120 * 1024)
         return fail(c, ORBHIP_E_ARG, "orbhip_search_by_projection_device: cap too large for the per-frame match table in LDS");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     int rc;
     if ((rc = orb_match_scratch(c, proj_scratch_bytes(B, cap_q, cap)))) return rc;
     launch_search_by_projection(c->stream, (const orbhip_keypoint *)d_kps, (const uint8_t *)d_desc, (const int32_t *)d_counts,
@@ -128,7 +128,7 @@ extern "C" int orbhip_search_by_projection(orbhip_ctx *c, const orbhip_keypoint 
     if (nmatches) *nmatches = 0;
     for (int i = 0; i < n; i++) match[i] = -1;
     if (n == 0 || nq == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     if ((rc = P.begin((size_t)n * (28 + 32 + 4 + 1 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (sizeof(orbhip_proj_query) + 32) + 16 * 256)))
@@ -166,7 +166,7 @@ extern "C" int orbhip_window_best_device(orbhip_ctx *c, const void *d_kps, const
         cap_q <= 0 || !d_best_idx || !d_best_dist || !grid_params_ok(inv_w, inv_h) || cap >= (1 << 23) ||
         (inv_level_sigma2 && (nlevels <= 0 || nlevels > 16)))
         return fail(c, ORBHIP_E_ARG, "orbhip_window_best_device: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     int rc;
     if ((rc = orb_match_scratch(c, window_best_scratch_bytes(B, cap)))) return rc;
     launch_window_best(c->stream, (const orbhip_keypoint *)d_kps, (const uint8_t *)d_desc, cap, B, (const float *)d_u_right,
@@ -194,7 +194,7 @@ extern "C" int orbhip_window_best(orbhip_ctx *c, const orbhip_keypoint *kps, con
         for (int i = 0; i < n; i++)
             if (kps[i].octave < 0 || kps[i].octave >= nlevels)
                 return fail(c, ORBHIP_E_ARG, "orbhip_window_best: a keypoint's octave has no entry in inv_level_sigma2");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     if ((rc = P.begin((size_t)n * (28 + 32 + 4 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + (size_t)nq * (sizeof(orbhip_proj_query) + 32 + 8) + 16 * 256)))
@@ -237,7 +237,7 @@ extern "C" int orbhip_search_for_initialization_device(orbhip_ctx *c, const void
         return fail(c, ORBHIP_E_ARG, "orbhip_search_for_initialization_device: bad argument");
     if (init_assign_lds(cap1, cap2) > 112 * 1024)
         return fail(c, ORBHIP_E_ARG, "orbhip_search_for_initialization_device: cap too large for the per-pair match tables in LDS");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     int rc;
     if ((rc = orb_match_scratch(c, init_scratch_bytes(B, cap1, cap2)))) return rc;
     launch_search_for_initialization(c->stream, (const orbhip_keypoint *)d_kps1, (const uint8_t *)d_desc1,
@@ -260,7 +260,7 @@ extern "C" int orbhip_search_for_initialization(orbhip_ctx *c, const orbhip_keyp
     if (nmatches) *nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     if ((rc = P.begin((size_t)n1 * (28 + 32 + 8 + 4) + (size_t)n2 * (28 + 32 + 4) + (ORBHIP_GRID_CELLS + 1) * 4 + 16 * 256))) return rc;

@@ -23,7 +23,7 @@ extern "C" int orbhip_hamming_knn2_device(orbhip_ctx *c, const void *d_q, int nq
     if (!c || nq < 0 || ndb < 0 || (nq > 0 && (!d_q || !d_best_idx || !d_best_d || !d_second_d)) || (ndb > 0 && !d_db))
         return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2_device: bad argument");
     if (nq == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     int rc;
     const size_t need = knn2_scratch_bytes(nq, ndb);
     if ((rc = orb_match_scratch(c, need))) return rc;
@@ -41,7 +41,7 @@ extern "C" int orbhip_hamming_knn2_seq_device(orbhip_ctx *c, const void *d_desc,
 {
     if (!c || !d_desc || !d_counts || cap <= 0 || B <= 0 || lag < 0 || !d_best_idx || !d_best_d || !d_second_d)
         return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2_seq_device: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     launch_knn2_seq(c->stream, (const uint8_t *)d_desc, (const int32_t *)d_counts, cap, B, lag,
                     (int32_t *)d_best_idx, (int32_t *)d_best_d, (int32_t *)d_second_d);
@@ -57,7 +57,7 @@ extern "C" int orbhip_hamming_knn2(orbhip_ctx *c, const uint8_t *q, int nq, cons
     if (!c || nq < 0 || ndb < 0 || (nq > 0 && (!q || !best_idx || !best_d || !second_d)) || (ndb > 0 && !db))
         return fail(c, ORBHIP_E_ARG, "orbhip_hamming_knn2: bad argument");
     if (nq == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     TmpDev T(c);
     int rc;
     if ((rc = T.reserve((size_t)nq * 32 + (size_t)ndb * 32 + (size_t)nq * 12 + 2048))) return rc;
@@ -87,7 +87,7 @@ extern "C" int orbhip_hamming_knn2_lists(orbhip_ctx *c, const uint8_t *q, int nq
         if (off[i] > off[i + 1] || off[i] < 0) return fail(c, ORBHIP_E_ARG, "offsets must be non-decreasing");
     for (int t = 0; t < ncand; t++)
         if (cand[t] < 0 || cand[t] >= ndb) return fail(c, ORBHIP_E_ARG, "candidate index out of range");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     TmpDev T(c);
     int rc;
     if ((rc = T.reserve((size_t)nq * 32 + (size_t)ndb * 32 + (size_t)nq * 16 + (size_t)ncand * 4 + 4096))) return rc;
@@ -176,7 +176,7 @@ extern "C" int orbhip_search_by_bow(orbhip_ctx *c, const uint8_t *desc1, int n1,
         if (idx1[t] < 0 || idx1[t] >= n1) return fail(c, ORBHIP_E_ARG, "idx1 out of range");
     for (int t = 0; t < m2; t++)
         if (idx2[t] < 0 || idx2[t] >= n2) return fail(c, ORBHIP_E_ARG, "idx2 out of range");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     const size_t total = (size_t)n1 * 32 + (size_t)n2 * 32 + (size_t)n1 + (size_t)n2 + (size_t)(ng1 + ng2 + 2) * 4 +
@@ -268,7 +268,7 @@ extern "C" int orbhip_vocab_load(orbhip_ctx *c, const void *blob, size_t nbytes)
     std::string err;
     int rc = orb_vocab_parse((const uint8_t *)blob, nbytes, H, err);
     if (rc != ORBHIP_OK) return fail(c, rc, "orbhip_vocab_load: " + err);
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const size_t ne = (size_t)H.nnodes - 1;
     // one device block, 256-byte aligned sections (tables by edge, see OrbVocabDev)
     size_t off[5], total = 0;
@@ -345,7 +345,7 @@ extern "C" int orbhip_vocab_share(orbhip_ctx *dst, const orbhip_ctx *src)
 extern "C" int orbhip_vocab_load_device(orbhip_ctx *c, const void *d_blob, size_t nbytes)
 {
     if (!c || !d_blob || nbytes < 24) return fail(c, ORBHIP_E_ARG, "orbhip_vocab_load_device: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     std::vector<uint8_t> host(nbytes);
     HIPCHK(c, hipMemcpy(host.data(), d_blob, nbytes, hipMemcpyDeviceToHost));
     return orbhip_vocab_load(c, host.data(), nbytes);
@@ -371,7 +371,7 @@ extern "C" int orbhip_vocab_transform_device(orbhip_ctx *c, const void *d_desc, 
         return fail(c, ORBHIP_E_ARG, "orbhip_vocab_transform_device: bad argument");
     if (!c->voc.desc) return fail(c, ORBHIP_E_ARG, "orbhip_vocab_transform: no vocabulary loaded");
     if (n == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     launch_vocab_transform(c->stream, c->voc, (const uint8_t *)d_desc, n, levelsup, (int32_t *)d_word, (float *)d_weight,
                            (int32_t *)d_node);
     HIPCHK(c, hipGetLastError());
@@ -384,7 +384,7 @@ extern "C" int orbhip_vocab_transform(orbhip_ctx *c, const uint8_t *desc, int n,
     if (!c || n < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id)))
         return fail(c, ORBHIP_E_ARG, "orbhip_vocab_transform: bad argument");
     if (n == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     if ((rc = P.begin((size_t)n * 44 + 4 * 256))) return rc;
@@ -411,7 +411,7 @@ extern "C" int orbhip_search_by_bow_seq_device(orbhip_ctx *c, const void *d_desc
     if (cap > 4096)   // the sorted keys, match table and work items of a frame pair live in LDS: 36 bytes per slot
         return fail(c, ORBHIP_E_SIZE, "orbhip_search_by_bow_seq_device: more than 4096 feature slots per frame (the per-pair "
                                       "tables exceed the 160 KB of LDS); use orbhip_search_by_bow per pair");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     if (c->stageTiming >= 2) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_bow_seq(c->stream, (const uint8_t *)d_desc, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts,
                              (const int32_t *)d_node, (const float *)d_weight, (const uint8_t *)d_valid, cap, B, lag, 50, th_mode,
@@ -427,7 +427,7 @@ extern "C" int orbhip_distinctive_descriptors_device(orbhip_ctx *c, const void *
     if (!c || P < 0 || (P > 0 && (!d_desc || !d_off || !d_best || !d_best_median)))
         return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors_device: bad argument");
     if (P == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     launch_distinctive(c->stream, (const uint8_t *)d_desc, (const int32_t *)d_off, P, (int32_t *)d_best, (int32_t *)d_best_median);
     HIPCHK(c, hipGetLastError());
     return ORBHIP_OK;
@@ -445,7 +445,7 @@ extern "C" int orbhip_distinctive_descriptors(orbhip_ctx *c, const uint8_t *desc
             return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors: offsets must ascend, a list holds fewer than 2^20 rows");
     const int total = off[P];
     if (total > 0 && !desc) return fail(c, ORBHIP_E_ARG, "orbhip_distinctive_descriptors: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     TmpDev T(c);
     int rc;
     if ((rc = T.reserve((size_t)total * 32 + (size_t)(P + 1) * 4 + (size_t)P * 8 + 4096))) return rc;
@@ -505,7 +505,7 @@ extern "C" int orbhip_search_for_triangulation(orbhip_ctx *c, const orbhip_keypo
         if (idx2[t] < 0 || idx2[t] >= n2) return fail(c, ORBHIP_E_ARG, "idx2 out of range");
     for (int i = 0; i < n2; i++)
         if (kps2[i].octave < 0 || kps2[i].octave >= nlevels2) return fail(c, ORBHIP_E_ARG, "octave of key frame 2 out of range");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     const size_t total = (size_t)(n1 + n2) * (28 + 32 + 1 + 4) + (size_t)(ng1 + ng2 + 2) * 4 + (size_t)(m1 + m2 + 2) * 4 +

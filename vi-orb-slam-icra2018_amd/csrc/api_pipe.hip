@@ -42,7 +42,7 @@ extern "C" void orbhip_host_free(void *p)
 extern "C" int orbhip_pipe_create(orbhip_ctx *c, int depth, int B, int w, int h)
 {
     if (!c || depth < 2 || depth > 8 || B < 1 || w < 1 || h < 1) return fail(c, ORBHIP_E_ARG, "orbhip_pipe_create: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     orb_pipe_release(c);
     // device rows are the image rows when they are 16-byte multiples (level 0 is then read in place), else padded to 64
@@ -96,7 +96,7 @@ extern "C" int orbhip_pipe_create(orbhip_ctx *c, int depth, int B, int w, int h)
 extern "C" int orbhip_pipe_destroy(orbhip_ctx *c)
 {
     if (!c) return ORBHIP_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     orb_pipe_release(c);
     return ORBHIP_OK;
@@ -110,7 +110,7 @@ extern "C" int orbhip_pipe_submit(orbhip_ctx *c, const uint8_t *frames, int B, i
         return fail(c, ORBHIP_E_ARG, "orbhip_pipe_submit: bad argument");
     if (P->submitted - P->waited >= P->depth)
         return fail(c, ORBHIP_E_CAPACITY, "orbhip_pipe_submit: every slot holds results that were not collected (orbhip_pipe_wait)");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     c->h_pyr_B = 0;          // no host copy of the pyramid in this mode (orbhip_host_pyramid_level reports that)
     c->h_in_valid = false;
     const int s = (int)(P->submitted % P->depth);
@@ -176,7 +176,7 @@ extern "C" int orbhip_pipe_wait(orbhip_ctx *c, const orbhip_keypoint **kps, cons
     if (!c || !c->pipe) return fail(c, ORBHIP_E_ARG, "orbhip_pipe_wait: no pipeline (orbhip_pipe_create)");
     OrbPipe *P = c->pipe;
     if (P->waited >= P->submitted) return fail(c, ORBHIP_E_ARG, "orbhip_pipe_wait: nothing submitted");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     const int s = (int)(P->waited % P->depth), hb = (int)(P->waited % (P->depth + 1));
     HIPCHK(c, hipEventSynchronize(P->evOut[s]));
     if (kps) *kps = (const orbhip_keypoint *)(P->h_out[hb] + P->koff);
@@ -195,7 +195,7 @@ extern "C" int orbhip_pipe_enable_bow(orbhip_ctx *c, int levelsup, float nnratio
     if (!c->voc.desc) return fail(c, ORBHIP_E_ARG, "orbhip_pipe_enable_bow: no vocabulary loaded");
     OrbPipe *P = c->pipe;
     if (P->dcap > 4096) return fail(c, ORBHIP_E_SIZE, "orbhip_pipe_enable_bow: more than 4096 feature slots per frame");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     if (!P->d_bowScratch) {
         void *p = nullptr;
         HIPCHK(c, hipMalloc(&p, (size_t)P->B * P->dcap * 12 + 256));

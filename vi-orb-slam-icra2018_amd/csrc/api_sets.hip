@@ -139,7 +139,7 @@ extern "C" int orbhip_set_drop(orbhip_ctx *c, uint64_t key)
 {
     if (!c) return ORBHIP_E_ARG;
     if (!c->setTable) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     OrbSetTable *T = static_cast<OrbSetTable *>(c->setTable);
     for (size_t i = 0; i < T->sets.size();)
@@ -258,7 +258,7 @@ extern "C" int orbhip_set_put(orbhip_ctx *c, uint64_t key, const orbhip_keypoint
         return fail(c, ORBHIP_E_ARG, "orbhip_set_put: bad argument");
     int rc;
     if ((rc = csr_check(c, "orbhip_set_put", node, off, idx, ng, n))) return rc;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     OrbSet *s = set_acquire(c, key, n);
     if (!s) return ORBHIP_E_HIP;
     OrbSetTable *T = table(c);
@@ -321,7 +321,7 @@ extern "C" int orbhip_set_put_from_frame(orbhip_ctx *c, uint64_t key, orbhip_ctx
     if (ng > n) return fail(c, ORBHIP_E_ARG, "orbhip_set_put_from_frame: bad argument");
     int rc;
     if ((rc = csr_check(c, "orbhip_set_put_from_frame", node, off, idx, ng, n))) return rc;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     OrbSet *s = set_acquire(c, key, n, dcap);
     if (!s) return ORBHIP_E_HIP;
     OrbSetTable *T = table(c);
@@ -382,7 +382,7 @@ extern "C" int orbhip_search_by_bow_sets(orbhip_ctx *c, uint64_t key1, const uin
     // (k_bow_match keeps the position inside a node's side-2 list in 20 bits, as in orbhip_search_by_bow)
     if (s2->ng > 0 && s2->off[s2->ng] >= (1 << 20))
         return fail(c, ORBHIP_E_SIZE, "orbhip_search_by_bow_sets: more than 2^20 - 1 entries in the second FeatureVector");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     if ((rc = P.begin((size_t)n1 + (size_t)n2 + pairs.size() * 4 + (size_t)(n1 + n2) * 4 + 12 * 256))) return rc;
@@ -438,7 +438,7 @@ extern "C" int orbhip_window_best_set(orbhip_ctx *c, uint64_t key, const float *
         best_dist[i] = 256;
     }
     if (nq == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     Packed P(c);
     int rc;
     const int n = s->n;

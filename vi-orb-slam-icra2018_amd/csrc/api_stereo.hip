@@ -82,7 +82,7 @@ extern "C" int orbhip_undistort_keypoints_device(orbhip_ctx *c, const void *d_kp
 {
     if (!c || !d_kps || !d_kps_un || cap <= 0 || B <= 0 || !dist_ok(K, dist, ndist))
         return fail(c, ORBHIP_E_ARG, "orbhip_undistort_keypoints_device: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     launch_undistort(c->stream, (const orbhip_keypoint *)d_kps, (const int32_t *)d_counts, cap, B, K, dist, ndist, P,
                      (orbhip_keypoint *)d_kps_un);
     HIPCHK(c, hipGetLastError());
@@ -95,7 +95,7 @@ extern "C" int orbhip_undistort_keypoints(orbhip_ctx *c, const orbhip_keypoint *
     if (!c || n < 0 || (n > 0 && (!kps || !kps_un)) || !dist_ok(K, dist, ndist))
         return fail(c, ORBHIP_E_ARG, "orbhip_undistort_keypoints: bad argument");
     if (n == 0) return ORBHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     TmpDev T(c);
     int rc;
     if ((rc = T.reserve((size_t)n * 56 + 1024))) return rc;
@@ -119,7 +119,7 @@ extern "C" int orbhip_init_undistort_rectify_map(const double K[9], const double
 extern "C" int orbhip_remap_set_maps(orbhip_ctx *c, const float *map_x, const float *map_y, int w, int h)
 {
     if (!c || !map_x || !map_y || w <= 0 || h <= 0) return fail(c, ORBHIP_E_ARG, "orbhip_remap_set_maps: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->d_maps) HIPCHK(c, hipFree(c->d_maps));
     c->d_maps = nullptr;
@@ -140,7 +140,7 @@ extern "C" int orbhip_remap_device(orbhip_ctx *c, const void *d_src, int B, int 
         return fail(c, ORBHIP_E_ARG, "orbhip_remap_device: bad argument");
     if (!c->d_maps) return fail(c, ORBHIP_E_ARG, "orbhip_remap_device: no maps (orbhip_remap_set_maps)");
     if (dst_stride < c->map_w) return fail(c, ORBHIP_E_ARG, "orbhip_remap_device: dst_stride smaller than the map width");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     launch_remap(c->stream, (const uint8_t *)d_src, B, src_w, src_h, src_stride, src_frame_stride, c->d_maps,
                  c->d_maps + (size_t)c->map_w * c->map_h, c->map_w, c->map_h, (uint8_t *)d_dst, dst_stride, dst_frame_stride);
     HIPCHK(c, hipGetLastError());
@@ -154,7 +154,7 @@ extern "C" int orbhip_remap(orbhip_ctx *c, const uint8_t *src, int src_w, int sr
         return fail(c, ORBHIP_E_ARG, "orbhip_remap: bad argument");
     if (!c->d_maps) return fail(c, ORBHIP_E_ARG, "orbhip_remap: no maps (orbhip_remap_set_maps)");
     if (dst_stride < c->map_w) return fail(c, ORBHIP_E_ARG, "orbhip_remap: dst_stride smaller than the map width");
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, orb_enter(c));
     TmpDev T(c);
     int rc;
     const size_t sbytes = (size_t)src_stride * src_h, dpitch = align_up((size_t)c->map_w, 64), dbytes = dpitch * c->map_h;
