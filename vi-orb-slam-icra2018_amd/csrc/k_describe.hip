@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 // 1.15 with spills / 1.08); the moments from the staged rows instead of loads of their own, in rounds of two keypoints per wave
 // with the angles of a round computed between two workgroup barriers (removes ~40 cache lines per keypoint, worth 0.09 ms
 // by ablation; the barriers and the lost overlap cost 0.17: 1.05); unused LDS capping the workgroups per CU at 4 / 3 / 2:
-// 0.99 / 1.16 / 1.52 for the kernel alone (0.85 at 5).
+// 0.99 / 1.16 / 1.52 for the kernel alone (0.85 at 5); every wave on its own (DF_AUTONOMOUS, no workgroup barrier): 0.972 / 0.969.
 // =====================================================================================================================
 #define DF_ROWS 48                    // staged raw rows: 43 needed, the rest complete the three 16-row tiles
 #define DF_PITCH 48                   // bytes per staged row: columns cx - 23 .. cx + 24 (12 dwords: the A operand's 16 rows fall on distinct banks)
@@ -527,6 +527,9 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 #endif
 #ifndef DF_KP
 #define DF_KP 32                      // keypoint slots per workgroup (a multiple of 16)
+#endif
+#ifndef DF_AUTONOMOUS
+#define DF_AUTONOMOUS 0                // 1: every wave decodes its own slots and computes its own angles, no workgroup barrier (measured: no change)
 #endif
 #ifndef DF_SKIP_CORNER
 #define DF_SKIP_CORNER 1
@@ -604,9 +607,13 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
     const int32_t *cnts = lvlKpCnt + frame * ORBHIP_MAX_LEVELS;
 
     // ---- 0. slot -> (level, position, output index): as k_describe ----
+    // (DF_AUTONOMOUS=1, an experiment kept as a compile-time option: lanes 0 .. 7 of EVERY wave decode the wave's own eight slots
+    // (wave + 4 q) and compute their angles, so that no workgroup barrier is left and a wave that waits for its loads or walks the
+    // scalar angle sequence holds no other -- 0.972 ms against 0.969 with the three barriers: they were not what the kernel waits for.)
     int my_score = 0;
-    if (tid < DS_KP) {
-        const int g = g0 + tid;
+    const int mySlot = DF_AUTONOMOUS ? wave + 4 * lane : tid;
+    if (DF_AUTONOMOUS ? lane < NQ : tid < DS_KP) {
+        const int g = g0 + mySlot;
         int pos = -1, o = 0;
         if (g < G.totalKps) {
             int l = 0, off = 0, total = 0;
@@ -628,14 +635,19 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
                 o = off + i;
             }
         }
-        s_pos[tid] = pos;
-        s_out[tid] = o;
+        s_pos[mySlot] = pos;
+        s_out[mySlot] = o;
         const int l = pos >= 0 ? pos >> 24 : 0;
-        s_ioff[tid] = l == 0 ? 0u : (unsigned)G.lv[l].imgOff;
-        s_istride[tid] = l == 0 ? stride0 : G.lv[l].stride;
-        s_wh[tid] = G.lv[l].w | (G.lv[l].h << 16);
+        s_ioff[mySlot] = l == 0 ? 0u : (unsigned)G.lv[l].imgOff;
+        s_istride[mySlot] = l == 0 ? stride0 : G.lv[l].stride;
+        s_wh[mySlot] = G.lv[l].w | (G.lv[l].h << 16);
     }
-    __syncthreads();
+    if (DF_AUTONOMOUS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else
+        __syncthreads();
     ORB_ABL_STOP(phases < 1);
 
     // the raw neighbourhood of slot kp -> buf: lane (row of 21, chunk of 3); rows 43.. repeat row 42
@@ -762,24 +774,29 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
         }
         }
     }
-    __syncthreads();
+    if (DF_AUTONOMOUS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else
+        __syncthreads();
     ORB_ABL_STOP(phases < 2);
 
     // ---- B. angle, cos / sin, keypoint record: one thread per keypoint (k_describe) ----
-    if (tid < DS_KP) {
-        const int pos = s_pos[tid];
+    if (DF_AUTONOMOUS ? lane < NQ : tid < DS_KP) {
+        const int pos = s_pos[mySlot];
         if (pos >= 0) {
             const int cx = pos & 0xFFF, cy = (pos >> 12) & 0xFFF, l = pos >> 24;
             const OrbLevel &L = G.lv[l];
-            const float angle = fast_atan2_dev((float)s_m01[tid], (float)s_m10[tid]);
+            const float angle = fast_atan2_dev((float)s_m01[mySlot], (float)s_m10[mySlot]);
             const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
             const float rad = __fmul_rn(angle, factorPI);
             float a, b;
             orb_sincosf(rad, &b, &a);
-            s_a[tid] = a;
-            s_b[tid] = b;
-            lvlAngle[(size_t)frame * G.totalKps + g0 + tid] = angle;
-            const int o = s_out[tid];
+            s_a[mySlot] = a;
+            s_b[mySlot] = b;
+            lvlAngle[(size_t)frame * G.totalKps + g0 + mySlot] = angle;
+            const int o = s_out[mySlot];
             if (o < cap) {
                 orbhip_keypoint kp;
                 kp.x = __fmul_rn((float)cx, L.scale);
@@ -793,7 +810,12 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
             }
         }
     }
-    __syncthreads();
+    if (DF_AUTONOMOUS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else
+        __syncthreads();
     ORB_ABL_STOP(phases < 3);
 
     // ---- C. per keypoint: blur of the staged neighbourhood, then the 256 tests on it ----
