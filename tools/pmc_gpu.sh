@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: one timeout 600 rocprofv3 --pmc pass with the given counters; prints per-kernel averages.
+# Runs ON THE GPU BOX: one rocprofv3 --pmc pass with the given counters; prints per-kernel averages.
 # Usage: tools/pmc_gpu.sh <tag> "<counters>" [bench args...]
 TAG=$1; CTRS=$2; shift 2
 ARGS=${@:---steps 3 --warmup 1 --batch 1024 --cpu-frames 0 --pipelined 0 --host-batch 0 --configs 0 --content 0 --batch-sweep 0 --verify 0}
