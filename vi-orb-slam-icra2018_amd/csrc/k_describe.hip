@@ -538,8 +538,6 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 #define DF_OP 40                      // pitch of the blurred patch, [column 0..36][row 0..36 (+3)]
 typedef int dfv4i __attribute__((ext_vector_type(4)));
 typedef float dfv4f __attribute__((ext_vector_type(4)));
-typedef uint32_t dfv8u __attribute__((ext_vector_type(8)));
-typedef uint32_t dfv4u __attribute__((ext_vector_type(4)));
 typedef _Float16 dfv8h __attribute__((ext_vector_type(8)));
 
 struct DfBands {
