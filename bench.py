@@ -113,26 +113,11 @@ def cpu_baseline(frames, nsample, match, blob, keep=0):
     return (res, kept) if keep else res
 
 
-_SCENE = None
-
-
-def _warp_one(t):
-    from orbhip import synth
-    return synth.warp_frame(_SCENE, W, H, t)
-
-
 def make_stream_frames(seed, count, workers):
     """`count` consecutive frames of the synthetic stream `seed` (orbhip.synth.make_frames: one scene under a slowly varying
     warp), drawn by a pool of forked workers -- 32 ms a frame on one core.  Call BEFORE anything touches the GPU."""
-    global _SCENE
     from orbhip import synth
-    _SCENE = synth.make_scene(seed, W, H)
-    workers = max(1, min(workers, count // 8))
-    if workers == 1:
-        return np.stack([_warp_one(t) for t in range(count)])
-    import multiprocessing as mp
-    with mp.get_context("fork").Pool(workers) as pool:
-        return np.stack(pool.map(_warp_one, range(count), chunksize=max(1, count // (4 * workers))))
+    return synth.make_frames_parallel(seed, W, H, count, workers)
 
 
 def oracle_worker(path, first, last, match, out_path):

@@ -85,3 +85,26 @@ def test_a_difference_beyond_a_frames_count_is_not_a_difference():
         bufs["desc"][b, n] ^= 0xFF
         bufs["m21"][b, n] += 7
     assert m.verify_tiled_copies(bufs, U, B, cap, "bow") == B - (U + 1)
+
+
+def test_stream_frames_by_forked_workers_and_oracle_by_worker_processes(oracle):
+    """Round 6: the timed batch is a stream of distinct frames drawn by forked workers, and every frame is verified against oracle
+    outputs computed by worker PROCESSES on slices of the batch.  Both must equal what one process computes: the frames of
+    orbhip.synth.make_frames, and the oracle's keypoints / descriptors / SearchByBoW of every pair -- also across the slice bounds
+    (a worker recomputes the frame in front of its slice for the pair)."""
+    from orbhip import distributed as D, synth
+    m = _bench()
+    frames = m.make_stream_frames(77, 16, 3)
+    assert frames.shape == (16, m.H, m.W) and np.array_equal(frames, synth.make_frames(77, m.W, m.H, 16))
+    assert np.array_equal(m.make_stream_frames(77, 9, 1), frames[:9])               # (one worker: in-process)
+    blob = D.make_synthetic_vocabulary(5, k=10, L=3)
+    n = 9
+    par = m.oracle_outputs_parallel(frames[:n], "bow", blob, 3)                      # 3 slices: 0-2, 3-5, 6-8
+    one = m.cpu_baseline(frames[:n], n, "bow", blob, keep=n)[1]
+    assert len(par) == len(one) == n
+    for b in range(n):
+        assert par[b]["k"].tobytes() == one[b]["k"].tobytes() and np.array_equal(par[b]["d"], one[b]["d"]), b
+        assert ("bow" in par[b]) == ("bow" in one[b]) == (b > 0)
+        if b:
+            assert par[b]["bow"][0] == one[b]["bow"][0] > 0
+            assert np.array_equal(par[b]["bow"][1], one[b]["bow"][1]) and np.array_equal(par[b]["bow"][2], one[b]["bow"][2])
