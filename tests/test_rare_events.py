@@ -320,7 +320,7 @@ def run_extraction_configs(nconf, seed, budget_s=1e9):
         nlev = int(rng.integers(2, 9))
         scale = float(rng.choice([1.2, 1.2, 1.15, 1.3, 1.5, 1.08, 1.75, 2.0]))
         ini, mn = (20, 7) if rng.random() < 0.7 else (int(rng.integers(12, 40)), int(rng.integers(3, 12)))
-        reps = 4 if n % 2 else 1
+        reps = 8 if n % 6 == 5 else (4 if n % 2 else 1)   # batches of 2, 8 and 16 frames (16: the two-stream schedule of the half-batches)
         aim = None
         r = rng.random()
         if r < 0.04:                                   # the global-memory quadtree: a per-level quota beyond the LDS tables
