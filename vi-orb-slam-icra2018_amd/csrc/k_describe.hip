@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 // 1.15 with spills / 1.08); the moments from the staged rows instead of loads of their own, in rounds of two keypoints per wave
 // with the angles of a round computed between two workgroup barriers (removes ~40 cache lines per keypoint, worth 0.09 ms
 // by ablation; the barriers and the lost overlap cost 0.17: 1.05); unused LDS capping the workgroups per CU at 4 / 3 / 2:
-// 0.99 / 1.16 / 1.52 for the kernel alone (0.85 at 5); every wave on its own (DF_AUTONOMOUS, no workgroup barrier): 0.972 / 0.969.
+// 0.99 / 1.16 / 1.52 for the kernel alone (0.85 at 5); every wave on its own (DF_AUTONOMOUS, no workgroup barrier): 0.972 / 0.969;
+// a keypoint's descriptor stored one iteration late (so that the wait at the top of the next iteration does not cover it): 0.975 / 0.975.
 // =====================================================================================================================
 #define DF_ROWS 48                    // staged raw rows: 43 needed, the rest complete the three 16-row tiles
 #define DF_PITCH 48                   // bytes per staged row: columns cx - 23 .. cx + 24 (12 dwords: the A operand's 16 rows fall on distinct banks)
