@@ -495,7 +495,9 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 //   column pass  v_mfma_f32_16x16x32_f16 with two row-pass tiles (rows 0-15 and 16-31 of a block) as the B operand IN PLACE:
 //                the contraction runs over the tiles' row index, which lives in the registers; k-slot j of lane quarter q is
 //                row 4q + j (j < 4) or 16 + 4q + j - 4, and the band operand A is laid out for exactly that order; byte planes
-//                as binary16 0x0400 | byte, weights tap * 2^8, accumulator started at minus the constant part: exact (k_blur.hip);
+//                as binary16 0x2400 | byte = (1024 + byte) * 2^-16, weights tap * 2^8 for the high plane and tap for the low one, both
+//                into one accumulator started at minus the constant part, high plane first: exact wherever the result is not
+//                saturated anyway (see the kernel; k_blur.hip keeps the planes at 2^-24, two accumulators and an fma);
 //   rounding     v_cvt_pk_u8_f32 = round half to even + saturation (the SSE2 column filter of OpenCV 2.4 for x < w - w % 4);
 //                keypoints whose patch reaches the scalar tail's columns take floor(v + 0.5) there (wave-uniform branch);
 // -- one strip of 16 blurred columns at a time (12 + 12 registers of tiles and planes live) into the wave's patch buffer (37 x 37,
@@ -510,6 +512,7 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 //   + the strip's six column products issued before their roundings                                 1.07
 //   + 32 slots per workgroup, first neighbourhood requested behind the disc loads                   1.01
 //   + one strip at a time into a patch buffer of its own (74 registers)                             0.97
+//   + both byte planes into ONE accumulator (planes at 2^-16, a band per plane: no combining fma)   0.955
 // and not kept: v_pk_mul / add / fma_f32 for the tests and the roundings (they issue at half the rate of the scalar forms: the
 // same time, 16 more registers: 1.17 at four workgroups per CU); five / six / four workgroups per CU by register bound (1.08 /
 // 1.15 with spills / 1.08); the moments from the staged rows instead of loads of their own, in rounds of two keypoints per wave
@@ -543,7 +546,8 @@ typedef _Float16 dfv8h __attribute__((ext_vector_type(8)));
 
 struct DfBands {
     unsigned row[64][4];   // B operand of the row pass: lane (n = l & 15, q = l >> 4), byte j: tap[16 q + j - n - DF_A]
-    unsigned col[64][4];   // A operand of the column pass: lane (m = l & 15, q), half j: tap[row(q, j) - m] * 256 as binary16
+    unsigned col[64][4];   // A operand of the column pass, HIGH byte plane: lane (m = l & 15, q), half j: tap[row(q, j) - m] * 256 as binary16
+    unsigned colLo[64][4]; // ... LOW byte plane: tap[row(q, j) - m]
 };
 constexpr unsigned df_half_bits(int v)   // binary16 pattern of a small positive integer (exact below 2048 * 2^k)
 {
@@ -566,14 +570,15 @@ constexpr DfBands make_df_bands()
         }
         for (int j = 0; j < 8; j++) {
             const int r = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4), i = r - n;
-            const unsigned v = (i >= 0 && i <= 6) ? df_half_bits(tap[i] * 256) : 0u;
+            const unsigned v = (i >= 0 && i <= 6) ? df_half_bits(tap[i] * 256) : 0u, vlo = (i >= 0 && i <= 6) ? df_half_bits(tap[i]) : 0u;
             b.col[l][j >> 1] |= v << (16 * (j & 1));
+            b.colLo[l][j >> 1] |= vlo << (16 * (j & 1));
         }
     }
     return b;
 }
 __constant__ __attribute__((aligned(16))) DfBands c_df_bands = make_df_bands();
-static_assert(df_half_bits(18 * 256) == 0x6C80 && df_half_bits(55 * 256) == 0x72E0, "binary16 of tap * 256");
+static_assert(df_half_bits(18 * 256) == 0x6C80 && df_half_bits(55 * 256) == 0x72E0 && df_half_bits(18) == 0x4C80 && df_half_bits(55) == 0x52E0, "binary16 of tap * 256, tap");
 
 __device__ __forceinline__ void df_glds16(const void *gsrc, uint32_t ldsAddr)
 {
@@ -829,13 +834,20 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
     }
     const uint4 bandRow = *reinterpret_cast<const uint4 *>(&c_df_bands.row[lane][0]);
     const uint4 bandCol = *reinterpret_cast<const uint4 *>(&c_df_bands.col[lane][0]);
+    const uint4 bandColLo = *reinterpret_cast<const uint4 *>(&c_df_bands.colLo[lane][0]);
     const int n16 = lane & 15, q4 = lane >> 4;
     dfv4i hinit;
     dfv4f zinit;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        hinit[i] = 128 * 257 + 0x04000000;
-        zinit[i] = -(float)(257 * 1024) / 65536.0f;
+        // Byte planes as binary16 0x2400 | byte = (1024 + byte) * 2^-16 (the 0x24 rides in the row pass's start value); the high plane is
+        // weighted tap * 2^8, the low plane tap, and BOTH accumulate into one register set started at minus the constant part
+        // (257 * 1024 * (2^-8 + 2^-16)), high plane first: after it every partial sum is a multiple of 2^-8 below 2^11 (19 bits); during the
+        // low plane they are multiples of 2^-16 that only grow -- exact below 256 (24 bits), and one that reaches 256 ends above 255.5,
+        // i.e. saturated whatever its last bit.  The result is S * 2^-16 itself: no combine, one start value per block (k_blur keeps two
+        // accumulators and an fma: its planes sit at 2^-24 because its 32 x 32 tiles leave no registers for a second band).
+        hinit[i] = 128 * 257 + 0x24000000;
+        zinit[i] = -(float)(257 * 1024) * (1.0f / 256.0f + 1.0f / 65536.0f);
     }
     bool sentCur = sent0;
 #pragma unroll 1
@@ -883,7 +895,7 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
                         lo[rt][d] = __builtin_amdgcn_perm(y, x, 0x07040300u);
                         hi[rt][d] = __builtin_amdgcn_perm(y, x, 0x07050301u);
                     }
-                dfv4f zl[3], zh[3];
+                dfv4f z[3];
 #pragma unroll
                 for (int mb = 0; mb < 3; mb++) {
                     // rows 32 .. 36 x columns 32 .. 36: 14 or more pixels from the centre both ways -- beyond the pattern's radius
@@ -892,15 +904,15 @@ __global__ __launch_bounds__(256, DF_WG_PER_CU) void k_describe_blur(const OrbLe
                     const int m2 = mb < 2 ? mb + 1 : 2;   // (what follows tile 2 is multiplied by zeros of the band)
                     const uint4 bl = make_uint4(lo[mb][0], lo[mb][1], lo[m2][0], lo[m2][1]);
                     const uint4 bh = make_uint4(hi[mb][0], hi[mb][1], hi[m2][0], hi[m2][1]);
-                    zl[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandCol), __builtin_bit_cast(dfv8h, bl), zinit, 0, 0, 0);
-                    zh[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandCol), __builtin_bit_cast(dfv8h, bh), zinit, 0, 0, 0);
+                    z[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandCol), __builtin_bit_cast(dfv8h, bh), zinit, 0, 0, 0);
+                    z[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dfv8h, bandColLo), __builtin_bit_cast(dfv8h, bl), z[mb], 0, 0, 0);
                 }
 #pragma unroll
                 for (int mb = 0; mb < 3; mb++) {
                     if (DF_SKIP_CORNER && mb == 2 && cs == 2) continue;
-                    float v[4];   // S * 2^-16 = high plane * 256 + low plane, exact
+                    float v[4];   // S * 2^-16
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = fmaf(zh[mb][e], 256.0f, zl[mb][e]);
+                    for (int e = 0; e < 4; e++) v[e] = z[mb][e];
                     if (tail) {
                         const bool up = cx - 18 + 16 * cs + n16 >= wvec;   // this lane's column: (S + 32768) >> 16
 #pragma unroll
