@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256, 8) void k_describe(const OrbLevels G, const ui
 // with the angles of a round computed between two workgroup barriers (removes ~40 cache lines per keypoint, worth 0.09 ms
 // by ablation; the barriers and the lost overlap cost 0.17: 1.05); unused LDS capping the workgroups per CU at 4 / 3 / 2:
 // 0.99 / 1.16 / 1.52 for the kernel alone (0.85 at 5); every wave on its own (DF_AUTONOMOUS, no workgroup barrier): 0.972 / 0.969;
-// a keypoint's descriptor stored one iteration late (so that the wait at the top of the next iteration does not cover it): 0.975 / 0.975.
+// a keypoint's descriptor stored one iteration late (so that the wait at the top of the next iteration does not cover it): 0.975 / 0.975;
+// the column pass on v_mfma_f32_16x16x16_f16 (K = 16 = one row-pass tile: its two plane registers ARE the operand, no copies into four
+// consecutive registers; four chained products per block, two for rows 32 .. 36): 0.955 / 0.953, bit-exact.
 // =====================================================================================================================
 #define DF_ROWS 48                    // staged raw rows: 43 needed, the rest complete the three 16-row tiles
 #define DF_PITCH 48                   // bytes per staged row: columns cx - 23 .. cx + 24 (12 dwords: the A operand's 16 rows fall on distinct banks)
