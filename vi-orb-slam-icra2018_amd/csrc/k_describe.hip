@@ -978,8 +978,9 @@ bool describe_blur_available(const OrbLevels &G, int B)
     }
     // Blurring 37 x 37 pixels per keypoint beats blurring the pyramid while the keypoints are few for the pixels: measured
     // (profiles/r06/describe_blur.md) +10 % of the whole step at 640 x 480 / 1000 features (1.1 keypoints per 1000 pyramid pixels),
-    // +6 % at 1241 x 376 / 2000 (1.4), -10 % at 640 x 480 / 4000 (4.2).  The switch sits at 2.5 (ORBHIP_DESCRIBE_FUSED=2: always).
-    if (fusedEnv != 2) ok = ok && (long long)G.totalKps * 400 <= px;
+    // +6 % at 1241 x 376 / 2000 (1.4), -10 % at 640 x 480 / 4000 (4.2); the extraction alone (tools/time_extract.py): -2.9 % of its
+    // time at 1.6, +2.1 % at 2.1, +5.6 % at 2.6, a tie at 2.1 on 1241 x 376.  The switch sits at 2.0 (ORBHIP_DESCRIBE_FUSED=2: always).
+    if (fusedEnv != 2) ok = ok && (long long)G.totalKps * 500 <= px;
     return ok;
 }
 
