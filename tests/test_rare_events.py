@@ -460,7 +460,7 @@ def test_describe_blur_border_keypoints_match_oracle(oracle, w, h, tally):
     frames = np.stack(frames)
     # as many features as the batch path still describes with k_describe_blur (up to 2.0 keypoints per 1000 pyramid pixels)
     P0 = oracle.params(1000)
-    NF = min(1500, sum(a * b for a, b in (oracle.level_size(P0, w, h, l) for l in range(8))) // 520)
+    NF = min(1500, sum(a * b for a, b in (oracle.level_size(P0, w, h, l) for l in range(8))) // 600)
     ref = oracle.Extractor(NF)
     want = [ref(f) for f in frames]
     path_mask(reset=True)
