@@ -410,10 +410,14 @@ int orb_run_pipeline(orbhip_ctx *c, const uint8_t *lvl0, int stride0, size_t fra
 #ifndef DF_SCHED
 #define DF_SCHED 1
 #endif
+#ifndef DF_SPLIT
+#define DF_SPLIT 4
+#endif
     static const bool noSplit = ORB_TUNE("NO_SPLIT", 0) != 0;   // A/B: r02 schedule
     static const int fusedSched = ORB_TUNE("DESCRIBE_FUSED_SCHED", DF_SCHED);   // 1: quadtree(B) beside describe(A); 0: one quadtree launch
+    static const int fusedSplit = ORB_TUNE("DESCRIBE_FUSED_SPLIT", DF_SPLIT);   // eighths of the batch in the first part
     if (fusedDescribe && B >= 16 && fusedSched >= 1) {
-        const int nA = B / 2, nB = B - nA;
+        const int nA = std::max(8, B * fusedSplit / 8), nB = B - nA;
         if (fusedSched == 2) {                                  // (A/B: both quadtree halves from the end of FAST, side by side)
             if (!evFast) HIPCHK(c, hipEventRecord(c->ev[2], s));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
