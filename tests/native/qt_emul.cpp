@@ -18,6 +18,7 @@ extern "C" int qt_emul_distribute(const uint32_t *pts, int n, int regw, int regh
     int m = N + 4;
     if (4 * P.nIni + 4 > m) m = 4 * P.nIni + 4;
     P.maxNodes = m;
+    P.maxIter = 64;
     void *mem = calloc(1, qt_shared_bytes(m));
     uint32_t *pnode = (uint32_t *)calloc((size_t)n + 1, 4);
     uint32_t *tmp = (uint32_t *)calloc((size_t)m, 4);

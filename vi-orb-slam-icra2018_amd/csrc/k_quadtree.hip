@@ -117,8 +117,11 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
                                                   int32_t *__restrict__ lvlCandCnt,
                                                   uint32_t *__restrict__ lvlKp,
                                                   int32_t *__restrict__ lvlKpCnt, int maxNodes, int qtBytes, int cellBytes,
-                                                  int ldsPts, uint8_t *__restrict__ tableScratch)
+                                                  int ldsPts, uint8_t *__restrict__ tableScratch ORB_ABL_PARAM)
 {
+    // timing ablation (liborbhip_ablation.so, ORBHIP_QT_PHASES; INVALID results): bits 0..7 = passes of the distribution (0: all),
+    // bit 8 = stop behind the gather, bits 12..15 = only level (value - 1)
+    ORB_ABL_STOP(((phases >> 12) & 15) != 0 && (int)blockIdx.y != ((phases >> 12) & 15) - 1);
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_wtot[18];
     // level = blockIdx.y: workgroups are dispatched x-fastest, so every frame's level 0 (the longest chain) starts first
@@ -148,6 +151,12 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
         }
     }
     for (int c = tid; c < ncells; c += blockDim.x) cellOff[c] = cc[c];
+    // batches, one root (nIni == 1): the gather below also labels the points for the first pass of the distribution and counts
+    // them into the root's four children (qt_distribute's firstCounted) -- one trip over the points and one barrier fewer
+    QtShared sh;
+    qt_carve(sh, GLOBALT ? tableScratch + ((size_t)frame * gridDim.y + l) * (size_t)qtBytes : smem, maxNodes);
+    const bool firstCounted = !LDSPTS && L.nIni == 1;
+    if (firstCounted && tid < 4) sh.ccnt[tid] = 0;
     if (LDSPTS) {
         // (pins the prefetched values above the barrier: the compiler would otherwise sink each load to its use)
 #pragma unroll
@@ -178,19 +187,59 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
                 for (int jj = idx & 15; jj < kk; jj += 16) P[o + jj] = src[jj];
             }
         } else {
-            for (int c = tid; c < ncells; c += blockDim.x) {
-                const int k = cc[c], o = cellOff[c];
-                const uint32_t *src = slots + (size_t)c * L.cellCap;
-                for (int j = 0; j < k; j++) P[o + j] = src[j];
+            // batches: 32 lanes per cell (a cell of the bench's frames holds ~26 candidates; a thread per cell walked them one
+            // dependent trip to memory after the other, a quarter of the kernel's time), four (cell, lane) pairs per thread and
+            // trip with the loads ahead of the stores
+            constexpr int GL = 32, GK = 4;
+            const int npairsB = ncells * GL;
+            const int midx = qt_ceil_half((int)(short)(int)(L.hX * 1.f)), midy = qt_ceil_half((int)(short)L.regh);   // the root: (0, 0) .. (hX, regh)
+            const bool split = firstCounted && n > 1;
+            int cq[4] = {0, 0, 0, 0};
+            auto put = [&](int d, uint32_t v) {
+                P[d] = v;
+                if (firstCounted) {
+                    const int q = split ? (QT_X(v) < midx ? 0 : 1) + (QT_Y(v) < midy ? 0 : 2) : 0;
+                    PN[d] = (uint32_t)q << 30;
+                    if (split) {
+                        cq[0] += q == 0;
+                        cq[1] += q == 1;
+                        cq[2] += q == 2;
+                        cq[3] += q == 3;
+                    }
+                }
+            };
+            for (int idx0 = tid; idx0 < npairsB; idx0 += GK * (int)blockDim.x) {
+                uint32_t val[GK];
+                int dst[GK], cnt[GK];
+#pragma unroll
+                for (int k = 0; k < GK; k++) {
+                    const int idx = idx0 + k * (int)blockDim.x;
+                    const bool live = idx < npairsB;
+                    const int c = live ? idx / GL : 0, j = idx % GL;
+                    const int o = cellOff[c];
+                    cnt[k] = live ? (c + 1 < ncells ? cellOff[c + 1] : n) - o : 0;
+                    dst[k] = o + j;
+                    val[k] = j < cnt[k] ? slots[(size_t)c * L.cellCap + j] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < GK; k++) {
+                    const int idx = idx0 + k * (int)blockDim.x;
+                    const int c = idx < npairsB ? idx / GL : 0, j = idx % GL;
+                    if (j < cnt[k]) put(dst[k], val[k]);
+                    for (int jj = j + GL; jj < cnt[k]; jj += GL) put(dst[k] - j + jj, slots[(size_t)c * L.cellCap + jj]);   // (rare)
+                }
+            }
+            if (split) {   // workgroup-uniform
+#pragma unroll
+                for (int q = 0; q < 4; q++) x.reduce_add(&sh.ccnt[q], cq[q]);
             }
         }
         if (tid == 0) lvlCandCnt[frame * ORBHIP_MAX_LEVELS + l] = n;
         // make the compact array visible to the whole workgroup (global memory, same CU)
         __threadfence_block();
         __syncthreads();
+        ORB_ABL_STOP(phases & 256);
 
-        QtShared sh;
-        qt_carve(sh, GLOBALT ? tableScratch + ((size_t)frame * gridDim.y + l) * (size_t)qtBytes : smem, maxNodes);
         QtParams Q;
         Q.N = L.N;
         Q.nIni = L.nIni;
@@ -198,8 +247,12 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
         Q.regw = L.regw;
         Q.regh = L.regh;
         Q.maxNodes = L.kpCap;
+        Q.maxIter = 64;
+#ifdef ORBHIP_ABLATION
+        if ((phases & 255) != 0) Q.maxIter = (phases & 255) - 1;
+#endif
         uint32_t *out = lvlKp + (size_t)frame * G.totalKps + L.kpBase;
-        const int S = qt_distribute(x, Q, n, P, PN, sh, out);
+        const int S = qt_distribute(x, Q, n, P, PN, sh, out, firstCounted);
         if (tid == 0) lvlKpCnt[frame * ORBHIP_MAX_LEVELS + l] = S;
     };
     if (LDSPTS && n <= ldsPts) {   // block-uniform
@@ -240,13 +293,15 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
     static const int forced = ORB_TUNE("QT_THREADS", 256);
     const int nthreads = forced >= 64 && forced <= 256 && forced % 64 == 0 ? forced : 256;
     dim3 grid(B, G.nlevels, 1), block(nthreads, 1, 1);
+    static const int phases = ORB_TUNE("QT_PHASES", 0);
+    (void)phases;
     const size_t base = quadtree_lds_bytes(G);
     const int cellBytes = (int)(base - (size_t)qtBytes);
     if (base > QT_LDS_LIMIT) {
         // tables in global memory (tableScratch sized by quadtree_table_scratch_bytes); LDS holds the cell offsets only
         orb_path(ORB_PATH_QT_GLOBAL);
         hipLaunchKernelGGL((k_quadtree<false, true>), grid, block, (size_t)cellBytes, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp,
-                           lvlKpCnt, maxNodes, qtBytes, cellBytes, 0, tableScratch);
+                           lvlKpCnt, maxNodes, qtBytes, cellBytes, 0, tableScratch ORB_ABL_ARG(phases));
         return;
     }
     if (B < 8) {
@@ -260,11 +315,11 @@ void launch_quadtree(hipStream_t s, const OrbLevels &G, const uint32_t *cand, co
             block = dim3(smallThreads >= 64 && smallThreads <= 1024 && smallThreads % 64 == 0 ? smallThreads : 1024, 1, 1);
             orb_path(ORB_PATH_QT_LDSPTS);
             hipLaunchKernelGGL((k_quadtree<true, false>), grid, block, base + (size_t)ldsPts * 8, s, G, cand, cellCnt, pts, pnode,
-                               lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes, cellBytes, ldsPts, nullptr);
+                               lvlCandCnt, lvlKp, lvlKpCnt, maxNodes, qtBytes, cellBytes, ldsPts, nullptr ORB_ABL_ARG(phases));
             return;
         }
     }
     orb_path(ORB_PATH_QT_LDS);
     hipLaunchKernelGGL((k_quadtree<false, false>), grid, block, base, s, G, cand, cellCnt, pts, pnode, lvlCandCnt, lvlKp, lvlKpCnt,
-                       maxNodes, qtBytes, cellBytes, 0, nullptr);
+                       maxNodes, qtBytes, cellBytes, 0, nullptr ORB_ABL_ARG(phases));
 }

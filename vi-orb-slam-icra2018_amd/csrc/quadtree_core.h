@@ -7,7 +7,8 @@
 //   * a "pass" (one trip of the reference's while loop, :596-741) is: count the points of the
 //     four children of every node that is being split (one atomic per point), then rebuild the
 //     node list with prefix sums so that it has exactly the order std::list would have after
-//     the push_front/erase sequence, then relabel the points;
+//     the push_front/erase sequence, then relabel the points -- and, in the same trip over the
+//     points (r06), count them into the children of their NEW node for the next pass;
 //   * the final phase (:675-739: expand the largest nodes first, stop as soon as the list has N
 //     nodes) splits all candidates speculatively, ranks them by (size desc, list position asc)
 //     and commits the prefix of that order up to the break point.  List position ascending is
@@ -28,8 +29,13 @@
 
 #if defined(__HIPCC__)
 #define QT_HD __host__ __device__ __forceinline__
+#define QT_UNROLL _Pragma("unroll")
 #else
 #define QT_HD inline
+#define QT_UNROLL
+#endif
+#ifndef QT_K
+#define QT_K 4   // points per thread and trip of the loops over the points
 #endif
 
 // Candidate packing: x[0..11] | y[12..23] | score[24..31]; x,y relative to (16,16) of the level.
@@ -45,6 +51,7 @@ struct QtParams {
     int regw;     // maxX - minX
     int regh;     // maxY - minY
     int maxNodes; // capacity of the node arrays (>= max(N + 3, 4 * nIni))
+    int maxIter;  // 64 (the reference's loop ends long before); fewer only in the timing ablation of k_quadtree
 };
 
 // Working set of one (frame, level) problem.  All arrays have maxNodes entries unless noted.
@@ -56,6 +63,7 @@ struct QtShared {
     short *n_ulx, *n_uly, *n_brx, *n_bry;
     int *n_cnt;
     int *ccnt;     // [4 * maxNodes] child point counts of the pass
+    int *ccnt2;    // [4 * maxNodes] ... of the next pass (filled while the points are relabelled; the two swap)
     int *npos;     // new list position of a surviving node (or -1 when it is erased)
     int *cpos;     // [4 * maxNodes] new list position of child q of node p (or -1)
     int *scan;     // scan workspace
@@ -79,7 +87,7 @@ QT_HD size_t qt_shared_bytes(int maxNodes)
     size_t m = (size_t)((maxNodes + 1) & ~1);
     return m * 2 * 8      // 8 short arrays
            + m * 4 * 2    // cnt, n_cnt
-           + m * 4 * 4    // ccnt
+           + m * 4 * 4 * 2 // ccnt, ccnt2
            + m * 4        // npos
            + m * 4 * 4    // cpos
            + (m + 8) * 4  // scan
@@ -103,6 +111,7 @@ QT_HD void qt_carve(QtShared &sh, void *base, int maxNodes)
     sh.cnt = (int *)p; p += m * 4;
     sh.n_cnt = (int *)p; p += m * 4;
     sh.ccnt = (int *)p; p += m * 16;
+    sh.ccnt2 = (int *)p; p += m * 16;
     sh.npos = (int *)p; p += m * 4;
     sh.cpos = (int *)p; p += m * 16;
     sh.scan = (int *)p; p += (m + 8) * 4;
@@ -136,64 +145,108 @@ QT_HD void qt_child_box(int q, int ulx, int uly, int brx, int bry, short &cx0, s
 //   pnode[n] scratch: list position of the owning node (bits 0..29) and quadrant (bits 30..31)
 //   out[]    packed winners in list order (capacity maxNodes)
 // Returns the number of winners (every thread gets the same value).
+//   firstCounted  (one root only) the caller has labelled the points for the first pass while it laid them out: pnode[i] =
+//            quadrant in the root << 30 (the root: (0, 0) .. ((int)hX, regh)), sh.ccnt[0..3] = the four counts
 template <class X>
 QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__restrict__ pts,
-                        uint32_t *__restrict__ pnode, QtShared &sh, uint32_t *__restrict__ out)
+                        uint32_t *__restrict__ pnode, QtShared &sh, uint32_t *__restrict__ out, const bool firstCounted = false)
 {
     const int M = P.maxNodes;
+    const bool oneRoot = P.nIni == 1;
+    int S;
     // ---- roots (:549-587): nIni nodes side by side, points by x/hX, empty roots erased ----
-    for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.ccnt[i] = 0;
-    x.sync();
-    if (P.nIni == 1) {
-        // one root (every image less than 1.5 times as wide as high): all points are its points
-        for (int i = x.tid(); i < n; i += x.nth()) pnode[i] = 0u;
-        if (x.tid() == 0) sh.ccnt[0] = n;
+    if (oneRoot) {
+        // one root (every image less than 1.5 times as wide as high): all points are its points -- no trip over the points here,
+        // the first pass labels them
+        if (x.tid() == 0) {
+            sh.ulx[0] = 0;
+            sh.uly[0] = 0;
+            sh.brx[0] = (short)(int)(P.hX * 1.f);
+            sh.bry[0] = (short)P.regh;
+            sh.cnt[0] = n;
+        }
+        if (!firstCounted)
+            for (int i = x.tid(); i < 4; i += x.nth()) sh.ccnt[i] = 0;
+        S = n > 0 ? 1 : 0;
+        x.sync();
     } else {
+        for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.ccnt[i] = 0;
+        x.sync();
         for (int i = x.tid(); i < n; i += x.nth()) {
             int r = (int)((float)QT_X(pts[i]) / P.hX);
             r = r < 0 ? 0 : (r >= P.nIni ? P.nIni - 1 : r);
             pnode[i] = (uint32_t)r;
             x.atomic_add(&sh.ccnt[r], 1);
         }
+        x.sync();
+        for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.scan[i] = sh.ccnt[i] > 0 ? 1 : 0;
+        x.sync();
+        S = x.scan_exclusive(sh.scan, P.nIni); // sh.scan[i] = new position of root i
+        for (int i = x.tid(); i < P.nIni; i += x.nth()) {
+            if (sh.ccnt[i] > 0) {
+                const int s = sh.scan[i];
+                sh.ulx[s] = (short)(int)(P.hX * (float)i);
+                sh.uly[s] = 0;
+                sh.brx[s] = (short)(int)(P.hX * (float)(i + 1));
+                sh.bry[s] = (short)P.regh;
+                sh.cnt[s] = sh.ccnt[i];
+                sh.npos[i] = s;
+            } else
+                sh.npos[i] = -1;
+        }
+        x.sync();
+        for (int i = x.tid(); i < n; i += x.nth()) pnode[i] = (uint32_t)sh.npos[pnode[i]];
+        for (int i = x.tid(); i < 4 * S; i += x.nth()) sh.ccnt[i] = 0;   // (the root counts were consumed before the last sync)
+        x.sync();
     }
-    x.sync();
-    for (int i = x.tid(); i < P.nIni; i += x.nth()) sh.scan[i] = sh.ccnt[i] > 0 ? 1 : 0;
-    x.sync();
-    int S = x.scan_exclusive(sh.scan, P.nIni); // sh.scan[i] = new position of root i
-    for (int i = x.tid(); i < P.nIni; i += x.nth()) {
-        if (sh.ccnt[i] > 0) {
-            const int s = sh.scan[i];
-            sh.ulx[s] = (short)(int)(P.hX * (float)i);
-            sh.uly[s] = 0;
-            sh.brx[s] = (short)(int)(P.hX * (float)(i + 1));
-            sh.bry[s] = (short)P.regh;
-            sh.cnt[s] = sh.ccnt[i];
-            sh.npos[i] = s;
-        } else
-            sh.npos[i] = -1;
-    }
-    x.sync();
-    for (int i = x.tid(); i < n; i += x.nth()) pnode[i] = (uint32_t)sh.npos[pnode[i]];
-    for (int i = x.tid(); i < 4 * S; i += x.nth()) sh.ccnt[i] = 0;   // (the root counts were consumed before the last sync)
-    x.sync();
 
     bool careful = false; // inside the final phase (:675-739)
-    for (int iter = 0; iter < 64; ++iter) {
+    bool winnersDone = false;
+    for (int iter = 0; iter < P.maxIter; ++iter) {
         // ---- which nodes are split candidates: every node holding more than one point ----
         // (after a full pass, and after a completed careful pass, all such nodes are children
         //  created by the previous pass, i.e. exactly vSizeAndPointerToNode)
-        // (ccnt[0 .. 4 S) is zero here: cleared before the loop and at the end of every pass)
         // ---- children point counts (speculative for every candidate) ----
-        for (int i = x.tid(); i < n; i += x.nth()) {
-            const uint32_t pn = pnode[i] & 0x3FFFFFFFu;
-            if (sh.cnt[pn] > 1) {
-                const uint32_t pk = pts[i];
-                const int q = qt_quadrant(QT_X(pk), QT_Y(pk), sh.ulx[pn], sh.uly[pn], sh.brx[pn], sh.bry[pn]);
-                pnode[i] = pn | ((uint32_t)q << 30);
-                x.atomic_add(&sh.ccnt[4 * pn + q], 1);
+        // First pass only (ccnt[0 .. 4 S) was cleared before the loop): every later pass finds them counted by the
+        // relabelling trip of the pass before it.
+        // The trips over the points take QT_K points per thread at a time, every stage for all of them before the next one:
+        // a trip is a chain of dependent round trips (labels and candidates from memory, then the node's table entries from
+        // LDS, then the atomic), and neither the compiler (the atomics and the label stores keep it from moving loads) nor the
+        // handful of waves a CU holds hides them.
+        if (iter == 0 && !(firstCounted && oneRoot)) {
+            for (int i0 = x.tid(); i0 < n; i0 += QT_K * x.nth()) {
+                uint32_t pn[QT_K], pk[QT_K];
+                int c[QT_K], bx0[QT_K], by0[QT_K], bx1[QT_K], by1[QT_K];
+                QT_UNROLL
+                for (int k = 0; k < QT_K; ++k) {
+                    const int i = i0 + k * x.nth();
+                    pn[k] = (!oneRoot && i < n) ? (pnode[i] & 0x3FFFFFFFu) : 0u;
+                    pk[k] = i < n ? pts[i] : 0u;
+                }
+                QT_UNROLL
+                for (int k = 0; k < QT_K; ++k) {
+                    c[k] = sh.cnt[pn[k]];
+                    bx0[k] = sh.ulx[pn[k]];
+                    by0[k] = sh.uly[pn[k]];
+                    bx1[k] = sh.brx[pn[k]];
+                    by1[k] = sh.bry[pn[k]];
+                }
+                QT_UNROLL
+                for (int k = 0; k < QT_K; ++k) {
+                    const int i = i0 + k * x.nth();
+                    if (i < n) {
+                        uint32_t lab = pn[k];
+                        if (c[k] > 1) {
+                            const int q = qt_quadrant(QT_X(pk[k]), QT_Y(pk[k]), bx0[k], by0[k], bx1[k], by1[k]);
+                            lab |= (uint32_t)q << 30;
+                            x.atomic_add(&sh.ccnt[4 * pn[k] + q], 1);
+                        }
+                        pnode[i] = lab;
+                    }
+                }
             }
+            x.sync();
         }
-        x.sync();
 
         int jstar = -1; // careful phase: last rank that is processed
         int C = 0;      // number of candidates
@@ -362,6 +415,9 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             x.sync();
         }
 
+        // The loop ends behind this pass when the list is long enough or did not grow (the loop control below): its trip over the
+        // points then picks the winners of the new nodes instead of preparing a pass that never runs.
+        const bool last = newS >= P.N || newS == S;
         // ---- build the next list ----
         // (the size of the next list is known from the scans above; the number of expandable children is summed per wave
         // before it touches the shared counter -- one atomic per node on two counters was the longest step of a pass)
@@ -390,16 +446,64 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             }
             x.reduce_add(&sh.scal[QT_S_NEXP], nexp);   // called by every thread of the workgroup
         }
-        x.sync();
-        // ---- relabel the points ----
-        for (int i = x.tid(); i < n; i += x.nth()) {
-            const uint32_t v = pnode[i];
-            const uint32_t pn = v & 0x3FFFFFFFu;
-            const int np = sh.npos[pn];
-            pnode[i] = (uint32_t)(np >= 0 ? np : sh.cpos[4 * pn + (v >> 30)]);
+        if (last) {
+            for (int i = x.tid(); i < newS; i += x.nth()) sh.best[i] = 0u;   // (the careful pass's keys in best[] are spent)
+        } else {
+            for (int i = x.tid(); i < 4 * newS; i += x.nth()) sh.ccnt2[i] = 0;   // the next pass's child counts
         }
-        // the child counts of this pass were consumed by the list build above: clear them for the next pass's list
-        for (int i = x.tid(); i < 4 * newS; i += x.nth()) sh.ccnt[i] = 0;
+        x.sync();
+        // ---- relabel the points, and count them into the children of their new node (the next pass's counts; one pass too
+        // many at the end, whose quadrant bits the winners mask off) ----
+        for (int i0 = x.tid(); i0 < n; i0 += QT_K * x.nth()) {
+            uint32_t v[QT_K], pk[QT_K];
+            int np[QT_K], cp[QT_K], c[QT_K], bx0[QT_K], by0[QT_K], bx1[QT_K], by1[QT_K];
+            QT_UNROLL
+            for (int k = 0; k < QT_K; ++k) {
+                const int i = i0 + k * x.nth();
+                v[k] = i < n ? pnode[i] : 0u;
+                pk[k] = i < n ? pts[i] : 0u;
+            }
+            QT_UNROLL
+            for (int k = 0; k < QT_K; ++k) {
+                const uint32_t pn = v[k] & 0x3FFFFFFFu;
+                np[k] = sh.npos[pn];
+                cp[k] = sh.cpos[4 * pn + (v[k] >> 30)];   // (stale where the node was not split: not taken then)
+            }
+            if (last) {
+                // winners (:743-764): max response per node, the first in candidate order among equals
+                QT_UNROLL
+                for (int k = 0; k < QT_K; ++k) {
+                    const int i = i0 + k * x.nth();
+                    if (i < n)
+                        x.atomic_max(&sh.best[np[k] >= 0 ? np[k] : cp[k]], ((uint32_t)QT_S(pk[k]) << 24) | (0xFFFFFFu - (uint32_t)i));
+                }
+                continue;
+            }
+            QT_UNROLL
+            for (int k = 0; k < QT_K; ++k) {
+                const int i = i0 + k * x.nth();
+                const int s = i < n ? (np[k] >= 0 ? np[k] : cp[k]) : 0;
+                np[k] = s;
+                c[k] = sh.n_cnt[s];
+                bx0[k] = sh.n_ulx[s];
+                by0[k] = sh.n_uly[s];
+                bx1[k] = sh.n_brx[s];
+                by1[k] = sh.n_bry[s];
+            }
+            QT_UNROLL
+            for (int k = 0; k < QT_K; ++k) {
+                const int i = i0 + k * x.nth();
+                if (i < n) {
+                    uint32_t lab = (uint32_t)np[k];
+                    if (c[k] > 1) {
+                        const int q = qt_quadrant(QT_X(pk[k]), QT_Y(pk[k]), bx0[k], by0[k], bx1[k], by1[k]);
+                        lab |= (uint32_t)q << 30;
+                        x.atomic_add(&sh.ccnt2[4 * np[k] + q], 1);
+                    }
+                    pnode[i] = lab;
+                }
+            }
+        }
         const int nToExpand = sh.scal[QT_S_NEXP];
         x.sync();
         // swap list buffers
@@ -411,23 +515,25 @@ QT_HD int qt_distribute(X &x, const QtParams P, const int n, const uint32_t *__r
             t = sh.brx; sh.brx = sh.n_brx; sh.n_brx = t;
             t = sh.bry; sh.bry = sh.n_bry; sh.n_bry = t;
             ti = sh.cnt; sh.cnt = sh.n_cnt; sh.n_cnt = ti;
+            ti = sh.ccnt; sh.ccnt = sh.ccnt2; sh.ccnt2 = ti;
         }
         const int prevS = S;
         S = newS;
+        winnersDone = last;
         // ---- loop control (:665-673, :736-737) ----
         if (S >= P.N || S == prevS) break;
         if (!careful && S + nToExpand * 3 > P.N) careful = true;
         (void)M;
     }
 
-    // ---- winners (:743-764) ----
-    for (int s = x.tid(); s < S; s += x.nth()) sh.best[s] = 0u;
-    x.sync();
-    for (int i = x.tid(); i < n; i += x.nth()) {
-        const uint32_t key = ((uint32_t)QT_S(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i);
-        x.atomic_max(&sh.best[pnode[i] & 0x3FFFFFFFu], key);
+    // ---- winners (:743-764) ---- (picked by the last pass; this trip only when the loop ran out of passes: the timing ablation)
+    if (!winnersDone) {
+        for (int s = x.tid(); s < S; s += x.nth()) sh.best[s] = 0u;
+        x.sync();
+        for (int i = x.tid(); i < n; i += x.nth())
+            x.atomic_max(&sh.best[pnode[i] & 0x3FFFFFFFu], ((uint32_t)QT_S(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i));
+        x.sync();
     }
-    x.sync();
     for (int s = x.tid(); s < S; s += x.nth()) out[s] = pts[0xFFFFFFu - (sh.best[s] & 0xFFFFFFu)];
     x.sync();
     return S;

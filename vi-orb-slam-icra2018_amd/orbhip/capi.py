@@ -18,7 +18,7 @@ CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 TUNE_KNOBS = (
     "BLUR_PLACE", "NO_SPLIT", "COPY_OUT", "BOW_THREADS", "BOW_GLOBAL_DESC", "BOW_PHASES", "CHAIN_DEPTH", "DESCRIBE_KPW",
     "DESCRIBE_MAP", "DESCRIBE_PHASES", "DESCRIBE_PADLDS", "DESCRIBE_AX4", "PROJ_SEQ", "PROJ_ROUNDS", "PROJ_K", "INIT_K",
-    "QT_THREADS", "QT_LDSPTS", "QT_THREADS_SMALL", "SETS_COPY", "STEREO_ENT_PER_KP", "FAST_TILE_CELLS", "FAST_LISTCAP",
+    "QT_THREADS", "QT_PHASES", "QT_LDSPTS", "QT_THREADS_SMALL", "SETS_COPY", "STEREO_ENT_PER_KP", "FAST_TILE_CELLS", "FAST_LISTCAP",
     "FAST_PHASES", "FAST_PITCH", "FAST_DEFER", "FAST_LDS_PAD", "XCD_MAP", "XCD_CHUNK", "FAST_XCD", "FRAME_SPLIT", "INIT_STOP",
     "VOCAB_QUAD", "FUSE_BLUR", "RESIZE_FIT_P", "RESIZE_FIT", "RESIZE_LDS_PAD", "DESCRIBE_FUSED", "DESCRIBE_FUSED_SCHED", "DESCRIBE_FUSED_SPLIT", "BOW_LANE", "DEBUG_DESTROY",
 )
