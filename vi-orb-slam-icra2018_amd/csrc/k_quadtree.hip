@@ -8,6 +8,9 @@
 
 #include <cstdlib>
 
+#ifndef QT_BATCH_LAT
+#define QT_BATCH_LAT 0   // 1: batches take the one-wave scan of the single-frame variant too
+#endif
 #define QT_LDS_LIMIT ((size_t)156 * 1024)   // node tables beyond this go to global memory (k_quadtree<.., true>)
 
 // inclusive prefix sum over the 64 lanes on the DPP network (row shifts, then the totals of the lower rows)
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
     const int l = blockIdx.y, frame = blockIdx.x;
     const OrbLevel &L = G.lv[l];
     const int tid = threadIdx.x;
-    QtBlock<LDSPTS> x;
+    QtBlock<LDSPTS || QT_BATCH_LAT> x;
     x.wtot = s_wtot;
 
     // ---- gather: per-cell slots -> compact array in canonical order ----
