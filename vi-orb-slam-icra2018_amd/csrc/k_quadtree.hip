@@ -11,6 +11,12 @@
 #ifndef QT_BATCH_LAT
 #define QT_BATCH_LAT 0   // 1: batches take the one-wave scan of the single-frame variant too
 #endif
+#ifndef QT_GK
+#define QT_GK 4    // batches, gather: (cell, lane) pairs per thread and trip
+#endif
+#ifndef QT_GL
+#define QT_GL 16   // ... lanes per cell (measured: 8 / 16 / 32 / 64 lanes x 4 / 8 / 16 pairs -- 16 x 4; 16 pairs cost registers, 64 lanes idle ones)
+#endif
 #define QT_LDS_LIMIT ((size_t)156 * 1024)   // node tables beyond this go to global memory (k_quadtree<.., true>)
 
 // inclusive prefix sum over the 64 lanes on the DPP network (row shifts, then the totals of the lower rows)
@@ -190,10 +196,10 @@ __global__ __launch_bounds__(LDSPTS ? 1024 : 256) void k_quadtree(const OrbLevel
                 for (int jj = idx & 15; jj < kk; jj += 16) P[o + jj] = src[jj];
             }
         } else {
-            // batches: 32 lanes per cell (a cell of the bench's frames holds ~26 candidates; a thread per cell walked them one
-            // dependent trip to memory after the other, a quarter of the kernel's time), four (cell, lane) pairs per thread and
-            // trip with the loads ahead of the stores
-            constexpr int GL = 32, GK = 4;
+            // batches: QT_GL lanes per cell (a cell of the bench's frames holds ~26 candidates; a thread per cell walked them one
+            // dependent trip to memory after the other), QT_GK (cell, lane) pairs per thread and trip with the loads ahead of
+            // the stores
+            constexpr int GL = QT_GL, GK = QT_GK;
             const int npairsB = ncells * GL;
             const int midx = qt_ceil_half((int)(short)(int)(L.hX * 1.f)), midy = qt_ceil_half((int)(short)L.regh);   // the root: (0, 0) .. (hX, regh)
             const bool split = firstCounted && n > 1;
