@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t *__restri
 // trip -- lane q holds half (q & 1) of child (q >> 1): the quad's four 16-byte loads are 64 consecutive bytes, one request --,
 // the halves' popcounts meet by a quad permute, and the smallest key (distance << 20 | position: the first child with the
 // smallest distance, the strict '<' over the children in order, :1470) by a second one.  A quarter of the requests for 1.5 x the
-// vector instructions.
+// vector instructions.  (r06: two descriptors per quad, their descents interleaved -- twice the loads in flight per wave at 5 .. 7 waves
+// per SIMD instead of 8 -- is slower, 0.164 -> 0.167 .. 0.184 ms on random descriptors: the kernel is bound by what the fabric delivers
+// (0.56 GB of tree per launch behind the L2s), not by a wave's chain of trips.)
 __device__ __forceinline__ unsigned vq_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ unsigned vq_swap2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
 
