@@ -5,8 +5,9 @@
 #include <math.h>
 #include "quadtree_core.h"
 
-extern "C" int qt_emul_distribute(const uint32_t *pts, int n, int regw, int regh, int N, uint32_t *out,
-                                  int cap)
+// first != 0: the caller's side of qt_distribute's firstCounted contract as k_quadtree's batch gather keeps it (one root only):
+// labels = quadrant in the root << 30, ccnt[0..3] = the four counts, before the call
+static int emul(const uint32_t *pts, int n, int regw, int regh, int N, uint32_t *out, int cap, int first)
 {
     QtParams P;
     P.N = N;
@@ -25,7 +26,17 @@ extern "C" int qt_emul_distribute(const uint32_t *pts, int n, int regw, int regh
     QtShared sh;
     qt_carve(sh, mem, m);
     QtSerial x;
-    int S = qt_distribute(x, P, n, pts, pnode, sh, tmp);
+    const bool firstCounted = first && P.nIni == 1;
+    if (firstCounted) {
+        const int midx = qt_ceil_half((int)(short)(int)(P.hX * 1.f)), midy = qt_ceil_half((int)(short)regh);
+        for (int q = 0; q < 4; q++) sh.ccnt[q] = 0;
+        for (int i = 0; i < n; i++) {
+            const int q = n > 1 ? (QT_X(pts[i]) < midx ? 0 : 1) + (QT_Y(pts[i]) < midy ? 0 : 2) : 0;
+            pnode[i] = (uint32_t)q << 30;
+            if (n > 1) sh.ccnt[q]++;
+        }
+    }
+    int S = qt_distribute(x, P, n, pts, pnode, sh, tmp, firstCounted);
     int rc = S;
     if (S > cap)
         rc = -3;
@@ -35,4 +46,14 @@ extern "C" int qt_emul_distribute(const uint32_t *pts, int n, int regw, int regh
     free(pnode);
     free(tmp);
     return rc;
+}
+
+extern "C" int qt_emul_distribute(const uint32_t *pts, int n, int regw, int regh, int N, uint32_t *out, int cap)
+{
+    return emul(pts, n, regw, regh, N, out, cap, 0);
+}
+
+extern "C" int qt_emul_distribute_first_counted(const uint32_t *pts, int n, int regw, int regh, int N, uint32_t *out, int cap)
+{
+    return emul(pts, n, regw, regh, N, out, cap, 1);
 }

@@ -19,6 +19,7 @@ def native():
     subprocess.check_call(["make", "-C", NATIVE, "all"], stdout=subprocess.DEVNULL)
     qt = C.CDLL(os.path.join(NATIVE, "libqt_emul.so"))
     qt.qt_emul_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    qt.qt_emul_distribute_first_counted.argtypes = qt.qt_emul_distribute.argtypes
     tr = C.CDLL(os.path.join(NATIVE, "libtrig_host.so"))
     tr.trig_host_sweep.restype = C.c_long
     tr.trig_host_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
@@ -76,6 +77,10 @@ def test_device_quadtree_formulation_equals_list_oracle(native, oracle):
         packed = np.ascontiguousarray(_pack(c))
         S = qt.qt_emul_distribute(packed.ctypes.data, len(c), w, h, N, out.ctypes.data, len(out))
         assert S == len(want) and np.array_equal(out[:S], want), (trial, w, h, len(c), N)
+        # ... and with the first pass labelled and counted by the caller, as k_quadtree's batch gather does for a single root (r06)
+        out[:] = 0
+        S = qt.qt_emul_distribute_first_counted(packed.ctypes.data, len(c), w, h, N, out.ctypes.data, len(out))
+        assert S == len(want) and np.array_equal(out[:S], want), ("first counted", trial, w, h, len(c), N)
         checked += 1
     assert checked > 150
 
